@@ -1,0 +1,94 @@
+"""ctypes binding of libemrt_hip.so, generated from include/emrt_hip.h (single source of truth).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises, and
+every op in emrt_amd.functional raises with it.  (INTEGRATION.md shows this same stub as the reference-side binding.)
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "emrt_hip.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "libemrt_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int, "unsigned": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double,
+    "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t,
+}
+
+
+class EmrtHipError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_str, [(type_str, arg_name), ...])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    text = text.replace('extern "C" {', " ").replace("}", " ")
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(emrt_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = " ".join(m.group(1).split()), m.group(2), m.group(3).strip()
+        arglist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                arglist.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = (ret, arglist)
+    return protos
+
+
+def _ctype_of(t):
+    t = t.replace("const ", "").strip()
+    if t.endswith("*"):
+        return ctypes.c_char_p if t == "char*" and False else ctypes.c_void_p
+    if t in _CTYPES:
+        return _CTYPES[t]
+    raise EmrtHipError("emrt_hip.h: unknown C type %r" % t)
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise EmrtHipError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU/PyTorch fallback for the EMRT hot path)" % LIB_PATH)
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                raise EmrtHipError("libemrt_hip.so does not export %s declared in emrt_hip.h" % name)
+            fn.argtypes = [_ctype_of(t) for t, _ in args]
+            if ret == "const char*":
+                fn.restype = ctypes.c_char_p
+            elif ret == "size_t":
+                fn.restype = ctypes.c_size_t
+            else:
+                fn.restype = ctypes.c_int
+            setattr(self, "_raw_" + name, fn)
+
+    def last_error(self):
+        return self._raw_emrt_last_error().decode("utf-8", "replace")
+
+    def call(self, name, *args):
+        """Invoke an int-returning entry point; raise EmrtHipError on a non-zero return."""
+        rc = getattr(self, "_raw_" + name)(*args)
+        if rc != 0:
+            raise EmrtHipError("%s failed (%d): %s" % (name, rc, self.last_error()))
+
+    def query(self, name, *args):
+        return getattr(self, "_raw_" + name)(*args)
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

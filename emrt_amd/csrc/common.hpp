@@ -1,0 +1,145 @@
+// Shared device/host helpers for the EMRT gfx950 kernels (internal; the public C-ABI is include/emrt_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define EMRT_F32 0
+#define EMRT_BF16 1
+
+namespace emrt {
+
+// ---- error plumbing (thread-local last-error string, see emrt_last_error) --------------------
+extern thread_local char g_err[512];
+inline int fail(const char* fn, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", fn, msg);
+  return -1;
+}
+inline int check_launch(const char* fn) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", fn, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+#define EMRT_REQUIRE(cond, msg) \
+  do {                          \
+    if (!(cond)) return emrt::fail(__func__, msg); \
+  } while (0)
+
+// ---- element types ---------------------------------------------------------------------------
+struct bf16_t {
+  unsigned short v;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+template <class T>
+__device__ __forceinline__ T from_f32(float f);
+template <>
+__device__ __forceinline__ float from_f32<float>(float f) {
+  return f;
+}
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {
+  __bf16 b = (__bf16)f;  // hipcc: v_cvt_pk_bf16_f32, round-to-nearest-even, NaN stays NaN
+  bf16_t r;
+  r.v = __builtin_bit_cast(unsigned short, b);
+  return r;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)from_f32<bf16_t>(lo).v | ((uint32_t)from_f32<bf16_t>(hi).v << 16);
+}
+
+// 4-element vector access (the unit most memory-bound kernels work in): 16 B for f32, 8 B for bf16.
+template <class T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <>
+struct Vec4<bf16_t> {
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = pack_bf16x2(o[0], o[1]);
+    v.y = pack_bf16x2(o[2], o[3]);
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+};
+
+// 8-element vector (16 B of bf16, 32 B of f32)
+template <class T>
+struct Vec8;
+template <>
+struct Vec8<float> {
+  __device__ static __forceinline__ void load(const float* p, float (&o)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&o)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+};
+template <>
+struct Vec8<bf16_t> {
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = bf16_bits_to_f32(w[i] & 0xffffu);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+    uint4 v;
+    v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]);
+    v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+};
+
+// ---- wave / block reductions (wave = 64 lanes on gfx950) ---------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// counter-based RNG for dropout: one 32-bit hash of (seed, salt, index).  keep iff u >= p.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint32_t salt, uint64_t idx) {
+  uint32_t a = mix32((uint32_t)idx ^ (uint32_t)seed);
+  uint32_t b = mix32((uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+  uint32_t h = mix32(a ^ (b + 0x9E3779B9U + (a << 6) + (a >> 2)));
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace emrt

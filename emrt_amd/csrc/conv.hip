@@ -1,0 +1,546 @@
+// Implicit-GEMM convolution / linear kernels for gfx950 (MFMA 32x32, NHWC activations).
+//
+// Replaces the cuDNN/cuBLAS work behind paddle.nn.Conv2D / nn.Linear on the EMRT path
+// (SURVEY.md 2.2 K1, K3, K4, K9): reference call sites e.g. paddle_vision_resnet.py:108-123,
+// paddle_EMRT.py:16-23,134-138,201-209, transformer_encoder_decoder.py:36-42,118-121,125-144.
+//
+// Data layout: activations NHWC with an explicit pixel stride (`ld`, elements) and batch stride
+// (`bs`, elements) so that a level slab of the [B, Lv, C] token tensor or a channel slice of a
+// concat buffer is a valid operand without a copy.  Weights are "packed" K-major rows:
+//   fwd  : Wf[OC][KH][KW][C]          (== torch [OC,C,KH,KW] in channels_last memory)
+//   dgrad: Wb[C ][KH][KW][OC]         (transposed copy made once per optimizer step, optim.hip)
+// so both MFMA operands are read from LDS as 16-byte k-contiguous chunks.
+//
+// out[m][n] = sum_{tap,c} in[pix(m,tap)][c] * Wp[n][tap*C + c]      (m = output pixel, n = out channel)
+//   MODE 0 (fwd)  : pix = (oh*stride - pad + kh, ow*stride - pad + kw)
+//   MODE 1 (dgrad): pix = ((oh + pad - kh)/stride, (ow + pad - kw)/stride) when divisible
+// wgrad: dW[oc][tap*C + c] += sum_m dy[m][oc] * x[pix(m,tap)][c]   (fp32 atomics, split over m)
+#include "common.hpp"
+
+using namespace emrt;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct ConvArgs {
+  const void* in;
+  const void* w;
+  void* out;
+  const float* bias;
+  const void* res;
+  int N, H, W, C, ldin;
+  long long in_bs;
+  int OH, OW, OC, ldout;
+  long long out_bs;
+  int ldres;
+  long long res_bs;
+  int KH, KW, stride, pad;
+  int relu, out_f32;
+};
+
+template <class T>
+__device__ __forceinline__ void mma_chunk(f32x16_t& acc, const uint4& a, const uint4& b);
+template <>
+__device__ __forceinline__ void mma_chunk<bf16_t>(f32x16_t& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const uint4& a, const uint4& b) {
+  // lane (r, h) holds 4 consecutive k of its row; MFMA e pairs k-slot h with element e of both operands.
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fwd / dgrad implicit GEMM.  256 threads = 4 waves laid out WR x WC, each wave TM x TN tiles of 32x32.
+// LDS: one [BM + BN] x 128-byte k-tile (rows padded to 144 B: conflict-free ds_read_b128), register
+// prefetch of the next k-tile while the MFMAs of the current one run.
+// ------------------------------------------------------------------------------------------------
+template <class T, int TM, int TN, int WR, int WC, int MODE>
+__global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  constexpr int PITCH = 144;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + BM * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int tiles_n = (p.OC + BN - 1) / BN;
+  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+  const int OHW = p.OH * p.OW;
+  const long long M = (long long)p.N * OHW;
+  const int chunk = tid & 7, row0 = tid >> 3;
+
+  const T* __restrict__ inp = (const T*)p.in;
+  const T* __restrict__ wp = (const T*)p.w;
+  const int K = p.KH * p.KW * p.C;
+  const int nkt = K / BK;
+
+  int a_h[AR], a_w[AR];
+  long long a_base[AR];
+  bool a_ok[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    long long m = (long long)bm * BM + row0 + 32 * i;
+    a_ok[i] = m < M;
+    long long mm = a_ok[i] ? m : 0;
+    int nb = (int)(mm / OHW);
+    int r = (int)(mm - (long long)nb * OHW);
+    int oh = r / p.OW, ow = r - oh * p.OW;
+    a_base[i] = (long long)nb * p.in_bs;
+    if (MODE == 0) { a_h[i] = oh * p.stride - p.pad; a_w[i] = ow * p.stride - p.pad; }
+    else { a_h[i] = oh + p.pad; a_w[i] = ow + p.pad; }
+  }
+  long long b_off[BR];
+  bool b_ok[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    int n = bn * BN + row0 + 32 * j;
+    b_ok[j] = n < p.OC;
+    b_off[j] = (long long)(b_ok[j] ? n : 0) * K + chunk * EPC;
+  }
+
+  uint4 ra[AR], rb[BR];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / p.C;
+    const int c0 = k0 - tap * p.C;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int hi, wi;
+      bool ok = a_ok[i];
+      if (MODE == 0) { hi = a_h[i] + kh; wi = a_w[i] + kw; }
+      else {
+        int th = a_h[i] - kh, tw = a_w[i] - kw;
+        hi = th / p.stride; wi = tw / p.stride;
+        ok = ok && th >= 0 && tw >= 0 && (hi * p.stride == th) && (wi * p.stride == tw);
+      }
+      ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *reinterpret_cast<const uint4*>(inp + a_base[i] + ((long long)hi * p.W + wi) * p.ldin + c0 + chunk * EPC);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_ok[j]) v = *reinterpret_cast<const uint4*>(wp + b_off[j] + k0);
+      rb[j] = v;
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tile(0);
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(sA + (row0 + 32 * i) * PITCH + chunk * 16) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4*>(sB + (row0 + 32 * j) * PITCH + chunk * 16) = rb[j];
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const uint4*>(sA + ((wr * TM + i) * 32 + frow) * PITCH + (2 * s + fh) * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const uint4*>(sB + ((wc * TN + j) * 32 + frow) * PITCH + (2 * s + fh) * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const T* resp = (const T*)p.res;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      const long long m = (long long)bm * BM + row;
+      if (m >= M) continue;
+      const int nb = (int)(m / OHW);
+      const int pix = (int)(m - (long long)nb * OHW);
+      const long long obase = (long long)nb * p.out_bs + (long long)pix * p.ldout;
+      const long long rbase = (long long)nb * p.res_bs + (long long)pix * p.ldres;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = bn * BN + (wc * TN + j) * 32 + frow;
+        if (n >= p.OC) continue;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[n];
+        if (resp) v += to_f32(resp[rbase + n]);
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.out_f32) ((float*)p.out)[obase + n] = v;
+        else ((T*)p.out)[obase + n] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+// Naive direct form of the same contraction for channel counts that do not fill 16-byte chunks
+// (7x7 stem and the first spatial-branch conv, Cin = 3).  One thread per (pixel, out channel).
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
+  const int OHW = p.OH * p.OW;
+  const long long total = (long long)p.N * OHW * p.OC;
+  const T* __restrict__ inp = (const T*)p.in;
+  const T* __restrict__ wp = (const T*)p.w;
+  const int K = p.KH * p.KW * p.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % p.OC);
+    const long long m = idx / p.OC;
+    const int nb = (int)(m / OHW);
+    const int pix = (int)(m - (long long)nb * OHW);
+    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    float acc = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw) {
+        int hi, wi;
+        bool ok = true;
+        if (MODE == 0) { hi = oh * p.stride - p.pad + kh; wi = ow * p.stride - p.pad + kw; }
+        else {
+          int th = oh + p.pad - kh, tw = ow + p.pad - kw;
+          hi = th / p.stride; wi = tw / p.stride;
+          ok = th >= 0 && tw >= 0 && hi * p.stride == th && wi * p.stride == tw;
+        }
+        if (!ok || (unsigned)hi >= (unsigned)p.H || (unsigned)wi >= (unsigned)p.W) continue;
+        const T* xp = inp + (long long)nb * p.in_bs + ((long long)hi * p.W + wi) * p.ldin;
+        const T* wk = wp + (long long)n * K + (kh * p.KW + kw) * p.C;
+        for (int c = 0; c < p.C; ++c) acc = fmaf(to_f32(xp[c]), to_f32(wk[c]), acc);
+      }
+    if (p.bias) acc += p.bias[n];
+    if (p.res) acc += to_f32(((const T*)p.res)[(long long)nb * p.res_bs + (long long)pix * p.ldres + n]);
+    if (p.relu) acc = fmaxf(acc, 0.f);
+    const long long o = (long long)nb * p.out_bs + (long long)pix * p.ldout + n;
+    if (p.out_f32) ((float*)p.out)[o] = acc;
+    else ((T*)p.out)[o] = from_f32<T>(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[oc][k] += sum_m dy[m][oc] * xcol[m][k], 128(oc) x 128(k) tile per block, reduction over
+// pixels m split across blockIdx.z, fp32 atomics into dW.  Both operands are pixel-major in memory, so
+// the MFMA fragments (8 consecutive m per lane) come from LDS through the transposing read
+// ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32, one k-slot per lane).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int N, H, W, C, ldx;
+  long long x_bs;
+  int OH, OW, OC, lddy;
+  long long dy_bs;
+  int KH, KW, stride, pad;
+  int tiles_per_split;  // number of BKm pixel tiles each z-slice processes
+};
+
+template <class T>
+struct WgradCfg;
+template <>
+struct WgradCfg<bf16_t> {
+  static constexpr int CPR = 16, RPP = 16, BKM = 64, PITCH = 320;
+};
+template <>
+struct WgradCfg<float> {
+  static constexpr int CPR = 32, RPP = 8, BKM = 32, PITCH = 528;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+  using Cfg = WgradCfg<T>;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int CPR = Cfg::CPR, RPP = Cfg::RPP, BKM = Cfg::BKM, PITCH = Cfg::PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sP = smem;                 // dy tile  [BKM][128 oc]
+  unsigned char* sQ = smem + BKM * PITCH;   // x  tile  [BKM][128 k ]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int K = p.KH * p.KW * p.C;
+  const int oc0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+  const int OHW = p.OH * p.OW;
+  const long long M = (long long)p.N * OHW;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dyp = (const T*)p.dy;
+
+  const int col = tid % CPR, prow = tid / CPR;
+  // this thread's fixed k-chunk (Q) and oc-chunk (P)
+  const int kq = k0 + col * EPC;
+  const bool kq_ok = kq < K;
+  const int tap = kq_ok ? kq / p.C : 0;
+  const int cq = kq - tap * p.C;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int ocp = oc0 + col * EPC;
+  const bool ocp_ok = ocp < p.OC;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 rp[4], rq[4];
+  auto load_tile = [&](long long mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = mt * BKM + prow + RPP * i;
+      uint4 vp = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
+      if (m < M) {
+        const int nb = (int)(m / OHW);
+        const int pix = (int)(m - (long long)nb * OHW);
+        if (ocp_ok) vp = *reinterpret_cast<const uint4*>(dyp + (long long)nb * p.dy_bs + (long long)pix * p.lddy + ocp);
+        const int oh = pix / p.OW, ow = pix - oh * p.OW;
+        const int hi = oh * p.stride - p.pad + kh, wi = ow * p.stride - p.pad + kw;
+        if (kq_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+          vq = *reinterpret_cast<const uint4*>(xp + (long long)nb * p.x_bs + ((long long)hi * p.W + wi) * p.ldx + cq);
+      }
+      rp[i] = vp;
+      rq[i] = vq;
+    }
+  };
+
+  const long long mt_begin = (long long)blockIdx.z * p.tiles_per_split;
+  const long long mt_total = (M + BKM - 1) / BKM;
+  long long mt_end = mt_begin + p.tiles_per_split;
+  if (mt_end > mt_total) mt_end = mt_total;
+  if (mt_begin >= mt_end) return;
+
+  load_tile(mt_begin);
+  for (long long mt = mt_begin; mt < mt_end; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(sP + (prow + RPP * i) * PITCH + col * 16) = rp[i];
+      *reinterpret_cast<uint4*>(sQ + (prow + RPP * i) * PITCH + col * 16) = rq[i];
+    }
+    __syncthreads();
+    if (mt + 1 < mt_end) load_tile(mt + 1);
+    if constexpr (sizeof(T) == 2) {
+      // lane: group g = lane>>4 (h = g>>1 picks k rows 8h.., half = g&1 picks 16 columns), t = lane&15.
+      const int g = lane >> 4, t = lane & 15;
+      const int h = g >> 1, half = g & 1, q = t >> 2, pp = t & 3;
+#pragma unroll
+      for (int s = 0; s < BKM / 16; ++s) {
+        uint4 fa[2], fb[2];
+        const int r0 = 16 * s + 8 * h + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cb = (wr * 64 + i * 32 + 16 * half + 4 * pp) * 2;
+          short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(sP + r0 * PITCH + cb));
+          short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(sP + (r0 + 4) * PITCH + cb));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fa[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cb = (wc * 64 + j * 32 + 16 * half + 4 * pp) * 2;
+          short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(sQ + r0 * PITCH + cb));
+          short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(sQ + (r0 + 4) * PITCH + cb));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const int r = lane & 31, h = lane >> 5;
+#pragma unroll 4
+      for (int s = 0; s < BKM / 2; ++s) {
+        float fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float*>(sP + (2 * s + h) * PITCH + (wr * 64 + i * 32 + r) * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const float*>(sQ + (2 * s + h) * PITCH + (wc * 64 + j * 32 + r) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = oc0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (oc >= p.OC) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wc * 64 + j * 32 + frow;
+        if (k < K) atomicAdd(p.dw + (long long)oc * K + k, acc[i][j][r]);
+      }
+    }
+}
+
+// naive wgrad for odd channel counts: thread per (oc, k), pixels split over blockIdx.y
+template <class T>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs p, int m_per_split) {
+  const int K = p.KH * p.KW * p.C;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.OC * K) return;
+  const int oc = (int)(idx % p.OC);   // oc fastest: dy reads coalesce, x reads broadcast
+  const int k = (int)(idx / p.OC);
+  const int tap = k / p.C, c = k - tap * p.C;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int OHW = p.OH * p.OW;
+  const long long M = (long long)p.N * OHW;
+  long long m0 = (long long)blockIdx.y * m_per_split, m1 = m0 + m_per_split;
+  if (m1 > M) m1 = M;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dyp = (const T*)p.dy;
+  float acc = 0.f;
+  for (long long m = m0; m < m1; ++m) {
+    const int nb = (int)(m / OHW);
+    const int pix = (int)(m - (long long)nb * OHW);
+    const int oh = pix / p.OW, ow = pix - oh * p.OW;
+    const int hi = oh * p.stride - p.pad + kh, wi = ow * p.stride - p.pad + kw;
+    if ((unsigned)hi >= (unsigned)p.H || (unsigned)wi >= (unsigned)p.W) continue;
+    acc = fmaf(to_f32(dyp[(long long)nb * p.dy_bs + (long long)pix * p.lddy + oc]),
+               to_f32(xp[(long long)nb * p.x_bs + ((long long)hi * p.W + wi) * p.ldx + c]), acc);
+  }
+  atomicAdd(p.dw + (long long)oc * K + k, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+template <class T, int TM, int TN, int WR, int WC, int MODE>
+static int launch_igemm(const ConvArgs& a, hipStream_t st) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const long long grid = ((M + BM - 1) / BM) * ((a.OC + BN - 1) / BN);
+  const size_t lds = (size_t)(BM + BN) * 144;
+  hipLaunchKernelGGL((igemm_kernel<T, TM, TN, WR, WC, MODE>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  return check_launch("emrt_conv2d");
+}
+
+template <class T, int MODE>
+static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  const bool vec = (a.C % BK == 0) && (a.ldin % EPC == 0) && (a.in_bs % EPC == 0) &&
+                   (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.w) % 16 == 0);
+  const long long M = (long long)a.N * a.OH * a.OW;
+  if (!vec) {
+    long long total = M * a.OC;
+    int grid = (int)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((conv_direct_kernel<T, MODE>), dim3(grid), dim3(256), 0, st, a);
+    return check_launch("emrt_conv2d(direct)");
+  }
+  if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE>(a, st);
+  if (a.OC <= 64) {
+    if (M >= 128 * 256) return launch_igemm<T, 2, 1, 2, 2, MODE>(a, st);
+    return launch_igemm<T, 1, 1, 2, 2, MODE>(a, st);
+  }
+  const long long big_tiles = ((M + 127) / 128) * ((a.OC + 127) / 128);
+  if (big_tiles >= 384) return launch_igemm<T, 2, 2, 2, 2, MODE>(a, st);
+  return launch_igemm<T, 1, 1, 2, 2, MODE>(a, st);
+}
+
+extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual,
+                           int N, int H, int W, int C, int ldin, long long in_bs,
+                           int OH, int OW, int OC, int ldout, long long out_bs,
+                           int ldres, long long res_bs,
+                           int KH, int KW, int stride, int pad,
+                           int mode, int relu, int out_f32, int dtype, void* stream) {
+  EMRT_REQUIRE(in && w_packed && out, "null pointer");
+  EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
+  EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
+  EMRT_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fwd) or 1 (dgrad)");
+  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  if (mode == 0) {
+    EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "fwd: output size mismatch");
+  } else {
+    EMRT_REQUIRE(H == (OH + 2 * pad - KH) / stride + 1 && W == (OW + 2 * pad - KW) / stride + 1, "dgrad: size mismatch");
+  }
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.res = residual;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs;
+  a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
+  a.ldres = ldres; a.res_bs = res_bs;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
+  return mode == 0 ? conv_dispatch<bf16_t, 0>(a, st) : conv_dispatch<bf16_t, 1>(a, st);
+}
+
+template <class T>
+static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
+  using Cfg = WgradCfg<T>;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  WgradArgs a = a0;
+  const int K = a.KH * a.KW * a.C;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const bool vec = (a.C % EPC == 0) && (a.OC % EPC == 0) && (a.ldx % EPC == 0) && (a.lddy % EPC == 0) &&
+                   (a.x_bs % EPC == 0) && (a.dy_bs % EPC == 0) && (((uintptr_t)a.x) % 16 == 0) && (((uintptr_t)a.dy) % 16 == 0);
+  if (!vec) {
+    long long outs = (long long)a.OC * K;
+    int gx = (int)((outs + 255) / 256);
+    int splits = (int)(M / 2048);
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    int mps = (int)((M + splits - 1) / splits);
+    a.tiles_per_split = 0;
+    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(gx, splits), dim3(256), 0, st, a, mps);
+    return check_launch("emrt_conv2d_wgrad(direct)");
+  }
+  const int tx = (K + 127) / 128, ty = (a.OC + 127) / 128;
+  const long long mt_total = (M + Cfg::BKM - 1) / Cfg::BKM;
+  long long want = (1024 + (long long)tx * ty - 1) / ((long long)tx * ty);
+  if (want < 1) want = 1;
+  long long max_split = mt_total / 4;
+  if (max_split < 1) max_split = 1;
+  long long S = want < max_split ? want : max_split;
+  a.tiles_per_split = (int)((mt_total + S - 1) / S);
+  S = (mt_total + a.tiles_per_split - 1) / a.tiles_per_split;
+  const size_t lds = 2 * (size_t)Cfg::BKM * Cfg::PITCH;
+  hipLaunchKernelGGL((wgrad_kernel<T>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
+  return check_launch("emrt_conv2d_wgrad");
+}
+
+extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
+                                 int N, int H, int W, int C, int ldx, long long x_bs,
+                                 int OH, int OW, int OC, int lddy, long long dy_bs,
+                                 int KH, int KW, int stride, int pad, int dtype, void* stream) {
+  EMRT_REQUIRE(x && dy && dw, "null pointer");
+  EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
+  EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
+  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.x_bs = x_bs;
+  a.OH = OH; a.OW = OW; a.OC = OC; a.lddy = lddy; a.dy_bs = dy_bs;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.tiles_per_split = 0;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? wgrad_dispatch<float>(a, st) : wgrad_dispatch<bf16_t>(a, st);
+}

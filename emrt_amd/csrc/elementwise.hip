@@ -1,0 +1,276 @@
+// Small streaming kernels: adds (with batch broadcast), gradient accumulation, dropout (+ReLU mask) forward/backward,
+// sigmoid, dtype casts, memset.  Reference sites: with_pos_embed (transformer_encoder_decoder.py:154-155,273-274),
+// nn.Dropout / nn.Dropout2D (:115,119,122,250,255,261,263; paddle_EMRT.py:208; fcn_head.py:65), F.sigmoid (:466).
+#include "common.hpp"
+
+using namespace emrt;
+
+thread_local char emrt::g_err[512] = {0};
+
+extern "C" const char* emrt_last_error(void) { return emrt::g_err; }
+extern "C" int emrt_abi_version(void) { return 1; }
+
+static inline int ew_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// out[i] = a[i] + b[i % period]   (n, period multiples of 4)
+template <class T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long n4,
+                                                  long long period4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float x[4], y[4];
+    Vec4<T>::load(a + i * 4, x);
+    Vec4<T>::load(b + (i % period4) * 4, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] += y[e];
+    Vec4<T>::store(out + i * 4, x);
+  }
+}
+
+// out[i] = a[i] + float_row[i % period]  (fp32 broadcast operand, e.g. a parameter row)
+template <class T>
+__global__ __launch_bounds__(256) void add_f32row_kernel(const T* __restrict__ a, const float* __restrict__ b, T* __restrict__ out,
+                                                         long long n4, long long period4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float x[4];
+    Vec4<T>::load(a + i * 4, x);
+    const float4 y = reinterpret_cast<const float4*>(b)[i % period4];
+    x[0] += y.x; x[1] += y.y; x[2] += y.z; x[3] += y.w;
+    Vec4<T>::store(out + i * 4, x);
+  }
+}
+
+// dst[r][c] += src[r][c] over a rows x cols window of two strided matrices (gradient accumulation into views)
+template <class T>
+__global__ __launch_bounds__(256) void acc2d_kernel(T* __restrict__ dst, long long dst_rs, const T* __restrict__ src, long long src_rs,
+                                                    long long rows, long long cols4) {
+  const long long total = rows * cols4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols4, c = (i - r * cols4) * 4;
+    float x[4], y[4];
+    Vec4<T>::load(dst + r * dst_rs + c, x);
+    Vec4<T>::load(src + r * src_rs + c, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] += y[e];
+    Vec4<T>::store(dst + r * dst_rs + c, x);
+  }
+}
+
+// out[r][c] = a[r][c] + b[r][c] over strided rows
+template <class T>
+__global__ __launch_bounds__(256) void add2d_kernel(const T* __restrict__ a, long long a_rs, const T* __restrict__ b, long long b_rs,
+                                                    T* __restrict__ out, long long out_rs, long long rows, long long cols4) {
+  const long long total = rows * cols4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols4, c = (i - r * cols4) * 4;
+    float x[4], y[4];
+    Vec4<T>::load(a + r * a_rs + c, x);
+    Vec4<T>::load(b + r * b_rs + c, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] += y[e];
+    Vec4<T>::store(out + r * out_rs + c, x);
+  }
+}
+
+// y = dropout(x) (inverted, scale 1/(1-p)).  mode 0: per element; mode 1: per (image, channel) (Dropout2D, NHWC rows of C)
+template <class T>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n4, float p,
+                                                          const unsigned long long* __restrict__ seed, unsigned salt, int mode,
+                                                          long long hw, int C) {
+  const unsigned long long sd = seed[0];
+  const float ks = 1.f / (1.f - p);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float v[4];
+    Vec4<T>::load(x + i * 4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long idx = i * 4 + e;
+      const unsigned long long key = mode == 0 ? (unsigned long long)idx : (unsigned long long)((idx / C / hw) * C + idx % C);
+      v[e] = uniform01(sd, salt, key) >= p ? v[e] * ks : 0.f;
+    }
+    Vec4<T>::store(y + i * 4, v);
+  }
+}
+
+// dx = dy * dropmask/(1-p) * (relu_out > 0)      (either mask optional: p == 0 / relu_out == null)
+template <class T>
+__global__ __launch_bounds__(256) void mask_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ relu_out, T* __restrict__ dx,
+                                                       long long n4, float p, const unsigned long long* __restrict__ seed,
+                                                       unsigned salt, int mode, long long hw, int C) {
+  const unsigned long long sd = p > 0.f ? seed[0] : 0ull;
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float g[4];
+    Vec4<T>::load(dy + i * 4, g);
+    if (p > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long idx = i * 4 + e;
+        const unsigned long long key = mode == 0 ? (unsigned long long)idx : (unsigned long long)((idx / C / hw) * C + idx % C);
+        g[e] = uniform01(sd, salt, key) >= p ? g[e] * ks : 0.f;
+      }
+    }
+    if (relu_out) {
+      float r[4];
+      Vec4<T>::load(relu_out + i * 4, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = r[e] > 0.f ? g[e] : 0.f;
+    }
+    Vec4<T>::store(dx + i * 4, g);
+  }
+}
+
+__global__ void sigmoid_fwd_kernel(const float* x, float* y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = 1.f / (1.f + __expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* y, const float* dy, float* dx, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * y[i] * (1.f - y[i]);
+}
+
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = from_f32<TO>(to_f32(in[i]));
+}
+
+// out[r][c] = in[r][c] for a strided 2-D copy with dtype conversion f32 -> T (rows x cols, lds in elements)
+#define LAUNCH_T(dtype, KERNEL, GRID, ...)                                                            \
+  do {                                                                                                \
+    if ((dtype) == EMRT_F32) hipLaunchKernelGGL((KERNEL<float>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<bf16_t>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);              \
+  } while (0)
+
+extern "C" int emrt_add(const void* a, const void* b, void* out, long long n, long long period, int dtype, void* stream) {
+  EMRT_REQUIRE(a && b && out, "null pointer");
+  EMRT_REQUIRE(n % 4 == 0 && period % 4 == 0 && period > 0, "n and period must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((add_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / 4, period / 4);
+  else hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 4, period / 4);
+  return check_launch("emrt_add");
+}
+
+extern "C" int emrt_add2d(const void* a, long long a_rs, const void* b, long long b_rs, void* out, long long out_rs, long long rows,
+                          long long cols, int dtype, void* stream) {
+  EMRT_REQUIRE(a && b && out, "null pointer");
+  EMRT_REQUIRE(cols % 4 == 0 && a_rs % 4 == 0 && b_rs % 4 == 0 && out_rs % 4 == 0, "cols and row strides must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(rows * (cols / 4));
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((add2d_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, a_rs, (const float*)b, b_rs, (float*)out, out_rs, rows, cols / 4);
+  else hipLaunchKernelGGL((add2d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, a_rs, (const bf16_t*)b, b_rs, (bf16_t*)out, out_rs, rows, cols / 4);
+  return check_launch("emrt_add2d");
+}
+
+extern "C" int emrt_acc2d(void* dst, long long dst_rs, const void* src, long long src_rs, long long rows, long long cols, int dtype,
+                          void* stream) {
+  EMRT_REQUIRE(dst && src, "null pointer");
+  EMRT_REQUIRE(cols % 4 == 0 && dst_rs % 4 == 0 && src_rs % 4 == 0, "cols and row strides must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(rows * (cols / 4));
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((acc2d_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, dst_rs, (const float*)src, src_rs, rows, cols / 4);
+  else hipLaunchKernelGGL((acc2d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, dst_rs, (const bf16_t*)src, src_rs, rows, cols / 4);
+  return check_launch("emrt_acc2d");
+}
+
+extern "C" int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream) {
+  EMRT_REQUIRE(a && row && out, "null pointer");
+  EMRT_REQUIRE(n % 4 == 0 && period % 4 == 0 && period > 0, "n and period must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((add_f32row_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)a, row, (float*)out, n / 4, period / 4);
+  else hipLaunchKernelGGL((add_f32row_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, row, (bf16_t*)out, n / 4, period / 4);
+  return check_launch("emrt_add_f32row");
+}
+
+extern "C" int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode,
+                                long long hw, int C, int dtype, void* stream) {
+  EMRT_REQUIRE(x && y && seed, "null pointer");
+  EMRT_REQUIRE(n % 4 == 0 && p >= 0.f && p < 1.f, "n must be a multiple of 4, 0 <= p < 1");
+  EMRT_REQUIRE(mode == 0 || (hw > 0 && C > 0), "channel mode needs hw and C");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((dropout_fwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)x, (float*)y, n / 4, p, seed, salt, mode, hw, C);
+  else hipLaunchKernelGGL((dropout_fwd_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / 4, p, seed, salt, mode, hw, C);
+  return check_launch("emrt_dropout_fwd");
+}
+
+extern "C" int emrt_mask_bwd(const void* dy, const void* relu_out, void* dx, long long n, float p, const unsigned long long* seed,
+                             unsigned salt, int mode, long long hw, int C, int dtype, void* stream) {
+  EMRT_REQUIRE(dy && dx, "null pointer");
+  EMRT_REQUIRE(n % 4 == 0 && p >= 0.f && p < 1.f, "n must be a multiple of 4, 0 <= p < 1");
+  EMRT_REQUIRE(p == 0.f || seed, "dropout needs a device seed");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((mask_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)relu_out, (float*)dx, n / 4, p, seed, salt, mode, hw, C);
+  else hipLaunchKernelGGL((mask_bwd_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)relu_out, (bf16_t*)dx, n / 4, p, seed, salt, mode, hw, C);
+  return check_launch("emrt_mask_bwd");
+}
+
+extern "C" int emrt_sigmoid_fwd(const float* x, float* y, long long n, void* stream) {
+  EMRT_REQUIRE(x && y, "null pointer");
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return check_launch("emrt_sigmoid_fwd");
+}
+extern "C" int emrt_sigmoid_bwd(const float* y, const float* dy, float* dx, long long n, void* stream) {
+  EMRT_REQUIRE(y && dy && dx, "null pointer");
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n);
+  return check_launch("emrt_sigmoid_bwd");
+}
+
+// direction 0: f32 -> dtype ; 1: dtype -> f32
+extern "C" int emrt_cast(const void* in, void* out, long long n, int direction, int dtype, void* stream) {
+  EMRT_REQUIRE(in && out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(n);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, n);
+  else if (direction == 0) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, n);
+  else hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out, n);
+  return check_launch("emrt_cast");
+}
+
+extern "C" int emrt_memset(void* ptr, int value, size_t bytes, void* stream) {
+  EMRT_REQUIRE(ptr || bytes == 0, "null pointer");
+  if (bytes == 0) return 0;
+  hipError_t e = hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return emrt::fail("emrt_memset", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return emrt::fail("emrt_device_info", hipGetErrorString(e));
+  hipDeviceProp_t p;
+  e = hipGetDeviceProperties(&p, dev);
+  if (e != hipSuccess) return emrt::fail("emrt_device_info", hipGetErrorString(e));
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = p.sharedMemPerBlock;
+  if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+  return 0;
+}
+
+// HIP-event timing helpers for bench.py: events are recorded on the SAME stream the kernels are launched on.
+extern "C" int emrt_event_create(void** ev) {
+  hipEvent_t e;
+  hipError_t r = hipEventCreate(&e);
+  if (r != hipSuccess) return emrt::fail("emrt_event_create", hipGetErrorString(r));
+  *ev = (void*)e;
+  return 0;
+}
+extern "C" int emrt_event_record(void* ev, void* stream) {
+  hipError_t r = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+  if (r != hipSuccess) return emrt::fail("emrt_event_record", hipGetErrorString(r));
+  return 0;
+}
+extern "C" int emrt_event_elapsed_ms(void* start, void* stop, float* ms) {
+  hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+  if (r == hipSuccess) r = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+  if (r != hipSuccess) return emrt::fail("emrt_event_elapsed_ms", hipGetErrorString(r));
+  return 0;
+}
+extern "C" int emrt_event_destroy(void* ev) {
+  hipEventDestroy((hipEvent_t)ev);
+  return 0;
+}

@@ -1,0 +1,276 @@
+// Loss, optimizer and weight-packing kernels for gfx950 (all HBM-bound streaming kernels).
+//
+//  * softmax cross-entropy with ignore_index over fp32 NCHW logits (reference:
+//    losses/mix_softmax_cross_entropy_loss.py:27-35 -> paddle nn.CrossEntropyLoss(ignore_index=255, axis=1))
+//  * ClipGradByGlobalNorm + L2 decay + Momentum over ONE flat fp32 parameter buffer
+//    (reference: solver/optimizer.py:29-40; PolynomialDecay lr_scheduler.py:244-248 evaluated on the device from a
+//    step counter so the whole step can live in one hipGraph)
+//  * per-step weight packing: fp32 master [OC][taps][C] -> compute-dtype forward copy [OC][taps][C] and transposed
+//    dgrad copy [C][taps][OC] (LDS 32x32 tile transpose, one launch for every GEMM weight of the model).
+#include "common.hpp"
+
+using namespace emrt;
+
+// ------------------------------------------------------------------------------------------------
+// cross entropy
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, int N,
+                                                     int C, long long HW, int ignore_index, float* __restrict__ partial) {
+  __shared__ float red[2 * 4];
+  const long long total = (long long)N * HW;
+  float ls = 0.f, cnt = 0.f;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long lab = labels[idx];
+    if (lab == ignore_index) continue;
+    const long long n = idx / HW, p = idx - n * HW;
+    const float* lp = logits + n * C * HW + p;
+    float mx = -3.0e38f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[c * HW]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += __expf(lp[c * HW] - mx);
+    const float picked = (lab >= 0 && lab < C) ? lp[lab * HW] : 0.f;
+    ls += logf(den) + mx - picked;
+    cnt += 1.f;
+  }
+  ls = wave_sum(ls);
+  cnt = wave_sum(cnt);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[wv * 2] = ls; red[wv * 2 + 1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 4; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+    partial[blockIdx.x * 2] = a;
+    partial[blockIdx.x * 2 + 1] = b;
+  }
+}
+
+// result[0] = mean loss over non-ignored pixels, result[1] = count
+__global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ result) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblk; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+  result[0] = (float)(a / b);
+  result[1] = (float)b;
+}
+
+// dlogits = weight * upstream * (softmax - onehot) / count     (upstream: device scalar or null == 1)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                     const float* __restrict__ result, const float* __restrict__ upstream,
+                                                     float weight, int N, int C, long long HW, int ignore_index,
+                                                     float* __restrict__ dlogits) {
+  const long long total = (long long)N * HW;
+  const float g = weight * (upstream ? upstream[0] : 1.f) / result[1];
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long lab = labels[idx];
+    const long long n = idx / HW, p = idx - n * HW;
+    const float* lp = logits + n * C * HW + p;
+    float* dp = dlogits + n * C * HW + p;
+    if (lab == ignore_index) {
+      for (int c = 0; c < C; ++c) dp[c * HW] = 0.f;
+      continue;
+    }
+    float mx = -3.0e38f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[c * HW]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += __expf(lp[c * HW] - mx);
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; ++c) dp[c * HW] = g * (__expf(lp[c * HW] - mx) * inv - (c == lab ? 1.f : 0.f));
+  }
+}
+
+__global__ void axpby_scalar_kernel(float* out, const float* a, float wa, const float* b, float wb) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = wa * a[0] + (b ? wb * b[0] : 0.f);
+}
+
+extern "C" size_t emrt_ce_workspace_bytes(void) { return 1024 * 2 * sizeof(float); }
+
+// result[2] (device): {mean loss, non-ignored count}
+extern "C" int emrt_softmax_ce_fwd(const float* logits, const long long* labels, int N, int C, int H, int W, int ignore_index,
+                                   float* result, void* workspace, void* stream) {
+  EMRT_REQUIRE(logits && labels && result && workspace, "null pointer");
+  const long long total = (long long)N * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, N, C, (long long)H * W, ignore_index, (float*)workspace);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, grid, result);
+  return check_launch("emrt_softmax_ce_fwd");
+}
+
+extern "C" int emrt_softmax_ce_bwd(const float* logits, const long long* labels, const float* result, const float* upstream,
+                                   float weight, int N, int C, int H, int W, int ignore_index, float* dlogits, void* stream) {
+  EMRT_REQUIRE(logits && labels && result && dlogits, "null pointer");
+  const long long total = (long long)N * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, labels, result, upstream, weight, N, C,
+                     (long long)H * W, ignore_index, dlogits);
+  return check_launch("emrt_softmax_ce_bwd");
+}
+
+extern "C" int emrt_scalar_axpby(float* out, const float* a, float wa, const float* b, float wb, void* stream) {
+  EMRT_REQUIRE(out && a, "null pointer");
+  hipLaunchKernelGGL(axpby_scalar_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, a, wa, b, wb);
+  return check_launch("emrt_scalar_axpby");
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// state[0] = clip scale (clip / max(norm, clip), or 1 when clip <= 0), state[1] = global grad norm
+__global__ void clip_scale_kernel(const float* __restrict__ partial, int nblk, float clip, float* __restrict__ state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += partial[i];
+  const float norm = (float)sqrt(s);
+  state[1] = norm;
+  state[0] = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
+}
+
+struct SgdArgs {
+  float* p; const float* g; float* v;
+  long long n;
+  const float* state;            // clip scale at [0]
+  const long long* step;         // device step counter (0-based index of this step)
+  float base_lr, end_lr, power; long long decay_steps;
+  float momentum, weight_decay;
+  int nranges;
+  long long r0[32], r1[32];      // element ranges whose learning rate is multiplied by `range_mult`
+  float range_mult;
+  float* lr_out;                 // optional: lr used this step
+};
+
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdArgs a) {
+  long long t = a.step ? a.step[0] : 0;
+  if (t > a.decay_steps) t = a.decay_steps;
+  const float frac = 1.f - (float)((double)t / (double)a.decay_steps);
+  const float lr = (a.base_lr - a.end_lr) * powf(frac, a.power) + a.end_lr;
+  if (a.lr_out && blockIdx.x == 0 && threadIdx.x == 0) a.lr_out[0] = lr;
+  const float scale = a.state ? a.state[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    float mult = 1.f;
+    for (int r = 0; r < a.nranges; ++r)
+      if (i >= a.r0[r] && i < a.r1[r]) mult = a.range_mult;
+    const float p = a.p[i];
+    const float g = a.g[i] * scale + a.weight_decay * p;
+    const float v = a.momentum * a.v[i] + g;
+    a.v[i] = v;
+    a.p[i] = p - lr * mult * v;
+  }
+}
+
+__global__ void counter_add_kernel(long long* c, long long d) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += d;
+}
+
+extern "C" size_t emrt_gradnorm_workspace_bytes(void) { return 2048 * sizeof(float); }
+
+extern "C" int emrt_grad_clip_scale(const float* grads, long long n, float clip, float* state /*[2]*/, void* workspace, void* stream) {
+  EMRT_REQUIRE(grads && state && workspace, "null pointer");
+  EMRT_REQUIRE(((uintptr_t)grads) % 16 == 0, "grads must be 16-byte aligned");
+  int grid = (int)((n / 4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(grid), dim3(256), 0, st, grads, n, (float*)workspace);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, grid, clip, state);
+  return check_launch("emrt_grad_clip_scale");
+}
+
+extern "C" int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state,
+                                      const long long* step, float base_lr, float end_lr, float power, long long decay_steps,
+                                      float momentum, float weight_decay, const long long* ranges /*host [nranges][2]*/,
+                                      int nranges, float range_mult, float* lr_out, void* stream) {
+  EMRT_REQUIRE(params && grads && velocity, "null pointer");
+  EMRT_REQUIRE(nranges >= 0 && nranges <= 32 && (nranges == 0 || ranges), "0..32 lr-mult ranges");
+  EMRT_REQUIRE(decay_steps > 0, "decay_steps must be positive");
+  SgdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.p = params; a.g = grads; a.v = velocity; a.n = n; a.state = clip_state; a.step = step;
+  a.base_lr = base_lr; a.end_lr = end_lr; a.power = power; a.decay_steps = decay_steps;
+  a.momentum = momentum; a.weight_decay = weight_decay; a.nranges = nranges; a.range_mult = range_mult; a.lr_out = lr_out;
+  for (int r = 0; r < nranges; ++r) { a.r0[r] = ranges[2 * r]; a.r1[r] = ranges[2 * r + 1]; }
+  int grid = (int)((n + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("emrt_sgd_momentum_step");
+}
+
+extern "C" int emrt_counter_add(long long* counter, long long delta, void* stream) {
+  EMRT_REQUIRE(counter, "null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, delta);
+  return check_launch("emrt_counter_add");
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing.  Descriptor table (device, int64 x 8 per entry):
+//   {src_off, fwd_off (-1: none), bwd_off (-1: none), OC, taps, C, tile_prefix (first flat tile id), unused}
+// One 32x32 (oc x c) tile per block per tap; flat tile id -> descriptor by binary search on tile_prefix.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ master, T* __restrict__ packed,
+                                                           const long long* __restrict__ desc, int ndesc) {
+  __shared__ float tile[32][33];
+  const long long tid = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid * 8 + 6] <= tid) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + lo * 8;
+  const long long src = d[0], fo = d[1], bo = d[2];
+  const int OC = (int)d[3], taps = (int)d[4], C = (int)d[5];
+  const int tc = (C + 31) / 32, toc = (OC + 31) / 32;
+  long long local = tid - d[6];
+  const int ct = (int)(local % tc); local /= tc;
+  const int ot = (int)(local % toc);
+  const int tap = (int)(local / toc);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oc = ot * 32 + ty + 8 * r, c = ct * 32 + tx;
+    float v = 0.f;
+    if (oc < OC && c < C) {
+      const long long idx = ((long long)oc * taps + tap) * C + c;
+      v = master[src + idx];
+      if (fo >= 0) packed[fo + idx] = from_f32<T>(v);
+    }
+    tile[ty + 8 * r][tx] = v;
+  }
+  if (bo < 0) return;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = ct * 32 + ty + 8 * r, oc = ot * 32 + tx;
+    if (oc < OC && c < C) packed[bo + ((long long)c * taps + tap) * OC + oc] = from_f32<T>(tile[tx][ty + 8 * r]);
+  }
+}
+
+extern "C" int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles,
+                                 int dtype, void* stream) {
+  EMRT_REQUIRE(master && packed && desc_dev, "null pointer");
+  EMRT_REQUIRE(ndesc > 0 && total_tiles > 0 && total_tiles < 2147483647LL, "bad descriptor table");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (float*)packed, desc_dev, ndesc);
+  else hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc);
+  return check_launch("emrt_pack_weights");
+}

@@ -1,0 +1,313 @@
+// Multi-scale deformable attention core for gfx950 -- the EMRT path's irregular gather.
+//
+// Replaces, in ONE kernel, the reference's softmax + location arithmetic + 3x grid_sample + stack + mul + sum
+// (transformer_encoder_decoder.py:89-104 and utils.py:64-97), which materialise a [B*M, D, Lq, L*P] tensor.
+//   a[b,q,m,:]   = softmax_{l,p}( logits[b,q,m,l,p] )
+//   loc[...,l,p] = ref[b,q,l,:] + off[b,q,m,l,p,:] / (W_l, H_l)                (x, y in [0,1])
+//   out[b,q,m,:] = sum_{l,p} a * bilinear_zero_pad(value_l[b,:,m,:], x = loc_x*W_l - 0.5, y = loc_y*H_l - 0.5)
+//
+// Layout: value [B][Lv][M*D] (row stride ldv), D = 32.  `offw` is the fp32 output of the fused
+// sampling_offsets|attention_weights projection: row (b*Lq+q) holds M*L*P*2 offsets then M*L*P logits.
+// Work split: 4 lanes x 8 channels per (q, head); a wave covers 2 queries x 8 heads (M = 8) so its output is two
+// full 256-channel rows.  Every sample corner is one 16-byte (bf16) / 32-byte (f32) load per lane; 4 lanes
+// fetch one contiguous 64/128-byte head slice.  HBM-compulsory bytes are tiny; the kernel is
+// bound by L2/TA gather throughput, which is why value stays L2-resident across the B*M slabs.
+#include "common.hpp"
+
+using namespace emrt;
+
+struct MsdaArgs {
+  const void* value;
+  int ldv;
+  long long v_bs;
+  const float* offw;
+  int ldo;
+  const float* ref;
+  long long ref_bs;   // 0 => same reference points for every batch element
+  int ref_L;          // reference points per query: L (one per level) or 1 (shared by all levels)
+  void* out;
+  int B, Lq, M;
+  int h[4], w[4], start[4];
+  // backward only
+  const void* dout;
+  float* dvalue;      // fp32 [B][Lv][M*32] dense, accumulated with atomics (caller zeroes)
+  long long dv_bs;
+  float* doffw;       // fp32 [B*Lq][ldo] (offset + logit gradients), fully overwritten
+  float* dref;        // fp32 [B][Lq][L][2] or null, fully overwritten
+};
+
+template <class T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[8]) { Vec8<T>::load(p, o); }
+
+template <class T, int L, int P>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
+  constexpr int LP = L * P;
+  const int lane = threadIdx.x & 63;
+  const long long pair = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+  const long long total = (long long)a.B * a.Lq * a.M;
+  if (pair >= total) return;
+  const int sub = lane & 3;
+  const int m = (int)(pair % a.M);
+  const long long bq = pair / a.M;
+  const int b = (int)(bq / a.Lq);
+  const int q = (int)(bq - (long long)b * a.Lq);
+
+  const float* row = a.offw + bq * a.ldo;
+  const float* offp = row + m * LP * 2;
+  const float* logp = row + a.M * LP * 2 + m * LP;
+  float lg[LP];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { lg[i] = logp[i]; mx = fmaxf(mx, lg[i]); }
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
+  const float inv = 1.f / den;
+
+  const T* vb = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8;
+  const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2;
+  const int rls = a.ref_L == 1 ? 0 : 2;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = a.h[l], W = a.w[l];
+    const float rx = refp[l * rls], ry = refp[l * rls + 1];
+    const T* vl = vb + (long long)a.start[l] * a.ldv;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float2 o = *reinterpret_cast<const float2*>(offp + (l * P + p) * 2);
+      const float x = (rx + o.x / (float)W) * (float)W - 0.5f;
+      const float y = (ry + o.y / (float)H) * (float)H - 0.5f;
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float aw = lg[l * P + p] * inv;
+      const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+      float v[8];
+      if (vy0 && vx0) { load8<T>(vl + ((long long)y0 * W + x0) * a.ldv, v); const float c = aw * (1.f - ly) * (1.f - lx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+      if (vy0 && vx1) { load8<T>(vl + ((long long)y0 * W + x0 + 1) * a.ldv, v); const float c = aw * (1.f - ly) * lx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+      if (vy1 && vx0) { load8<T>(vl + ((long long)(y0 + 1) * W + x0) * a.ldv, v); const float c = aw * ly * (1.f - lx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+      if (vy1 && vx1) { load8<T>(vl + ((long long)(y0 + 1) * W + x0 + 1) * a.ldv, v); const float c = aw * ly * lx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+    }
+  }
+  Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
+}
+
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes that share one (q, head)
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// Backward with recompute.  grad_value is scattered with fp32 atomics (v1; LDS-privatised slabs are the planned
+// follow-up); offset/logit gradients are written by lane sub==0 of each quad; the reference-point
+// gradient (decoder only) is reduced over the 8 heads of a query inside the wave.
+template <class T, int L, int P>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
+  constexpr int LP = L * P;
+  const int lane = threadIdx.x & 63;
+  const long long pair_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+  const long long total = (long long)a.B * a.Lq * a.M;
+  const bool live = pair_raw < total;
+  const long long pair = live ? pair_raw : total - 1;   // dead lanes shadow a live pair so shuffles stay full-wave
+  const int sub = lane & 3;
+  const int m = (int)(pair % a.M);
+  const long long bq = pair / a.M;
+  const int b = (int)(bq / a.Lq);
+  const int q = (int)(bq - (long long)b * a.Lq);
+
+  const float* row = a.offw + bq * a.ldo;
+  const float* offp = row + m * LP * 2;
+  const float* logp = row + a.M * LP * 2 + m * LP;
+  float pr[LP];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { pr[i] = logp[i]; mx = fmaxf(mx, pr[i]); }
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { pr[i] = __expf(pr[i] - mx); den += pr[i]; }
+  const float inv = 1.f / den;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) pr[i] *= inv;
+
+  float go[8];
+  load8<T>((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8, go);
+  if (!live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) go[e] = 0.f;
+  }
+
+  const T* vb = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8;
+  float* gvb = a.dvalue + (long long)b * a.dv_bs + m * 32 + sub * 8;
+  const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2;
+  const int rls = a.ref_L == 1 ? 0 : 2;
+  const int ldg = a.M * 32;
+
+  float dA[LP];          // d loss / d attention prob
+  float gx[LP], gy[LP];  // d loss / d pixel coordinate (== d offset)
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = a.h[l], W = a.w[l];
+    const float rx = refp[l * rls], ry = refp[l * rls + 1];
+    const T* vl = vb + (long long)a.start[l] * a.ldv;
+    float* gl = gvb + (long long)a.start[l] * ldg;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      const float2 o = *reinterpret_cast<const float2*>(offp + i * 2);
+      const float x = (rx + o.x / (float)W) * (float)W - 0.5f;
+      const float y = (ry + o.y / (float)H) * (float)H - 0.5f;
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float aw = pr[i];
+      const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+      float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;   // <dout, v_corner> over this lane's 8 channels
+      float v[8];
+      if (vy0 && vx0) {
+        const long long off = (long long)y0 * W + x0;
+        load8<T>(vl + off * a.ldv, v);
+        const float c = aw * (1.f - ly) * (1.f - lx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d00 = fmaf(go[e], v[e], d00); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+      }
+      if (vy0 && vx1) {
+        const long long off = (long long)y0 * W + x0 + 1;
+        load8<T>(vl + off * a.ldv, v);
+        const float c = aw * (1.f - ly) * lx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d01 = fmaf(go[e], v[e], d01); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+      }
+      if (vy1 && vx0) {
+        const long long off = (long long)(y0 + 1) * W + x0;
+        load8<T>(vl + off * a.ldv, v);
+        const float c = aw * ly * (1.f - lx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d10 = fmaf(go[e], v[e], d10); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+      }
+      if (vy1 && vx1) {
+        const long long off = (long long)(y0 + 1) * W + x0 + 1;
+        load8<T>(vl + off * a.ldv, v);
+        const float c = aw * ly * lx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d11 = fmaf(go[e], v[e], d11); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+      }
+      d00 = quad_sum(d00); d01 = quad_sum(d01); d10 = quad_sum(d10); d11 = quad_sum(d11);
+      dA[i] = (1.f - ly) * ((1.f - lx) * d00 + lx * d01) + ly * ((1.f - lx) * d10 + lx * d11);
+      gx[i] = aw * ((1.f - ly) * (d01 - d00) + ly * (d11 - d10));
+      gy[i] = aw * ((1.f - lx) * (d10 - d00) + lx * (d11 - d01));
+    }
+  }
+  // softmax backward: dlogit_i = p_i * (dA_i - sum_j p_j dA_j)
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) dot = fmaf(pr[i], dA[i], dot);
+  if (live && sub == 0) {
+    float* drow = a.doffw + bq * a.ldo;
+    float* doff = drow + m * LP * 2;
+    float* dlog = drow + a.M * LP * 2 + m * LP;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+      *reinterpret_cast<float2*>(doff + i * 2) = make_float2(gx[i], gy[i]);
+      dlog[i] = pr[i] * (dA[i] - dot);
+    }
+  }
+  if (a.dref) {
+    // loc = ref + off/W  =>  d ref_x = W * d x ; sum over points, then over the 8 heads (lane bits 2..4; needs M == 8)
+    float tx = 0.f, ty = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float sx = 0.f, sy = 0.f;
+#pragma unroll
+      for (int p = 0; p < P; ++p) { sx += gx[l * P + p]; sy += gy[l * P + p]; }
+      sx *= (float)a.w[l]; sy *= (float)a.h[l];
+      if (!live) { sx = 0.f; sy = 0.f; }
+      sx += __shfl_xor(sx, 4, 64); sx += __shfl_xor(sx, 8, 64); sx += __shfl_xor(sx, 16, 64);
+      sy += __shfl_xor(sy, 4, 64); sy += __shfl_xor(sy, 8, 64); sy += __shfl_xor(sy, 16, 64);
+      tx += sx; ty += sy;
+      if (a.ref_L != 1 && live && sub == 0 && m == 0)
+        *reinterpret_cast<float2*>(a.dref + (bq * L + l) * 2) = make_float2(sx, sy);
+    }
+    if (a.ref_L == 1 && live && sub == 0 && m == 0) *reinterpret_cast<float2*>(a.dref + bq * 2) = make_float2(tx, ty);
+  }
+}
+
+template <class T>
+static int msda_launch(const MsdaArgs& a, int L, int P, bool bwd, hipStream_t st) {
+  const long long pairs = (long long)a.B * a.Lq * a.M;
+  const unsigned grid = (unsigned)((pairs + 63) / 64);
+#define MSDA_CASE(LL, PP)                                                                                     \
+  if (L == LL && P == PP) {                                                                                   \
+    if (bwd) hipLaunchKernelGGL((msda_bwd_kernel<T, LL, PP>), dim3(grid), dim3(256), 0, st, a);                \
+    else hipLaunchKernelGGL((msda_fwd_kernel<T, LL, PP>), dim3(grid), dim3(256), 0, st, a);                    \
+    return check_launch(bwd ? "emrt_msda_bwd" : "emrt_msda_fwd");                                             \
+  }
+  MSDA_CASE(3, 6)
+  MSDA_CASE(4, 4)
+  MSDA_CASE(3, 4)
+  MSDA_CASE(1, 4)
+#undef MSDA_CASE
+  return fail("emrt_msda", "unsupported (levels, points): built for (3,6), (4,4), (3,4), (1,4)");
+}
+
+static int msda_fill(MsdaArgs& a, const int* shapes_hw, int L, int Lv) {
+  int start = 0;
+  for (int l = 0; l < 4; ++l) { a.h[l] = 1; a.w[l] = 1; a.start[l] = 0; }
+  for (int l = 0; l < L; ++l) {
+    a.h[l] = shapes_hw[2 * l];
+    a.w[l] = shapes_hw[2 * l + 1];
+    a.start[l] = start;
+    start += a.h[l] * a.w[l];
+  }
+  return start == Lv ? 0 : -1;
+}
+
+extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
+                             long long ref_bs, int ref_L, void* out, int B, int Lq, int Lv, int M, int D, int L, int P,
+                             const int* shapes_hw /*host, [L][2]*/, int dtype, void* stream) {
+  EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
+  EMRT_REQUIRE(value && offw && ref && out && shapes_hw, "null pointer");
+  EMRT_REQUIRE(D == 32, "head dim must be 32");
+  EMRT_REQUIRE(M >= 1 && L >= 1 && L <= 4 && P >= 1, "bad M/L/P");
+  EMRT_REQUIRE(ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 2 == 0, "value strides must be multiples of 8 elements");
+  EMRT_REQUIRE(ldo >= M * L * P * 3, "offw row too short");
+  MsdaArgs a;
+  memset(&a, 0, sizeof(a));
+  a.value = value; a.ldv = ldv; a.v_bs = v_bs; a.offw = offw; a.ldo = ldo; a.ref = ref; a.ref_bs = ref_bs; a.ref_L = ref_L; a.out = out;
+  a.B = B; a.Lq = Lq; a.M = M;
+  EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, false, st) : msda_launch<bf16_t>(a, L, P, false, st);
+}
+
+extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
+                             long long ref_bs, int ref_L, const void* dout, float* dvalue, float* doffw, float* dref, int B, int Lq,
+                             int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream) {
+  EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
+  EMRT_REQUIRE(value && offw && ref && dout && dvalue && doffw && shapes_hw, "null pointer");
+  EMRT_REQUIRE(D == 32, "head dim must be 32");
+  EMRT_REQUIRE(M >= 1 && L >= 1 && L <= 4 && P >= 1, "bad M/L/P");
+  EMRT_REQUIRE(!dref || M == 8, "reference-point gradient needs M == 8");
+  EMRT_REQUIRE(ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 2 == 0, "value strides must be multiples of 8 elements");
+  MsdaArgs a;
+  memset(&a, 0, sizeof(a));
+  a.value = value; a.ldv = ldv; a.v_bs = v_bs; a.offw = offw; a.ldo = ldo; a.ref = ref; a.ref_bs = ref_bs; a.ref_L = ref_L;
+  a.dout = dout; a.dvalue = dvalue; a.dv_bs = (long long)Lv * M * 32; a.doffw = doffw; a.dref = dref;
+  a.B = B; a.Lq = Lq; a.M = M;
+  EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, true, st) : msda_launch<bf16_t>(a, L, P, true, st);
+}

@@ -1,0 +1,690 @@
+// Normalisation kernels for gfx950: BatchNorm (train/eval, +residual, +ReLU), GroupNorm(+GELU)(+residual),
+// residual-add + LayerNorm, and per-channel column sums (bias gradients).  All HBM-bound: rows of C
+// contiguous channels (NHWC), 4 channels per thread (16 B f32 / 8 B bf16 accesses), fp32 statistics.
+//
+// Reference call sites replaced: nn.BatchNorm2D / nn.SyncBatchNorm
+// (paddle_vision_resnet.py:132-147, paddle_EMRT.py:18,64,131,139-141,203,206, fcn_head.py:53),
+// nn.GroupNorm(32,256)+nn.GELU (transformer_encoder_decoder.py:125-144,378), nn.LayerNorm(256)
+// (transformer_encoder_decoder.py:116,123,251,256,264).
+#include "common.hpp"
+
+using namespace emrt;
+
+// ------------------------------------------------------------------------------------------------
+// column reductions over rows of a [M][C] (row stride ld) matrix.
+// MODE 0: sum x, sum x^2                       (BN statistics)
+// MODE 1: sum dy', sum dy' * xhat              (BN backward; dy' = dy masked by y > 0 when relu)
+// MODE 2: sum x                                (bias gradient)
+// partial[blk][2][C]; a finalize kernel combines the blocks in double precision (deterministic).
+// Block = 256 threads = TX channel-quads x TY row lanes; grid.y walks channel chunks of 4*TX.
+// ------------------------------------------------------------------------------------------------
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                         const T* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, long long M, int C, int tx_n,
+                                                         float* __restrict__ partial, long long rpb, long long bs) {
+  __shared__ float red[256 * 8];
+  const int ty_n = 256 / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int c = (blockIdx.y * tx_n + tx) * 4;
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (c < C) {
+    float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+    }
+    for (long long r = (long long)blockIdx.x * ty_n + ty; r < M; r += (long long)gridDim.x * ty_n) {
+      float v[4];
+      if (MODE == 0) {
+        Vec4<T>::load(x + r * ldx + c, v);   // BN statistics: always dense rows
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += v[e]; s1[e] = fmaf(v[e], v[e], s1[e]); }
+      } else if (MODE == 1) {
+        float g[4];
+        Vec4<T>::load(x + r * ldx + c, v);
+        Vec4<T>::load(dy + r * lddy + c, g);
+        if (y) {
+          float o[4];
+          Vec4<T>::load(y + r * ldy + c, o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], (v[e] - mu[e]) * is[e], s1[e]); }
+      } else {
+        const long long bb = r / rpb;   // batch-strided rows: row r = (batch bb, row r - bb*rpb)
+        Vec4<T>::load(x + bb * bs + (r - bb * rpb) * ldx + c, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s0[e] += v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s0[e]; red[threadIdx.x * 8 + 4 + e] = s1[e]; }
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    for (int t = 1; t < ty_n; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] += red[(t * tx_n + tx) * 8 + e]; s1[e] += red[(t * tx_n + tx) * 8 + 4 + e]; }
+    }
+    float* pp = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pp[c + e] = s0[e]; pp[C + c + e] = s1[e]; }
+  }
+}
+
+static inline void col_reduce_geometry(long long M, int C, int& tx_n, int& gx, int& gy) {
+  int quads = (C + 3) / 4;
+  tx_n = 64;
+  while (tx_n > 1 && tx_n / 2 >= quads) tx_n /= 2;
+  gy = (quads + tx_n - 1) / tx_n;
+  int ty_n = 256 / tx_n;
+  long long want = (M + (long long)ty_n * 8 - 1) / ((long long)ty_n * 8);
+  long long cap = 1024 / gy;
+  if (cap < 1) cap = 1;
+  gx = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+// BN train finalize: partial[nblk][2][C] (local sums) -> mean, invstd (saved for bwd), running stats update
+// (Paddle convention: running = mom*running + (1-mom)*batch, biased variance).
+// `count` is the number of rows the sums cover (after a cross-rank all-reduce of `sums` for SyncBN it is
+// the global count).  Split in two so SyncBN can all-reduce between them.
+__global__ void bn_sum_partials_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums /*[2][C]*/) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(long long)b * 2 * C + c];
+  sums[c] = (float)s;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mu = (double)sums[c] / count;
+  double var = (double)sums[C + c] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * (float)mu;
+    run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)var;
+  }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = run_mean[c];
+  invstd[c] = rsqrtf(run_var[c] + eps);
+}
+
+// y = [relu]((x - mean) * invstd * gamma + beta [+ res])
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ res, int ldres,
+                                                       T* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long M, int C, int relu) {
+  const int quads = C / 4;
+  const long long total = M * quads;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long r = idx / quads;
+    const int c = (int)(idx - r * quads) * 4;
+    float v[4], o[4];
+    Vec4<T>::load(x + r * ldx + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean[c + e]) * invstd[c + e] * gamma[c + e] + beta[c + e];
+    if (res) {
+      float q[4];
+      Vec4<T>::load(res + r * ldres + c, q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += q[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    Vec4<T>::store(y + r * ldy + c, o);
+  }
+}
+
+// BN backward finalize: sums[2][C] = (sum dy', sum dy'*xhat) -> dgamma += , dbeta +=   (sums kept for dx)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] += sums[c];
+  if (dgamma) dgamma[c] += sums[C + c];
+}
+
+// dx = gamma*invstd*(dy' - sum_dy/count - xhat*sum_dyxhat/count); optional dres = dy' (gradient of the fused residual)
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                        const T* __restrict__ y, int ldy, T* __restrict__ dx, int lddx,
+                                                        T* __restrict__ dres, int lddres, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ sums, float inv_count, long long M, int C) {
+  const int quads = C / 4;
+  const long long total = M * quads;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long r = idx / quads;
+    const int c = (int)(idx - r * quads) * 4;
+    float v[4], g[4], o[4];
+    Vec4<T>::load(x + r * ldx + c, v);
+    Vec4<T>::load(dy + r * lddy + c, g);
+    if (y) {
+      float yy[4];
+      Vec4<T>::load(y + r * ldy + c, yy);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mean[c + e]) * invstd[c + e];
+      o[e] = gamma[c + e] * invstd[c + e] * (g[e] - sums[c + e] * inv_count - xh * sums[C + c + e] * inv_count);
+    }
+    Vec4<T>::store(dx + r * lddx + c, o);
+    if (dres) Vec4<T>::store(dres + r * lddres + c, g);
+  }
+}
+
+// eval-mode BN backward is never needed (no training in eval); not provided.
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (+ exact-erf GELU) (+ residual):  out = act(GN(x)) + res.   One 1024-thread block per image:
+// TX = C/4 channel quads x TY pixel lanes, two passes over that image's [HW][C] slab (second pass is L2-hot).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <class T>
+__global__ __launch_bounds__(1024) void gn_fwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ res,
+                                                      int ldres, long long res_bs, T* __restrict__ out, int ldout,
+                                                      long long out_bs, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ mean_out,
+                                                      float* __restrict__ rstd_out, int HW, int C, int G, float eps, int gelu) {
+  extern __shared__ float sm[];  // [1024*2] scratch, then [G*2] stats
+  const int tx_n = C / 4, ty_n = blockDim.x / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int n = blockIdx.x, c = tx * 4;
+  const int cpg = C / G;
+  const T* xp = x + (long long)n * x_bs;
+  float s0 = 0.f, s1 = 0.f;
+  if (ty < ty_n) {
+    for (int p = ty; p < HW; p += ty_n) {
+      float v[4];
+      Vec4<T>::load(xp + (long long)p * ldx + c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0 += v[e]; s1 = fmaf(v[e], v[e], s1); }
+    }
+  }
+  sm[threadIdx.x * 2] = s0;
+  sm[threadIdx.x * 2 + 1] = s1;
+  __syncthreads();
+  float* stats = sm + 2 * blockDim.x;
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    const int q0 = g * cpg / 4, q1 = (g + 1) * cpg / 4;
+    for (int t = 0; t < ty_n; ++t)
+      for (int q = q0; q < q1; ++q) { a += sm[(t * tx_n + q) * 2]; b += sm[(t * tx_n + q) * 2 + 1]; }
+    const double cnt = (double)HW * cpg;
+    const double mu = a / cnt;
+    double var = b / cnt - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    stats[g * 2] = (float)mu;
+    stats[g * 2 + 1] = rs;
+    if (mean_out) { mean_out[n * G + g] = (float)mu; rstd_out[n * G + g] = rs; }
+  }
+  __syncthreads();
+  if (ty < ty_n) {
+    const int g = c / cpg;
+    const float mu = stats[g * 2], rs = stats[g * 2 + 1];
+    float ga[4], be[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
+    for (int p = ty; p < HW; p += ty_n) {
+      float v[4], o[4];
+      Vec4<T>::load(xp + (long long)p * ldx + c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = (v[e] - mu) * rs * ga[e] + be[e];
+        o[e] = gelu ? gelu_f(u) : u;
+      }
+      if (res) {
+        float q[4];
+        Vec4<T>::load(res + (long long)n * res_bs + (long long)p * ldres + c, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += q[e];
+      }
+      Vec4<T>::store(out + (long long)n * out_bs + (long long)p * ldout + c, o);
+    }
+  }
+}
+
+// GN backward: dx (w.r.t. GN input), dgamma/dbeta (atomics, one add per image per channel).  The residual's
+// gradient is dy itself and is handled by the caller.
+template <class T>
+__global__ __launch_bounds__(1024) void gn_bwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy,
+                                                      int lddy, long long dy_bs, T* __restrict__ dx, int lddx, long long dx_bs,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G,
+                                                      int gelu) {
+  extern __shared__ float sm[];
+  const int tx_n = C / 4, ty_n = blockDim.x / tx_n;
+  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+  const int n = blockIdx.x, c = tx * 4;
+  const int cpg = C / G, g = c / cpg;
+  const T* xp = x + (long long)n * x_bs;
+  const T* gp = dy + (long long)n * dy_bs;
+  const float mu = mean[n * G + g], rs = rstd[n * G + g];
+  float ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (ty < ty_n) {
+    for (int p = ty; p < HW; p += ty_n) {
+      float v[4], d[4];
+      Vec4<T>::load(xp + (long long)p * ldx + c, v);
+      Vec4<T>::load(gp + (long long)p * lddy + c, d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[e] - mu) * rs;
+        const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+        s0[e] += dd;
+        s1[e] = fmaf(dd, xh, s1[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sm[threadIdx.x * 8 + e] = s0[e]; sm[threadIdx.x * 8 + 4 + e] = s1[e]; }
+  __syncthreads();
+  float* chs = sm + 8 * blockDim.x;       // [C][2] per-channel sums for this image
+  float* gs = chs + 2 * C;                // [G][2]
+  if (ty == 0) {
+    for (int t = 1; t < ty_n; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] += sm[(t * tx_n + tx) * 8 + e]; s1[e] += sm[(t * tx_n + tx) * 8 + 4 + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      chs[(c + e) * 2] = s0[e];
+      chs[(c + e) * 2 + 1] = s1[e];
+      if (dbeta) atomicAdd(dbeta + c + e, s0[e]);
+      if (dgamma) atomicAdd(dgamma + c + e, s1[e]);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int gg = threadIdx.x;
+    float a = 0.f, b = 0.f;
+    for (int cc = gg * cpg; cc < (gg + 1) * cpg; ++cc) { a += gamma[cc] * chs[cc * 2]; b += gamma[cc] * chs[cc * 2 + 1]; }
+    const float inv = 1.f / ((float)HW * cpg);
+    gs[gg * 2] = a * inv;
+    gs[gg * 2 + 1] = b * inv;
+  }
+  __syncthreads();
+  if (ty < ty_n) {
+    const float A = gs[g * 2], Bq = gs[g * 2 + 1];
+    for (int p = ty; p < HW; p += ty_n) {
+      float v[4], d[4], o[4];
+      Vec4<T>::load(xp + (long long)p * ldx + c, v);
+      Vec4<T>::load(gp + (long long)p * lddy + c, d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[e] - mu) * rs;
+        const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+        o[e] = rs * (ga[e] * dd - A - xh * Bq);
+      }
+      Vec4<T>::store(dx + (long long)n * dx_bs + (long long)p * lddx + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim C (C % 4 == 0, C <= 1024) with fused residual add:
+//   z = a (+ b);  out = LN(z)*gamma + beta (+ post)        one wave per row, 4 rows per 256-thread block.
+// `post` is the encoder's "src = src + src_flatten" (transformer_encoder_decoder.py:203), fused here.
+// z (the LN input) and mean/rstd are saved for backward.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ post,
+                                                     T* __restrict__ z, T* __restrict__ out, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, long long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nq = C / 256 + ((C % 256) ? 1 : 0);
+  float v[4][4];
+  float s = 0.f;
+  for (int j = 0; j < nq; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < C) {
+      Vec4<T>::load(a + row * C + c, v[j]);
+      if (b) {
+        float w[4];
+        Vec4<T>::load(b + row * C + c, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] += w[e];
+      }
+      if (z) {
+        // round z through T so forward and backward see the same LN input
+        Vec4<T>::store(z + row * C + c, v[j]);
+        if (sizeof(T) == 2) Vec4<T>::load(z + row * C + c, v[j]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[j][e];
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int j = 0; j < nq; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q = fmaf(d, d, q); }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0 && mean_out) { mean_out[row] = mu; rstd_out[row] = rs; }
+  for (int j = 0; j < nq; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < C) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * gamma[c + e] + beta[c + e];
+      if (post) {
+        float w[4];
+        Vec4<T>::load(post + row * C + c, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += w[e];
+      }
+      Vec4<T>::store(out + row * C + c, o);
+    }
+  }
+}
+
+// LN backward: dz = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  per-block partial dgamma/dbeta
+// -> partial[blk][2][C]; combined by bn_sum_partials_kernel + bn_bwd_finalize_kernel.
+template <class T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
+                                                     int C, int rows_per_block) {
+  extern __shared__ float sm[];  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nq = C / 256 + ((C % 256) ? 1 : 0);
+  float dg[4][4], db[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long long row = r0 + wv; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[4][4], gd[4][4];
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = 0; j < nq; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (c < C) {
+        float zz[4], d[4];
+        Vec4<T>::load(z + row * C + c, zz);
+        Vec4<T>::load(dy + row * C + c, d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[j][e] = (zz[e] - mu) * rs;
+          gd[j][e] = gamma[c + e] * d[e];
+          s0 += gd[j][e];
+          s1 = fmaf(gd[j][e], xh[j][e], s1);
+          dg[j][e] = fmaf(d[e], xh[j][e], dg[j][e]);
+          db[j][e] += d[e];
+        }
+      }
+    }
+    s0 = wave_sum(s0) / (float)C;
+    s1 = wave_sum(s1) / (float)C;
+    for (int j = 0; j < nq; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (c < C) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gd[j][e] - s0 - xh[j][e] * s1);
+        Vec4<T>::store(dz + row * C + c, o);
+      }
+    }
+  }
+  for (int j = 0; j < nq; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sm[(wv * 2 + 0) * C + c + e] = db[j][e]; sm[(wv * 2 + 1) * C + c + e] = dg[j][e]; }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float b0 = 0.f, g0 = 0.f;
+    for (int w = 0; w < 4; ++w) { b0 += sm[(w * 2 + 0) * C + c]; g0 += sm[(w * 2 + 1) * C + c]; }
+    partial[(long long)blockIdx.x * 2 * C + c] = b0;       // slot 0: dbeta  (matches bn_bwd_finalize: sums[c] -> dbeta)
+    partial[(long long)blockIdx.x * 2 * C + C + c] = g0;   // slot 1: dgamma
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+#define DT_SWITCH(dtype, EXPR_F32, EXPR_BF16) \
+  do {                                        \
+    if ((dtype) == EMRT_F32) { EXPR_F32; } else { EXPR_BF16; } \
+  } while (0)
+
+static inline int ew_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" size_t emrt_colreduce_workspace_bytes(long long M, int C) {
+  int tx, gx, gy;
+  col_reduce_geometry(M, C, tx, gx, gy);
+  return ((size_t)gx * 2 * C + 2 * (size_t)C) * sizeof(float);
+}
+
+// BN training statistics, step 1: local sums -> sums[2][C] (sum x, sum x^2).  workspace >= emrt_colreduce_workspace_bytes.
+extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, float* sums, void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE(x && sums && workspace, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0, "C and ld must be multiples of 4");
+  int tx, gx, gy;
+  col_reduce_geometry(M, C, tx, gx, gy);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((col_reduce_kernel<float, 0>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, M, 0LL),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, M, 0LL));
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, gx, C, sums);
+  return check_launch("emrt_bn_stats");
+}
+
+// step 2: sums (+count) -> mean/invstd, running-stat update (run_* may be null)
+extern "C" int emrt_bn_finalize(const float* sums, double count, int C, float eps, float momentum, float* mean, float* invstd,
+                                float* run_mean, float* run_var, void* stream) {
+  EMRT_REQUIRE(sums && mean && invstd, "null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, C, eps, momentum, mean, invstd, run_mean, run_var);
+  return check_launch("emrt_bn_finalize");
+}
+
+extern "C" int emrt_bn_eval_stats(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd, void* stream) {
+  EMRT_REQUIRE(run_mean && run_var && mean && invstd, "null pointer");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, run_mean, run_var, C, eps, mean, invstd);
+  return check_launch("emrt_bn_eval_stats");
+}
+
+extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, long long M, int C, int relu, int dtype,
+                             void* stream) {
+  EMRT_REQUIRE(x && y && mean && invstd && gamma && beta, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0), "C and ld must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(M * (C / 4));
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, mean, invstd, gamma, beta, M, C, relu),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, mean, invstd, gamma, beta, M, C, relu));
+  return check_launch("emrt_bn_apply");
+}
+
+// BN backward step 1: sums[2][C] = (sum dy', sum dy'*xhat); y (post-ReLU output) may be null when no ReLU was fused.
+extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean,
+                                  const float* invstd, long long M, int C, float* sums, void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE(x && dy && mean && invstd && sums && workspace, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!y || ldy % 4 == 0), "C and ld must be multiples of 4");
+  int tx, gx, gy;
+  col_reduce_geometry(M, C, tx, gx, gy);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, partial, M, 0LL),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, partial, M, 0LL));
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, gx, C, sums);
+  return check_launch("emrt_bn_bwd_reduce");
+}
+
+// BN backward step 2: dgamma += sums[1], dbeta += sums[0]; dx (and optional dres = masked dy). inv_count = 1/rows (global for SyncBN).
+extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
+                              void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
+                              const float* sums, float inv_count, float* dgamma, float* dbeta, long long M, int C, int dtype,
+                              void* stream) {
+  EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  if (dgamma || dbeta) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+  const int grid = ew_grid(M * (C / 4));
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, inv_count, M, C),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, inv_count, M, C));
+  return check_launch("emrt_bn_bwd_dx");
+}
+
+// narrow matrices (C not a multiple of 4: class logits, reference-point coordinates): one block per channel
+template <class T>
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict__ x, int ldx, long long rpb, long long bs, long long M,
+                                                            float* __restrict__ dbias) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (long long r = threadIdx.x; r < M; r += 256) {
+    const long long bb = r / rpb;
+    s += to_f32(x[bb * bs + (r - bb * rpb) * ldx + c]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dbias[c] += red[0] + red[1] + red[2] + red[3];
+}
+
+// per-channel column sum (bias / embedding gradient): dbias[c] += sum_r x[r][c]; row r lives at
+// x + (r / rows_per_batch) * x_bs + (r % rows_per_batch) * ldx   (rows_per_batch == M, x_bs == 0 for a dense matrix)
+extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias,
+                               void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE(rows_per_batch > 0, "bad batch geometry");
+  EMRT_REQUIRE(x && dbias && workspace, "null pointer");
+  if (C % 4 != 0 || ldx % 4 != 0 || x_bs % 4 != 0) {
+    hipStream_t st0 = (hipStream_t)stream;
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((colsum_scalar_kernel<float>), dim3(C), dim3(256), 0, st0, (const float*)x, ldx, rows_per_batch, x_bs, M, dbias);
+    else hipLaunchKernelGGL((colsum_scalar_kernel<bf16_t>), dim3(C), dim3(256), 0, st0, (const bf16_t*)x, ldx, rows_per_batch, x_bs, M, dbias);
+    return check_launch("emrt_colsum_acc(scalar)");
+  }
+  int tx, gx, gy;
+  col_reduce_geometry(M, C, tx, gx, gy);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  float* sums = partial + (size_t)gx * 2 * C;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs));
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, gx, C, sums);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, (float*)nullptr, dbias);
+  return check_launch("emrt_colsum_acc");
+}
+
+extern "C" int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out,
+                                  int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd,
+                                  int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE(x && out && gamma && beta, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && C / 4 <= 1024 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && G <= 1024, "unsupported C/G");
+  EMRT_REQUIRE(ldx % 4 == 0 && ldout % 4 == 0 && x_bs % 4 == 0 && out_bs % 4 == 0, "strides must be multiples of 4");
+  const int tx = C / 4;
+  int threads = (1024 / tx) * tx;
+  const size_t lds = (size_t)(2 * threads + 2 * G) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_fwd_kernel<float>), dim3(N), dim3(threads), lds, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu),
+            hipLaunchKernelGGL((gn_fwd_kernel<bf16_t>), dim3(N), dim3(threads), lds, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu));
+  return check_launch("emrt_groupnorm_fwd");
+}
+
+extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx,
+                                  int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, float* dgamma, float* dbeta, int N, int HW, int C, int G, int gelu,
+                                  int dtype, void* stream) {
+  EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && C / 4 <= 1024 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && G <= 1024, "unsupported C/G");
+  const int tx = C / 4;
+  int threads = (1024 / tx) * tx;
+  const size_t lds = (size_t)(8 * threads + 2 * C + 2 * G) * sizeof(float);
+  EMRT_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_bwd_kernel<float>), dim3(N), dim3(threads), lds, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, gamma, beta, mean, rstd, dgamma, dbeta, HW, C, G, gelu),
+            hipLaunchKernelGGL((gn_bwd_kernel<bf16_t>), dim3(N), dim3(threads), lds, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, gamma, beta, mean, rstd, dgamma, dbeta, HW, C, G, gelu));
+  return check_launch("emrt_groupnorm_bwd");
+}
+
+extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma,
+                                  const float* beta, float* mean, float* rstd, long long rows, int C, float eps, int dtype,
+                                  void* stream) {
+  EMRT_REQUIRE(a && out && gamma && beta, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)((rows + 3) / 4);
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)post, (float*)z, (float*)out, gamma, beta, mean, rstd, rows, C, eps),
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps));
+  return check_launch("emrt_layernorm_fwd");
+}
+
+extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
+  long long blocks = (rows + 31) / 32;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  return ((size_t)blocks * 2 * C + 2 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
+                                  float* dgamma, float* dbeta, long long rows, int C, void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE(z && dy && dz && gamma && mean && rstd && workspace, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
+  long long blocks = (rows + 31) / 32;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  int rpb = (int)((rows + blocks - 1) / blocks);
+  rpb = (rpb + 3) / 4 * 4;
+  blocks = (rows + rpb - 1) / rpb;
+  float* partial = (float*)workspace;
+  float* sums = partial + (size_t)blocks * 2 * C;
+  const size_t lds = (size_t)8 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb),
+            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb));
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, (int)blocks, C, sums);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+  return check_launch("emrt_layernorm_bwd");
+}

@@ -1,0 +1,477 @@
+// Spatial resampling kernels for gfx950 (NHWC, HBM-bound, 4-channel vectors where C % 4 == 0):
+// bilinear resize (both align_corners conventions; fused "+ addend", strided concat-slice output, fp32 NCHW logits
+// output), its gather-form backward, multi-scale adaptive average pooling, 3x3/s2 max pooling, NCHW->NHWC ingest.
+//
+// Reference call sites replaced: F.interpolate (paddle_EMRT.py:40,44,169,174,180,
+// 288-289,301; fcn_head.py:80), nn.AdaptiveAvgPool2D (paddle_EMRT.py:62), nn.MaxPool2D(3,2,1)
+// (paddle_vision_resnet.py:201, paddle_EMRT.py:84), paddle.concat (paddle_EMRT.py:290-293 -- replaced by writing
+// each producer straight into its channel slice of the [B,S,S,1536] buffer).
+#include "common.hpp"
+
+using namespace emrt;
+
+struct Axis {  // source coordinate of destination index d:  src = max(0?, s*d + t)
+  float s, t;
+  int clamp0;  // align_corners=False clamps negative src to 0
+};
+
+__host__ __device__ inline Axis make_axis(int in, int out, int align_corners) {
+  Axis a;
+  if (align_corners) { a.s = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; a.t = 0.f; a.clamp0 = 0; }
+  else { a.s = (float)in / (float)out; a.t = 0.5f * a.s - 0.5f; a.clamp0 = 1; }
+  return a;
+}
+
+__device__ __forceinline__ void axis_src(const Axis& a, int d, int in, int& i0, int& i1, float& l0, float& l1) {
+  float src = a.clamp0 ? a.s * ((float)d + 0.5f) - 0.5f : a.s * (float)d;
+  if (a.clamp0 && src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+struct ResizeArgs {
+  const void* in; long long in_bs; int in_ld; int IH, IW;
+  void* out; long long out_bs; int out_ld; int OH, OW;
+  const void* add; long long add_bs; int add_ld;
+  int N, C;
+  Axis ay, ax;
+  int out_nchw_f32;   // out is float [N][C][OH][OW]
+};
+
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs a) {
+  const int cv = a.C / VEC;
+  const long long total = (long long)a.N * a.OH * a.OW * cv;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * VEC;
+    long long r = idx / cv;
+    const int ow = (int)(r % a.OW); r /= a.OW;
+    const int oh = (int)(r % a.OH);
+    const int n = (int)(r / a.OH);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
+    axis_src(a.ax, ow, a.IW, x0, x1, wx0, wx1);
+    const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
+    float o[VEC];
+    if (VEC == 4) {
+      float v00[4], v01[4], v10[4], v11[4];
+      Vec4<T>::load(ip + ((long long)y0 * a.IW + x0) * a.in_ld, v00);
+      Vec4<T>::load(ip + ((long long)y0 * a.IW + x1) * a.in_ld, v01);
+      Vec4<T>::load(ip + ((long long)y1 * a.IW + x0) * a.in_ld, v10);
+      Vec4<T>::load(ip + ((long long)y1 * a.IW + x1) * a.in_ld, v11);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    } else {
+      o[0] = wy0 * (wx0 * to_f32(ip[((long long)y0 * a.IW + x0) * a.in_ld]) + wx1 * to_f32(ip[((long long)y0 * a.IW + x1) * a.in_ld])) +
+             wy1 * (wx0 * to_f32(ip[((long long)y1 * a.IW + x0) * a.in_ld]) + wx1 * to_f32(ip[((long long)y1 * a.IW + x1) * a.in_ld]));
+    }
+    if (a.add) {
+      const T* ap = (const T*)a.add + (long long)n * a.add_bs + ((long long)oh * a.OW + ow) * a.add_ld + c;
+      if (VEC == 4) {
+        float q[4];
+        Vec4<T>::load(ap, q);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += q[e];
+      } else o[0] += to_f32(ap[0]);
+    }
+    if (a.out_nchw_f32) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) ((float*)a.out)[(((long long)n * a.C + c + e) * a.OH + oh) * a.OW + ow] = o[e];
+    } else {
+      T* op = (T*)a.out + (long long)n * a.out_bs + ((long long)oh * a.OW + ow) * a.out_ld + c;
+      if (VEC == 4) {
+        float w4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = o[e < VEC ? e : 0];
+        Vec4<T>::store(op, w4);
+      } else op[0] = from_f32<T>(o[0]);
+    }
+  }
+}
+
+// NCHW-ordered variant for the final logits (C = num classes): thread index runs over ow fastest so the fp32 NCHW
+// stores coalesce.
+template <class T>
+__global__ __launch_bounds__(256) void resize_fwd_nchw_kernel(ResizeArgs a) {
+  const long long total = (long long)a.N * a.C * a.OH * a.OW;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int ow = (int)(idx % a.OW);
+    long long r = idx / a.OW;
+    const int oh = (int)(r % a.OH); r /= a.OH;
+    const int c = (int)(r % a.C);
+    const int n = (int)(r / a.C);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
+    axis_src(a.ax, ow, a.IW, x0, x1, wx0, wx1);
+    const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
+    const float v = wy0 * (wx0 * to_f32(ip[((long long)y0 * a.IW + x0) * a.in_ld]) + wx1 * to_f32(ip[((long long)y0 * a.IW + x1) * a.in_ld])) +
+                    wy1 * (wx0 * to_f32(ip[((long long)y1 * a.IW + x0) * a.in_ld]) + wx1 * to_f32(ip[((long long)y1 * a.IW + x1) * a.in_ld]));
+    ((float*)a.out)[idx] = v;
+  }
+}
+
+// Backward in gather form (deterministic, no atomics): one thread per INPUT pixel (x VEC channels) visits the
+// destination pixels whose 2x2 footprint can include it and re-derives their weights exactly as the forward does.
+struct ResizeBwdArgs {
+  const void* dout; long long do_bs; int do_ld; int OH, OW;   // NHWC T, or fp32 NCHW when dout_nchw_f32
+  void* din; long long di_bs; int di_ld; int IH, IW;
+  int N, C;
+  Axis ay, ax;
+  int dout_nchw_f32;
+};
+
+__device__ __forceinline__ void axis_range(const Axis& a, int i, int out, int& lo, int& hi) {
+  if (a.s <= 0.f) { lo = 0; hi = out - 1; return; }
+  const float t = a.clamp0 ? a.t : 0.f;
+  lo = (int)floorf(((float)i - 1.f - t) / a.s) - 1;
+  hi = (int)ceilf(((float)i + 1.f - t) / a.s) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
+  const int cv = a.C / VEC;
+  const long long total = (long long)a.N * a.IH * a.IW * cv;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * VEC;
+    long long r = idx / cv;
+    const int iw = (int)(r % a.IW); r /= a.IW;
+    const int ih = (int)(r % a.IH);
+    const int n = (int)(r / a.IH);
+    int ylo, yhi, xlo, xhi;
+    axis_range(a.ay, ih, a.OH, ylo, yhi);
+    axis_range(a.ax, iw, a.OW, xlo, xhi);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int oh = ylo; oh <= yhi; ++oh) {
+      int y0, y1;
+      float wy0, wy1;
+      axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
+      const float wy = (y0 == ih ? wy0 : 0.f) + (y1 == ih ? wy1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ow = xlo; ow <= xhi; ++ow) {
+        int x0, x1;
+        float wx0, wx1;
+        axis_src(a.ax, ow, a.IW, x0, x1, wx0, wx1);
+        const float wx = (x0 == iw ? wx0 : 0.f) + (x1 == iw ? wx1 : 0.f);
+        if (wx == 0.f) continue;
+        const float wgt = wy * wx;
+        if (a.dout_nchw_f32) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            acc[e] = fmaf(wgt, ((const float*)a.dout)[(((long long)n * a.C + c + e) * a.OH + oh) * a.OW + ow], acc[e]);
+        } else {
+          const T* gp = (const T*)a.dout + (long long)n * a.do_bs + ((long long)oh * a.OW + ow) * a.do_ld + c;
+          if (VEC == 4) {
+            float g[4];
+            Vec4<T>::load(gp, g);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+          } else acc[0] = fmaf(wgt, to_f32(gp[0]), acc[0]);
+        }
+      }
+    }
+    T* dp = (T*)a.din + (long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + c;
+    if (VEC == 4) {
+      float w4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w4[e] = acc[e < VEC ? e : 0];
+      Vec4<T>::store(dp, w4);
+    } else dp[0] = from_f32<T>(acc[0]);
+  }
+}
+
+// ---- multi-scale adaptive average pooling: in [N][H][W][C] -> out [N][sum k_i^2][C] (token order: scale, row, col) ----
+struct PoolArgs {
+  const void* in; long long in_bs; int in_ld; int H, W;
+  void* out; long long out_bs; int out_ld;
+  int N, C, nscales;
+  int k[4], tok0[4];
+  int ntok;
+};
+
+__device__ __forceinline__ void bin_of(int i, int k, int S, int& b0, int& b1) {
+  b0 = (i * S) / k;
+  b1 = ((i + 1) * S + k - 1) / k;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(PoolArgs a) {
+  const long long total = (long long)a.N * a.ntok * a.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % a.C);
+    long long r = idx / a.C;
+    const int tok = (int)(r % a.ntok);
+    const int n = (int)(r / a.ntok);
+    int s = 0;
+    while (s + 1 < a.nscales && tok >= a.tok0[s + 1]) ++s;
+    const int k = a.k[s], t = tok - a.tok0[s];
+    const int oi = t / k, oj = t - oi * k;
+    int h0, h1, w0, w1;
+    bin_of(oi, k, a.H, h0, h1);
+    bin_of(oj, k, a.W, w0, w1);
+    float acc = 0.f;
+    const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) acc += to_f32(ip[((long long)h * a.W + w) * a.in_ld]);
+    ((T*)a.out)[(long long)n * a.out_bs + (long long)tok * a.out_ld + c] = from_f32<T>(acc / (float)((h1 - h0) * (w1 - w0)));
+  }
+}
+
+// backward: `in` = d(out) tokens, `out` = d(in) map (fully overwritten)
+template <class T>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(PoolArgs a) {
+  const long long total = (long long)a.N * a.H * a.W * a.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % a.C);
+    long long r = idx / a.C;
+    const int w = (int)(r % a.W); r /= a.W;
+    const int h = (int)(r % a.H);
+    const int n = (int)(r / a.H);
+    const T* gp = (const T*)a.out + (long long)n * a.out_bs + c;   // tokens gradient
+    float acc = 0.f;
+    for (int s = 0; s < a.nscales; ++s) {
+      const int k = a.k[s];
+      for (int oi = 0; oi < k; ++oi) {
+        int h0, h1;
+        bin_of(oi, k, a.H, h0, h1);
+        if (h < h0 || h >= h1) continue;
+        for (int oj = 0; oj < k; ++oj) {
+          int w0, w1;
+          bin_of(oj, k, a.W, w0, w1);
+          if (w < w0 || w >= w1) continue;
+          acc += to_f32(gp[(long long)(a.tok0[s] + oi * k + oj) * a.out_ld]) / (float)((h1 - h0) * (w1 - w0));
+        }
+      }
+    }
+    ((T*)const_cast<void*>(a.in))[(long long)n * a.in_bs + ((long long)h * a.W + w) * a.in_ld + c] = from_f32<T>(acc);
+  }
+}
+
+// ---- max pooling (k x k, stride, pad; -inf padding; first maximum wins, as torch/paddle) ----
+struct MaxPoolArgs {
+  const void* in; void* out; const void* dout; void* din;
+  int N, H, W, C, OH, OW, k, stride, pad;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxPoolArgs a) {
+  const long long total = (long long)a.N * a.OH * a.OW * a.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % a.C);
+    long long r = idx / a.C;
+    const int ow = (int)(r % a.OW); r /= a.OW;
+    const int oh = (int)(r % a.OH);
+    const int n = (int)(r / a.OH);
+    float best = -INFINITY;
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int h = oh * a.stride - a.pad + kh;
+      if ((unsigned)h >= (unsigned)a.H) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int w = ow * a.stride - a.pad + kw;
+        if ((unsigned)w >= (unsigned)a.W) continue;
+        const float v = to_f32(((const T*)a.in)[(((long long)n * a.H + h) * a.W + w) * a.C + c]);
+        if (v > best || v != v) best = v;
+      }
+    }
+    ((T*)a.out)[idx] = from_f32<T>(best);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
+  const long long total = (long long)a.N * a.H * a.W * a.C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % a.C);
+    long long r = idx / a.C;
+    const int w = (int)(r % a.W); r /= a.W;
+    const int h = (int)(r % a.H);
+    const int n = (int)(r / a.H);
+    float acc = 0.f;
+    // output windows that contain (h, w): oh in [ceil((h+pad-k+1)/s), floor((h+pad)/s)]
+    int oh_lo = (h + a.pad - a.k + 1 + a.stride - 1);
+    oh_lo = oh_lo > 0 ? oh_lo / a.stride : 0;
+    int oh_hi = (h + a.pad) / a.stride;
+    if (oh_hi > a.OH - 1) oh_hi = a.OH - 1;
+    int ow_lo = (w + a.pad - a.k + 1 + a.stride - 1);
+    ow_lo = ow_lo > 0 ? ow_lo / a.stride : 0;
+    int ow_hi = (w + a.pad) / a.stride;
+    if (ow_hi > a.OW - 1) ow_hi = a.OW - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        float best = -INFINITY;
+        int bh = -1, bw = -1;
+        for (int kh = 0; kh < a.k; ++kh) {
+          const int hh = oh * a.stride - a.pad + kh;
+          if ((unsigned)hh >= (unsigned)a.H) continue;
+          for (int kw = 0; kw < a.k; ++kw) {
+            const int ww = ow * a.stride - a.pad + kw;
+            if ((unsigned)ww >= (unsigned)a.W) continue;
+            const float v = to_f32(((const T*)a.in)[(((long long)n * a.H + hh) * a.W + ww) * a.C + c]);
+            if (v > best || v != v) { best = v; bh = hh; bw = ww; }
+          }
+        }
+        if (bh == h && bw == w) acc += to_f32(((const T*)a.dout)[(((long long)n * a.OH + oh) * a.OW + ow) * a.C + c]);
+      }
+    ((T*)a.din)[idx] = from_f32<T>(acc);
+  }
+}
+
+// fp32 NCHW images -> T NHWC
+template <class T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, int H, int W) {
+  const long long total = (long long)N * H * W * C;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long long r = idx / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    out[idx] = from_f32<T>(in[(((long long)n * C + c) * H + h) * W + w]);
+  }
+}
+
+static inline int ew_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define DT2(dtype, KERNEL, GRID, ...)                                                                 \
+  do {                                                                                                \
+    if ((dtype) == EMRT_F32) hipLaunchKernelGGL((KERNEL<float>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<bf16_t>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);              \
+  } while (0)
+
+extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs,
+                                        int out_ld, int OH, int OW, const void* add, long long add_bs, int add_ld, int N, int C,
+                                        int align_corners, int out_nchw_f32, int dtype, void* stream) {
+  EMRT_REQUIRE(in && out, "null pointer");
+  EMRT_REQUIRE(N > 0 && C > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "bad dims");
+  EMRT_REQUIRE(!(out_nchw_f32 && add), "addend not supported with NCHW output");
+  ResizeArgs a;
+  a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.IH = IH; a.IW = IW;
+  a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.OH = OH; a.OW = OW;
+  a.add = add; a.add_bs = add_bs; a.add_ld = add_ld; a.N = N; a.C = C;
+  a.ay = make_axis(IH, OH, align_corners); a.ax = make_axis(IW, OW, align_corners); a.out_nchw_f32 = out_nchw_f32;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_nchw_f32) {
+    const int grid = ew_grid((long long)N * C * OH * OW);
+    DT2(dtype, resize_fwd_nchw_kernel, grid, a);
+    return check_launch("emrt_resize_bilinear_fwd");
+  }
+  const bool v4 = C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && in_bs % 4 == 0 && out_bs % 4 == 0 &&
+                  (!add || (add_ld % 4 == 0 && add_bs % 4 == 0)) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                  (!add || (uintptr_t)add % 16 == 0);
+  if (v4) {
+    const int grid = ew_grid((long long)N * OH * OW * (C / 4));
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    const int grid = ew_grid((long long)N * OH * OW * C);
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_kernel<float, 1>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, a);
+  }
+  return check_launch("emrt_resize_bilinear_fwd");
+}
+
+extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs,
+                                        int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, int dtype,
+                                        void* stream) {
+  EMRT_REQUIRE(dout && din, "null pointer");
+  ResizeBwdArgs a;
+  a.dout = dout; a.do_bs = do_bs; a.do_ld = do_ld; a.OH = OH; a.OW = OW;
+  a.din = din; a.di_bs = di_bs; a.di_ld = di_ld; a.IH = IH; a.IW = IW; a.N = N; a.C = C;
+  a.ay = make_axis(IH, OH, align_corners); a.ax = make_axis(IW, OW, align_corners); a.dout_nchw_f32 = dout_nchw_f32;
+  hipStream_t st = (hipStream_t)stream;
+  const bool v4 = !dout_nchw_f32 && C % 4 == 0 && do_ld % 4 == 0 && di_ld % 4 == 0 && do_bs % 4 == 0 && di_bs % 4 == 0 &&
+                  ((uintptr_t)dout % 16 == 0) && ((uintptr_t)din % 16 == 0);
+  if (v4) {
+    const int grid = ew_grid((long long)N * IH * IW * (C / 4));
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    const int grid = ew_grid((long long)N * IH * IW * C);
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_kernel<float, 1>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, a);
+  }
+  return check_launch("emrt_resize_bilinear_bwd");
+}
+
+static int fill_pool(PoolArgs& a, const int* scales, int nscales) {
+  if (nscales < 1 || nscales > 4) return -1;
+  int tok = 0;
+  for (int s = 0; s < 4; ++s) { a.k[s] = 1; a.tok0[s] = 0; }
+  for (int s = 0; s < nscales; ++s) { a.k[s] = scales[s]; a.tok0[s] = tok; tok += scales[s] * scales[s]; }
+  a.ntok = tok;
+  a.nscales = nscales;
+  return 0;
+}
+
+// out tokens [N][sum k^2][C] (row stride out_ld, batch stride out_bs)
+extern "C" int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs,
+                                         int out_ld, int N, int C, const int* scales /*host*/, int nscales, int dtype, void* stream) {
+  EMRT_REQUIRE(in && out && scales, "null pointer");
+  PoolArgs a;
+  a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.N = N; a.C = C;
+  EMRT_REQUIRE(fill_pool(a, scales, nscales) == 0, "1..4 scales supported");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid((long long)N * a.ntok * C);
+  DT2(dtype, adaptive_pool_fwd_kernel, grid, a);
+  return check_launch("emrt_adaptive_avgpool_fwd");
+}
+
+extern "C" int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void* din, long long di_bs, int di_ld, int H,
+                                         int W, int N, int C, const int* scales, int nscales, int dtype, void* stream) {
+  EMRT_REQUIRE(dout && din && scales, "null pointer");
+  PoolArgs a;
+  a.in = din; a.in_bs = di_bs; a.in_ld = di_ld; a.H = H; a.W = W; a.out = const_cast<void*>(dout); a.out_bs = do_bs; a.out_ld = do_ld;
+  a.N = N; a.C = C;
+  EMRT_REQUIRE(fill_pool(a, scales, nscales) == 0, "1..4 scales supported");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid((long long)N * H * W * C);
+  DT2(dtype, adaptive_pool_bwd_kernel, grid, a);
+  return check_launch("emrt_adaptive_avgpool_bwd");
+}
+
+extern "C" int emrt_maxpool_fwd(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream) {
+  EMRT_REQUIRE(in && out, "null pointer");
+  MaxPoolArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.out = out; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.pad = pad;
+  a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid((long long)N * a.OH * a.OW * C);
+  DT2(dtype, maxpool_fwd_kernel, grid, a);
+  return check_launch("emrt_maxpool_fwd");
+}
+
+extern "C" int emrt_maxpool_bwd(const void* in, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad,
+                                int dtype, void* stream) {
+  EMRT_REQUIRE(in && dout && din, "null pointer");
+  MaxPoolArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.dout = dout; a.din = din; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.pad = pad;
+  a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid((long long)N * H * W * C);
+  DT2(dtype, maxpool_bwd_kernel, grid, a);
+  return check_launch("emrt_maxpool_bwd");
+}
+
+extern "C" int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream) {
+  EMRT_REQUIRE(in && out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid((long long)N * C * H * W);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, in, (float*)out, N, C, H, W);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W);
+  return check_launch("emrt_nchw_to_nhwc");
+}

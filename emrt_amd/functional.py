@@ -1,0 +1,701 @@
+"""Functional ops of the EMRT HIP path: each launches libemrt_hip.so kernels through the C-ABI and, when a tape is
+recording, appends the closure that runs the matching backward kernels.  No torch compute op is used anywhere here
+(torch only allocates memory and supplies the stream); if the HIP library is missing every op raises.
+
+Tensor conventions: feature maps are [N, H, W, C] (NHWC) views with stride(-1) == 1 and dense rows
+(stride(1) == W * stride(2)); token tensors are [B, L, C].  Views into larger buffers (level slabs of the token
+tensor, channel slices of the concat buffer) are first-class: kernels take the pixel stride `ld` and batch stride `bs`.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from .runtime import ctx, F32, BF16
+
+
+def _L():
+    return _lib.lib()
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _check_map(t):
+    """(N, H, W, C, ld, bs) of an NHWC map view; [B, L, C] tokens count as [B, 1, L, C], [M, C] as [1, 1, M, C]."""
+    assert t.stride(-1) == 1, "inner stride must be 1: %s %s" % (tuple(t.shape), t.stride())
+    if t.dim() == 4:
+        assert t.stride(1) == t.shape[2] * t.stride(2), \
+            "expected an NHWC view with dense rows, got shape %s strides %s" % (tuple(t.shape), t.stride())
+        return t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.stride(2), t.stride(0)
+    if t.dim() == 3:
+        return t.shape[0], 1, t.shape[1], t.shape[2], t.stride(1), t.stride(0)
+    assert t.dim() == 2
+    return 1, 1, t.shape[0], t.shape[1], t.stride(0), t.shape[0] * t.stride(0)
+
+
+def _like_shape(t, C):
+    """Dense output shape with the leading dims of t and C channels."""
+    return tuple(t.shape[:-1]) + (C,)
+
+
+def _rows(t):
+    """[..., C] tensor whose leading dims collapse to dense rows -> (rows, C, ld)."""
+    C = t.shape[-1]
+    assert t.stride(-1) == 1
+    ld = t.stride(-2) if t.dim() >= 2 else C
+    rows = t.numel() // C
+    for d in range(t.dim() - 2):
+        assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "rows are not uniformly strided: %s %s" % (tuple(t.shape), t.stride())
+    return rows, C, ld
+
+
+def tokens_as_map(t, h, w):
+    """[B, h*w, C] token slab view -> [B, h, w, C] map view (no copy)."""
+    B, n, C = t.shape
+    assert n == h * w
+    v = t.as_strided((B, h, w, C), (t.stride(0), w * t.stride(1), t.stride(1), 1), t.storage_offset())
+    tape = ctx().tape
+    if tape is not None:
+        tape.register_alias(v, t, lambda g: g.as_strided((B, h, w, C), (g.stride(0), w * g.stride(1), g.stride(1), 1), g.storage_offset()))
+    return v
+
+
+def map_as_tokens(t):
+    """[B, h, w, C] map view -> [B, h*w, C] tokens view (no copy)."""
+    B, h, w, C = t.shape
+    assert t.stride(1) == w * t.stride(2)
+    v = t.as_strided((B, h * w, C), (t.stride(0), t.stride(2), 1), t.storage_offset())
+    tape = ctx().tape
+    if tape is not None:
+        tape.register_alias(v, t, lambda g: g.as_strided((B, h * w, C), (g.stride(0), g.stride(2), 1), g.storage_offset()))
+    return v
+
+
+def view_as(t, shape):
+    """Contiguous reshape view registered as an alias of t."""
+    v = t.view(shape)
+    tape = ctx().tape
+    if tape is not None:
+        tape.register_alias(v, t, lambda g: g.view(shape))
+    return v
+
+
+def param_input(p_data, p_grad):
+    """A fp32 parameter used as an activation: returns it in the compute dtype; its gradient flows back into p_grad."""
+    c = ctx()
+    t = cast_from_f32(p_data)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(t)
+            if g is not None:
+                add_into(p_grad, cast_to_f32(g))
+        tape.record(bwd)
+    return t
+
+
+def narrow(t, dim, start, length):
+    """View t.narrow(dim, start, length), registered on the tape as an alias of t."""
+    v = t.narrow(dim, start, length)
+    tape = ctx().tape
+    if tape is not None:
+        tape.register_alias(v, t, lambda g: g.narrow(dim, start, length))
+    return v
+
+
+# ---------------------------------------------------------------------------------------------------
+# elementwise helpers
+# ---------------------------------------------------------------------------------------------------
+def add_into(dst, src):
+    """dst += src (both may be strided 'rows x cols' views with a unit inner stride)."""
+    c = ctx()
+    assert dst.shape == src.shape and dst.dtype == src.dtype, (dst.shape, src.shape, dst.dtype, src.dtype)
+    dt = F32 if dst.dtype == torch.float32 else BF16
+    rd, cd, sd = _rows2d(dst)
+    rs, cs, ss = _rows2d(src)
+    cols = min(cd, cs)
+    n = dst.numel()
+    assert n % cols == 0 and cd % cols == 0 and cs % cols == 0
+    if cd != cols:
+        assert rd == 1, "incompatible row structure"
+        sd = cols
+    if cs != cols:
+        assert rs == 1, "incompatible row structure"
+        ss = cols
+    _L().call("emrt_acc2d", P(dst), sd, P(src), ss, n // cols, cols, dt, c.stream)
+
+
+def add(a, b, period=None, bgrad=None):
+    """out = a + b with b broadcast with period `period` elements (None: same shape).
+    bgrad(g): optional callback that reduces the gradient of the broadcast operand (parameters / embeddings)."""
+    c = ctx()
+    assert a.is_contiguous() and b.is_contiguous()
+    out = c.empty(tuple(a.shape), a.dtype)
+    n = a.numel()
+    per = n if period is None else period
+    dt = F32 if a.dtype == torch.float32 else BF16
+    _L().call("emrt_add", P(a), P(b), P(out), n, per, dt, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(out)
+            if g is None:
+                return
+            if bgrad is not None:
+                bgrad(g)
+            if period is None:
+                tape.add_grad(b, g)
+            tape.add_grad(a, g)
+        tape.record(bwd)
+    return out
+
+
+def _rows2d(t):
+    """(rows, cols, row_stride) of a view that is a set of dense rows (token slab / channel slice / dense tensor)."""
+    cols, k, expect = 1, t.dim(), 1
+    while k > 0 and t.stride(k - 1) == expect:
+        expect *= t.shape[k - 1]
+        cols = expect
+        k -= 1
+    if k == 0:
+        return 1, cols, cols
+    for d in range(k - 1):
+        assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "cannot collapse view %s %s" % (tuple(t.shape), t.stride())
+    rows = 1
+    for d in range(k):
+        rows *= t.shape[d]
+    return rows, cols, t.stride(k - 1)
+
+
+def add_maps(a, b):
+    """out (dense) = a + b where a, b may be strided views of equal shape (e.g. residual = level slab of `memory`)."""
+    c = ctx()
+    assert a.shape == b.shape and a.dtype == b.dtype
+    out = c.empty(tuple(a.shape), a.dtype)
+    ra, ca, sa = _rows2d(a)
+    rb, cb, sb = _rows2d(b)
+    cols = min(ca, cb)
+    n = a.numel()
+    assert n % cols == 0 and ca % cols == 0 and cb % cols == 0
+    rows = n // cols
+    # a view with longer dense runs than `cols` is still addressable with row stride == cols when it is fully dense
+    if ca != cols:
+        assert ra == 1, "incompatible row structure"
+        sa = cols
+    if cb != cols:
+        assert rb == 1, "incompatible row structure"
+        sb = cols
+    dt = F32 if a.dtype == torch.float32 else BF16
+    _L().call("emrt_add2d", P(a), sa, P(b), sb, P(out), cols, rows, cols, dt, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(out)
+            if g is None:
+                return
+            tape.add_grad(a, g)
+            tape.add_grad(b, g)
+        tape.record(bwd)
+    return out
+
+
+def concat_tokens(parts):
+    """[B, n_i, C] dense parts -> dense [B, sum n_i, C]."""
+    c = ctx()
+    B, C = parts[0].shape[0], parts[0].shape[2]
+    total = sum(p_.shape[1] for p_ in parts)
+    out = c.zeros((B, total, C), parts[0].dtype)
+    start = 0
+    spans = []
+    for p_ in parts:
+        n = p_.shape[1]
+        add_into(out.narrow(1, start, n), p_)
+        spans.append((start, n))
+        start += n
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(out)
+            if g is None:
+                return
+            for p_, (s0, n) in zip(parts, spans):
+                gp = c.zeros(tuple(p_.shape), p_.dtype)
+                add_into(gp, g.narrow(1, s0, n))
+                tape.add_grad(p_, gp)
+        tape.record(bwd)
+    return out
+
+
+def cast_from_f32(x):
+    c = ctx()
+    if c.dtype == F32:
+        return x
+    out = c.empty(tuple(x.shape))
+    _L().call("emrt_cast", P(x), P(out), x.numel(), 0, c.dtype, c.stream)
+    return out
+
+
+def cast_to_f32(x):
+    c = ctx()
+    if x.dtype == torch.float32:
+        return x
+    out = c.empty(tuple(x.shape), torch.float32)
+    _L().call("emrt_cast", P(x), P(out), x.numel(), 1, c.dtype, c.stream)
+    return out
+
+
+def dropout(x, p, salt, mode=0, hw=1):
+    """Inverted dropout (mode 0) / Dropout2D on NHWC (mode 1); identity unless training."""
+    c = ctx()
+    if not c.training or p <= 0.0:
+        return x
+    assert x.is_contiguous()
+    y = c.empty(tuple(x.shape), x.dtype)
+    C = x.shape[-1]
+    _L().call("emrt_dropout_fwd", P(x), P(y), x.numel(), float(p), c.seed_ptr, salt, mode, hw, C, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is None:
+                return
+            assert g.is_contiguous()
+            dx = c.empty(tuple(x.shape), x.dtype)
+            _L().call("emrt_mask_bwd", P(g), None, P(dx), x.numel(), float(p), c.seed_ptr, salt, mode, hw, C, c.dtype, c.stream)
+            tape.add_grad(x, dx)
+        tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution / linear
+# ---------------------------------------------------------------------------------------------------
+class GemmWeight:
+    """A [OC][KH][KW][C] GEMM weight living in the flat parameter store: fp32 master / grad views plus the packed
+    forward and (transposed) dgrad copies in the compute dtype."""
+
+    def __init__(self, OC, C, KH=1, KW=1):
+        self.OC, self.C, self.KH, self.KW = OC, C, KH, KW
+        self.fwd_ptr = None     # int device address of packed [OC][KH][KW][C]
+        self.bwd_ptr = None     # int device address of packed [C][KH][KW][OC]
+        self.grad = None        # fp32 tensor view [OC*KH*KW*C]
+        self.bias = None        # fp32 tensor view [OC] or None
+        self.bias_grad = None
+        self.need_bwd = True
+
+
+def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True):
+    """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice)."""
+    c = ctx()
+    N, H, W, C, ldin, in_bs = _check_map(x)
+    assert C == w.C, (C, w.C)
+    OH = (H + 2 * pad - w.KH) // stride + 1
+    OW = (W + 2 * pad - w.KW) // stride + 1
+    if out is None:
+        oshape = (N, OH, OW, w.OC) if x.dim() == 4 else _like_shape(x, w.OC)
+        out = c.empty(oshape, torch.float32 if out_f32 else None)
+    _, oh_, ow_, oc_, ldout, out_bs = _check_map(out)
+    assert (oh_, ow_, oc_) == (OH, OW, w.OC), ((oh_, ow_, oc_), (OH, OW, w.OC))
+    ldres = res_bs = 0
+    if residual is not None:
+        _, _, _, _, ldres, res_bs = _check_map(residual)
+    _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
+              OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            if out_f32:
+                dy = cast_from_f32(dy)
+            if relu:
+                assert dy.is_contiguous() and out.is_contiguous()
+                dm = c.empty(tuple(dy.shape), dy.dtype)
+                _L().call("emrt_mask_bwd", P(dy), P(out), P(dm), dy.numel(), 0.0, None, 0, 0, 1, 1, c.dtype, c.stream)
+                dy = dm
+            _, _, _, _, lddy, dy_bs = _check_map(dy)
+            _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
+                      w.KH, w.KW, stride, pad, c.dtype, c.stream)
+            if w.bias is not None:
+                colsum_acc(dy, w.bias_grad)
+            if residual is not None:
+                tape.add_grad(residual, dy)
+            if need_dx:
+                dx = c.empty(tuple(x.shape))
+                _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
+                          H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, c.dtype, c.stream)
+                tape.add_grad(x, dx)
+        tape.record(bwd)
+    return out
+
+
+def linear(x, w, relu=False, out_f32=False, need_dx=True):
+    """x [B, L, C] or [M, C] (strided rows allowed) -> [..., OC]: a 1x1 convolution over the row axis."""
+    return conv2d(x, w, 1, 0, relu=relu, out_f32=out_f32, need_dx=need_dx)
+
+
+def colsum_acc(x, dst_f32):
+    """dst[c] += sum over all rows of x[..., c]  (bias / embedding-row gradients)."""
+    c = ctx()
+    N, H, W, C, ld, bs = _check_map(x)
+    assert dst_f32.dtype == torch.float32 and dst_f32.is_contiguous() and dst_f32.numel() == C
+    dt = F32 if x.dtype == torch.float32 else BF16
+    ws = c.workspace(_L().query("emrt_colreduce_workspace_bytes", N * H * W, C))
+    _L().call("emrt_colsum_acc", P(x), ld, H * W, bs, N * H * W, C, P(dst_f32), P(ws), dt, c.stream)
+
+
+# ---------------------------------------------------------------------------------------------------
+# normalisation
+# ---------------------------------------------------------------------------------------------------
+class BNState:
+    """Parameter/buffer views for one BatchNorm layer (all fp32)."""
+
+    def __init__(self, C, eps=1e-5, momentum=0.9, sync=False):
+        self.C, self.eps, self.momentum, self.sync = C, eps, momentum, sync
+        self.gamma = self.beta = self.dgamma = self.dbeta = self.run_mean = self.run_var = None
+
+
+def _allreduce_sums(sums, count):
+    """SyncBatchNorm: sum the per-rank (sum, sumsq) vectors and the row count over ranks (RCCL all-reduce)."""
+    import torch.distributed as dist
+    dist.all_reduce(sums)
+    return count * dist.get_world_size()
+
+
+def batch_norm(x, bn, relu=False, residual=None, out=None):
+    """y = [relu](BN(x) [+ residual]); training uses batch statistics (all-reduced over ranks when bn.sync)."""
+    c = ctx()
+    N, H, W, C, ldx, x_bs = _check_map(x)
+    assert x_bs == H * W * ldx, "batch_norm input must be a dense NHWC tensor (possibly channel-sliced)"
+    M = N * H * W
+    if out is None:
+        out = c.empty(tuple(x.shape))
+    _, _, _, _, ldy, y_bs = _check_map(out)
+    assert y_bs == H * W * ldy
+    ldres = 0
+    if residual is not None:
+        _, _, _, _, ldres, r_bs = _check_map(residual)
+        assert r_bs == H * W * ldres
+    mean = c.empty((C,), torch.float32)
+    invstd = c.empty((C,), torch.float32)
+    count = M
+    if c.training:
+        sums = c.empty((2 * C,), torch.float32)
+        ws = c.workspace(_L().query("emrt_colreduce_workspace_bytes", M, C))
+        _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), P(ws), c.dtype, c.stream)
+        if bn.sync and c.world_size > 1 and c.sync_bn:
+            count = _allreduce_sums(sums, M)
+        _L().call("emrt_bn_finalize", P(sums), float(count), C, bn.eps, bn.momentum, P(mean), P(invstd), P(bn.run_mean), P(bn.run_var), c.stream)
+    else:
+        _L().call("emrt_bn_eval_stats", P(bn.run_mean), P(bn.run_var), C, bn.eps, P(mean), P(invstd), c.stream)
+    _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(mean), P(invstd), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        assert c.training, "backward through eval-mode BatchNorm is not supported"
+
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            _, _, _, _, lddy, dy_bs = _check_map(dy)
+            assert dy_bs == H * W * lddy
+            sums2 = c.empty((2 * C,), torch.float32)
+            ws2 = c.workspace(_L().query("emrt_colreduce_workspace_bytes", M, C))
+            yv = out if relu else None
+            _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), P(ws2), c.dtype, c.stream)
+            # dgamma/dbeta use the LOCAL sums (the gradient all-reduce combines ranks); dx needs the GLOBAL sums
+            synced = bn.sync and c.world_size > 1 and c.sync_bn
+            if synced:
+                local = c.empty((2 * C,), torch.float32)
+                _L().call("emrt_cast", P(sums2), P(local), 2 * C, 0, F32, c.stream)
+                _allreduce_sums(sums2, M)
+            dx = c.empty(tuple(x.shape))
+            dres = c.empty(tuple(x.shape)) if (residual is not None and relu) else None
+            _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
+                      P(sums2), 1.0 / count, None if synced else P(bn.dgamma), None if synced else P(bn.dbeta), M, C, c.dtype, c.stream)
+            if synced:
+                add_into(bn.dbeta, local[:C])
+                add_into(bn.dgamma, local[C:])
+            tape.add_grad(x, dx)
+            if residual is not None:
+                tape.add_grad(residual, dres if dres is not None else dy)
+        tape.record(bwd)
+    return out
+
+
+def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residual=None, out=None):
+    """out = [gelu](GN(x)) [+ residual];  x [N,H,W,C] view."""
+    c = ctx()
+    N, H, W, C, ldx, x_bs = _check_map(x)
+    if out is None:
+        out = c.empty(tuple(x.shape))
+    _, _, _, _, ldo, o_bs = _check_map(out)
+    ldr = r_bs = 0
+    if residual is not None:
+        _, _, _, _, ldr, r_bs = _check_map(residual)
+    mean = c.empty((N * G,), torch.float32)
+    rstd = c.empty((N * G,), torch.float32)
+    _L().call("emrt_groupnorm_fwd", P(x), ldx, x_bs, P(residual), ldr, r_bs, P(out), ldo, o_bs, P(gamma), P(beta), P(mean), P(rstd),
+              N, H * W, C, G, eps, int(gelu), c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            _, _, _, _, lddy, dy_bs = _check_map(dy)
+            dx = c.empty(tuple(x.shape))
+            _L().call("emrt_groupnorm_bwd", P(x), ldx, x_bs, P(dy), lddy, dy_bs, P(dx), C, H * W * C, P(gamma), P(beta), P(mean), P(rstd),
+                      P(dgamma), P(dbeta), N, H * W, C, G, int(gelu), c.dtype, c.stream)
+            tape.add_grad(x, dx)
+            if residual is not None:
+                tape.add_grad(residual, dy)
+        tape.record(bwd)
+    return out
+
+
+def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5):
+    """out = LN(a + b) * gamma + beta (+ post);  a, b, post contiguous [.., C]."""
+    c = ctx()
+    assert a.is_contiguous() and (b is None or b.is_contiguous()) and (post is None or post.is_contiguous())
+    C = a.shape[-1]
+    rows = a.numel() // C
+    out = c.empty(tuple(a.shape))
+    keep = c.tape is not None
+    z = c.empty(tuple(a.shape)) if (keep and b is not None) else None
+    mean = c.empty((rows,), torch.float32) if keep else None
+    rstd = c.empty((rows,), torch.float32) if keep else None
+    _L().call("emrt_layernorm_fwd", P(a), P(b), P(post), P(z), P(out), P(gamma), P(beta), P(mean), P(rstd), rows, C, eps, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        zz = z if z is not None else a
+
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            assert dy.is_contiguous()
+            dz = c.empty(tuple(a.shape))
+            ws = c.workspace(_L().query("emrt_layernorm_bwd_workspace_bytes", rows, C))
+            _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), c.dtype, c.stream)
+            tape.add_grad(a, dz)
+            if b is not None:
+                tape.add_grad(b, dz)
+            if post is not None:
+                tape.add_grad(post, dy)
+        tape.record(bwd)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
+    """value [B,Lv,M*32] (T), offw fp32 [B,Lq,ldo], ref fp32 [B or 1, Lq, L, 2] -> [B,Lq,M*32] (T)."""
+    c = ctx()
+    B, Lv, CC = value.shape
+    M, L, Pn = n_heads, len(shapes), n_points
+    assert CC == M * 32 and value.stride(2) == 1
+    Lq, ldo = offw.shape[1], offw.shape[2]
+    assert offw.is_contiguous() and offw.dtype == torch.float32 and ref.dtype == torch.float32 and ref.is_contiguous()
+    ref_L = ref.shape[2]
+    assert ref.shape[1] == Lq and ref_L in (1, L) and ref.shape[3] == 2
+    ref_bs = 0 if ref.shape[0] == 1 else Lq * ref_L * 2
+    arr = (ctypes.c_int * (2 * L))(*[int(v) for hw in shapes for v in hw])
+    out = c.empty((B, Lq, CC))
+    _L().call("emrt_msda_fwd", P(value), value.stride(1), value.stride(0), P(offw), ldo, P(ref), ref_bs, ref_L, P(out), B, Lq, Lv, M, 32, L, Pn,
+              ctypes.cast(arr, ctypes.c_void_p), c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            assert dy.is_contiguous()
+            dvalue = c.zeros((B, Lv, CC), torch.float32)
+            doffw = c.zeros((B, Lq, ldo), torch.float32) if ldo != M * L * Pn * 3 else c.empty((B, Lq, ldo), torch.float32)
+            dref = c.empty((B, Lq, ref_L, 2), torch.float32) if need_dref else None
+            _L().call("emrt_msda_bwd", P(value), value.stride(1), value.stride(0), P(offw), ldo, P(ref), ref_bs, ref_L, P(dy), P(dvalue), P(doffw),
+                      P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), c.dtype, c.stream)
+            tape.add_grad(value, cast_from_f32(dvalue))
+            tape.add_grad(offw, doffw)
+            if need_dref:
+                if ref.shape[0] == 1 and B > 1:   # reference points shared by the batch: reduce over b
+                    red = c.zeros((1, Lq, ref_L, 2), torch.float32)
+                    colsum_acc(dref.view(B, Lq * ref_L * 2), red.view(-1))
+                    dref = red
+                tape.add_grad(ref, dref)
+        tape.record(bwd)
+    return out
+
+
+def mha(qk, v, n_heads, pdrop, salt):
+    """qk [B,L,2E] (q | k), v [B,L,E] -> [B,L,E]; softmax(q k^T / sqrt(d)) v with dropout on the weights."""
+    c = ctx()
+    B, L, E2 = qk.shape
+    E = E2 // 2
+    assert qk.is_contiguous() and v.is_contiguous() and E == n_heads * 32
+    out = c.empty((B, L, E))
+    probs = c.empty((B, n_heads, L, L), torch.float32)
+    p = float(pdrop) if c.training else 0.0
+    scale = 1.0 / math.sqrt(32.0)
+    q_ptr = qk.data_ptr()
+    k_ptr = qk.data_ptr() + E * qk.element_size()
+    _L().call("emrt_mha_fwd", ctypes.c_void_p(q_ptr), E2, ctypes.c_void_p(k_ptr), E2, P(v), E, P(out), E, P(probs), B, n_heads, L, 32, scale, p,
+              c.seed_ptr, salt, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            assert dy.is_contiguous()
+            dqk = c.empty((B, L, E2))
+            dv = c.empty((B, L, E))
+            _L().call("emrt_mha_bwd", ctypes.c_void_p(q_ptr), E2, ctypes.c_void_p(k_ptr), E2, P(v), E, P(probs), P(dy), E,
+                      ctypes.c_void_p(dqk.data_ptr()), E2, ctypes.c_void_p(dqk.data_ptr() + E * dqk.element_size()), E2, P(dv), E,
+                      B, n_heads, L, 32, scale, p, c.seed_ptr, salt, c.dtype, c.stream)
+            tape.add_grad(qk, dqk)
+            tape.add_grad(v, dv)
+        tape.record(bwd)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# spatial ops
+# ---------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(img):
+    c = ctx()
+    N, C, H, W = img.shape
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    out = c.empty((N, H, W, C))
+    _L().call("emrt_nchw_to_nhwc", P(img), P(out), N, C, H, W, c.dtype, c.stream)
+    return out
+
+
+def resize_bilinear(x, OH, OW, align_corners, add_t=None, out=None, out_nchw_f32=False):
+    """x [N,IH,IW,C] view -> [N,OH,OW,C] (or fp32 [N,C,OH,OW] when out_nchw_f32), optional fused '+ add_t'."""
+    c = ctx()
+    N, IH, IW, C, in_ld, in_bs = _check_map(x)
+    if out_nchw_f32:
+        assert out is None and add_t is None
+        out = c.empty((N, C, OH, OW), torch.float32)
+        out_ld, out_bs = 0, 0
+    else:
+        if out is None:
+            out = c.empty((N, OH, OW, C))
+        _, _, _, _, out_ld, out_bs = _check_map(out)
+    add_ld = add_bs = 0
+    if add_t is not None:
+        _, _, _, _, add_ld, add_bs = _check_map(add_t)
+    _L().call("emrt_resize_bilinear_fwd", P(x), in_bs, in_ld, IH, IW, P(out), out_bs, out_ld, OH, OW, P(add_t), add_bs, add_ld, N, C,
+              int(align_corners), int(out_nchw_f32), c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            dx = c.empty((N, IH, IW, C))
+            if out_nchw_f32:
+                assert dy.is_contiguous() and dy.dtype == torch.float32
+                do_bs, do_ld = 0, 0
+            else:
+                _, _, _, _, do_ld, do_bs = _check_map(dy)
+            _L().call("emrt_resize_bilinear_bwd", P(dy), do_bs, do_ld, OH, OW, P(dx), IH * IW * C, C, IH, IW, N, C, int(align_corners),
+                      int(out_nchw_f32), c.dtype, c.stream)
+            tape.add_grad(x, dx)
+            if add_t is not None:
+                tape.add_grad(add_t, dy)
+        tape.record(bwd)
+    return out
+
+
+def adaptive_avgpool_tokens(x, scales):
+    """x [N,H,W,C] view -> tokens [N, sum k^2, C] (all pyramid scales in one launch)."""
+    c = ctx()
+    N, H, W, C, in_ld, in_bs = _check_map(x)
+    ntok = sum(k * k for k in scales)
+    out = c.empty((N, ntok, C))
+    arr = (ctypes.c_int * len(scales))(*scales)
+    _L().call("emrt_adaptive_avgpool_fwd", P(x), in_bs, in_ld, H, W, P(out), ntok * C, C, N, C, ctypes.cast(arr, ctypes.c_void_p), len(scales),
+              c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            assert dy.is_contiguous()
+            dx = c.empty((N, H, W, C))
+            _L().call("emrt_adaptive_avgpool_bwd", P(dy), ntok * C, C, P(dx), H * W * C, C, H, W, N, C, ctypes.cast(arr, ctypes.c_void_p),
+                      len(scales), c.dtype, c.stream)
+            tape.add_grad(x, dx)
+        tape.record(bwd)
+    return out
+
+
+def maxpool(x, k=3, stride=2, pad=1, need_dx=True):
+    c = ctx()
+    assert x.is_contiguous()
+    N, H, W, C = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = c.empty((N, OH, OW, C))
+    _L().call("emrt_maxpool_fwd", P(x), P(out), N, H, W, C, k, stride, pad, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None and need_dx:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            assert dy.is_contiguous()
+            dx = c.empty((N, H, W, C))
+            _L().call("emrt_maxpool_bwd", P(x), P(dy), P(dx), N, H, W, C, k, stride, pad, c.dtype, c.stream)
+            tape.add_grad(x, dx)
+        tape.record(bwd)
+    return out
+
+
+def sigmoid_f32(x):
+    c = ctx()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = c.empty(tuple(x.shape), torch.float32)
+    _L().call("emrt_sigmoid_fwd", P(x), P(y), x.numel(), c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dx = c.empty(tuple(x.shape), torch.float32)
+            _L().call("emrt_sigmoid_bwd", P(y), P(dy), P(dx), x.numel(), c.stream)
+            tape.add_grad(x, dx)
+        tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# loss
+# ---------------------------------------------------------------------------------------------------
+def softmax_ce(logits, labels, ignore_index, weight=1.0):
+    """Mean CE over non-ignored pixels of fp32 NCHW logits; returns a device float[2] = {loss, count}.
+    Backward writes weight * upstream * (softmax - onehot)/count as the gradient of `logits`."""
+    c = ctx()
+    N, C, H, W = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous()
+    res = c.empty((2,), torch.float32)
+    ws = c.workspace(_L().query("emrt_ce_workspace_bytes"))
+    _L().call("emrt_softmax_ce_fwd", P(logits), P(labels), N, C, H, W, ignore_index, P(res), P(ws), c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            up = tape.pop_grad(res)   # device scalar or None (== 1)
+            dl = c.empty((N, C, H, W), torch.float32)
+            _L().call("emrt_softmax_ce_bwd", P(logits), P(labels), P(res), P(up), float(weight), N, C, H, W, ignore_index, P(dl), c.stream)
+            tape.add_grad(logits, dl)
+        tape.record(bwd)
+    return res

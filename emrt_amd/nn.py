@@ -1,0 +1,261 @@
+"""Layer classes and the flat parameter store of the HIP path.
+
+Layers subclass torch.nn.Module only for parameter registration / naming / state_dict (keys mirror the reference,
+SURVEY.md Appendix A); their forward methods launch HIP kernels through emrt_amd.functional.
+
+ParamStore lays every parameter out in ONE flat fp32 device buffer (master), with twin flat buffers for gradients
+and momentum, so that gradient clipping, the SGD update and the RCCL gradient all-reduce each touch one contiguous
+range, and keeps the packed compute-dtype copies of all GEMM weights (forward layout [OC][KH][KW][C] and the
+transposed dgrad layout [C][KH][KW][OC]) that emrt_pack_weights refreshes once per optimizer step.
+Conv weights keep the reference's logical shape [OC, C, KH, KW] in the state dict but live in memory as OHWI.
+"""
+import ctypes
+
+import torch
+import torch.nn as tnn
+
+from . import _lib
+from . import functional as Fn
+from .runtime import ctx, F32, BF16
+
+
+def _align(n, a):
+    return (n + a - 1) // a * a
+
+
+class ParamStore:
+    def __init__(self, model, device, dtype, nograd_names=(), fused_groups=(), lr_mult_names=(), lr_mult=0.1):
+        self.dtype = dtype
+        self.device = device
+        named = list(model.named_parameters())
+        by_name = dict(named)
+        in_group = {}
+        for grp in fused_groups:
+            for n in grp:
+                in_group[n] = grp
+        order, seen = [], set()
+        for n, _ in named:
+            if n in seen or n in nograd_names:
+                continue
+            for m in in_group.get(n, [n]):
+                order.append(m)
+                seen.add(m)
+        self.n_trainable_names = len(order)
+        order += [n for n, _ in named if n in nograd_names]
+        self.offsets, off = {}, 0
+        fused_follow = {m for grp in fused_groups for m in grp[1:]}
+        self.n_train = 0
+        for i, n in enumerate(order):
+            p = by_name[n]
+            if n not in fused_follow:
+                off = _align(off, 4)
+            else:
+                assert off % 4 == 0, "fused parameter group member %s must start 16-byte aligned" % n
+            self.offsets[n] = off
+            off += p.numel()
+            if i == self.n_trainable_names - 1:
+                self.n_train = _align(off, 4)     # [0, n_train) is what clip / SGD / all-reduce cover
+        self.n_total = _align(off, 4)
+        self.master = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+        self.velocity = torch.zeros(self.n_total, dtype=torch.float32, device=device)
+        self.views = {}
+        for n in order:
+            p = by_name[n]
+            a, cnt = self.offsets[n], p.numel()
+            flat, gflat = self.master[a:a + cnt], self.grad[a:a + cnt]
+            if p.dim() == 4:    # conv weight: logical [OC,C,KH,KW], memory [OC][KH][KW][C]
+                OC, C, KH, KW = p.shape
+                view = flat.view(OC, KH, KW, C).permute(0, 3, 1, 2)
+                gview = gflat.view(OC, KH, KW, C).permute(0, 3, 1, 2)
+            else:
+                view, gview = flat.view(p.shape), gflat.view(p.shape)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+            p.grad = gview
+            p.requires_grad_(False)
+            self.views[n] = (a, cnt)
+        self.lr_ranges = [(self.offsets[n], self.offsets[n] + by_name[n].numel()) for n in lr_mult_names]
+        self.lr_mult = lr_mult
+        # buffers (BN running statistics): one flat fp32 buffer
+        bufs = [(n, b) for n, b in model.named_buffers()]
+        tot = sum(_align(b.numel(), 4) for _, b in bufs)
+        self.buffers = torch.zeros(max(tot, 4), dtype=torch.float32, device=device)
+        boff = 0
+        for n, b in bufs:
+            mod_name, _, bname = n.rpartition(".")
+            mod = model.get_submodule(mod_name) if mod_name else model
+            view = self.buffers[boff:boff + b.numel()].view(b.shape)
+            view.copy_(b.to(device=device, dtype=torch.float32))
+            mod._buffers[bname] = view
+            boff += _align(b.numel(), 4)
+        self.gemms = []
+        self.packed = None
+        self.desc = None
+        self.total_tiles = 0
+        self.dirty = True
+
+    # ---- GEMM weights ---------------------------------------------------------------------------
+    def make_gemm(self, offset, OC, C, KH=1, KW=1, bias_offset=None, need_bwd=True):
+        g = Fn.GemmWeight(OC, C, KH, KW)
+        g.offset = offset
+        g.need_bwd = need_bwd
+        cnt = OC * KH * KW * C
+        g.grad = self.grad[offset:offset + cnt]
+        if bias_offset is not None:
+            g.bias = self.master[bias_offset:bias_offset + OC]
+            g.bias_grad = self.grad[bias_offset:bias_offset + OC]
+        self.gemms.append(g)
+        return g
+
+    def finalize(self):
+        """Allocate the packed-weight buffer and the device descriptor table (after every layer registered its GEMMs)."""
+        esz = 4 if self.dtype == F32 else 2
+        off, rows, tiles = 0, [], 0
+        for g in self.gemms:
+            cnt = g.OC * g.KH * g.KW * g.C
+            fo = bo = -1
+            if self.dtype != F32:
+                fo = off
+                off = _align(off + cnt, 8)
+            if g.need_bwd:
+                bo = off
+                off = _align(off + cnt, 8)
+            g._fo, g._bo = fo, bo
+            if fo < 0 and bo < 0:
+                continue
+            rows.append([g.offset, fo, bo, g.OC, g.KH * g.KW, g.C, tiles, 0])
+            tiles += g.KH * g.KW * ((g.OC + 31) // 32) * ((g.C + 31) // 32)
+        self.packed = torch.zeros(max(off, 8), dtype=torch.float32 if self.dtype == F32 else torch.bfloat16, device=self.device)
+        base = self.packed.data_ptr()
+        for g in self.gemms:
+            g.fwd_ptr = self.master.data_ptr() + 4 * g.offset if g._fo < 0 else base + esz * g._fo
+            g.bwd_ptr = None if g._bo < 0 else base + esz * g._bo
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(self.device) if rows else None
+        self.ndesc, self.total_tiles = len(rows), tiles
+        self.dirty = True
+
+    def pack(self):
+        if self.desc is not None:
+            _lib.lib().call("emrt_pack_weights", Fn.P(self.master), Fn.P(self.packed), Fn.P(self.desc), self.ndesc, self.total_tiles,
+                            self.dtype, ctx().stream)
+        self.dirty = False
+
+    def zero_grad(self):
+        _lib.lib().call("emrt_memset", Fn.P(self.grad), 0, self.n_train * 4, ctx().stream)
+
+
+# ---------------------------------------------------------------------------------------------------
+# layers
+# ---------------------------------------------------------------------------------------------------
+class HipLayer(tnn.Module):
+    def bind(self, store, prefix):
+        """Create kernel-side views (GemmWeight / BNState ...) once parameters live in the flat store."""
+
+
+class Conv2D(HipLayer):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, need_dx=True):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.padding, self.need_dx = cin, cout, k, stride, padding, need_dx
+        self.weight = tnn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = tnn.Parameter(torch.zeros(cout)) if bias else None
+        self.gw = None
+
+    def bind(self, store, prefix):
+        self.gw = store.make_gemm(store.offsets[prefix + "weight"], self.cout, self.cin, self.k, self.k,
+                                  store.offsets[prefix + "bias"] if self.bias is not None else None, need_bwd=self.need_dx)
+
+    def forward(self, x, relu=False, residual=None, out=None, out_f32=False):
+        return Fn.conv2d(x, self.gw, self.stride, self.padding, relu=relu, residual=residual, out=out, out_f32=out_f32, need_dx=self.need_dx)
+
+
+class Linear(HipLayer):
+    """weight [out, in] (torch convention; the reference's Paddle layout is [in, out])."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.weight = tnn.Parameter(torch.empty(cout, cin))
+        self.bias = tnn.Parameter(torch.zeros(cout)) if bias else None
+        self.gw = None
+        self.standalone = True   # False when a parent fuses this weight into a wider GEMM
+
+    def bind(self, store, prefix):
+        if self.standalone:
+            self.gw = store.make_gemm(store.offsets[prefix + "weight"], self.cout, self.cin, 1, 1,
+                                      store.offsets[prefix + "bias"] if self.bias is not None else None)
+
+    def forward(self, x, relu=False, out_f32=False):
+        return Fn.linear(x, self.gw, relu=relu, out_f32=out_f32)
+
+
+class BatchNorm2D(HipLayer):
+    """Paddle-semantics BN (momentum 0.9 => running = 0.9*running + 0.1*batch; biased running variance); buffers keep
+    Paddle's names `_mean` / `_variance`.  sync=True marks the reference's nn.SyncBatchNorm layers."""
+
+    def __init__(self, c, sync=False):
+        super().__init__()
+        self.c = c
+        self.weight = tnn.Parameter(torch.ones(c))
+        self.bias = tnn.Parameter(torch.zeros(c))
+        self.register_buffer("_mean", torch.zeros(c))
+        self.register_buffer("_variance", torch.ones(c))
+        self.state = Fn.BNState(c, 1e-5, 0.9, sync)
+
+    def bind(self, store, prefix):
+        st = self.state
+        st.gamma, st.beta = self.weight.data.view(-1), self.bias.data.view(-1)
+        st.dgamma, st.dbeta = self.weight.grad.view(-1), self.bias.grad.view(-1)
+        st.run_mean, st.run_var = self._buffers["_mean"], self._buffers["_variance"]
+
+    def forward(self, x, relu=False, residual=None, out=None):
+        return Fn.batch_norm(x, self.state, relu=relu, residual=residual, out=out)
+
+
+class GroupNorm(HipLayer):
+    def __init__(self, groups, c):
+        super().__init__()
+        self.groups, self.c = groups, c
+        self.weight = tnn.Parameter(torch.ones(c))
+        self.bias = tnn.Parameter(torch.zeros(c))
+
+    def forward(self, x, gelu=False, residual=None, out=None):
+        return Fn.group_norm(x, self.weight.data, self.bias.data, self.weight.grad, self.bias.grad, self.groups, 1e-5,
+                             gelu=gelu, residual=residual, out=out)
+
+
+class LayerNorm(HipLayer):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = tnn.Parameter(torch.ones(c))
+        self.bias = tnn.Parameter(torch.zeros(c))
+
+    def forward(self, a, b=None, post=None):
+        return Fn.layer_norm(a, b, self.weight.data, self.bias.data, self.weight.grad, self.bias.grad, post=post)
+
+
+class Embedding(HipLayer):
+    def __init__(self, n, c):
+        super().__init__()
+        self.weight = tnn.Parameter(torch.empty(n, c))
+
+
+class Sequential(HipLayer):
+    """Index-named container (keys '0', '1', ... as paddle.nn.Sequential); entries may be None placeholders for the
+    parameter-free layers of the reference (ReLU, pooling, dropout) so that state-dict indices line up."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            if m is not None:
+                self.add_module(str(i), m)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+def bind_all(model, store):
+    for name, mod in model.named_modules():
+        if isinstance(mod, HipLayer):
+            mod.bind(store, name + "." if name else "")
+    store.finalize()

@@ -1,0 +1,185 @@
+"""Execution context for the HIP path: compute dtype, stream, backward tape, scratch workspaces.
+
+PyTorch is used here only as plumbing (device memory through its caching allocator, the current HIP stream, hipGraph
+capture via torch.cuda.graphs, torch.distributed/RCCL).  All arithmetic is done by libemrt_hip.so kernels launched
+on torch's current stream, so a whole training step can be captured into one hipGraph and replayed.
+
+The backward pass is an explicit tape of closures (no torch.autograd): every functional op that runs while a tape is
+active appends a closure that reads the gradient of its output(s), launches the backward kernels and hands gradients
+to its inputs through Tape.add_grad.  Views (token slabs, concat-buffer channel slices) are registered as aliases of
+their base buffer so gradients land in the right sub-region.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+class Tape:
+    def __init__(self):
+        self.ops = []
+        self.grads = {}
+        self.keep = []      # keeps every registered tensor alive so id() keys stay unique for the step
+        self.alias = {}     # id(view) -> (base, slicer)
+        self.watched = {}   # id(t) -> t : tensors whose gradient survives backward() (tests / debugging)
+        self.results = {}
+
+    def watch(self, t):
+        self.keep.append(t)
+        self.watched[id(t)] = t
+        return t
+
+    def result(self, t):
+        return self.results.get(id(t))
+
+    def record(self, fn):
+        self.ops.append(fn)
+
+    def register_alias(self, view, base, slicer):
+        self.keep.append(view)
+        self.keep.append(base)
+        self.alias[id(view)] = (base, slicer)
+
+    def grad(self, t):
+        a = self.alias.get(id(t))
+        if a is not None:
+            g = self.grad(a[0])
+            return None if g is None else a[1](g)
+        e = self.grads.get(id(t))
+        return None if e is None else e[0]
+
+    def pop_grad(self, t):
+        if id(t) in self.alias:
+            return self.grad(t)
+        e = self.grads.pop(id(t), None)
+        return None if e is None else e[0]
+
+    def _own(self, t):
+        """Make t's gradient buffer private to the tape (it may be accumulated into in place afterwards)."""
+        from . import functional as Fn
+        e = self.grads[id(t)]
+        if not e[1]:
+            priv = ctx().zeros(tuple(e[0].shape), e[0].dtype)
+            Fn.add_into(priv, e[0])
+            e[0], e[1] = priv, True
+        return e[0]
+
+    def add_grad(self, t, g):
+        """Accumulate gradient g (same shape as t) into t's gradient.  A gradient tensor handed in is never modified
+        in place unless the tape allocated it itself, so one tensor may safely be passed for several targets."""
+        from . import functional as Fn
+        a = self.alias.get(id(t))
+        if a is not None:
+            base, slicer = a
+            root = base
+            while id(root) in self.alias:
+                root = self.alias[id(root)][0]
+            if id(root) not in self.grads:
+                self.keep.append(root)
+                self.grads[id(root)] = [ctx().zeros(tuple(root.shape), g.dtype), True]
+            else:
+                self._own(root)
+            Fn.add_into(self.grad(t), g)
+            return
+        e = self.grads.get(id(t))
+        if e is None:
+            if tuple(g.shape) != tuple(t.shape):
+                g = g.reshape(t.shape)
+            self.keep.append(t)
+            self.grads[id(t)] = [g, False]
+        else:
+            Fn.add_into(self._own(t), g)
+
+    def backward(self):
+        _CTX.tape = None            # backward kernels must not record
+        for fn in reversed(self.ops):
+            fn()
+        self.results = {k: self.grad(t) for k, t in self.watched.items()}
+        self.ops = []
+        self.grads = {}
+        self.keep = []
+        self.alias = {}
+
+
+class Context:
+    def __init__(self):
+        self.dtype = F32
+        self.tape = None
+        self.training = False
+        self.device = None
+        self._ws = None
+        self._seed = None
+        self.step_counter = None
+        self.world_size = 1
+        self.sync_bn = True
+        self.salt_counter = 0
+
+    # ---- device / dtype -------------------------------------------------------------------------
+    def init_device(self, device="cuda:0", dtype=F32, seed=1234):
+        if not torch.cuda.is_available():
+            raise _lib.EmrtHipError("the EMRT HIP path needs a GPU (torch.cuda.is_available() is False); "
+                                    "there is no CPU fallback")
+        _lib.lib()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.dtype = dtype
+        self._ws = torch.empty(8 << 20, dtype=torch.uint8, device=self.device)
+        self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    @property
+    def tdtype(self):
+        return _TORCH_DTYPE[self.dtype]
+
+    @property
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def workspace(self, nbytes):
+        if self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.5), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @property
+    def seed_ptr(self):
+        return ctypes.c_void_p(self._seed.data_ptr())
+
+    def empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        t = torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+        _lib.lib().call("emrt_memset", ctypes.c_void_p(t.data_ptr()), 0, t.numel() * t.element_size(), self.stream)
+        return t
+
+    def zeros_like(self, t):
+        """Zero buffer with the same logical shape as t (dense)."""
+        return self.zeros(tuple(t.shape), t.dtype)
+
+    def next_salt(self):
+        self.salt_counter += 1
+        return self.salt_counter
+
+
+_CTX = Context()
+
+
+def ctx():
+    return _CTX
+
+
+class recording:
+    """with recording() as tape: ... forward ...; tape.backward()"""
+
+    def __enter__(self):
+        self.prev = _CTX.tape
+        _CTX.tape = Tape()
+        return _CTX.tape
+
+    def __exit__(self, *exc):
+        _CTX.tape = self.prev
+        return False

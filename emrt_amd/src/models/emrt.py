@@ -1,0 +1,648 @@
+"""EMRT on the MI355X HIP path: ResNet backbone -> multiscale deformable-attention encoder -> cross-attention decoder
+-> segmentation head, NHWC / [B, L, C] end to end, every arithmetic op a libemrt_hip.so kernel.
+
+Mirrors the reference model's module tree and state-dict keys:
+  /root/reference/semantic_segmentation/src/models/paddle_EMRT.py:13-304  (Conv2dBlock, EFP, PyramidPoolingModule,
+      branch_block, spatial_branch, UpHead, EMRT)
+  .../EMRT_utils/transformer_encoder_decoder.py:21-473 (MSDeformableAttention, Transformer*Layer, EncoderDecoder)
+  .../EMRT_utils/layers.py:144-311 (MultiHeadAttention), .../EMRT_utils/position_encoding.py:59-75 (sine embedding)
+  .../backbones/paddle_vision_resnet.py:43-257 (ResNet), .../decoders/fcn_head.py:19-81 (FCNHead)
+
+What is different from the reference by design (not by result):
+  * no NCHW<->[B,L,C] transposes/concats: a level's NHWC map IS its token slab, `memory` is three slabs back to back,
+    the 1536-channel concat buffer is written slice-wise by its producers (paddle_EMRT.py:266-293 disappears);
+  * sampling_offsets | attention_weights are one 256->432 GEMM whose fp32 output feeds the fused MSDA kernel;
+  * sine position embedding and encoder reference points are constants of (H, W) and are cached per shape
+    (the reference recomputes them and syncs to the host ~40 times per forward);
+  * Linear weights are stored [out, in]; MHA in_proj_weight [3E, E] (Paddle: transposed) -- see INTEGRATION.md.
+"""
+import math
+
+import torch
+import torch.nn as tnn
+
+from ... import functional as Fn
+from ... import nn as hnn
+from ...runtime import ctx, Tape, F32, BF16
+
+NOGRAD_PARAMS = ("backbone.fc.weight", "backbone.fc.bias", "model.tgt_embed.weight")
+
+
+def _salt():
+    return ctx().next_salt()
+
+
+# ---------------------------------------------------------------------------------------------------
+# ResNet (paddle_vision_resnet.py)
+# ---------------------------------------------------------------------------------------------------
+class BasicBlock(hnn.HipLayer):  # :43-88
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = hnn.Conv2D(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = hnn.BatchNorm2D(planes)
+        self.conv2 = hnn.Conv2D(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = hnn.BatchNorm2D(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.conv2(out)
+        identity = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        return self.bn2(out, relu=True, residual=identity)
+
+
+class BottleneckBlock(hnn.HipLayer):  # :91-149
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = hnn.Conv2D(inplanes, planes, 1, bias=False)
+        self.bn1 = hnn.BatchNorm2D(planes)
+        self.conv2 = hnn.Conv2D(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = hnn.BatchNorm2D(planes)
+        self.conv3 = hnn.Conv2D(planes, planes * 4, 1, bias=False)
+        self.bn3 = hnn.BatchNorm2D(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        out = self.conv3(out)
+        identity = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
+        return self.bn3(out, relu=True, residual=identity)
+
+
+class ResNet(hnn.HipLayer):  # :152-257
+    layer_cfg = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+    def __init__(self, depth, num_classes=1000):
+        super().__init__()
+        block = BasicBlock if depth in (18, 34) else BottleneckBlock
+        layers = self.layer_cfg[depth]
+        self.inplanes = 64
+        self.conv1 = hnn.Conv2D(3, 64, 7, 2, 3, bias=False, need_dx=False)
+        self.bn1 = hnn.BatchNorm2D(64)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        self.fc = hnn.Linear(512 * block.expansion, num_classes)   # in the reference state dict, never used (:213-214)
+        self.fc.standalone = False
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = hnn.Sequential(hnn.Conv2D(self.inplanes, planes * block.expansion, 1, stride, 0, bias=False),
+                                        hnn.BatchNorm2D(planes * block.expansion))
+        mods = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            mods.append(block(self.inplanes, planes))
+        return hnn.Sequential(*mods)
+
+    def forward(self, x):
+        x = self.bn1(self.conv1(x), relu=True)
+        x = Fn.maxpool(x, 3, 2, 1)
+        feats = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer._modules.values():
+                x = blk(x)
+            feats.append(x)
+        return feats
+
+
+# ---------------------------------------------------------------------------------------------------
+# FCNHead (fcn_head.py:19-81)
+# ---------------------------------------------------------------------------------------------------
+class FCNHead(hnn.HipLayer):
+    def __init__(self, in_channels, channels, num_classes, dropout_ratio=0.1, up_ratio=16):
+        super().__init__()
+        self.up_ratio, self.p = up_ratio, dropout_ratio
+        self.convs = hnn.Sequential(hnn.Sequential(hnn.Conv2D(in_channels, channels, 3, 1, 1, bias=False),
+                                                   hnn.BatchNorm2D(channels, sync=True), None))
+        self.conv_seg = hnn.Conv2D(channels, num_classes, 1)
+        self.salt = _salt()
+
+    def forward(self, x):
+        N, H, W, _ = x.shape
+        o = self.convs[0][1](self.convs[0][0](x), relu=True)
+        o = Fn.dropout(o, self.p, self.salt, mode=1, hw=H * W)
+        o = self.conv_seg(o)
+        return Fn.resize_bilinear(o, H * self.up_ratio, W * self.up_ratio, False, out_nchw_f32=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Deformable transformer (transformer_encoder_decoder.py)
+# ---------------------------------------------------------------------------------------------------
+class MSDeformableAttention(hnn.HipLayer):  # :21-107
+    def __init__(self, embed_dim=256, num_heads=8, num_levels=3, num_points=6):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.num_levels, self.num_points = embed_dim, num_heads, num_levels, num_points
+        tp = num_heads * num_levels * num_points
+        self.total_points = tp
+        self.sampling_offsets = hnn.Linear(embed_dim, tp * 2)      # lr_mult 0.1 (:36-38)
+        self.attention_weights = hnn.Linear(embed_dim, tp)
+        self.value_proj = hnn.Linear(embed_dim, embed_dim)
+        self.output_proj = hnn.Linear(embed_dim, embed_dim)
+        self.sampling_offsets.standalone = False                    # fused with attention_weights: one 256 -> 3*tp GEMM
+        self.attention_weights.standalone = False
+        self.offw_gemm = None
+        self._reset_parameters()
+
+    @torch.no_grad()
+    def _reset_parameters(self):  # :46-63
+        tnn.init.zeros_(self.sampling_offsets.weight)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True)[0]
+        grid = grid.reshape(self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        grid = grid * torch.arange(1, self.num_points + 1, dtype=torch.float32).reshape(1, 1, -1, 1)
+        self.sampling_offsets.bias.copy_(grid.flatten())
+        tnn.init.zeros_(self.attention_weights.weight)
+        tnn.init.zeros_(self.attention_weights.bias)
+        tnn.init.xavier_uniform_(self.value_proj.weight)
+        tnn.init.zeros_(self.value_proj.bias)
+        tnn.init.xavier_uniform_(self.output_proj.weight)
+        tnn.init.zeros_(self.output_proj.bias)
+
+    def bind(self, store, prefix):
+        ow, ob = store.offsets[prefix + "sampling_offsets.weight"], store.offsets[prefix + "sampling_offsets.bias"]
+        assert store.offsets[prefix + "attention_weights.weight"] == ow + self.total_points * 2 * self.embed_dim
+        assert store.offsets[prefix + "attention_weights.bias"] == ob + self.total_points * 2
+        self.offw_gemm = store.make_gemm(ow, self.total_points * 3, self.embed_dim, 1, 1, ob)
+
+    def forward(self, query, reference_points, value, spatial_shapes, need_dref=False):  # :65-107 (value_mask is all ones)
+        value = self.value_proj(value)
+        offw = Fn.linear(query, self.offw_gemm, out_f32=True)      # [B, Lq, 2*tp offsets | tp logits], fp32
+        out = Fn.msda(value, offw, reference_points, spatial_shapes, self.num_heads, self.num_points, need_dref=need_dref)
+        return self.output_proj(out)
+
+
+class MultiHeadAttention(hnn.HipLayer):  # layers.py:144-311
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = tnn.Parameter(torch.empty(3 * embed_dim, embed_dim))   # rows: q | k | v
+        self.in_proj_bias = tnn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = hnn.Linear(embed_dim, embed_dim)
+        self.salt = _salt()
+        with torch.no_grad():  # layers.py:214-219 (xavier over the packed [E, 3E] matrix)
+            bound = math.sqrt(6.0 / (embed_dim + 3 * embed_dim))
+            self.in_proj_weight.uniform_(-bound, bound)
+            tnn.init.xavier_uniform_(self.out_proj.weight)
+            tnn.init.zeros_(self.out_proj.bias)
+
+    def bind(self, store, prefix):
+        E = self.embed_dim
+        w, b = store.offsets[prefix + "in_proj_weight"], store.offsets[prefix + "in_proj_bias"]
+        self.qk_gemm = store.make_gemm(w, 2 * E, E, 1, 1, b)
+        self.v_gemm = store.make_gemm(w + 2 * E * E, E, E, 1, 1, b + 2 * E)
+
+    def forward(self, qk_in, v_in):  # :236-311 with query == key
+        qk = Fn.linear(qk_in, self.qk_gemm)
+        v = Fn.linear(v_in, self.v_gemm)
+        out = Fn.mha(qk, v, self.num_heads, self.dropout, self.salt)
+        return self.out_proj(out)
+
+
+def _linear_init_(m):  # initializer.py:267-270 (Paddle weight [in, out] => bound 1/sqrt(in))
+    bound = 1 / math.sqrt(m.weight.shape[1])
+    tnn.init.uniform_(m.weight, -bound, bound)
+    tnn.init.uniform_(m.bias, -bound, bound)
+
+
+@torch.no_grad()
+def _paddle_conv_default_(conv):
+    fan = conv.weight.shape[1] * conv.weight.shape[2] * conv.weight.shape[3]
+    conv.weight.normal_(0.0, math.sqrt(2.0 / fan))
+    if conv.bias is not None:
+        conv.bias.zero_()
+
+
+class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
+    def __init__(self, d_model=256, n_head=8, dim_feedforward=1024, dropout=0.1, n_levels=3, n_points=6):
+        super().__init__()
+        self.p = dropout
+        self.self_attn = MSDeformableAttention(d_model, n_head, n_levels, n_points)
+        self.norm1 = hnn.LayerNorm(d_model)
+        self.linear1 = hnn.Linear(d_model, dim_feedforward)
+        self.linear2 = hnn.Linear(dim_feedforward, d_model)
+        self.norm2 = hnn.LayerNorm(d_model)
+        self.conv0 = hnn.Sequential(hnn.Conv2D(d_model, d_model, 3, 1, 1, bias=False), hnn.GroupNorm(32, d_model), None)
+        self.conv1 = hnn.Sequential(hnn.Conv2D(d_model, d_model, 3, 1, 1, bias=False), hnn.GroupNorm(32, d_model), None)
+        self.conv2 = hnn.Sequential(hnn.Conv2D(d_model, d_model, 3, 1, 1, bias=False), hnn.GroupNorm(32, d_model), None)
+        self.salts = [_salt(), _salt(), _salt()]
+        with torch.no_grad():  # :148-152
+            for seq in (self.conv0, self.conv1, self.conv2):
+                _paddle_conv_default_(seq[0])
+            _linear_init_(self.linear1)
+            _linear_init_(self.linear2)
+            tnn.init.xavier_uniform_(self.linear1.weight)
+            tnn.init.xavier_uniform_(self.linear2.weight)
+
+    def forward(self, src, reference_points, spatial_shapes, level_spans, pos, pos_bgrad):  # :184-204
+        B, Lv, C = src.shape
+        src_flatten = ctx().empty((B, Lv, C))
+        for (h, w), (s0, n), seq in zip(spatial_shapes, level_spans, (self.conv0, self.conv1, self.conv2)):
+            x_l = Fn.tokens_as_map(Fn.narrow(src, 1, s0, n), h, w)
+            y = seq[0](x_l)
+            seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
+        q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes)
+        src2 = Fn.dropout(src2, self.p, self.salts[0])
+        src = self.norm1(src, src2)
+        h1 = self.linear1(src, relu=True)
+        h1 = Fn.dropout(h1, self.p, self.salts[1])
+        ff = Fn.dropout(self.linear2(h1), self.p, self.salts[2])
+        return self.norm2(src, ff, post=src_flatten)    # LN(src + ffn) + conv-branch tokens (:202-203)
+
+
+class TransformerEncoder(hnn.HipLayer):  # :207-239
+    def __init__(self, make_layer, num_layers):
+        super().__init__()
+        first = make_layer()
+        layers = [first]
+        for _ in range(1, num_layers):
+            lyr = make_layer()
+            lyr.load_state_dict(first.state_dict())   # _get_clones deep-copies one layer (utils.py:31-32)
+            layers.append(lyr)
+        self.layers = tnn.ModuleList(layers)
+
+
+class TransformerDecoderLayer(hnn.HipLayer):  # :242-295
+    def __init__(self, d_model=256, n_head=8, dim_feedforward=1024, dropout=0.1, n_levels=3, n_points=6):
+        super().__init__()
+        self.p = dropout
+        self.self_attn = MultiHeadAttention(d_model, n_head, dropout=dropout)
+        self.norm1 = hnn.LayerNorm(d_model)
+        self.cross_attn = MSDeformableAttention(d_model, n_head, n_levels, n_points)
+        self.norm2 = hnn.LayerNorm(d_model)
+        self.linear1 = hnn.Linear(d_model, dim_feedforward)
+        self.linear2 = hnn.Linear(dim_feedforward, d_model)
+        self.norm3 = hnn.LayerNorm(d_model)
+        self.salts = [_salt(), _salt(), _salt(), _salt()]
+        with torch.no_grad():  # :267-271
+            _linear_init_(self.linear1)
+            _linear_init_(self.linear2)
+            tnn.init.xavier_uniform_(self.linear1.weight)
+            tnn.init.xavier_uniform_(self.linear2.weight)
+
+    def forward(self, tgt, reference_points, memory, spatial_shapes, query_pos, qpos_bgrad):  # :282-295
+        Lq, C = tgt.shape[1], tgt.shape[2]
+        q = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
+        tgt2 = Fn.dropout(self.self_attn(q, tgt), self.p, self.salts[0])
+        tgt = self.norm1(tgt, tgt2)
+        q2 = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
+        tgt2 = self.cross_attn(q2, reference_points, memory, spatial_shapes, need_dref=True)
+        tgt = self.norm2(tgt, Fn.dropout(tgt2, self.p, self.salts[1]))
+        h1 = Fn.dropout(self.linear1(tgt, relu=True), self.p, self.salts[2])
+        ff = Fn.dropout(self.linear2(h1), self.p, self.salts[3])
+        return self.norm3(tgt, ff)
+
+
+class TransformerDecoder(hnn.HipLayer):  # :298-334
+    def __init__(self, make_layer, num_layers):
+        super().__init__()
+        first = make_layer()
+        layers = [first]
+        for _ in range(1, num_layers):
+            lyr = make_layer()
+            lyr.load_state_dict(first.state_dict())
+            layers.append(lyr)
+        self.layers = tnn.ModuleList(layers)
+
+
+def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000, offset=-0.5, eps=1e-6, scale=2 * math.pi):
+    """position_encoding.py:59-75 for an all-ones mask -> [h*w, 2*num_pos_feats] (host, fp32)."""
+    y_embed = torch.arange(1, h + 1, dtype=torch.float32).reshape(h, 1).expand(h, w)
+    x_embed = torch.arange(1, w + 1, dtype=torch.float32).reshape(1, w).expand(h, w)
+    y_embed = (y_embed + offset) / (y_embed[-1:, :] + eps) * scale
+    x_embed = (x_embed + offset) / (x_embed[:, -1:] + eps) * scale
+    dim_t = 2 * (torch.arange(num_pos_feats) // 2).to(torch.float32)
+    dim_t = temperature ** (dim_t / num_pos_feats)
+    pos_x = x_embed.unsqueeze(-1) / dim_t
+    pos_y = y_embed.unsqueeze(-1) / dim_t
+    pos_x = torch.stack((pos_x[:, :, 0::2].sin(), pos_x[:, :, 1::2].cos()), dim=3).flatten(2)
+    pos_y = torch.stack((pos_y[:, :, 0::2].sin(), pos_y[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((pos_y, pos_x), dim=2).reshape(h * w, 2 * num_pos_feats)
+
+
+def encoder_reference_points(spatial_shapes):
+    """transformer_encoder_decoder.py:213-228 with valid_ratios == 1 -> [1, Lv, 1, 2] (x, y), identical for every level."""
+    pts = []
+    for (H, W) in spatial_shapes:
+        ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H - 0.5, H), torch.linspace(0.5, W - 0.5, W), indexing="ij")
+        pts.append(torch.stack((ref_x.flatten() / W, ref_y.flatten() / H), dim=-1))
+    return torch.cat(pts, 0).reshape(1, -1, 1, 2).contiguous()
+
+
+class EncoderDecoder(hnn.HipLayer):  # :337-473
+    def __init__(self, num_queries=110, backbone_num_channels=(512, 1024, 2048), num_feature_levels=3,
+                 num_encoder_points=6, num_decoder_points=6, hidden_dim=256, nhead=8, num_encoder_layers=4,
+                 num_decoder_layers=2, dim_feedforward=1024, dropout=0.1):
+        super().__init__()
+        self.hidden_dim, self.nhead, self.num_queries = hidden_dim, nhead, num_queries
+        self.encoder = TransformerEncoder(lambda: TransformerEncoderLayer(hidden_dim, nhead, dim_feedforward, dropout,
+                                                                          num_feature_levels, num_encoder_points), num_encoder_layers)
+        self.decoder = TransformerDecoder(lambda: TransformerDecoderLayer(hidden_dim, nhead, dim_feedforward, dropout,
+                                                                          num_feature_levels, num_decoder_points), num_decoder_layers)
+        self.level_embed = hnn.Embedding(num_feature_levels, hidden_dim)
+        self.tgt_embed = hnn.Embedding(num_queries, hidden_dim)         # created, never used (:368, :469)
+        self.query_pos_embed = hnn.Embedding(num_queries, hidden_dim)
+        self.reference_points = hnn.Linear(hidden_dim, 2)               # lr_mult 0.1 (:371-372)
+        self.input_proj = tnn.ModuleList([hnn.Sequential(hnn.Conv2D(c, hidden_dim, 1), hnn.GroupNorm(32, hidden_dim))
+                                          for c in backbone_num_channels])
+        self._const_cache = {}
+        with torch.no_grad():  # :394-402
+            tnn.init.normal_(self.level_embed.weight)
+            tnn.init.normal_(self.tgt_embed.weight)
+            tnn.init.normal_(self.query_pos_embed.weight)
+            tnn.init.xavier_uniform_(self.reference_points.weight)
+            tnn.init.zeros_(self.reference_points.bias)
+            for l in self.input_proj:
+                tnn.init.xavier_uniform_(l[0].weight)
+                tnn.init.zeros_(l[0].bias)
+
+    def _constants(self, spatial_shapes):
+        key = (tuple(spatial_shapes), ctx().dtype)
+        if key not in self._const_cache:
+            dev = ctx().device
+            sine = torch.cat([sine_position_embedding(h, w, self.hidden_dim // 2) for h, w in spatial_shapes], 0)
+            self._const_cache[key] = (sine.to(device=dev, dtype=ctx().tdtype).contiguous(),
+                                      encoder_reference_points(spatial_shapes).to(dev))
+        return self._const_cache[key]
+
+    def forward(self, src_feats, src_psp):  # :416-473
+        c = ctx()
+        B = src_feats[0].shape[0]
+        C = self.hidden_dim
+        spatial_shapes = [(f.shape[1], f.shape[2]) for f in src_feats]
+        spans, s0 = [], 0
+        for h, w in spatial_shapes:
+            spans.append((s0, h * w))
+            s0 += h * w
+        Lv = s0
+        src = c.empty((B, Lv, C))
+        for f, (h, w), (a, n), proj in zip(src_feats, spatial_shapes, spans, self.input_proj):
+            y = proj[0](f)                                                       # 1x1 conv + bias
+            proj[1](y, out=Fn.tokens_as_map(Fn.narrow(src, 1, a, n), h, w))      # GroupNorm straight into the token slab
+        sine, ref_enc = self._constants(spatial_shapes)
+        pos = c.empty((Lv, C))
+        lvl = self.level_embed.weight
+        for l, (a, n) in enumerate(spans):                                       # pos = sine + level_embed[l]  (:447-448)
+            Fn._L().call("emrt_add_f32row", Fn.P(sine[a:a + n]), Fn.P(lvl.data[l]), Fn.P(pos[a:a + n]), n * C, C, c.dtype, c.stream)
+
+        def pos_bgrad(g):   # d level_embed[l] += sum over batch and the level's tokens
+            for l, (a, n) in enumerate(spans):
+                Fn.colsum_acc(g.narrow(1, a, n), lvl.grad[l])
+
+        memory = src
+        for layer in self.encoder.layers:
+            memory = layer(memory, ref_enc, spatial_shapes, spans, pos, pos_bgrad)
+
+        qpe = self.query_pos_embed.weight
+        query_pos = Fn.param_input(qpe.data, qpe.grad)                           # [110, C] in the compute dtype
+
+        def qpos_bgrad(g):  # d query_pos_embed += sum over batch of the broadcast-add gradient
+            Fn.colsum_acc(g.reshape(g.shape[0], -1), qpe.grad.view(-1))
+
+        ref_logit = self.reference_points(query_pos, out_f32=True)               # [110, 2] fp32   (:466)
+        ref_dec = Fn.view_as(Fn.sigmoid_f32(ref_logit), (1, self.num_queries, 1, 2))   # one point per query, all levels
+        tgt = src_psp
+        for layer in self.decoder.layers:
+            tgt = layer(tgt, ref_dec, memory, spatial_shapes, query_pos, qpos_bgrad)
+        return tgt, memory, spatial_shapes, spans
+
+
+# ---------------------------------------------------------------------------------------------------
+# EMRT parts (paddle_EMRT.py)
+# ---------------------------------------------------------------------------------------------------
+class Conv2dBlock(hnn.HipLayer):  # :13-29
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = hnn.Sequential(hnn.Conv2D(cin, cout, 3, 1, 1, bias=False), hnn.BatchNorm2D(cout), None)
+        self.conv2 = hnn.Sequential(hnn.Conv2D(cout, cout, 3, 1, 1, bias=False), hnn.BatchNorm2D(cout), None)
+
+    def forward(self, x):
+        o = self.conv1[1](self.conv1[0](x), relu=True)
+        o = self.conv2[1](self.conv2[0](o), relu=True)
+        return Fn.add_maps(o, x)
+
+
+class EFP(hnn.HipLayer):  # :31-48
+    def __init__(self, cin=256, cout=256):
+        super().__init__()
+        self.conv0, self.conv1, self.conv2 = Conv2dBlock(cin, cout), Conv2dBlock(cin, cout), Conv2dBlock(cin, cout)
+
+    def forward(self, x0, x1, x2, out):
+        o2 = self.conv2(x2)
+        o1 = self.conv1(x1)
+        x21 = Fn.resize_bilinear(o2, x1.shape[1], x1.shape[2], True, add_t=o1)            # conv1(x1) + up(conv2(x2))
+        o0 = self.conv0(x0)
+        return Fn.resize_bilinear(x21, x0.shape[1], x0.shape[2], True, add_t=o0, out=out)  # conv0(x0) + up(.)
+
+
+class PyramidPoolingModule(hnn.HipLayer):  # :50-78
+    def __init__(self, pool_scales, in_channels, channels):
+        super().__init__()
+        self.pool_scales = list(pool_scales)
+        self.pool_branches = tnn.ModuleList([
+            hnn.Sequential(None, hnn.Conv2D(in_channels, channels, 1, bias=False), hnn.BatchNorm2D(channels, sync=True), None)
+            for _ in pool_scales])
+
+    def forward(self, x):
+        tokens = Fn.adaptive_avgpool_tokens(x, self.pool_scales)       # all four pools in one launch -> [B, 110, C]
+        parts, s0 = [], 0
+        for k, br in zip(self.pool_scales, self.pool_branches):
+            t = Fn.narrow(tokens, 1, s0, k * k)
+            parts.append(br[2](br[1](t), relu=True))
+            s0 += k * k
+        return Fn.concat_tokens(parts)
+
+
+class branch_block(hnn.HipLayer):  # :80-97
+    def __init__(self, cin, cout, first=False):
+        super().__init__()
+        self.first = first
+        self.encode = hnn.Sequential(hnn.Conv2D(cin, cout, 3, 1, 1, bias=False, need_dx=not first), hnn.BatchNorm2D(cout), None,
+                                     hnn.Conv2D(cout, cout, 3, 1, 1, bias=False), hnn.BatchNorm2D(cout), None)
+
+    def forward(self, x, out=None):
+        x = Fn.maxpool(x, 3, 2, 1, need_dx=not self.first)
+        x = self.encode[1](self.encode[0](x), relu=True)
+        return self.encode[4](self.encode[3](x), relu=True, out=out)
+
+
+class spatial_branch(hnn.HipLayer):  # :99-113
+    def __init__(self, in_channels=3):
+        super().__init__()
+        self.Enc0, self.Enc1, self.Enc2 = branch_block(in_channels, 64, first=True), branch_block(64, 128), branch_block(128, 256)
+
+    def forward(self, x, out):
+        return self.Enc2(self.Enc1(self.Enc0(x)), out=out)
+
+
+class UpHead(hnn.HipLayer):  # :115-181 (num_conv == 3)
+    def __init__(self, embed_dim=256, num_classes=6):
+        super().__init__()
+        self.conv_0 = hnn.Conv2D(embed_dim, 256, 3, 1, 1)
+        self.conv_1 = hnn.Conv2D(256, 256, 3, 1, 1)
+        self.conv_2 = hnn.Conv2D(256, 256, 3, 1, 1)
+        self.conv_3 = hnn.Conv2D(256, num_classes, 1)
+        self.syncbn_fc_0, self.syncbn_fc_1, self.syncbn_fc_2 = hnn.BatchNorm2D(256), hnn.BatchNorm2D(256), hnn.BatchNorm2D(256)
+
+    def forward(self, x):  # :164-180
+        x = self.syncbn_fc_0(self.conv_0(x), relu=True)
+        x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
+        x = self.syncbn_fc_1(self.conv_1(x), relu=True)
+        x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
+        x = self.syncbn_fc_2(self.conv_2(x), relu=True)
+        x = self.conv_3(x)
+        return Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False, out_nchw_f32=True)
+
+
+class LogitsTuple(tuple):
+    """(logits, aux_logits) as the reference returns them (paddle_EMRT.py:304) + the tape that produced them."""
+    tape = None
+
+
+class EMRT(hnn.HipLayer):  # :184-304
+    def __init__(self, config=None, num_classes=None, backbone=None):
+        super().__init__()
+        if config is not None:
+            num_classes = config.DATA.NUM_CLASSES
+            backbone = config.MODEL.ENCODER.TYPE.lower()
+        depth = int(backbone.replace("resnet", "")) if backbone.startswith("resnet") and backbone[6:].isdigit() else None
+        if depth not in ResNet.layer_cfg:
+            raise NotImplementedError("EMRT HIP path supports resnet18/34/50/101/152 backbones, got %r" % backbone)
+        self.nclass = num_classes
+        # resnet18/34: build-side extension (the reference hard-codes [512,1024,2048], paddle_EMRT.py:188-192)
+        self.backbone_num_channels = [128, 256, 512] if depth in (18, 34) else [512, 1024, 2048]
+        self.hidden_dim = 256
+        self.psp_scale = [1, 3, 6, 8]
+        self.spatial_branch = spatial_branch(3)
+        self.psp_module = PyramidPoolingModule(self.psp_scale, 256, 256)
+        self.uphead = UpHead(256, num_classes)
+        self.cls_psp = hnn.Sequential(hnn.Conv2D(256 * (2 + len(self.psp_scale)), 512, 3, 1, 1, bias=False), hnn.BatchNorm2D(512), None,
+                                      hnn.Conv2D(512, 256, 3, 1, 1, bias=False), hnn.BatchNorm2D(256), None, None)
+        self.cls_salt = _salt()
+        self.cls_p = 0.1
+        self.EFP = EFP(256, 256)
+        self.auxlayer = FCNHead(self.backbone_num_channels[1], self.backbone_num_channels[1] // 4, num_classes)
+        with torch.no_grad():  # :217-225 (before the backbone / transformer exist)
+            for m in self.modules():
+                if isinstance(m, hnn.Conv2D):
+                    tnn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="relu")
+        self.backbone = ResNet(depth)
+        with torch.no_grad():   # reference downloads ImageNet weights (:231-232); offline => Paddle default init
+            for m in self.backbone.modules():
+                if isinstance(m, hnn.Conv2D):
+                    _paddle_conv_default_(m)
+            tnn.init.xavier_uniform_(self.backbone.fc.weight)
+            tnn.init.zeros_(self.backbone.fc.bias)
+        self.model = EncoderDecoder(backbone_num_channels=self.backbone_num_channels, hidden_dim=256, dim_feedforward=1024,
+                                    dropout=0.1, num_feature_levels=3, nhead=8, num_encoder_layers=4, num_decoder_layers=2,
+                                    num_encoder_points=6, num_decoder_points=6)
+        self.store = None
+        self.compute_aux_in_eval = True   # the reference always evaluates the aux head (paddle_EMRT.py:300-302)
+
+    # ---- device placement -----------------------------------------------------------------------
+    def fused_groups(self):
+        groups = []
+        for name, m in self.named_modules():
+            if isinstance(m, MSDeformableAttention):
+                groups.append([name + ".sampling_offsets.weight", name + ".attention_weights.weight"])
+                groups.append([name + ".sampling_offsets.bias", name + ".attention_weights.bias"])
+        return groups
+
+    def lr_mult_names(self):
+        names = []
+        for name, m in self.named_modules():
+            if isinstance(m, MSDeformableAttention):
+                names += [name + ".sampling_offsets.weight", name + ".sampling_offsets.bias"]
+        return names + ["model.reference_points.weight", "model.reference_points.bias"]
+
+    def to_hip(self, device="cuda:0", dtype=F32, seed=1234):
+        """Move the model onto the GPU: flat parameter store + packed GEMM weights.  dtype: runtime.F32 / runtime.BF16."""
+        c = ctx()
+        c.init_device(device, dtype, seed)
+        self.store = hnn.ParamStore(self, c.device, dtype, nograd_names=NOGRAD_PARAMS, fused_groups=self.fused_groups(),
+                                    lr_mult_names=self.lr_mult_names(), lr_mult=0.1)
+        hnn.bind_all(self, self.store)
+        self.store.pack()
+        return self
+
+    def set_dropout(self, p):
+        """Override every dropout probability (parity tests run with p = 0; the recipe's value is 0.1 everywhere)."""
+        for m in self.modules():
+            if isinstance(m, (TransformerEncoderLayer, TransformerDecoderLayer, FCNHead)):
+                m.p = p
+            if isinstance(m, MultiHeadAttention):
+                m.dropout = p
+        self.cls_p = p
+
+    def sync_weights(self):
+        """Re-pack the compute-dtype weight copies after parameters were modified from outside (state-dict load)."""
+        self.store.dirty = True
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict)
+        if self.store is not None:
+            self.store.dirty = True
+        return r
+
+    set_state_dict = load_state_dict       # paddle spelling used by the reference (checkpoint.py)
+
+    def clear_gradients(self):
+        self.store.zero_grad()
+
+    # ---- forward --------------------------------------------------------------------------------
+    def __call__(self, images):
+        if self.store is None:
+            raise RuntimeError("call model.to_hip(device, dtype) before the first forward")
+        c = ctx()
+        if self.store.dirty:
+            self.store.pack()
+        c.training = self.training
+        tape = Tape() if self.training else None
+        c.tape = tape
+        try:
+            out = self.forward(images)
+        finally:
+            c.tape = None
+        res = LogitsTuple(out)
+        res.tape = tape
+        return res
+
+    def forward(self, inputs):  # :252-304
+        c = ctx()
+        assert inputs.dim() == 4 and inputs.shape[1] == 3 and inputs.shape[2] % 32 == 0 and inputs.shape[3] % 32 == 0, \
+            "EMRT expects fp32 NCHW images whose H and W are multiples of 32 (paddle_EMRT.py:293)"
+        x = Fn.nchw_to_nhwc(inputs.contiguous())
+        B, H, W, _ = x.shape
+        c1, c2, c3, c4 = self.backbone(x)
+        S = H // 8
+        psp_cat = c.empty((B, S, S, 256 * (2 + len(self.psp_scale))))
+        x_context = self.spatial_branch(x, out=Fn.narrow(psp_cat, 3, 0, 256))
+        x_psp = self.psp_module(x_context)
+        hs, memory, shapes, spans = self.model([c2, c3, c4], x_psp)
+        maps = [Fn.tokens_as_map(Fn.narrow(memory, 1, a, n), h, w) for (h, w), (a, n) in zip(shapes, spans)]
+        nps = len(self.psp_scale)
+        self.EFP(maps[0], maps[1], maps[2], out=Fn.narrow(psp_cat, 3, 256 * (1 + nps), 256))
+        idx = 0
+        for i, k in enumerate(self.psp_scale):  # :281-291
+            pooled = Fn.tokens_as_map(Fn.narrow(hs, 1, idx, k * k), k, k)
+            Fn.resize_bilinear(pooled, S, S, True, out=Fn.narrow(psp_cat, 3, 256 * (1 + i), 256))
+            idx += k * k
+        o = self.cls_psp[1](self.cls_psp[0](psp_cat), relu=True)
+        o = self.cls_psp[4](self.cls_psp[3](o), relu=True)
+        o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=S * S)
+        logits = self.uphead(o)
+        if self.training or self.compute_aux_in_eval:
+            aux = self.auxlayer(c3)      # x16 bilinear; the reference's final align_corners=True resize is the identity here
+            assert aux.shape[2] == H and aux.shape[3] == W
+        else:
+            aux = None
+        return (logits, aux)

@@ -1,0 +1,77 @@
+"""Optimizer / LR schedule of the EMRT recipe (reference: src/models/solver/optimizer.py:29-40, lr_scheduler.py:244-248).
+
+Momentum = ClipGradByGlobalNorm -> L2 decay (g += wd * p) -> v = mu * v + g -> p -= lr * lr_mult * v, run by two HIP
+kernels over the model's flat parameter buffer; PolynomialDecay is evaluated on the device from the step counter (the
+host mirrors it for logging), so one optimizer step is capturable in a hipGraph."""
+import ctypes
+
+import torch
+
+from .... import _lib
+from .... import functional as Fn
+from ....runtime import ctx
+
+
+class PolynomialDecay:
+    def __init__(self, learning_rate, decay_steps, end_lr=0.0, power=0.9):
+        self.base_lr, self.decay_steps, self.end_lr, self.power = learning_rate, decay_steps, end_lr, power
+        self.last_epoch = 0
+
+    def get_lr(self):
+        t = min(self.last_epoch, self.decay_steps)
+        return (self.base_lr - self.end_lr) * (1.0 - t / self.decay_steps) ** self.power + self.end_lr
+
+    def step(self):
+        self.last_epoch += 1
+
+
+class Momentum:
+    def __init__(self, model, lr_scheduler, momentum=0.9, weight_decay=0.0, grad_clip=None, use_nesterov=False):
+        if use_nesterov:
+            raise NotImplementedError("Nesterov momentum is not used by any EMRT config")
+        self.model, self._learning_rate = model, lr_scheduler
+        self.momentum, self.weight_decay, self.grad_clip = momentum, float(weight_decay), grad_clip
+        st = model.store
+        c = ctx()
+        self.clip_state = c.zeros((2,), torch.float32)
+        self.lr_dev = c.zeros((1,), torch.float32)
+        self.ranges = (ctypes.c_longlong * (2 * len(st.lr_ranges)))(*[v for r in st.lr_ranges for v in r])
+
+    def get_lr(self):
+        return self._learning_rate.get_lr()
+
+    def grad_norm(self):
+        return float(self.clip_state[1].item())
+
+    def step(self):
+        """Enqueues clip + update + weight re-pack on the current stream; advances the device step counter."""
+        c, st, L = ctx(), self.model.store, _lib.lib()
+        sch = self._learning_rate
+        ws = c.workspace(L.query("emrt_gradnorm_workspace_bytes"))
+        L.call("emrt_grad_clip_scale", Fn.P(st.grad), st.n_train, float(self.grad_clip or 0.0), Fn.P(self.clip_state), Fn.P(ws), c.stream)
+        L.call("emrt_sgd_momentum_step", Fn.P(st.master), Fn.P(st.grad), Fn.P(st.velocity), st.n_train, Fn.P(self.clip_state),
+               Fn.P(c.step_counter), sch.base_lr, sch.end_lr, sch.power, sch.decay_steps, self.momentum, self.weight_decay,
+               ctypes.cast(self.ranges, ctypes.c_void_p), len(st.lr_ranges), st.lr_mult, Fn.P(self.lr_dev), c.stream)
+        L.call("emrt_counter_add", Fn.P(c.step_counter), 1, c.stream)
+        st.pack()
+
+    def state_dict(self):
+        return {"velocity": self.model.store.velocity.clone(), "step": int(ctx().step_counter.item())}
+
+    def set_state_dict(self, sd):
+        self.model.store.velocity.copy_(sd["velocity"])
+        ctx().step_counter.fill_(int(sd["step"]))
+        self._learning_rate.last_epoch = int(sd["step"])
+
+
+def get_scheduler(config):
+    if config.TRAIN.LR_SCHEDULER.NAME == "PolynomialDecay":
+        return PolynomialDecay(config.TRAIN.BASE_LR, config.TRAIN.ITERS, config.TRAIN.END_LR, config.TRAIN.POWER)
+    raise NotImplementedError("only PolynomialDecay is on the EMRT path (every EMRT yaml uses it)")
+
+
+def get_optimizer(model, lr_scheduler, config):
+    if config.TRAIN.OPTIMIZER.NAME.lower() != "sgd":
+        raise NotImplementedError("only SGD-momentum is on the EMRT path (every EMRT yaml uses it)")
+    return Momentum(model, lr_scheduler, momentum=config.TRAIN.OPTIMIZER.MOMENTUM, weight_decay=float(config.TRAIN.OPTIMIZER.WEIGHT_DECAY),
+                    grad_clip=config.TRAIN.OPTIMIZER.GRAD_CLIP, use_nesterov=config.TRAIN.OPTIMIZER.NESTEROV)

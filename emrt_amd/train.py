@@ -1,0 +1,159 @@
+"""Training entry point with the reference's CLI and step order (semantic_segmentation/train.py:26-266).
+
+    python -m emrt_amd.train --config emrt_amd/configs/EMRT/EMRT_256x256_160k_potsdam.yaml [--seed 1234]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m emrt_amd.train --config ...
+
+Per iteration (train.py:141-159): forward -> MixSoftmaxCrossEntropyLoss -> backward (+ RCCL gradient all-reduce when
+WORLD_SIZE > 1) -> Momentum step with global-norm clip -> poly LR step -> clear grads; every LOGGING_INFO_FREQ
+iterations rank 0 prints the reference's log line (:177-181); every SAVE_FREQ_CHECKPOINT iterations a checkpoint
+(model + optimizer state + iteration, so training can actually be resumed -- the reference never wired that, :103).
+The dataset pipeline (cv2 / Potsdam readers) is outside this path: tiles come from --data synthetic (default: seeded
+random tiles of DATA.CROP_SIZE, resident on the device) or from an .npz of pre-cut tiles (--data file.npz with arrays
+`images` [N,3,H,W] float32 normalised and `labels` [N,H,W] int64).
+"""
+import argparse
+import os
+import time
+from collections import deque
+
+import numpy as np
+import torch
+
+from .config import get_config, update_config
+from .distributed import DistributedTileSampler, init_process_group
+from .engine import TrainEngine
+from .runtime import BF16, F32
+from .src.models import get_model
+from .src.models.losses import get_loss_function
+from .src.models.solver import get_optimizer, get_scheduler
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="EMRT (MI355X HIP path) training")
+    p.add_argument("--config", dest="cfg", type=str,
+                   default=os.path.join(os.path.dirname(__file__), "configs/EMRT/EMRT_256x256_160k_potsdam.yaml"), help="The config file.")
+    p.add_argument("--seed", dest="seed", default=1234, type=int, help="Set the random seed during training.")
+    p.add_argument("--data", default="synthetic", help="'synthetic' or a .npz of pre-cut tiles")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--iters", type=int, default=None, help="override TRAIN.ITERS")
+    p.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a captured hipGraph")
+    p.add_argument("--resume", default=None, help="checkpoint written by this script")
+    return p.parse_args(argv)
+
+
+class TimeAverager:  # utils/timer.py:17-40
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self._cnt, self._total_time, self._total_samples = 0, 0.0, 0
+
+    def record(self, usetime, num_samples=None):
+        self._cnt += 1
+        self._total_time += usetime
+        if num_samples:
+            self._total_samples += num_samples
+
+    def get_average(self):
+        return 0 if self._cnt == 0 else self._total_time / float(self._cnt)
+
+    def get_ips_average(self):
+        return 0 if not self._total_samples or self._cnt == 0 else float(self._total_samples) / self._total_time
+
+
+def calculate_eta(remaining_step, speed):  # utils/timer.py:43-51
+    remaining_time = int(max(remaining_step, 0) * speed)
+    h, r = divmod(remaining_time, 3600)
+    m, s = divmod(r, 60)
+    return "{:0>2}:{:0>2}:{:0>2}".format(h, m, s)
+
+
+def synthetic_tiles(n, crop, ncls, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(n, 3, crop[1], crop[0], generator=g)
+    labels = torch.randint(0, ncls, (n, crop[1], crop[0]), generator=g)
+    labels[torch.rand(n, crop[1], crop[0], generator=g) < 0.02] = 255
+    return images.to(device), labels.to(device)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config = update_config(get_config(), args)
+    rank, local_rank, nranks = init_process_group()
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    model = get_model(config)
+    model.to_hip("cuda:%d" % local_rank, BF16 if args.dtype == "bf16" else F32, seed=args.seed + rank)   # per-rank dropout streams
+    model.train()
+    iters = args.iters or config.TRAIN.ITERS
+    if args.iters:
+        config.TRAIN.ITERS = iters
+    lr_scheduler = get_scheduler(config)
+    optimizer = get_optimizer(model, lr_scheduler, config)
+    loss_func = get_loss_function(config)
+    bs = config.DATA.BATCH_SIZE
+    dev = torch.device("cuda", local_rank)
+    if args.data == "synthetic":
+        images, labels = synthetic_tiles(max(4 * bs * nranks, 64), config.DATA.CROP_SIZE, config.DATA.NUM_CLASSES, args.seed, dev)
+    else:
+        z = np.load(args.data)
+        images, labels = torch.from_numpy(z["images"]).float().to(dev), torch.from_numpy(z["labels"]).long().to(dev)
+    sampler = DistributedTileSampler(images.shape[0], bs, rank, nranks, shuffle=True, drop_last=True, seed=args.seed)
+    start_iter = 0
+    if args.resume:
+        ck = torch.load(args.resume, map_location="cpu")
+        model.load_state_dict(ck["model"])
+        optimizer.set_state_dict(ck["optimizer"])
+        start_iter = ck["iter"]
+    engine = TrainEngine(model, optimizer, loss_func, nranks, use_graph=not args.no_graph)
+    if rank == 0:
+        os.makedirs(config.SAVE_DIR, exist_ok=True) if os.access(os.path.dirname(config.SAVE_DIR) or ".", os.W_OK) else None
+        print("train_cfg: {}\ntrain_model_name: {}\ntrain_datatset: {}".format(args.cfg, config.MODEL.NAME, config.DATA.DATASET))
+    iters_per_epoch = max(len(sampler), 1)
+    total_epoch = iters // iters_per_epoch
+    reader_cost, batch_cost = TimeAverager(), TimeAverager()
+    save_models = deque()
+    avg_loss, cur_iter, epoch = 0.0, start_iter, 0
+    batch_start = time.time()
+    pending = []
+    while cur_iter < iters:
+        sampler.set_epoch(epoch)
+        epoch += 1
+        for idx in sampler:
+            if cur_iter >= iters:
+                break
+            cur_iter += 1
+            reader_cost.record(time.time() - batch_start)
+            ib = torch.as_tensor(idx, device=dev)
+            lr = optimizer.get_lr()
+            loss_t = engine.step(images[ib], labels[ib])
+            pending.append(loss_t.clone())          # no device->host sync per step (the reference syncs here, :160)
+            batch_cost.record(time.time() - batch_start, num_samples=bs)
+            if cur_iter % config.LOGGING_INFO_FREQ == 0:
+                avg_loss = float(torch.stack(pending).mean().item())
+                pending = []
+                if rank == 0:
+                    print("[TRAIN] Epochs: {}/{}, iter: {}/{}, loss: {:.4f}, lr: {:.8f}, batch_cost: {:.4f}, reader_cost: {:.5f}, ips: {:.4f} samples/sec | ETA {}".format(
+                        (cur_iter - 1) // iters_per_epoch + 1, total_epoch + 1, cur_iter, iters, avg_loss, lr, batch_cost.get_average(),
+                        reader_cost.get_average(), batch_cost.get_ips_average() * nranks, calculate_eta(iters - cur_iter, batch_cost.get_average())), flush=True)
+                reader_cost.reset()
+                batch_cost.reset()
+            if (cur_iter % config.SAVE_FREQ_CHECKPOINT == 0 or cur_iter == iters) and rank == 0 and os.path.isdir(config.SAVE_DIR):
+                path = os.path.join(config.SAVE_DIR, "iter_{}_state.pt".format(cur_iter))
+                torch.save({"model": {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()},
+                            "optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()},
+                            "iter": cur_iter}, path)
+                save_models.append(path)
+                print("saving the weights of model to {}".format(path))
+                if len(save_models) > config.KEEP_CHECKPOINT_MAX > 0:
+                    os.remove(save_models.popleft())
+            batch_start = time.time()
+    torch.cuda.synchronize()
+    total = sum(int(np.prod(p.shape)) for p in model.parameters())
+    if rank == 0:
+        print("Total params: {}".format(total))
+    return model
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Evaluation entry point (reference: semantic_segmentation/val.py:34-231, val_in_train.py:19-125).
+
+    python -m emrt_amd.val --config <yaml> --model_path <iter_N_state.pt> [--data tiles.npz]
+
+Single-scale sliding-window inference (src/api/infer.py) over a set of tiles, per-image area accumulation, one
+all-reduce of the [3, ncls] int64 areas at the end when WORLD_SIZE > 1 (the reference all-gathers three tensors per
+image, val.py:164-170), then mIoU / Acc / Kappa / per-class F1 exactly as val.py:197-209 prints them.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from .config import get_config, update_config
+from .distributed import init_process_group
+from .runtime import BF16, F32
+from .src.api import infer
+from .src.models import get_model
+from .src.utils import metrics
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="EMRT (MI355X HIP path) evaluation")
+    p.add_argument("--config", dest="cfg", type=str,
+                   default=os.path.join(os.path.dirname(__file__), "configs/EMRT/EMRT_256x256_160k_potsdam.yaml"))
+    p.add_argument("--model_path", default=None, type=str)
+    p.add_argument("--multi_scales", action="store_true", help="(reference flag; multi-scale/flip inference is not on this path yet)")
+    p.add_argument("--data", default="synthetic")
+    p.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"])
+    return p.parse_args(argv)
+
+
+def evaluate(model, images, labels, config, rank=0, nranks=1):
+    """images: list of fp32 [3,h,w] device tensors, labels: list of int64 [h,w].  Returns the reference's metric tuple."""
+    model.eval()
+    ncls = config.DATA.NUM_CLASSES
+    tot = torch.zeros(3, ncls, dtype=torch.int64, device=images[0].device)
+    t0 = time.time()
+    for i in range(rank, len(images), nranks):
+        pred = infer.ss_inference(model, [images[i]], [labels[i].shape[-2:]], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
+                                  config.VAL.CROP_SIZE, ncls, config.VAL.RESCALE_FROM_ORI)[0]
+        inter, pa, la = metrics.calculate_area(pred, labels[i], ncls, config.TRAIN.IGNORE_INDEX)
+        tot[0] += inter
+        tot[1] += pa
+        tot[2] += la
+    if nranks > 1:
+        torch.distributed.all_reduce(tot)
+    class_iou, miou = metrics.mean_iou(tot[0], tot[1], tot[2])
+    acc, class_acc, class_rec = metrics.accuracy(tot[0], tot[1], tot[2])
+    kap = metrics.kappa(tot[0], tot[1], tot[2])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        class_f1 = np.nan_to_num(2 * class_acc * class_rec / (class_acc + class_rec))
+    return time.time() - t0, miou, acc, kap, class_iou, class_acc, class_f1, float(np.mean(class_f1))
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config = update_config(get_config(), args)
+    if args.multi_scales:
+        raise NotImplementedError("multi-scale/flip inference (infer.py:160-260) is listed as NEXT in SURVEY.md 8(f)-3")
+    rank, local_rank, nranks = init_process_group()
+    model = get_model(config)
+    if args.model_path:
+        ck = torch.load(args.model_path, map_location="cpu")
+        model.load_state_dict(ck.get("model", ck))
+    model.to_hip("cuda:%d" % local_rank, BF16 if args.dtype == "bf16" else F32)
+    dev = torch.device("cuda", local_rank)
+    if args.data == "synthetic":
+        g = torch.Generator().manual_seed(0)
+        h = w = config.VAL.IMAGE_BASE_SIZE or config.DATA.CROP_SIZE[0]
+        images = [torch.randn(3, h, w, generator=g).to(dev) for _ in range(8)]
+        labels = [torch.randint(0, config.DATA.NUM_CLASSES, (h, w), generator=g).to(dev) for _ in range(8)]
+    else:
+        z = np.load(args.data)
+        images = [torch.from_numpy(a).float().to(dev) for a in z["images"]]
+        labels = [torch.from_numpy(a).long().to(dev) for a in z["labels"]]
+    if list(config.VAL.STRIDE_SIZE) == [320, 320] and list(config.VAL.CROP_SIZE)[0] < 320:
+        config.VAL.STRIDE_SIZE = list(config.VAL.CROP_SIZE)   # default stride > crop leaves NaN stripes
+    cost, miou, acc, kap, ciou, cacc, cf1, mf1 = evaluate(model, images, labels, config, rank, nranks)
+    if rank == 0:
+        print("[EVAL] Images: {}  mIoU: {:.4f}  Acc: {:.4f}  Kappa: {:.4f}  mF1: {:.4f}".format(len(images), miou, acc, kap, mf1))
+        print("[EVAL] Class IoU: " + str(np.round(ciou, 4)))
+        print("[EVAL] Class Acc: " + str(np.round(cacc, 4)))
+        print("[EVAL] Class F1-score: " + str(np.round(cf1, 4)))
+    return miou
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+/* emrt_hip.h -- C-ABI of libemrt_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the EMRT per-tile
+ * forward/backward hot path (ResNet-50 -> MSDeformAttn encoder -> cross-attention decoder -> segmentation head).
+ *
+ * The reference (peach-xiao/EMRT) is pure PaddlePaddle Python and has no FFI layer of its own: the
+ * arithmetic lives in Paddle's cuDNN/cuBLAS/CUDA operators.  Each entry point below therefore names the Paddle
+ * operator CALL SITE in the reference that it replaces (paths relative to
+ * /root/reference/semantic_segmentation/src/models/).  The reference-side binding a maintainer would add is the
+ * ctypes stub shown in INTEGRATION.md (the same one emrt_amd/_lib.py generates from this header).
+ *
+ * Conventions (all entry points):
+ *  - plain C, no C++/torch types; every pointer is a caller-owned DEVICE pointer unless marked "host";
+ *  - the library never allocates, frees or synchronises: work is enqueued on `stream` (a hipStream_t; 0 = default),
+ *    so calls can be captured in a hipGraph; workspaces are sized by the *_workspace_bytes queries;
+ *  - returns 0 on success, negative on error; emrt_last_error() gives a thread-local message;
+ *  - dtype: 0 = float32, 1 = bfloat16 (storage type of activations / packed weights; accumulation is always fp32);
+ *  - activations are NHWC: `ld` = pixel (row) stride in elements, `bs` = batch stride in elements, so a level slab
+ *    of the [B, Lv, C] token tensor or a channel slice of a concat buffer is addressed in place.
+ */
+#ifndef EMRT_HIP_H
+#define EMRT_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMRT_DTYPE_F32 0
+#define EMRT_DTYPE_BF16 1
+
+const char* emrt_last_error(void);
+int emrt_abi_version(void);
+int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len);
+
+/* ---- convolution / linear as implicit GEMM (MFMA 32x32) ---------------------------------------------------
+ * replaces nn.Conv2D: backbones/paddle_vision_resnet.py:108-123,192-198,226-233; paddle_EMRT.py:16-23,63,85-91,
+ * 134-138,201-209; decoders/fcn_head.py:52,66; EMRT_utils/transformer_encoder_decoder.py:125-144,374-378
+ * and nn.Linear / F.linear: transformer_encoder_decoder.py:36-42,118-121,259-262,371; EMRT_utils/layers.py:221-229,306.
+ * mode 0: out = conv(in, W) [+bias][+residual][relu];  w_packed = [OC][KH][KW][C]  (dims N,H,W,C describe `in`)
+ * mode 1: data gradient; `in` is dY (N,H,W,C = its dims), out is dX (OH,OW,OC), w_packed = [Cin][KH][KW][Cout]. */
+int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, int dtype, void* stream);
+/* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C] */
+int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, int dtype, void* stream);
+
+/* ---- BatchNorm / SyncBatchNorm (train: stats -> [all-reduce of sums across ranks] -> finalize -> apply) ---------
+ * replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add): paddle_vision_resnet.py:132-147;
+ * paddle_EMRT.py:18,22,64,86-91,131,139-141,203,206; fcn_head.py:53. */
+size_t emrt_colreduce_workspace_bytes(long long M, int C);
+int emrt_bn_stats(const void* x, int ldx, long long M, int C, float* sums, void* workspace, int dtype, void* stream);
+int emrt_bn_finalize(const float* sums, double count, int C, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, void* stream);
+int emrt_bn_eval_stats(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd, void* stream);
+int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const float* mean, const float* invstd, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
+int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, float* sums, void* workspace, int dtype, void* stream);
+int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_count, float* dgamma, float* dbeta, long long M, int C, int dtype, void* stream);
+/* per-channel sum accumulated into dbias (bias / embedding gradients) */
+int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
+
+/* ---- GroupNorm(32) [+ erf-GELU] [+ residual]: transformer_encoder_decoder.py:125-144 (conv branch), :378 (input_proj) */
+int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream);
+int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, int N, int HW, int C, int G, int gelu, int dtype, void* stream);
+
+/* ---- residual add + LayerNorm (+ post add): transformer_encoder_decoder.py:199-203,159-160,285-291,278-279
+ * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward. */
+int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma, const float* beta, float* mean, float* rstd, long long rows, int C, float eps, int dtype, void* stream);
+size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C);
+int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, long long rows, int C, void* workspace, int dtype, void* stream);
+
+/* ---- multi-scale deformable attention core (fused softmax + sampling locations + bilinear gather + weighted sum)
+ * replaces transformer_encoder_decoder.py:89-104 and EMRT_utils/utils.py:64-97 (deformable_attention_core_func).
+ * value [B][Lv][M*D] (D = 32); offw fp32 [B*Lq][ldo] = M*L*P*2 offsets then M*L*P logits per row;
+ * ref fp32 [B or 1][Lq][ref_L][2] (ref_bs = 0 broadcasts over batch; ref_L = L, or 1 to share one point across levels); shapes_hw: HOST int [L][2] = (H_l, W_l); out [B][Lq][M*D]. */
+int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, void* out, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream);
+/* dvalue fp32 [B][Lv][M*D] must be zeroed by the caller (atomically accumulated); doffw [B*Lq][ldo] and
+ * dref [B][Lq][ref_L][2] (nullable) are overwritten. */
+int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, float* dvalue, float* doffw, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream);
+
+/* ---- fused softmax(QK^T/sqrt(d)) V with dropout on the weights: EMRT_utils/layers.py:283-303 (L <= 128, D = 32) */
+int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
+int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* probs, const void* dout, int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
+
+/* ---- bilinear F.interpolate (align_corners True/False), optional fused "+ add", strided (concat-slice) output,
+ * optional fp32 NCHW output for the returned logits: paddle_EMRT.py:40,44,169,174,180,288-289,301; fcn_head.py:80 */
+int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs, int out_ld, int OH, int OW, const void* add, long long add_bs, int add_ld, int N, int C, int align_corners, int out_nchw_f32, int dtype, void* stream);
+int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs, int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, int dtype, void* stream);
+/* nn.AdaptiveAvgPool2D(k), k in scales (host int[nscales], <= 4), all scales in one launch -> tokens [N][sum k^2][C]:
+ * paddle_EMRT.py:62,70-78 */
+int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs, int out_ld, int N, int C, const int* scales, int nscales, int dtype, void* stream);
+int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void* din, long long di_bs, int di_ld, int H, int W, int N, int C, const int* scales, int nscales, int dtype, void* stream);
+/* nn.MaxPool2D(3, 2, 1): paddle_vision_resnet.py:201; paddle_EMRT.py:84 (dense NHWC) */
+int emrt_maxpool_fwd(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
+int emrt_maxpool_bwd(const void* in, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
+/* model input: fp32 NCHW images (paddle_EMRT.py:252) -> NHWC compute dtype */
+int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream);
+
+/* ---- loss: nn.CrossEntropyLoss(ignore_index, axis=1) on fp32 NCHW logits, int64 labels:
+ * losses/mix_softmax_cross_entropy_loss.py:27-35.  result (device float[2]) = {mean loss, non-ignored count}. */
+size_t emrt_ce_workspace_bytes(void);
+int emrt_softmax_ce_fwd(const float* logits, const long long* labels, int N, int C, int H, int W, int ignore_index, float* result, void* workspace, void* stream);
+int emrt_softmax_ce_bwd(const float* logits, const long long* labels, const float* result, const float* upstream, float weight, int N, int C, int H, int W, int ignore_index, float* dlogits, void* stream);
+int emrt_scalar_axpby(float* out, const float* a, float wa, const float* b, float wb, void* stream);
+
+/* ---- optimizer: ClipGradByGlobalNorm + L2 decay + Momentum over one flat fp32 buffer, PolynomialDecay evaluated
+ * on the device from a step counter: solver/optimizer.py:29-40, solver/lr_scheduler.py:244-248.
+ * ranges: HOST int64 [nranges][2] element ranges whose lr is multiplied by range_mult (ParamAttr(learning_rate=0.1),
+ * transformer_encoder_decoder.py:36-38,371-372). */
+size_t emrt_gradnorm_workspace_bytes(void);
+int emrt_grad_clip_scale(const float* grads, long long n, float clip, float* state, void* workspace, void* stream);
+int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state, const long long* step, float base_lr, float end_lr, float power, long long decay_steps, float momentum, float weight_decay, const long long* ranges, int nranges, float range_mult, float* lr_out, void* stream);
+int emrt_counter_add(long long* counter, long long delta, void* stream);
+/* fp32 master weights -> compute-dtype forward copy [OC][taps][C] and transposed dgrad copy [C][taps][OC];
+ * desc_dev: DEVICE int64 [ndesc][8] = {src_off, fwd_off|-1, bwd_off|-1, OC, taps, C, first_tile, 0}. */
+int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles, int dtype, void* stream);
+
+/* ---- small streaming ops: with_pos_embed adds, nn.Dropout/nn.Dropout2D (mode 1), ReLU/dropout backward masks,
+ * F.sigmoid, casts: transformer_encoder_decoder.py:115-122,154-161,250-263,273-280,466; paddle_EMRT.py:208; fcn_head.py:65 */
+int emrt_add(const void* a, const void* b, void* out, long long n, long long period, int dtype, void* stream);
+int emrt_add2d(const void* a, long long a_rs, const void* b, long long b_rs, void* out, long long out_rs, long long rows, long long cols, int dtype, void* stream);
+int emrt_acc2d(void* dst, long long dst_rs, const void* src, long long src_rs, long long rows, long long cols, int dtype, void* stream);
+int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream);
+int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode, long long hw, int C, int dtype, void* stream);
+int emrt_mask_bwd(const void* dy, const void* relu_out, void* dx, long long n, float p, const unsigned long long* seed, unsigned salt, int mode, long long hw, int C, int dtype, void* stream);
+int emrt_sigmoid_fwd(const float* x, float* y, long long n, void* stream);
+int emrt_sigmoid_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
+int emrt_cast(const void* in, void* out, long long n, int direction, int dtype, void* stream);
+int emrt_memset(void* ptr, int value, size_t bytes, void* stream);
+
+/* ---- HIP events on the caller's stream (bench.py roofline timing) ---- */
+int emrt_event_create(void** ev);
+int emrt_event_record(void* ev, void* stream);
+int emrt_event_elapsed_ms(void* start, void* stop, float* ms);
+int emrt_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMRT_HIP_H */

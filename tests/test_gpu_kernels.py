@@ -1,0 +1,582 @@
+"""-m gpu parity tests, kernel level: every libemrt_hip.so op (through the C-ABI, via emrt_amd.functional) against the
+torch-CPU expression the oracle uses for the same reference operator.  fp32: tight tolerances; bf16: inputs are
+rounded through bf16 on both sides and tolerances reflect bf16 storage of the outputs.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from emrt_amd import functional as Fn          # noqa: E402
+from emrt_amd import nn as hnn                  # noqa: E402
+from emrt_amd.runtime import ctx, F32, BF16, Tape   # noqa: E402
+from tests.hip_utils import init, dev_map, host_map, dev, host, rnd, Holder, close   # noqa: E402
+
+DTYPES = [F32, BF16]
+
+
+def run_bwd(tape, outs_and_grads, watched):
+    for o, g in outs_and_grads:
+        tape.add_grad(o, g)
+    tape.backward()
+    return [tape.result(w) for w in watched]
+
+
+# -----------------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, bias
+    (2, 16, 16, 64, 64, 3, 1, 1, False),
+    (2, 16, 16, 128, 128, 3, 2, 1, False),
+    (2, 12, 20, 256, 512, 1, 1, 0, True),
+    (3, 16, 16, 64, 256, 1, 2, 0, False),
+    (2, 32, 32, 3, 64, 7, 2, 3, False),
+    (2, 16, 16, 3, 64, 3, 1, 1, False),
+    (2, 24, 24, 256, 6, 1, 1, 0, True),
+    (1, 40, 40, 64, 192, 3, 1, 1, True),
+    (2, 8, 8, 512, 128, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(dtype, case):
+    N, H, W, Cin, Cout, k, stride, pad, bias = case
+    c = init(dtype)
+    g = torch.Generator().manual_seed(1)
+    x = rnd(torch.randn(N, Cin, H, W, generator=g))
+    conv = hnn.Conv2D(Cin, Cout, k, stride, pad, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)))
+        if bias:
+            conv.bias.copy_(torch.randn(Cout, generator=g))
+    w_ref, b_ref = conv.weight.detach().clone(), (conv.bias.detach().clone() if bias else None)
+    Holder(conv=conv).place()
+    xr = x.clone().requires_grad_(True)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    dy = rnd(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+
+    xd = dev_map(x)
+    tape = Tape()
+    c.tape = tape
+    y = conv(xd)
+    c.tape = None
+    tape.watch(xd)
+    scale = 1.0
+    close("conv fwd", host_map(y), yr.detach(), dtype, scale)
+    dx, = run_bwd(tape, [(y, dev_map(dy))], [xd])
+    kscale = math.sqrt(Cout * k * k / (stride * stride))
+    close("conv dgrad", host_map(dx), xr.grad, dtype, kscale * (1.0 if dtype == F32 else 0.3))
+    wscale = math.sqrt(N * yr.shape[2] * yr.shape[3])
+    close("conv wgrad", host(conv.weight.grad), wr.grad, dtype, wscale * (1.0 if dtype == F32 else 0.3))
+    if bias:
+        close("conv bias grad", host(conv.bias.grad), br.grad, dtype, wscale)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_views_residual_relu(dtype):
+    """token-slab input view, concat-slice output view, fused bias + residual + relu epilogue, fp32 output."""
+    c = init(dtype)
+    g = torch.Generator().manual_seed(2)
+    B, h, w, C, OC = 2, 8, 8, 64, 128
+    Lv = h * w + 16
+    tokens = rnd(torch.randn(B, Lv, C, generator=g))
+    conv = hnn.Conv2D(C, OC, 3, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(OC, C, 3, 3, generator=g) / 24))
+        conv.bias.copy_(torch.randn(OC, generator=g))
+    wref, bref = conv.weight.detach().clone(), conv.bias.detach().clone()
+    Holder(conv=conv).place()
+    res = rnd(torch.randn(B, OC, h, w, generator=g))
+    td = dev(tokens)
+    xin = Fn.tokens_as_map(td.narrow(1, 16, h * w), h, w)
+    cat = c.zeros((B, h, w, 3 * OC))
+    out = cat.narrow(3, OC, OC)
+    y = Fn.conv2d(xin, conv.gw, 1, 1, relu=True, residual=dev_map(res), out=out)
+    xr = tokens[:, 16:].transpose(1, 2).reshape(B, C, h, w)
+    yr = F.relu(F.conv2d(xr, wref, bref, padding=1) + res)
+    close("conv view fwd", host_map(cat[..., OC:2 * OC].contiguous()), yr, dtype)
+    assert float(cat[..., :OC].float().abs().max()) == 0 and float(cat[..., 2 * OC:].float().abs().max()) == 0
+    y32 = Fn.conv2d(xin, conv.gw, 1, 1, out_f32=True)
+    assert y32.dtype == torch.float32
+    close("conv f32 out", host_map(y32), F.conv2d(xr, wref, bref, padding=1), dtype, atol=(2e-4 if dtype == F32 else 2e-2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_relu_backward(dtype):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(3)
+    B, L, C, OC = 2, 37, 256, 1024
+    x = rnd(torch.randn(B, L, C, generator=g))
+    lin = hnn.Linear(C, OC)
+    with torch.no_grad():
+        lin.weight.copy_(rnd(torch.randn(OC, C, generator=g) / 16))
+        lin.bias.copy_(torch.randn(OC, generator=g) * 0.1)
+    wref, bref = lin.weight.detach().clone(), lin.bias.detach().clone()
+    Holder(lin=lin).place()
+    xr = x.clone().requires_grad_(True)
+    wr, br = wref.clone().requires_grad_(True), bref.clone().requires_grad_(True)
+    yr = F.relu(F.linear(xr, wr, br))
+    dy = rnd(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    xd = dev(x)
+    tape = Tape()
+    c.tape = tape
+    y = lin(xd, relu=True)
+    c.tape = None
+    tape.watch(xd)
+    close("linear fwd", host(y), yr.detach(), dtype)
+    dx, = run_bwd(tape, [(y, dev(dy))], [xd])
+    close("linear dx", host(dx), xr.grad, dtype, 8.0)
+    close("linear dw", host(lin.weight.grad), wr.grad, dtype, 8.0)
+    close("linear db", host(lin.bias.grad), br.grad, dtype, 8.0)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 16, 16, 64), (2, 8, 8, 512), (8, 3, 3, 256), (2, 32, 32, 2048)])
+@pytest.mark.parametrize("relu,with_res", [(True, True), (True, False), (False, False)])
+def test_batch_norm_train(dtype, shape, relu, with_res):
+    N, H, W, C = shape
+    c = init(dtype)
+    g = torch.Generator().manual_seed(4)
+    x = rnd(torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
+    res = rnd(torch.randn(N, C, H, W, generator=g)) if with_res else None
+    bn = hnn.BatchNorm2D(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    gam, bet = bn.weight.detach().clone(), bn.bias.detach().clone()
+    Holder(bn=bn).place()
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    gr, br_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    o = F.batch_norm(xr, None, None, gr, br_, True, 0.1, 1e-5)
+    if with_res:
+        o = o + rr
+    if relu:
+        o = F.relu(o)
+    dy = rnd(torch.randn(o.shape, generator=g))
+    o.backward(dy)
+    xd = dev_map(x)
+    rd = dev_map(res) if with_res else None
+    tape = Tape()
+    c.tape = tape
+    y = bn(xd, relu=relu, residual=rd)
+    c.tape = None
+    tape.watch(xd)
+    if rd is not None:
+        tape.watch(rd)
+    close("bn fwd", host_map(y), o.detach(), dtype)
+    outs = run_bwd(tape, [(y, dev_map(dy))], [xd] + ([rd] if rd is not None else []))
+    close("bn dx", host_map(outs[0]), xr.grad, dtype, 2.0)
+    if with_res:
+        close("bn dres", host_map(outs[1]), rr.grad, dtype)
+    sc = math.sqrt(N * H * W)
+    close("bn dgamma", host(bn.weight.grad), gr.grad, dtype, sc)
+    close("bn dbeta", host(bn.bias.grad), br_.grad, dtype, sc)
+    # running statistics: Paddle convention (momentum 0.9, biased variance)
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    close("bn run_mean", host(bn._buffers["_mean"]), 0.1 * mean, F32, atol=1e-4)
+    close("bn run_var", host(bn._buffers["_variance"]), 0.9 + 0.1 * var, F32, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batch_norm_eval_and_slice_output(dtype):
+    c = init(dtype)
+    c.training = False
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C = 2, 8, 8, 256
+    x = rnd(torch.randn(N, C, H, W, generator=g))
+    bn = hnn.BatchNorm2D(C)
+    with torch.no_grad():
+        bn._mean.copy_(torch.randn(C, generator=g) * 0.3)
+        bn._variance.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+    rm, rv, gam, bet = bn._mean.clone(), bn._variance.clone(), bn.weight.detach().clone(), bn.bias.detach().clone()
+    Holder(bn=bn).place()
+    cat = c.zeros((N, H, W, 3 * C))
+    bn(dev_map(x), relu=True, out=cat.narrow(3, C, C))
+    ref = F.relu(F.batch_norm(x, rm, rv, gam, bet, False, 0.1, 1e-5))
+    close("bn eval slice", host_map(cat[..., C:2 * C].contiguous()), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("gelu,with_res", [(True, True), (False, False)])
+def test_group_norm(dtype, gelu, with_res):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(6)
+    N, H, W, C = 3, 16, 16, 256
+    x = rnd(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3)
+    res = rnd(torch.randn(N, C, H, W, generator=g)) if with_res else None
+    gn = hnn.GroupNorm(32, C)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    gam, bet = gn.weight.detach().clone(), gn.bias.detach().clone()
+    Holder(gn=gn).place()
+    xr = x.clone().requires_grad_(True)
+    gr, br_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    o = F.group_norm(xr, 32, gr, br_, 1e-5)
+    if gelu:
+        o = F.gelu(o)
+    rr = None
+    if with_res:
+        rr = res.clone().requires_grad_(True)
+        o = o + rr
+    dy = rnd(torch.randn(o.shape, generator=g))
+    o.backward(dy)
+    xd = dev_map(x)
+    rd = dev_map(res) if with_res else None
+    tape = Tape()
+    c.tape = tape
+    y = gn(xd, gelu=gelu, residual=rd)
+    c.tape = None
+    tape.watch(xd)
+    if rd is not None:
+        tape.watch(rd)
+    close("gn fwd", host_map(y), o.detach(), dtype)
+    outs = run_bwd(tape, [(y, dev_map(dy))], [xd] + ([rd] if rd is not None else []))
+    close("gn dx", host_map(outs[0]), xr.grad, dtype, 2.0)
+    if with_res:
+        close("gn dres", host_map(outs[1]), rr.grad, dtype)
+    sc = math.sqrt(N * H * W)
+    close("gn dgamma", host(gn.weight.grad), gr.grad, dtype, sc)
+    close("gn dbeta", host(gn.bias.grad), br_.grad, dtype, sc)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layer_norm_residual_post(dtype):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(7)
+    B, L, C = 3, 113, 256
+    a, b, post = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(3))
+    ln = hnn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    gam, bet = ln.weight.detach().clone(), ln.bias.detach().clone()
+    Holder(ln=ln).place()
+    ar, br_, pr = (t.clone().requires_grad_(True) for t in (a, b, post))
+    gr, ber = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    zr = rnd((ar + br_).detach()) if dtype == BF16 else None
+    o = F.layer_norm(ar + br_, (C,), gr, ber, 1e-5) + pr
+    dy = rnd(torch.randn(o.shape, generator=g))
+    o.backward(dy)
+    ad, bd, pd = dev(a), dev(b), dev(post)
+    tape = Tape()
+    c.tape = tape
+    y = ln(ad, bd, post=pd)
+    c.tape = None
+    for t in (ad, bd, pd):
+        tape.watch(t)
+    close("ln fwd", host(y), o.detach(), dtype)
+    da, db, dp = run_bwd(tape, [(y, dev(dy))], [ad, bd, pd])
+    close("ln da", host(da), ar.grad, dtype, 2.0)
+    close("ln db", host(db), br_.grad, dtype, 2.0)
+    close("ln dpost", host(dp), pr.grad, dtype)
+    sc = math.sqrt(B * L)
+    close("ln dgamma", host(ln.weight.grad), gr.grad, dtype, sc)
+    close("ln dbeta", host(ln.bias.grad), ber.grad, dtype, sc)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+def _msda_ref(value, offw, ref, shapes, M, L, Pn):
+    from oracle.emrt_torch import deformable_attention_core_func
+    B, Lq = offw.shape[:2]
+    tp = M * L * Pn
+    off = offw[..., :2 * tp].reshape(B, Lq, M, L, Pn, 2)
+    aw = torch.softmax(offw[..., 2 * tp:3 * tp].reshape(B, Lq, M, L * Pn), -1).reshape(B, Lq, M, L, Pn)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).reshape(1, 1, 1, L, 1, 2)
+    rl = ref.expand(B, Lq, L if ref.shape[2] == L else 1, 2)
+    if rl.shape[2] == 1:
+        rl = rl.expand(B, Lq, L, 2)
+    loc = rl.reshape(B, Lq, 1, L, 1, 2) + off / norm
+    return deformable_attention_core_func(value.reshape(B, -1, M, 32), shapes, loc, aw)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [dict(B=2, Lq=None, shapes=[(8, 8), (4, 4), (2, 2)], refL=1, shared=True),
+                                 dict(B=3, Lq=37, shapes=[(16, 12), (8, 6), (4, 3)], refL=1, shared=True),
+                                 dict(B=2, Lq=21, shapes=[(8, 8), (4, 4), (2, 2)], refL=3, shared=False)])
+def test_msda_fwd_bwd(dtype, cfg):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(8)
+    M, L, Pn = 8, 3, 6
+    shapes = cfg["shapes"]
+    Lv = sum(h * w for h, w in shapes)
+    B = cfg["B"]
+    Lq = cfg["Lq"] or Lv
+    tp = M * L * Pn
+    value = rnd(torch.randn(B, Lv, M * 32, generator=g))
+    offw = torch.cat([torch.randn(B, Lq, 2 * tp, generator=g) * 2.0, torch.randn(B, Lq, tp, generator=g)], -1)
+    ref = torch.rand(1 if cfg["shared"] else B, Lq, cfg["refL"], 2, generator=g) * 1.2 - 0.1    # some samples fall outside
+    vr, orq, rr = value.clone().requires_grad_(True), offw.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+    out_r = _msda_ref(vr, orq, rr, shapes, M, L, Pn)
+    dy = rnd(torch.randn(out_r.shape, generator=g))
+    out_r.backward(dy)
+    vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.msda(vd, od, rd, shapes, M, Pn, need_dref=True)
+    c.tape = None
+    for t in (vd, od, rd):
+        tape.watch(t)
+    close("msda fwd", host(y), out_r.detach(), dtype)
+    dv, do, dr = run_bwd(tape, [(y, dev(dy))], [vd, od, rd])
+    close("msda dvalue", host(dv), vr.grad, dtype, 2.0)
+    close("msda doffw", host(do), orq.grad, dtype, 4.0, atol=(5e-4 if dtype == F32 else 6e-2))
+    close("msda dref", host(dr), rr.grad, dtype, 64.0, atol=(5e-4 if dtype == F32 else 6e-2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mha_fwd_bwd(dtype):
+    c = init(dtype)
+    c.training = False   # no dropout
+    g = torch.Generator().manual_seed(9)
+    B, L, E, Mh = 3, 110, 256, 8
+    qk = rnd(torch.randn(B, L, 2 * E, generator=g))
+    v = rnd(torch.randn(B, L, E, generator=g))
+    qkr, vr = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    q = qkr[..., :E].reshape(B, L, Mh, 32).transpose(1, 2)
+    k = qkr[..., E:].reshape(B, L, Mh, 32).transpose(1, 2)
+    vv = vr.reshape(B, L, Mh, 32).transpose(1, 2)
+    w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), -1)
+    o = (w @ vv).transpose(1, 2).reshape(B, L, E)
+    dy = rnd(torch.randn(o.shape, generator=g))
+    o.backward(dy)
+    qd, vd = dev(qk), dev(v)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.mha(qd, vd, Mh, 0.1, 3)
+    c.tape = None
+    tape.watch(qd)
+    tape.watch(vd)
+    close("mha fwd", host(y), o.detach(), dtype)
+    dqk, dv = run_bwd(tape, [(y, dev(dy))], [qd, vd])
+    close("mha dqk", host(dqk), qkr.grad, dtype)
+    close("mha dv", host(dv), vr.grad, dtype)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 16, 16, True), (2, 8, 8, 64, 16, 16, False), (2, 3, 3, 256, 32, 32, True),
+                                  (1, 6, 6, 128, 32, 32, True), (2, 1, 1, 64, 8, 8, True), (2, 16, 12, 6, 64, 48, False),
+                                  (2, 10, 10, 32, 10, 10, True)])
+def test_resize_bilinear(dtype, case):
+    N, IH, IW, C, OH, OW, ac = case
+    c = init(dtype)
+    g = torch.Generator().manual_seed(10)
+    x = rnd(torch.randn(N, C, IH, IW, generator=g))
+    add_t = rnd(torch.randn(N, C, OH, OW, generator=g))
+    xr, ar = x.clone().requires_grad_(True), add_t.clone().requires_grad_(True)
+    o = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=ac) + ar
+    dy = rnd(torch.randn(o.shape, generator=g))
+    o.backward(dy)
+    xd, ad = dev_map(x), dev_map(add_t)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.resize_bilinear(xd, OH, OW, ac, add_t=ad)
+    c.tape = None
+    tape.watch(xd)
+    tape.watch(ad)
+    close("resize fwd", host_map(y), o.detach(), dtype)
+    dx, da = run_bwd(tape, [(y, dev_map(dy))], [xd, ad])
+    close("resize dx", host_map(dx), xr.grad, dtype, float(max(1, (OH // IH) * (OW // IW))) ** 0.5)
+    close("resize dadd", host_map(da), ar.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resize_to_nchw_logits(dtype):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(11)
+    N, IH, IW, C = 2, 16, 16, 6
+    x = rnd(torch.randn(N, C, IH, IW, generator=g))
+    xr = x.clone().requires_grad_(True)
+    o = F.interpolate(xr, size=(32, 32), mode="bilinear", align_corners=False)
+    dy = torch.randn(o.shape, generator=g)
+    o.backward(dy)
+    xd = dev_map(x)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.resize_bilinear(xd, 32, 32, False, out_nchw_f32=True)
+    c.tape = None
+    tape.watch(xd)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (N, C, 32, 32)
+    close("resize nchw fwd", y.cpu(), o.detach(), dtype, atol=1e-5 if dtype == F32 else None)
+    dx, = run_bwd(tape, [(y, dev(dy, torch.float32))], [xd])
+    close("resize nchw dx", host_map(dx), xr.grad, dtype, 2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adaptive_pool_and_maxpool(dtype):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(12)
+    N, H, W, C = 2, 32, 32, 64
+    x = rnd(torch.randn(N, C, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    scales = [1, 3, 6, 8]
+    toks = torch.cat([F.adaptive_avg_pool2d(xr, k).reshape(N, C, -1) for k in scales], -1).transpose(1, 2)
+    dy = rnd(torch.randn(toks.shape, generator=g))
+    toks.backward(dy)
+    xd = dev_map(x)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.adaptive_avgpool_tokens(xd, scales)
+    c.tape = None
+    tape.watch(xd)
+    close("pool fwd", host(y), toks.detach(), dtype)
+    dx, = run_bwd(tape, [(y, dev(dy))], [xd])
+    close("pool dx", host_map(dx), xr.grad, dtype)
+    # max pool, with ties (post-ReLU style input)
+    x2 = rnd(F.relu(torch.randn(N, C, 17, 19, generator=g)))
+    x2r = x2.clone().requires_grad_(True)
+    m = F.max_pool2d(x2r, 3, 2, 1)
+    dm = rnd(torch.randn(m.shape, generator=g))
+    m.backward(dm)
+    x2d = dev_map(x2)
+    tape = Tape()
+    c.tape = tape
+    y2 = Fn.maxpool(x2d, 3, 2, 1)
+    c.tape = None
+    tape.watch(x2d)
+    close("maxpool fwd", host_map(y2), m.detach(), dtype, atol=0, rtol=0)
+    dx2, = run_bwd(tape, [(y2, dev_map(dm))], [x2d])
+    close("maxpool dx", host_map(dx2), x2r.grad, dtype)
+
+
+def test_nchw_ingest_and_elementwise():
+    for dtype in DTYPES:
+        c = init(dtype)
+        g = torch.Generator().manual_seed(13)
+        img = torch.randn(2, 3, 16, 24, generator=g)
+        y = Fn.nchw_to_nhwc(img.cuda())
+        close("ingest", host_map(y), rnd(img), dtype, atol=0, rtol=0)
+        a, b = rnd(torch.randn(2, 21, 64, generator=g)), rnd(torch.randn(21, 64, generator=g))
+        s = Fn.add(dev(a), dev(b), period=21 * 64)
+        close("add bcast", host(s), a + b, dtype)
+        # strided accumulate into a token slab and a channel slice
+        base = c.zeros((2, 21, 64))
+        Fn.add_into(base.narrow(1, 5, 16), dev(a[:, :16]))
+        ref = torch.zeros(2, 21, 64)
+        ref[:, 5:] += a[:, :16]
+        close("acc slab", host(base), ref, dtype)
+        cat = c.zeros((2, 4, 4, 192))
+        part = rnd(torch.randn(2, 4, 4, 64, generator=g))
+        Fn.add_into(cat.narrow(3, 64, 64), dev(part))
+        ref = torch.zeros(2, 4, 4, 192)
+        ref[..., 64:128] = part
+        close("acc slice", host(cat), ref, dtype)
+        sg = Fn.sigmoid_f32(dev(torch.linspace(-4, 4, 220), torch.float32))
+        close("sigmoid", sg.cpu(), torch.sigmoid(torch.linspace(-4, 4, 220)), F32, atol=1e-6)
+
+
+def test_dropout_statistics_and_determinism():
+    c = init(F32)
+    x = torch.ones(64, 1024)
+    xd = dev(x)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.dropout(xd, 0.1, 5)
+    c.tape = None
+    tape.watch(xd)
+    yh = host(y)
+    keep = (yh != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01, keep
+    assert torch.allclose(yh[yh != 0], torch.tensor(1.0 / 0.9))
+    dx, = run_bwd(tape, [(y, dev(torch.ones(64, 1024)))], [xd])
+    assert torch.equal(host(dx), yh)                      # same mask, same scale in backward
+    y2 = Fn.dropout(xd, 0.1, 6)
+    assert not torch.equal(host(y2), yh)                  # different salt -> different mask
+    # Dropout2D: whole (image, channel) planes
+    x4 = dev(torch.ones(4, 5, 5, 64))
+    y4 = host(Fn.dropout(x4, 0.3, 7, mode=1, hw=25))
+    per = y4.reshape(4, 25, 64)
+    assert ((per == 0).all(1) | (per != 0).all(1)).all()
+
+
+# -----------------------------------------------------------------------------------------------------------------
+def test_softmax_ce_and_optimizer():
+    c = init(F32)
+    g = torch.Generator().manual_seed(14)
+    N, C, H, W = 3, 6, 16, 20
+    logits = torch.randn(N, C, H, W, generator=g) * 2
+    labels = torch.randint(0, C, (N, H, W), generator=g)
+    labels[torch.rand(N, H, W, generator=g) < 0.1] = 255
+    lr_ = logits.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr_, labels, ignore_index=255)
+    (0.4 * ref).backward()
+    ld = dev(logits, torch.float32)
+    tape = Tape()
+    c.tape = tape
+    res = Fn.softmax_ce(ld, labels.cuda(), 255, weight=0.4)
+    c.tape = None
+    tape.watch(ld)
+    tape.backward()
+    close("ce loss", res[:1].cpu(), ref.detach().reshape(1), F32, atol=1e-5)
+    assert int(res[1].item()) == int((labels != 255).sum())
+    close("ce dlogits", tape.result(ld).cpu(), lr_.grad, F32, atol=1e-7)
+
+
+def test_sgd_momentum_matches_reference_optimizer():
+    from oracle.train_ref import MomentumRef, poly_lr
+    from emrt_amd.src.models.solver import Momentum, PolynomialDecay
+    c = init(F32)
+    g = torch.Generator().manual_seed(15)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = hnn.Linear(8, 12)
+            self.sampling_offsets = hnn.Linear(8, 4)     # lr_mult 0.1 by name
+            self.b = hnn.LayerNorm(12)
+
+    m = Tiny()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g))
+    refp = [(n, p.detach().clone().requires_grad_(True)) for n, p in m.named_parameters()]
+    store = hnn.ParamStore(m, c.device, F32, lr_mult_names=["sampling_offsets.weight", "sampling_offsets.bias"])
+    hnn.bind_all(m, store)
+    m.store = store
+    opt = Momentum(m, PolynomialDecay(0.01, 100, 0.0, 0.9), 0.9, 1e-4, 1.0)
+    ropt = MomentumRef(refp, 0.9, 1e-4, 1.0)
+    for step in range(3):
+        grads = {n: torch.randn(p.shape, generator=g) * (3.0 if step == 0 else 0.05) for n, p in refp}
+        for n, p in refp:
+            p.grad = grads[n].clone()
+        for n, p in m.named_parameters():
+            p.grad.copy_(grads[n].cuda())
+        ropt.step(poly_lr(step, 0.01, 0.0, 100, 0.9))
+        opt.step()
+        assert abs(opt.grad_norm() - ropt.last_grad_norm) < 1e-4 * max(1.0, ropt.last_grad_norm)
+        for (n, p), (_, q) in zip(refp, m.named_parameters()):
+            close("sgd step %d %s" % (step, n), q.detach().cpu(), p.detach(), F32, atol=1e-6, rtol=1e-5)
+    assert int(c.step_counter.item()) == 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_weights_layouts(dtype):
+    c = init(dtype)
+    g = torch.Generator().manual_seed(16)
+    conv = hnn.Conv2D(40, 72, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(72, 40, 3, 3, generator=g)))
+    w = conv.weight.detach().clone()
+    h = Holder(conv=conv).place()
+    esz = 4 if dtype == F32 else 2
+    base = h.store.packed.data_ptr()
+    if dtype == BF16:
+        off = (conv.gw.fwd_ptr - base) // esz
+        fwd = h.store.packed[off:off + w.numel()].float().cpu().view(72, 3, 3, 40)
+        assert torch.equal(fwd, w.permute(0, 2, 3, 1))
+    off = (conv.gw.bwd_ptr - base) // esz
+    bwd = h.store.packed[off:off + w.numel()].float().cpu().view(40, 3, 3, 72)
+    assert torch.equal(bwd, w.permute(1, 2, 3, 0))

@@ -1,0 +1,215 @@
+"""-m gpu parity tests, model level: the HIP EMRT (through get_model / config surface) against the torch-CPU oracle
+on identical weights and inputs.  fp32: logits within 1e-3, argmax masks bit-exact (BASELINE.json north_star);
+gradients, a 3-step training trace and hipGraph replay are checked too.  bf16 is checked for sanity/correlation."""
+import argparse
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from emrt_amd.config import get_config, update_config                    # noqa: E402
+from emrt_amd.runtime import ctx, F32, BF16                               # noqa: E402
+from emrt_amd.src.models import get_model                                  # noqa: E402
+from emrt_amd.src.models.losses import get_loss_function                   # noqa: E402
+from emrt_amd.src.models.solver import get_optimizer, get_scheduler        # noqa: E402
+from emrt_amd.engine import TrainEngine                                    # noqa: E402
+from oracle.emrt_torch import EMRT as OracleEMRT, BatchNorm2D as OBN        # noqa: E402
+from oracle import train_ref                                               # noqa: E402
+
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "emrt_amd/configs/EMRT/EMRT_256x256_160k_potsdam.yaml")
+
+
+def make_config(backbone="resnet18", iters=1000):
+    cfg = update_config(get_config(), argparse.Namespace(cfg=CFG))
+    cfg.MODEL.ENCODER.TYPE = backbone
+    cfg.TRAIN.ITERS = iters
+    return cfg
+
+
+def oracle_no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            mod.p = 0.0
+        if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+            mod.dropout = 0.0
+
+
+def calibrated_oracle(backbone, x, seed=0):
+    """Oracle with BN running statistics set from one batch (momentum 0 => running = batch) so that eval-mode
+    activations are O(1) with random-initialised weights."""
+    torch.manual_seed(seed)
+    ref = OracleEMRT(6, backbone)
+    oracle_no_dropout(ref)
+    for mod in ref.modules():
+        if isinstance(mod, OBN):
+            mod.momentum = 0.0
+    ref.train()
+    with torch.no_grad():
+        ref(x)
+    for mod in ref.modules():
+        if isinstance(mod, OBN):
+            mod.momentum = 0.9
+    return ref
+
+
+def build_pair(backbone, x, dtype=F32):
+    ref = calibrated_oracle(backbone, x)
+    model = get_model(make_config(backbone))
+    model.load_state_dict(ref.state_dict())
+    model.to_hip("cuda:0", dtype)
+    model.set_dropout(0.0)
+    return ref, model
+
+
+@pytest.mark.parametrize("backbone,B,S", [("resnet18", 2, 64), ("resnet50", 2, 64), ("resnet50", 1, 256)])
+def test_forward_logits_match_oracle_eval(backbone, B, S):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, S, S, generator=g)
+    ref, model = build_pair(backbone, x)
+    ref.eval()
+    model.eval()
+    with torch.no_grad():
+        want = ref(x)
+    got = model(x.cuda())
+    for name, a, b in (("main", got[0], want[0]), ("aux", got[1], want[1])):
+        a = a.cpu()
+        err = (a - b).abs().max().item()
+        assert a.shape == b.shape == (B, 6, S, S)
+        assert err < 1e-3, "%s logits: max |diff| %.3g (|ref| max %.3g)" % (name, err, b.abs().max().item())
+    assert torch.equal(got[0].cpu().argmax(1), want[0].argmax(1)), "argmax masks differ"
+
+
+def test_train_forward_and_gradients_match_oracle():
+    g = torch.Generator().manual_seed(7)
+    B, S = 2, 64
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
+    ref, model = build_pair("resnet50", x)
+    ref.train()
+    model.train()
+    out_r = ref(x)
+    loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
+    loss_r.backward()
+    loss_fn = get_loss_function(make_config("resnet50"))
+    model.clear_gradients()
+    out = model(x.cuda())
+    loss = loss_fn(out, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (out[0].cpu() - out_r[0].detach()).abs().max().item() < 1e-3
+    assert (out[1].cpu() - out_r[1].detach()).abs().max().item() < 1e-3
+    assert abs(loss.item() - loss_r.item()) < 1e-4 * max(1.0, abs(loss_r.item()))
+    refp = dict(ref.named_parameters())
+    worst = []
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None:
+            assert float(p.grad.abs().max()) == 0.0, "%s should receive no gradient" % n
+            continue
+        gg = p.grad.cpu()
+        denom = gr.abs().max().item() + 1e-6
+        rel = (gg - gr).abs().max().item() / denom
+        worst.append((rel, n, denom))
+    worst.sort(reverse=True)
+    bad = [w for w in worst if w[0] > 2e-2]
+    assert not bad, "gradient mismatch (rel max err, name, ref max): %s" % bad[:8]
+    # BN running statistics were updated identically
+    refb = dict(ref.named_buffers())
+    for n, b in model.named_buffers():
+        assert (b.cpu() - refb[n]).abs().max().item() < 1e-3 * (1 + refb[n].abs().max().item()), n
+
+
+def test_three_step_training_trace_matches_oracle():
+    g = torch.Generator().manual_seed(11)
+    B, S = 2, 64
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    ref, model = build_pair("resnet18", x)
+    cfg = make_config("resnet18", iters=100)
+    ref.train()
+    ropt = train_ref.MomentumRef(list(ref.named_parameters()), 0.9, 1e-4, 1.0)
+    sch = get_scheduler(cfg)
+    opt = get_optimizer(model, sch, cfg)
+    eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=False)
+    for step in range(3):
+        lr_ref_loss, lr_ref = train_ref.train_step(ref, ropt, x, labels, step, 0.01, 0.0, 100, 0.9)
+        lr_host = opt.get_lr()
+        loss_t = eng.step(x.cuda(), labels.cuda())
+        assert abs(lr_host - lr_ref) < 1e-12
+        assert abs(float(opt.lr_dev.item()) - lr_ref) < 1e-8
+        assert abs(loss_t.item() - lr_ref_loss) < 2e-3 * max(1.0, lr_ref_loss), (step, loss_t.item(), lr_ref_loss)
+        assert abs(opt.grad_norm() - ropt.last_grad_norm) < 2e-2 * ropt.last_grad_norm, (step, opt.grad_norm(), ropt.last_grad_norm)
+
+
+def test_hipgraph_replay_equals_eager():
+    g = torch.Generator().manual_seed(12)
+    B, S = 2, 64
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    losses = {}
+    for mode in ("eager", "graph"):
+        ref, model = build_pair("resnet18", x)
+        cfg = make_config("resnet18", iters=100)
+        opt = get_optimizer(model, get_scheduler(cfg), cfg)
+        eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=(mode == "graph"), warmup_eager=1)
+        ls = []
+        for _ in range(4):
+            ls.append(eng.step(x.cuda(), labels.cuda()).item())
+        losses[mode] = ls
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) < 1e-3 * max(1.0, abs(a)), losses
+    assert losses["graph"][-1] < losses["graph"][0], "loss should decrease on a repeated batch: %s" % losses
+
+
+def test_bf16_path_is_sane():
+    g = torch.Generator().manual_seed(13)
+    B, S = 2, 64
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    ref, model = build_pair("resnet50", x, BF16)
+    ref.eval()
+    model.eval()
+    with torch.no_grad():
+        want = ref(x)[0]
+    got = model(x.cuda())[0].cpu()
+    assert torch.isfinite(got).all()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+    assert cos > 0.98, cos
+    agree = (got.argmax(1) == want.argmax(1)).float().mean().item()
+    assert agree > 0.9, agree
+    model.train()
+    cfg = make_config("resnet50", iters=100)
+    opt = get_optimizer(model, get_scheduler(cfg), cfg)
+    eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=False)
+    l0 = eng.step(x.cuda(), labels.cuda()).item()
+    for _ in range(5):
+        l1 = eng.step(x.cuda(), labels.cuda()).item()
+    assert l1 == l1 and l1 < l0, (l0, l1)
+
+
+def test_sliding_window_inference_and_metrics():
+    from emrt_amd.src.api import infer
+    from emrt_amd.src.utils import metrics
+    from oracle import infer_ref
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    ref, model = build_pair("resnet18", x)
+    ref.eval()
+    model.eval()
+    img = torch.randn(3, 96, 128, generator=g)
+    with torch.no_grad():
+        want = infer_ref.slide_inference(ref, [img], (64, 64), (32, 32), 6)[0]
+    got = infer.slide_inference(model, [img.cuda()], (64, 64), (32, 32), 6)[0].cpu()
+    assert (got - want).abs().max().item() < 1e-3
+    pred = infer.ss_inference(model, [img.cuda()], [(96, 128)], True, 64, (32, 32), (64, 64), 6)[0]
+    wantp = infer_ref.logits_to_pred(want, (96, 128))
+    assert torch.equal(pred.cpu(), wantp)
+    lab = torch.randint(0, 6, (96, 128), generator=g)
+    lab[:4] = 255
+    a = metrics.calculate_area(pred, lab.cuda(), 6, 255)
+    b = infer_ref.calculate_area(wantp.numpy(), lab.numpy(), 6, 255)
+    for u, v in zip(a, b):
+        assert u.cpu().tolist() == v.tolist()
