@@ -44,35 +44,41 @@ __global__ __launch_bounds__(256) void add_f32row_kernel(const T* __restrict__ a
   }
 }
 
-// dst[r][c] += src[r][c] over a rows x cols window of two strided matrices (gradient accumulation into views)
+// dst[b][r][c] += src[b][r][c]: three-level strided views (batch stride, row stride, unit column stride) -- covers
+// dense tensors, token slabs of [B, Lv, C] and channel slices of the concat buffer (gradient accumulation into views)
 template <class T>
-__global__ __launch_bounds__(256) void acc2d_kernel(T* __restrict__ dst, long long dst_rs, const T* __restrict__ src, long long src_rs,
-                                                    long long rows, long long cols4) {
-  const long long total = rows * cols4;
+__global__ __launch_bounds__(256) void acc3d_kernel(T* __restrict__ dst, long long dst_bs, long long dst_rs, const T* __restrict__ src,
+                                                    long long src_bs, long long src_rs, long long B, long long rows, long long cols4) {
+  const long long total = B * rows * cols4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cols4, c = (i - r * cols4) * 4;
+    const long long c = (i % cols4) * 4;
+    const long long br = i / cols4;
+    const long long r = br % rows, b = br / rows;
     float x[4], y[4];
-    Vec4<T>::load(dst + r * dst_rs + c, x);
-    Vec4<T>::load(src + r * src_rs + c, y);
+    Vec4<T>::load(dst + b * dst_bs + r * dst_rs + c, x);
+    Vec4<T>::load(src + b * src_bs + r * src_rs + c, y);
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] += y[e];
-    Vec4<T>::store(dst + r * dst_rs + c, x);
+    Vec4<T>::store(dst + b * dst_bs + r * dst_rs + c, x);
   }
 }
 
-// out[r][c] = a[r][c] + b[r][c] over strided rows
+// out[b][r][c] = a[b][r][c] + b2[b][r][c]
 template <class T>
-__global__ __launch_bounds__(256) void add2d_kernel(const T* __restrict__ a, long long a_rs, const T* __restrict__ b, long long b_rs,
-                                                    T* __restrict__ out, long long out_rs, long long rows, long long cols4) {
-  const long long total = rows * cols4;
+__global__ __launch_bounds__(256) void add3d_kernel(const T* __restrict__ a, long long a_bs, long long a_rs, const T* __restrict__ b2,
+                                                    long long b_bs, long long b_rs, T* __restrict__ out, long long o_bs, long long o_rs,
+                                                    long long B, long long rows, long long cols4) {
+  const long long total = B * rows * cols4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / cols4, c = (i - r * cols4) * 4;
+    const long long c = (i % cols4) * 4;
+    const long long br = i / cols4;
+    const long long r = br % rows, b = br / rows;
     float x[4], y[4];
-    Vec4<T>::load(a + r * a_rs + c, x);
-    Vec4<T>::load(b + r * b_rs + c, y);
+    Vec4<T>::load(a + b * a_bs + r * a_rs + c, x);
+    Vec4<T>::load(b2 + b * b_bs + r * b_rs + c, y);
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] += y[e];
-    Vec4<T>::store(out + r * out_rs + c, x);
+    Vec4<T>::store(out + b * o_bs + r * o_rs + c, x);
   }
 }
 
@@ -155,26 +161,27 @@ extern "C" int emrt_add(const void* a, const void* b, void* out, long long n, lo
   return check_launch("emrt_add");
 }
 
-extern "C" int emrt_add2d(const void* a, long long a_rs, const void* b, long long b_rs, void* out, long long out_rs, long long rows,
-                          long long cols, int dtype, void* stream) {
+extern "C" int emrt_add3d(const void* a, long long a_bs, long long a_rs, const void* b, long long b_bs, long long b_rs, void* out,
+                          long long out_bs, long long out_rs, long long B, long long rows, long long cols, int dtype, void* stream) {
   EMRT_REQUIRE(a && b && out, "null pointer");
-  EMRT_REQUIRE(cols % 4 == 0 && a_rs % 4 == 0 && b_rs % 4 == 0 && out_rs % 4 == 0, "cols and row strides must be multiples of 4");
+  EMRT_REQUIRE(cols % 4 == 0 && a_rs % 4 == 0 && b_rs % 4 == 0 && out_rs % 4 == 0 && a_bs % 4 == 0 && b_bs % 4 == 0 && out_bs % 4 == 0,
+               "cols and strides must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ew_grid(rows * (cols / 4));
-  if (dtype == EMRT_F32) hipLaunchKernelGGL((add2d_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, a_rs, (const float*)b, b_rs, (float*)out, out_rs, rows, cols / 4);
-  else hipLaunchKernelGGL((add2d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, a_rs, (const bf16_t*)b, b_rs, (bf16_t*)out, out_rs, rows, cols / 4);
-  return check_launch("emrt_add2d");
+  const int grid = ew_grid(B * rows * (cols / 4));
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((add3d_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, a_bs, a_rs, (const float*)b, b_bs, b_rs, (float*)out, out_bs, out_rs, B, rows, cols / 4);
+  else hipLaunchKernelGGL((add3d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, a_bs, a_rs, (const bf16_t*)b, b_bs, b_rs, (bf16_t*)out, out_bs, out_rs, B, rows, cols / 4);
+  return check_launch("emrt_add3d");
 }
 
-extern "C" int emrt_acc2d(void* dst, long long dst_rs, const void* src, long long src_rs, long long rows, long long cols, int dtype,
-                          void* stream) {
+extern "C" int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const void* src, long long src_bs, long long src_rs, long long B,
+                          long long rows, long long cols, int dtype, void* stream) {
   EMRT_REQUIRE(dst && src, "null pointer");
-  EMRT_REQUIRE(cols % 4 == 0 && dst_rs % 4 == 0 && src_rs % 4 == 0, "cols and row strides must be multiples of 4");
+  EMRT_REQUIRE(cols % 4 == 0 && dst_rs % 4 == 0 && src_rs % 4 == 0 && dst_bs % 4 == 0 && src_bs % 4 == 0, "cols and strides must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ew_grid(rows * (cols / 4));
-  if (dtype == EMRT_F32) hipLaunchKernelGGL((acc2d_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, dst_rs, (const float*)src, src_rs, rows, cols / 4);
-  else hipLaunchKernelGGL((acc2d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, dst_rs, (const bf16_t*)src, src_rs, rows, cols / 4);
-  return check_launch("emrt_acc2d");
+  const int grid = ew_grid(B * rows * (cols / 4));
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((acc3d_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, dst_bs, dst_rs, (const float*)src, src_bs, src_rs, B, rows, cols / 4);
+  else hipLaunchKernelGGL((acc3d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, dst_bs, dst_rs, (const bf16_t*)src, src_bs, src_rs, B, rows, cols / 4);
+  return check_launch("emrt_acc3d");
 }
 
 extern "C" int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream) {

@@ -109,23 +109,39 @@ def narrow(t, dim, start, length):
 # ---------------------------------------------------------------------------------------------------
 # elementwise helpers
 # ---------------------------------------------------------------------------------------------------
+def _brc(t):
+    """(B, rows, cols, batch_stride, row_stride) of a dense tensor / token slab / channel slice."""
+    if t.dim() <= 1 or t.is_contiguous():
+        n = t.numel()
+        return 1, 1, n, n, n
+    N, H, W, C, ld, bs = _check_map(t)
+    return N, H * W, C, bs, ld
+
+
+def _common_brc(x, y):
+    bx, by = _brc(x), _brc(y)
+    if bx[:3] == by[:3]:
+        return bx, by
+    # one side collapsed to a single dense run: re-express it with the other side's (B, rows, cols)
+    if bx[0] == 1 and bx[1] == 1:
+        B, R, Cc = by[:3]
+        assert B * R * Cc == bx[2]
+        return (B, R, Cc, R * Cc, Cc), by
+    if by[0] == 1 and by[1] == 1:
+        B, R, Cc = bx[:3]
+        assert B * R * Cc == by[2]
+        return bx, (B, R, Cc, R * Cc, Cc)
+    # both strided with different splits (e.g. [B,h,w,C] vs [B,h*w,C]) -- _check_map already normalises those
+    raise AssertionError("incompatible views %s %s / %s %s" % (tuple(x.shape), x.stride(), tuple(y.shape), y.stride()))
+
+
 def add_into(dst, src):
-    """dst += src (both may be strided 'rows x cols' views with a unit inner stride)."""
+    """dst += src (dense tensors, token slabs or channel slices in any combination)."""
     c = ctx()
-    assert dst.shape == src.shape and dst.dtype == src.dtype, (dst.shape, src.shape, dst.dtype, src.dtype)
+    assert dst.numel() == src.numel() and dst.dtype == src.dtype, (dst.shape, src.shape, dst.dtype, src.dtype)
     dt = F32 if dst.dtype == torch.float32 else BF16
-    rd, cd, sd = _rows2d(dst)
-    rs, cs, ss = _rows2d(src)
-    cols = min(cd, cs)
-    n = dst.numel()
-    assert n % cols == 0 and cd % cols == 0 and cs % cols == 0
-    if cd != cols:
-        assert rd == 1, "incompatible row structure"
-        sd = cols
-    if cs != cols:
-        assert rs == 1, "incompatible row structure"
-        ss = cols
-    _L().call("emrt_acc2d", P(dst), sd, P(src), ss, n // cols, cols, dt, c.stream)
+    d, s_ = _common_brc(dst, src)
+    _L().call("emrt_acc3d", P(dst), d[3], d[4], P(src), s_[3], s_[4], d[0], d[1], d[2], dt, c.stream)
 
 
 def add(a, b, period=None, bgrad=None):
@@ -153,43 +169,16 @@ def add(a, b, period=None, bgrad=None):
     return out
 
 
-def _rows2d(t):
-    """(rows, cols, row_stride) of a view that is a set of dense rows (token slab / channel slice / dense tensor)."""
-    cols, k, expect = 1, t.dim(), 1
-    while k > 0 and t.stride(k - 1) == expect:
-        expect *= t.shape[k - 1]
-        cols = expect
-        k -= 1
-    if k == 0:
-        return 1, cols, cols
-    for d in range(k - 1):
-        assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], "cannot collapse view %s %s" % (tuple(t.shape), t.stride())
-    rows = 1
-    for d in range(k):
-        rows *= t.shape[d]
-    return rows, cols, t.stride(k - 1)
-
-
 def add_maps(a, b):
     """out (dense) = a + b where a, b may be strided views of equal shape (e.g. residual = level slab of `memory`)."""
     c = ctx()
     assert a.shape == b.shape and a.dtype == b.dtype
     out = c.empty(tuple(a.shape), a.dtype)
-    ra, ca, sa = _rows2d(a)
-    rb, cb, sb = _rows2d(b)
-    cols = min(ca, cb)
-    n = a.numel()
-    assert n % cols == 0 and ca % cols == 0 and cb % cols == 0
-    rows = n // cols
-    # a view with longer dense runs than `cols` is still addressable with row stride == cols when it is fully dense
-    if ca != cols:
-        assert ra == 1, "incompatible row structure"
-        sa = cols
-    if cb != cols:
-        assert rb == 1, "incompatible row structure"
-        sb = cols
+    ga, gb = _common_brc(a, b)
+    go, ga = _common_brc(out, a) if ga[:3] != _brc(out)[:3] else (_brc(out), ga)
+    go, gb = _common_brc(out, b) if gb[:3] != go[:3] else (go, gb)
     dt = F32 if a.dtype == torch.float32 else BF16
-    _L().call("emrt_add2d", P(a), sa, P(b), sb, P(out), cols, rows, cols, dt, c.stream)
+    _L().call("emrt_add3d", P(a), ga[3], ga[4], P(b), gb[3], gb[4], P(out), go[3], go[4], go[0], go[1], go[2], dt, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
