@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "emrt_hip.h")
 LIB_PATH = os.path.join(_HERE, "csrc", "libemrt_hip.so")
 
+_TRACE = bool(int(os.environ.get("EMRT_TRACE", "0")))
+
 _CTYPES = {
     "int": ctypes.c_int, "unsigned": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double,
     "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t,
@@ -75,10 +77,16 @@ class _Lib:
         return self._raw_emrt_last_error().decode("utf-8", "replace")
 
     def call(self, name, *args):
-        """Invoke an int-returning entry point; raise EmrtHipError on a non-zero return."""
+        """Invoke an int-returning entry point; raise EmrtHipError on a non-zero return.
+        EMRT_TRACE=1 prints every call before launching it and synchronises after it (locates GPU faults)."""
+        if _TRACE:
+            print("[emrt] %s%r" % (name, tuple(a.value if hasattr(a, "value") else a for a in args)), flush=True)
         rc = getattr(self, "_raw_" + name)(*args)
         if rc != 0:
             raise EmrtHipError("%s failed (%d): %s" % (name, rc, self.last_error()))
+        if _TRACE:
+            import torch
+            torch.cuda.synchronize()
 
     def query(self, name, *args):
         return getattr(self, "_raw_" + name)(*args)

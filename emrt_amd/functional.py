@@ -109,39 +109,38 @@ def narrow(t, dim, start, length):
 # ---------------------------------------------------------------------------------------------------
 # elementwise helpers
 # ---------------------------------------------------------------------------------------------------
-def _brc(t):
-    """(B, rows, cols, batch_stride, row_stride) of a dense tensor / token slab / channel slice."""
-    if t.dim() <= 1 or t.is_contiguous():
-        n = t.numel()
-        return 1, 1, n, n, n
-    N, H, W, C, ld, bs = _check_map(t)
-    return N, H * W, C, bs, ld
-
-
-def _common_brc(x, y):
-    bx, by = _brc(x), _brc(y)
-    if bx[:3] == by[:3]:
-        return bx, by
-    # one side collapsed to a single dense run: re-express it with the other side's (B, rows, cols)
-    if bx[0] == 1 and bx[1] == 1:
-        B, R, Cc = by[:3]
-        assert B * R * Cc == bx[2]
-        return (B, R, Cc, R * Cc, Cc), by
-    if by[0] == 1 and by[1] == 1:
-        B, R, Cc = bx[:3]
-        assert B * R * Cc == by[2]
-        return bx, (B, R, Cc, R * Cc, Cc)
-    # both strided with different splits (e.g. [B,h,w,C] vs [B,h*w,C]) -- _check_map already normalises those
-    raise AssertionError("incompatible views %s %s / %s %s" % (tuple(x.shape), x.stride(), tuple(y.shape), y.stride()))
+def _geom3(*tensors):
+    """Common (B, rows, cols) of equally-sized operands plus each operand's (batch_stride, row_stride).
+    Dense tensors adopt the (B, rows, cols) split of the strided ones (token slabs / channel slices)."""
+    n = tensors[0].numel()
+    split = None
+    for t in tensors:
+        assert t.numel() == n
+        if t.dim() >= 2 and not t.is_contiguous():
+            N, H, W, C, ld, bs = _check_map(t)
+            cur = (N, H * W, C)
+            assert split is None or split == cur, "incompatible views %s vs %s" % (split, cur)
+            split = cur
+    if split is None:
+        split = (1, 1, n)
+    B, R, Cc = split
+    strides = []
+    for t in tensors:
+        if t.dim() >= 2 and not t.is_contiguous():
+            _, _, _, _, ld, bs = _check_map(t)
+            strides.append((bs, ld))
+        else:
+            strides.append((R * Cc, Cc))
+    return B, R, Cc, strides
 
 
 def add_into(dst, src):
     """dst += src (dense tensors, token slabs or channel slices in any combination)."""
     c = ctx()
-    assert dst.numel() == src.numel() and dst.dtype == src.dtype, (dst.shape, src.shape, dst.dtype, src.dtype)
+    assert dst.dtype == src.dtype, (dst.dtype, src.dtype)
     dt = F32 if dst.dtype == torch.float32 else BF16
-    d, s_ = _common_brc(dst, src)
-    _L().call("emrt_acc3d", P(dst), d[3], d[4], P(src), s_[3], s_[4], d[0], d[1], d[2], dt, c.stream)
+    B, R, Cc, (sd, ss) = _geom3(dst, src)
+    _L().call("emrt_acc3d", P(dst), sd[0], sd[1], P(src), ss[0], ss[1], B, R, Cc, dt, c.stream)
 
 
 def add(a, b, period=None, bgrad=None):
@@ -174,11 +173,9 @@ def add_maps(a, b):
     c = ctx()
     assert a.shape == b.shape and a.dtype == b.dtype
     out = c.empty(tuple(a.shape), a.dtype)
-    ga, gb = _common_brc(a, b)
-    go, ga = _common_brc(out, a) if ga[:3] != _brc(out)[:3] else (_brc(out), ga)
-    go, gb = _common_brc(out, b) if gb[:3] != go[:3] else (go, gb)
+    B, R, Cc, (sa, sb, so) = _geom3(a, b, out)
     dt = F32 if a.dtype == torch.float32 else BF16
-    _L().call("emrt_add3d", P(a), ga[3], ga[4], P(b), gb[3], gb[4], P(out), go[3], go[4], go[0], go[1], go[2], dt, c.stream)
+    _L().call("emrt_add3d", P(a), sa[0], sa[1], P(b), sb[0], sb[1], P(out), so[0], so[1], B, R, Cc, dt, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():

@@ -131,6 +131,7 @@ class ParamStore:
         for g in self.gemms:
             g.fwd_ptr = self.master.data_ptr() + 4 * g.offset if g._fo < 0 else base + esz * g._fo
             g.bwd_ptr = None if g._bo < 0 else base + esz * g._bo
+            g._keepalive = (self.packed, self.master, self.grad)   # raw device addresses above point into these
         self.desc = torch.tensor(rows, dtype=torch.int64).to(self.device) if rows else None
         self.ndesc, self.total_tiles = len(rows), tiles
         self.dirty = True
