@@ -58,6 +58,7 @@ class _Lib:
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU/PyTorch fallback for the EMRT hot path)" % LIB_PATH)
         self._dll = ctypes.CDLL(LIB_PATH)
+        self._prof = None
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():
             try:
@@ -76,14 +77,42 @@ class _Lib:
     def last_error(self):
         return self._raw_emrt_last_error().decode("utf-8", "replace")
 
+    # ---- per-call HIP-event timing (bench.py): events are recorded on the stream the kernels are launched on ----
+    def start_profile(self):
+        self._prof = []
+
+    def stop_profile(self):
+        """-> [(name, args, milliseconds)] for every call made since start_profile()."""
+        import torch
+        torch.cuda.synchronize()
+        out, ms = [], ctypes.c_float(0.0)
+        for name, args, e0, e1 in self._prof:
+            self._raw_emrt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
+            out.append((name, args, ms.value))
+            self._raw_emrt_event_destroy(e0)
+            self._raw_emrt_event_destroy(e1)
+        self._prof = None
+        return out
+
+    def _event(self, stream):
+        ev = ctypes.c_void_p()
+        self._raw_emrt_event_create(ctypes.byref(ev))
+        self._raw_emrt_event_record(ev, stream)
+        return ev
+
     def call(self, name, *args):
         """Invoke an int-returning entry point; raise EmrtHipError on a non-zero return.
         EMRT_TRACE=1 prints every call before launching it and synchronises after it (locates GPU faults)."""
         if _TRACE:
             print("[emrt] %s%r" % (name, tuple(a.value if hasattr(a, "value") else a for a in args)), flush=True)
+        prof = self._prof
+        if prof is not None:
+            e0 = self._event(args[-1])
         rc = getattr(self, "_raw_" + name)(*args)
         if rc != 0:
             raise EmrtHipError("%s failed (%d): %s" % (name, rc, self.last_error()))
+        if prof is not None:
+            prof.append((name, args, e0, self._event(args[-1])))
         if _TRACE:
             import torch
             torch.cuda.synchronize()
