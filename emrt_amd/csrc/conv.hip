@@ -59,7 +59,10 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const uint4& a, 
 // LDS: one [BM + BN] x 128-byte k-tile (rows padded to 144 B: conflict-free ds_read_b128), register
 // prefetch of the next k-tile while the MFMAs of the current one run.
 // ------------------------------------------------------------------------------------------------
-template <class T, int TM, int TN, int WR, int WC, int MODE>
+// VEC = true : C % (16 B of elements) == 0 and 16-byte aligned rows -> one 16-byte load per chunk; the last k-tile may
+//              be partial (K % BK != 0, e.g. the fused 432-wide offsets|logits projection) and is zero-filled.
+// VEC = false: any C / alignment (7x7x3 stem, 3x3x3 branch conv, 6-class logits): chunks are assembled from element loads.
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   const T* __restrict__ inp = (const T*)p.in;
   const T* __restrict__ wp = (const T*)p.w;
   const int K = p.KH * p.KW * p.C;
-  const int nkt = K / BK;
+  const int nkt = (K + BK - 1) / BK;
 
   int a_h[AR], a_w[AR];
   long long a_base[AR];
@@ -104,35 +107,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   for (int j = 0; j < BR; ++j) {
     int n = bn * BN + row0 + 32 * j;
     b_ok[j] = n < p.OC;
-    b_off[j] = (long long)(b_ok[j] ? n : 0) * K + chunk * EPC;
+    b_off[j] = (long long)(b_ok[j] ? n : 0) * K;
   }
 
   uint4 ra[AR], rb[BR];
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / p.C;
-    const int c0 = k0 - tap * p.C;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int hi, wi;
-      bool ok = a_ok[i];
-      if (MODE == 0) { hi = a_h[i] + kh; wi = a_w[i] + kw; }
-      else {
-        int th = a_h[i] - kh, tw = a_w[i] - kw;
-        hi = th / p.stride; wi = tw / p.stride;
-        ok = ok && th >= 0 && tw >= 0 && (hi * p.stride == th) && (wi * p.stride == tw);
-      }
-      ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(inp + a_base[i] + ((long long)hi * p.W + wi) * p.ldin + c0 + chunk * EPC);
-      ra[i] = v;
+  auto a_pixel = [&](int i, int kh, int kw, long long& off) -> bool {
+    int hi, wi;
+    bool ok = a_ok[i];
+    if (MODE == 0) { hi = a_h[i] + kh; wi = a_w[i] + kw; }
+    else {
+      int th = a_h[i] - kh, tw = a_w[i] - kw;
+      hi = th / p.stride; wi = tw / p.stride;
+      ok = ok && th >= 0 && tw >= 0 && (hi * p.stride == th) && (wi * p.stride == tw);
     }
+    ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+    off = a_base[i] + ((long long)hi * p.W + wi) * p.ldin;
+    return ok;
+  };
+  auto load_tile = [&](int kt) {
+    const int kc = kt * BK + chunk * EPC;       // first k index of this thread's 16-byte chunk
+    if constexpr (VEC) {
+      const bool kok = kc < K;
+      const int tap = kok ? kc / p.C : 0;
+      const int c0 = kc - tap * p.C;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (b_ok[j]) v = *reinterpret_cast<const uint4*>(wp + b_off[j] + k0);
-      rb[j] = v;
+      for (int i = 0; i < AR; ++i) {
+        long long off;
+        const bool ok = a_pixel(i, kh, kw, off) && kok;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = *reinterpret_cast<const uint4*>(inp + off + c0);
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b_ok[j] && kok) v = *reinterpret_cast<const uint4*>(wp + b_off[j] + kc);
+        rb[j] = v;
+      }
+    } else {
+      T ea[AR][EPC], eb[BR][EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int kk = kc + e;
+        const bool kok = kk < K;
+        const int tap = kok ? kk / p.C : 0;
+        const int cc = kk - tap * p.C;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          long long off;
+          const bool ok = a_pixel(i, kh, kw, off) && kok;
+          ea[i][e] = ok ? inp[off + cc] : from_f32<T>(0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) eb[j][e] = (b_ok[j] && kok) ? wp[b_off[j] + kk] : from_f32<T>(0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const uint4*>(&ea[i][0]);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const uint4*>(&eb[j][0]);
     }
   };
 
@@ -198,46 +232,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   }
 }
 
-// Naive direct form of the same contraction for channel counts that do not fill 16-byte chunks
-// (7x7 stem and the first spatial-branch conv, Cin = 3).  One thread per (pixel, out channel).
-template <class T, int MODE>
-__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p) {
-  const int OHW = p.OH * p.OW;
-  const long long total = (long long)p.N * OHW * p.OC;
-  const T* __restrict__ inp = (const T*)p.in;
-  const T* __restrict__ wp = (const T*)p.w;
-  const int K = p.KH * p.KW * p.C;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(idx % p.OC);
-    const long long m = idx / p.OC;
-    const int nb = (int)(m / OHW);
-    const int pix = (int)(m - (long long)nb * OHW);
-    const int oh = pix / p.OW, ow = pix - oh * p.OW;
-    float acc = 0.f;
-    for (int kh = 0; kh < p.KH; ++kh)
-      for (int kw = 0; kw < p.KW; ++kw) {
-        int hi, wi;
-        bool ok = true;
-        if (MODE == 0) { hi = oh * p.stride - p.pad + kh; wi = ow * p.stride - p.pad + kw; }
-        else {
-          int th = oh + p.pad - kh, tw = ow + p.pad - kw;
-          hi = th / p.stride; wi = tw / p.stride;
-          ok = th >= 0 && tw >= 0 && hi * p.stride == th && wi * p.stride == tw;
-        }
-        if (!ok || (unsigned)hi >= (unsigned)p.H || (unsigned)wi >= (unsigned)p.W) continue;
-        const T* xp = inp + (long long)nb * p.in_bs + ((long long)hi * p.W + wi) * p.ldin;
-        const T* wk = wp + (long long)n * K + (kh * p.KW + kw) * p.C;
-        for (int c = 0; c < p.C; ++c) acc = fmaf(to_f32(xp[c]), to_f32(wk[c]), acc);
-      }
-    if (p.bias) acc += p.bias[n];
-    if (p.res) acc += to_f32(((const T*)p.res)[(long long)nb * p.res_bs + (long long)pix * p.ldres + n]);
-    if (p.relu) acc = fmaxf(acc, 0.f);
-    const long long o = (long long)nb * p.out_bs + (long long)pix * p.ldout + n;
-    if (p.out_f32) ((float*)p.out)[o] = acc;
-    else ((T*)p.out)[o] = from_f32<T>(acc);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[oc][k] += sum_m dy[m][oc] * xcol[m][k], 128(oc) x 128(k) tile per block, reduction over
 // pixels m split across blockIdx.z, fp32 atomics into dW.  Both operands are pixel-major in memory, so
@@ -267,7 +261,7 @@ struct WgradCfg<float> {
   static constexpr int CPR = 32, RPP = 8, BKM = 32, PITCH = 528;
 };
 
-template <class T>
+template <class T, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   using Cfg = WgradCfg<T>;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -304,6 +298,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   uint4 rp[4], rq[4];
+  // scalar path: per-element decode of this thread's fixed chunk columns (done once)
+  int e_c[EPC], e_kh[EPC], e_kw[EPC];
+  bool e_kok[EPC], e_ocok[EPC];
+  if constexpr (!VEC) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int kk = kq + e;
+      e_kok[e] = kk < K;
+      const int tp = e_kok[e] ? kk / p.C : 0;
+      e_c[e] = kk - tp * p.C;
+      e_kh[e] = tp / p.KW;
+      e_kw[e] = tp - e_kh[e] * p.KW;
+      e_ocok[e] = ocp + e < p.OC;
+    }
+  }
   auto load_tile = [&](long long mt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -312,11 +321,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       if (m < M) {
         const int nb = (int)(m / OHW);
         const int pix = (int)(m - (long long)nb * OHW);
-        if (ocp_ok) vp = *reinterpret_cast<const uint4*>(dyp + (long long)nb * p.dy_bs + (long long)pix * p.lddy + ocp);
         const int oh = pix / p.OW, ow = pix - oh * p.OW;
-        const int hi = oh * p.stride - p.pad + kh, wi = ow * p.stride - p.pad + kw;
-        if (kq_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          vq = *reinterpret_cast<const uint4*>(xp + (long long)nb * p.x_bs + ((long long)hi * p.W + wi) * p.ldx + cq);
+        const T* dyrow = dyp + (long long)nb * p.dy_bs + (long long)pix * p.lddy;
+        const T* ximg = xp + (long long)nb * p.x_bs;
+        if constexpr (VEC) {
+          if (ocp_ok) vp = *reinterpret_cast<const uint4*>(dyrow + ocp);
+          const int hi = oh * p.stride - p.pad + kh, wi = ow * p.stride - p.pad + kw;
+          if (kq_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+            vq = *reinterpret_cast<const uint4*>(ximg + ((long long)hi * p.W + wi) * p.ldx + cq);
+        } else {
+          T ep[EPC], eq[EPC];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            ep[e] = e_ocok[e] ? dyrow[ocp + e] : from_f32<T>(0.f);
+            const int hi = oh * p.stride - p.pad + e_kh[e], wi = ow * p.stride - p.pad + e_kw[e];
+            const bool ok = e_kok[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            eq[e] = ok ? ximg[((long long)hi * p.W + wi) * p.ldx + e_c[e]] : from_f32<T>(0.f);
+          }
+          vp = *reinterpret_cast<const uint4*>(&ep[0]);
+          vq = *reinterpret_cast<const uint4*>(&eq[0]);
+        }
       }
       rp[i] = vp;
       rq[i] = vq;
@@ -401,70 +425,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
 }
 
-// naive wgrad for odd channel counts: thread per (oc, k), pixels split over blockIdx.y
-template <class T>
-__global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs p, int m_per_split) {
-  const int K = p.KH * p.KW * p.C;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)p.OC * K) return;
-  const int oc = (int)(idx % p.OC);   // oc fastest: dy reads coalesce, x reads broadcast
-  const int k = (int)(idx / p.OC);
-  const int tap = k / p.C, c = k - tap * p.C;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int OHW = p.OH * p.OW;
-  const long long M = (long long)p.N * OHW;
-  long long m0 = (long long)blockIdx.y * m_per_split, m1 = m0 + m_per_split;
-  if (m1 > M) m1 = M;
-  const T* __restrict__ xp = (const T*)p.x;
-  const T* __restrict__ dyp = (const T*)p.dy;
-  float acc = 0.f;
-  for (long long m = m0; m < m1; ++m) {
-    const int nb = (int)(m / OHW);
-    const int pix = (int)(m - (long long)nb * OHW);
-    const int oh = pix / p.OW, ow = pix - oh * p.OW;
-    const int hi = oh * p.stride - p.pad + kh, wi = ow * p.stride - p.pad + kw;
-    if ((unsigned)hi >= (unsigned)p.H || (unsigned)wi >= (unsigned)p.W) continue;
-    acc = fmaf(to_f32(dyp[(long long)nb * p.dy_bs + (long long)pix * p.lddy + oc]),
-               to_f32(xp[(long long)nb * p.x_bs + ((long long)hi * p.W + wi) * p.ldx + c]), acc);
-  }
-  atomicAdd(p.dw + (long long)oc * K + k, acc);
-}
-
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
-template <class T, int TM, int TN, int WR, int WC, int MODE>
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC>
 static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long grid = ((M + BM - 1) / BM) * ((a.OC + BN - 1) / BN);
   const size_t lds = (size_t)(BM + BN) * 144;
-  hipLaunchKernelGGL((igemm_kernel<T, TM, TN, WR, WC, MODE>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((igemm_kernel<T, TM, TN, WR, WC, MODE, VEC>), dim3((unsigned)grid), dim3(256), lds, st, a);
   return check_launch("emrt_conv2d");
+}
+
+template <class T, int MODE, bool VEC>
+static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
+  const long long M = (long long)a.N * a.OH * a.OW;
+  if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
+  if (a.OC <= 64) {
+    if (M >= 128 * 256) return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
+    return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
+  }
+  const long long big_tiles = ((M + 127) / 128) * ((a.OC + 127) / 128);
+  if (big_tiles >= 384) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
+  return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
 }
 
 template <class T, int MODE>
 static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int BK = 8 * EPC;
-  const bool vec = (a.C % BK == 0) && (a.ldin % EPC == 0) && (a.in_bs % EPC == 0) &&
+  const bool vec = (a.C % EPC == 0) && (a.ldin % EPC == 0) && (a.in_bs % EPC == 0) &&
                    (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.w) % 16 == 0);
-  const long long M = (long long)a.N * a.OH * a.OW;
-  if (!vec) {
-    long long total = M * a.OC;
-    int grid = (int)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((conv_direct_kernel<T, MODE>), dim3(grid), dim3(256), 0, st, a);
-    return check_launch("emrt_conv2d(direct)");
-  }
-  if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE>(a, st);
-  if (a.OC <= 64) {
-    if (M >= 128 * 256) return launch_igemm<T, 2, 1, 2, 2, MODE>(a, st);
-    return launch_igemm<T, 1, 1, 2, 2, MODE>(a, st);
-  }
-  const long long big_tiles = ((M + 127) / 128) * ((a.OC + 127) / 128);
-  if (big_tiles >= 384) return launch_igemm<T, 2, 2, 2, 2, MODE>(a, st);
-  return launch_igemm<T, 1, 1, 2, 2, MODE>(a, st);
+  return vec ? conv_pick_tile<T, MODE, true>(a, st) : conv_pick_tile<T, MODE, false>(a, st);
 }
 
 extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual,
@@ -503,17 +495,6 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   const long long M = (long long)a.N * a.OH * a.OW;
   const bool vec = (a.C % EPC == 0) && (a.OC % EPC == 0) && (a.ldx % EPC == 0) && (a.lddy % EPC == 0) &&
                    (a.x_bs % EPC == 0) && (a.dy_bs % EPC == 0) && (((uintptr_t)a.x) % 16 == 0) && (((uintptr_t)a.dy) % 16 == 0);
-  if (!vec) {
-    long long outs = (long long)a.OC * K;
-    int gx = (int)((outs + 255) / 256);
-    int splits = (int)(M / 2048);
-    if (splits < 1) splits = 1;
-    if (splits > 256) splits = 256;
-    int mps = (int)((M + splits - 1) / splits);
-    a.tiles_per_split = 0;
-    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(gx, splits), dim3(256), 0, st, a, mps);
-    return check_launch("emrt_conv2d_wgrad(direct)");
-  }
   const int tx = (K + 127) / 128, ty = (a.OC + 127) / 128;
   const long long mt_total = (M + Cfg::BKM - 1) / Cfg::BKM;
   long long want = (1024 + (long long)tx * ty - 1) / ((long long)tx * ty);
@@ -524,7 +505,8 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   a.tiles_per_split = (int)((mt_total + S - 1) / S);
   S = (mt_total + a.tiles_per_split - 1) / a.tiles_per_split;
   const size_t lds = 2 * (size_t)Cfg::BKM * Cfg::PITCH;
-  hipLaunchKernelGGL((wgrad_kernel<T>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
+  if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((wgrad_kernel<T, false>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
   return check_launch("emrt_conv2d_wgrad");
 }
 

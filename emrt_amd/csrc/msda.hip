@@ -33,7 +33,11 @@ struct MsdaArgs {
   float* dvalue;      // fp32 [B][Lv][M*32] dense, accumulated with atomics (caller zeroes)
   long long dv_bs;
   float* doffw;       // fp32 [B*Lq][ldo] (offset + logit gradients), fully overwritten
-  float* dref;        // fp32 [B][Lq][L][2] or null, fully overwritten
+  float* dref;        // fp32 [B][Lq][ref_L][2] or null, fully overwritten
+  float* probs;       // fp32 [B*Lq][M*L*P] softmax probabilities (written by the gradient kernel, read by the LDS scatter)
+  void* dvalue_t;     // LDS path: [B][Lv][M*32] in the compute dtype, fully overwritten
+  int Lv;
+  int g_lbeg[4], g_lend[4], g_pix0[4], g_npix[4];   // level groups whose fp32 gradient slab fits in LDS
 };
 
 template <class T>
@@ -114,7 +118,7 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes th
 // Backward with recompute.  grad_value is scattered with fp32 atomics (v1; LDS-privatised slabs are the planned
 // follow-up); offset/logit gradients are written by lane sub==0 of each quad; the reference-point
 // gradient (decoder only) is reduced over the 8 heads of a query inside the wave.
-template <class T, int L, int P>
+template <class T, int L, int P, bool ATOMIC_DV>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   constexpr int LP = L * P;
   const int lane = threadIdx.x & 63;
@@ -182,28 +186,28 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * (1.f - ly) * (1.f - lx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d00 = fmaf(go[e], v[e], d00); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d00 = fmaf(go[e], v[e], d00); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       if (vy0 && vx1) {
         const long long off = (long long)y0 * W + x0 + 1;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * (1.f - ly) * lx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d01 = fmaf(go[e], v[e], d01); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d01 = fmaf(go[e], v[e], d01); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       if (vy1 && vx0) {
         const long long off = (long long)(y0 + 1) * W + x0;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * ly * (1.f - lx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d10 = fmaf(go[e], v[e], d10); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d10 = fmaf(go[e], v[e], d10); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       if (vy1 && vx1) {
         const long long off = (long long)(y0 + 1) * W + x0 + 1;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * ly * lx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d11 = fmaf(go[e], v[e], d11); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d11 = fmaf(go[e], v[e], d11); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       d00 = quad_sum(d00); d01 = quad_sum(d01); d10 = quad_sum(d10); d11 = quad_sum(d11);
       dA[i] = (1.f - ly) * ((1.f - lx) * d00 + lx * d01) + ly * ((1.f - lx) * d10 + lx * d11);
@@ -215,6 +219,11 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   float dot = 0.f;
 #pragma unroll
   for (int i = 0; i < LP; ++i) dot = fmaf(pr[i], dA[i], dot);
+  if (!ATOMIC_DV && live && sub == 0) {
+    float* pp = a.probs + bq * (a.M * LP) + m * LP;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) pp[i] = pr[i];
+  }
   if (live && sub == 0) {
     float* drow = a.doffw + bq * a.ldo;
     float* doff = drow + m * LP * 2;
@@ -245,15 +254,102 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   }
 }
 
+// d value via LDS-privatised scatter: one block per (batch, head, level group).  The group's fp32 gradient slab
+// [npix][33] (odd pitch spreads pixels over banks) lives in LDS; each half-wave owns one sample (lane = channel), so a
+// wave-level ds_add_f32 touches two pixels x 32 consecutive channels.  The slab is then written out once, in the compute
+// dtype, with plain coalesced stores: no global atomics, no zero-fill, no cast pass.
+#define MSDA_SLAB_PITCH 33
+template <class T, int P>
+__global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
+  extern __shared__ float slab[];
+  const int g = blockIdx.y;
+  const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
+  const int lbeg = a.g_lbeg[g], nl = a.g_lend[g] - lbeg;
+  const int pix0 = a.g_pix0[g], npix = a.g_npix[g];
+  for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0.f;
+  __syncthreads();
+  const int ch = threadIdx.x & 31;
+  const int half = threadIdx.x >> 5, nhalf = blockDim.x >> 5;
+  const int per_q = nl * P;
+  const long long items = (long long)a.Lq * per_q;
+  for (long long it = half; it < items; it += nhalf) {
+    const int q = (int)(it / per_q);
+    const int r = (int)(it - (long long)q * per_q);
+    const int l = lbeg + r / P, p = r - (r / P) * P;
+    const long long bq = (long long)b * a.Lq + q;
+    const int H = a.h[l], W = a.w[l];
+    const float* row = a.offw + bq * a.ldo;
+    const int nlev = a.g_lend[3];           // total number of levels is stored in the last group slot
+    const int lp_all = nlev * P;
+    const float2 o = *reinterpret_cast<const float2*>(row + (m * lp_all + l * P + p) * 2);
+    const float aw = a.probs[bq * (a.M * lp_all) + m * lp_all + l * P + p];
+    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : l * 2);
+    const float x = (refp[0] + o.x / (float)W) * (float)W - 0.5f;
+    const float y = (refp[1] + o.y / (float)H) * (float)H - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float lx = x - xf, ly = y - yf;
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float go = aw * to_f32(((const T*)a.dout)[bq * (a.M * 32) + m * 32 + ch]);
+    const int base = (a.start[l] - pix0) * MSDA_SLAB_PITCH + ch;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    if (vy0 && vx0) atomicAdd(&slab[base + (y0 * W + x0) * MSDA_SLAB_PITCH], go * (1.f - ly) * (1.f - lx));
+    if (vy0 && vx1) atomicAdd(&slab[base + (y0 * W + x0 + 1) * MSDA_SLAB_PITCH], go * (1.f - ly) * lx);
+    if (vy1 && vx0) atomicAdd(&slab[base + ((y0 + 1) * W + x0) * MSDA_SLAB_PITCH], go * ly * (1.f - lx));
+    if (vy1 && vx1) atomicAdd(&slab[base + ((y0 + 1) * W + x0 + 1) * MSDA_SLAB_PITCH], go * ly * lx);
+  }
+  __syncthreads();
+  T* outp = (T*)a.dvalue_t + ((long long)b * a.Lv + pix0) * (a.M * 32) + m * 32;
+  for (int i = threadIdx.x; i < npix * 32; i += blockDim.x) {
+    const int pix = i >> 5, c = i & 31;
+    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>(slab[pix * MSDA_SLAB_PITCH + c]);
+  }
+}
+
+static const size_t MSDA_LDS_BUDGET = 150 * 1024;
+
+// greedy level groups; returns the number of groups, or 0 when some level's slab does not fit in LDS
+static int msda_groups(const int* shapes_hw, int L, int* lbeg, int* lend, int* pix0, int* npix) {
+  int ng = 0, start = 0, l = 0;
+  while (l < L) {
+    int cur = 0, first = l, p0 = start;
+    while (l < L) {
+      const int n = shapes_hw[2 * l] * shapes_hw[2 * l + 1];
+      if ((size_t)(cur + n) * MSDA_SLAB_PITCH * sizeof(float) > MSDA_LDS_BUDGET) break;
+      cur += n;
+      start += n;
+      ++l;
+    }
+    if (l == first) return 0;
+    if (ng == 3 && l < L) return 0;   // slot 3's g_lend doubles as "number of levels": keep at most 3 real groups + spill
+    lbeg[ng] = first; lend[ng] = l; pix0[ng] = p0; npix[ng] = cur;
+    ++ng;
+    if (ng == 4 && l < L) return 0;
+  }
+  return ng;
+}
+
+extern "C" int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L) {
+  int a[4], b[4], c[4], d[4];
+  if (!shapes_hw || L < 1 || L > 4) return 0;
+  const int ng = msda_groups(shapes_hw, L, a, b, c, d);
+  return (ng >= 1 && ng <= 3) ? 1 : 0;
+}
+
+extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P) {
+  return (size_t)B * Lq * M * L * P * sizeof(float);
+}
+
 template <class T>
-static int msda_launch(const MsdaArgs& a, int L, int P, bool bwd, hipStream_t st) {
+static int msda_launch(const MsdaArgs& a, int L, int P, int mode /*0 fwd, 1 bwd atomic, 2 bwd grads only*/, hipStream_t st) {
   const long long pairs = (long long)a.B * a.Lq * a.M;
   const unsigned grid = (unsigned)((pairs + 63) / 64);
 #define MSDA_CASE(LL, PP)                                                                                     \
   if (L == LL && P == PP) {                                                                                   \
-    if (bwd) hipLaunchKernelGGL((msda_bwd_kernel<T, LL, PP>), dim3(grid), dim3(256), 0, st, a);                \
-    else hipLaunchKernelGGL((msda_fwd_kernel<T, LL, PP>), dim3(grid), dim3(256), 0, st, a);                    \
-    return check_launch(bwd ? "emrt_msda_bwd" : "emrt_msda_fwd");                                             \
+    if (mode == 0) hipLaunchKernelGGL((msda_fwd_kernel<T, LL, PP>), dim3(grid), dim3(256), 0, st, a);          \
+    else if (mode == 1) hipLaunchKernelGGL((msda_bwd_kernel<T, LL, PP, true>), dim3(grid), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((msda_bwd_kernel<T, LL, PP, false>), dim3(grid), dim3(256), 0, st, a);             \
+    return check_launch(mode ? "emrt_msda_bwd" : "emrt_msda_fwd");                                            \
   }
   MSDA_CASE(3, 6)
   MSDA_CASE(4, 4)
@@ -261,6 +357,21 @@ static int msda_launch(const MsdaArgs& a, int L, int P, bool bwd, hipStream_t st
   MSDA_CASE(1, 4)
 #undef MSDA_CASE
   return fail("emrt_msda", "unsupported (levels, points): built for (3,6), (4,4), (3,4), (1,4)");
+}
+
+template <class T>
+static int msda_launch_lds(const MsdaArgs& a, int P, int ngroups, size_t lds, hipStream_t st) {
+#define MSDA_LDS_CASE(PP)                                                                                     \
+  if (P == PP) {                                                                                              \
+    static bool attr = false;                                                                                 \
+    if (!attr) { hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a);   \
+    return check_launch("emrt_msda_bwd(lds scatter)");                                                        \
+  }
+  MSDA_LDS_CASE(6)
+  MSDA_LDS_CASE(4)
+#undef MSDA_LDS_CASE
+  return fail("emrt_msda_bwd", "unsupported points per level for the LDS scatter");
 }
 
 static int msda_fill(MsdaArgs& a, const int* shapes_hw, int L, int Lv) {
@@ -290,12 +401,14 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   a.B = B; a.Lq = Lq; a.M = M;
   EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
   hipStream_t st = (hipStream_t)stream;
-  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, false, st) : msda_launch<bf16_t>(a, L, P, false, st);
+  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 0, st) : msda_launch<bf16_t>(a, L, P, 0, st);
 }
 
+// dvalue: when emrt_msda_bwd_uses_lds(shapes) it is [B][Lv][M*D] in the COMPUTE dtype and fully overwritten (workspace
+// of emrt_msda_bwd_workspace_bytes required); otherwise fp32, pre-zeroed by the caller, accumulated with global atomics.
 extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
-                             long long ref_bs, int ref_L, const void* dout, float* dvalue, float* doffw, float* dref, int B, int Lq,
-                             int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream) {
+                             long long ref_bs, int ref_L, const void* dout, void* dvalue, float* doffw, float* dref, int B, int Lq,
+                             int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream) {
   EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
   EMRT_REQUIRE(value && offw && ref && dout && dvalue && doffw && shapes_hw, "null pointer");
   EMRT_REQUIRE(D == 32, "head dim must be 32");
@@ -305,9 +418,23 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
   MsdaArgs a;
   memset(&a, 0, sizeof(a));
   a.value = value; a.ldv = ldv; a.v_bs = v_bs; a.offw = offw; a.ldo = ldo; a.ref = ref; a.ref_bs = ref_bs; a.ref_L = ref_L;
-  a.dout = dout; a.dvalue = dvalue; a.dv_bs = (long long)Lv * M * 32; a.doffw = doffw; a.dref = dref;
-  a.B = B; a.Lq = Lq; a.M = M;
+  a.dout = dout; a.dv_bs = (long long)Lv * M * 32; a.doffw = doffw; a.dref = dref;
+  a.B = B; a.Lq = Lq; a.M = M; a.Lv = Lv;
   EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
   hipStream_t st = (hipStream_t)stream;
-  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, true, st) : msda_launch<bf16_t>(a, L, P, true, st);
+  const int ng = msda_groups(shapes_hw, L, a.g_lbeg, a.g_lend, a.g_pix0, a.g_npix);
+  if (ng >= 1 && ng <= 3 && (P == 6 || P == 4)) {
+    EMRT_REQUIRE(workspace, "LDS scatter path needs the probability workspace");
+    a.probs = (float*)workspace;
+    a.dvalue_t = dvalue;
+    a.g_lend[3] = L;     // total level count for the scatter kernel's row indexing
+    int rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
+    if (rc) return rc;
+    int maxpix = 0;
+    for (int g = 0; g < ng; ++g) maxpix = a.g_npix[g] > maxpix ? a.g_npix[g] : maxpix;
+    const size_t lds = (size_t)maxpix * MSDA_SLAB_PITCH * sizeof(float);
+    return dtype == EMRT_F32 ? msda_launch_lds<float>(a, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, P, ng, lds, st);
+  }
+  a.dvalue = (float*)dvalue;
+  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 1, st) : msda_launch<bf16_t>(a, L, P, 1, st);
 }

@@ -81,7 +81,7 @@ static inline void col_reduce_geometry(long long M, int C, int& tx_n, int& gx, i
   gy = (quads + tx_n - 1) / tx_n;
   int ty_n = 256 / tx_n;
   long long want = (M + (long long)ty_n * 8 - 1) / ((long long)ty_n * 8);
-  long long cap = 1024 / gy;
+  long long cap = 512 / gy;
   if (cap < 1) cap = 1;
   gx = (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
@@ -90,12 +90,22 @@ static inline void col_reduce_geometry(long long M, int C, int& tx_n, int& gx, i
 // (Paddle convention: running = mom*running + (1-mom)*batch, biased variance).
 // `count` is the number of rows the sums cover (after a cross-rank all-reduce of `sums` for SyncBN it is
 // the global count).  Split in two so SyncBN can all-reduce between them.
-__global__ void bn_sum_partials_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums /*[2][C]*/) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
+__global__ __launch_bounds__(256) void bn_sum_partials_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums /*[2][C]*/) {
+  // 32 columns x 8 partial-lanes per block; each lane walks every 8th partial row (coalesced over columns), fp64 combine
+  __shared__ double red[8][33];
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(long long)b * 2 * C + c];
-  sums[c] = (float)s;
+  if (c < 2 * C)
+    for (int b = py; b < nblk; b += 8) s += (double)partial[(long long)b * 2 * C + c];
+  red[py][cx] = s;
+  __syncthreads();
+  if (py == 0 && c < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    sums[c] = (float)t;
+  }
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, int C, float eps, float momentum,
@@ -509,7 +519,7 @@ extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, float* 
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((col_reduce_kernel<float, 0>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, M, 0LL),
             hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, M, 0LL));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, gx, C, sums);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
   return check_launch("emrt_bn_stats");
 }
 
@@ -552,7 +562,7 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, partial, M, 0LL),
             hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, partial, M, 0LL));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, gx, C, sums);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
   return check_launch("emrt_bn_bwd_reduce");
 }
 
@@ -609,7 +619,7 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs),
             hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, gx, C, sums);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, (float*)nullptr, dbias);
   return check_launch("emrt_colsum_acc");
 }
@@ -684,7 +694,7 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb),
             hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, partial, (int)blocks, C, sums);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, sums);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }

@@ -502,12 +502,18 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
             if dy is None:
                 return
             assert dy.is_contiguous()
-            dvalue = c.zeros((B, Lv, CC), torch.float32)
+            use_lds = bool(_L().query("emrt_msda_bwd_uses_lds", ctypes.cast(arr, ctypes.c_void_p), L))
             doffw = c.zeros((B, Lq, ldo), torch.float32) if ldo != M * L * Pn * 3 else c.empty((B, Lq, ldo), torch.float32)
             dref = c.empty((B, Lq, ref_L, 2), torch.float32) if need_dref else None
+            if use_lds:
+                dvalue = c.empty((B, Lv, CC))          # compute dtype, fully overwritten by the LDS scatter
+                ws = c.empty((_L().query("emrt_msda_bwd_workspace_bytes", B, Lq, M, L, Pn) // 4,), torch.float32)
+            else:
+                dvalue = c.zeros((B, Lv, CC), torch.float32)
+                ws = None
             _L().call("emrt_msda_bwd", P(value), value.stride(1), value.stride(0), P(offw), ldo, P(ref), ref_bs, ref_L, P(dy), P(dvalue), P(doffw),
-                      P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), c.dtype, c.stream)
-            tape.add_grad(value, cast_from_f32(dvalue))
+                      P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), P(ws), c.dtype, c.stream)
+            tape.add_grad(value, dvalue if use_lds else cast_from_f32(dvalue))
             tape.add_grad(offw, doffw)
             if need_dref:
                 if ref.shape[0] == 1 and B > 1:   # reference points shared by the batch: reduce over b
