@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
 
     from emrt_amd import _lib
@@ -129,6 +130,16 @@ def main():
         L.start_profile()
         eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels)
         calls = L.stop_profile()
+        if args.dump_calls:
+            with open(args.dump_calls, "w") as f:
+                for name, a, ms in calls:
+                    vals = [x.value if hasattr(x, "value") else x for x in a]
+                    extra = ""
+                    if name == "emrt_conv2d":
+                        extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
+                    elif name == "emrt_conv2d_wgrad":
+                        extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
+                    f.write("%-26s %9.4f ms  %s\n" % (name, ms, extra))
         fam = {}
         for name, a, ms in calls:
             f = fam.setdefault(name, [0, 0.0, 0.0])

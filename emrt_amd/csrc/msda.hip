@@ -254,86 +254,90 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   }
 }
 
-// d value via LDS-privatised scatter: one block per (batch, head, level group).  The group's fp32 gradient slab
-// [npix][33] (odd pitch spreads pixels over banks) lives in LDS; each half-wave owns one sample (lane = channel), so a
-// wave-level ds_add_f32 touches two pixels x 32 consecutive channels.  The slab is then written out once, in the compute
-// dtype, with plain coalesced stores: no global atomics, no zero-fill, no cast pass.
+// d value via LDS-privatised scatter.  Float LDS atomics run at ~1 lane / 4 clk on gfx950 (measured: 245 clk per
+// wave-level ds_add_f32) while integer LDS atomics are native rate, so contributions are accumulated in 64-bit fixed point
+// (2^-40 resolution, +-2^23 range: no data-dependent scaling, order-independent => bit-reproducible).
+// One block per (batch, head, pixel range of <= 448..581 flat value pixels); the range's slab [npix][33] x int64 lives in
+// LDS (odd pitch spreads pixels over banks).  Each half-wave takes one query per iteration: lane j computes sample j's
+// pixel coordinates once, the 32 lanes (= channels) fetch the output gradient once, then the L*P samples are broadcast
+// with width-32 shuffles and every in-range corner is one ds_add_u64 per lane.  The slab is written out once, in the
+// compute dtype, with plain coalesced stores: no global atomics, no zero-fill, no cast pass.
 #define MSDA_SLAB_PITCH 33
-template <class T, int P>
+#define MSDA_FIX_SCALE 1099511627776.0f        /* 2^40 */
+#define MSDA_FIX_INV 9.094947017729282e-13f    /* 2^-40 */
+template <class T, int L, int P>
 __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
-  extern __shared__ float slab[];
-  const int g = blockIdx.y;
+  constexpr int LP = L * P;
+  static_assert(LP <= 32, "one lane per sample");
+  extern __shared__ unsigned long long slab[];
   const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
-  const int lbeg = a.g_lbeg[g], nl = a.g_lend[g] - lbeg;
-  const int pix0 = a.g_pix0[g], npix = a.g_npix[g];
-  for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0.f;
+  const int pix0 = a.g_pix0[0] + blockIdx.y * a.g_npix[0];
+  int npix = a.Lv - pix0;
+  if (npix > a.g_npix[0]) npix = a.g_npix[0];
+  for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0ull;
   __syncthreads();
   const int ch = threadIdx.x & 31;
   const int half = threadIdx.x >> 5, nhalf = blockDim.x >> 5;
-  const int per_q = nl * P;
-  const long long items = (long long)a.Lq * per_q;
-  for (long long it = half; it < items; it += nhalf) {
-    const int q = (int)(it / per_q);
-    const int r = (int)(it - (long long)q * per_q);
-    const int l = lbeg + r / P, p = r - (r / P) * P;
+  // this lane's sample (lanes >= LP idle in the per-sample prologue)
+  const int my_l = ch < LP ? ch / P : 0;
+  int myH = a.h[0], myW = a.w[0];
+#pragma unroll
+  for (int l = 1; l < L; ++l)
+    if (my_l == l) { myH = a.h[l]; myW = a.w[l]; }
+  for (int q = half; q < a.Lq; q += nhalf) {
     const long long bq = (long long)b * a.Lq + q;
-    const int H = a.h[l], W = a.w[l];
-    const float* row = a.offw + bq * a.ldo;
-    const int nlev = a.g_lend[3];           // total number of levels is stored in the last group slot
-    const int lp_all = nlev * P;
-    const float2 o = *reinterpret_cast<const float2*>(row + (m * lp_all + l * P + p) * 2);
-    const float aw = a.probs[bq * (a.M * lp_all) + m * lp_all + l * P + p];
-    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : l * 2);
-    const float x = (refp[0] + o.x / (float)W) * (float)W - 0.5f;
-    const float y = (refp[1] + o.y / (float)H) * (float)H - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float lx = x - xf, ly = y - yf;
-    const int x0 = (int)xf, y0 = (int)yf;
-    const float go = aw * to_f32(((const T*)a.dout)[bq * (a.M * 32) + m * 32 + ch]);
-    const int base = (a.start[l] - pix0) * MSDA_SLAB_PITCH + ch;
-    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
-    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-    if (vy0 && vx0) atomicAdd(&slab[base + (y0 * W + x0) * MSDA_SLAB_PITCH], go * (1.f - ly) * (1.f - lx));
-    if (vy0 && vx1) atomicAdd(&slab[base + (y0 * W + x0 + 1) * MSDA_SLAB_PITCH], go * (1.f - ly) * lx);
-    if (vy1 && vx0) atomicAdd(&slab[base + ((y0 + 1) * W + x0) * MSDA_SLAB_PITCH], go * ly * (1.f - lx));
-    if (vy1 && vx1) atomicAdd(&slab[base + ((y0 + 1) * W + x0 + 1) * MSDA_SLAB_PITCH], go * ly * lx);
+    float sx = 0.f, sy = 0.f, pw = 0.f;
+    if (ch < LP) {
+      const float* row = a.offw + bq * a.ldo;
+      const float2 o = *reinterpret_cast<const float2*>(row + (m * LP + ch) * 2);
+      const float* refq = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : my_l * 2);
+      sx = (refq[0] + o.x / (float)myW) * (float)myW - 0.5f;
+      sy = (refq[1] + o.y / (float)myH) * (float)myH - 0.5f;
+      pw = a.probs[bq * (a.M * LP) + m * LP + ch];
+    }
+    const float gch = to_f32(((const T*)a.dout)[bq * (a.M * 32) + m * 32 + ch]);
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      constexpr int dummy = 0; (void)dummy;
+      const int l = j / P;
+      const int H = a.h[l], W = a.w[l];
+      const float x = __shfl(sx, j, 32), y = __shfl(sy, j, 32), aw = __shfl(pw, j, 32);
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float go = aw * gch * MSDA_FIX_SCALE;
+      const int f00 = a.start[l] + y0 * W + x0 - pix0;       // flat pixel index relative to this block's range
+      const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+      if (vy0 && vx0 && (unsigned)f00 < (unsigned)npix)
+        atomicAdd(&slab[f00 * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * (1.f - ly) * (1.f - lx)));
+      if (vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix)
+        atomicAdd(&slab[(f00 + 1) * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * (1.f - ly) * lx));
+      if (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix)
+        atomicAdd(&slab[(f00 + W) * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * ly * (1.f - lx)));
+      if (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix)
+        atomicAdd(&slab[(f00 + W + 1) * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * ly * lx));
+    }
   }
   __syncthreads();
   T* outp = (T*)a.dvalue_t + ((long long)b * a.Lv + pix0) * (a.M * 32) + m * 32;
   for (int i = threadIdx.x; i < npix * 32; i += blockDim.x) {
     const int pix = i >> 5, c = i & 31;
-    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>(slab[pix * MSDA_SLAB_PITCH + c]);
+    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>((float)(long long)slab[pix * MSDA_SLAB_PITCH + c] * MSDA_FIX_INV);
   }
 }
 
-static const size_t MSDA_LDS_BUDGET = 150 * 1024;
+static const int MSDA_MAX_NPIX = 576;    // 576 * 33 * 8 B = 152 064 B of the 160 KiB LDS
 
-// greedy level groups; returns the number of groups, or 0 when some level's slab does not fit in LDS
-static int msda_groups(const int* shapes_hw, int L, int* lbeg, int* lend, int* pix0, int* npix) {
-  int ng = 0, start = 0, l = 0;
-  while (l < L) {
-    int cur = 0, first = l, p0 = start;
-    while (l < L) {
-      const int n = shapes_hw[2 * l] * shapes_hw[2 * l + 1];
-      if ((size_t)(cur + n) * MSDA_SLAB_PITCH * sizeof(float) > MSDA_LDS_BUDGET) break;
-      cur += n;
-      start += n;
-      ++l;
-    }
-    if (l == first) return 0;
-    if (ng == 3 && l < L) return 0;   // slot 3's g_lend doubles as "number of levels": keep at most 3 real groups + spill
-    lbeg[ng] = first; lend[ng] = l; pix0[ng] = p0; npix[ng] = cur;
-    ++ng;
-    if (ng == 4 && l < L) return 0;
-  }
-  return ng;
+// pixel-range split of the flattened value map: ngroups equal ranges of <= MSDA_MAX_NPIX pixels
+static void msda_ranges(int Lv, int* ngroups, int* npix) {
+  *ngroups = (Lv + MSDA_MAX_NPIX - 1) / MSDA_MAX_NPIX;
+  *npix = (Lv + *ngroups - 1) / *ngroups;
 }
 
 extern "C" int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L) {
-  int a[4], b[4], c[4], d[4];
-  if (!shapes_hw || L < 1 || L > 4) return 0;
-  const int ng = msda_groups(shapes_hw, L, a, b, c, d);
-  return (ng >= 1 && ng <= 3) ? 1 : 0;
+  (void)shapes_hw;
+  return (L >= 1 && L <= 4) ? 1 : 0;     // pixel-range slabs fit for every map size
 }
 
 extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P) {
@@ -360,18 +364,20 @@ static int msda_launch(const MsdaArgs& a, int L, int P, int mode /*0 fwd, 1 bwd 
 }
 
 template <class T>
-static int msda_launch_lds(const MsdaArgs& a, int P, int ngroups, size_t lds, hipStream_t st) {
-#define MSDA_LDS_CASE(PP)                                                                                     \
-  if (P == PP) {                                                                                              \
+static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t lds, hipStream_t st) {
+#define MSDA_LDS_CASE(LL, PP)                                                                                 \
+  if (L == LL && P == PP) {                                                                                   \
     static bool attr = false;                                                                                 \
-    if (!attr) { hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a);   \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, LL, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a); \
     return check_launch("emrt_msda_bwd(lds scatter)");                                                        \
   }
-  MSDA_LDS_CASE(6)
-  MSDA_LDS_CASE(4)
+  MSDA_LDS_CASE(3, 6)
+  MSDA_LDS_CASE(4, 4)
+  MSDA_LDS_CASE(3, 4)
+  MSDA_LDS_CASE(1, 4)
 #undef MSDA_LDS_CASE
-  return fail("emrt_msda_bwd", "unsupported points per level for the LDS scatter");
+  return fail("emrt_msda_bwd", "unsupported (levels, points) for the LDS scatter");
 }
 
 static int msda_fill(MsdaArgs& a, const int* shapes_hw, int L, int Lv) {
@@ -422,18 +428,18 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
   a.B = B; a.Lq = Lq; a.M = M; a.Lv = Lv;
   EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
   hipStream_t st = (hipStream_t)stream;
-  const int ng = msda_groups(shapes_hw, L, a.g_lbeg, a.g_lend, a.g_pix0, a.g_npix);
-  if (ng >= 1 && ng <= 3 && (P == 6 || P == 4)) {
+  const bool lds_ok = (L == 3 && P == 6) || (L == 4 && P == 4) || (L == 3 && P == 4) || (L == 1 && P == 4);
+  if (lds_ok) {
     EMRT_REQUIRE(workspace, "LDS scatter path needs the probability workspace");
     a.probs = (float*)workspace;
     a.dvalue_t = dvalue;
-    a.g_lend[3] = L;     // total level count for the scatter kernel's row indexing
+    int ng, npix;
+    msda_ranges(Lv, &ng, &npix);
+    a.g_pix0[0] = 0; a.g_npix[0] = npix;
     int rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
     if (rc) return rc;
-    int maxpix = 0;
-    for (int g = 0; g < ng; ++g) maxpix = a.g_npix[g] > maxpix ? a.g_npix[g] : maxpix;
-    const size_t lds = (size_t)maxpix * MSDA_SLAB_PITCH * sizeof(float);
-    return dtype == EMRT_F32 ? msda_launch_lds<float>(a, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, P, ng, lds, st);
+    const size_t lds = (size_t)npix * MSDA_SLAB_PITCH * sizeof(unsigned long long);
+    return dtype == EMRT_F32 ? msda_launch_lds<float>(a, L, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, L, P, ng, lds, st);
   }
   a.dvalue = (float*)dvalue;
   return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 1, st) : msda_launch<bf16_t>(a, L, P, 1, st);
