@@ -58,7 +58,7 @@ class _Lib:
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU/PyTorch fallback for the EMRT hot path)" % LIB_PATH)
         self._dll = ctypes.CDLL(LIB_PATH)
-        self._prof = None
+        self._rec = None
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():
             try:
@@ -77,21 +77,40 @@ class _Lib:
     def last_error(self):
         return self._raw_emrt_last_error().decode("utf-8", "replace")
 
-    # ---- per-call HIP-event timing (bench.py): events are recorded on the stream the kernels are launched on ----
-    def start_profile(self):
-        self._prof = []
+    # ---- launch recording / timed replay (bench.py) ------------------------------------------------------------
+    # In eager mode the host needs ~20-30 us of Python per launch, so a HIP-event pair around a single small kernel
+    # measures the HOST, not the GPU.  Instead the launches of one step are recorded (name + C arguments; the runtime
+    # keeps every temporary alive meanwhile) and then replayed from a tight ctypes loop: once untimed as a backlog so the
+    # host runs ahead of the GPU, then again with a HIP-event pair -- on the launch stream -- around every launch.
+    def start_record(self):
+        self._rec = []
 
-    def stop_profile(self):
-        """-> [(name, args, milliseconds)] for every call made since start_profile()."""
+    def stop_record(self):
+        rec, self._rec = self._rec, None
+        return rec
+
+    def replay(self, rec, timed=False):
+        """Re-issue recorded launches.  timed=True -> [(name, args, milliseconds)] from per-launch HIP events."""
         import torch
+        raw = [(getattr(self, "_raw_" + n), a, n) for n, a in rec]
+        if not timed:
+            for fn, a, n in raw:
+                rc = fn(*a)
+                if rc != 0:
+                    raise EmrtHipError("%s failed during replay (%d): %s" % (n, rc, self.last_error()))
+            return None
+        evs = []
+        for fn, a, n in raw:
+            e0 = self._event(a[-1])
+            fn(*a)
+            evs.append((e0, self._event(a[-1])))
         torch.cuda.synchronize()
         out, ms = [], ctypes.c_float(0.0)
-        for name, args, e0, e1 in self._prof:
+        for (n, a), (e0, e1) in zip(rec, evs):
             self._raw_emrt_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-            out.append((name, args, ms.value))
+            out.append((n, a, ms.value))
             self._raw_emrt_event_destroy(e0)
             self._raw_emrt_event_destroy(e1)
-        self._prof = None
         return out
 
     def _event(self, stream):
@@ -105,14 +124,11 @@ class _Lib:
         EMRT_TRACE=1 prints every call before launching it and synchronises after it (locates GPU faults)."""
         if _TRACE:
             print("[emrt] %s%r" % (name, tuple(a.value if hasattr(a, "value") else a for a in args)), flush=True)
-        prof = self._prof
-        if prof is not None:
-            e0 = self._event(args[-1])
+        if self._rec is not None:
+            self._rec.append((name, args))
         rc = getattr(self, "_raw_" + name)(*args)
         if rc != 0:
             raise EmrtHipError("%s failed (%d): %s" % (name, rc, self.last_error()))
-        if prof is not None:
-            prof.append((name, args, e0, self._event(args[-1])))
         if _TRACE:
             import torch
             torch.cuda.synchronize()

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
     b_off[j] = (long long)(b_ok[j] ? n : 0) * K;
   }
 
-  uint4 ra[AR], rb[BR];
+  constexpr int NST = 3;      // k-tiles in flight in registers: hides the ~1 us L2/HBM round trip of short-grid launches
+  uint4 ra[NST][AR], rb[NST][BR];
   auto a_pixel = [&](int i, int kh, int kw, long long& off) -> bool {
     int hi, wi;
     bool ok = a_ok[i];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
     off = a_base[i] + ((long long)hi * p.W + wi) * p.ldin;
     return ok;
   };
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
     const int kc = kt * BK + chunk * EPC;       // first k index of this thread's 16-byte chunk
     if constexpr (VEC) {
       const bool kok = kc < K;
@@ -137,13 +138,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
         const bool ok = a_pixel(i, kh, kw, off) && kok;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ok) v = *reinterpret_cast<const uint4*>(inp + off + c0);
-        ra[i] = v;
+        ra_[i] = v;
       }
 #pragma unroll
       for (int j = 0; j < BR; ++j) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (b_ok[j] && kok) v = *reinterpret_cast<const uint4*>(wp + b_off[j] + kc);
-        rb[j] = v;
+        rb_[j] = v;
       }
     } else {
       T ea[AR][EPC], eb[BR][EPC];
@@ -164,9 +165,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
         for (int j = 0; j < BR; ++j) eb[j][e] = (b_ok[j] && kok) ? wp[b_off[j] + kk] : from_f32<T>(0.f);
       }
 #pragma unroll
-      for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const uint4*>(&ea[i][0]);
+      for (int i = 0; i < AR; ++i) ra_[i] = *reinterpret_cast<const uint4*>(&ea[i][0]);
 #pragma unroll
-      for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const uint4*>(&eb[j][0]);
+      for (int j = 0; j < BR; ++j) rb_[j] = *reinterpret_cast<const uint4*>(&eb[j][0]);
     }
   };
 
@@ -178,30 +179,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_tile(0);
+#pragma unroll
+  for (int d = 0; d < NST; ++d)
+    if (d < nkt) load_tile(d, ra[d], rb[d]);
   const int frow = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt0 = 0; kt0 < nkt; kt0 += NST) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(sA + (row0 + 32 * i) * PITCH + chunk * 16) = ra[i];
+    for (int d = 0; d < NST; ++d) {
+      const int kt = kt0 + d;
+      if (kt < nkt) {
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4*>(sB + (row0 + 32 * j) * PITCH + chunk * 16) = rb[j];
-    __syncthreads();
-    if (kt + 1 < nkt) load_tile(kt + 1);
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(sA + (row0 + 32 * i) * PITCH + chunk * 16) = ra[d][i];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint4 fa[TM], fb[TN];
+        for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4*>(sB + (row0 + 32 * j) * PITCH + chunk * 16) = rb[d][j];
+        __syncthreads();
+        if (kt + NST < nkt) load_tile(kt + NST, ra[d], rb[d]);     // refill the stage just written to LDS
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const uint4*>(sA + ((wr * TM + i) * 32 + frow) * PITCH + (2 * s + fh) * 16);
+        for (int s = 0; s < 4; ++s) {
+          uint4 fa[TM], fb[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const uint4*>(sB + ((wc * TN + j) * 32 + frow) * PITCH + (2 * s + fh) * 16);
+          for (int i = 0; i < TM; ++i)
+            fa[i] = *reinterpret_cast<const uint4*>(sA + ((wr * TM + i) * 32 + frow) * PITCH + (2 * s + fh) * 16);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int j = 0; j < TN; ++j)
+            fb[j] = *reinterpret_cast<const uint4*>(sB + ((wc * TN + j) * 32 + frow) * PITCH + (2 * s + fh) * 16);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -297,7 +306,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 rp[4], rq[4];
+  constexpr int NST = 3;
+  uint4 rp[NST][4], rq[NST][4];
   // scalar path: per-element decode of this thread's fixed chunk columns (done once)
   int e_c[EPC], e_kh[EPC], e_kw[EPC];
   bool e_kok[EPC], e_ocok[EPC];
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       e_ocok[e] = ocp + e < p.OC;
     }
   }
-  auto load_tile = [&](long long mt) {
+  auto load_tile = [&](long long mt, uint4 (&rp_)[4], uint4 (&rq_)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long m = mt * BKM + prow + RPP * i;
@@ -342,8 +352,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
           vq = *reinterpret_cast<const uint4*>(&eq[0]);
         }
       }
-      rp[i] = vp;
-      rq[i] = vq;
+      rp_[i] = vp;
+      rq_[i] = vq;
     }
   };
 
@@ -353,15 +363,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
   if (mt_end > mt_total) mt_end = mt_total;
   if (mt_begin >= mt_end) return;
 
-  load_tile(mt_begin);
-  for (long long mt = mt_begin; mt < mt_end; ++mt) {
+#pragma unroll
+  for (int d = 0; d < NST; ++d)
+    if (mt_begin + d < mt_end) load_tile(mt_begin + d, rp[d], rq[d]);
+  for (long long mt0 = mt_begin; mt0 < mt_end; mt0 += NST) {
+#pragma unroll
+    for (int d = 0; d < NST; ++d) {
+      const long long mt = mt0 + d;
+      if (mt < mt_end) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sP + (prow + RPP * i) * PITCH + col * 16) = rp[i];
-      *reinterpret_cast<uint4*>(sQ + (prow + RPP * i) * PITCH + col * 16) = rq[i];
+      *reinterpret_cast<uint4*>(sP + (prow + RPP * i) * PITCH + col * 16) = rp[d][i];
+      *reinterpret_cast<uint4*>(sQ + (prow + RPP * i) * PITCH + col * 16) = rq[d][i];
     }
     __syncthreads();
-    if (mt + 1 < mt_end) load_tile(mt + 1);
+    if (mt + NST < mt_end) load_tile(mt + NST, rp[d], rq[d]);
     if constexpr (sizeof(T) == 2) {
       // lane: group g = lane>>4 (h = g>>1 picks k rows 8h.., half = g&1 picks 16 columns), t = lane&15.
       const int g = lane >> 4, t = lane & 15;
@@ -408,6 +424,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
       }
     }
     __syncthreads();
+      }
+    }
   }
 
   const int frow = lane & 31, fh = lane >> 5;
@@ -497,9 +515,9 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
                    (a.x_bs % EPC == 0) && (a.dy_bs % EPC == 0) && (((uintptr_t)a.x) % 16 == 0) && (((uintptr_t)a.dy) % 16 == 0);
   const int tx = (K + 127) / 128, ty = (a.OC + 127) / 128;
   const long long mt_total = (M + Cfg::BKM - 1) / Cfg::BKM;
-  long long want = (1024 + (long long)tx * ty - 1) / ((long long)tx * ty);
+  long long want = (512 + (long long)tx * ty - 1) / ((long long)tx * ty);   // ~2 blocks per CU; every extra slice re-adds dW atomically
   if (want < 1) want = 1;
-  long long max_split = mt_total / 4;
+  long long max_split = mt_total / 8;
   if (max_split < 1) max_split = 1;
   long long S = want < max_split ? want : max_split;
   a.tiles_per_split = (int)((mt_total + S - 1) / S);

@@ -117,6 +117,7 @@ class Context:
         self.world_size = 1
         self.sync_bn = True
         self.salt_counter = 0
+        self.keepalive = None     # list: while set, every tensor handed out by empty()/zeros() is kept alive (bench replay)
 
     # ---- device / dtype -------------------------------------------------------------------------
     def init_device(self, device="cuda:0", dtype=F32, seed=1234):
@@ -149,10 +150,13 @@ class Context:
         return ctypes.c_void_p(self._seed.data_ptr())
 
     def empty(self, shape, dtype=None):
-        return torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+        t = torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+        if self.keepalive is not None:
+            self.keepalive.append(t)
+        return t
 
     def zeros(self, shape, dtype=None):
-        t = torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+        t = self.empty(shape, dtype)
         _lib.lib().call("emrt_memset", ctypes.c_void_p(t.data_ptr()), 0, t.numel() * t.element_size(), self.stream)
         return t
 
