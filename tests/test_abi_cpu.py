@@ -1,0 +1,69 @@
+"""CPU: the C-ABI shared library loads and exports exactly what include/emrt_hip.h declares; the header's prototypes are
+the definitions' prototypes (no compute calls -- there is no GPU here)."""
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from emrt_amd import build_ext
+    return build_ext.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built):
+    from emrt_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 50
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [n for n in protos if n not in exported]
+    assert not missing, missing
+    undeclared = [n for n in exported if n.startswith("emrt_") and n not in protos]
+    assert not undeclared, "exported but not declared in emrt_hip.h: %s" % undeclared
+
+
+def test_header_matches_definitions():
+    from emrt_amd import _lib
+    protos = _lib.parse_header()
+    defs = {}
+    for f in glob.glob(os.path.join(ROOT, "emrt_amd/csrc/*.hip")):
+        s = open(f).read()
+        for m in re.finditer(r'extern "C" ([^{;]+?)\{', s, re.S):
+            p = re.sub(r"/\*.*?\*/", "", " ".join(m.group(1).split()))
+            name = re.search(r"(\w+)\s*\(", p).group(1)
+            args = p[p.index("(") + 1:p.rindex(")")]
+            types = [] if args.strip() in ("", "void") else [re.match(r"(.*?)(\w+)$", " ".join(a.split())).group(1).strip() for a in args.split(",")]
+            defs[name] = types
+    assert set(defs) == set(protos)
+    for name, (ret, args) in protos.items():
+        assert [t for t, _ in args] == defs[name], name
+
+
+def test_loader_binds_all_entry_points(built):
+    from emrt_amd import _lib
+    _lib._LIB = None
+    L = _lib.lib()
+    assert L.query("emrt_abi_version") == 1
+    assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
+    assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6) == 2 * 10 * 8 * 18 * 4
+    assert L.last_error() == "" or isinstance(L.last_error(), str)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from emrt_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(_lib.EmrtHipError):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    for f in glob.glob(os.path.join(ROOT, "emrt_amd/**/*.py"), recursive=True):
+        src = open(f).read()
+        assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,76 @@
+"""CPU: config surface (reference config.py:5-251) -- defaults, yaml BASE inheritance, every EMRT ResNet yaml parsed
+key by key into the values transcribed from the reference's configs/EMRT/*.yaml."""
+import argparse
+import os
+
+import pytest
+
+from emrt_amd.config import CfgNode, get_config, update_config
+
+CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "emrt_amd/configs/EMRT")
+
+EXPECT = {
+    "EMRT_256x256_160k_potsdam.yaml": dict(DATASET="Potsdam", CROP=(256, 256), NCLS=6, ITERS=160000, SAVE=2000, PATH="/data/sdu02_peach/potsdam_processing_tif"),
+    "EMRT_224x224_160k_potsdam.yaml": dict(DATASET="Potsdam", CROP=(224, 224), NCLS=6, ITERS=160000, SAVE=2000, PATH="/data/sdu02_peach/potsdam_processing_tif_224"),
+    "EMRT_384x384_160k_potsdam.yaml": dict(DATASET="Potsdam", CROP=(384, 384), NCLS=6, ITERS=160000, SAVE=2000, PATH="/data/sdu02_peach/potsdam_processing_tif_384"),
+    "EMRT_448x448_160k_potsdam.yaml": dict(DATASET="Potsdam", CROP=(448, 448), NCLS=6, ITERS=160000, SAVE=2000, PATH="/data/sdu02_peach/potsdam_processing_tif_448"),
+    "EMRT_512x512_160k_potsdam.yaml": dict(DATASET="Potsdam", CROP=(512, 512), NCLS=6, ITERS=160000, SAVE=2000, PATH="/data/sdu02_peach/potsdam_processing_tif_512"),
+    "EMRT_256x256_160k_loveda.yaml": dict(DATASET="LoveDA", CROP=(256, 256), NCLS=7, ITERS=160000, SAVE=2000, PATH="/data/sdu02_peach/2021LoveDA_merge_256"),
+    "EMRT_256x256_120k_vaihingen.yaml": dict(DATASET="Vaihingen", CROP=(256, 256), NCLS=6, ITERS=120000, SAVE=1000, PATH="/data/sdu02_peach/Vaihingen_processing_tif"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT))
+def test_emrt_yaml_values(name):
+    e = EXPECT[name]
+    cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(CFG_DIR, name)))
+    assert not cfg.is_frozen()                                   # update_config returns a DEFROSTED node (config.py:243-247)
+    assert cfg.DATA.DATASET == e["DATASET"] and cfg.DATA.DATA_PATH == e["PATH"]
+    assert cfg.DATA.CROP_SIZE == e["CROP"] and isinstance(cfg.DATA.CROP_SIZE, tuple)   # "(256, 256)" string literal_eval'ed
+    assert cfg.DATA.NUM_CLASSES == e["NCLS"] and cfg.DATA.BATCH_SIZE == 8 and cfg.DATA.BATCH_SIZE_VAL == 4
+    assert cfg.TRAIN.BASE_LR == 0.01 and cfg.TRAIN.END_LR == 0.0 and cfg.TRAIN.ITERS == e["ITERS"] and cfg.TRAIN.POWER == 0.9
+    assert cfg.TRAIN.IGNORE_INDEX == 255 and cfg.TRAIN.LOSS == "MixSoftmaxCrossEntropyLoss"
+    assert cfg.TRAIN.LR_SCHEDULER.NAME == "PolynomialDecay"
+    o = cfg.TRAIN.OPTIMIZER
+    assert (o.NAME, o.MOMENTUM, o.WEIGHT_DECAY, o.GRAD_CLIP, o.NESTEROV) == ("SGD", 0.9, 1e-4, 1.0, False)
+    assert cfg.MODEL.NAME == "EMRT" and cfg.MODEL.ENCODER.TYPE == "resnet50" and cfg.MODEL.OUTPUT_STRIDE == 32
+    assert cfg.MODEL.AUX.LOSS is True and cfg.MODEL.AUX.AUX_WEIGHT == 0.4 and cfg.MODEL.AUX.AUXIHEAD is False
+    assert cfg.VAL.IMAGE_BASE_SIZE == e["CROP"][0] and cfg.VAL.CROP_SIZE == list(e["CROP"]) and cfg.VAL.STRIDE_SIZE == [320, 320]
+    assert cfg.VAL.MEAN == [123.675, 116.28, 103.53] and cfg.VAL.STD == [58.395, 57.12, 57.375]
+    assert cfg.SAVE_FREQ_CHECKPOINT == e["SAVE"] and cfg.LOGGING_INFO_FREQ == 100 and cfg.KEEP_CHECKPOINT_MAX == 1
+
+
+def test_defaults_and_cfgnode_semantics(tmp_path):
+    c = get_config()
+    assert c.DATA.BATCH_SIZE == 4 and c.MODEL.NAME == "SETR_MLA" and c.TRAIN.BASE_LR == 0.001 and c.VAL.STRIDE_SIZE == [320, 320]
+    c2 = c.clone()
+    c2.DATA.BATCH_SIZE = 9
+    assert c.DATA.BATCH_SIZE == 4
+    c2.freeze()
+    with pytest.raises(AttributeError):
+        c2.DATA.BATCH_SIZE = 1
+    c2.defrost()
+    c2.DATA.BATCH_SIZE = 1
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("DATA: {NO_SUCH_KEY: 1}\n")
+    with pytest.raises(KeyError):
+        get_config().merge_from_file(str(bad))
+    base = tmp_path / "base.yaml"
+    base.write_text("DATA: {BATCH_SIZE: 16, NUM_CLASSES: 3}\n")
+    child = tmp_path / "child.yaml"
+    child.write_text("BASE: ['base.yaml']\nDATA: {NUM_CLASSES: 5}\n")
+    cfg = update_config(get_config(), argparse.Namespace(cfg=str(child)))
+    assert cfg.DATA.BATCH_SIZE == 16 and cfg.DATA.NUM_CLASSES == 5
+    cfg = update_config(get_config(), argparse.Namespace(cfg=None, pretrained_backbone="/w.pdparams"))
+    assert cfg.MODEL.PRETRAINED == "/w.pdparams"
+
+
+def test_get_model_dispatch():
+    from emrt_amd.src.models import get_model
+    cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(CFG_DIR, "EMRT_256x256_160k_potsdam.yaml")))
+    m = get_model(cfg)
+    assert type(m).__name__ == "EMRT" and m.nclass == 6
+    for name in ("EMRT_CSwin", "EMRT_HRNet_w48", "SETR_MLA", "UperNet_Swin"):
+        cfg.MODEL.NAME = name
+        with pytest.raises(NotImplementedError):
+            get_model(cfg)

@@ -1,0 +1,135 @@
+"""CPU: host logic of the HIP path with a recording stand-in for the C-ABI (tests/fake_abi.py): the full EMRT train step
+is driven through emrt_amd (model -> loss -> backward tape -> optimizer) and the launch sequence is checked for
+completeness and argument sanity.  Nothing is computed; this guards shapes / strides / tape wiring without a GPU."""
+import collections
+
+import pytest
+import torch
+
+from tests import fake_abi
+
+
+@pytest.fixture()
+def fake():
+    f = fake_abi.install()
+    yield f
+    fake_abi.uninstall()
+
+
+def _place(model):
+    from emrt_amd import nn as hnn
+    from emrt_amd.runtime import ctx, F32
+    from emrt_amd.src.models.emrt import NOGRAD_PARAMS
+    model.store = hnn.ParamStore(model, ctx().device, F32, nograd_names=NOGRAD_PARAMS, fused_groups=model.fused_groups(),
+                                 lr_mult_names=model.lr_mult_names())
+    hnn.bind_all(model, model.store)
+    model.store.pack()
+    return model
+
+
+@pytest.mark.parametrize("backbone", ["resnet18", "resnet50"])
+def test_train_step_launch_sequence(fake, backbone):
+    from emrt_amd.src.models.emrt import EMRT
+    from emrt_amd.src.models.losses import MixSoftmaxCrossEntropyLoss
+    from emrt_amd.src.models.solver import Momentum, PolynomialDecay
+    torch.manual_seed(0)
+    m = _place(EMRT(num_classes=6, backbone=backbone))
+    st = m.store
+    # flat layout: fused offsets|logits weights adjacent, no-grad parameters outside the trainable range
+    for name, mod in m.named_modules():
+        if type(mod).__name__ == "MSDeformableAttention":
+            assert st.offsets[name + ".attention_weights.weight"] == st.offsets[name + ".sampling_offsets.weight"] + 288 * 256
+            assert st.offsets[name + ".attention_weights.bias"] == st.offsets[name + ".sampling_offsets.bias"] + 288
+    for n in ("backbone.fc.weight", "backbone.fc.bias", "model.tgt_embed.weight"):
+        assert st.offsets[n] >= st.n_train
+    assert len(st.lr_ranges) == 14 and all(b <= st.n_train for _, b in st.lr_ranges)
+    if backbone == "resnet50":
+        assert st.n_total - st.n_train >= 2048 * 1000 + 1000 + 110 * 256 and abs(st.n_train - 54.03e6) < 0.05e6
+    x, lab = torch.randn(2, 3, 64, 64), torch.randint(0, 6, (2, 64, 64))
+    m.eval()
+    out = m(x)
+    assert tuple(out[0].shape) == tuple(out[1].shape) == (2, 6, 64, 64) and out.tape is None
+    n_eval = len(fake.calls)
+    fake.calls.clear()
+    m.train()
+    opt = Momentum(m, PolynomialDecay(0.01, 100), 0.9, 1e-4, 1.0)
+    m.clear_gradients()
+    out = m(x)
+    n_fwd = len(fake.calls)
+    loss = MixSoftmaxCrossEntropyLoss()(out, lab)
+    loss.backward()
+    opt.step()
+    cnt = collections.Counter(n for n, _ in fake.calls)
+    assert n_fwd > n_eval                                              # training adds dropout / statistics launches
+    assert cnt["emrt_conv2d_wgrad"] == len(st.gemms)                   # every GEMM weight gets exactly one wgrad
+    n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
+    assert cnt["emrt_bn_stats"] == cnt["emrt_bn_bwd_dx"] == n_bn
+    assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
+    assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14 and cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 15
+    assert cnt["emrt_softmax_ce_fwd"] == cnt["emrt_softmax_ce_bwd"] == 2
+    assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
+    # wgrad destinations are distinct slices inside the trainable gradient range
+    g0 = st.grad.data_ptr()
+    dws = [a[2].value - g0 for n, a in fake.calls if n == "emrt_conv2d_wgrad"]
+    assert len(set(dws)) == len(dws) and all(0 <= d < 4 * st.n_train for d in dws)
+    # every device pointer handed to a conv is 2-byte aligned at least and non-null
+    for n, a in fake.calls:
+        if n == "emrt_conv2d":
+            assert a[0].value and a[1].value and a[2].value
+
+
+def test_tape_accumulates_into_views(fake):
+    """alias bookkeeping: gradients of token-slab / channel-slice views land in the base buffer's gradient."""
+    from emrt_amd import functional as Fn
+    from emrt_amd.runtime import ctx, Tape
+    c = ctx()
+    tape = Tape()
+    c.tape = tape
+    base = c.zeros((2, 21, 8))
+    v = Fn.tokens_as_map(Fn.narrow(base, 1, 5, 16), 4, 4)
+    c.tape = None
+    g = c.zeros((2, 4, 4, 8))
+    tape.add_grad(v, g)
+    bg = tape.grad(base)
+    assert bg is not None and tuple(bg.shape) == (2, 21, 8)
+    assert tape.grad(v).data_ptr() == bg.data_ptr() + 5 * 8 * bg.element_size()
+    name, args = fake.calls[-1]
+    assert name == "emrt_acc3d" and args[6:9] == (2, 16, 8) and (args[1], args[2]) == (21 * 8, 8) and (args[4], args[5]) == (16 * 8, 8)
+    # a gradient handed to two targets is never modified in place through either of them
+    t1, t2, shared = c.zeros((4, 8)), c.zeros((4, 8)), c.zeros((4, 8))
+    tape.add_grad(t1, shared)
+    tape.add_grad(t2, shared)
+    tape.add_grad(t1, c.zeros((4, 8)))
+    assert tape.grad(t1).data_ptr() != shared.data_ptr() and tape.grad(t2).data_ptr() == shared.data_ptr()
+
+
+def test_strided_geometry_helper():
+    from emrt_amd import functional as Fn
+    g = torch.zeros(2, 21, 8)
+    v = g.narrow(1, 4, 16)
+    m = v.as_strided((2, 4, 4, 8), (168, 32, 8, 1), v.storage_offset())
+    assert Fn._geom3(m, torch.zeros(2, 4, 4, 8)) == (2, 16, 8, [(168, 8), (128, 8)])
+    cat = torch.zeros(2, 4, 4, 24)
+    assert Fn._geom3(m, cat[..., 8:16]) == (2, 16, 8, [(168, 8), (384, 24)])
+    assert Fn._geom3(torch.zeros(3, 8), torch.zeros(3, 8)) == (1, 1, 24, [(24, 24), (24, 24)])
+
+
+def test_window_grid_properties():
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from emrt_amd.src.api import infer
+    from oracle import infer_ref
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 700), st.integers(1, 700), st.integers(16, 300), st.integers(8, 400))
+    def run(h, w, crop, stride):
+        wins = infer.window_grid(h, w, (crop, crop), (stride, stride))
+        assert wins == infer_ref.window_grid(h, w, (crop, crop), (stride, stride))
+        for (a, b, c_, d) in wins:
+            assert 0 <= a < c_ <= h and 0 <= b < d <= w and c_ - a <= crop and d - b <= crop
+        if stride <= crop:
+            cov = torch.zeros(h, w, dtype=torch.int32)
+            for (a, b, c_, d) in wins:
+                cov[a:c_, b:d] += 1
+            assert int(cov.min()) >= 1          # full coverage whenever stride <= crop
+    run()
