@@ -580,3 +580,26 @@ def test_pack_weights_layouts(dtype):
     off = (conv.gw.bwd_ptr - base) // esz
     bwd = h.store.packed[off:off + w.numel()].float().cpu().view(40, 3, 3, 72)
     assert torch.equal(bwd, w.permute(1, 2, 3, 0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_msda_golden_vectors(dtype):
+    """The committed golden vectors (numpy-f64 oracle) through the HIP kernel: locations enter as offsets from ref = 0."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msda_core.npz"))
+    c = init(dtype)
+    shapes = [tuple(int(v) for v in s) for s in z["shapes"]]
+    value, loc, aw = torch.from_numpy(z["value"]), torch.from_numpy(z["loc"]), torch.from_numpy(z["aw"])
+    B, Lq, M, L, Pn, _ = loc.shape
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).reshape(1, 1, 1, L, 1, 2)
+    off = (loc * norm).reshape(B, Lq, M * L * Pn * 2)          # loc = 0 + off / (W, H)
+    logits = torch.log(aw.reshape(B, Lq, M * L * Pn))           # softmax(log p) = p (p sums to 1 per head)
+    offw = torch.cat([off, logits], -1)
+    ref = torch.zeros(1, Lq, 1, 2)
+    y = Fn.msda(dev(rnd(value).reshape(B, -1, M * 32)), dev(offw, torch.float32), dev(ref, torch.float32), shapes, M, Pn)
+    want = torch.from_numpy(z["out"]) if dtype == F32 else None
+    if dtype == F32:
+        close("msda golden", host(y), want, dtype, atol=2e-5, rtol=1e-4)
+    else:
+        close("msda golden", host(y), torch.from_numpy(z["out"]), dtype)

@@ -133,3 +133,14 @@ def test_window_grid_properties():
                 cov[a:c_, b:d] += 1
             assert int(cov.min()) >= 1          # full coverage whenever stride <= crop
     run()
+
+
+def test_state_dict_matches_oracle_key_by_key():
+    """The product's state dict has exactly the oracle's (= the reference's) keys and shapes."""
+    from emrt_amd.src.models.emrt import EMRT
+    from oracle.emrt_torch import EMRT as OracleEMRT
+    for bb in ("resnet18", "resnet50"):
+        a, b = OracleEMRT(6, bb).state_dict(), EMRT(num_classes=6, backbone=bb).state_dict()
+        assert list(a.keys()) == list(b.keys()) or set(a) == set(b)
+        assert all(a[k].shape == b[k].shape for k in a)
+    assert len(a) == 545 and sum(v.numel() for k, v in a.items() if not k.endswith(("_mean", "_variance"))) == 56107286
