@@ -37,6 +37,7 @@ struct ConvArgs {
   long long res_bs;
   int KH, KW, stride, pad;
   int relu, out_f32;
+  double* stats;   // optional [2*OC]: per-channel sum / sum of squares of the STORED outputs (BatchNorm statistics), fp64 atomics
 };
 
 template <class T>
@@ -215,6 +216,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const T* resp = (const T*)p.res;
+  float st_s[TN], st_q[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -235,7 +239,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
         if (resp) v += to_f32(resp[rbase + n]);
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.out_f32) ((float*)p.out)[obase + n] = v;
-        else ((T*)p.out)[obase + n] = from_f32<T>(v);
+        else {
+          const T q = from_f32<T>(v);
+          ((T*)p.out)[obase + n] = q;
+          v = to_f32(q);                 // statistics of what the next kernel will actually read
+        }
+        st_s[j] += v;
+        st_q[j] = fmaf(v, v, st_q[j]);
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s2 = st_s[j] + __shfl_xor(st_s[j], 32, 64);     // the two half-waves hold the same column
+      const float q2 = st_q[j] + __shfl_xor(st_q[j], 32, 64);
+      const int n = bn * BN + (wc * TN + j) * 32 + frow;
+      if (fh == 0 && n < p.OC) {
+        atomicAdd(p.stats + n, (double)s2);
+        atomicAdd(p.stats + p.OC + n, (double)q2);
       }
     }
   }
@@ -458,14 +480,12 @@ static int launch_igemm(const ConvArgs& a, hipStream_t st) {
 
 template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
+  // largest tile that still puts about one block on each of the 256 CUs; tiny problems take 64x64
   const long long M = (long long)a.N * a.OH * a.OW;
+  auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
   if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
-  if (a.OC <= 64) {
-    if (M >= 128 * 256) return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
-    return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
-  }
-  const long long big_tiles = ((M + 127) / 128) * ((a.OC + 127) / 128);
-  if (big_tiles >= 384) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
+  if (a.OC > 64 && blocks(128, 128) >= 224) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
+  if (blocks(128, 64) >= 224) return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
   return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
 }
 
@@ -482,7 +502,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
                            int OH, int OW, int OC, int ldout, long long out_bs,
                            int ldres, long long res_bs,
                            int KH, int KW, int stride, int pad,
-                           int mode, int relu, int out_f32, int dtype, void* stream) {
+                           int mode, int relu, int out_f32, double* bn_stats, int dtype, void* stream) {
   EMRT_REQUIRE(in && w_packed && out, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
@@ -498,7 +518,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
-  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
   return mode == 0 ? conv_dispatch<bf16_t, 0>(a, st) : conv_dispatch<bf16_t, 1>(a, st);

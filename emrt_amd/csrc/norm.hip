@@ -22,7 +22,8 @@ template <class T, int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                          const T* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, long long M, int C, int tx_n,
-                                                         float* __restrict__ partial, long long rpb, long long bs) {
+                                                         float* __restrict__ partial, long long rpb, long long bs,
+                                                         double* __restrict__ dsums) {
   __shared__ float red[256 * 8];
   const int ty_n = 256 / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -68,9 +69,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s0[e] += red[(t * tx_n + tx) * 8 + e]; s1[e] += red[(t * tx_n + tx) * 8 + 4 + e]; }
     }
-    float* pp = partial + (long long)blockIdx.x * 2 * C;
+    if (dsums) {      // BatchNorm path: fp64 atomics straight into the [2C] sums (no partial buffer, no combine launch)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { pp[c + e] = s0[e]; pp[C + c + e] = s1[e]; }
+      for (int e = 0; e < 4; ++e) { atomicAdd(dsums + c + e, (double)s0[e]); atomicAdd(dsums + C + c + e, (double)s1[e]); }
+    } else {
+      float* pp = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pp[c + e] = s0[e]; pp[C + c + e] = s1[e]; }
+    }
   }
 }
 
@@ -108,50 +114,74 @@ __global__ __launch_bounds__(256) void bn_sum_partials_kernel(const float* __res
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var) {
+// BN backward finalize: sums[2][C] = (sum dy', sum dy'*xhat) -> dgamma += , dbeta +=   (sums kept for dx)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double mu = (double)sums[c] / count;
-  double var = (double)sums[C + c] / count - mu * mu;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)mu;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (run_mean) {
-    run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * (float)mu;
-    run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)var;
+  if (dbeta) dbeta[c] += sums[c];
+  if (dgamma) dgamma[c] += sums[C + c];
+}
+
+// Per-channel constants of one BatchNorm layer, from fp64 sums (training) or the running statistics (eval).
+struct BnChan { float mean, invstd; };
+__device__ __forceinline__ BnChan bn_chan(const double* __restrict__ sums, const float* __restrict__ run_mean,
+                                          const float* __restrict__ run_var, int C, int c, double inv_count, float eps) {
+  BnChan o;
+  if (sums) {
+    const double mu = sums[c] * inv_count;
+    double var = sums[C + c] * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    o.mean = (float)mu;
+    o.invstd = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    o.mean = run_mean[c];
+    o.invstd = rsqrtf(run_var[c] + eps);
   }
+  return o;
 }
 
-__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float eps,
-                                     float* __restrict__ mean, float* __restrict__ invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  mean[c] = run_mean[c];
-  invstd[c] = rsqrtf(run_var[c] + eps);
-}
-
-// y = [relu]((x - mean) * invstd * gamma + beta [+ res])
+// y = [relu]((x - mean) * invstd * gamma + beta [+ res]).  Training (sums != null): mean/invstd come from the fp64
+// sums; block 0 also saves them for backward and updates the running statistics (Paddle convention: momentum 0.9 =>
+// running = 0.9*running + 0.1*batch, biased variance).  Threads own a fixed channel quad, so the per-channel constants
+// are computed once per thread and the row loop is a pure streaming fma.
 template <class T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ res, int ldres,
-                                                       T* __restrict__ y, int ldy, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, long long M, int C, int relu) {
+__global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ res, int ldres,
+                                                       T* __restrict__ y, int ldy, const double* __restrict__ sums, double inv_count,
+                                                       float eps, float momentum, float* __restrict__ mean_out,
+                                                       float* __restrict__ invstd_out, float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long M, int C, int relu, int rows_per_pass) {
   const int quads = C / 4;
-  const long long total = M * quads;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const long long r = idx / quads;
-    const int c = (int)(idx - r * quads) * 4;
+  const int c = (threadIdx.x % quads) * 4;
+  const int lane_row = threadIdx.x / quads;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const BnChan k = bn_chan(sums, run_mean, run_var, C, c + e, inv_count, eps);
+    sc[e] = k.invstd * gamma[c + e];
+    sh[e] = beta[c + e] - k.mean * sc[e];
+    if (sums && blockIdx.x == 0 && lane_row == 0) {
+      mean_out[c + e] = k.mean;
+      invstd_out[c + e] = k.invstd;
+      if (run_mean) {
+        const double mu = sums[c + e] * inv_count;
+        double var = sums[C + c + e] * inv_count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        run_mean[c + e] = momentum * run_mean[c + e] + (1.f - momentum) * (float)mu;
+        run_var[c + e] = momentum * run_var[c + e] + (1.f - momentum) * (float)var;
+      }
+    }
+  }
+  for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {
     float v[4], o[4];
     Vec4<T>::load(x + r * ldx + c, v);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean[c + e]) * invstd[c + e] * gamma[c + e] + beta[c + e];
+    for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], sc[e], sh[e]);
     if (res) {
-      float q[4];
-      Vec4<T>::load(res + r * ldres + c, q);
+      float w[4];
+      Vec4<T>::load(res + r * ldres + c, w);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += q[e];
+      for (int e = 0; e < 4; ++e) o[e] += w[e];
     }
     if (relu) {
 #pragma unroll
@@ -161,26 +191,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
-// BN backward finalize: sums[2][C] = (sum dy', sum dy'*xhat) -> dgamma += , dbeta +=   (sums kept for dx)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  if (dbeta) dbeta[c] += sums[c];
-  if (dgamma) dgamma[c] += sums[C + c];
-}
-
-// dx = gamma*invstd*(dy' - sum_dy/count - xhat*sum_dyxhat/count); optional dres = dy' (gradient of the fused residual)
+// dx = gamma*invstd*(dy' - sum_dy/count - xhat*sum_dyxhat/count); optional dres = dy' (gradient of the fused residual);
+// block 0 accumulates dgamma += sum dy'*xhat, dbeta += sum dy' (from this rank's `lsums` when given: SyncBN).
 template <class T>
-__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+__global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                         const T* __restrict__ y, int ldy, T* __restrict__ dx, int lddx,
                                                         T* __restrict__ dres, int lddres, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ sums, float inv_count, long long M, int C) {
+                                                        const double* __restrict__ sums, const double* __restrict__ lsums,
+                                                        double inv_count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        long long M, int C, int rows_per_pass) {
   const int quads = C / 4;
-  const long long total = M * quads;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const long long r = idx / quads;
-    const int c = (int)(idx - r * quads) * 4;
+  const int c = (threadIdx.x % quads) * 4;
+  const int lane_row = threadIdx.x / quads;
+  float mu[4], is[4], k0[4], k1[4], gi[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mu[e] = mean[c + e];
+    is[e] = invstd[c + e];
+    gi[e] = gamma[c + e] * is[e];
+    k0[e] = (float)(sums[c + e] * inv_count);
+    k1[e] = (float)(sums[C + c + e] * inv_count);
+    if (blockIdx.x == 0 && lane_row == 0) {
+      const double* ls = lsums ? lsums : sums;
+      if (dbeta) dbeta[c + e] += (float)ls[c + e];
+      if (dgamma) dgamma[c + e] += (float)ls[C + c + e];
+    }
+  }
+  for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {
     float v[4], g[4], o[4];
     Vec4<T>::load(x + r * ldx + c, v);
     Vec4<T>::load(dy + r * lddy + c, g);
@@ -191,10 +229,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* __restrict__ x,
       for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xh = (v[e] - mean[c + e]) * invstd[c + e];
-      o[e] = gamma[c + e] * invstd[c + e] * (g[e] - sums[c + e] * inv_count - xh * sums[C + c + e] * inv_count);
-    }
+    for (int e = 0; e < 4; ++e) o[e] = gi[e] * (g[e] - k0[e] - (v[e] - mu[e]) * is[e] * k1[e]);
     Vec4<T>::store(dx + r * lddx + c, o);
     if (dres) Vec4<T>::store(dres + r * lddres + c, g);
   }
@@ -508,77 +543,78 @@ extern "C" size_t emrt_colreduce_workspace_bytes(long long M, int C) {
   return ((size_t)gx * 2 * C + 2 * (size_t)C) * sizeof(float);
 }
 
-// BN training statistics, step 1: local sums -> sums[2][C] (sum x, sum x^2).  workspace >= emrt_colreduce_workspace_bytes.
-extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, float* sums, void* workspace, int dtype, void* stream) {
-  EMRT_REQUIRE(x && sums && workspace, "null pointer");
+// threads / rows-per-pass / grid for the hoisted (fixed channel quad per thread) BN kernels
+static inline bool bn_rowgeom(long long M, int C, int& threads, int& rows_per_pass, int& grid) {
+  const int quads = C / 4;
+  if (quads <= 256) { if (256 % quads) return false; threads = 256; rows_per_pass = 256 / quads; }
+  else if (quads <= 512) { threads = quads; rows_per_pass = 1; }          // C = 2048 -> 512 threads
+  else return false;
+  long long g = (M + (long long)rows_per_pass * 4 - 1) / ((long long)rows_per_pass * 4);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  grid = (int)g;
+  return true;
+}
+
+// BatchNorm statistics when the producer could not fuse them: sums[2C] (fp64, PRE-ZEROED by the caller) += (sum x, sum x^2)
+extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream) {
+  EMRT_REQUIRE(x && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0, "C and ld must be multiples of 4");
   int tx, gx, gy;
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
-  float* partial = (float*)workspace;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 0>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, M, 0LL),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, M, 0LL));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
+            hipLaunchKernelGGL((col_reduce_kernel<float, 0>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, nullptr, M, 0LL, sums),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, nullptr, M, 0LL, sums));
   return check_launch("emrt_bn_stats");
 }
 
-// step 2: sums (+count) -> mean/invstd, running-stat update (run_* may be null)
-extern "C" int emrt_bn_finalize(const float* sums, double count, int C, float eps, float momentum, float* mean, float* invstd,
-                                float* run_mean, float* run_var, void* stream) {
-  EMRT_REQUIRE(sums && mean && invstd, "null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, C, eps, momentum, mean, invstd, run_mean, run_var);
-  return check_launch("emrt_bn_finalize");
-}
-
-extern "C" int emrt_bn_eval_stats(const float* run_mean, const float* run_var, int C, float eps, float* mean, float* invstd, void* stream) {
-  EMRT_REQUIRE(run_mean && run_var && mean && invstd, "null pointer");
-  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, run_mean, run_var, C, eps, mean, invstd);
-  return check_launch("emrt_bn_eval_stats");
-}
-
-extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const float* mean,
-                             const float* invstd, const float* gamma, const float* beta, long long M, int C, int relu, int dtype,
-                             void* stream) {
-  EMRT_REQUIRE(x && y && mean && invstd && gamma && beta, "null pointer");
+// y = [relu](BN(x) [+ res]).  sums != null: training -- statistics = sums / count (count may be the global row count after a
+// cross-rank all-reduce of sums for SyncBatchNorm); mean/invstd are saved and run_* updated.  sums == null: eval -- run_* are used.
+extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count,
+                             float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+                             const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream) {
+  EMRT_REQUIRE(x && y && gamma && beta, "null pointer");
+  EMRT_REQUIRE(sums ? (mean && invstd) : (run_mean && run_var), "training needs mean/invstd outputs, eval needs running statistics");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0), "C and ld must be multiples of 4");
+  int threads, rpp, grid;
+  EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ew_grid(M * (C / 4));
+  const double inv_count = sums ? 1.0 / count : 0.0;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, mean, invstd, gamma, beta, M, C, relu),
-            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, mean, invstd, gamma, beta, M, C, relu));
+            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), 0, st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
   return check_launch("emrt_bn_apply");
 }
 
-// BN backward step 1: sums[2][C] = (sum dy', sum dy'*xhat); y (post-ReLU output) may be null when no ReLU was fused.
+// BN backward step 1: sums[2C] (fp64, PRE-ZEROED) += (sum dy', sum dy'*xhat); y (post-ReLU output) may be null when no ReLU was fused.
 extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean,
-                                  const float* invstd, long long M, int C, float* sums, void* workspace, int dtype, void* stream) {
-  EMRT_REQUIRE(x && dy && mean && invstd && sums && workspace, "null pointer");
+                                  const float* invstd, long long M, int C, double* sums, int dtype, void* stream) {
+  EMRT_REQUIRE(x && dy && mean && invstd && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!y || ldy % 4 == 0), "C and ld must be multiples of 4");
   int tx, gx, gy;
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
-  float* partial = (float*)workspace;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, partial, M, 0LL),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, partial, M, 0LL));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
+            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums));
   return check_launch("emrt_bn_bwd_reduce");
 }
 
-// BN backward step 2: dgamma += sums[1], dbeta += sums[0]; dx (and optional dres = masked dy). inv_count = 1/rows (global for SyncBN).
+// BN backward step 2: dx (and optional dres = masked dy); dgamma += , dbeta += from `local_sums` when given (SyncBN: the
+// dx formula uses the rank-summed `sums` with the global count, the parameter gradients use this rank's sums) else from `sums`.
 extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
                               void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
-                              const float* sums, float inv_count, float* dgamma, float* dbeta, long long M, int C, int dtype,
-                              void* stream) {
+                              const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M,
+                              int C, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
+  int threads, rpp, grid;
+  EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
-  if (dgamma || dbeta) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
-  const int grid = ew_grid(M * (C / 4));
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, inv_count, M, C),
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, inv_count, M, C));
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp));
   return check_launch("emrt_bn_bwd_dx");
 }
 
@@ -617,8 +653,8 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   float* partial = (float*)workspace;
   float* sums = partial + (size_t)gx * 2 * C;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs));
+            hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr));
   hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, (float*)nullptr, dbias);
   return check_launch("emrt_colsum_acc");

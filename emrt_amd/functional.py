@@ -273,7 +273,7 @@ class GemmWeight:
         self.need_bwd = True
 
 
-def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True):
+def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None):
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice)."""
     c = ctx()
     N, H, W, C, ldin, in_bs = _check_map(x)
@@ -289,7 +289,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     if residual is not None:
         _, _, _, _, ldres, res_bs = _check_map(residual)
     _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
-              OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), c.dtype, c.stream)
+              OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
@@ -313,7 +313,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
             if need_dx:
                 dx = c.empty(tuple(x.shape))
                 _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
-                          H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, c.dtype, c.stream)
+                          H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, None, c.dtype, c.stream)
                 tape.add_grad(x, dx)
         tape.record(bwd)
     return out
@@ -346,14 +346,15 @@ class BNState:
 
 
 def _allreduce_sums(sums, count):
-    """SyncBatchNorm: sum the per-rank (sum, sumsq) vectors and the row count over ranks (RCCL all-reduce)."""
+    """SyncBatchNorm: sum the per-rank fp64 (sum, sumsq) vectors and the row count over ranks (RCCL all-reduce)."""
     import torch.distributed as dist
     dist.all_reduce(sums)
     return count * dist.get_world_size()
 
 
-def batch_norm(x, bn, relu=False, residual=None, out=None):
-    """y = [relu](BN(x) [+ residual]); training uses batch statistics (all-reduced over ranks when bn.sync)."""
+def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
+    """y = [relu](BN(x) [+ residual]).  Training uses batch statistics from the fp64 `sums` [2C] that the producing conv's
+    epilogue accumulated (or from a statistics pass when `sums` is None), all-reduced over ranks when bn.sync."""
     c = ctx()
     N, H, W, C, ldx, x_bs = _check_map(x)
     assert x_bs == H * W * ldx, "batch_norm input must be a dense NHWC tensor (possibly channel-sliced)"
@@ -366,19 +367,21 @@ def batch_norm(x, bn, relu=False, residual=None, out=None):
     if residual is not None:
         _, _, _, _, ldres, r_bs = _check_map(residual)
         assert r_bs == H * W * ldres
-    mean = c.empty((C,), torch.float32)
-    invstd = c.empty((C,), torch.float32)
     count = M
+    mean = invstd = None
     if c.training:
-        sums = c.empty((2 * C,), torch.float32)
-        ws = c.workspace(_L().query("emrt_colreduce_workspace_bytes", M, C))
-        _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), P(ws), c.dtype, c.stream)
+        mean = c.empty((C,), torch.float32)
+        invstd = c.empty((C,), torch.float32)
+        if sums is None:
+            sums = c.zeros_f64(2 * C)
+            _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), c.dtype, c.stream)
         if bn.sync and c.world_size > 1 and c.sync_bn:
             count = _allreduce_sums(sums, M)
-        _L().call("emrt_bn_finalize", P(sums), float(count), C, bn.eps, bn.momentum, P(mean), P(invstd), P(bn.run_mean), P(bn.run_var), c.stream)
+        _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd),
+                  P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     else:
-        _L().call("emrt_bn_eval_stats", P(bn.run_mean), P(bn.run_var), C, bn.eps, P(mean), P(invstd), c.stream)
-    _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(mean), P(invstd), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
+        _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, None, 1.0, bn.eps, bn.momentum, None, None,
+                  P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         assert c.training, "backward through eval-mode BatchNorm is not supported"
@@ -389,28 +392,32 @@ def batch_norm(x, bn, relu=False, residual=None, out=None):
                 return
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             assert dy_bs == H * W * lddy
-            sums2 = c.empty((2 * C,), torch.float32)
-            ws2 = c.workspace(_L().query("emrt_colreduce_workspace_bytes", M, C))
+            sums2 = c.zeros_f64(2 * C)
             yv = out if relu else None
-            _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), P(ws2), c.dtype, c.stream)
+            _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), c.dtype, c.stream)
             # dgamma/dbeta use the LOCAL sums (the gradient all-reduce combines ranks); dx needs the GLOBAL sums
-            synced = bn.sync and c.world_size > 1 and c.sync_bn
-            if synced:
-                local = c.empty((2 * C,), torch.float32)
-                _L().call("emrt_cast", P(sums2), P(local), 2 * C, 0, F32, c.stream)
+            local = None
+            if bn.sync and c.world_size > 1 and c.sync_bn:
+                local = c.empty((2 * C,), torch.float64)
+                _L().call("emrt_cast", P(sums2), P(local), 4 * C, 0, F32, c.stream)     # raw 8-byte copy as 2 x f32
                 _allreduce_sums(sums2, M)
             dx = c.empty(tuple(x.shape))
             dres = c.empty(tuple(x.shape)) if (residual is not None and relu) else None
             _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
-                      P(sums2), 1.0 / count, None if synced else P(bn.dgamma), None if synced else P(bn.dbeta), M, C, c.dtype, c.stream)
-            if synced:
-                add_into(bn.dbeta, local[:C])
-                add_into(bn.dgamma, local[C:])
+                      P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C, c.dtype, c.stream)
             tape.add_grad(x, dx)
             if residual is not None:
                 tape.add_grad(residual, dres if dres is not None else dy)
         tape.record(bwd)
     return out
+
+
+def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
+    """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training)."""
+    c = ctx()
+    sums = c.zeros_f64(2 * bn.C) if c.training else None
+    y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums)
+    return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 
 
 def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residual=None, out=None):

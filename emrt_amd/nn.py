@@ -196,7 +196,7 @@ class BatchNorm2D(HipLayer):
 
     def __init__(self, c, sync=False):
         super().__init__()
-        self.c = c
+        self.c = self.C = c
         self.weight = tnn.Parameter(torch.ones(c))
         self.bias = tnn.Parameter(torch.zeros(c))
         self.register_buffer("_mean", torch.zeros(c))
@@ -209,8 +209,8 @@ class BatchNorm2D(HipLayer):
         st.dgamma, st.dbeta = self.weight.grad.view(-1), self.bias.grad.view(-1)
         st.run_mean, st.run_var = self._buffers["_mean"], self._buffers["_variance"]
 
-    def forward(self, x, relu=False, residual=None, out=None):
-        return Fn.batch_norm(x, self.state, relu=relu, residual=residual, out=out)
+    def forward(self, x, relu=False, residual=None, out=None, sums=None):
+        return Fn.batch_norm(x, self.state, relu=relu, residual=residual, out=out, sums=sums)
 
 
 class GroupNorm(HipLayer):

@@ -118,6 +118,9 @@ class Context:
         self.sync_bn = True
         self.salt_counter = 0
         self.keepalive = None     # list: while set, every tensor handed out by empty()/zeros() is kept alive (bench replay)
+        self._arena = None        # fp64 zero arena for BatchNorm sums: one memset per step instead of ~150 tiny ones
+        self._arena_off = 0
+        self._arena_live = False
 
     # ---- device / dtype -------------------------------------------------------------------------
     def init_device(self, device="cuda:0", dtype=F32, seed=1234):
@@ -131,6 +134,7 @@ class Context:
         self._ws = torch.empty(8 << 20, dtype=torch.uint8, device=self.device)
         self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._arena, self._arena_off, self._arena_live = None, 0, False
 
     @property
     def tdtype(self):
@@ -159,6 +163,22 @@ class Context:
         t = self.empty(shape, dtype)
         _lib.lib().call("emrt_memset", ctypes.c_void_p(t.data_ptr()), 0, t.numel() * t.element_size(), self.stream)
         return t
+
+    def begin_step(self, arena_doubles=1 << 19):
+        """Start of a training step: re-zero the fp64 arena that zeros_f64() hands out slices of."""
+        if self._arena is None or self._arena.numel() < arena_doubles:
+            self._arena = torch.empty(arena_doubles, dtype=torch.float64, device=self.device)
+        _lib.lib().call("emrt_memset", ctypes.c_void_p(self._arena.data_ptr()), 0, self._arena.numel() * 8, self.stream)
+        self._arena_off = 0
+        self._arena_live = True
+
+    def zeros_f64(self, n):
+        """Zeroed fp64 [n] buffer (BatchNorm sums).  Inside a step it is a slice of the pre-zeroed arena."""
+        if self._arena_live and self._arena_off + n <= self._arena.numel():
+            t = self._arena[self._arena_off:self._arena_off + n]
+            self._arena_off += (n + 1) // 2 * 2
+            return t
+        return self.zeros((n,), torch.float64)
 
     def zeros_like(self, t):
         """Zero buffer with the same logical shape as t (dense)."""

@@ -47,10 +47,9 @@ class BasicBlock(hnn.HipLayer):  # :43-88
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.conv2(out)
-        identity = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        return self.bn2(out, relu=True, residual=identity)
+        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
+        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x)
+        return Fn.conv_bn(self.conv2, self.bn2, out, relu=True, residual=identity)
 
 
 class BottleneckBlock(hnn.HipLayer):  # :91-149
@@ -67,11 +66,10 @@ class BottleneckBlock(hnn.HipLayer):  # :91-149
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        out = self.conv3(out)
-        identity = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        return self.bn3(out, relu=True, residual=identity)
+        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = Fn.conv_bn(self.conv2, self.bn2, out, relu=True)
+        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x)
+        return Fn.conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 
 class ResNet(hnn.HipLayer):  # :152-257
@@ -103,7 +101,7 @@ class ResNet(hnn.HipLayer):  # :152-257
         return hnn.Sequential(*mods)
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
+        x = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
         x = Fn.maxpool(x, 3, 2, 1)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -127,7 +125,7 @@ class FCNHead(hnn.HipLayer):
 
     def forward(self, x):
         N, H, W, _ = x.shape
-        o = self.convs[0][1](self.convs[0][0](x), relu=True)
+        o = Fn.conv_bn(self.convs[0][0], self.convs[0][1], x, relu=True)
         o = Fn.dropout(o, self.p, self.salt, mode=1, hw=H * W)
         o = self.conv_seg(o)
         return Fn.resize_bilinear(o, H * self.up_ratio, W * self.up_ratio, False, out_nchw_f32=True)
@@ -426,8 +424,8 @@ class Conv2dBlock(hnn.HipLayer):  # :13-29
         self.conv2 = hnn.Sequential(hnn.Conv2D(cout, cout, 3, 1, 1, bias=False), hnn.BatchNorm2D(cout), None)
 
     def forward(self, x):
-        o = self.conv1[1](self.conv1[0](x), relu=True)
-        o = self.conv2[1](self.conv2[0](o), relu=True)
+        o = Fn.conv_bn(self.conv1[0], self.conv1[1], x, relu=True)
+        o = Fn.conv_bn(self.conv2[0], self.conv2[1], o, relu=True)
         return Fn.add_maps(o, x)
 
 
@@ -457,7 +455,7 @@ class PyramidPoolingModule(hnn.HipLayer):  # :50-78
         parts, s0 = [], 0
         for k, br in zip(self.pool_scales, self.pool_branches):
             t = Fn.narrow(tokens, 1, s0, k * k)
-            parts.append(br[2](br[1](t), relu=True))
+            parts.append(Fn.conv_bn(br[1], br[2], t, relu=True))
             s0 += k * k
         return Fn.concat_tokens(parts)
 
@@ -471,8 +469,8 @@ class branch_block(hnn.HipLayer):  # :80-97
 
     def forward(self, x, out=None):
         x = Fn.maxpool(x, 3, 2, 1, need_dx=not self.first)
-        x = self.encode[1](self.encode[0](x), relu=True)
-        return self.encode[4](self.encode[3](x), relu=True, out=out)
+        x = Fn.conv_bn(self.encode[0], self.encode[1], x, relu=True)
+        return Fn.conv_bn(self.encode[3], self.encode[4], x, relu=True, out=out)
 
 
 class spatial_branch(hnn.HipLayer):  # :99-113
@@ -494,11 +492,11 @@ class UpHead(hnn.HipLayer):  # :115-181 (num_conv == 3)
         self.syncbn_fc_0, self.syncbn_fc_1, self.syncbn_fc_2 = hnn.BatchNorm2D(256), hnn.BatchNorm2D(256), hnn.BatchNorm2D(256)
 
     def forward(self, x):  # :164-180
-        x = self.syncbn_fc_0(self.conv_0(x), relu=True)
+        x = Fn.conv_bn(self.conv_0, self.syncbn_fc_0, x, relu=True)
         x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
-        x = self.syncbn_fc_1(self.conv_1(x), relu=True)
+        x = Fn.conv_bn(self.conv_1, self.syncbn_fc_1, x, relu=True)
         x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
-        x = self.syncbn_fc_2(self.conv_2(x), relu=True)
+        x = Fn.conv_bn(self.conv_2, self.syncbn_fc_2, x, relu=True)
         x = self.conv_3(x)
         return Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False, out_nchw_f32=True)
 
@@ -606,6 +604,8 @@ class EMRT(hnn.HipLayer):  # :184-304
         if self.store.dirty:
             self.store.pack()
         c.training = self.training
+        if self.training:
+            c.begin_step()
         tape = Tape() if self.training else None
         c.tape = tape
         try:
@@ -636,8 +636,8 @@ class EMRT(hnn.HipLayer):  # :184-304
             pooled = Fn.tokens_as_map(Fn.narrow(hs, 1, idx, k * k), k, k)
             Fn.resize_bilinear(pooled, S, S, True, out=Fn.narrow(psp_cat, 3, 256 * (1 + i), 256))
             idx += k * k
-        o = self.cls_psp[1](self.cls_psp[0](psp_cat), relu=True)
-        o = self.cls_psp[4](self.cls_psp[3](o), relu=True)
+        o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True)
+        o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
         o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=S * S)
         logits = self.uphead(o)
         if self.training or self.compute_aux_in_eval:
