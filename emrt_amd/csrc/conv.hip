@@ -37,7 +37,8 @@ struct ConvArgs {
   long long res_bs;
   int KH, KW, stride, pad;
   int relu, out_f32;
-  double* stats;   // optional [2*OC]: per-channel sum / sum of squares of the STORED outputs (BatchNorm statistics), fp64 atomics
+  double* stats;   // optional [8][2*OC]: per-channel sum / sum of squares of the STORED outputs (BatchNorm statistics);
+                   // fp64 atomics spread over 8 replicas (by M-tile index) so that blocks do not pile onto one address
 };
 
 template <class T>
@@ -256,8 +257,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
       const float q2 = st_q[j] + __shfl_xor(st_q[j], 32, 64);
       const int n = bn * BN + (wc * TN + j) * 32 + frow;
       if (fh == 0 && n < p.OC) {
-        atomicAdd(p.stats + n, (double)s2);
-        atomicAdd(p.stats + p.OC + n, (double)q2);
+        double* rep = p.stats + (long long)(bm & 7) * 2 * p.OC;
+        atomicAdd(rep + n, (double)s2);
+        atomicAdd(rep + p.OC + n, (double)q2);
       }
     }
   }
@@ -480,12 +482,13 @@ static int launch_igemm(const ConvArgs& a, hipStream_t st) {
 
 template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
-  // largest tile that still puts about one block on each of the 256 CUs; tiny problems take 64x64
+  // largest tile that still leaves >= 2-3 blocks per CU; everything else takes 64x64
   const long long M = (long long)a.N * a.OH * a.OW;
   auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
   if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
-  if (a.OC > 64 && blocks(128, 128) >= 224) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
-  if (blocks(128, 64) >= 224) return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
+  // measured: 64x64 tiles at >= 2 blocks per CU beat 128x64 tiles at ~1 per CU on the 32x32 / token GEMMs
+  if (a.OC > 64 && blocks(128, 128) >= 384) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
+  if (blocks(128, 64) >= 768) return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
   return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
 }
 

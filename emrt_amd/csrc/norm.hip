@@ -69,9 +69,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s0[e] += red[(t * tx_n + tx) * 8 + e]; s1[e] += red[(t * tx_n + tx) * 8 + 4 + e]; }
     }
-    if (dsums) {      // BatchNorm path: fp64 atomics straight into the [2C] sums (no partial buffer, no combine launch)
+    if (dsums) {      // BatchNorm path: fp64 atomics into one of 8 replicas of the [2C] sums (no partial buffer, no combine launch)
+      double* rep = dsums + (long long)(blockIdx.x & 7) * 2 * C;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(dsums + c + e, (double)s0[e]); atomicAdd(dsums + C + c + e, (double)s1[e]); }
+      for (int e = 0; e < 4; ++e) { atomicAdd(rep + c + e, (double)s0[e]); atomicAdd(rep + C + c + e, (double)s1[e]); }
     } else {
       float* pp = partial + (long long)blockIdx.x * 2 * C;
 #pragma unroll
@@ -122,14 +123,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, fl
   if (dgamma) dgamma[c] += sums[C + c];
 }
 
+// BatchNorm sums are accumulated into 8 replicas [8][2C] (fewer adders per address); consumers add them up.
+#define BN_REPLICAS 8
+__device__ __forceinline__ double rep_sum(const double* __restrict__ sums, int C, int idx) {
+  double t = 0.0;
+#pragma unroll
+  for (int r = 0; r < BN_REPLICAS; ++r) t += sums[(long long)r * 2 * C + idx];
+  return t;
+}
+
 // Per-channel constants of one BatchNorm layer, from fp64 sums (training) or the running statistics (eval).
 struct BnChan { float mean, invstd; };
 __device__ __forceinline__ BnChan bn_chan(const double* __restrict__ sums, const float* __restrict__ run_mean,
                                           const float* __restrict__ run_var, int C, int c, double inv_count, float eps) {
   BnChan o;
   if (sums) {
-    const double mu = sums[c] * inv_count;
-    double var = sums[C + c] * inv_count - mu * mu;
+    const double mu = rep_sum(sums, C, c) * inv_count;
+    double var = rep_sum(sums, C, C + c) * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
     o.mean = (float)mu;
     o.invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -164,8 +174,8 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
       mean_out[c + e] = k.mean;
       invstd_out[c + e] = k.invstd;
       if (run_mean) {
-        const double mu = sums[c + e] * inv_count;
-        double var = sums[C + c + e] * inv_count - mu * mu;
+        const double mu = rep_sum(sums, C, c + e) * inv_count;
+        double var = rep_sum(sums, C, C + c + e) * inv_count - mu * mu;
         if (var < 0.0) var = 0.0;
         run_mean[c + e] = momentum * run_mean[c + e] + (1.f - momentum) * (float)mu;
         run_var[c + e] = momentum * run_var[c + e] + (1.f - momentum) * (float)var;
@@ -210,12 +220,12 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     mu[e] = mean[c + e];
     is[e] = invstd[c + e];
     gi[e] = gamma[c + e] * is[e];
-    k0[e] = (float)(sums[c + e] * inv_count);
-    k1[e] = (float)(sums[C + c + e] * inv_count);
+    const double t0 = rep_sum(sums, C, c + e), t1 = rep_sum(sums, C, C + c + e);
+    k0[e] = (float)(t0 * inv_count);
+    k1[e] = (float)(t1 * inv_count);
     if (blockIdx.x == 0 && lane_row == 0) {
-      const double* ls = lsums ? lsums : sums;
-      if (dbeta) dbeta[c + e] += (float)ls[c + e];
-      if (dgamma) dgamma[c + e] += (float)ls[C + c + e];
+      if (dbeta) dbeta[c + e] += (float)(lsums ? rep_sum(lsums, C, c + e) : t0);
+      if (dgamma) dgamma[c + e] += (float)(lsums ? rep_sum(lsums, C, C + c + e) : t1);
     }
   }
   for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {

@@ -345,6 +345,9 @@ class BNState:
         self.gamma = self.beta = self.dgamma = self.dbeta = self.run_mean = self.run_var = None
 
 
+BN_REPLICAS = 8     # fp64 BatchNorm sums are [8][2C]: producers spread atomics over replicas, consumers add them
+
+
 def _allreduce_sums(sums, count):
     """SyncBatchNorm: sum the per-rank fp64 (sum, sumsq) vectors and the row count over ranks (RCCL all-reduce)."""
     import torch.distributed as dist
@@ -373,7 +376,7 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
         mean = c.empty((C,), torch.float32)
         invstd = c.empty((C,), torch.float32)
         if sums is None:
-            sums = c.zeros_f64(2 * C)
+            sums = c.zeros_f64(BN_REPLICAS * 2 * C)
             _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), c.dtype, c.stream)
         if bn.sync and c.world_size > 1 and c.sync_bn:
             count = _allreduce_sums(sums, M)
@@ -392,14 +395,14 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
                 return
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             assert dy_bs == H * W * lddy
-            sums2 = c.zeros_f64(2 * C)
+            sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
             yv = out if relu else None
             _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), c.dtype, c.stream)
             # dgamma/dbeta use the LOCAL sums (the gradient all-reduce combines ranks); dx needs the GLOBAL sums
             local = None
             if bn.sync and c.world_size > 1 and c.sync_bn:
-                local = c.empty((2 * C,), torch.float64)
-                _L().call("emrt_cast", P(sums2), P(local), 4 * C, 0, F32, c.stream)     # raw 8-byte copy as 2 x f32
+                local = c.empty((BN_REPLICAS * 2 * C,), torch.float64)
+                _L().call("emrt_cast", P(sums2), P(local), BN_REPLICAS * 4 * C, 0, F32, c.stream)     # raw 8-byte copy as 2 x f32
                 _allreduce_sums(sums2, M)
             dx = c.empty(tuple(x.shape))
             dres = c.empty(tuple(x.shape)) if (residual is not None and relu) else None
@@ -415,7 +418,7 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
 def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
     """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training)."""
     c = ctx()
-    sums = c.zeros_f64(2 * bn.C) if c.training else None
+    sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
     y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums)
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 

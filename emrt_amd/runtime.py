@@ -164,7 +164,7 @@ class Context:
         _lib.lib().call("emrt_memset", ctypes.c_void_p(t.data_ptr()), 0, t.numel() * t.element_size(), self.stream)
         return t
 
-    def begin_step(self, arena_doubles=1 << 19):
+    def begin_step(self, arena_doubles=1 << 21):
         """Start of a training step: re-zero the fp64 arena that zeros_f64() hands out slices of."""
         if self._arena is None or self._arena.numel() < arena_doubles:
             self._arena = torch.empty(arena_doubles, dtype=torch.float64, device=self.device)

@@ -37,7 +37,7 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * and nn.Linear / F.linear: transformer_encoder_decoder.py:36-42,118-121,259-262,371; EMRT_utils/layers.py:221-229,306.
  * mode 0: out = conv(in, W) [+bias][+residual][relu];  w_packed = [OC][KH][KW][C]  (dims N,H,W,C describe `in`)
  * mode 1: data gradient; `in` is dY (N,H,W,C = its dims), out is dX (OH,OW,OC), w_packed = [Cin][KH][KW][Cout].
- * bn_stats (nullable): fp64 [2*OC], pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
+ * bn_stats (nullable): fp64 [8][2*OC] (8 replicas, see BatchNorm below), pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
  * (the BatchNorm statistics of the layer that follows, fused so the activation is not re-read). */
 int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C] */
@@ -46,7 +46,8 @@ int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, in
 /* ---- BatchNorm / SyncBatchNorm (train: fp64 sums [from the conv epilogue or emrt_bn_stats] -> [all-reduce of sums across
  * ranks] -> apply; eval: running statistics).  replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add):
  * paddle_vision_resnet.py:132-147; paddle_EMRT.py:18,22,64,86-91,131,139-141,203,206; fcn_head.py:53.
- * All `sums` buffers are fp64 [2*C] and must be zeroed by the caller before the producing kernel runs. */
+ * All `sums` buffers are fp64 [8][2*C] -- producers spread their atomics over 8 replicas, consumers add them -- and must be
+ * zeroed by the caller before the producing kernel runs. */
 size_t emrt_colreduce_workspace_bytes(long long M, int C);
 int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream);
 int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
