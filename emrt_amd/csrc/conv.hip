@@ -281,6 +281,7 @@ struct WgradArgs {
   long long dy_bs;
   int KH, KW, stride, pad;
   int tiles_per_split;  // number of BKm pixel tiles each z-slice processes
+  float* dbias;         // optional [OC]: += sum_m dy[m][oc] (bias gradient), accumulated by the k-tile-0 blocks from the dy tiles they stream
 };
 
 template <class T>
@@ -332,6 +333,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 
   constexpr int NST = 3;
   uint4 rp[NST][4], rq[NST][4];
+  const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
+  float bsum[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) bsum[e] = 0.f;
   // scalar path: per-element decode of this thread's fixed chunk columns (done once)
   int e_c[EPC], e_kh[EPC], e_kw[EPC];
   bool e_kok[EPC], e_ocok[EPC];
@@ -399,6 +404,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<uint4*>(sP + (prow + RPP * i) * PITCH + col * 16) = rp[d][i];
       *reinterpret_cast<uint4*>(sQ + (prow + RPP * i) * PITCH + col * 16) = rq[d][i];
+      if (do_bias) {
+        const T* ev = reinterpret_cast<const T*>(&rp[d][i]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) bsum[e] += to_f32(ev[e]);
+      }
     }
     __syncthreads();
     if (mt + NST < mt_end) load_tile(mt + NST, rp[d], rq[d]);
@@ -452,6 +462,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
   }
 
+  if (do_bias) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (ocp + e < p.OC && bsum[e] != 0.f) atomicAdd(p.dbias + ocp + e, bsum[e]);
+  }
   const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -554,7 +569,7 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
 extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
                                  int N, int H, int W, int C, int ldx, long long x_bs,
                                  int OH, int OW, int OC, int lddy, long long dy_bs,
-                                 int KH, int KW, int stride, int pad, int dtype, void* stream) {
+                                 int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && dw, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
@@ -563,7 +578,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.x_bs = x_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.lddy = lddy; a.dy_bs = dy_bs;
-  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.tiles_per_split = 0;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.tiles_per_split = 0; a.dbias = dbias;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? wgrad_dispatch<float>(a, st) : wgrad_dispatch<bf16_t>(a, st);
 }

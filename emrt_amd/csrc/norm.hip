@@ -164,24 +164,29 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
-  float sc[4], sh[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const BnChan k = bn_chan(sums, run_mean, run_var, C, c + e, inv_count, eps);
-    sc[e] = k.invstd * gamma[c + e];
-    sh[e] = beta[c + e] - k.mean * sc[e];
-    if (sums && blockIdx.x == 0 && lane_row == 0) {
-      mean_out[c + e] = k.mean;
-      invstd_out[c + e] = k.invstd;
+  // per-channel scale/shift computed cooperatively (one channel per thread) and shared through LDS
+  extern __shared__ float bn_lds[];          // [2][C]
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const BnChan k = bn_chan(sums, run_mean, run_var, C, ch, inv_count, eps);
+    const float scale = k.invstd * gamma[ch];
+    bn_lds[ch] = scale;
+    bn_lds[C + ch] = beta[ch] - k.mean * scale;
+    if (sums && blockIdx.x == 0) {
+      mean_out[ch] = k.mean;
+      invstd_out[ch] = k.invstd;
       if (run_mean) {
-        const double mu = rep_sum(sums, C, c + e) * inv_count;
-        double var = rep_sum(sums, C, C + c + e) * inv_count - mu * mu;
+        const double mu = rep_sum(sums, C, ch) * inv_count;
+        double var = rep_sum(sums, C, C + ch) * inv_count - mu * mu;
         if (var < 0.0) var = 0.0;
-        run_mean[c + e] = momentum * run_mean[c + e] + (1.f - momentum) * (float)mu;
-        run_var[c + e] = momentum * run_var[c + e] + (1.f - momentum) * (float)var;
+        run_mean[ch] = momentum * run_mean[ch] + (1.f - momentum) * (float)mu;
+        run_var[ch] = momentum * run_var[ch] + (1.f - momentum) * (float)var;
       }
     }
   }
+  __syncthreads();
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e]; }
   for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {
     float v[4], o[4];
     Vec4<T>::load(x + r * ldx + c, v);
@@ -214,19 +219,25 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
+  extern __shared__ float bn_lds[];          // [2][C]: sum_dy/count, sum_dyxhat/count
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const double t0 = rep_sum(sums, C, ch), t1 = rep_sum(sums, C, C + ch);
+    bn_lds[ch] = (float)(t0 * inv_count);
+    bn_lds[C + ch] = (float)(t1 * inv_count);
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[ch] += (float)(lsums ? rep_sum(lsums, C, ch) : t0);
+      if (dgamma) dgamma[ch] += (float)(lsums ? rep_sum(lsums, C, C + ch) : t1);
+    }
+  }
+  __syncthreads();
   float mu[4], is[4], k0[4], k1[4], gi[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     mu[e] = mean[c + e];
     is[e] = invstd[c + e];
     gi[e] = gamma[c + e] * is[e];
-    const double t0 = rep_sum(sums, C, c + e), t1 = rep_sum(sums, C, C + c + e);
-    k0[e] = (float)(t0 * inv_count);
-    k1[e] = (float)(t1 * inv_count);
-    if (blockIdx.x == 0 && lane_row == 0) {
-      if (dbeta) dbeta[c + e] += (float)(lsums ? rep_sum(lsums, C, c + e) : t0);
-      if (dgamma) dgamma[c + e] += (float)(lsums ? rep_sum(lsums, C, C + c + e) : t1);
-    }
+    k0[e] = bn_lds[c + e];
+    k1[e] = bn_lds[C + c + e];
   }
   for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {
     float v[4], g[4], o[4];
@@ -256,148 +267,181 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// GroupNorm is split over many blocks per image (a level map is only 8 images): pass 1 accumulates fp64 group sums with
+// atomics, pass 2 is a fully parallel elementwise apply.  Threads own a fixed channel quad; 256 threads = (C/4) x lanes.
 template <class T>
-__global__ __launch_bounds__(1024) void gn_fwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ res,
-                                                      int ldres, long long res_bs, T* __restrict__ out, int ldout,
-                                                      long long out_bs, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ mean_out,
-                                                      float* __restrict__ rstd_out, int HW, int C, int G, float eps, int gelu) {
-  extern __shared__ float sm[];  // [1024*2] scratch, then [G*2] stats
-  const int tx_n = C / 4, ty_n = blockDim.x / tx_n;
-  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
-  const int n = blockIdx.x, c = tx * 4;
-  const int cpg = C / G;
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, long long x_bs, double* __restrict__ sums,
+                                                       int HW, int C, int G, int pix_per_block) {
+  __shared__ float red[256 * 2];
+  const int quads = C / 4, lanes = 256 / quads;
+  const int q = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const int n = blockIdx.y, c = q * 4, cpg = C / G;
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block;
+  if (p1 > HW) p1 = HW;
   const T* xp = x + (long long)n * x_bs;
   float s0 = 0.f, s1 = 0.f;
-  if (ty < ty_n) {
-    for (int p = ty; p < HW; p += ty_n) {
-      float v[4];
-      Vec4<T>::load(xp + (long long)p * ldx + c, v);
+  for (int p = p0 + ty; p < p1; p += lanes) {
+    float v[4];
+    Vec4<T>::load(xp + (long long)p * ldx + c, v);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s0 += v[e]; s1 = fmaf(v[e], v[e], s1); }
-    }
+    for (int e = 0; e < 4; ++e) { s0 += v[e]; s1 = fmaf(v[e], v[e], s1); }
   }
-  sm[threadIdx.x * 2] = s0;
-  sm[threadIdx.x * 2 + 1] = s1;
+  red[threadIdx.x * 2] = s0;
+  red[threadIdx.x * 2 + 1] = s1;
   __syncthreads();
-  float* stats = sm + 2 * blockDim.x;
   if ((int)threadIdx.x < G) {
     const int g = threadIdx.x;
     double a = 0.0, b = 0.0;
     const int q0 = g * cpg / 4, q1 = (g + 1) * cpg / 4;
-    for (int t = 0; t < ty_n; ++t)
-      for (int q = q0; q < q1; ++q) { a += sm[(t * tx_n + q) * 2]; b += sm[(t * tx_n + q) * 2 + 1]; }
-    const double cnt = (double)HW * cpg;
-    const double mu = a / cnt;
-    double var = b / cnt - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float rs = (float)(1.0 / sqrt(var + (double)eps));
-    stats[g * 2] = (float)mu;
-    stats[g * 2 + 1] = rs;
-    if (mean_out) { mean_out[n * G + g] = (float)mu; rstd_out[n * G + g] = rs; }
-  }
-  __syncthreads();
-  if (ty < ty_n) {
-    const int g = c / cpg;
-    const float mu = stats[g * 2], rs = stats[g * 2 + 1];
-    float ga[4], be[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
-    for (int p = ty; p < HW; p += ty_n) {
-      float v[4], o[4];
-      Vec4<T>::load(xp + (long long)p * ldx + c, v);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float u = (v[e] - mu) * rs * ga[e] + be[e];
-        o[e] = gelu ? gelu_f(u) : u;
-      }
-      if (res) {
-        float q[4];
-        Vec4<T>::load(res + (long long)n * res_bs + (long long)p * ldres + c, q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += q[e];
-      }
-      Vec4<T>::store(out + (long long)n * out_bs + (long long)p * ldout + c, o);
-    }
+    for (int t = 0; t < lanes; ++t)
+      for (int qq = q0; qq < q1; ++qq) { a += red[(t * quads + qq) * 2]; b += red[(t * quads + qq) * 2 + 1]; }
+    atomicAdd(sums + ((long long)n * G + g) * 2, a);
+    atomicAdd(sums + ((long long)n * G + g) * 2 + 1, b);
   }
 }
 
-// GN backward: dx (w.r.t. GN input), dgamma/dbeta (atomics, one add per image per channel).  The residual's
-// gradient is dy itself and is handled by the caller.
 template <class T>
-__global__ __launch_bounds__(1024) void gn_bwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy,
-                                                      int lddy, long long dy_bs, T* __restrict__ dx, int lddx, long long dx_bs,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G,
-                                                      int gelu) {
-  extern __shared__ float sm[];
-  const int tx_n = C / 4, ty_n = blockDim.x / tx_n;
-  const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
-  const int n = blockIdx.x, c = tx * 4;
-  const int cpg = C / G, g = c / cpg;
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ res,
+                                                       int ldres, long long res_bs, T* __restrict__ out, int ldout, long long out_bs,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const double* __restrict__ sums, float* __restrict__ mean_out,
+                                                       float* __restrict__ rstd_out, int HW, int C, int G, float eps, int gelu,
+                                                       int pix_per_block) {
+  const int quads = C / 4, lanes = 256 / quads;
+  const int q = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const int n = blockIdx.y, c = q * 4, cpg = C / G, g = c / cpg;
+  const double cnt = (double)HW * cpg;
+  const double mu_d = sums[((long long)n * G + g) * 2] / cnt;
+  double var = sums[((long long)n * G + g) * 2 + 1] / cnt - mu_d * mu_d;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (mean_out && blockIdx.x == 0 && ty == 0 && (c % cpg) == 0) { mean_out[n * G + g] = mu; rstd_out[n * G + g] = rs; }
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = rs * gamma[c + e]; sh[e] = beta[c + e] - mu * sc[e]; }
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block;
+  if (p1 > HW) p1 = HW;
   const T* xp = x + (long long)n * x_bs;
-  const T* gp = dy + (long long)n * dy_bs;
+  for (int p = p0 + ty; p < p1; p += lanes) {
+    float v[4], o[4];
+    Vec4<T>::load(xp + (long long)p * ldx + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = fmaf(v[e], sc[e], sh[e]);
+      o[e] = gelu ? gelu_f(u) : u;
+    }
+    if (res) {
+      float w[4];
+      Vec4<T>::load(res + (long long)n * res_bs + (long long)p * ldres + c, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += w[e];
+    }
+    Vec4<T>::store(out + (long long)n * out_bs + (long long)p * ldout + c, o);
+  }
+}
+
+// backward pass 1: chs[n][c][2] (fp64, pre-zeroed) += per-channel (sum dy', sum dy'*xhat) over the block's pixels
+template <class T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy,
+                                                            int lddy, long long dy_bs, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, double* __restrict__ chs, int HW, int C,
+                                                            int G, int gelu, int pix_per_block) {
+  __shared__ float red[256 * 8];
+  const int quads = C / 4, lanes = 256 / quads;
+  const int q = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const int n = blockIdx.y, c = q * 4, cpg = C / G, g = c / cpg;
   const float mu = mean[n * G + g], rs = rstd[n * G + g];
   float ga[4], be[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block;
+  if (p1 > HW) p1 = HW;
+  const T* xp = x + (long long)n * x_bs;
+  const T* gp = dy + (long long)n * dy_bs;
   float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-  if (ty < ty_n) {
-    for (int p = ty; p < HW; p += ty_n) {
-      float v[4], d[4];
-      Vec4<T>::load(xp + (long long)p * ldx + c, v);
-      Vec4<T>::load(gp + (long long)p * lddy + c, d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (v[e] - mu) * rs;
-        const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
-        s0[e] += dd;
-        s1[e] = fmaf(dd, xh, s1[e]);
-      }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { sm[threadIdx.x * 8 + e] = s0[e]; sm[threadIdx.x * 8 + 4 + e] = s1[e]; }
-  __syncthreads();
-  float* chs = sm + 8 * blockDim.x;       // [C][2] per-channel sums for this image
-  float* gs = chs + 2 * C;                // [G][2]
-  if (ty == 0) {
-    for (int t = 1; t < ty_n; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s0[e] += sm[(t * tx_n + tx) * 8 + e]; s1[e] += sm[(t * tx_n + tx) * 8 + 4 + e]; }
+  for (int p = p0 + ty; p < p1; p += lanes) {
+    float v[4], d[4];
+    Vec4<T>::load(xp + (long long)p * ldx + c, v);
+    Vec4<T>::load(gp + (long long)p * lddy + c, d);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      chs[(c + e) * 2] = s0[e];
-      chs[(c + e) * 2 + 1] = s1[e];
-      if (dbeta) atomicAdd(dbeta + c + e, s0[e]);
-      if (dgamma) atomicAdd(dgamma + c + e, s1[e]);
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      s0[e] += dd;
+      s1[e] = fmaf(dd, xh, s1[e]);
     }
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s0[e]; red[threadIdx.x * 8 + 4 + e] = s1[e]; }
   __syncthreads();
+  if (ty == 0) {
+    for (int t = 1; t < lanes; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] += red[(t * quads + q) * 8 + e]; s1[e] += red[(t * quads + q) * 8 + 4 + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(chs + ((long long)n * C + c + e) * 2, (double)s0[e]);
+      atomicAdd(chs + ((long long)n * C + c + e) * 2 + 1, (double)s1[e]);
+    }
+  }
+}
+
+// backward pass 2: dx = rstd*(gamma*dy' - A_g - xhat*B_g), A_g/B_g = group means of gamma*(per-channel sums); the
+// pixel-chunk-0 block of every image adds that image's per-channel sums into dgamma / dbeta.
+template <class T>
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy,
+                                                        int lddy, long long dy_bs, T* __restrict__ dx, int lddx, long long dx_bs,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const double* __restrict__ chs, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int HW, int C, int G, int gelu, int pix_per_block) {
+  extern __shared__ float gsm[];      // [G][2]
+  const int quads = C / 4, lanes = 256 / quads;
+  const int q = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const int n = blockIdx.y, c = q * 4, cpg = C / G, g = c / cpg;
   if ((int)threadIdx.x < G) {
     const int gg = threadIdx.x;
-    float a = 0.f, b = 0.f;
-    for (int cc = gg * cpg; cc < (gg + 1) * cpg; ++cc) { a += gamma[cc] * chs[cc * 2]; b += gamma[cc] * chs[cc * 2 + 1]; }
-    const float inv = 1.f / ((float)HW * cpg);
-    gs[gg * 2] = a * inv;
-    gs[gg * 2 + 1] = b * inv;
+    double a = 0.0, b = 0.0;
+    for (int cc = gg * cpg; cc < (gg + 1) * cpg; ++cc) {
+      a += (double)gamma[cc] * chs[((long long)n * C + cc) * 2];
+      b += (double)gamma[cc] * chs[((long long)n * C + cc) * 2 + 1];
+    }
+    const double inv = 1.0 / ((double)HW * cpg);
+    gsm[gg * 2] = (float)(a * inv);
+    gsm[gg * 2 + 1] = (float)(b * inv);
+  }
+  if (blockIdx.x == 0) {
+    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+      if (dbeta) atomicAdd(dbeta + cc, (float)chs[((long long)n * C + cc) * 2]);
+      if (dgamma) atomicAdd(dgamma + cc, (float)chs[((long long)n * C + cc) * 2 + 1]);
+    }
   }
   __syncthreads();
-  if (ty < ty_n) {
-    const float A = gs[g * 2], Bq = gs[g * 2 + 1];
-    for (int p = ty; p < HW; p += ty_n) {
-      float v[4], d[4], o[4];
-      Vec4<T>::load(xp + (long long)p * ldx + c, v);
-      Vec4<T>::load(gp + (long long)p * lddy + c, d);
+  const float mu = mean[n * G + g], rs = rstd[n * G + g];
+  const float A = gsm[g * 2], Bq = gsm[g * 2 + 1];
+  float ga[4], be[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (v[e] - mu) * rs;
-        const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
-        o[e] = rs * (ga[e] * dd - A - xh * Bq);
-      }
-      Vec4<T>::store(dx + (long long)n * dx_bs + (long long)p * lddx + c, o);
+  for (int e = 0; e < 4; ++e) { ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block;
+  if (p1 > HW) p1 = HW;
+  const T* xp = x + (long long)n * x_bs;
+  const T* gp = dy + (long long)n * dy_bs;
+  for (int p = p0 + ty; p < p1; p += lanes) {
+    float v[4], d[4], o[4];
+    Vec4<T>::load(xp + (long long)p * ldx + c, v);
+    Vec4<T>::load(gp + (long long)p * lddy + c, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      o[e] = rs * (ga[e] * dd - A - xh * Bq);
     }
+    Vec4<T>::store(dx + (long long)n * dx_bs + (long long)p * lddx + c, o);
   }
 }
 
@@ -592,8 +636,8 @@ extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres,
   hipStream_t st = (hipStream_t)stream;
   const double inv_count = sums ? 1.0 / count : 0.0;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), 0, st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
-            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
+            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
   return check_launch("emrt_bn_apply");
 }
 
@@ -623,8 +667,8 @@ extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, 
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp),
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp));
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp));
   return check_launch("emrt_bn_bwd_dx");
 }
 
@@ -670,36 +714,51 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   return check_launch("emrt_colsum_acc");
 }
 
+static inline int gn_geom(int HW, int C, int* pix_per_block) {
+  const int lanes = 256 / (C / 4);
+  int ppb = lanes * 8;                       // each thread walks ~8 pixels
+  int blocks = (HW + ppb - 1) / ppb;
+  if (blocks > 64) { blocks = 64; ppb = (HW + 63) / 64; ppb = (ppb + lanes - 1) / lanes * lanes; blocks = (HW + ppb - 1) / ppb; }
+  *pix_per_block = ppb;
+  return blocks;
+}
+
+// workspace: fp64 [N*G*2], PRE-ZEROED by the caller (group sums)
 extern "C" int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out,
                                   int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd,
-                                  int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream) {
-  EMRT_REQUIRE(x && out && gamma && beta, "null pointer");
-  EMRT_REQUIRE(C % 4 == 0 && C / 4 <= 1024 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && G <= 1024, "unsupported C/G");
+                                  double* workspace, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE(x && out && gamma && beta && workspace, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 256 && C % G == 0 && (C / G) % 4 == 0, "unsupported C/G");
   EMRT_REQUIRE(ldx % 4 == 0 && ldout % 4 == 0 && x_bs % 4 == 0 && out_bs % 4 == 0, "strides must be multiples of 4");
-  const int tx = C / 4;
-  int threads = (1024 / tx) * tx;
-  const size_t lds = (size_t)(2 * threads + 2 * G) * sizeof(float);
+  int ppb;
+  const int blocks = gn_geom(HW, C, &ppb);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((gn_fwd_kernel<float>), dim3(N), dim3(threads), lds, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu),
-            hipLaunchKernelGGL((gn_fwd_kernel<bf16_t>), dim3(N), dim3(threads), lds, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu));
+            hipLaunchKernelGGL((gn_stats_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, workspace, HW, C, G, ppb),
+            hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, workspace, HW, C, G, ppb));
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, gamma, beta, workspace, mean, rstd, HW, C, G, eps, gelu, ppb),
+            hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, workspace, mean, rstd, HW, C, G, eps, gelu, ppb));
   return check_launch("emrt_groupnorm_fwd");
 }
 
+// workspace: fp64 [N*C*2], PRE-ZEROED by the caller (per-image per-channel sums)
 extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx,
                                   int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean,
-                                  const float* rstd, float* dgamma, float* dbeta, int N, int HW, int C, int G, int gelu,
-                                  int dtype, void* stream) {
-  EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd, "null pointer");
-  EMRT_REQUIRE(C % 4 == 0 && C / 4 <= 1024 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && G <= 1024, "unsupported C/G");
-  const int tx = C / 4;
-  int threads = (1024 / tx) * tx;
-  const size_t lds = (size_t)(8 * threads + 2 * C + 2 * G) * sizeof(float);
-  EMRT_REQUIRE(lds <= 160 * 1024, "LDS budget exceeded");
+                                  const float* rstd, float* dgamma, float* dbeta, double* workspace, int N, int HW, int C, int G,
+                                  int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd && workspace, "null pointer");
+  EMRT_REQUIRE(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 256 && C % G == 0 && (C / G) % 4 == 0, "unsupported C/G");
+  int ppb;
+  const int blocks = gn_geom(HW, C, &ppb);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((gn_bwd_kernel<float>), dim3(N), dim3(threads), lds, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, gamma, beta, mean, rstd, dgamma, dbeta, HW, C, G, gelu),
-            hipLaunchKernelGGL((gn_bwd_kernel<bf16_t>), dim3(N), dim3(threads), lds, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, gamma, beta, mean, rstd, dgamma, dbeta, HW, C, G, gelu));
+            hipLaunchKernelGGL((gn_bwd_reduce_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, gamma, beta, mean, rstd, workspace, HW, C, G, gelu, ppb),
+            hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, gamma, beta, mean, rstd, workspace, HW, C, G, gelu, ppb));
+  const size_t lds = (size_t)2 * G * sizeof(float);
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_bwd_dx_kernel<float>), dim3(blocks, N), dim3(256), lds, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, gamma, beta, mean, rstd, workspace, dgamma, dbeta, HW, C, G, gelu, ppb),
+            hipLaunchKernelGGL((gn_bwd_dx_kernel<bf16_t>), dim3(blocks, N), dim3(256), lds, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, gamma, beta, mean, rstd, workspace, dgamma, dbeta, HW, C, G, gelu, ppb));
   return check_launch("emrt_groupnorm_bwd");
 }
 

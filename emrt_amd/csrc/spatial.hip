@@ -128,8 +128,10 @@ struct ResizeBwdArgs {
 __device__ __forceinline__ void axis_range(const Axis& a, int i, int out, int& lo, int& hi) {
   if (a.s <= 0.f) { lo = 0; hi = out - 1; return; }
   const float t = a.clamp0 ? a.t : 0.f;
-  lo = (int)floorf(((float)i - 1.f - t) / a.s) - 1;
-  hi = (int)ceilf(((float)i + 1.f - t) / a.s) + 1;
+  // destination d touches source i only when s*d + t lies in (i-1, i+1) (or is clamped onto i at a border, which the
+  // clamps below keep inside the window); inclusive floor/ceil bounds leave one index of slack for float rounding
+  lo = (int)floorf(((float)i - 1.f - t) / a.s);
+  hi = (int)ceilf(((float)i + 1.f - t) / a.s);
   if (lo < 0) lo = 0;
   if (hi > out - 1) hi = out - 1;
 }

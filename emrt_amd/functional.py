@@ -305,9 +305,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 dy = dm
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
-                      w.KH, w.KW, stride, pad, c.dtype, c.stream)
-            if w.bias is not None:
-                colsum_acc(dy, w.bias_grad)
+                      w.KH, w.KW, stride, pad, P(w.bias_grad) if w.bias is not None else None, c.dtype, c.stream)
             if residual is not None:
                 tape.add_grad(residual, dy)
             if need_dx:
@@ -436,7 +434,7 @@ def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residu
     mean = c.empty((N * G,), torch.float32)
     rstd = c.empty((N * G,), torch.float32)
     _L().call("emrt_groupnorm_fwd", P(x), ldx, x_bs, P(residual), ldr, r_bs, P(out), ldo, o_bs, P(gamma), P(beta), P(mean), P(rstd),
-              N, H * W, C, G, eps, int(gelu), c.dtype, c.stream)
+              P(c.zeros_f64(N * G * 2)), N, H * W, C, G, eps, int(gelu), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
@@ -446,7 +444,7 @@ def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residu
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             dx = c.empty(tuple(x.shape))
             _L().call("emrt_groupnorm_bwd", P(x), ldx, x_bs, P(dy), lddy, dy_bs, P(dx), C, H * W * C, P(gamma), P(beta), P(mean), P(rstd),
-                      P(dgamma), P(dbeta), N, H * W, C, G, int(gelu), c.dtype, c.stream)
+                      P(dgamma), P(dbeta), P(c.zeros_f64(N * C * 2)), N, H * W, C, G, int(gelu), c.dtype, c.stream)
             tape.add_grad(x, dx)
             if residual is not None:
                 tape.add_grad(residual, dy)

@@ -40,8 +40,8 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * bn_stats (nullable): fp64 [8][2*OC] (8 replicas, see BatchNorm below), pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
  * (the BatchNorm statistics of the layer that follows, fused so the activation is not re-read). */
 int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, int dtype, void* stream);
-/* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C] */
-int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, int dtype, void* stream);
+/* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
+int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream);
 
 /* ---- BatchNorm / SyncBatchNorm (train: fp64 sums [from the conv epilogue or emrt_bn_stats] -> [all-reduce of sums across
  * ranks] -> apply; eval: running statistics).  replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add):
@@ -56,9 +56,10 @@ int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void*
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
 
-/* ---- GroupNorm(32) [+ erf-GELU] [+ residual]: transformer_encoder_decoder.py:125-144 (conv branch), :378 (input_proj) */
-int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream);
-int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, int N, int HW, int C, int G, int gelu, int dtype, void* stream);
+/* ---- GroupNorm(32) [+ erf-GELU] [+ residual]: transformer_encoder_decoder.py:125-144 (conv branch), :378 (input_proj).
+ * workspace: PRE-ZEROED fp64, [N*G*2] for fwd (group sums), [N*C*2] for bwd (per-image channel sums). */
+int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd, double* workspace, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream);
+int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, double* workspace, int N, int HW, int C, int G, int gelu, int dtype, void* stream);
 
 /* ---- residual add + LayerNorm (+ post add): transformer_encoder_decoder.py:199-203,159-160,285-291,278-279
  * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward. */
