@@ -462,10 +462,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
     }
   }
 
-  if (do_bias) {
+  if (do_bias) {      // block-level reduction over the RPP row lanes in LDS, then ONE atomic per output channel
+    float* sb = reinterpret_cast<float*>(smem);     // [RPP][128]; the k-loop's last barrier has retired every LDS read
 #pragma unroll
-    for (int e = 0; e < EPC; ++e)
-      if (ocp + e < p.OC && bsum[e] != 0.f) atomicAdd(p.dbias + ocp + e, bsum[e]);
+    for (int e = 0; e < EPC; ++e) sb[prow * 128 + col * EPC + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && oc0 + tid < p.OC) {
+      float t = 0.f;
+      for (int r = 0; r < RPP; ++r) t += sb[r * 128 + tid];
+      atomicAdd(p.dbias + oc0 + tid, t);
+    }
   }
   const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll
