@@ -56,29 +56,58 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const uint4& a, 
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// ---- raw buffer loads -------------------------------------------------------------------------
+// Every operand is addressed as base + 32-bit byte offset through a buffer descriptor whose range is BUF_RANGE bytes.
+// Offsets with bit 31 set are out of range and the hardware returns zeros for them (the host checks that no operand
+// spans 2 GiB or more, so a valid offset never has that bit).
+constexpr unsigned BUF_RANGE = 0x80000000u;
+constexpr unsigned BUF_OOB = 0x80000000u;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <class T>
+__device__ __forceinline__ uint32_t buf_load_elem(__amdgpu_buffer_rsrc_t rs, unsigned off);   // element bits, zero-extended
+template <>
+__device__ __forceinline__ uint32_t buf_load_elem<bf16_t>(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+}
+template <>
+__device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fwd / dgrad implicit GEMM.  256 threads = 4 waves laid out WR x WC, each wave TM x TN tiles of 32x32.
-// LDS: one [BM + BN] x 128-byte k-tile (rows padded to 144 B: conflict-free ds_read_b128), register
-// prefetch of the next k-tile while the MFMAs of the current one run.
+// LDS: two [BM + BN] x 128-byte k-tile buffers (rows padded to 144 B: conflict-free ds_read_b128), ONE barrier per
+// k-tile.  Global loads run NST k-tiles ahead in a register ring.  Every load is unconditional (an out-of-range or
+// padding chunk reads the operand's base address and is zeroed by a select afterwards) and the ring is refilled in
+// straight-line code, so that the compiler can wait with a counted vmcnt(N) for the oldest stage only; predicated
+// loads behind branches made it drain the whole ring (vmcnt(0)) at every k-tile.
 // ------------------------------------------------------------------------------------------------
 // VEC = true : C % (16 B of elements) == 0 and 16-byte aligned rows -> one 16-byte load per chunk; the last k-tile may
 //              be partial (K % BK != 0, e.g. the fused 432-wide offsets|logits projection) and is zero-filled.
 // VEC = false: any C / alignment (7x7x3 stem, 3x3x3 branch conv, 6-class logits): chunks are assembled from element loads.
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC>
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST>
 __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
   constexpr int PITCH = 144;
   constexpr int AR = BM / 32, BR = BN / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + BM * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int tiles_n = (p.OC + BN - 1) / BN;
-  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+  // consecutive workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of tiles so that the
+  // tiles that share an activation row block (same bm) hit the same L2
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int bm = bid / tiles_n, bn = bid % tiles_n;
   const int OHW = p.OH * p.OW;
   const long long M = (long long)p.N * OHW;
   const int chunk = tid & 7, row0 = tid >> 3;
@@ -88,8 +117,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   const int K = p.KH * p.KW * p.C;
   const int nkt = (K + BK - 1) / BK;
 
+  // Operands are read through raw buffer descriptors: an out-of-range byte offset returns zeros, which is how padding
+  // taps, stride holes, rows beyond M / OC and the k tail are zero-filled without a branch or a select on the data.
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)BUF_RANGE, 0x00020000);
+
   int a_h[AR], a_w[AR];
-  long long a_base[AR];
+  unsigned a_base[AR];      // byte offset of the row's image
   bool a_ok[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
@@ -99,77 +133,111 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
     int nb = (int)(mm / OHW);
     int r = (int)(mm - (long long)nb * OHW);
     int oh = r / p.OW, ow = r - oh * p.OW;
-    a_base[i] = (long long)nb * p.in_bs;
+    a_base[i] = (unsigned)((long long)nb * p.in_bs * (long long)sizeof(T));
     if (MODE == 0) { a_h[i] = oh * p.stride - p.pad; a_w[i] = ow * p.stride - p.pad; }
     else { a_h[i] = oh + p.pad; a_w[i] = ow + p.pad; }
   }
-  long long b_off[BR];
-  bool b_ok[BR];
+  unsigned b_off[BR];       // byte offset of the weight row, BUF_OOB when the row is beyond OC
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
     int n = bn * BN + row0 + 32 * j;
-    b_ok[j] = n < p.OC;
-    b_off[j] = (long long)(b_ok[j] ? n : 0) * K;
+    b_off[j] = n < p.OC ? (unsigned)((long long)n * K * (long long)sizeof(T)) : BUF_OOB;
   }
 
-  constexpr int NST = 3;      // k-tiles in flight in registers: hides the ~1 us L2/HBM round trip of short-grid launches
   uint4 ra[NST][AR], rb[NST][BR];
-  auto a_pixel = [&](int i, int kh, int kw, long long& off) -> bool {
+  // byte offset of input pixel (row i, tap kh,kw), or BUF_OOB when the tap falls on padding / a stride hole / m >= M
+  auto a_pixel = [&](int i, int kh, int kw) -> unsigned {
     int hi, wi;
     bool ok = a_ok[i];
     if (MODE == 0) { hi = a_h[i] + kh; wi = a_w[i] + kw; }
     else {
-      int th = a_h[i] - kh, tw = a_w[i] - kw;
-      hi = th / p.stride; wi = tw / p.stride;
-      ok = ok && th >= 0 && tw >= 0 && (hi * p.stride == th) && (wi * p.stride == tw);
+      const int th = a_h[i] - kh, tw = a_w[i] - kw;
+      if (p.stride == 1) { hi = th; wi = tw; }                 // (negative values fail the range test below)
+      else if (p.stride == 2) { hi = th >> 1; wi = tw >> 1; ok = ok && ((th | tw) & 1) == 0; }
+      else {
+        hi = th / p.stride; wi = tw / p.stride;
+        ok = ok && th >= 0 && tw >= 0 && (hi * p.stride == th) && (wi * p.stride == tw);
+      }
     }
     ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-    off = a_base[i] + ((long long)hi * p.W + wi) * p.ldin;
-    return ok;
+    const unsigned off = a_base[i] + (unsigned)((hi * p.W + wi) * p.ldin) * (unsigned)sizeof(T);
+    return ok ? off : BUF_OOB;
   };
-  auto load_tile = [&](int kt, uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
-    const int kc = kt * BK + chunk * EPC;       // first k index of this thread's 16-byte chunk
+  // 1x1 kernels (every linear layer, the bottleneck 1x1 convs): the pixel of a row does not depend on k
+  const bool one_tap = p.KH * p.KW == 1;
+  unsigned a_off1[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) a_off1[i] = a_pixel(i, 0, 0);
+  // loader cursor: k index / tap / channel of this thread's 16-byte chunk in the NEXT k-tile to fetch.  It keeps
+  // advancing past K (the ring prefetches beyond the last tile): those chunks are all-zero.
+  int ld_kc = chunk * EPC, ld_kh, ld_kw, ld_c0;
+  {
+    const int tap = ld_kc / p.C;
+    ld_c0 = ld_kc - tap * p.C;
+    ld_kh = tap / p.KW;
+    ld_kw = tap - ld_kh * p.KW;
+  }
+  const bool c_ge_bk = p.C >= BK;
+  auto load_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
     if constexpr (VEC) {
-      const bool kok = kc < K;
-      const int tap = kok ? kc / p.C : 0;
-      const int c0 = kc - tap * p.C;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const unsigned kbad = ld_kc < K ? 0u : BUF_OOB;      // OR-ing BUF_OOB into an offset < BUF_OOB puts it out of range
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        long long off;
-        const bool ok = a_pixel(i, kh, kw, off) && kok;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) v = *reinterpret_cast<const uint4*>(inp + off + c0);
-        ra_[i] = v;
+        const unsigned off = (one_tap ? a_off1[i] : a_pixel(i, ld_kh, ld_kw)) | kbad;
+        ra_[i] = buf_load16(rs_in, off + (unsigned)ld_c0 * (unsigned)sizeof(T));
       }
 #pragma unroll
-      for (int j = 0; j < BR; ++j) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (b_ok[j] && kok) v = *reinterpret_cast<const uint4*>(wp + b_off[j] + kc);
-        rb_[j] = v;
+      for (int j = 0; j < BR; ++j) rb_[j] = buf_load16(rs_w, (b_off[j] | kbad) + (unsigned)ld_kc * (unsigned)sizeof(T));
+      ld_kc += BK;
+      if (c_ge_bk) {          // at most one tap boundary per step: plain selects
+        ld_c0 += BK;
+        const bool wrap = ld_c0 >= p.C;
+        ld_c0 -= wrap ? p.C : 0;
+        ld_kw += wrap ? 1 : 0;
+        const bool wrap2 = ld_kw == p.KW;
+        ld_kw = wrap2 ? 0 : ld_kw;
+        ld_kh += wrap2 ? 1 : 0;
+      } else {
+        const int tap = ld_kc / p.C;
+        ld_c0 = ld_kc - tap * p.C;
+        ld_kh = tap / p.KW;
+        ld_kw = tap - ld_kh * p.KW;
       }
     } else {
-      T ea[AR][EPC], eb[BR][EPC];
+      uint32_t wa[AR][4], wb[BR][4];
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wa[i][q] = 0u;
+#pragma unroll
+      for (int j = 0; j < BR; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wb[j][q] = 0u;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        const int kk = kc + e;
-        const bool kok = kk < K;
-        const int tap = kok ? kk / p.C : 0;
+        const int kk = ld_kc + e;
+        const unsigned kbad = kk < K ? 0u : BUF_OOB;
+        const int tap = kk / p.C;
         const int cc = kk - tap * p.C;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-          long long off;
-          const bool ok = a_pixel(i, kh, kw, off) && kok;
-          ea[i][e] = ok ? inp[off + cc] : from_f32<T>(0.f);
+          const uint32_t v = buf_load_elem<T>(rs_in, (a_pixel(i, kh, kw) | kbad) + (unsigned)cc * (unsigned)sizeof(T));
+          if constexpr (sizeof(T) == 2) wa[i][e >> 1] |= v << (16 * (e & 1));
+          else wa[i][e] = v;
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) eb[j][e] = (b_ok[j] && kok) ? wp[b_off[j] + kk] : from_f32<T>(0.f);
+        for (int j = 0; j < BR; ++j) {
+          const uint32_t v = buf_load_elem<T>(rs_w, (b_off[j] | kbad) + (unsigned)kk * (unsigned)sizeof(T));
+          if constexpr (sizeof(T) == 2) wb[j][e >> 1] |= v << (16 * (e & 1));
+          else wb[j][e] = v;
+        }
       }
 #pragma unroll
-      for (int i = 0; i < AR; ++i) ra_[i] = *reinterpret_cast<const uint4*>(&ea[i][0]);
+      for (int i = 0; i < AR; ++i) ra_[i] = make_uint4(wa[i][0], wa[i][1], wa[i][2], wa[i][3]);
 #pragma unroll
-      for (int j = 0; j < BR; ++j) rb_[j] = *reinterpret_cast<const uint4*>(&eb[j][0]);
+      for (int j = 0; j < BR; ++j) rb_[j] = make_uint4(wb[j][0], wb[j][1], wb[j][2], wb[j][3]);
+      ld_kc += BK;
     }
   };
 
@@ -181,62 +249,77 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#pragma unroll
-  for (int d = 0; d < NST; ++d)
-    if (d < nkt) load_tile(d, ra[d], rb[d]);
   const int frow = lane & 31, fh = lane >> 5;
-  for (int kt0 = 0; kt0 < nkt; kt0 += NST) {
+  // one k-tile: ring stage d -> LDS buffer `par`, barrier, (refill stage d), MFMAs.  A buffer is rewritten two tiles
+  // later, i.e. after the barrier of the tile in between, which every wave reaches only after its reads of this one.
+  auto k_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR], int par, bool refill) {
+    unsigned char* sA = smem + par * STAGE_BYTES;
+    unsigned char* sB = sA + BM * PITCH;
 #pragma unroll
-    for (int d = 0; d < NST; ++d) {
-      const int kt = kt0 + d;
-      if (kt < nkt) {
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(sA + (row0 + 32 * i) * PITCH + chunk * 16) = ra_[i];
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(sA + (row0 + 32 * i) * PITCH + chunk * 16) = ra[d][i];
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4*>(sB + (row0 + 32 * j) * PITCH + chunk * 16) = rb_[j];
+    __syncthreads();
+    if (refill) load_tile(ra_, rb_);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4*>(sB + (row0 + 32 * j) * PITCH + chunk * 16) = rb[d][j];
-        __syncthreads();
-        if (kt + NST < nkt) load_tile(kt + NST, ra[d], rb[d]);     // refill the stage just written to LDS
+    for (int s = 0; s < 4; ++s) {
+      uint4 fa[TM], fb[TN];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          uint4 fa[TM], fb[TN];
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const uint4*>(sA + ((wr * TM + i) * 32 + frow) * PITCH + (2 * s + fh) * 16);
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-            fa[i] = *reinterpret_cast<const uint4*>(sA + ((wr * TM + i) * 32 + frow) * PITCH + (2 * s + fh) * 16);
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const uint4*>(sB + ((wc * TN + j) * 32 + frow) * PITCH + (2 * s + fh) * 16);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            fb[j] = *reinterpret_cast<const uint4*>(sB + ((wc * TN + j) * 32 + frow) * PITCH + (2 * s + fh) * 16);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
-        }
-        __syncthreads();
-      }
+        for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
     }
-  }
+  };
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int d = 0; d < NST; ++d) load_tile(ra[d], rb[d]);
+  int kt = 0;
+  for (; kt + NST <= nkt; kt += NST) {
+#pragma unroll
+    for (int d = 0; d < NST; ++d) k_tile(ra[d], rb[d], (kt + d) & 1, true);
+  }
+  const int rem = nkt - kt;
+#pragma unroll
+  for (int d = 0; d < NST - 1; ++d)
+    if (d < rem) k_tile(ra[d], rb[d], (kt + d) & 1, false);
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Rows are visited in
+  // increasing order, so (image, pixel) is carried along instead of divided out per row.
   const T* resp = (const T*)p.res;
   float st_s[TN], st_q[TN];
+  float bias_v[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+  for (int j = 0; j < TN; ++j) {
+    st_s[j] = 0.f; st_q[j] = 0.f;
+    const int n = bn * BN + (wc * TN + j) * 32 + frow;
+    bias_v[j] = (p.bias && n < p.OC) ? p.bias[n] : 0.f;
+  }
+  long long m_cur = (long long)bm * BM + wr * TM * 32 + 4 * fh;
+  int e_nb = (int)(m_cur / OHW);
+  int e_pix = (int)(m_cur - (long long)e_nb * OHW);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      const long long m = (long long)bm * BM + row;
-      if (m >= M) continue;
-      const int nb = (int)(m / OHW);
-      const int pix = (int)(m - (long long)nb * OHW);
-      const long long obase = (long long)nb * p.out_bs + (long long)pix * p.ldout;
-      const long long rbase = (long long)nb * p.res_bs + (long long)pix * p.ldres;
+      // step from the previous visited row to this one: +1 inside a group of 4, +5 between groups, +5 to the next tile
+      const int step = (i == 0 && r == 0) ? 0 : ((r & 3) != 0 ? 1 : 5);
+      m_cur += step;
+      e_pix += step;
+      while (e_pix >= OHW) { e_pix -= OHW; ++e_nb; }
+      if (m_cur >= M) continue;
+      const long long obase = (long long)e_nb * p.out_bs + (long long)e_pix * p.ldout;
+      const long long rbase = (long long)e_nb * p.res_bs + (long long)e_pix * p.ldres;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = bn * BN + (wc * TN + j) * 32 + frow;
         if (n >= p.OC) continue;
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[n];
+        float v = acc[i][j][r] + bias_v[j];
         if (resp) v += to_f32(resp[rbase + n]);
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.out_f32) ((float*)p.out)[obase + n] = v;
@@ -296,32 +379,45 @@ struct WgradCfg<float> {
 };
 
 template <class T, bool VEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD = 2 blocks per CU (<= 256 registers)
   using Cfg = WgradCfg<T>;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int CPR = Cfg::CPR, RPP = Cfg::RPP, BKM = Cfg::BKM, PITCH = Cfg::PITCH;
+  constexpr int NST = VEC ? 3 : 1;               // pixel tiles in flight in registers (8 x 16 B each per thread)
+  constexpr int STAGE_BYTES = 2 * BKM * PITCH;   // dy tile [BKM][128 oc] + x tile [BKM][128 k]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sP = smem;                 // dy tile  [BKM][128 oc]
-  unsigned char* sQ = smem + BKM * PITCH;   // x  tile  [BKM][128 k ]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = p.KH * p.KW * p.C;
   const int oc0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-  const int OHW = p.OH * p.OW;
-  const long long M = (long long)p.N * OHW;
-  const T* __restrict__ xp = (const T*)p.x;
-  const T* __restrict__ dyp = (const T*)p.dy;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)BUF_RANGE, 0x00020000);
 
   const int col = tid % CPR, prow = tid / CPR;
-  // this thread's fixed k-chunk (Q) and oc-chunk (P)
+  // this thread's fixed k-chunk (x operand) and oc-chunk (dy operand); BUF_OOB when the chunk is outside the matrix
   const int kq = k0 + col * EPC;
-  const bool kq_ok = kq < K;
-  const int tap = kq_ok ? kq / p.C : 0;
+  const int tap = kq < K ? kq / p.C : 0;
   const int cq = kq - tap * p.C;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int ocp = oc0 + col * EPC;
-  const bool ocp_ok = ocp < p.OC;
+  const unsigned q_bad = kq < K ? 0u : BUF_OOB;
+  const unsigned p_bad = ocp < p.OC ? 0u : BUF_OOB;
+  // scalar path: per-element decode of this thread's fixed chunk columns (done once)
+  int e_c[EPC], e_kh[EPC], e_kw[EPC];
+  unsigned e_qbad[EPC], e_pbad[EPC];
+  if constexpr (!VEC) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int kk = kq + e;
+      e_qbad[e] = kk < K ? 0u : BUF_OOB;
+      const int tp = kk < K ? kk / p.C : 0;
+      e_c[e] = kk - tp * p.C;
+      e_kh[e] = tp / p.KW;
+      e_kw[e] = tp - e_kh[e] * p.KW;
+      e_pbad[e] = ocp + e < p.OC ? 0u : BUF_OOB;
+    }
+  }
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -331,87 +427,96 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  constexpr int NST = 3;
+  const long long mt_begin = (long long)blockIdx.z * p.tiles_per_split;
+  const long long mt_total = ((long long)p.N * p.OH * p.OW + BKM - 1) / BKM;
+  long long mt_end = mt_begin + p.tiles_per_split;
+  if (mt_end > mt_total) mt_end = mt_total;
+  if (mt_begin >= mt_end) return;
+  const int ntile = (int)(mt_end - mt_begin);
+
+  // loader cursor: (image, oh, ow) of this thread's 4 pixel rows in the NEXT tile to fetch, advanced by BKM pixels per
+  // tile with mixed-radix carries (no division in the loop).  Rows past the last image read out of range (= zeros).
+  int r_nb[4], r_oh[4], r_ow[4];
+  {
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = mt_begin * BKM + prow + RPP * i;
+      r_nb[i] = (int)(m / OHW);
+      const int pix = (int)(m - (long long)r_nb[i] * OHW);
+      r_oh[i] = pix / p.OW;
+      r_ow[i] = pix - r_oh[i] * p.OW;
+    }
+  }
+  const int adv_w = BKM % p.OW, adv_q = BKM / p.OW;
+  const int adv_h = adv_q % p.OH, adv_n = adv_q / p.OH;
+
   uint4 rp[NST][4], rq[NST][4];
+  auto load_tile = [&](uint4 (&rp_)[4], uint4 (&rq_)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned m_bad = r_nb[i] < p.N ? 0u : BUF_OOB;
+      const unsigned dy_row = (unsigned)(((long long)r_nb[i] * p.dy_bs + (long long)(r_oh[i] * p.OW + r_ow[i]) * p.lddy) * (long long)sizeof(T)) | m_bad;
+      const unsigned x_img = (unsigned)((long long)r_nb[i] * p.x_bs * (long long)sizeof(T)) | m_bad;
+      if constexpr (VEC) {
+        rp_[i] = buf_load16(rs_dy, (dy_row | p_bad) + (unsigned)ocp * (unsigned)sizeof(T));
+        const int hi = r_oh[i] * p.stride - p.pad + kh, wi = r_ow[i] * p.stride - p.pad + kw;
+        const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const unsigned off = x_img + (unsigned)((hi * p.W + wi) * p.ldx + cq) * (unsigned)sizeof(T);
+        rq_[i] = buf_load16(rs_x, inb ? (off | q_bad) : BUF_OOB);
+      } else {
+        uint32_t wp_[4] = {0u, 0u, 0u, 0u}, wq_[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const uint32_t vp = buf_load_elem<T>(rs_dy, (dy_row | e_pbad[e]) + (unsigned)(ocp + e) * (unsigned)sizeof(T));
+          const int hi = r_oh[i] * p.stride - p.pad + e_kh[e], wi = r_ow[i] * p.stride - p.pad + e_kw[e];
+          const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+          const unsigned off = x_img + (unsigned)((hi * p.W + wi) * p.ldx + e_c[e]) * (unsigned)sizeof(T);
+          const uint32_t vq = buf_load_elem<T>(rs_x, inb ? (off | e_qbad[e]) : BUF_OOB);
+          if constexpr (sizeof(T) == 2) { wp_[e >> 1] |= vp << (16 * (e & 1)); wq_[e >> 1] |= vq << (16 * (e & 1)); }
+          else { wp_[e] = vp; wq_[e] = vq; }
+        }
+        rp_[i] = make_uint4(wp_[0], wp_[1], wp_[2], wp_[3]);
+        rq_[i] = make_uint4(wq_[0], wq_[1], wq_[2], wq_[3]);
+      }
+      // advance this row by BKM pixels
+      r_ow[i] += adv_w;
+      const int c1 = r_ow[i] >= p.OW ? 1 : 0;
+      r_ow[i] -= c1 ? p.OW : 0;
+      r_oh[i] += adv_h + c1;
+      const int c2 = r_oh[i] >= p.OH ? 1 : 0;
+      r_oh[i] -= c2 ? p.OH : 0;
+      r_nb[i] += adv_n + c2;
+    }
+  };
+
   const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
   float bsum[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) bsum[e] = 0.f;
-  // scalar path: per-element decode of this thread's fixed chunk columns (done once)
-  int e_c[EPC], e_kh[EPC], e_kw[EPC];
-  bool e_kok[EPC], e_ocok[EPC];
-  if constexpr (!VEC) {
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const int kk = kq + e;
-      e_kok[e] = kk < K;
-      const int tp = e_kok[e] ? kk / p.C : 0;
-      e_c[e] = kk - tp * p.C;
-      e_kh[e] = tp / p.KW;
-      e_kw[e] = tp - e_kh[e] * p.KW;
-      e_ocok[e] = ocp + e < p.OC;
-    }
-  }
-  auto load_tile = [&](long long mt, uint4 (&rp_)[4], uint4 (&rq_)[4]) {
+
+  // one pixel tile: ring stage -> LDS buffer `par`, barrier, (refill the stage), MFMAs; see igemm_kernel for the hazards
+  auto m_tile = [&](uint4 (&rp_)[4], uint4 (&rq_)[4], int par, bool refill) {
+    unsigned char* sP = smem + par * STAGE_BYTES;
+    unsigned char* sQ = sP + BKM * PITCH;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long m = mt * BKM + prow + RPP * i;
-      uint4 vp = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
-      if (m < M) {
-        const int nb = (int)(m / OHW);
-        const int pix = (int)(m - (long long)nb * OHW);
-        const int oh = pix / p.OW, ow = pix - oh * p.OW;
-        const T* dyrow = dyp + (long long)nb * p.dy_bs + (long long)pix * p.lddy;
-        const T* ximg = xp + (long long)nb * p.x_bs;
-        if constexpr (VEC) {
-          if (ocp_ok) vp = *reinterpret_cast<const uint4*>(dyrow + ocp);
-          const int hi = oh * p.stride - p.pad + kh, wi = ow * p.stride - p.pad + kw;
-          if (kq_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-            vq = *reinterpret_cast<const uint4*>(ximg + ((long long)hi * p.W + wi) * p.ldx + cq);
-        } else {
-          T ep[EPC], eq[EPC];
+      *reinterpret_cast<uint4*>(sP + (prow + RPP * i) * PITCH + col * 16) = rp_[i];
+      *reinterpret_cast<uint4*>(sQ + (prow + RPP * i) * PITCH + col * 16) = rq_[i];
+    }
+    if (do_bias) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            ep[e] = e_ocok[e] ? dyrow[ocp + e] : from_f32<T>(0.f);
-            const int hi = oh * p.stride - p.pad + e_kh[e], wi = ow * p.stride - p.pad + e_kw[e];
-            const bool ok = e_kok[e] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            eq[e] = ok ? ximg[((long long)hi * p.W + wi) * p.ldx + e_c[e]] : from_f32<T>(0.f);
-          }
-          vp = *reinterpret_cast<const uint4*>(&ep[0]);
-          vq = *reinterpret_cast<const uint4*>(&eq[0]);
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t w4[4] = {rp_[i].x, rp_[i].y, rp_[i].z, rp_[i].w};
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          if constexpr (sizeof(T) == 2) bsum[e] += bf16_bits_to_f32((w4[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+          else bsum[e] += __uint_as_float(w4[e]);
         }
-      }
-      rp_[i] = vp;
-      rq_[i] = vq;
-    }
-  };
-
-  const long long mt_begin = (long long)blockIdx.z * p.tiles_per_split;
-  const long long mt_total = (M + BKM - 1) / BKM;
-  long long mt_end = mt_begin + p.tiles_per_split;
-  if (mt_end > mt_total) mt_end = mt_total;
-  if (mt_begin >= mt_end) return;
-
-#pragma unroll
-  for (int d = 0; d < NST; ++d)
-    if (mt_begin + d < mt_end) load_tile(mt_begin + d, rp[d], rq[d]);
-  for (long long mt0 = mt_begin; mt0 < mt_end; mt0 += NST) {
-#pragma unroll
-    for (int d = 0; d < NST; ++d) {
-      const long long mt = mt0 + d;
-      if (mt < mt_end) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sP + (prow + RPP * i) * PITCH + col * 16) = rp[d][i];
-      *reinterpret_cast<uint4*>(sQ + (prow + RPP * i) * PITCH + col * 16) = rq[d][i];
-      if (do_bias) {
-        const T* ev = reinterpret_cast<const T*>(&rp[d][i]);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) bsum[e] += to_f32(ev[e]);
       }
     }
     __syncthreads();
-    if (mt + NST < mt_end) load_tile(mt + NST, rp[d], rq[d]);
+    if (refill) load_tile(rp_, rq_);
     if constexpr (sizeof(T) == 2) {
       // lane: group g = lane>>4 (h = g>>1 picks k rows 8h.., half = g&1 picks 16 columns), t = lane&15.
       const int g = lane >> 4, t = lane & 15;
@@ -457,20 +562,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();
-      }
-    }
+  };
+
+#pragma unroll
+  for (int d = 0; d < NST; ++d) load_tile(rp[d], rq[d]);
+  int t = 0;
+  for (; t + NST <= ntile; t += NST) {
+#pragma unroll
+    for (int d = 0; d < NST; ++d) m_tile(rp[d], rq[d], (t + d) & 1, true);
   }
+  const int rem = ntile - t;
+#pragma unroll
+  for (int d = 0; d < NST - 1; ++d)
+    if (d < rem) m_tile(rp[d], rq[d], (t + d) & 1, false);
+  __syncthreads();      // the bias reduction below reuses the LDS tiles
 
   if (do_bias) {      // block-level reduction over the RPP row lanes in LDS, then ONE atomic per output channel
-    float* sb = reinterpret_cast<float*>(smem);     // [RPP][128]; the k-loop's last barrier has retired every LDS read
+    float* sb = reinterpret_cast<float*>(smem);     // [RPP][128]
 #pragma unroll
     for (int e = 0; e < EPC; ++e) sb[prow * 128 + col * EPC + e] = bsum[e];
     __syncthreads();
     if (tid < 128 && oc0 + tid < p.OC) {
-      float t = 0.f;
-      for (int r = 0; r < RPP; ++r) t += sb[r * 128 + tid];
-      atomicAdd(p.dbias + oc0 + tid, t);
+      float tsum = 0.f;
+      for (int r = 0; r < RPP; ++r) tsum += sb[r * 128 + tid];
+      atomicAdd(p.dbias + oc0 + tid, tsum);
     }
   }
   const int frow = lane & 31, fh = lane >> 5;
@@ -494,10 +609,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs p) {
 template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC>
 static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  // ring depth: ~96 VGPRs of loads in flight per thread whatever the tile (16 B x (BM + BN) / 32 per stage)
+  constexpr int NST = VEC ? ((BM + BN) / 32 <= 4 ? 6 : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long grid = ((M + BM - 1) / BM) * ((a.OC + BN - 1) / BN);
-  const size_t lds = (size_t)(BM + BN) * 144;
-  hipLaunchKernelGGL((igemm_kernel<T, TM, TN, WR, WC, MODE, VEC>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  const size_t lds = 2 * (size_t)(BM + BN) * 144;
+  auto kern = igemm_kernel<T, TM, TN, WR, WC, MODE, VEC, NST>;
+  static bool attr_done = false;      // one flag per instantiation
+  if (!attr_done && lds > 65536) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("emrt_conv2d", "cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
   return check_launch("emrt_conv2d");
 }
 
@@ -537,6 +661,12 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   } else {
     EMRT_REQUIRE(H == (OH + 2 * pad - KH) / stride + 1 && W == (OW + 2 * pad - KW) / stride + 1, "dgrad: size mismatch");
   }
+  {
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long in_ext = ((long long)(N - 1) * in_bs + ((long long)H * W - 1) * ldin + C) * esz;
+    const long long w_ext = (long long)OC * KH * KW * C * esz;
+    EMRT_REQUIRE(in_bs >= 0 && in_ext < (1ll << 31) && w_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
+  }
   ConvArgs a;
   a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.res = residual;
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs;
@@ -566,7 +696,14 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   long long S = want < max_split ? want : max_split;
   a.tiles_per_split = (int)((mt_total + S - 1) / S);
   S = (mt_total + a.tiles_per_split - 1) / a.tiles_per_split;
-  const size_t lds = 2 * (size_t)Cfg::BKM * Cfg::PITCH;
+  const size_t lds = 2 * 2 * (size_t)Cfg::BKM * Cfg::PITCH;      // two stages of (dy tile + x tile)
+  static bool attr_done = false;      // one flag per element type
+  if (!attr_done && lds > 65536) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("emrt_conv2d_wgrad", "cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
   if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wgrad_kernel<T, false>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
   return check_launch("emrt_conv2d_wgrad");
@@ -580,6 +717,12 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
   EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  {
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long x_ext = ((long long)(N - 1) * x_bs + ((long long)H * W - 1) * ldx + C) * esz;
+    const long long dy_ext = ((long long)(N - 1) * dy_bs + ((long long)OH * OW - 1) * lddy + OC) * esz;
+    EMRT_REQUIRE(x_bs >= 0 && dy_bs >= 0 && x_ext < (1ll << 31) && dy_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
+  }
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.x_bs = x_bs;
