@@ -16,6 +16,7 @@
 //   MODE 1 (dgrad): pix = ((oh + pad - kh)/stride, (ow + pad - kw)/stride) when divisible
 // wgrad: dW[oc][tap*C + c] += sum_m dy[m][oc] * x[pix(m,tap)][c]   (fp32 atomics, split over m)
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace emrt;
 
@@ -627,13 +628,23 @@ static int launch_igemm(const ConvArgs& a, hipStream_t st) {
 
 template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
-  // largest tile that still leaves >= 2-3 blocks per CU; everything else takes 64x64
   const long long M = (long long)a.N * a.OH * a.OW;
   auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
+  if (const char* ov = getenv("EMRT_CONV_TILE")) {     // developer knob for tools/bench_conv.py; unset in production
+    switch (atoi(ov)) {
+      case 1: return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
+      case 2: return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
+      case 3: return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
+      case 4: return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
+      default: break;
+    }
+  }
   if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
-  // measured: 64x64 tiles at >= 2 blocks per CU beat 128x64 tiles at ~1 per CU on the 32x32 / token GEMMs
-  if (a.OC > 64 && blocks(128, 128) >= 384) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
-  if (blocks(128, 64) >= 768) return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
+  // measured on MI355X (tools/bench_conv.py): 128x128 tiles win only when the k loop is long enough to amortise their
+  // prologue / epilogue (>= 16 k-tiles) and there is at least one block per CU; everything else is fastest on 64x64
+  constexpr int BK = 8 * (16 / (int)sizeof(T));
+  const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
+  if (a.OC > 64 && nkt >= 16 && blocks(128, 128) >= 256) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
   return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
 }
 
@@ -689,11 +700,25 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
                    (a.x_bs % EPC == 0) && (a.dy_bs % EPC == 0) && (((uintptr_t)a.x) % 16 == 0) && (((uintptr_t)a.dy) % 16 == 0);
   const int tx = (K + 127) / 128, ty = (a.OC + 127) / 128;
   const long long mt_total = (M + Cfg::BKM - 1) / Cfg::BKM;
-  long long want = (512 + (long long)tx * ty - 1) / ((long long)tx * ty);   // ~2 blocks per CU; every extra slice re-adds dW atomically
-  if (want < 1) want = 1;
-  long long max_split = mt_total / 8;
-  if (max_split < 1) max_split = 1;
-  long long S = want < max_split ? want : max_split;
+  // Split of the pixel reduction over blockIdx.z.  Cost model fitted to tools/bench_conv.py on MI355X:
+  //   t(S) = tiles_per_block * 1 us * max(1, blocks / 1024)  +  S * |dW| / 1.3 TB/s (every slice re-adds dW atomically)
+  // i.e. a lone block needs ~1 us per pixel tile, up to ~4 blocks per CU overlap for free, fp32 atomics run at ~1.3 TB/s.
+  const double atom_us = (double)tx * 128.0 * (double)ty * 128.0 * 4.0 / 1.3e6;
+  long long S = 1;
+  double best = 1e30;
+  static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
+    const long long sc = cand[ci];
+    if (sc > mt_total) break;
+    const double per = (double)((mt_total + sc - 1) / sc);
+    const double nblk = (double)tx * ty * sc;
+    const double t = per * (nblk > 1024.0 ? nblk / 1024.0 : 1.0) + sc * atom_us;
+    if (t < best) { best = t; S = sc; }
+  }
+  if (const char* ov = getenv("EMRT_WGRAD_SPLIT")) {   // developer knob for tools/bench_conv.py
+    const long long v = atoll(ov);
+    if (v > 0) S = v < mt_total ? v : mt_total;
+  }
   a.tiles_per_split = (int)((mt_total + S - 1) / S);
   S = (mt_total + a.tiles_per_split - 1) / a.tiles_per_split;
   const size_t lds = 2 * 2 * (size_t)Cfg::BKM * Cfg::PITCH;      // two stages of (dy tile + x tile)

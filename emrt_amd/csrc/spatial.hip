@@ -136,6 +136,16 @@ __device__ __forceinline__ void axis_range(const Axis& a, int i, int out, int& l
   if (hi > out - 1) hi = out - 1;
 }
 
+// weight with which destination index d reads source index i along one axis (0 when it does not)
+__device__ __forceinline__ float axis_weight(const Axis& a, int d, int in, int i) {
+  int i0, i1;
+  float l0, l1;
+  axis_src(a, d, in, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+constexpr int RB_WIN = 8;   // separable fast path: the destination window of a source pixel is at most 8 wide (scale >= 1/3)
+
 template <class T, int VEC>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
   const int cv = a.C / VEC;
@@ -152,25 +162,37 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-    for (int oh = ylo; oh <= yhi; ++oh) {
-      int y0, y1;
-      float wy0, wy1;
-      axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
-      const float wy = (y0 == ih ? wy0 : 0.f) + (y1 == ih ? wy1 : 0.f);
-      if (wy == 0.f) continue;
-      for (int ow = xlo; ow <= xhi; ++ow) {
-        int x0, x1;
-        float wx0, wx1;
-        axis_src(a.ax, ow, a.IW, x0, x1, wx0, wx1);
-        const float wx = (x0 == iw ? wx0 : 0.f) + (x1 == iw ? wx1 : 0.f);
-        if (wx == 0.f) continue;
-        const float wgt = wy * wx;
-        if (a.dout_nchw_f32) {
+    const T* gimg = (const T*)a.dout + (long long)n * a.do_bs + c;
+    if (xhi - xlo < RB_WIN) {
+      // the x weights do not depend on the row: evaluate them once (registers), then stream the rows
+      float wxa[RB_WIN];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            acc[e] = fmaf(wgt, ((const float*)a.dout)[(((long long)n * a.C + c + e) * a.OH + oh) * a.OW + ow], acc[e]);
-        } else {
-          const T* gp = (const T*)a.dout + (long long)n * a.do_bs + ((long long)oh * a.OW + ow) * a.do_ld + c;
+      for (int j = 0; j < RB_WIN; ++j) wxa[j] = (xlo + j <= xhi) ? axis_weight(a.ax, xlo + j, a.IW, iw) : 0.f;
+      for (int oh = ylo; oh <= yhi; ++oh) {
+        const float wy = axis_weight(a.ay, oh, a.IH, ih);
+        if (wy == 0.f) continue;
+        const T* grow = gimg + ((long long)oh * a.OW + xlo) * a.do_ld;
+#pragma unroll
+        for (int j = 0; j < RB_WIN; ++j) {
+          if (wxa[j] == 0.f) continue;
+          const float wgt = wy * wxa[j];
+          if (VEC == 4) {
+            float g[4];
+            Vec4<T>::load(grow + (long long)j * a.do_ld, g);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+          } else acc[0] = fmaf(wgt, to_f32(grow[(long long)j * a.do_ld]), acc[0]);
+        }
+      }
+    } else {
+      for (int oh = ylo; oh <= yhi; ++oh) {
+        const float wy = axis_weight(a.ay, oh, a.IH, ih);
+        if (wy == 0.f) continue;
+        for (int ow = xlo; ow <= xhi; ++ow) {
+          const float wx = axis_weight(a.ax, ow, a.IW, iw);
+          if (wx == 0.f) continue;
+          const float wgt = wy * wx;
+          const T* gp = gimg + ((long long)oh * a.OW + ow) * a.do_ld;
           if (VEC == 4) {
             float g[4];
             Vec4<T>::load(gp, g);
@@ -190,6 +212,42 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
   }
 }
 
+// fp32 NCHW gradient (the logits): separable two-pass gather.  Pass W folds the columns, tmp[n][c][oh][iw] =
+// sum_ow wx(ow -> iw) dout[n][c][oh][ow] (threads run along iw, the reads sweep each dout row once); pass H folds the rows
+// and writes the NHWC result.  dout is read once instead of once per source pixel of its window (16x16 for the x16 aux head).
+__global__ __launch_bounds__(256) void resize_bwd_nchw_w_kernel(ResizeBwdArgs a, float* __restrict__ tmp) {
+  const long long total = (long long)a.N * a.C * a.OH * a.IW;
+  const float* __restrict__ g = (const float*)a.dout;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int iw = (int)(idx % a.IW);
+    const long long row = idx / a.IW;            // (n, c, oh)
+    int xlo, xhi;
+    axis_range(a.ax, iw, a.OW, xlo, xhi);
+    const float* gr = g + row * a.OW;
+    float acc = 0.f;
+    for (int ow = xlo; ow <= xhi; ++ow) acc = fmaf(axis_weight(a.ax, ow, a.IW, iw), gr[ow], acc);
+    tmp[idx] = acc;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void resize_bwd_nchw_h_kernel(ResizeBwdArgs a, const float* __restrict__ tmp) {
+  const long long total = (long long)a.N * a.C * a.IH * a.IW;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int iw = (int)(idx % a.IW);
+    long long r = idx / a.IW;
+    const int ih = (int)(r % a.IH); r /= a.IH;
+    const int c = (int)(r % a.C);
+    const int n = (int)(r / a.C);
+    int ylo, yhi;
+    axis_range(a.ay, ih, a.OH, ylo, yhi);
+    const float* tp = tmp + ((long long)n * a.C + c) * a.OH * a.IW + iw;
+    float acc = 0.f;
+    for (int oh = ylo; oh <= yhi; ++oh) acc = fmaf(axis_weight(a.ay, oh, a.IH, ih), tp[(long long)oh * a.IW], acc);
+    ((T*)a.din)[(long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + c] = from_f32<T>(acc);
+  }
+}
+
 // ---- multi-scale adaptive average pooling: in [N][H][W][C] -> out [N][sum k_i^2][C] (token order: scale, row, col) ----
 struct PoolArgs {
   const void* in; long long in_bs; int in_ld; int H, W;
@@ -204,30 +262,67 @@ __device__ __forceinline__ void bin_of(int i, int k, int S, int& b0, int& b1) {
   b1 = ((i + 1) * S + k - 1) / k;
 }
 
+// One block per (image, token): the threads cover the channels (4 at a time) x row phases of the bin, so that the
+// 32x32-pixel bin of the 1x1 scale is not one thread's 1024-step serial loop; the phases are reduced through LDS.
+constexpr int POOL_THREADS = 512;
+
 template <class T>
-__global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(PoolArgs a) {
-  const long long total = (long long)a.N * a.ntok * a.C;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % a.C);
-    long long r = idx / a.C;
-    const int tok = (int)(r % a.ntok);
-    const int n = (int)(r / a.ntok);
-    int s = 0;
-    while (s + 1 < a.nscales && tok >= a.tok0[s + 1]) ++s;
-    const int k = a.k[s], t = tok - a.tok0[s];
-    const int oi = t / k, oj = t - oi * k;
-    int h0, h1, w0, w1;
-    bin_of(oi, k, a.H, h0, h1);
-    bin_of(oj, k, a.W, w0, w1);
-    float acc = 0.f;
-    const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
-    for (int h = h0; h < h1; ++h)
-      for (int w = w0; w < w1; ++w) acc += to_f32(ip[((long long)h * a.W + w) * a.in_ld]);
-    ((T*)a.out)[(long long)n * a.out_bs + (long long)tok * a.out_ld + c] = from_f32<T>(acc / (float)((h1 - h0) * (w1 - w0)));
+__global__ __launch_bounds__(POOL_THREADS) void adaptive_pool_fwd_kernel(PoolArgs a) {
+  __shared__ float red[POOL_THREADS * 4];
+  const int tok = blockIdx.x % a.ntok, n = blockIdx.x / a.ntok;
+  int s = 0;
+  while (s + 1 < a.nscales && tok >= a.tok0[s + 1]) ++s;
+  const int k = a.k[s], t = tok - a.tok0[s];
+  const int oi = t / k, oj = t - oi * k;
+  int h0, h1, w0, w1;
+  bin_of(oi, k, a.H, h0, h1);
+  bin_of(oj, k, a.W, w0, w1);
+  const int bw = w1 - w0, npix = (h1 - h0) * bw;
+  const int cq = (a.C + 3) / 4;                       // channel quads
+  int phases = POOL_THREADS / cq;
+  if (phases < 1) phases = 1;
+  const bool vec = (a.C % 4 == 0) && (a.in_ld % 4 == 0) && (a.in_bs % 4 == 0) && (((uintptr_t)a.in) % 16 == 0);
+  const float inv = 1.f / (float)npix;
+  for (int q0 = 0; q0 < cq; q0 += POOL_THREADS) {     // (only when C > 2048)
+    const int q = q0 + (int)threadIdx.x % (cq < POOL_THREADS ? cq : POOL_THREADS);
+    const int ph = (int)threadIdx.x / (cq < POOL_THREADS ? cq : POOL_THREADS);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q < cq && ph < phases) {
+      const T* ip = (const T*)a.in + (long long)n * a.in_bs + q * 4;
+      for (int pxi = ph; pxi < npix; pxi += phases) {
+        const int hh = h0 + pxi / bw, ww = w0 + pxi % bw;
+        const T* pp = ip + ((long long)hh * a.W + ww) * a.in_ld;
+        if (vec) {
+          float v[4];
+          Vec4<T>::load(pp, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < a.C) acc[e] += to_f32(pp[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = acc[e];
+    __syncthreads();
+    if (q < cq && ph == 0) {
+      const int stride_t = cq < POOL_THREADS ? cq : POOL_THREADS;
+      for (int o = 1; o < phases; ++o)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += red[(threadIdx.x + o * stride_t) * 4 + e];
+      T* op = (T*)a.out + (long long)n * a.out_bs + (long long)tok * a.out_ld + q * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < a.C) op[e] = from_f32<T>(acc[e] * inv);
+    }
+    __syncthreads();
   }
 }
 
-// backward: `in` = d(out) tokens, `out` = d(in) map (fully overwritten)
+// backward: `in` = d(out) tokens, `out` = d(in) map (fully overwritten).  A pixel lies in at most two (overlapping)
+// bins per axis and scale: the bin floor(h*k/H) and its predecessor.
 template <class T>
 __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(PoolArgs a) {
   const long long total = (long long)a.N * a.H * a.W * a.C;
@@ -241,11 +336,12 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(PoolArgs a) {
     float acc = 0.f;
     for (int s = 0; s < a.nscales; ++s) {
       const int k = a.k[s];
-      for (int oi = 0; oi < k; ++oi) {
+      const int oi_hi = (h * k) / a.H, oj_hi = (w * k) / a.W;
+      for (int oi = oi_hi > 0 ? oi_hi - 1 : 0; oi <= oi_hi + 1 && oi < k; ++oi) {
         int h0, h1;
         bin_of(oi, k, a.H, h0, h1);
         if (h < h0 || h >= h1) continue;
-        for (int oj = 0; oj < k; ++oj) {
+        for (int oj = oj_hi > 0 ? oj_hi - 1 : 0; oj <= oj_hi + 1 && oj < k; ++oj) {
           int w0, w1;
           bin_of(oj, k, a.W, w0, w1);
           if (w < w0 || w >= w1) continue;
@@ -258,8 +354,11 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(PoolArgs a) {
 }
 
 // ---- max pooling (k x k, stride, pad; -inf padding; first maximum wins, as torch/paddle) ----
+// The forward stores, next to the maxima, the window slot (kh * k + kw, one byte) that won; the backward is then a
+// gather over the <= ceil(k/stride)^2 windows that contain an input pixel instead of a re-run of every window's scan.
 struct MaxPoolArgs {
   const void* in; void* out; const void* dout; void* din;
+  unsigned char* arg;
   int N, H, W, C, OH, OW, k, stride, pad;
 };
 
@@ -273,6 +372,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxPoolArgs a) {
     const int oh = (int)(r % a.OH);
     const int n = (int)(r / a.OH);
     float best = -INFINITY;
+    int slot = 255;
     for (int kh = 0; kh < a.k; ++kh) {
       const int h = oh * a.stride - a.pad + kh;
       if ((unsigned)h >= (unsigned)a.H) continue;
@@ -280,10 +380,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxPoolArgs a) {
         const int w = ow * a.stride - a.pad + kw;
         if ((unsigned)w >= (unsigned)a.W) continue;
         const float v = to_f32(((const T*)a.in)[(((long long)n * a.H + h) * a.W + w) * a.C + c]);
-        if (v > best || v != v) best = v;
+        if (v > best || v != v || slot == 255) { best = v; slot = kh * a.k + kw; }
       }
     }
     ((T*)a.out)[idx] = from_f32<T>(best);
+    if (a.arg) a.arg[idx] = (unsigned char)slot;
   }
 }
 
@@ -308,19 +409,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
     if (ow_hi > a.OW - 1) ow_hi = a.OW - 1;
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        float best = -INFINITY;
-        int bh = -1, bw = -1;
-        for (int kh = 0; kh < a.k; ++kh) {
-          const int hh = oh * a.stride - a.pad + kh;
-          if ((unsigned)hh >= (unsigned)a.H) continue;
-          for (int kw = 0; kw < a.k; ++kw) {
-            const int ww = ow * a.stride - a.pad + kw;
-            if ((unsigned)ww >= (unsigned)a.W) continue;
-            const float v = to_f32(((const T*)a.in)[(((long long)n * a.H + hh) * a.W + ww) * a.C + c]);
-            if (v > best || v != v) { best = v; bh = hh; bw = ww; }
-          }
-        }
-        if (bh == h && bw == w) acc += to_f32(((const T*)a.dout)[(((long long)n * a.OH + oh) * a.OW + ow) * a.C + c]);
+        const long long o = (((long long)n * a.OH + oh) * a.OW + ow) * a.C + c;
+        const int slot = (h - (oh * a.stride - a.pad)) * a.k + (w - (ow * a.stride - a.pad));
+        if ((int)a.arg[o] == slot) acc += to_f32(((const T*)a.dout)[o]);
       }
     ((T*)a.din)[idx] = from_f32<T>(acc);
   }
@@ -385,16 +476,29 @@ extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_
   return check_launch("emrt_resize_bilinear_fwd");
 }
 
+extern "C" size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, int dout_nchw_f32) {
+  return dout_nchw_f32 ? (size_t)N * C * OH * IW * sizeof(float) : 0;
+}
+
 extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs,
-                                        int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, int dtype,
-                                        void* stream) {
+                                        int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32,
+                                        void* workspace, int dtype, void* stream) {
   EMRT_REQUIRE(dout && din, "null pointer");
   ResizeBwdArgs a;
   a.dout = dout; a.do_bs = do_bs; a.do_ld = do_ld; a.OH = OH; a.OW = OW;
   a.din = din; a.di_bs = di_bs; a.di_ld = di_ld; a.IH = IH; a.IW = IW; a.N = N; a.C = C;
   a.ay = make_axis(IH, OH, align_corners); a.ax = make_axis(IW, OW, align_corners); a.dout_nchw_f32 = dout_nchw_f32;
   hipStream_t st = (hipStream_t)stream;
-  const bool v4 = !dout_nchw_f32 && C % 4 == 0 && do_ld % 4 == 0 && di_ld % 4 == 0 && do_bs % 4 == 0 && di_bs % 4 == 0 &&
+  if (dout_nchw_f32) {
+    EMRT_REQUIRE(workspace, "fp32 NCHW gradient needs the emrt_resize_bwd_workspace_bytes() workspace");
+    float* tmp = (float*)workspace;
+    hipLaunchKernelGGL(resize_bwd_nchw_w_kernel, dim3(ew_grid((long long)N * C * OH * IW)), dim3(256), 0, st, a, tmp);
+    const int grid = ew_grid((long long)N * C * IH * IW);
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_nchw_h_kernel<float>), dim3(grid), dim3(256), 0, st, a, (const float*)tmp);
+    else hipLaunchKernelGGL((resize_bwd_nchw_h_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (const float*)tmp);
+    return check_launch("emrt_resize_bilinear_bwd");
+  }
+  const bool v4 = C % 4 == 0 && do_ld % 4 == 0 && di_ld % 4 == 0 && do_bs % 4 == 0 && di_bs % 4 == 0 &&
                   ((uintptr_t)dout % 16 == 0) && ((uintptr_t)din % 16 == 0);
   if (v4) {
     const int grid = ew_grid((long long)N * IH * IW * (C / 4));
@@ -426,8 +530,8 @@ extern "C" int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in
   a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.N = N; a.C = C;
   EMRT_REQUIRE(fill_pool(a, scales, nscales) == 0, "1..4 scales supported");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ew_grid((long long)N * a.ntok * C);
-  DT2(dtype, adaptive_pool_fwd_kernel, grid, a);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((adaptive_pool_fwd_kernel<float>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((adaptive_pool_fwd_kernel<bf16_t>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
   return check_launch("emrt_adaptive_avgpool_fwd");
 }
 
@@ -444,11 +548,13 @@ extern "C" int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int 
   return check_launch("emrt_adaptive_avgpool_bwd");
 }
 
-extern "C" int emrt_maxpool_fwd(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream) {
+extern "C" int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad,
+                                int dtype, void* stream) {
   EMRT_REQUIRE(in && out, "null pointer");
+  EMRT_REQUIRE(k > 0 && k <= 15 && stride > 0 && pad >= 0 && pad < k, "bad window");
   MaxPoolArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = in; a.out = out; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.pad = pad;
+  a.in = in; a.out = out; a.arg = argmax; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.pad = pad;
   a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid((long long)N * a.OH * a.OW * C);
@@ -456,12 +562,14 @@ extern "C" int emrt_maxpool_fwd(const void* in, void* out, int N, int H, int W, 
   return check_launch("emrt_maxpool_fwd");
 }
 
-extern "C" int emrt_maxpool_bwd(const void* in, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad,
-                                int dtype, void* stream) {
-  EMRT_REQUIRE(in && dout && din, "null pointer");
+extern "C" int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, int N, int H, int W, int C, int k, int stride,
+                                int pad, int dtype, void* stream) {
+  EMRT_REQUIRE(argmax && dout && din, "null pointer");
+  EMRT_REQUIRE(k > 0 && k <= 15 && stride > 0 && pad >= 0 && pad < k, "bad window");
   MaxPoolArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = in; a.dout = dout; a.din = din; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.pad = pad;
+  a.arg = const_cast<unsigned char*>(argmax); a.dout = dout; a.din = din; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride;
+  a.pad = pad;
   a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid((long long)N * H * W * C);

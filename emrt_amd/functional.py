@@ -606,8 +606,11 @@ def resize_bilinear(x, OH, OW, align_corners, add_t=None, out=None, out_nchw_f32
                 do_bs, do_ld = 0, 0
             else:
                 _, _, _, _, do_ld, do_bs = _check_map(dy)
+            ws = None
+            if out_nchw_f32:
+                ws = c.workspace(_L().query("emrt_resize_bwd_workspace_bytes", N, C, OH, IW, 1))
             _L().call("emrt_resize_bilinear_bwd", P(dy), do_bs, do_ld, OH, OW, P(dx), IH * IW * C, C, IH, IW, N, C, int(align_corners),
-                      int(out_nchw_f32), c.dtype, c.stream)
+                      int(out_nchw_f32), P(ws), c.dtype, c.stream)
             tape.add_grad(x, dx)
             if add_t is not None:
                 tape.add_grad(add_t, dy)
@@ -645,16 +648,18 @@ def maxpool(x, k=3, stride=2, pad=1, need_dx=True):
     N, H, W, C = x.shape
     OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = c.empty((N, OH, OW, C))
-    _L().call("emrt_maxpool_fwd", P(x), P(out), N, H, W, C, k, stride, pad, c.dtype, c.stream)
     tape = c.tape
-    if tape is not None and need_dx:
+    keep = tape is not None and need_dx
+    arg = c.empty((N, OH, OW, C), torch.uint8) if keep else None      # winning window slot per output, for the backward
+    _L().call("emrt_maxpool_fwd", P(x), P(out), P(arg), N, H, W, C, k, stride, pad, c.dtype, c.stream)
+    if keep:
         def bwd():
             dy = tape.pop_grad(out)
             if dy is None:
                 return
             assert dy.is_contiguous()
             dx = c.empty((N, H, W, C))
-            _L().call("emrt_maxpool_bwd", P(x), P(dy), P(dx), N, H, W, C, k, stride, pad, c.dtype, c.stream)
+            _L().call("emrt_maxpool_bwd", P(arg), P(dy), P(dx), N, H, W, C, k, stride, pad, c.dtype, c.stream)
             tape.add_grad(x, dx)
         tape.record(bwd)
     return out

@@ -87,14 +87,15 @@ int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, 
 /* ---- bilinear F.interpolate (align_corners True/False), optional fused "+ add", strided (concat-slice) output,
  * optional fp32 NCHW output for the returned logits: paddle_EMRT.py:40,44,169,174,180,288-289,301; fcn_head.py:80 */
 int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs, int out_ld, int OH, int OW, const void* add, long long add_bs, int add_ld, int N, int C, int align_corners, int out_nchw_f32, int dtype, void* stream);
-int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs, int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, int dtype, void* stream);
+size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, int dout_nchw_f32);
+int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs, int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, void* workspace, int dtype, void* stream);
 /* nn.AdaptiveAvgPool2D(k), k in scales (host int[nscales], <= 4), all scales in one launch -> tokens [N][sum k^2][C]:
  * paddle_EMRT.py:62,70-78 */
 int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs, int out_ld, int N, int C, const int* scales, int nscales, int dtype, void* stream);
 int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void* din, long long di_bs, int di_ld, int H, int W, int N, int C, const int* scales, int nscales, int dtype, void* stream);
 /* nn.MaxPool2D(3, 2, 1): paddle_vision_resnet.py:201; paddle_EMRT.py:84 (dense NHWC) */
-int emrt_maxpool_fwd(const void* in, void* out, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
-int emrt_maxpool_bwd(const void* in, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
+int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
+int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
 /* model input: fp32 NCHW images (paddle_EMRT.py:252) -> NHWC compute dtype */
 int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream);
 

@@ -1,0 +1,105 @@
+"""Sweep the implicit-GEMM tile choice / wgrad split over the layer shapes of the EMRT step (developer tool, GPU).
+
+usage: python tools/bench_conv.py            # prints one line per shape: time per tile config
+"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, ".")
+import torch
+
+from emrt_amd import _lib
+
+L = _lib.lib()
+dev = torch.device("cuda:0")
+stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+SHAPES = [  # N, H, W, C, OC, k, stride, pad
+    (8, 32, 32, 256, 256, 3, 1, 1),
+    (8, 16, 16, 256, 256, 3, 1, 1),
+    (8, 8, 8, 256, 256, 3, 1, 1),
+    (8, 1, 1344, 256, 1024, 1, 1, 0),
+    (8, 1, 1344, 1024, 256, 1, 1, 0),
+    (8, 1, 1344, 256, 256, 1, 1, 0),
+    (8, 1, 1344, 256, 432, 1, 1, 0),
+    (8, 64, 64, 64, 256, 1, 1, 0),
+    (8, 64, 64, 256, 64, 1, 1, 0),
+    (8, 64, 64, 64, 64, 3, 1, 1),
+    (8, 32, 32, 128, 128, 3, 1, 1),
+    (8, 32, 32, 512, 128, 1, 1, 0),
+    (8, 32, 32, 128, 512, 1, 1, 0),
+    (8, 16, 16, 1024, 256, 1, 1, 0),
+    (8, 16, 16, 256, 1024, 1, 1, 0),
+    (8, 8, 8, 512, 512, 3, 1, 1),
+    (8, 8, 8, 2048, 512, 1, 1, 0),
+    (8, 8, 8, 512, 2048, 1, 1, 0),
+    (8, 64, 64, 256, 256, 3, 1, 1),
+    (8, 128, 128, 64, 64, 3, 1, 1),
+    (8, 128, 128, 256, 256, 3, 1, 1),
+    (8, 32, 32, 1536, 512, 3, 1, 1),
+]
+
+
+def timed(fn, n=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for (N, H, W, C, OC, k, s, pad) in SHAPES:
+        OH = (H + 2 * pad - k) // s + 1
+        OW = (W + 2 * pad - k) // s + 1
+        x = torch.randn(N, H, W, C, device=dev).bfloat16()
+        wf = (torch.randn(OC, k, k, C, device=dev) * 0.05).bfloat16()
+        wb = (torch.randn(C, k, k, OC, device=dev) * 0.05).bfloat16()
+        y = torch.empty(N, OH, OW, OC, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty_like(x)
+        dw = torch.zeros(OC, k, k, C, device=dev, dtype=torch.float32)
+        gf = 2.0 * N * OH * OW * OC * k * k * C / 1e9
+
+        def fwd():
+            L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC, 0, 0,
+                               k, k, s, pad, 0, 0, 0, None, 1, stream)
+
+        def dgrad():
+            L._raw_emrt_conv2d(P(y), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0,
+                               k, k, s, pad, 1, 0, 0, None, 1, stream)
+
+        def wgrad():
+            L._raw_emrt_conv2d_wgrad(P(x), P(y), P(dw), N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
+                                     k, k, s, pad, None, 1, stream)
+
+        line = "N%d %dx%dx%d->%d k%d  %6.2f GF |" % (N, H, W, C, OC, k, gf)
+        if which in ("all", "conv"):
+            for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
+                res = []
+                for tile in (0, 1, 2, 3):
+                    os.environ["EMRT_CONV_TILE"] = str(tile)
+                    res.append(timed(fn))
+                os.environ.pop("EMRT_CONV_TILE")
+                line += " %s auto %.1f 64x64 %.1f 128x64 %.1f 128x128 %.1f |" % (name, *res)
+        if which in ("all", "wgrad"):
+            res = []
+            for sp in (0, 1, 2, 4, 8, 16, 32):
+                if sp:
+                    os.environ["EMRT_WGRAD_SPLIT"] = str(sp)
+                res.append(timed(wgrad))
+            os.environ.pop("EMRT_WGRAD_SPLIT")
+            line += " wgrad auto %.1f S1 %.1f S2 %.1f S4 %.1f S8 %.1f S16 %.1f S32 %.1f" % tuple(res)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
