@@ -145,6 +145,8 @@ def main():
                         extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
                     elif name == "emrt_conv2d_wgrad":
                         extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
+                    else:       # integer arguments only: enough to recognise the layer
+                        extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))
                     f.write("%-26s %9.4f ms  %s\n" % (name, ms, extra))
         fam = {}
         for name, a, ms in calls:

@@ -37,7 +37,7 @@ struct MsdaArgs {
   float* probs;       // fp32 [B*Lq][M*L*P] softmax probabilities (written by the gradient kernel, read by the LDS scatter)
   void* dvalue_t;     // LDS path: [B][Lv][M*32] in the compute dtype, fully overwritten
   int Lv;
-  int g_lbeg[4], g_lend[4], g_pix0[4], g_npix[4];   // level groups whose fp32 gradient slab fits in LDS
+  int g_level[8], g_pix0[8], g_npix[8];   // scatter blocks: (level, first flat pixel, pixel count) of each LDS slab range
 };
 
 template <class T>
@@ -255,84 +255,133 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
 }
 
 // d value via LDS-privatised scatter.  Float LDS atomics run at ~1 lane / 4 clk on gfx950 (measured: 245 clk per
-// wave-level ds_add_f32) while integer LDS atomics are native rate, so contributions are accumulated in 64-bit fixed point
-// (2^-40 resolution, +-2^23 range: no data-dependent scaling, order-independent => bit-reproducible).
-// One block per (batch, head, pixel range of <= 448..581 flat value pixels); the range's slab [npix][33] x int64 lives in
-// LDS (odd pitch spreads pixels over banks).  Each half-wave takes one query per iteration: lane j computes sample j's
-// pixel coordinates once, the 32 lanes (= channels) fetch the output gradient once, then the L*P samples are broadcast
-// with width-32 shuffles and every in-range corner is one ds_add_u64 per lane.  The slab is written out once, in the
-// compute dtype, with plain coalesced stores: no global atomics, no zero-fill, no cast pass.
+// wave-level ds_add_f32) while integer LDS atomics are native rate, so contributions are accumulated in 32-bit fixed
+// point.  The scale is safe by construction: a query adds at most |g| to any (pixel, channel) (its sample weights are
+// probabilities times bilinear weights), so |sum| <= Lq * max|g|, and scale = 2^30 / (Lq * max|g|) taken over the
+// block's (batch, head) slice cannot overflow; integer adds commute, so the result is bit-reproducible.
+// One block per (batch, head, slab range); a range is a run of rows of ONE level (<= MSDA_MAX_NPIX pixels), so a block
+// only walks that level's P samples of every query.  Its slab [npix][33] x int32 lives in LDS (odd pitch spreads
+// pixels over banks).  Each half-wave takes QB = 32 / P queries per iteration: lane (qq, p) computes sample p of query qq
+// once, then the QB * P samples are broadcast one by one (width-32 shuffles) and the 32 lanes, one per channel, add
+// their corner contributions.
 #define MSDA_SLAB_PITCH 33
-#define MSDA_FIX_SCALE 1099511627776.0f        /* 2^40 */
-#define MSDA_FIX_INV 9.094947017729282e-13f    /* 2^-40 */
 template <class T, int L, int P>
 __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
   constexpr int LP = L * P;
-  static_assert(LP <= 32, "one lane per sample");
-  extern __shared__ unsigned long long slab[];
+  constexpr int QB = 32 / P;          // queries per half-wave iteration
+  static_assert(P <= 32, "one lane per sample");
+  extern __shared__ int slab[];
+  __shared__ float red[16];
   const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
-  const int pix0 = a.g_pix0[0] + blockIdx.y * a.g_npix[0];
-  int npix = a.Lv - pix0;
-  if (npix > a.g_npix[0]) npix = a.g_npix[0];
-  for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0ull;
-  __syncthreads();
-  const int ch = threadIdx.x & 31;
-  const int half = threadIdx.x >> 5, nhalf = blockDim.x >> 5;
-  // this lane's sample (lanes >= LP idle in the per-sample prologue)
-  const int my_l = ch < LP ? ch / P : 0;
-  int myH = a.h[0], myW = a.w[0];
+  const int lev = a.g_level[blockIdx.y], pix0 = a.g_pix0[blockIdx.y], npix = a.g_npix[blockIdx.y];
+  int H = a.h[0], W = a.w[0], lstart = a.start[0];
 #pragma unroll
   for (int l = 1; l < L; ++l)
-    if (my_l == l) { myH = a.h[l]; myW = a.w[l]; }
-  for (int q = half; q < a.Lq; q += nhalf) {
-    const long long bq = (long long)b * a.Lq + q;
-    float sx = 0.f, sy = 0.f, pw = 0.f;
-    if (ch < LP) {
-      const float* row = a.offw + bq * a.ldo;
-      const float2 o = *reinterpret_cast<const float2*>(row + (m * LP + ch) * 2);
-      const float* refq = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : my_l * 2);
-      sx = (refq[0] + o.x / (float)myW) * (float)myW - 0.5f;
-      sy = (refq[1] + o.y / (float)myH) * (float)myH - 0.5f;
-      pw = a.probs[bq * (a.M * LP) + m * LP + ch];
-    }
-    const float gch = to_f32(((const T*)a.dout)[bq * (a.M * 32) + m * 32 + ch]);
+    if (lev == l) { H = a.h[l]; W = a.w[l]; lstart = a.start[l]; }
+  for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0;
+  const T* gbase = (const T*)a.dout + (long long)b * a.Lq * (a.M * 32) + m * 32;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < a.Lq * 32; i += blockDim.x) mx = fmaxf(mx, fabsf(to_f32(gbase[(long long)(i >> 5) * (a.M * 32) + (i & 31)])));
 #pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      constexpr int dummy = 0; (void)dummy;
-      const int l = j / P;
-      const int H = a.h[l], W = a.w[l];
-      const float x = __shfl(sx, j, 32), y = __shfl(sy, j, 32), aw = __shfl(pw, j, 32);
-      const float xf = floorf(x), yf = floorf(y);
-      const float lx = x - xf, ly = y - yf;
-      const int x0 = (int)xf, y0 = (int)yf;
-      const float go = aw * gch * MSDA_FIX_SCALE;
-      const int f00 = a.start[l] + y0 * W + x0 - pix0;       // flat pixel index relative to this block's range
-      const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
-      const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-      if (vy0 && vx0 && (unsigned)f00 < (unsigned)npix)
-        atomicAdd(&slab[f00 * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * (1.f - ly) * (1.f - lx)));
-      if (vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix)
-        atomicAdd(&slab[(f00 + 1) * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * (1.f - ly) * lx));
-      if (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix)
-        atomicAdd(&slab[(f00 + W) * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * ly * (1.f - lx)));
-      if (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix)
-        atomicAdd(&slab[(f00 + W + 1) * MSDA_SLAB_PITCH + ch], (unsigned long long)__float2ll_rn(go * ly * lx));
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  const bool usable = mx > 0.f && mx < 3.0e38f;       // all-zero (or non-finite) gradients produce zeros
+  const float scale = usable ? 1073741824.f / ((float)a.Lq * mx) : 0.f;
+  const float inv_scale = usable ? ((float)a.Lq * mx) * (1.f / 1073741824.f) : 0.f;
+
+  const int ch = threadIdx.x & 31;
+  const int half = threadIdx.x >> 5, nhalf = blockDim.x >> 5;
+  const int my_qq = ch / P, my_p = ch - my_qq * P;    // this lane's (query, point) in the per-sample prologue
+  const float fW = (float)W, fH = (float)H;
+  const int rel0 = lstart - pix0;                      // flat index of the level's pixel (0,0) relative to the slab
+  for (int q0 = half * QB; q0 < a.Lq; q0 += nhalf * QB) {
+    float sx = 0.f, sy = 0.f, pw = 0.f;
+    if (my_qq < QB && q0 + my_qq < a.Lq) {
+      const long long bq = (long long)b * a.Lq + q0 + my_qq;
+      const int smp = lev * P + my_p;
+      const float2 o = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
+      const float* refq = a.ref + (long long)b * a.ref_bs + (long long)(q0 + my_qq) * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
+      sx = (refq[0] + o.x / fW) * fW - 0.5f;
+      sy = (refq[1] + o.y / fH) * fH - 0.5f;
+      pw = a.probs[bq * (a.M * LP) + m * LP + smp];     // 0 for queries past Lq: they add nothing
+    }
+    float gq[QB];
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq)
+      gq[qq] = q0 + qq < a.Lq ? to_f32(gbase[(long long)(q0 + qq) * (a.M * 32) + ch]) * scale : 0.f;
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int src = qq * P + p;
+        const float x = __shfl(sx, src, 32), y = __shfl(sy, src, 32), aw = __shfl(pw, src, 32);
+        const float xf = floorf(x), yf = floorf(y);
+        const float lx = x - xf, ly = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float go = aw * gq[qq];
+        const int f00 = rel0 + y0 * W + x0;          // flat pixel index relative to this block's range
+        const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+        const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+        if (vy0 && vx0 && (unsigned)f00 < (unsigned)npix)
+          atomicAdd(&slab[f00 * MSDA_SLAB_PITCH + ch], __float2int_rn(go * (1.f - ly) * (1.f - lx)));
+        if (vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix)
+          atomicAdd(&slab[(f00 + 1) * MSDA_SLAB_PITCH + ch], __float2int_rn(go * (1.f - ly) * lx));
+        if (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix)
+          atomicAdd(&slab[(f00 + W) * MSDA_SLAB_PITCH + ch], __float2int_rn(go * ly * (1.f - lx)));
+        if (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix)
+          atomicAdd(&slab[(f00 + W + 1) * MSDA_SLAB_PITCH + ch], __float2int_rn(go * ly * lx));
+      }
     }
   }
   __syncthreads();
   T* outp = (T*)a.dvalue_t + ((long long)b * a.Lv + pix0) * (a.M * 32) + m * 32;
   for (int i = threadIdx.x; i < npix * 32; i += blockDim.x) {
     const int pix = i >> 5, c = i & 31;
-    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>((float)(long long)slab[pix * MSDA_SLAB_PITCH + c] * MSDA_FIX_INV);
+    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>((float)slab[pix * MSDA_SLAB_PITCH + c] * inv_scale);
   }
 }
 
-static const int MSDA_MAX_NPIX = 576;    // 576 * 33 * 8 B = 152 064 B of the 160 KiB LDS
+static const int MSDA_MAX_NPIX = 1152;   // 1152 * 33 * 4 B = 152 064 B of the 160 KiB LDS
 
-// pixel-range split of the flattened value map: ngroups equal ranges of <= MSDA_MAX_NPIX pixels
-static void msda_ranges(int Lv, int* ngroups, int* npix) {
-  *ngroups = (Lv + MSDA_MAX_NPIX - 1) / MSDA_MAX_NPIX;
-  *npix = (Lv + *ngroups - 1) / *ngroups;
+// Slab ranges: every level is cut into equal runs of whole rows, at least enough that a run fits in LDS, and more when
+// the grid would otherwise leave CUs idle (a block's work is Lq * P sample steps whatever its range size, so the largest
+// level is the one worth cutting further).  Returns the number of ranges (<= 8) or -1.
+static int msda_ranges(MsdaArgs& a, int L, int bm) {
+  int cuts[4];
+  int total = 0;
+  for (int l = 0; l < L; ++l) {
+    const int px = a.h[l] * a.w[l];
+    cuts[l] = (px + MSDA_MAX_NPIX - 1) / MSDA_MAX_NPIX;
+    if (cuts[l] > a.h[l]) return -1;                    // a single row does not fit
+    total += cuts[l];
+  }
+  while (total < 8 && (long long)total * bm < 256) {     // below one block per CU: halve the tallest remaining piece
+    int best = -1, best_rows = 1;
+    for (int l = 0; l < L; ++l) {
+      const int rows = (a.h[l] + cuts[l] - 1) / cuts[l];
+      if (rows > best_rows) { best_rows = rows; best = l; }
+    }
+    if (best < 0) break;
+    ++cuts[best];
+    ++total;
+  }
+  if (total > 8) return -1;
+  int g = 0;
+  for (int l = 0; l < L; ++l) {
+    const int rows_per = (a.h[l] + cuts[l] - 1) / cuts[l];
+    for (int r0 = 0; r0 < a.h[l]; r0 += rows_per) {
+      const int rows = a.h[l] - r0 < rows_per ? a.h[l] - r0 : rows_per;
+      a.g_level[g] = l;
+      a.g_pix0[g] = a.start[l] + r0 * a.w[l];
+      a.g_npix[g] = rows * a.w[l];
+      ++g;
+    }
+  }
+  return g;
 }
 
 extern "C" int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L) {
@@ -368,7 +417,7 @@ static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t 
 #define MSDA_LDS_CASE(LL, PP)                                                                                 \
   if (L == LL && P == PP) {                                                                                   \
     static bool attr = false;                                                                                 \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
     hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, LL, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a); \
     return check_launch("emrt_msda_bwd(lds scatter)");                                                        \
   }
@@ -433,12 +482,13 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     EMRT_REQUIRE(workspace, "LDS scatter path needs the probability workspace");
     a.probs = (float*)workspace;
     a.dvalue_t = dvalue;
-    int ng, npix;
-    msda_ranges(Lv, &ng, &npix);
-    a.g_pix0[0] = 0; a.g_npix[0] = npix;
+    const int ng = msda_ranges(a, L, B * M);
+    EMRT_REQUIRE(ng > 0, "value map rows too long for the LDS slab");
+    int npix_max = 0;
+    for (int g = 0; g < ng; ++g) npix_max = a.g_npix[g] > npix_max ? a.g_npix[g] : npix_max;
     int rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
     if (rc) return rc;
-    const size_t lds = (size_t)npix * MSDA_SLAB_PITCH * sizeof(unsigned long long);
+    const size_t lds = (size_t)npix_max * MSDA_SLAB_PITCH * sizeof(int);
     return dtype == EMRT_F32 ? msda_launch_lds<float>(a, L, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, L, P, ng, lds, st);
   }
   a.dvalue = (float*)dvalue;

@@ -144,7 +144,7 @@ __device__ __forceinline__ float axis_weight(const Axis& a, int d, int in, int i
   return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
 }
 
-constexpr int RB_WIN = 8;   // separable fast path: the destination window of a source pixel is at most 8 wide (scale >= 1/3)
+constexpr int RB_WIN = 12;  // separable fast path: the destination window of a source pixel is at most 12 wide (up to x4 upsampling)
 
 template <class T, int VEC>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
