@@ -212,6 +212,45 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
   }
 }
 
+// Large upsampling factors (the 1x1 / 3x3 / 6x6 / 8x8 pyramid maps blown up to 32x32): a source pixel collects from
+// hundreds of destination pixels, so one BLOCK takes one source pixel: threads = channel quads x phases over its
+// destination window, reduced through LDS.
+constexpr int RBW_THREADS = 1024;
+template <class T>
+__global__ __launch_bounds__(RBW_THREADS) void resize_bwd_wide_kernel(ResizeBwdArgs a) {
+  __shared__ float red[RBW_THREADS * 4];
+  const int iw = blockIdx.x % a.IW, ih = (blockIdx.x / a.IW) % a.IH, n = blockIdx.x / (a.IW * a.IH);
+  int ylo, yhi, xlo, xhi;
+  axis_range(a.ay, ih, a.OH, ylo, yhi);
+  axis_range(a.ax, iw, a.OW, xlo, xhi);
+  const int bw = xhi - xlo + 1, npix = (yhi - ylo + 1) * bw;
+  const int cq = a.C / 4;                          // host guarantees C % 4 == 0 and cq <= RBW_THREADS
+  const int phases = RBW_THREADS / cq;
+  const int q = (int)threadIdx.x % cq, ph = (int)threadIdx.x / cq;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ph < phases) {
+    const T* gimg = (const T*)a.dout + (long long)n * a.do_bs + q * 4;
+    for (int pxi = ph; pxi < npix; pxi += phases) {
+      const int oh = ylo + pxi / bw, ow = xlo + pxi % bw;
+      const float wgt = axis_weight(a.ay, oh, a.IH, ih) * axis_weight(a.ax, ow, a.IW, iw);
+      if (wgt == 0.f) continue;
+      float g[4];
+      Vec4<T>::load(gimg + ((long long)oh * a.OW + ow) * a.do_ld, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = acc[e];
+  __syncthreads();
+  if (ph == 0) {
+    for (int o = 1; o < phases; ++o)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += red[(threadIdx.x + o * cq) * 4 + e];
+    Vec4<T>::store((T*)a.din + (long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + q * 4, acc);
+  }
+}
+
 // fp32 NCHW gradient (the logits): separable two-pass gather.  Pass W folds the columns, tmp[n][c][oh][iw] =
 // sum_ow wx(ow -> iw) dout[n][c][oh][ow] (threads run along iw, the reads sweep each dout row once); pass H folds the rows
 // and writes the NHWC result.  dout is read once instead of once per source pixel of its window (16x16 for the x16 aux head).
@@ -500,6 +539,11 @@ extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int d
   }
   const bool v4 = C % 4 == 0 && do_ld % 4 == 0 && di_ld % 4 == 0 && do_bs % 4 == 0 && di_bs % 4 == 0 &&
                   ((uintptr_t)dout % 16 == 0) && ((uintptr_t)din % 16 == 0);
+  if (v4 && C / 4 <= RBW_THREADS && ((long long)OH * OW >= 16ll * IH * IW)) {     // >= x4 per axis: block per source pixel
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_wide_kernel<float>), dim3(N * IH * IW), dim3(RBW_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((resize_bwd_wide_kernel<bf16_t>), dim3(N * IH * IW), dim3(RBW_THREADS), 0, st, a);
+    return check_launch("emrt_resize_bilinear_bwd");
+  }
   if (v4) {
     const int grid = ew_grid((long long)N * IH * IW * (C / 4));
     if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);

@@ -369,7 +369,7 @@ def test_mha_fwd_bwd(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 16, 16, True), (2, 8, 8, 64, 16, 16, False), (2, 3, 3, 256, 32, 32, True),
                                   (1, 6, 6, 128, 32, 32, True), (2, 1, 1, 64, 8, 8, True), (2, 16, 12, 6, 64, 48, False),
-                                  (2, 10, 10, 32, 10, 10, True)])
+                                  (2, 10, 10, 32, 10, 10, True), (2, 2, 2, 64, 16, 16, False), (1, 8, 8, 512, 32, 32, False)])
 def test_resize_bilinear(dtype, case):
     N, IH, IW, C, OH, OW, ac = case
     c = init(dtype)
