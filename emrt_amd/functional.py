@@ -251,7 +251,7 @@ def dropout(x, p, salt, mode=0, hw=1):
             assert g.is_contiguous()
             dx = c.empty(tuple(x.shape), x.dtype)
             _L().call("emrt_mask_bwd", P(g), None, P(dx), x.numel(), float(p), c.seed_ptr, salt, mode, hw, C, c.dtype, c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return y
 
@@ -304,15 +304,21 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 _L().call("emrt_mask_bwd", P(dy), P(out), P(dm), dy.numel(), 0.0, None, 0, 0, 1, 1, c.dtype, c.stream)
                 dy = dm
             _, _, _, _, lddy, dy_bs = _check_map(dy)
+            # the weight gradient and the data gradient only share their inputs: with overlap on, wgrad goes to the side
+            # stream and runs next to dgrad (most of these launches are too small to fill the GPU on their own)
+            side = c.fork() if need_dx else None
             _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
-                      w.KH, w.KW, stride, pad, P(w.bias_grad) if w.bias is not None else None, c.dtype, c.stream)
-            if residual is not None:
-                tape.add_grad(residual, dy)
+                      w.KH, w.KW, stride, pad, P(w.bias_grad) if w.bias is not None else None, c.dtype, side or c.stream)
             if need_dx:
                 dx = c.empty(tuple(x.shape))
                 _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
                           H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, None, c.dtype, c.stream)
-                tape.add_grad(x, dx)
+            if side is not None:
+                c.join()
+            if residual is not None:
+                tape.add_grad(residual, dy)
+            if need_dx:
+                tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return out
 
@@ -406,9 +412,9 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
             dres = c.empty(tuple(x.shape)) if (residual is not None and relu) else None
             _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
                       P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C, c.dtype, c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
             if residual is not None:
-                tape.add_grad(residual, dres if dres is not None else dy)
+                tape.add_grad(residual, dres if dres is not None else dy, owned=dres is not None)
         tape.record(bwd)
     return out
 
@@ -445,7 +451,7 @@ def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residu
             dx = c.empty(tuple(x.shape))
             _L().call("emrt_groupnorm_bwd", P(x), ldx, x_bs, P(dy), lddy, dy_bs, P(dx), C, H * W * C, P(gamma), P(beta), P(mean), P(rstd),
                       P(dgamma), P(dbeta), P(c.zeros_f64(N * C * 2)), N, H * W, C, G, int(gelu), c.dtype, c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
             if residual is not None:
                 tape.add_grad(residual, dy)
         tape.record(bwd)
@@ -521,8 +527,8 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
                 ws = None
             _L().call("emrt_msda_bwd", P(value), value.stride(1), value.stride(0), P(offw), ldo, P(ref), ref_bs, ref_L, P(dy), P(dvalue), P(doffw),
                       P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), P(ws), c.dtype, c.stream)
-            tape.add_grad(value, dvalue if use_lds else cast_from_f32(dvalue))
-            tape.add_grad(offw, doffw)
+            tape.add_grad(value, dvalue if use_lds else cast_from_f32(dvalue), owned=True)
+            tape.add_grad(offw, doffw, owned=True)
             if need_dref:
                 if ref.shape[0] == 1 and B > 1:   # reference points shared by the batch: reduce over b
                     red = c.zeros((1, Lq, ref_L, 2), torch.float32)
@@ -559,8 +565,8 @@ def mha(qk, v, n_heads, pdrop, salt):
             _L().call("emrt_mha_bwd", ctypes.c_void_p(q_ptr), E2, ctypes.c_void_p(k_ptr), E2, P(v), E, P(probs), P(dy), E,
                       ctypes.c_void_p(dqk.data_ptr()), E2, ctypes.c_void_p(dqk.data_ptr() + E * dqk.element_size()), E2, P(dv), E,
                       B, n_heads, L, 32, scale, p, c.seed_ptr, salt, c.dtype, c.stream)
-            tape.add_grad(qk, dqk)
-            tape.add_grad(v, dv)
+            tape.add_grad(qk, dqk, owned=True)
+            tape.add_grad(v, dv, owned=True)
         tape.record(bwd)
     return out
 
@@ -611,7 +617,7 @@ def resize_bilinear(x, OH, OW, align_corners, add_t=None, out=None, out_nchw_f32
                 ws = c.workspace(_L().query("emrt_resize_bwd_workspace_bytes", N, C, OH, IW, 1))
             _L().call("emrt_resize_bilinear_bwd", P(dy), do_bs, do_ld, OH, OW, P(dx), IH * IW * C, C, IH, IW, N, C, int(align_corners),
                       int(out_nchw_f32), P(ws), c.dtype, c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
             if add_t is not None:
                 tape.add_grad(add_t, dy)
         tape.record(bwd)
@@ -637,7 +643,7 @@ def adaptive_avgpool_tokens(x, scales):
             dx = c.empty((N, H, W, C))
             _L().call("emrt_adaptive_avgpool_bwd", P(dy), ntok * C, C, P(dx), H * W * C, C, H, W, N, C, ctypes.cast(arr, ctypes.c_void_p),
                       len(scales), c.dtype, c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return out
 
@@ -660,7 +666,7 @@ def maxpool(x, k=3, stride=2, pad=1, need_dx=True):
             assert dy.is_contiguous()
             dx = c.empty((N, H, W, C))
             _L().call("emrt_maxpool_bwd", P(arg), P(dy), P(dx), N, H, W, C, k, stride, pad, c.dtype, c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return out
 
@@ -678,7 +684,7 @@ def sigmoid_f32(x):
                 return
             dx = c.empty(tuple(x.shape), torch.float32)
             _L().call("emrt_sigmoid_bwd", P(y), P(dy), P(dx), x.numel(), c.stream)
-            tape.add_grad(x, dx)
+            tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return y
 
@@ -701,6 +707,6 @@ def softmax_ce(logits, labels, ignore_index, weight=1.0):
             up = tape.pop_grad(res)   # device scalar or None (== 1)
             dl = c.empty((N, C, H, W), torch.float32)
             _L().call("emrt_softmax_ce_bwd", P(logits), P(labels), P(res), P(up), float(weight), N, C, H, W, ignore_index, P(dl), c.stream)
-            tape.add_grad(logits, dl)
+            tape.add_grad(logits, dl, owned=True)
         tape.record(bwd)
     return res

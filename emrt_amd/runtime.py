@@ -68,9 +68,12 @@ class Tape:
             e[0], e[1] = priv, True
         return e[0]
 
-    def add_grad(self, t, g):
-        """Accumulate gradient g (same shape as t) into t's gradient.  A gradient tensor handed in is never modified
-        in place unless the tape allocated it itself, so one tensor may safely be passed for several targets."""
+    def add_grad(self, t, g, owned=False):
+        """Accumulate gradient g (same shape as t) into t's gradient.
+        owned=True: g is a fresh buffer that the caller hands over (nobody else reads it afterwards), so the tape may
+        accumulate into it in place.  A gradient passed without it is never modified, so one tensor may safely be
+        passed for several targets.  A second contribution costs ONE launch: in place when either side is owned,
+        else an out-of-place sum."""
         from . import functional as Fn
         a = self.alias.get(id(t))
         if a is not None:
@@ -86,13 +89,18 @@ class Tape:
             Fn.add_into(self.grad(t), g)
             return
         e = self.grads.get(id(t))
+        if tuple(g.shape) != tuple(t.shape):
+            g = g.reshape(t.shape)
         if e is None:
-            if tuple(g.shape) != tuple(t.shape):
-                g = g.reshape(t.shape)
             self.keep.append(t)
-            self.grads[id(t)] = [g, False]
+            self.grads[id(t)] = [g, bool(owned)]
+        elif e[1]:
+            Fn.add_into(e[0], g)
+        elif owned:
+            Fn.add_into(g, e[0])
+            e[0], e[1] = g, True
         else:
-            Fn.add_into(self._own(t), g)
+            e[0], e[1] = Fn.add_maps(e[0], g), True
 
     def backward(self):
         _CTX.tape = None            # backward kernels must not record
@@ -121,6 +129,22 @@ class Context:
         self._arena = None        # fp64 zero arena for BatchNorm sums: one memset per step instead of ~150 tiny ones
         self._arena_off = 0
         self._arena_live = False
+        self.overlap = False      # run independent backward kernels (wgrad next to dgrad) on a second HIP stream
+        self._side = None
+
+    # ---- second stream: fork()/join() bracket work that may overlap with what follows on the main stream -------------
+    def fork(self):
+        """Side stream (as a C handle) ordered after everything issued so far on the current stream, or None when
+        overlap is off.  Buffers used there must stay alive until join()."""
+        if not self.overlap:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        return ctypes.c_void_p(self._side.cuda_stream)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self._side)
 
     # ---- device / dtype -------------------------------------------------------------------------
     def init_device(self, device="cuda:0", dtype=F32, seed=1234):
