@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--overlap", action="store_true", help="wgrad on a second stream next to dgrad (A/B; slower inside the hipGraph)")
+    ap.add_argument("--overlap", default="", choices=["", "pair", "deferred"], help="wgrad on a second stream (A/B experiment)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
 
@@ -89,7 +89,7 @@ def main():
     model.to_hip(str(dev), dtype, seed=1234 + rank)
     opt = Momentum(model, PolynomialDecay(0.01, 160000, 0.0, 0.9), momentum=0.9, weight_decay=1e-4, grad_clip=1.0)
     loss_fn = MixSoftmaxCrossEntropyLoss(ignore_index=255, aux=True, aux_weight=0.4)
-    eng = TrainEngine(model, opt, loss_fn, world, use_graph=not args.no_graph, overlap=args.overlap)
+    eng = TrainEngine(model, opt, loss_fn, world, use_graph=not args.no_graph, overlap=args.overlap or False)
     g = torch.Generator().manual_seed(1234 + rank)
     B, S = args.batch, args.size
     images = torch.randn(B, 3, S, S, generator=g).to(dev)

@@ -90,17 +90,23 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // VEC = true : C % (16 B of elements) == 0 and 16-byte aligned rows -> one 16-byte load per chunk; the last k-tile may
 //              be partial (K % BK != 0, e.g. the fused 432-wide offsets|logits projection) and is zero-filled.
 // VEC = false: any C / alignment (7x7x3 stem, 3x3x3 branch conv, 6-class logits): chunks are assembled from element loads.
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST>
-__global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
+// G > 1 (in-block K split): the block has G groups of 4 waves; group g walks the k-tiles g, g+G, ... with its own LDS
+// buffers and the groups' accumulators are summed through LDS before the epilogue.  Small-M layers (16x16 / 8x8 maps)
+// launch fewer blocks than there are CUs and are bound by the latency of the serial k loop: the split shortens that
+// chain G-fold with waves the CU would otherwise leave idle, without global atomics or a second pass.
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G>
+__global__ __launch_bounds__(256 * G) void igemm_kernel(ConvArgs p) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
   constexpr int PITCH = 144;
   constexpr int AR = BM / 32, BR = BN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * PITCH;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = G == 1 ? 0 : (int)threadIdx.x >> 8;
+  unsigned char* smem = smem_all + grp * 2 * STAGE_BYTES;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int tiles_n = (p.OC + BN - 1) / BN;
   // consecutive workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of tiles so that the
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   const T* __restrict__ inp = (const T*)p.in;
   const T* __restrict__ wp = (const T*)p.w;
   const int K = p.KH * p.KW * p.C;
-  const int nkt = (K + BK - 1) / BK;
+  const int nkt = ((K + BK - 1) / BK + G - 1) / G;       // k-tiles walked by each group (tiles past K are all-zero)
 
   // Operands are read through raw buffer descriptors: an out-of-range byte offset returns zeros, which is how padding
   // taps, stride holes, rows beyond M / OC and the k tail are zero-filled without a branch or a select on the data.
@@ -171,14 +177,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
   for (int i = 0; i < AR; ++i) a_off1[i] = a_pixel(i, 0, 0);
   // loader cursor: k index / tap / channel of this thread's 16-byte chunk in the NEXT k-tile to fetch.  It keeps
   // advancing past K (the ring prefetches beyond the last tile): those chunks are all-zero.
-  int ld_kc = chunk * EPC, ld_kh, ld_kw, ld_c0;
+  constexpr int KSTEP = BK * G;        // a group's consecutive tiles are G tiles apart
+  int ld_kc = grp * BK + chunk * EPC, ld_kh, ld_kw, ld_c0;
   {
     const int tap = ld_kc / p.C;
     ld_c0 = ld_kc - tap * p.C;
     ld_kh = tap / p.KW;
     ld_kw = tap - ld_kh * p.KW;
   }
-  const bool c_ge_bk = p.C >= BK;
+  const bool c_ge_bk = p.C >= KSTEP;
   auto load_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
     if constexpr (VEC) {
       const unsigned kbad = ld_kc < K ? 0u : BUF_OOB;      // OR-ing BUF_OOB into an offset < BUF_OOB puts it out of range
@@ -189,9 +196,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < BR; ++j) rb_[j] = buf_load16(rs_w, (b_off[j] | kbad) + (unsigned)ld_kc * (unsigned)sizeof(T));
-      ld_kc += BK;
+      ld_kc += KSTEP;
       if (c_ge_bk) {          // at most one tap boundary per step: plain selects
-        ld_c0 += BK;
+        ld_c0 += KSTEP;
         const bool wrap = ld_c0 >= p.C;
         ld_c0 -= wrap ? p.C : 0;
         ld_kw += wrap ? 1 : 0;
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
       for (int i = 0; i < AR; ++i) ra_[i] = make_uint4(wa[i][0], wa[i][1], wa[i][2], wa[i][3]);
 #pragma unroll
       for (int j = 0; j < BR; ++j) rb_[j] = make_uint4(wb[j][0], wb[j][1], wb[j][2], wb[j][3]);
-      ld_kc += BK;
+      ld_kc += KSTEP;
     }
   };
 
@@ -289,6 +296,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvArgs p) {
 #pragma unroll
   for (int d = 0; d < NST - 1; ++d)
     if (d < rem) k_tile(ra[d], rb[d], (kt + d) & 1, false);
+
+  if constexpr (G > 1) {
+    // sum the groups' accumulators: groups 1..G-1 park theirs in LDS ([group-1][register][thread], conflict-free),
+    // group 0 adds them and alone runs the epilogue
+    __syncthreads();
+    float* park = reinterpret_cast<float*>(smem_all);
+    constexpr int NACC = TM * TN * 16;
+    if (grp > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) park[((grp - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += park[((g - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid];
+  }
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Rows are visited in
   // increasing order, so (image, pixel) is carried along instead of divided out per row.
@@ -607,22 +640,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {   // 2 wav
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC>
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int G = 1>
 static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   // ring depth: ~96 VGPRs of loads in flight per thread whatever the tile (16 B x (BM + BN) / 32 per stage)
-  constexpr int NST = VEC ? ((BM + BN) / 32 <= 4 ? 6 : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
+  // (a 1024-thread block, G = 4, has 128 registers per thread: 4 stages)
+  constexpr int NST = VEC ? (G >= 4 ? 4 : (BM + BN) / 32 <= 4 ? 6 : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long grid = ((M + BM - 1) / BM) * ((a.OC + BN - 1) / BN);
-  const size_t lds = 2 * (size_t)(BM + BN) * 144;
-  auto kern = igemm_kernel<T, TM, TN, WR, WC, MODE, VEC, NST>;
+  size_t lds = (size_t)G * 2 * (BM + BN) * 144;
+  if (G > 1 && lds < (size_t)(G - 1) * TM * TN * 16 * 256 * 4) lds = (size_t)(G - 1) * TM * TN * 16 * 256 * 4;
+  auto kern = igemm_kernel<T, TM, TN, WR, WC, MODE, VEC, NST, G>;
   static bool attr_done = false;      // one flag per instantiation
   if (!attr_done && lds > 65536) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail("emrt_conv2d", "cannot raise the dynamic LDS limit");
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * G), lds, st, a);
   return check_launch("emrt_conv2d");
 }
 
@@ -636,6 +671,8 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
       case 2: return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
       case 3: return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
       case 4: return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
+      case 5: if constexpr (VEC) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 2>(a, st); break;
+      case 6: if constexpr (VEC) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 4>(a, st); break;
       default: break;
     }
   }
@@ -645,6 +682,12 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
   constexpr int BK = 8 * (16 / (int)sizeof(T));
   const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
   if (a.OC > 64 && nkt >= 16 && blocks(128, 128) >= 256) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
+  if constexpr (VEC) {
+    // at most one 64x64 block per CU and a long k loop: split K inside the block (see igemm_kernel; thresholds measured)
+    const long long nb = blocks(64, 64);
+    if (nb <= 128 && nkt >= 32) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 4>(a, st);
+    if (nb <= 256 && nkt >= 16) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 2>(a, st);
+  }
   return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
 }
 

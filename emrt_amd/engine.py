@@ -32,7 +32,7 @@ class TrainEngine:
         self.loss_t = None
         c = ctx()
         c.world_size = world_size
-        c.overlap = bool(overlap)      # wgrad on a second stream next to dgrad; measured SLOWER inside a hipGraph (16.7 vs 16.3 ms)
+        c.overlap = overlap            # False | "pair" | "deferred": wgrad on a second stream (runtime.Context.fork)
         self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems) if world_size > 1 else None
 
     # -- pieces ------------------------------------------------------------------------------------
@@ -43,6 +43,7 @@ class TrainEngine:
         out = self.model(images)
         loss = self.loss_fn(out, labels)
         loss.backward()
+        ctx().join_all()               # side-stream weight gradients (if any) land before the reducer / optimizer
         return loss.tensor
 
     def _eager_step(self, images, labels):

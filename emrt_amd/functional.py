@@ -306,7 +306,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             # the weight gradient and the data gradient only share their inputs: with overlap on, wgrad goes to the side
             # stream and runs next to dgrad (most of these launches are too small to fill the GPU on their own)
-            side = c.fork() if need_dx else None
+            side = c.fork(x, dy) if need_dx else None
             _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
                       w.KH, w.KW, stride, pad, P(w.bias_grad) if w.bias is not None else None, c.dtype, side or c.stream)
             if need_dx:

@@ -132,19 +132,30 @@ class Context:
         self.overlap = False      # run independent backward kernels (wgrad next to dgrad) on a second HIP stream
         self._side = None
 
-    # ---- second stream: fork()/join() bracket work that may overlap with what follows on the main stream -------------
-    def fork(self):
-        """Side stream (as a C handle) ordered after everything issued so far on the current stream, or None when
-        overlap is off.  Buffers used there must stay alive until join()."""
+    # ---- second stream -------------------------------------------------------------------------------------------
+    # overlap = False | "pair" | "deferred".  fork() returns the side stream (C handle) ordered after everything issued so
+    # far on the current stream.  "pair": the caller join()s right after the overlapping main-stream kernel.  "deferred":
+    # nothing is joined until join_all() (before the optimizer); the buffers the side-stream kernels read are parked in
+    # _side_keep so that the allocator cannot hand them out again meanwhile.
+    def fork(self, *keep):
         if not self.overlap:
             return None
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+            self._side_keep = []
         self._side.wait_stream(torch.cuda.current_stream())
+        if self.overlap == "deferred":
+            self._side_keep.extend(keep)
         return ctypes.c_void_p(self._side.cuda_stream)
 
     def join(self):
-        torch.cuda.current_stream().wait_stream(self._side)
+        if self.overlap == "pair":
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def join_all(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_keep = []
 
     # ---- device / dtype -------------------------------------------------------------------------
     def init_device(self, device="cuda:0", dtype=F32, seed=1234):

@@ -85,11 +85,11 @@ def main():
         if which in ("all", "conv"):
             for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
                 res = []
-                for tile in (0, 1, 2, 3):
+                for tile in (0, 1, 5, 6, 3):
                     os.environ["EMRT_CONV_TILE"] = str(tile)
                     res.append(timed(fn))
                 os.environ.pop("EMRT_CONV_TILE")
-                line += " %s auto %.1f 64x64 %.1f 128x64 %.1f 128x128 %.1f |" % (name, *res)
+                line += " %s auto %.1f 64x64 %.1f ksplit2 %.1f ksplit4 %.1f 128x128 %.1f |" % (name, *res)
         if which in ("all", "wgrad"):
             res = []
             for sp in (0, 1, 2, 4, 8, 16, 32):
