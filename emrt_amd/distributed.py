@@ -42,14 +42,15 @@ class FlatGradReducer:
     """Averages the flat gradient buffer over ranks.  `launch()` enqueues async all-reduces (one per bucket) and
     `wait()` blocks the compute stream on them; with bucket_elems >= n it is a single collective."""
 
-    def __init__(self, flat_grad, n, world_size, bucket_elems=32 * 1024 * 1024):
+    def __init__(self, flat_grad, n, world_size, bucket_elems=32 * 1024 * 1024, always=False):
         self.flat, self.n, self.world = flat_grad, n, world_size
         self.slices = bucket_slices(n, bucket_elems)
         self.handles = []
+        self.always = always        # issue the collectives even in a 1-rank group (single-GPU test of the N > 1 path)
 
     def launch(self):
         self.handles = []
-        if self.world <= 1:
+        if self.world <= 1 and not self.always:
             return
         use_avg = self.flat.is_cuda
         for s, e in self.slices:

@@ -21,7 +21,7 @@ _SEED_STRIDE = 0x2545F4914F6CDD1D
 
 class TrainEngine:
     def __init__(self, model, optimizer, loss_fn, world_size=1, use_graph=True, warmup_eager=2, bucket_elems=32 * 1024 * 1024,
-                 overlap=False):
+                 overlap=False, two_phase=None):
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.world = world_size
         self.use_graph = use_graph
@@ -33,7 +33,11 @@ class TrainEngine:
         c = ctx()
         c.world_size = world_size
         c.overlap = overlap            # False | "pair" | "deferred": wgrad on a second stream (runtime.Context.fork)
-        self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems) if world_size > 1 else None
+        # two_phase=True with world_size == 1 runs the N > 1 structure (graph A / RCCL all-reduce / graph B, per-rank BN
+        # statistics inside the capture) in a 1-rank process group: the single-GPU test of the multi-GPU path
+        self.two_phase = (world_size > 1) if two_phase is None else bool(two_phase)
+        self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems,
+                                       always=self.two_phase) if self.two_phase else None
 
     # -- pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, images, labels):
@@ -56,7 +60,7 @@ class TrainEngine:
 
     def _capture(self, images, labels):
         c = ctx()
-        c.sync_bn = self.world == 1
+        c.sync_bn = not self.two_phase
         self.images = images.clone()
         self.labels = labels.clone()
         c.workspace(64 << 20)

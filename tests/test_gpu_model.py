@@ -213,6 +213,41 @@ def test_hipgraph_replay_equals_eager():
     assert losses["graph"][-1] < losses["graph"][0], "loss should decrease on a repeated batch: %s" % losses
 
 
+def test_two_phase_dp_step_over_rccl_matches_single_graph():
+    """The N > 1 step structure -- hipGraph A (zero/fwd/loss/bwd) -> eager RCCL all-reduce(AVG) of the flat gradient
+    buffer -> hipGraph B (clip + SGD + re-pack), per-rank BatchNorm statistics inside the capture -- exercised on one GPU
+    in a 1-rank nccl process group.  Averaging over one rank is the identity, so the loss trace must equal the
+    single-graph engine's."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        g = torch.Generator().manual_seed(21)
+        B, S = 2, 64
+        x = torch.randn(B, 3, S, S, generator=g)
+        labels = torch.randint(0, 6, (B, S, S), generator=g)
+        losses = {}
+        for mode in ("single", "two_phase"):
+            ref, model = build_pair("resnet18", x)
+            cfg = make_config("resnet18", iters=100)
+            opt = get_optimizer(model, get_scheduler(cfg), cfg)
+            eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=True, warmup_eager=1, two_phase=(mode == "two_phase"),
+                              bucket_elems=4 * 1024 * 1024)
+            losses[mode] = [eng.step(x.cuda(), labels.cuda()).item() for _ in range(4)]
+            if mode == "two_phase":
+                assert eng.graph_b is not None and eng.reducer is not None and len(eng.reducer.slices) > 1
+        for a, b in zip(losses["single"], losses["two_phase"]):
+            assert abs(a - b) < 1e-3 * max(1.0, abs(a)), losses
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_bf16_path_is_sane():
     """bf16 storage / fp32 accumulate.  The random-initialised ResNet-50 amplifies bf16 rounding strongly (c4 is ~50 %
     off in relative norm for ANY bf16 implementation), so the yardstick is torch's own CPU bf16 autocast run of the
