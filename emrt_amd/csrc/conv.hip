@@ -94,8 +94,11 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // buffers and the groups' accumulators are summed through LDS before the epilogue.  Small-M layers (16x16 / 8x8 maps)
 // launch fewer blocks than there are CUs and are bound by the latency of the serial k loop: the split shortens that
 // chain G-fold with waves the CU would otherwise leave idle, without global atomics or a second pass.
+// Occupancy: the 64x64 tile without K split is what every many-block, short-K layer runs (token linears, 1x1 convs);
+// those are prologue / epilogue dominated, so it is held to 128 registers = 4 blocks per CU (measured: 180 registers, i.e.
+// 2 blocks per CU, cost 25-35 % on those shapes).
 template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G>
-__global__ __launch_bounds__(256 * G) void igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void igemm_kernel(ConvArgs p) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
@@ -170,11 +173,11 @@ __global__ __launch_bounds__(256 * G) void igemm_kernel(ConvArgs p) {
     const unsigned off = a_base[i] + (unsigned)((hi * p.W + wi) * p.ldin) * (unsigned)sizeof(T);
     return ok ? off : BUF_OOB;
   };
-  // 1x1 kernels (every linear layer, the bottleneck 1x1 convs): the pixel of a row does not depend on k
+  // The pixel of a row only changes when the tap does (never for 1x1 kernels: every linear layer, the bottleneck 1x1
+  // convs; every C / BK tiles for 3x3): its byte offset is cached and re-derived on a tap change only.  The k loop of the
+  // 64x64 tile is bound by this address arithmetic (VALU), not by the MFMAs.
+  unsigned a_cur[AR];
   const bool one_tap = p.KH * p.KW == 1;
-  unsigned a_off1[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) a_off1[i] = a_pixel(i, 0, 0);
   // loader cursor: k index / tap / channel of this thread's 16-byte chunk in the NEXT k-tile to fetch.  It keeps
   // advancing past K (the ring prefetches beyond the last tile): those chunks are all-zero.
   constexpr int KSTEP = BK * G;        // a group's consecutive tiles are G tiles apart
@@ -186,22 +189,25 @@ __global__ __launch_bounds__(256 * G) void igemm_kernel(ConvArgs p) {
     ld_kw = tap - ld_kh * p.KW;
   }
   const bool c_ge_bk = p.C >= KSTEP;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) a_cur[i] = a_pixel(i, ld_kh, ld_kw);
+  }
   auto load_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
     if constexpr (VEC) {
       const unsigned kbad = ld_kc < K ? 0u : BUF_OOB;      // OR-ing BUF_OOB into an offset < BUF_OOB puts it out of range
+      const unsigned cbytes = (unsigned)ld_c0 * (unsigned)sizeof(T), kbytes = (unsigned)ld_kc * (unsigned)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const unsigned off = (one_tap ? a_off1[i] : a_pixel(i, ld_kh, ld_kw)) | kbad;
-        ra_[i] = buf_load16(rs_in, off + (unsigned)ld_c0 * (unsigned)sizeof(T));
-      }
+      for (int i = 0; i < AR; ++i) ra_[i] = buf_load16(rs_in, (a_cur[i] | kbad) + cbytes);
 #pragma unroll
-      for (int j = 0; j < BR; ++j) rb_[j] = buf_load16(rs_w, (b_off[j] | kbad) + (unsigned)ld_kc * (unsigned)sizeof(T));
+      for (int j = 0; j < BR; ++j) rb_[j] = buf_load16(rs_w, (b_off[j] | kbad) + kbytes);
       ld_kc += KSTEP;
+      bool new_tap;
       if (c_ge_bk) {          // at most one tap boundary per step: plain selects
         ld_c0 += KSTEP;
-        const bool wrap = ld_c0 >= p.C;
-        ld_c0 -= wrap ? p.C : 0;
-        ld_kw += wrap ? 1 : 0;
+        new_tap = ld_c0 >= p.C;
+        ld_c0 -= new_tap ? p.C : 0;
+        ld_kw += new_tap ? 1 : 0;
         const bool wrap2 = ld_kw == p.KW;
         ld_kw = wrap2 ? 0 : ld_kw;
         ld_kh += wrap2 ? 1 : 0;
@@ -210,6 +216,11 @@ __global__ __launch_bounds__(256 * G) void igemm_kernel(ConvArgs p) {
         ld_c0 = ld_kc - tap * p.C;
         ld_kh = tap / p.KW;
         ld_kw = tap - ld_kh * p.KW;
+        new_tap = true;
+      }
+      if (new_tap && !one_tap) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) a_cur[i] = a_pixel(i, ld_kh, ld_kw);
       }
     } else {
       uint32_t wa[AR][4], wb[BR][4];
@@ -412,16 +423,21 @@ struct WgradCfg<float> {
   static constexpr int CPR = 32, RPP = 8, BKM = 32, PITCH = 528;
 };
 
-template <class T, bool VEC>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD = 2 blocks per CU (<= 256 registers)
+// G = 2: two groups of 4 waves per block take alternate pixel tiles of the block's range (own LDS buffers) and their
+// accumulators are summed through LDS before the atomic epilogue: half the reduction slices (fp32 atomic traffic into dW,
+// ~14 MB per launch by WRITE_SIZE) for the same number of waves.  Kept for experiments; the dispatcher uses G = 1.
+template <class T, bool VEC, int G>
+__global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD (<= 256 registers)
   using Cfg = WgradCfg<T>;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int CPR = Cfg::CPR, RPP = Cfg::RPP, BKM = Cfg::BKM, PITCH = Cfg::PITCH;
   constexpr int NST = VEC ? 3 : 1;               // pixel tiles in flight in registers (8 x 16 B each per thread)
   constexpr int STAGE_BYTES = 2 * BKM * PITCH;   // dy tile [BKM][128 oc] + x tile [BKM][128 k]
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = G == 1 ? 0 : (int)threadIdx.x >> 8;
+  unsigned char* smem = smem_all + grp * 2 * STAGE_BYTES;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = p.KH * p.KW * p.C;
   const int oc0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
@@ -475,21 +491,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {   // 2 wav
     const int OHW = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long m = mt_begin * BKM + prow + RPP * i;
+      const long long m = (mt_begin + grp) * BKM + prow + RPP * i;
       r_nb[i] = (int)(m / OHW);
       const int pix = (int)(m - (long long)r_nb[i] * OHW);
       r_oh[i] = pix / p.OW;
       r_ow[i] = pix - r_oh[i] * p.OW;
     }
   }
-  const int adv_w = BKM % p.OW, adv_q = BKM / p.OW;
+  const int adv_w = (BKM * G) % p.OW, adv_q = (BKM * G) / p.OW;      // a group's consecutive tiles are G tiles apart
   const int adv_h = adv_q % p.OH, adv_n = adv_q / p.OH;
+  int ld_t = grp;                                                   // tile (relative to mt_begin) fetched next
 
   uint4 rp[NST][4], rq[NST][4];
   auto load_tile = [&](uint4 (&rp_)[4], uint4 (&rq_)[4]) {
+    const unsigned t_bad = (G == 1 || ld_t < ntile) ? 0u : BUF_OOB;  // G > 1: the odd group may run one tile past the range
+    ld_t += G;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned m_bad = r_nb[i] < p.N ? 0u : BUF_OOB;
+      const unsigned m_bad = (r_nb[i] < p.N ? 0u : BUF_OOB) | t_bad;
       const unsigned dy_row = (unsigned)(((long long)r_nb[i] * p.dy_bs + (long long)(r_oh[i] * p.OW + r_ow[i]) * p.lddy) * (long long)sizeof(T)) | m_bad;
       const unsigned x_img = (unsigned)((long long)r_nb[i] * p.x_bs * (long long)sizeof(T)) | m_bad;
       if constexpr (VEC) {
@@ -600,28 +619,54 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p) {   // 2 wav
 
 #pragma unroll
   for (int d = 0; d < NST; ++d) load_tile(rp[d], rq[d]);
+  const int niter = (ntile + G - 1) / G;      // pixel tiles walked by each group
   int t = 0;
-  for (; t + NST <= ntile; t += NST) {
+  for (; t + NST <= niter; t += NST) {
 #pragma unroll
     for (int d = 0; d < NST; ++d) m_tile(rp[d], rq[d], (t + d) & 1, true);
   }
-  const int rem = ntile - t;
+  const int rem = niter - t;
 #pragma unroll
   for (int d = 0; d < NST - 1; ++d)
     if (d < rem) m_tile(rp[d], rq[d], (t + d) & 1, false);
-  __syncthreads();      // the bias reduction below reuses the LDS tiles
+  __syncthreads();      // the reductions below reuse the LDS tiles
 
-  if (do_bias) {      // block-level reduction over the RPP row lanes in LDS, then ONE atomic per output channel
-    float* sb = reinterpret_cast<float*>(smem);     // [RPP][128]
+  if constexpr (G > 1) {      // fold the groups' accumulators ([register][thread] in LDS) into group 0
+    float* park = reinterpret_cast<float*>(smem_all);
+    if (grp > 0) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) sb[prow * 128 + col * EPC + e] = bsum[e];
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) park[(((grp - 1) * 4 + i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+    }
     __syncthreads();
-    if (tid < 128 && oc0 + tid < p.OC) {
+    if (grp == 0) {
+#pragma unroll
+      for (int g = 1; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += park[(((g - 1) * 4 + i * 2 + j) * 16 + r) * 256 + tid];
+    }
+    __syncthreads();
+  }
+
+  if (do_bias) {      // block-level reduction over the (group, row) lanes in LDS, then ONE atomic per output channel
+    float* sb = reinterpret_cast<float*>(smem_all);     // [G * RPP][128]
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) sb[(grp * RPP + prow) * 128 + col * EPC + e] = bsum[e];
+    __syncthreads();
+    if (grp == 0 && tid < 128 && oc0 + tid < p.OC) {
       float tsum = 0.f;
-      for (int r = 0; r < RPP; ++r) tsum += sb[r * 128 + tid];
+      for (int r = 0; r < G * RPP; ++r) tsum += sb[r * 128 + tid];
       atomicAdd(p.dbias + oc0 + tid, tsum);
     }
   }
+  if (grp > 0) return;
   const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -645,7 +690,7 @@ static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   // ring depth: ~96 VGPRs of loads in flight per thread whatever the tile (16 B x (BM + BN) / 32 per stage)
   // (a 1024-thread block, G = 4, has 128 registers per thread: 4 stages)
-  constexpr int NST = VEC ? (G >= 4 ? 4 : (BM + BN) / 32 <= 4 ? 6 : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
+  constexpr int NST = VEC ? (G >= 4 ? 4 : (BM + BN) / 32 <= 4 ? (G == 1 ? 4 : 6) : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long grid = ((M + BM - 1) / BM) * ((a.OC + BN - 1) / BN);
   size_t lds = (size_t)G * 2 * (BM + BN) * 144;
@@ -744,8 +789,13 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   const int tx = (K + 127) / 128, ty = (a.OC + 127) / 128;
   const long long mt_total = (M + Cfg::BKM - 1) / Cfg::BKM;
   // Split of the pixel reduction over blockIdx.z.  Cost model fitted to tools/bench_conv.py on MI355X:
-  //   t(S) = tiles_per_block * 1 us * max(1, blocks / 1024)  +  S * |dW| / 1.3 TB/s (every slice re-adds dW atomically)
-  // i.e. a lone block needs ~1 us per pixel tile, up to ~4 blocks per CU overlap for free, fp32 atomics run at ~1.3 TB/s.
+  //   t(S) = tiles_per_block * t_tile * max(1, blocks / 1024)  +  S * |dW| / 1.3 TB/s (every slice re-adds dW atomically)
+  // i.e. a lone 4-wave group needs ~1 us per pixel tile (t_tile = 1 us / G), up to ~4 groups per CU overlap for free,
+  // fp32 atomics run at ~1.3 TB/s.
+  // wave groups per block on the vector path (wgrad_kernel).  G = 2 measured SLOWER than two independent G = 1 blocks per
+  // CU on every EMRT shape but one (coupled barriers, 160 KB of LDS per block), so 1 it is.
+  constexpr int G = 1;
+  const int gv = vec ? G : 1;
   const double atom_us = (double)tx * 128.0 * (double)ty * 128.0 * 4.0 / 1.3e6;
   long long S = 1;
   double best = 1e30;
@@ -753,8 +803,8 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
     const long long sc = cand[ci];
     if (sc > mt_total) break;
-    const double per = (double)((mt_total + sc - 1) / sc);
-    const double nblk = (double)tx * ty * sc;
+    const double per = (double)((mt_total + sc - 1) / sc) / gv;
+    const double nblk = (double)tx * ty * sc * gv;
     const double t = per * (nblk > 1024.0 ? nblk / 1024.0 : 1.0) + sc * atom_us;
     if (t < best) { best = t; S = sc; }
   }
@@ -764,16 +814,18 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   }
   a.tiles_per_split = (int)((mt_total + S - 1) / S);
   S = (mt_total + a.tiles_per_split - 1) / a.tiles_per_split;
-  const size_t lds = 2 * 2 * (size_t)Cfg::BKM * Cfg::PITCH;      // two stages of (dy tile + x tile)
+  const size_t lds = (size_t)gv * 2 * 2 * Cfg::BKM * Cfg::PITCH;      // per group: two stages of (dy tile + x tile)
   static bool attr_done = false;      // one flag per element type
-  if (!attr_done && lds > 65536) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, true, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)G * 4 * Cfg::BKM * Cfg::PITCH)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)4 * Cfg::BKM * Cfg::PITCH)) != hipSuccess)
       return fail("emrt_conv2d_wgrad", "cannot raise the dynamic LDS limit");
     attr_done = true;
   }
-  if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((wgrad_kernel<T, false>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
+  if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true, G>), dim3(tx, ty, (unsigned)S), dim3(256 * G), lds, st, a);
+  else hipLaunchKernelGGL((wgrad_kernel<T, false, 1>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
   return check_launch("emrt_conv2d_wgrad");
 }
 
