@@ -484,9 +484,13 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
   if (mt_begin >= mt_end) return;
   const int ntile = (int)(mt_end - mt_begin);
 
-  // loader cursor: (image, oh, ow) of this thread's 4 pixel rows in the NEXT tile to fetch, advanced by BKM pixels per
-  // tile with mixed-radix carries (no division in the loop).  Rows past the last image read out of range (= zeros).
+  // loader cursor: (image, oh, ow) of this thread's 4 pixel rows in the NEXT tile to fetch, advanced by BKM * G pixels per
+  // tile with mixed-radix carries, plus the running byte offsets of the dy row and of the x image (no division and no
+  // 64-bit arithmetic in the loop: this address arithmetic, not the MFMAs, bounds the loop).  Rows past the last image
+  // read out of range (= zeros).
+  constexpr unsigned ESZ = (unsigned)sizeof(T);
   int r_nb[4], r_oh[4], r_ow[4];
+  unsigned r_dy[4], r_ximg[4];
   {
     const int OHW = p.OH * p.OW;
 #pragma unroll
@@ -496,10 +500,18 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
       const int pix = (int)(m - (long long)r_nb[i] * OHW);
       r_oh[i] = pix / p.OW;
       r_ow[i] = pix - r_oh[i] * p.OW;
+      r_dy[i] = (unsigned)(((long long)r_nb[i] * p.dy_bs + (long long)pix * p.lddy) * (long long)ESZ);      // (garbage past the last image: masked)
+      r_ximg[i] = (unsigned)((long long)r_nb[i] * p.x_bs * (long long)ESZ);
     }
   }
   const int adv_w = (BKM * G) % p.OW, adv_q = (BKM * G) / p.OW;      // a group's consecutive tiles are G tiles apart
   const int adv_h = adv_q % p.OH, adv_n = adv_q / p.OH;
+  const unsigned dy_step = (unsigned)(BKM * G) * (unsigned)p.lddy * ESZ;                                    // BKM*G pixels further in a dense image
+  const unsigned dy_wrap = (unsigned)((p.dy_bs - (long long)p.OH * p.OW * p.lddy) * (long long)ESZ);        // extra per image boundary crossed
+  const unsigned x_bs_b = (unsigned)(p.x_bs * (long long)ESZ);
+  const unsigned dy_adv = dy_step + (unsigned)adv_n * dy_wrap, x_adv = (unsigned)adv_n * x_bs_b;
+  const unsigned ldx_b = (unsigned)p.ldx * ESZ, cq_b = (unsigned)cq * ESZ, ocp_b = (unsigned)ocp * ESZ;
+  const int hi0 = kh - p.pad, wi0 = kw - p.pad;
   int ld_t = grp;                                                   // tile (relative to mt_begin) fetched next
 
   uint4 rp[NST][4], rq[NST][4];
@@ -509,37 +521,38 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned m_bad = (r_nb[i] < p.N ? 0u : BUF_OOB) | t_bad;
-      const unsigned dy_row = (unsigned)(((long long)r_nb[i] * p.dy_bs + (long long)(r_oh[i] * p.OW + r_ow[i]) * p.lddy) * (long long)sizeof(T)) | m_bad;
-      const unsigned x_img = (unsigned)((long long)r_nb[i] * p.x_bs * (long long)sizeof(T)) | m_bad;
       if constexpr (VEC) {
-        rp_[i] = buf_load16(rs_dy, (dy_row | p_bad) + (unsigned)ocp * (unsigned)sizeof(T));
-        const int hi = r_oh[i] * p.stride - p.pad + kh, wi = r_ow[i] * p.stride - p.pad + kw;
+        rp_[i] = buf_load16(rs_dy, (r_dy[i] | m_bad | p_bad) + ocp_b);
+        // 24-bit multiplies (full rate): coordinates, H*W and the pixel stride in bytes are all < 2^24 (host-checked)
+        const int hi = __mul24(r_oh[i], p.stride) + hi0, wi = __mul24(r_ow[i], p.stride) + wi0;
         const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const unsigned off = x_img + (unsigned)((hi * p.W + wi) * p.ldx + cq) * (unsigned)sizeof(T);
-        rq_[i] = buf_load16(rs_x, inb ? (off | q_bad) : BUF_OOB);
+        const unsigned off = r_ximg[i] + __umul24((unsigned)(__mul24(hi, p.W) + wi), ldx_b) + cq_b;
+        rq_[i] = buf_load16(rs_x, inb ? (off | m_bad | q_bad) : BUF_OOB);
       } else {
         uint32_t wp_[4] = {0u, 0u, 0u, 0u}, wq_[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          const uint32_t vp = buf_load_elem<T>(rs_dy, (dy_row | e_pbad[e]) + (unsigned)(ocp + e) * (unsigned)sizeof(T));
+          const uint32_t vp = buf_load_elem<T>(rs_dy, (r_dy[i] | m_bad | e_pbad[e]) + (unsigned)(ocp + e) * ESZ);
           const int hi = r_oh[i] * p.stride - p.pad + e_kh[e], wi = r_ow[i] * p.stride - p.pad + e_kw[e];
           const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-          const unsigned off = x_img + (unsigned)((hi * p.W + wi) * p.ldx + e_c[e]) * (unsigned)sizeof(T);
-          const uint32_t vq = buf_load_elem<T>(rs_x, inb ? (off | e_qbad[e]) : BUF_OOB);
+          const unsigned off = r_ximg[i] + (unsigned)((hi * p.W + wi) * p.ldx + e_c[e]) * ESZ;
+          const uint32_t vq = buf_load_elem<T>(rs_x, inb ? (off | m_bad | e_qbad[e]) : BUF_OOB);
           if constexpr (sizeof(T) == 2) { wp_[e >> 1] |= vp << (16 * (e & 1)); wq_[e >> 1] |= vq << (16 * (e & 1)); }
           else { wp_[e] = vp; wq_[e] = vq; }
         }
         rp_[i] = make_uint4(wp_[0], wp_[1], wp_[2], wp_[3]);
         rq_[i] = make_uint4(wq_[0], wq_[1], wq_[2], wq_[3]);
       }
-      // advance this row by BKM pixels
+      // advance this row by BKM * G pixels
       r_ow[i] += adv_w;
       const int c1 = r_ow[i] >= p.OW ? 1 : 0;
       r_ow[i] -= c1 ? p.OW : 0;
       r_oh[i] += adv_h + c1;
       const int c2 = r_oh[i] >= p.OH ? 1 : 0;
       r_oh[i] -= c2 ? p.OH : 0;
-      r_nb[i] += adv_n + c2;
+      r_nb[i] += adv_n + c2;                     // image boundaries crossed: adv_n (+1 on a carry)
+      r_dy[i] += dy_adv + (c2 ? dy_wrap : 0u);
+      r_ximg[i] += x_adv + (c2 ? x_bs_b : 0u);
     }
   };
 
@@ -799,10 +812,11 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   const double atom_us = (double)tx * 128.0 * (double)ty * 128.0 * 4.0 / 1.3e6;
   long long S = 1;
   double best = 1e30;
-  static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  static const int cand[] = {1, 2, 4, 8, 16, 32, 64, 128};
   for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
     const long long sc = cand[ci];
     if (sc > mt_total) break;
+    if (sc > 1 && (long long)tx * ty >= 256) break;      // already one block per CU and a large dW: slices only add atomics
     const double per = (double)((mt_total + sc - 1) / sc) / gv;
     const double nblk = (double)tx * ty * sc * gv;
     const double t = per * (nblk > 1024.0 ? nblk / 1024.0 : 1.0) + sc * atom_us;
@@ -842,6 +856,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
     const long long x_ext = ((long long)(N - 1) * x_bs + ((long long)H * W - 1) * ldx + C) * esz;
     const long long dy_ext = ((long long)(N - 1) * dy_bs + ((long long)OH * OW - 1) * lddy + OC) * esz;
     EMRT_REQUIRE(x_bs >= 0 && dy_bs >= 0 && x_ext < (1ll << 31) && dy_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
+    EMRT_REQUIRE((long long)H * W < (1 << 24) && (long long)ldx * esz < (1 << 24) && stride < (1 << 12), "map too large for the 24-bit address arithmetic");
   }
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw;
