@@ -170,6 +170,15 @@ def main():
                     "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
                     "algorithmic_gflop_per_step": round(fl / 1e9, 1), "share_of_step_kernel_time": round(ms / total_ms, 3),
                     "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch"}
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot profile itself); bf16 B=8 256^2 only
+        pmc, pmc_src = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_pmc_traffic.json")
+        if os.path.exists(pmc_src) and dtype == BF16 and B == 8 and S == 256:
+            with open(pmc_src) as f:
+                pmc = json.load(f)
+            key = "igemm_kernel" if dom_name == "emrt_conv2d" else "wgrad_kernel"
+            roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
+            roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, average over the step's launches)"
+            roofline["traffic_source"] = "profiles/r1d_pmc_traffic.json: " + pmc["method"]
         esz = 2 if dtype == BF16 else 4
         enc = [(a, ms) for name, a, ms in calls if name == "emrt_msda_fwd" and (a[9].value if hasattr(a[9], "value") else a[9]) > 0]
         enc = [(a, ms) for a, ms in enc if a[10] == a[11]]     # Lq == Lv: encoder self-attention calls
@@ -182,6 +191,12 @@ def main():
                              "achieved": round(by / avg_ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": round(by / avg_ms / 1e6 / PEAK_HBM_GBPS, 4), "traffic": None,
                              "algorithmic_mbytes_per_launch": round(by / 1e6, 2), "avg_launch_us": round(1e3 * avg_ms, 2)}
+            if pmc is not None:
+                m = pmc["msda_fwd_kernel_encoder"]
+                roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)
+                roofline_msda["traffic_unit"] = ("bytes per launch, FETCH_SIZE + WRITE_SIZE as counted; the gfx950 x2 read correction "
+                                                 "(valid for 16-B/lane streams) gives the upper bound %d" % int(m["traffic_mb_corrected"] * 1e6))
+                roofline_msda["traffic_source"] = "profiles/r1d_pmc_traffic.json"
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(B, S, args.cpu_threads)
