@@ -38,6 +38,7 @@ struct MsdaArgs {
   void* dvalue_t;     // LDS path: [B][Lv][M*32] in the compute dtype, fully overwritten
   int Lv;
   int g_level[8], g_pix0[8], g_npix[8];   // scatter blocks: (level, first flat pixel, pixel count) of each LDS slab range
+  int g_npix_max;                         // largest g_npix: the per-half-wave sample records sit behind a slab of that size
 };
 
 template <class T>
@@ -109,6 +110,36 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
   Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
 }
 
+// <dout, value corner> over a lane's 8 channels.  bf16: straight from the packed 16-byte loads with v_dot2c_f32_bf16
+// (the gradient kernel is VALU-bound: unpack + fma per element cost 4x the instructions).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <class T>
+struct Dot8;
+template <>
+struct Dot8<bf16_t> {
+  typedef uint4 Raw;
+  static __device__ __forceinline__ Raw load(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ Raw zero() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ float dot(const Raw& a, const Raw& b) {
+    float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x), __builtin_bit_cast(bf16x2_t, b.x), 0.f, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y), __builtin_bit_cast(bf16x2_t, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z), __builtin_bit_cast(bf16x2_t, b.z), acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w), __builtin_bit_cast(bf16x2_t, b.w), acc, false);
+  }
+};
+template <>
+struct Dot8<float> {
+  struct Raw { float v[8]; };
+  static __device__ __forceinline__ Raw load(const float* p) { Raw r; Vec8<float>::load(p, r.v); return r; }
+  static __device__ __forceinline__ Raw zero() { Raw r; for (int e = 0; e < 8; ++e) r.v[e] = 0.f; return r; }
+  static __device__ __forceinline__ float dot(const Raw& a, const Raw& b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(a.v[e], b.v[e], acc);
+    return acc;
+  }
+};
+
 __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes that share one (q, head)
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
@@ -147,10 +178,15 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   for (int i = 0; i < LP; ++i) pr[i] *= inv;
 
   float go[8];
-  load8<T>((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8, go);
-  if (!live) {
+  typename Dot8<T>::Raw go_raw = Dot8<T>::zero();
+  if constexpr (ATOMIC_DV) {
+    load8<T>((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8, go);
+    if (!live) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) go[e] = 0.f;
+      for (int e = 0; e < 8; ++e) go[e] = 0.f;
+    }
+  } else {
+    if (live) go_raw = Dot8<T>::load((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8);
   }
 
   const T* vb = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8;
@@ -180,39 +216,47 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
       const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
       const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
       float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;   // <dout, v_corner> over this lane's 8 channels
+      if constexpr (!ATOMIC_DV) {
+        const long long o00 = (long long)y0 * W + x0;
+        if (vy0 && vx0) d00 = Dot8<T>::dot(go_raw, Dot8<T>::load(vl + o00 * a.ldv));
+        if (vy0 && vx1) d01 = Dot8<T>::dot(go_raw, Dot8<T>::load(vl + (o00 + 1) * a.ldv));
+        if (vy1 && vx0) d10 = Dot8<T>::dot(go_raw, Dot8<T>::load(vl + (o00 + W) * a.ldv));
+        if (vy1 && vx1) d11 = Dot8<T>::dot(go_raw, Dot8<T>::load(vl + (o00 + W + 1) * a.ldv));
+      } else {
       float v[8];
       if (vy0 && vx0) {
         const long long off = (long long)y0 * W + x0;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * (1.f - ly) * (1.f - lx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d00 = fmaf(go[e], v[e], d00); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d00 = fmaf(go[e], v[e], d00); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       if (vy0 && vx1) {
         const long long off = (long long)y0 * W + x0 + 1;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * (1.f - ly) * lx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d01 = fmaf(go[e], v[e], d01); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d01 = fmaf(go[e], v[e], d01); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       if (vy1 && vx0) {
         const long long off = (long long)(y0 + 1) * W + x0;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * ly * (1.f - lx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d10 = fmaf(go[e], v[e], d10); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d10 = fmaf(go[e], v[e], d10); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
       if (vy1 && vx1) {
         const long long off = (long long)(y0 + 1) * W + x0 + 1;
         load8<T>(vl + off * a.ldv, v);
         const float c = aw * ly * lx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { d11 = fmaf(go[e], v[e], d11); if (ATOMIC_DV && live) atomicAdd(gl + off * ldg + e, c * go[e]); }
+        for (int e = 0; e < 8; ++e) { d11 = fmaf(go[e], v[e], d11); if (live) atomicAdd(gl + off * ldg + e, c * go[e]); }
       }
-      d00 = quad_sum(d00); d01 = quad_sum(d01); d10 = quad_sum(d10); d11 = quad_sum(d11);
-      dA[i] = (1.f - ly) * ((1.f - lx) * d00 + lx * d01) + ly * ((1.f - lx) * d10 + lx * d11);
-      gx[i] = aw * ((1.f - ly) * (d01 - d00) + ly * (d11 - d10));
-      gy[i] = aw * ((1.f - lx) * (d10 - d00) + lx * (d11 - d01));
+      }
+      // dA, gx, gy are linear in the corner dots: combine per lane first, then 3 quad reductions instead of 4
+      dA[i] = quad_sum((1.f - ly) * ((1.f - lx) * d00 + lx * d01) + ly * ((1.f - lx) * d10 + lx * d11));
+      gx[i] = aw * quad_sum((1.f - ly) * (d01 - d00) + ly * (d11 - d10));
+      gy[i] = aw * quad_sum((1.f - lx) * (d10 - d00) + lx * (d11 - d01));
     }
   }
   // softmax backward: dlogit_i = p_i * (dA_i - sum_j p_j dA_j)
@@ -270,7 +314,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
   constexpr int LP = L * P;
   constexpr int QB = 32 / P;          // queries per half-wave iteration
   static_assert(P <= 32, "one lane per sample");
-  extern __shared__ int slab[];
+  extern __shared__ __attribute__((aligned(16))) int slab[];
   __shared__ float red[16];
   const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
   const int lev = a.g_level[blockIdx.y], pix0 = a.g_pix0[blockIdx.y], npix = a.g_npix[blockIdx.y];
@@ -298,16 +342,36 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
   const int my_qq = ch / P, my_p = ch - my_qq * P;    // this lane's (query, point) in the per-sample prologue
   const float fW = (float)W, fH = (float)H;
   const int rel0 = lstart - pix0;                      // flat index of the level's pixel (0,0) relative to the slab
+  // per-half-wave sample records (corner index + the 4 corner weights, probability and validity folded in), written by
+  // the prologue lanes and read back by all 32 lanes with broadcast LDS reads: the step loop is bound by VALU issue, and
+  // this replaces three cross-lane shuffles plus the per-lane floor / weight / validity arithmetic of every step
+  float4* rec_w = reinterpret_cast<float4*>(slab + a.g_npix_max * MSDA_SLAB_PITCH) + half * 32;
+  int* rec_f = reinterpret_cast<int*>(reinterpret_cast<float4*>(slab + a.g_npix_max * MSDA_SLAB_PITCH) + nhalf * 32) + half * 32;
   for (int q0 = half * QB; q0 < a.Lq; q0 += nhalf * QB) {
-    float sx = 0.f, sy = 0.f, pw = 0.f;
-    if (my_qq < QB && q0 + my_qq < a.Lq) {
-      const long long bq = (long long)b * a.Lq + q0 + my_qq;
-      const int smp = lev * P + my_p;
-      const float2 o = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
-      const float* refq = a.ref + (long long)b * a.ref_bs + (long long)(q0 + my_qq) * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
-      sx = (refq[0] + o.x / fW) * fW - 0.5f;
-      sy = (refq[1] + o.y / fH) * fH - 0.5f;
-      pw = a.probs[bq * (a.M * LP) + m * LP + smp];     // 0 for queries past Lq: they add nothing
+    {
+      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      int f00 = 0;
+      if (my_qq < QB && q0 + my_qq < a.Lq) {
+        const long long bq = (long long)b * a.Lq + q0 + my_qq;
+        const int smp = lev * P + my_p;
+        const float2 o = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
+        const float* refq = a.ref + (long long)b * a.ref_bs + (long long)(q0 + my_qq) * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
+        const float x = (refq[0] + o.x / fW) * fW - 0.5f;
+        const float y = (refq[1] + o.y / fH) * fH - 0.5f;
+        const float aw = a.probs[bq * (a.M * LP) + m * LP + smp];
+        const float xf = floorf(x), yf = floorf(y);
+        const float lx = x - xf, ly = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        f00 = rel0 + y0 * W + x0;          // flat pixel index relative to this block's range
+        const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+        const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+        w4.x = (vy0 && vx0 && (unsigned)f00 < (unsigned)npix) ? aw * (1.f - ly) * (1.f - lx) : 0.f;
+        w4.y = (vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix) ? aw * (1.f - ly) * lx : 0.f;
+        w4.z = (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix) ? aw * ly * (1.f - lx) : 0.f;
+        w4.w = (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix) ? aw * ly * lx : 0.f;
+      }
+      rec_w[ch] = w4;
+      rec_f[ch] = f00;
     }
     float gq[QB];
 #pragma unroll
@@ -318,22 +382,13 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int src = qq * P + p;
-        const float x = __shfl(sx, src, 32), y = __shfl(sy, src, 32), aw = __shfl(pw, src, 32);
-        const float xf = floorf(x), yf = floorf(y);
-        const float lx = x - xf, ly = y - yf;
-        const int x0 = (int)xf, y0 = (int)yf;
-        const float go = aw * gq[qq];
-        const int f00 = rel0 + y0 * W + x0;          // flat pixel index relative to this block's range
-        const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
-        const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-        if (vy0 && vx0 && (unsigned)f00 < (unsigned)npix)
-          atomicAdd(&slab[f00 * MSDA_SLAB_PITCH + ch], __float2int_rn(go * (1.f - ly) * (1.f - lx)));
-        if (vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix)
-          atomicAdd(&slab[(f00 + 1) * MSDA_SLAB_PITCH + ch], __float2int_rn(go * (1.f - ly) * lx));
-        if (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix)
-          atomicAdd(&slab[(f00 + W) * MSDA_SLAB_PITCH + ch], __float2int_rn(go * ly * (1.f - lx)));
-        if (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix)
-          atomicAdd(&slab[(f00 + W + 1) * MSDA_SLAB_PITCH + ch], __float2int_rn(go * ly * lx));
+        const float4 w4 = rec_w[src];          // same address in all 32 lanes: broadcast
+        const int f00 = rec_f[src];
+        int* cell = slab + f00 * MSDA_SLAB_PITCH + ch;
+        if (w4.x != 0.f) atomicAdd(cell, __float2int_rn(gq[qq] * w4.x));
+        if (w4.y != 0.f) atomicAdd(cell + MSDA_SLAB_PITCH, __float2int_rn(gq[qq] * w4.y));
+        if (w4.z != 0.f) atomicAdd(cell + W * MSDA_SLAB_PITCH, __float2int_rn(gq[qq] * w4.z));
+        if (w4.w != 0.f) atomicAdd(cell + (W + 1) * MSDA_SLAB_PITCH, __float2int_rn(gq[qq] * w4.w));
       }
     }
   }
@@ -345,7 +400,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
   }
 }
 
-static const int MSDA_MAX_NPIX = 1152;   // 1152 * 33 * 4 B = 152 064 B of the 160 KiB LDS
+static const int MSDA_MAX_NPIX = 1024;   // 1024 * 33 * 4 B = 135 168 B slab + 20 480 B of sample records of the 160 KiB LDS
 
 // Slab ranges: every level is cut into equal runs of whole rows, at least enough that a run fits in LDS, and more when
 // the grid would otherwise leave CUs idle (a block's work is Lq * P sample steps whatever its range size, so the largest
@@ -488,7 +543,8 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     for (int g = 0; g < ng; ++g) npix_max = a.g_npix[g] > npix_max ? a.g_npix[g] : npix_max;
     int rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
     if (rc) return rc;
-    const size_t lds = (size_t)npix_max * MSDA_SLAB_PITCH * sizeof(int);
+    a.g_npix_max = (npix_max + 3) & ~3;          // keeps the records 16-byte aligned
+    const size_t lds = (size_t)a.g_npix_max * MSDA_SLAB_PITCH * sizeof(int) + 32 * 32 * (sizeof(float4) + sizeof(int));
     return dtype == EMRT_F32 ? msda_launch_lds<float>(a, L, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, L, P, ng, lds, st);
   }
   a.dvalue = (float*)dvalue;
