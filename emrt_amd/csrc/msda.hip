@@ -13,6 +13,7 @@
 // fetch one contiguous 64/128-byte head slice.  HBM-compulsory bytes are tiny; the kernel is
 // bound by L2/TA gather throughput, which is why value stays L2-resident across the B*M slabs.
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace emrt;
 
@@ -28,6 +29,7 @@ struct MsdaArgs {
   void* out;
   int B, Lq, M;
   int h[4], w[4], start[4];
+  float inv_h[4], inv_w[4];   // 1/H_l, 1/W_l: the offset normalisation off / (W, H) as a multiply (exact for power-of-two maps)
   // backward only
   const void* dout;
   float* dvalue;      // fp32 [B][Lv][M*32] dense, accumulated with atomics (caller zeroes)
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const float2 o = *reinterpret_cast<const float2*>(offp + (l * P + p) * 2);
-      const float x = (rx + o.x / (float)W) * (float)W - 0.5f;
-      const float y = (ry + o.y / (float)H) * (float)H - 0.5f;
+      const float x = (rx + o.x * a.inv_w[l]) * (float)W - 0.5f;
+      const float y = (ry + o.y * a.inv_h[l]) * (float)H - 0.5f;
       const float xf = floorf(x), yf = floorf(y);
       const float lx = x - xf, ly = y - yf;
       const int x0 = (int)xf, y0 = (int)yf;
@@ -108,6 +110,84 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
     }
   }
   Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
+}
+
+// Forward with the (batch, head) value slab staged in LDS: one block per (batch, head, chunk of queries).  The global
+// kernel above gathers 64-byte head slices from L2 (396 MB of L2->CU traffic per encoder call for 5.5 MB of value); here
+// every block copies its head's [Lv][32] slab once (rows padded to 80 B so that random pixels spread over the banks) and
+// the 4 x 18 corner reads of a query are ds_read_b128.  Same arithmetic in the same order as msda_fwd_kernel, so the two
+// are bit-identical.  Used when the slab fits (bf16 up to Lv = 1894, i.e. 256^2 tiles; fp32 maps fall back).
+#define MSDA_FWD_PITCH 80        /* bytes per LDS row: 64 B of bf16 data + 16 B pad */
+template <class T, int L, int P>
+__global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_per_block) {
+  static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
+  constexpr int LP = L * P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vslab[];
+  const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
+  {
+    const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32;
+    for (int i = threadIdx.x; i < a.Lv * 4; i += blockDim.x) {
+      const int pix = i >> 2, part = i & 3;
+      *reinterpret_cast<uint4*>(vslab + pix * MSDA_FWD_PITCH + part * 16) = *reinterpret_cast<const uint4*>(src + (long long)pix * a.ldv + part * 8);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3;
+  const int q_begin = blockIdx.y * q_per_block;
+  int q_end = q_begin + q_per_block;
+  if (q_end > a.Lq) q_end = a.Lq;
+  for (int q = q_begin + wave * 16 + (lane >> 2); q < q_end; q += 16 * 16) {
+    const long long bq = (long long)b * a.Lq + q;
+    const float* row = a.offw + bq * a.ldo;
+    const float* offp = row + m * LP * 2;
+    const float* logp = row + a.M * LP * 2 + m * LP;
+    float lg[LP];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { lg[i] = logp[i]; mx = fmaxf(mx, lg[i]); }
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
+    const float inv = 1.f / den;
+    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2;
+    const int rls = a.ref_L == 1 ? 0 : 2;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = a.h[l], W = a.w[l];
+      const float rx = refp[l * rls], ry = refp[l * rls + 1];
+      const unsigned char* vl = vslab + a.start[l] * MSDA_FWD_PITCH + sub * 16;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float2 o = *reinterpret_cast<const float2*>(offp + (l * P + p) * 2);
+        const float x = (rx + o.x * a.inv_w[l]) * (float)W - 0.5f;
+        const float y = (ry + o.y * a.inv_h[l]) * (float)H - 0.5f;
+        const float xf = floorf(x), yf = floorf(y);
+        const float lx = x - xf, ly = y - yf;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float aw = lg[l * P + p] * inv;
+        const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+        const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+        float v[8];
+        const unsigned char* p00 = vl + (y0 * W + x0) * MSDA_FWD_PITCH;
+        if (vy0 && vx0) { load8<T>(reinterpret_cast<const T*>(p00), v); const float c = aw * (1.f - ly) * (1.f - lx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+        if (vy0 && vx1) { load8<T>(reinterpret_cast<const T*>(p00 + MSDA_FWD_PITCH), v); const float c = aw * (1.f - ly) * lx;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+        if (vy1 && vx0) { load8<T>(reinterpret_cast<const T*>(p00 + W * MSDA_FWD_PITCH), v); const float c = aw * ly * (1.f - lx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+        if (vy1 && vx1) { load8<T>(reinterpret_cast<const T*>(p00 + (W + 1) * MSDA_FWD_PITCH), v); const float c = aw * ly * lx;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
+      }
+    }
+    Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
+  }
 }
 
 // <dout, value corner> over a lane's 8 channels.  bf16: straight from the packed 16-byte loads with v_dot2c_f32_bf16
@@ -207,8 +287,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
     for (int p = 0; p < P; ++p) {
       const int i = l * P + p;
       const float2 o = *reinterpret_cast<const float2*>(offp + i * 2);
-      const float x = (rx + o.x / (float)W) * (float)W - 0.5f;
-      const float y = (ry + o.y / (float)H) * (float)H - 0.5f;
+      const float x = (rx + o.x * a.inv_w[l]) * (float)W - 0.5f;
+      const float y = (ry + o.y * a.inv_h[l]) * (float)H - 0.5f;
       const float xf = floorf(x), yf = floorf(y);
       const float lx = x - xf, ly = y - yf;
       const int x0 = (int)xf, y0 = (int)yf;
@@ -340,7 +420,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
   const int ch = threadIdx.x & 31;
   const int half = threadIdx.x >> 5, nhalf = blockDim.x >> 5;
   const int my_qq = ch / P, my_p = ch - my_qq * P;    // this lane's (query, point) in the per-sample prologue
-  const float fW = (float)W, fH = (float)H;
+  const float fW = (float)W, fH = (float)H, ifW = 1.f / fW, ifH = 1.f / fH;
   const int rel0 = lstart - pix0;                      // flat index of the level's pixel (0,0) relative to the slab
   // per-half-wave sample records (corner index + the 4 corner weights, probability and validity folded in), written by
   // the prologue lanes and read back by all 32 lanes with broadcast LDS reads: the step loop is bound by VALU issue, and
@@ -356,8 +436,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
         const int smp = lev * P + my_p;
         const float2 o = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
         const float* refq = a.ref + (long long)b * a.ref_bs + (long long)(q0 + my_qq) * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
-        const float x = (refq[0] + o.x / fW) * fW - 0.5f;
-        const float y = (refq[1] + o.y / fH) * fH - 0.5f;
+        const float x = (refq[0] + o.x * ifW) * fW - 0.5f;
+        const float y = (refq[1] + o.y * ifH) * fH - 0.5f;
         const float aw = a.probs[bq * (a.M * LP) + m * LP + smp];
         const float xf = floorf(x), yf = floorf(y);
         const float lx = x - xf, ly = y - yf;
@@ -486,10 +566,12 @@ static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t 
 
 static int msda_fill(MsdaArgs& a, const int* shapes_hw, int L, int Lv) {
   int start = 0;
-  for (int l = 0; l < 4; ++l) { a.h[l] = 1; a.w[l] = 1; a.start[l] = 0; }
+  for (int l = 0; l < 4; ++l) { a.h[l] = 1; a.w[l] = 1; a.start[l] = 0; a.inv_h[l] = 1.f; a.inv_w[l] = 1.f; }
   for (int l = 0; l < L; ++l) {
     a.h[l] = shapes_hw[2 * l];
     a.w[l] = shapes_hw[2 * l + 1];
+    a.inv_h[l] = 1.f / (float)a.h[l];
+    a.inv_w[l] = 1.f / (float)a.w[l];
     a.start[l] = start;
     start += a.h[l] * a.w[l];
   }
@@ -511,6 +593,27 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   a.B = B; a.Lq = Lq; a.M = M;
   EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
   hipStream_t st = (hipStream_t)stream;
+  a.Lv = Lv;
+  const size_t slab = (size_t)Lv * MSDA_FWD_PITCH;
+  if (dtype == EMRT_BF16 && slab <= 150 * 1024 && (long long)B * M * Lq >= 8192 && !getenv("EMRT_MSDA_FWD_GLOBAL")) {       // LDS-staged slab (see msda_fwd_lds_kernel)
+    int chunks = (512 + B * M - 1) / (B * M);                  // ~2 blocks per CU
+    if (chunks > (Lq + 255) / 256) chunks = (Lq + 255) / 256;  // at least one 256-query pass per block
+    if (chunks < 1) chunks = 1;
+    const int qpb = (Lq + chunks - 1) / chunks;
+    chunks = (Lq + qpb - 1) / qpb;
+#define MSDA_FWD_LDS_CASE(LL, PP)                                                                                         \
+    if (L == LL && P == PP) {                                                                                           \
+      static bool attr = false;                                                                                         \
+      if (!attr) { (void)hipFuncSetAttribute((const void*)msda_fwd_lds_kernel<bf16_t, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
+      hipLaunchKernelGGL((msda_fwd_lds_kernel<bf16_t, LL, PP>), dim3(B * M, chunks), dim3(1024), slab, st, a, qpb);       \
+      return check_launch("emrt_msda_fwd(lds)");                                                                        \
+    }
+    MSDA_FWD_LDS_CASE(3, 6)
+    MSDA_FWD_LDS_CASE(4, 4)
+    MSDA_FWD_LDS_CASE(3, 4)
+    MSDA_FWD_LDS_CASE(1, 4)
+#undef MSDA_FWD_LDS_CASE
+  }
   return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 0, st) : msda_launch<bf16_t>(a, L, P, 0, st);
 }
 
