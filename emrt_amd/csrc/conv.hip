@@ -40,6 +40,12 @@ struct ConvArgs {
   int relu, out_f32;
   double* stats;   // optional [8][2*OC]: per-channel sum / sum of squares of the STORED outputs (BatchNorm statistics);
                    // fp64 atomics spread over 8 replicas (by M-tile index) so that blocks do not pile onto one address
+  // optional ReLU mask: outputs are zeroed where mask_y <= 0 (same geometry as the output, own strides), and with it the
+  // statistics become (sum v, sum v * mask_y).  dgrad of a conv whose input is y = relu(BatchNorm(x)) uses it to produce
+  // the masked dy AND that BatchNorm's backward sums in one pass: where y > 0, xhat = (y - beta) / gamma.
+  const void* mask_y;
+  int ldy;
+  long long y_bs;
 };
 
 template <class T>
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Rows are visited in
   // increasing order, so (image, pixel) is carried along instead of divided out per row.
   const T* resp = (const T*)p.res;
+  const T* ymask = (const T*)p.mask_y;
   float st_s[TN], st_q[TN];
   float bias_v[TN];
 #pragma unroll
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
       if (m_cur >= M) continue;
       const long long obase = (long long)e_nb * p.out_bs + (long long)e_pix * p.ldout;
       const long long rbase = (long long)e_nb * p.res_bs + (long long)e_pix * p.ldres;
+      const long long ybase = (long long)e_nb * p.y_bs + (long long)e_pix * p.ldy;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = bn * BN + (wc * TN + j) * 32 + frow;
@@ -367,6 +375,11 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
         float v = acc[i][j][r] + bias_v[j];
         if (resp) v += to_f32(resp[rbase + n]);
         if (p.relu) v = fmaxf(v, 0.f);
+        float second = 0.f;              // what the second statistic multiplies v with
+        if (ymask) {
+          second = to_f32(ymask[ybase + n]);
+          v = second > 0.f ? v : 0.f;
+        }
         if (p.out_f32) ((float*)p.out)[obase + n] = v;
         else {
           const T q = from_f32<T>(v);
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
           v = to_f32(q);                 // statistics of what the next kernel will actually read
         }
         st_s[j] += v;
-        st_q[j] = fmaf(v, v, st_q[j]);
+        st_q[j] = fmaf(v, ymask ? second : v, st_q[j]);
       }
     }
   }
@@ -762,7 +775,8 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
                            int OH, int OW, int OC, int ldout, long long out_bs,
                            int ldres, long long res_bs,
                            int KH, int KW, int stride, int pad,
-                           int mode, int relu, int out_f32, double* bn_stats, int dtype, void* stream) {
+                           int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
+                           int dtype, void* stream) {
   EMRT_REQUIRE(in && w_packed && out, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
@@ -785,6 +799,8 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
+  a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs;
+  EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
   return mode == 0 ? conv_dispatch<bf16_t, 0>(a, st) : conv_dispatch<bf16_t, 1>(a, st);

@@ -115,6 +115,27 @@ __global__ __launch_bounds__(256) void bn_sum_partials_kernel(const float* __res
   }
 }
 
+// partial[nblk][2][C] -> dbeta[c] += column sums of slot 0, dgamma[c] += column sums of slot 1 (either may be null):
+// bn_sum_partials + bn_bwd_finalize in one launch for the callers that do not need the sums afterwards.
+__global__ __launch_bounds__(256) void partials_acc_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  __shared__ double red[8][33];
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double s = 0.0;
+  if (c < 2 * C)
+    for (int b = py; b < nblk; b += 8) s += (double)partial[(long long)b * 2 * C + c];
+  red[py][cx] = s;
+  __syncthreads();
+  if (py == 0 && c < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    if (c < C) { if (dbeta) dbeta[c] += (float)t; }
+    else if (dgamma) dgamma[c - C] += (float)t;
+  }
+}
+
 // BN backward finalize: sums[2][C] = (sum dy', sum dy'*xhat) -> dgamma += , dbeta +=   (sums kept for dx)
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,13 +236,18 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const double* __restrict__ sums, const double* __restrict__ lsums,
                                                         double inv_count, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        long long M, int C, int rows_per_pass) {
+                                                        long long M, int C, int rows_per_pass, const float* __restrict__ beta_y) {
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
   extern __shared__ float bn_lds[];          // [2][C]: sum_dy/count, sum_dyxhat/count
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-    const double t0 = rep_sum(sums, C, ch), t1 = rep_sum(sums, C, C + ch);
+    const double t0 = rep_sum(sums, C, ch);
+    double t1 = rep_sum(sums, C, C + ch);
+    if (beta_y) {      // the sums are (sum dy', sum dy' * y) from the consumer's dgrad epilogue: xhat = (y - beta) / gamma where y > 0
+      const double gm = (double)gamma[ch];
+      t1 = gm != 0.0 ? (t1 - (double)beta_y[ch] * t0) / gm : 0.0;
+    }
     bn_lds[ch] = (float)(t0 * inv_count);
     bn_lds[C + ch] = (float)(t1 * inv_count);
     if (blockIdx.x == 0) {
@@ -657,18 +683,20 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
 
 // BN backward step 2: dx (and optional dres = masked dy); dgamma += , dbeta += from `local_sums` when given (SyncBN: the
 // dx formula uses the rank-summed `sums` with the global count, the parameter gradients use this rank's sums) else from `sums`.
+// beta_y_moments != null: `sums` hold (sum dy', sum dy' * y) as accumulated by emrt_conv2d(mask_y = y) -- the dgrad of the
+// conv that consumes y = relu(BN(x)) -- and are converted with xhat = (y - beta) / gamma; emrt_bn_bwd_reduce is then not needed.
 extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
                               void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
                               const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M,
-                              int C, int dtype, void* stream) {
+                              int C, const float* beta_y_moments, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
   int threads, rpp, grid;
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp),
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp));
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments));
   return check_launch("emrt_bn_bwd_dx");
 }
 
@@ -705,12 +733,10 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  float* sums = partial + (size_t)gx * 2 * C;
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr),
             hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gx, C, sums);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, (float*)nullptr, dbias);
+  hipLaunchKernelGGL(partials_acc_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, gx, C, (float*)nullptr, dbias);   // slot 0 only
   return check_launch("emrt_colsum_acc");
 }
 
@@ -793,13 +819,11 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   rpb = (rpb + 3) / 4 * 4;
   blocks = (rows + rpb - 1) / rpb;
   float* partial = (float*)workspace;
-  float* sums = partial + (size_t)blocks * 2 * C;
   const size_t lds = (size_t)8 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb),
             hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb));
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, sums);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+  hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }

@@ -289,8 +289,10 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     if residual is not None:
         _, _, _, _, ldres, res_bs = _check_map(residual)
     _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
-              OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), c.dtype, c.stream)
+              OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), None, 0, 0,
+              c.dtype, c.stream)
     tape = c.tape
+    bn_rec = getattr(x, "_bn_rec", None)      # x = relu(BatchNorm(.)) fresh from batch_norm(): see the dgrad call below
     if tape is not None:
         def bwd():
             dy = tape.pop_grad(out)
@@ -311,8 +313,17 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                       w.KH, w.KW, stride, pad, P(w.bias_grad) if w.bias is not None else None, c.dtype, side or c.stream)
             if need_dx:
                 dx = c.empty(tuple(x.shape))
+                ysums = ymask = None
+                if bn_rec is not None and c.training:
+                    # dgrad also applies that BatchNorm's ReLU mask and accumulates its backward sums (sum dy', sum dy'*y):
+                    # the BatchNorm's own reduction pass is skipped when this turns out to be its only gradient
+                    ysums = c.zeros_f64(BN_REPLICAS * 2 * C)
+                    ymask = x
                 _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
-                          H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, None, c.dtype, c.stream)
+                          H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
+                          in_bs if ymask is not None else 0, c.dtype, c.stream)
+                if ymask is not None:
+                    bn_rec["dx"], bn_rec["sums"] = dx, ysums
             if side is not None:
                 c.join()
             if residual is not None:
@@ -390,28 +401,39 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
         _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, None, 1.0, bn.eps, bn.momentum, None, None,
                   P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     tape = c.tape
+    rec = None
+    if tape is not None and c.training and relu and residual is None and out.dim() == 4:
+        # lets a conv that consumes this tensor fold the backward reduction into its dgrad (functional.conv2d)
+        rec = {"dx": None, "sums": None}
+        out._bn_rec = rec
     if tape is not None:
         assert c.training, "backward through eval-mode BatchNorm is not supported"
 
         def bwd():
-            dy = tape.pop_grad(out)
+            dy, ncontrib = tape.pop_grad(out, with_count=True)
             if dy is None:
                 return
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             assert dy_bs == H * W * lddy
-            sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
             yv = out if relu else None
-            _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), c.dtype, c.stream)
+            sync = bn.sync and c.world_size > 1 and c.sync_bn
+            # the consumer conv's dgrad already produced the sums when its dx is the one and only gradient of `out`
+            fused = rec is not None and ncontrib == 1 and rec["dx"] is dy and not sync
+            if fused:
+                sums2 = rec["sums"]
+            else:
+                sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
+                _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), c.dtype, c.stream)
             # dgamma/dbeta use the LOCAL sums (the gradient all-reduce combines ranks); dx needs the GLOBAL sums
             local = None
-            if bn.sync and c.world_size > 1 and c.sync_bn:
+            if sync:
                 local = c.empty((BN_REPLICAS * 2 * C,), torch.float64)
                 _L().call("emrt_cast", P(sums2), P(local), BN_REPLICAS * 4 * C, 0, F32, c.stream)     # raw 8-byte copy as 2 x f32
                 _allreduce_sums(sums2, M)
             dx = c.empty(tuple(x.shape))
             dres = c.empty(tuple(x.shape)) if (residual is not None and relu) else None
             _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
-                      P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C, c.dtype, c.stream)
+                      P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C, P(bn.beta) if fused else None, c.dtype, c.stream)
             tape.add_grad(x, dx, owned=True)
             if residual is not None:
                 tape.add_grad(residual, dres if dres is not None else dy, owned=dres is not None)

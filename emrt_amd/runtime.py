@@ -52,10 +52,15 @@ class Tape:
         e = self.grads.get(id(t))
         return None if e is None else e[0]
 
-    def pop_grad(self, t):
+    def pop_grad(self, t, with_count=False):
+        """Gradient accumulated for t (None if none).  with_count=True -> (gradient, number of contributions it sums; 0 for
+        views, whose gradient lives in a slice of their base)."""
         if id(t) in self.alias:
-            return self.grad(t)
+            g = self.grad(t)
+            return (g, 0) if with_count else g
         e = self.grads.pop(id(t), None)
+        if with_count:
+            return (None, 0) if e is None else (e[0], e[2])
         return None if e is None else e[0]
 
     def _own(self, t):
@@ -83,7 +88,7 @@ class Tape:
                 root = self.alias[id(root)][0]
             if id(root) not in self.grads:
                 self.keep.append(root)
-                self.grads[id(root)] = [ctx().zeros(tuple(root.shape), g.dtype), True]
+                self.grads[id(root)] = [ctx().zeros(tuple(root.shape), g.dtype), True, 0]
             else:
                 self._own(root)
             Fn.add_into(self.grad(t), g)
@@ -93,8 +98,10 @@ class Tape:
             g = g.reshape(t.shape)
         if e is None:
             self.keep.append(t)
-            self.grads[id(t)] = [g, bool(owned)]
-        elif e[1]:
+            self.grads[id(t)] = [g, bool(owned), 1]
+            return
+        e[2] += 1
+        if e[1]:
             Fn.add_into(e[0], g)
         elif owned:
             Fn.add_into(g, e[0])

@@ -39,7 +39,7 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * mode 1: data gradient; `in` is dY (N,H,W,C = its dims), out is dX (OH,OW,OC), w_packed = [Cin][KH][KW][Cout].
  * bn_stats (nullable): fp64 [8][2*OC] (8 replicas, see BatchNorm below), pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
  * (the BatchNorm statistics of the layer that follows, fused so the activation is not re-read). */
-int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, int dtype, void* stream);
+int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream);
 
@@ -52,7 +52,7 @@ size_t emrt_colreduce_workspace_bytes(long long M, int C);
 int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream);
 int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
 int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, int dtype, void* stream);
-int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, int dtype, void* stream);
+int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
 

@@ -188,6 +188,55 @@ def test_batch_norm_train(dtype, shape, relu, with_res):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, True), (2, 12, 12, 256, 128, 1, 0, True), (2, 16, 16, 64, 64, 3, 1, False)])
+def test_bn_relu_conv_chain_backward_fused_in_dgrad(dtype, case):
+    """x -> BatchNorm -> ReLU -> conv: the conv's dgrad applies the ReLU mask and accumulates the BatchNorm's backward sums
+    (sum dy', sum dy'*y; xhat = (y - beta) / gamma where y > 0), so emrt_bn_bwd_reduce is not launched.  With a second
+    consumer of the BatchNorm output (sole=False) the separate reduction must be used and give the same answer."""
+    from emrt_amd import _lib
+    N, H, W, C, OC, k, pad, sole = case
+    c = init(dtype)
+    g = torch.Generator().manual_seed(31)
+    x = rnd(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.2)
+    bn = hnn.BatchNorm2D(C)
+    conv = hnn.Conv2D(C, OC, k, 1, pad, bias=False)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        conv.weight.copy_(rnd(torch.randn(OC, C, k, k, generator=g) / math.sqrt(C * k * k)))
+    gam, bet, wref = bn.weight.detach().clone(), bn.bias.detach().clone(), conv.weight.detach().clone()
+    Holder(bn=bn, conv=conv).place()
+    xr = x.clone().requires_grad_(True)
+    gr, br_, wr = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True), wref.clone().requires_grad_(True)
+    yb = F.relu(F.batch_norm(xr, None, None, gr, br_, True, 0.1, 1e-5))
+    o = F.conv2d(yb, wr, None, padding=pad)
+    dy = rnd(torch.randn(o.shape, generator=g))
+    extra = rnd(torch.randn(yb.shape, generator=g)) if not sole else None
+    loss = (o * dy).sum() + ((yb * extra).sum() if extra is not None else 0.0)
+    loss.backward()
+
+    xd = dev_map(x)
+    tape = Tape()
+    c.tape = tape
+    yd = bn(xd, relu=True)
+    od = conv(yd)
+    c.tape = None
+    tape.watch(xd)
+    L = _lib.lib()
+    L.start_record()
+    grads = [(od, dev_map(dy))] + ([(yd, dev_map(extra))] if extra is not None else [])
+    dx, = run_bwd(tape, grads, [xd])
+    names = [n for n, _ in L.stop_record()]
+    assert ("emrt_bn_bwd_reduce" in names) == (not sole), names
+    sc = math.sqrt(N * H * W)
+    ksc = math.sqrt(OC * k * k)
+    close("chain dx", host_map(dx), xr.grad, dtype, 2.0 * ksc * (1.0 if dtype == F32 else 0.3))
+    close("chain dgamma", host(bn.weight.grad), gr.grad, dtype, sc * ksc * (1.0 if dtype == F32 else 0.5))
+    close("chain dbeta", host(bn.bias.grad), br_.grad, dtype, sc * ksc * (1.0 if dtype == F32 else 0.5))
+    close("chain dw", host(conv.weight.grad), wr.grad, dtype, sc * (1.0 if dtype == F32 else 0.3))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_batch_norm_eval_and_slice_output(dtype):
     c = init(dtype)
     c.training = False

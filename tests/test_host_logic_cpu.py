@@ -63,8 +63,17 @@ def test_train_step_launch_sequence(fake, backbone):
     assert n_fwd > n_eval                                              # training adds dropout / statistics launches
     assert cnt["emrt_conv2d_wgrad"] == len(st.gemms)                   # every GEMM weight gets exactly one wgrad
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
-    assert cnt["emrt_bn_apply"] == cnt["emrt_bn_bwd_reduce"] == cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
-    assert sum(1 for n, a in fake.calls if n == "emrt_conv2d" and a[25] is not None) == n_bn     # statistics fused into the conv epilogue
+    assert cnt["emrt_bn_apply"] == cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
+    fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
+    dgrads = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 1]
+    assert sum(1 for a in fwd_convs if a[25] is not None) == n_bn     # forward statistics fused into the conv epilogue
+    # BatchNorm -> ReLU -> conv chains: the conv's dgrad carries the ReLU mask and the BatchNorm's backward sums, and the
+    # separate reduction pass only remains for the other BatchNorms (residual joins, multi-consumer outputs, no ReLU)
+    n_fused = sum(1 for a in dgrads if a[26] is not None)
+    assert all((a[25] is not None) == (a[26] is not None) for a in dgrads)
+    fused_dx = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[20] is not None)
+    assert fused_dx + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_dx <= n_fused
+    assert fused_dx >= n_bn // 3, (fused_dx, n_bn)
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
     assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14 and cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 15
     assert cnt["emrt_softmax_ce_fwd"] == cnt["emrt_softmax_ce_bwd"] == 2
