@@ -59,8 +59,8 @@ def msda_bytes(a, esz):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="tiles per GPU (BASELINE config: 8)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])

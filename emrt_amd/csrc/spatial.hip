@@ -629,3 +629,112 @@ extern "C" int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H
   else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W);
   return check_launch("emrt_nchw_to_nhwc");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window inference glue (reference: src/api/infer.py:22-80, 145-155): crop the windows of one image into a
+// batch, accumulate the windows' logits with a hit count, normalise, argmax.  fp32 NCHW throughout, as the reference.
+// ------------------------------------------------------------------------------------------------
+#define EMRT_MAX_WINDOWS 64
+struct WindowArgs {
+  int n, C, H, W, ch, cw;
+  int y0[EMRT_MAX_WINDOWS], x0[EMRT_MAX_WINDOWS];
+};
+
+__global__ __launch_bounds__(256) void crop_windows_kernel(const float* __restrict__ img, float* __restrict__ batch, WindowArgs a) {
+  const long long total = (long long)a.n * a.C * a.ch * a.cw;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % a.cw);
+    long long r = idx / a.cw;
+    const int y = (int)(r % a.ch); r /= a.ch;
+    const int c = (int)(r % a.C);
+    const int j = (int)(r / a.C);
+    batch[idx] = img[((long long)c * a.H + a.y0[j] + y) * a.W + a.x0[j] + x];
+  }
+}
+
+// one thread per image pixel and class: sums the windows that cover it (any overlap pattern, deterministic order)
+__global__ __launch_bounds__(256) void window_accumulate_kernel(const float* __restrict__ logits, float* __restrict__ final,
+                                                                float* __restrict__ count, WindowArgs a) {
+  const long long total = (long long)a.C * a.H * a.W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % a.W);
+    long long r = idx / a.W;
+    const int y = (int)(r % a.H);
+    const int c = (int)(r / a.H);
+    float s = 0.f, k = 0.f;
+    for (int j = 0; j < a.n; ++j) {
+      const int yy = y - a.y0[j], xx = x - a.x0[j];
+      if ((unsigned)yy < (unsigned)a.ch && (unsigned)xx < (unsigned)a.cw) {
+        s += logits[(((long long)j * a.C + c) * a.ch + yy) * a.cw + xx];
+        k += 1.f;
+      }
+    }
+    final[idx] += s;
+    if (c == 0) count[(long long)y * a.W + x] += k;
+  }
+}
+
+__global__ __launch_bounds__(256) void window_normalise_kernel(const float* __restrict__ final, const float* __restrict__ count,
+                                                               float* __restrict__ out, int C, long long HW) {
+  const long long total = (long long)C * HW;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x)
+    out[idx] = final[idx] / count[idx % HW];        // uncovered pixels: 0/0 = NaN, exactly as the reference (infer.py:79)
+}
+
+// argmax over the class axis of fp32 [N][C][H][W]; first maximum wins, a NaN counts as the maximum (torch / paddle)
+__global__ __launch_bounds__(256) void argmax_nchw_kernel(const float* __restrict__ logits, int* __restrict__ pred, int N, int C, long long HW) {
+  const long long total = (long long)N * HW;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long n = idx / HW, p = idx - n * HW;
+    const float* lp = logits + n * C * HW + p;
+    float best = lp[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = lp[(long long)c * HW];
+      if (best == best && (v > best || v != v)) { best = v; bi = c; }
+    }
+    pred[idx] = bi;
+  }
+}
+
+static int fill_windows(WindowArgs& a, const int* origins_yx, int n, int C, int H, int W, int ch, int cw) {
+  if (n < 1 || n > EMRT_MAX_WINDOWS) return -1;
+  a.n = n; a.C = C; a.H = H; a.W = W; a.ch = ch; a.cw = cw;
+  for (int j = 0; j < n; ++j) {
+    a.y0[j] = origins_yx[2 * j];
+    a.x0[j] = origins_yx[2 * j + 1];
+    if (a.y0[j] < 0 || a.x0[j] < 0 || a.y0[j] + ch > H || a.x0[j] + cw > W) return -1;
+  }
+  return 0;
+}
+
+extern "C" int emrt_crop_windows(const float* img, float* batch, const int* origins_yx /*host, [n][2]*/, int n, int C, int H, int W,
+                                 int ch, int cw, void* stream) {
+  EMRT_REQUIRE(img && batch && origins_yx, "null pointer");
+  WindowArgs a;
+  EMRT_REQUIRE(fill_windows(a, origins_yx, n, C, H, W, ch, cw) == 0, "1..64 windows inside the image");
+  hipLaunchKernelGGL(crop_windows_kernel, dim3(ew_grid((long long)n * C * ch * cw)), dim3(256), 0, (hipStream_t)stream, img, batch, a);
+  return check_launch("emrt_crop_windows");
+}
+
+extern "C" int emrt_window_accumulate(const float* logits, float* final, float* count, const int* origins_yx /*host*/, int n, int C,
+                                      int H, int W, int ch, int cw, void* stream) {
+  EMRT_REQUIRE(logits && final && count && origins_yx, "null pointer");
+  WindowArgs a;
+  EMRT_REQUIRE(fill_windows(a, origins_yx, n, C, H, W, ch, cw) == 0, "1..64 windows inside the image");
+  hipLaunchKernelGGL(window_accumulate_kernel, dim3(ew_grid((long long)C * H * W)), dim3(256), 0, (hipStream_t)stream, logits, final, count, a);
+  return check_launch("emrt_window_accumulate");
+}
+
+extern "C" int emrt_window_normalise(const float* final, const float* count, float* out, int C, int H, int W, void* stream) {
+  EMRT_REQUIRE(final && count && out, "null pointer");
+  hipLaunchKernelGGL(window_normalise_kernel, dim3(ew_grid((long long)C * H * W)), dim3(256), 0, (hipStream_t)stream, final, count, out, C,
+                     (long long)H * W);
+  return check_launch("emrt_window_normalise");
+}
+
+extern "C" int emrt_argmax_nchw(const float* logits, int* pred, int N, int C, int H, int W, void* stream) {
+  EMRT_REQUIRE(logits && pred && C >= 1, "bad arguments");
+  hipLaunchKernelGGL(argmax_nchw_kernel, dim3(ew_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, N, C, (long long)H * W);
+  return check_launch("emrt_argmax_nchw");
+}

@@ -1,8 +1,9 @@
 """Sliding-window / single-scale inference (reference: src/api/infer.py:22-80 slide_inference, :82-157 ss_inference).
 
 Windows of one image are gathered into ONE batch per model call (the reference issues one call per window position);
-logit accumulation / count normalisation / final resize + argmax follow the reference exactly.  Host-side control only:
-the per-window arithmetic is the model's HIP forward; the final bilinear resize runs through the HIP resize kernel.
+logit accumulation / count normalisation / argmax follow the reference exactly and run as HIP kernels.  The only torch op
+left is the bilinear resize of the logits when the network output size differs from `ori_shape` (never the case for
+the EMRT configs, whose tiles are evaluated at their own size).
 """
 import torch
 
@@ -29,21 +30,33 @@ def window_grid(h, w, crop_size, stride_size):
 
 
 def slide_inference(model, imgs, crop_size, stride_size, num_classes, max_batch=32):
-    """imgs: list of fp32 [3, h, w] device tensors -> list of [1, ncls, h, w] fp32 logits (infer.py:22-80)."""
+    """imgs: list of fp32 [3, h, w] device tensors -> list of [1, ncls, h, w] fp32 logits (infer.py:22-80).
+    Windows are cropped into one batch per model call and their logits accumulated / counted / normalised by HIP kernels
+    (emrt_crop_windows, emrt_window_accumulate, emrt_window_normalise): no torch arithmetic on the path."""
+    import ctypes
+    L, c = Fn._L(), ctx()
+    P = Fn.P
     outs = []
     for img in imgs:
-        h, w = img.shape[-2:]
+        img = img.contiguous().float()
+        C, h, w = img.shape[-3:]
         wins = window_grid(h, w, crop_size, stride_size)
-        final = torch.zeros(1, num_classes, h, w, device=img.device)
-        count = torch.zeros(1, 1, h, w, device=img.device)
+        final = c.zeros((1, num_classes, h, w), torch.float32)
+        count = c.zeros((1, 1, h, w), torch.float32)
         for i in range(0, len(wins), max_batch):
             chunk = wins[i:i + max_batch]
-            batch = torch.stack([img[:, a:c_, b:d] for (a, b, c_, d) in chunk], 0).contiguous()
+            ch, cw = chunk[0][2] - chunk[0][0], chunk[0][3] - chunk[0][1]
+            assert all((c_ - a, d - b) == (ch, cw) for (a, b, c_, d) in chunk)
+            org = (ctypes.c_int * (2 * len(chunk)))(*[v for (a, b, _, _) in chunk for v in (a, b)])
+            orgp = ctypes.cast(org, ctypes.c_void_p)
+            batch = c.empty((len(chunk), C, ch, cw), torch.float32)
+            L.call("emrt_crop_windows", P(img), P(batch), orgp, len(chunk), C, h, w, ch, cw, c.stream)
             logits = model(batch)[0]
-            for j, (a, b, c_, d) in enumerate(chunk):
-                final[0, :, a:c_, b:d] += logits[j]
-                count[0, :, a:c_, b:d] += 1
-        outs.append(final / count)      # uncovered pixels give 0/0 = NaN exactly as the reference (:79)
+            assert logits.dtype == torch.float32 and logits.is_contiguous()
+            L.call("emrt_window_accumulate", P(logits), P(final), P(count), orgp, len(chunk), num_classes, h, w, ch, cw, c.stream)
+        out = c.empty((1, num_classes, h, w), torch.float32)
+        L.call("emrt_window_normalise", P(final), P(count), P(out), num_classes, h, w, c.stream)
+        outs.append(out)
     return outs
 
 
@@ -65,5 +78,9 @@ def ss_inference(model, img, ori_shape, is_slide, base_size, stride_size, crop_s
         if tuple(logit.shape[-2:]) != shape:
             logit = torch.nn.functional.interpolate(logit, shape, mode="bilinear", align_corners=False)
         # softmax is monotonic: argmax(softmax(x)) == argmax(x)  (infer.py:152-153)
-        preds.append(torch.argmax(logit, dim=1, keepdim=True).to(torch.int32))
+        logit = logit.contiguous()
+        n, ncls, hh, ww = logit.shape
+        pred = ctx().empty((n, 1, hh, ww), torch.int32)
+        Fn._L().call("emrt_argmax_nchw", Fn.P(logit), Fn.P(pred), n, ncls, hh, ww, ctx().stream)
+        preds.append(pred)
     return preds

@@ -99,6 +99,14 @@ int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, i
 /* model input: fp32 NCHW images (paddle_EMRT.py:252) -> NHWC compute dtype */
 int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream);
 
+/* ---- sliding-window inference glue, fp32 NCHW as the reference: src/api/infer.py:60-79 (crop / accumulate / count /
+ * divide) and :150-155 (argmax; softmax dropped, it is monotonic).  origins_yx: HOST int[n][2], n <= 64 windows of
+ * ch x cw inside the C x H x W image; final/count are caller-zeroed accumulators; uncovered pixels normalise to NaN. */
+int emrt_crop_windows(const float* img, float* batch, const int* origins_yx, int n, int C, int H, int W, int ch, int cw, void* stream);
+int emrt_window_accumulate(const float* logits, float* final, float* count, const int* origins_yx, int n, int C, int H, int W, int ch, int cw, void* stream);
+int emrt_window_normalise(const float* final, const float* count, float* out, int C, int H, int W, void* stream);
+int emrt_argmax_nchw(const float* logits, int* pred, int N, int C, int H, int W, void* stream);
+
 /* ---- loss: nn.CrossEntropyLoss(ignore_index, axis=1) on fp32 NCHW logits, int64 labels:
  * losses/mix_softmax_cross_entropy_loss.py:27-35.  result (device float[2]) = {mean loss, non-ignored count}. */
 size_t emrt_ce_workspace_bytes(void);
