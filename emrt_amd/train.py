@@ -38,6 +38,7 @@ def parse_args(argv=None):
     p.add_argument("--iters", type=int, default=None, help="override TRAIN.ITERS")
     p.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a captured hipGraph")
     p.add_argument("--resume", default=None, help="checkpoint written by this script")
+    p.add_argument("--pretrained_backbone", default=None, help="weights to start from (.pdparams or torch): whole model or ResNet backbone")
     return p.parse_args(argv)
 
 
@@ -83,6 +84,14 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     model = get_model(config)
+    if config.MODEL.PRETRAINED:
+        # MODEL.PRETRAINED / --pretrained_backbone (config.py:245-246): a whole-model file (.pdparams or torch) or an ImageNet
+        # ResNet file as paddle.vision saves it (keys without the "backbone." prefix; detected from the key names)
+        from .src.utils.checkpoint import load_pretrained_model, load_pdparams
+        path = config.MODEL.PRETRAINED
+        keys = load_pdparams(path).keys() if path.endswith(".pdparams") else torch.load(path, map_location="cpu").get("model", {}).keys()
+        prefix = "" if any(k.startswith("backbone.") or k.startswith("model.") for k in keys) else "backbone."
+        load_pretrained_model(model, path, prefix=prefix)
     model.to_hip("cuda:%d" % local_rank, BF16 if args.dtype == "bf16" else F32, seed=args.seed + rank)   # per-rank dropout streams
     model.train()
     iters = args.iters or config.TRAIN.ITERS
@@ -143,6 +152,9 @@ def main(argv=None):
                 torch.save({"model": {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()},
                             "optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()},
                             "iter": cur_iter}, path)
+                # and the weights alone in the reference's own format (train.py:200-203: iter_{n}_model_state.pdparams)
+                from .src.utils.checkpoint import save_pdparams
+                save_pdparams(model.state_dict(), os.path.join(config.SAVE_DIR, "iter_{}_model_state.pdparams".format(cur_iter)))
                 save_models.append(path)
                 print("saving the weights of model to {}".format(path))
                 if len(save_models) > config.KEEP_CHECKPOINT_MAX > 0:

@@ -62,9 +62,9 @@ def main(argv=None):
         raise NotImplementedError("multi-scale/flip inference (infer.py:160-260) is listed as NEXT in SURVEY.md 8(f)-3")
     rank, local_rank, nranks = init_process_group()
     model = get_model(config)
-    if args.model_path:
-        ck = torch.load(args.model_path, map_location="cpu")
-        model.load_state_dict(ck.get("model", ck))
+    if args.model_path:                 # a .pdparams written by the reference / by train.py, or a torch checkpoint
+        from .src.utils.checkpoint import load_entire_model
+        load_entire_model(model, args.model_path)
     model.to_hip("cuda:%d" % local_rank, BF16 if args.dtype == "bf16" else F32)
     dev = torch.device("cuda", local_rank)
     if args.data == "synthetic":
