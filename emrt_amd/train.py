@@ -38,6 +38,7 @@ def parse_args(argv=None):
     p.add_argument("--iters", type=int, default=None, help="override TRAIN.ITERS")
     p.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a captured hipGraph")
     p.add_argument("--resume", default=None, help="checkpoint written by this script")
+    p.add_argument("--save_dir", default=None, help="override SAVE_DIR of the yaml (the reference's yamls point at the authors' disks)")
     p.add_argument("--pretrained_backbone", default=None, help="weights to start from (.pdparams or torch): whole model or ResNet backbone")
     return p.parse_args(argv)
 
@@ -83,6 +84,8 @@ def main(argv=None):
     rank, local_rank, nranks = init_process_group()
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
+    if args.save_dir:
+        config.SAVE_DIR = args.save_dir
     model = get_model(config)
     if config.MODEL.PRETRAINED:
         # MODEL.PRETRAINED / --pretrained_backbone (config.py:245-246): a whole-model file (.pdparams or torch) or an ImageNet
