@@ -738,3 +738,41 @@ extern "C" int emrt_argmax_nchw(const float* logits, int* pred, int N, int C, in
   hipLaunchKernelGGL(argmax_nchw_kernel, dim3(ew_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, logits, pred, N, C, (long long)H * W);
   return check_launch("emrt_argmax_nchw");
 }
+
+// ---- multi-scale / flip inference glue (reference: src/api/infer.py:160-260): horizontal flip of fp32 NCHW maps and
+// "final += softmax(logits, axis=1)" over the class axis
+__global__ __launch_bounds__(256) void flip_w_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows, int W) {
+  const long long total = rows * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long r = idx / W;
+    const int x = (int)(idx - r * W);
+    out[idx] = in[r * W + (W - 1 - x)];
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_nchw_acc_kernel(const float* __restrict__ logits, float* __restrict__ acc, int N, int C, long long HW) {
+  const long long total = (long long)N * HW;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long n = idx / HW, p = idx - n * HW;
+    const float* lp = logits + n * C * HW + p;
+    float* ap = acc + n * C * HW + p;
+    float mx = lp[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lp[(long long)c * HW]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(lp[(long long)c * HW] - mx);
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; ++c) ap[(long long)c * HW] += expf(lp[(long long)c * HW] - mx) * inv;
+  }
+}
+
+extern "C" int emrt_flip_w(const float* in, float* out, long long rows, int W, void* stream) {
+  EMRT_REQUIRE(in && out && in != out, "null or aliased pointers");
+  hipLaunchKernelGGL(flip_w_kernel, dim3(ew_grid(rows * W)), dim3(256), 0, (hipStream_t)stream, in, out, rows, W);
+  return check_launch("emrt_flip_w");
+}
+
+extern "C" int emrt_softmax_nchw_acc(const float* logits, float* acc, int N, int C, int H, int W, void* stream) {
+  EMRT_REQUIRE(logits && acc && C >= 1, "bad arguments");
+  hipLaunchKernelGGL(softmax_nchw_acc_kernel, dim3(ew_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, logits, acc, N, C, (long long)H * W);
+  return check_launch("emrt_softmax_nchw_acc");
+}

@@ -84,3 +84,65 @@ def ss_inference(model, img, ori_shape, is_slide, base_size, stride_size, crop_s
         Fn._L().call("emrt_argmax_nchw", Fn.P(logit), Fn.P(pred), n, ncls, hh, ww, ctx().stream)
         preds.append(pred)
     return preds
+
+
+def _resize_nchw_f32(x, h, w):
+    """fp32 [N,C,H,W] -> fp32 [N,C,h,w], bilinear, align_corners=False (F.interpolate(mode='bilinear') default), through the
+    HIP resize kernel: NCHW -> NHWC ingest, then the kernel's fp32-NCHW output mode."""
+    from ...runtime import F32
+    L, c = Fn._L(), ctx()
+    N, C, H, W = x.shape
+    if (H, W) == (h, w):
+        return x
+    x = x.contiguous()
+    nhwc = c.empty((N, H, W, C), torch.float32)
+    L.call("emrt_nchw_to_nhwc", Fn.P(x), Fn.P(nhwc), N, C, H, W, F32, c.stream)
+    out = c.empty((N, C, h, w), torch.float32)
+    L.call("emrt_resize_bilinear_fwd", Fn.P(nhwc), H * W * C, C, H, W, Fn.P(out), 0, 0, h, w, None, 0, 0, N, C, 0, 1, F32, c.stream)
+    return out
+
+
+def _flip_w(x):
+    out = ctx().empty(tuple(x.shape), torch.float32)
+    x = x.contiguous()
+    Fn._L().call("emrt_flip_w", Fn.P(x), Fn.P(out), x.numel() // x.shape[-1], x.shape[-1], ctx().stream)
+    return out
+
+
+def ms_inference(model, img, ori_shape, is_slide, base_size, stride_size, crop_size, num_classes, scales=(1.0,),
+                 flip_horizontal=True, flip_vertical=False, rescale_from_ori=False):
+    """Multi-scale + horizontal-flip inference (infer.py:160-260): per scale, sliding-window logits -> resize to
+    `ori_shape` -> softmax, summed over scales and flips, then argmax.  img: one fp32 [3,h,w] device tensor (or a list of
+    one); returns int32 [1,1,H,W].  The reference's quirk is kept: each scale resizes the image produced for the previous
+    scale (its `img` variable is reassigned, :240) to a size derived from the ORIGINAL input size.  Every array operation
+    is a HIP kernel (resize, flip, softmax-accumulate, argmax)."""
+    if not isinstance(scales, (tuple, list)):
+        raise TypeError("`scales` expects tuple/list, but received {}".format(type(scales)))
+    if rescale_from_ori or not is_slide:
+        raise NotImplementedError("whole-image rescale_from_ori testing is off in every EMRT config (config.py:203)")
+    if flip_vertical:
+        raise NotImplementedError("flip_vertical is a TODO in the reference as well (infer.py:258)")
+    if isinstance(img, (list, tuple)):
+        assert len(img) == 1
+        img = img[0]
+    L, c = Fn._L(), ctx()
+    cur = img.float().unsqueeze(0) if img.dim() == 3 else img.float()
+    h_input, w_input = cur.shape[-2], cur.shape[-1]
+    H, W = (int(v) for v in ori_shape)
+    final = c.zeros((1, num_classes, H, W), torch.float32)
+    for scale in scales:
+        h, w = int(h_input * scale + 0.5), int(w_input * scale + 0.5)
+        if min(h, w) < crop_size[0]:
+            new_short = crop_size[0]
+            h, w = (int(new_short * h / w), new_short) if h > w else (new_short, int(new_short * w / h))
+        cur = _resize_nchw_f32(cur, h, w)
+        variants = [(cur, False)] + ([(_flip_w(cur), True)] if flip_horizontal else [])
+        for im, flipped in variants:
+            logit = slide_inference(model, [im[0]], crop_size, stride_size, num_classes)[0]
+            if flipped:
+                logit = _flip_w(logit)
+            logit = _resize_nchw_f32(logit, H, W)
+            L.call("emrt_softmax_nchw_acc", Fn.P(logit), Fn.P(final), 1, num_classes, H, W, c.stream)
+    pred = c.empty((1, 1, H, W), torch.int32)
+    L.call("emrt_argmax_nchw", Fn.P(final), Fn.P(pred), 1, num_classes, H, W, c.stream)
+    return pred

@@ -26,21 +26,26 @@ def parse_args(argv=None):
     p.add_argument("--config", dest="cfg", type=str,
                    default=os.path.join(os.path.dirname(__file__), "configs/EMRT/EMRT_256x256_160k_potsdam.yaml"))
     p.add_argument("--model_path", default=None, type=str)
-    p.add_argument("--multi_scales", action="store_true", help="(reference flag; multi-scale/flip inference is not on this path yet)")
+    p.add_argument("--multi_scales", action="store_true", help="multi-scale (VAL.SCALE_RATIOS) + horizontal-flip inference, infer.py:160-260")
     p.add_argument("--data", default="synthetic")
     p.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"])
     return p.parse_args(argv)
 
 
-def evaluate(model, images, labels, config, rank=0, nranks=1):
+def evaluate(model, images, labels, config, rank=0, nranks=1, multi_scales=False):
     """images: list of fp32 [3,h,w] device tensors, labels: list of int64 [h,w].  Returns the reference's metric tuple."""
     model.eval()
     ncls = config.DATA.NUM_CLASSES
     tot = torch.zeros(3, ncls, dtype=torch.int64, device=images[0].device)
     t0 = time.time()
     for i in range(rank, len(images), nranks):
-        pred = infer.ss_inference(model, [images[i]], [labels[i].shape[-2:]], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
-                                  config.VAL.CROP_SIZE, ncls, config.VAL.RESCALE_FROM_ORI)[0]
+        if multi_scales:            # val.py:168-181: VAL.SCALE_RATIOS + horizontal flip
+            pred = infer.ms_inference(model, [images[i]], labels[i].shape[-2:], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
+                                      config.VAL.CROP_SIZE, ncls, scales=list(config.VAL.SCALE_RATIOS), flip_horizontal=True,
+                                      flip_vertical=False, rescale_from_ori=config.VAL.RESCALE_FROM_ORI)
+        else:
+            pred = infer.ss_inference(model, [images[i]], [labels[i].shape[-2:]], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
+                                      config.VAL.CROP_SIZE, ncls, config.VAL.RESCALE_FROM_ORI)[0]
         inter, pa, la = metrics.calculate_area(pred, labels[i], ncls, config.TRAIN.IGNORE_INDEX)
         tot[0] += inter
         tot[1] += pa
@@ -58,8 +63,6 @@ def evaluate(model, images, labels, config, rank=0, nranks=1):
 def main(argv=None):
     args = parse_args(argv)
     config = update_config(get_config(), args)
-    if args.multi_scales:
-        raise NotImplementedError("multi-scale/flip inference (infer.py:160-260) is listed as NEXT in SURVEY.md 8(f)-3")
     rank, local_rank, nranks = init_process_group()
     model = get_model(config)
     if args.model_path:                 # a .pdparams written by the reference / by train.py, or a torch checkpoint
@@ -78,7 +81,7 @@ def main(argv=None):
         labels = [torch.from_numpy(a).long().to(dev) for a in z["labels"]]
     if list(config.VAL.STRIDE_SIZE) == [320, 320] and list(config.VAL.CROP_SIZE)[0] < 320:
         config.VAL.STRIDE_SIZE = list(config.VAL.CROP_SIZE)   # default stride > crop leaves NaN stripes
-    cost, miou, acc, kap, ciou, cacc, cf1, mf1 = evaluate(model, images, labels, config, rank, nranks)
+    cost, miou, acc, kap, ciou, cacc, cf1, mf1 = evaluate(model, images, labels, config, rank, nranks, multi_scales=args.multi_scales or config.VAL.MULTI_SCALES_VAL)
     if rank == 0:
         print("[EVAL] Images: {}  mIoU: {:.4f}  Acc: {:.4f}  Kappa: {:.4f}  mF1: {:.4f}".format(len(images), miou, acc, kap, mf1))
         print("[EVAL] Class IoU: " + str(np.round(ciou, 4)))

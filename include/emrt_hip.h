@@ -106,6 +106,9 @@ int emrt_crop_windows(const float* img, float* batch, const int* origins_yx, int
 int emrt_window_accumulate(const float* logits, float* final, float* count, const int* origins_yx, int n, int C, int H, int W, int ch, int cw, void* stream);
 int emrt_window_normalise(const float* final, const float* count, float* out, int C, int H, int W, void* stream);
 int emrt_argmax_nchw(const float* logits, int* pred, int N, int C, int H, int W, void* stream);
+/* multi-scale / flip test-time augmentation (infer.py:160-260): img[..., ::-1] and final += softmax(logit, axis=1) */
+int emrt_flip_w(const float* in, float* out, long long rows, int W, void* stream);
+int emrt_softmax_nchw_acc(const float* logits, float* acc, int N, int C, int H, int W, void* stream);
 
 /* ---- loss: nn.CrossEntropyLoss(ignore_index, axis=1) on fp32 NCHW logits, int64 labels:
  * losses/mix_softmax_cross_entropy_loss.py:27-35.  result (device float[2]) = {mean loss, non-ignored count}. */

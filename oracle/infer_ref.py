@@ -81,3 +81,26 @@ def kappa(inter, pred_area, label_area):  # metrics.py:140-161
     po = np.sum(inter) / total
     pe = np.sum(pred_area.astype(np.float64) * label_area) / (float(total) * float(total))
     return float((po - pe) / (1 - pe))
+
+
+def ms_inference(model, img, ori_shape, stride_size, crop_size, num_classes, scales=(1.0,), flip_horizontal=True):
+    """infer.py:160-260, sliding-window branch (rescale_from_ori is off in every EMRT config).  img: [3,h,w].
+    Reference quirk kept: `img` is REASSIGNED by each scale's resize (:240), so scale k resizes the image already
+    resized for scale k-1, while the target size is always derived from the ORIGINAL input size (:209-212)."""
+    img = img.unsqueeze(0)
+    h_input, w_input = img.shape[-2], img.shape[-1]
+    final = 0
+    for scale in scales:
+        h, w = int(h_input * scale + 0.5), int(w_input * scale + 0.5)
+        if min(h, w) < crop_size[0]:
+            new_short = crop_size[0]
+            h, w = (int(new_short * h / w), new_short) if h > w else (new_short, int(new_short * w / h))
+        img = F.interpolate(img, (h, w), mode="bilinear", align_corners=False)
+        logit = slide_inference(model, [img[0]], crop_size, stride_size, num_classes)[0]
+        logit = F.interpolate(logit, tuple(ori_shape), mode="bilinear", align_corners=False)
+        final = final + F.softmax(logit, dim=1)
+        if flip_horizontal:
+            lf = slide_inference(model, [img[0].flip(-1)], crop_size, stride_size, num_classes)[0].flip(-1)
+            lf = F.interpolate(lf, tuple(ori_shape), mode="bilinear", align_corners=False)
+            final = final + F.softmax(lf, dim=1)
+    return final, torch.argmax(final, dim=1, keepdim=True).to(torch.int32)

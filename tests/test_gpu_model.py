@@ -357,3 +357,26 @@ def test_sliding_window_1024_resnet50():
     got192 = infer.slide_inference(model, [img.cuda()], (256, 256), (192, 192), 6)[0].cpu()
     assert torch.isfinite(got192).all()                       # every pixel covered at least once
     assert (got192[..., :192, :192] - got[..., :192, :192]).abs().max().item() < 5e-4   # singly-covered corner: same window (other batch size => other GEMM tiling / summation order)
+
+
+def test_multi_scale_flip_inference_matches_oracle():
+    """infer.ms_inference: scales + horizontal flip, softmax-averaged; HIP glue kernels against the
+    oracle's restatement of infer.py:160-260 (including its cumulative-resize quirk)."""
+    from emrt_amd.src.api import infer
+    from oracle import infer_ref
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    ref, model = build_pair("resnet18", x)
+    ref.eval()
+    model.eval()
+    img = torch.randn(3, 96, 128, generator=g)
+    scales = [0.75, 1.0, 1.25]
+    with torch.no_grad():
+        want_prob, want_pred = infer_ref.ms_inference(ref, img, (96, 128), (32, 32), (64, 64), 6, scales, True)
+    pred = infer.ms_inference(model, [img.cuda()], (96, 128), True, 64, (32, 32), (64, 64), 6, scales=scales, flip_horizontal=True)
+    assert pred.dtype == torch.int32 and tuple(pred.shape) == (1, 1, 96, 128)
+    # decisions may only differ where the summed probabilities are a near-tie
+    top2 = want_prob.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[0]
+    bad = (pred.cpu()[0, 0] != want_pred[0, 0]) & (margin > 2e-3)
+    assert not bad.any(), int(bad.sum())
