@@ -33,7 +33,9 @@ def parse_args(argv=None):
     p.add_argument("--config", dest="cfg", type=str,
                    default=os.path.join(os.path.dirname(__file__), "configs/EMRT/EMRT_256x256_160k_potsdam.yaml"), help="The config file.")
     p.add_argument("--seed", dest="seed", default=1234, type=int, help="Set the random seed during training.")
-    p.add_argument("--data", default="synthetic", help="'synthetic' or a .npz of pre-cut tiles")
+    p.add_argument("--data", default="synthetic", help="'synthetic', 'dataset' (DATA.DATASET under DATA.DATA_PATH, the reference's "
+                   "directory layout) or a .npz of pre-cut tiles")
+    p.add_argument("--data_path", default=None, help="override DATA.DATA_PATH of the yaml")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--iters", type=int, default=None, help="override TRAIN.ITERS")
     p.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a captured hipGraph")
@@ -86,6 +88,8 @@ def main(argv=None):
     np.random.seed(args.seed)
     if args.save_dir:
         config.SAVE_DIR = args.save_dir
+    if args.data_path:
+        config.DATA.DATA_PATH = args.data_path
     model = get_model(config)
     if config.MODEL.PRETRAINED:
         # MODEL.PRETRAINED / --pretrained_backbone (config.py:245-246): a whole-model file (.pdparams or torch) or an ImageNet
@@ -105,12 +109,23 @@ def main(argv=None):
     loss_func = get_loss_function(config)
     bs = config.DATA.BATCH_SIZE
     dev = torch.device("cuda", local_rank)
+    loader = None
     if args.data == "synthetic":
         images, labels = synthetic_tiles(max(4 * bs * nranks, 64), config.DATA.CROP_SIZE, config.DATA.NUM_CLASSES, args.seed, dev)
+        n_tiles = images.shape[0]
+    elif args.data == "dataset":        # the reference's pipeline: DATA.DATASET under DATA.DATA_PATH (train.py:79-86)
+        from .src.datasets import get_dataset, TileLoader
+        from .src.transforms import get_transforms
+        dataset_train = get_dataset(config, data_transform=get_transforms(config), mode="train")
+        n_tiles = len(dataset_train)
     else:
         z = np.load(args.data)
         images, labels = torch.from_numpy(z["images"]).float().to(dev), torch.from_numpy(z["labels"]).long().to(dev)
-    sampler = DistributedTileSampler(images.shape[0], bs, rank, nranks, shuffle=True, drop_last=True, seed=args.seed)
+        n_tiles = images.shape[0]
+    sampler = DistributedTileSampler(n_tiles, bs, rank, nranks, shuffle=True, drop_last=True, seed=args.seed)
+    if args.data == "dataset":
+        import copy
+        loader = TileLoader(dataset_train, copy.copy(sampler), dev, workers=max(1, config.DATA.NUM_WORKERS), prefetch=4).epochs()
     start_iter = 0
     if args.resume:
         ck = torch.load(args.resume, map_location="cpu")
@@ -136,9 +151,13 @@ def main(argv=None):
                 break
             cur_iter += 1
             reader_cost.record(time.time() - batch_start)
-            ib = torch.as_tensor(idx, device=dev)
             lr = optimizer.get_lr()
-            loss_t = engine.step(images[ib], labels[ib])
+            if loader is not None:
+                bx, by = next(loader)       # decoded / augmented by the reader threads, already on the device
+            else:
+                ib = torch.as_tensor(idx, device=dev)
+                bx, by = images[ib], labels[ib]
+            loss_t = engine.step(bx, by)
             pending.append(loss_t.clone())          # no device->host sync per step (the reference syncs here, :160)
             batch_cost.record(time.time() - batch_start, num_samples=bs)
             if cur_iter % config.LOGGING_INFO_FREQ == 0:

@@ -27,7 +27,8 @@ def parse_args(argv=None):
                    default=os.path.join(os.path.dirname(__file__), "configs/EMRT/EMRT_256x256_160k_potsdam.yaml"))
     p.add_argument("--model_path", default=None, type=str)
     p.add_argument("--multi_scales", action="store_true", help="multi-scale (VAL.SCALE_RATIOS) + horizontal-flip inference, infer.py:160-260")
-    p.add_argument("--data", default="synthetic")
+    p.add_argument("--data", default="synthetic", help="'synthetic', 'dataset' (DATA.DATASET under DATA.DATA_PATH) or a .npz")
+    p.add_argument("--data_path", default=None, help="override DATA.DATA_PATH of the yaml")
     p.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"])
     return p.parse_args(argv)
 
@@ -75,6 +76,15 @@ def main(argv=None):
         h = w = config.VAL.IMAGE_BASE_SIZE or config.DATA.CROP_SIZE[0]
         images = [torch.randn(3, h, w, generator=g).to(dev) for _ in range(8)]
         labels = [torch.randint(0, config.DATA.NUM_CLASSES, (h, w), generator=g).to(dev) for _ in range(8)]
+    elif args.data == "dataset":        # the reference's pipeline (val.py:95-104): DATA.DATASET under DATA.DATA_PATH, mode 'val'
+        from .src.datasets import get_dataset
+        from .src.transforms import get_val_transforms
+        if getattr(args, "data_path", None):
+            config.DATA.DATA_PATH = args.data_path
+        ds = get_dataset(config, data_transform=get_val_transforms(config), mode="val")
+        items = [ds[i] for i in range(len(ds))]
+        images = [torch.from_numpy(a).float().to(dev) for a, _ in items]
+        labels = [torch.from_numpy(np.ascontiguousarray(b[0])).long().to(dev) for _, b in items]
     else:
         z = np.load(args.data)
         images = [torch.from_numpy(a).float().to(dev) for a in z["images"]]
