@@ -12,6 +12,7 @@ using namespace emrt;
 
 #define MHA_MAXL 128
 #define MHA_D 32
+#define MHA_P 36      /* LDS row pitch in floats: 16-byte aligned rows so that the broadcast row reads are ds_read_b128 */
 
 struct MhaArgs {
   const void* q; const void* k; const void* v;   // row (b*L + i), column head*32 + d
@@ -47,13 +48,32 @@ __device__ __forceinline__ void store_row32(T* p, const float* src) {
   }
 }
 
+
+// dot of a register row with an LDS row / axpy of an LDS row into a register row, 4 floats per LDS read
+__device__ __forceinline__ float dot_row(const float* __restrict__ r, const float* __restrict__ srow) {
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < MHA_D; d += 4) {
+    const float4 k4 = *reinterpret_cast<const float4*>(srow + d);
+    s = fmaf(r[d], k4.x, s); s = fmaf(r[d + 1], k4.y, s); s = fmaf(r[d + 2], k4.z, s); s = fmaf(r[d + 3], k4.w, s);
+  }
+  return s;
+}
+__device__ __forceinline__ void axpy_row(float w, const float* __restrict__ srow, float* __restrict__ acc) {
+#pragma unroll
+  for (int d = 0; d < MHA_D; d += 4) {
+    const float4 v4 = *reinterpret_cast<const float4*>(srow + d);
+    acc[d] = fmaf(w, v4.x, acc[d]); acc[d + 1] = fmaf(w, v4.y, acc[d + 1]); acc[d + 2] = fmaf(w, v4.z, acc[d + 2]); acc[d + 3] = fmaf(w, v4.w, acc[d + 3]);
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(MHA_MAXL) void mha_fwd_kernel(MhaArgs a) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int L = a.L;
-  float* sK = sm;                       // [L][33]
-  float* sV = sK + L * 33;              // [L][33]
-  float* sS = sV + L * 33;              // [MHA_MAXL][L + 1]
+  float* sK = sm;                       // [L][MHA_P]
+  float* sV = sK + L * MHA_P;              // [L][MHA_P]
+  float* sS = sV + L * MHA_P;              // [MHA_MAXL][L + 1]
   const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
   const int i = threadIdx.x;
   const long long r0 = (long long)b * L;
@@ -62,10 +82,10 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_fwd_kernel(MhaArgs a) {
     float t[MHA_D];
     load_row32<T>((const T*)a.k + (r0 + i) * a.ldk + m * MHA_D, t);
 #pragma unroll
-    for (int d = 0; d < MHA_D; ++d) sK[i * 33 + d] = t[d];
+    for (int d = 0; d < MHA_D; ++d) sK[i * MHA_P + d] = t[d];
     load_row32<T>((const T*)a.v + (r0 + i) * a.ldv + m * MHA_D, t);
 #pragma unroll
-    for (int d = 0; d < MHA_D; ++d) sV[i * 33 + d] = t[d];
+    for (int d = 0; d < MHA_D; ++d) sV[i * MHA_P + d] = t[d];
     load_row32<T>((const T*)a.q + (r0 + i) * a.ldq + m * MHA_D, qi);
   }
   __syncthreads();
@@ -73,9 +93,7 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_fwd_kernel(MhaArgs a) {
   float* Si = sS + i * (L + 1);
   float mx = -3.0e38f;
   for (int j = 0; j < L; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < MHA_D; ++d) s = fmaf(qi[d], sK[j * 33 + d], s);
+    float s = dot_row(qi, sK + j * MHA_P);
     s *= a.scale;
     Si[j] = s;
     mx = fmaxf(mx, s);
@@ -96,21 +114,20 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_fwd_kernel(MhaArgs a) {
       const unsigned long long idx = (((unsigned long long)b * a.M + m) * L + i) * L + j;
       pj = uniform01(seed, a.salt, idx) >= a.pdrop ? pj * keep_scale : 0.f;
     }
-#pragma unroll
-    for (int d = 0; d < MHA_D; ++d) out[d] = fmaf(pj, sV[j * 33 + d], out[d]);
+    axpy_row(pj, sV + j * MHA_P, out);
   }
   store_row32<T>((T*)a.o + (r0 + i) * a.ldo + m * MHA_D, out);
 }
 
 template <class T>
 __global__ __launch_bounds__(MHA_MAXL) void mha_bwd_kernel(MhaArgs a) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int L = a.L;
-  float* sK = sm;                 // [L][33]
-  float* sV = sK + L * 33;
-  float* sQ = sV + L * 33;
-  float* sG = sQ + L * 33;        // dout rows
-  float* sD = sG + L * 33;        // dS  [MHA_MAXL][L + 1]
+  float* sK = sm;                 // [L][MHA_P]
+  float* sV = sK + L * MHA_P;
+  float* sQ = sV + L * MHA_P;
+  float* sG = sQ + L * MHA_P;        // dout rows
+  float* sD = sG + L * MHA_P;        // dS  [MHA_MAXL][L + 1]
   const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
   const int i = threadIdx.x;
   const long long r0 = (long long)b * L;
@@ -119,14 +136,14 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_bwd_kernel(MhaArgs a) {
     float t[MHA_D];
     load_row32<T>((const T*)a.k + (r0 + i) * a.ldk + m * MHA_D, t);
 #pragma unroll
-    for (int d = 0; d < MHA_D; ++d) sK[i * 33 + d] = t[d];
+    for (int d = 0; d < MHA_D; ++d) sK[i * MHA_P + d] = t[d];
     load_row32<T>((const T*)a.v + (r0 + i) * a.ldv + m * MHA_D, t);
 #pragma unroll
-    for (int d = 0; d < MHA_D; ++d) sV[i * 33 + d] = t[d];
+    for (int d = 0; d < MHA_D; ++d) sV[i * MHA_P + d] = t[d];
     load_row32<T>((const T*)a.q + (r0 + i) * a.ldq + m * MHA_D, qi);
     load_row32<T>((const T*)a.dout + (r0 + i) * a.lddo + m * MHA_D, gi);
 #pragma unroll
-    for (int d = 0; d < MHA_D; ++d) { sQ[i * 33 + d] = qi[d]; sG[i * 33 + d] = gi[d]; }
+    for (int d = 0; d < MHA_D; ++d) { sQ[i * MHA_P + d] = qi[d]; sG[i * MHA_P + d] = gi[d]; }
   }
   __syncthreads();
   const float* pgb = a.probs + ((long long)b * a.M + m) * L * L;
@@ -137,9 +154,7 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_bwd_kernel(MhaArgs a) {
     const float* pi = pgb + (long long)i * L;
     float dot = 0.f;
     for (int j = 0; j < L; ++j) {
-      float dp = 0.f;
-#pragma unroll
-      for (int d = 0; d < MHA_D; ++d) dp = fmaf(gi[d], sV[j * 33 + d], dp);
+      float dp = dot_row(gi, sV + j * MHA_P);
       if (a.pdrop > 0.f) {
         const unsigned long long idx = (((unsigned long long)b * a.M + m) * L + i) * L + j;
         dp = uniform01(seed, a.salt, idx) >= a.pdrop ? dp * keep_scale : 0.f;
@@ -153,8 +168,7 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_bwd_kernel(MhaArgs a) {
     for (int j = 0; j < L; ++j) {
       const float ds = pi[j] * (Di[j] - dot);
       Di[j] = ds;
-#pragma unroll
-      for (int d = 0; d < MHA_D; ++d) dq[d] = fmaf(ds, sK[j * 33 + d], dq[d]);
+      axpy_row(ds, sK + j * MHA_P, dq);
     }
 #pragma unroll
     for (int d = 0; d < MHA_D; ++d) dq[d] *= a.scale;
@@ -173,8 +187,8 @@ __global__ __launch_bounds__(MHA_MAXL) void mha_bwd_kernel(MhaArgs a) {
         const unsigned long long idx = (((unsigned long long)b * a.M + m) * L + r) * L + j;
         pd = uniform01(seed, a.salt, idx) >= a.pdrop ? pd * keep_scale : 0.f;
       }
-#pragma unroll
-      for (int d = 0; d < MHA_D; ++d) { dk[d] = fmaf(ds, sQ[r * 33 + d], dk[d]); dv[d] = fmaf(pd, sG[r * 33 + d], dv[d]); }
+      axpy_row(ds, sQ + r * MHA_P, dk);
+      axpy_row(pd, sG + r * MHA_P, dv);
     }
 #pragma unroll
     for (int d = 0; d < MHA_D; ++d) dk[d] *= a.scale;
@@ -195,7 +209,7 @@ extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, cons
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.probs = probs;
   a.B = B; a.M = M; a.L = L; a.scale = scale; a.pdrop = pdrop; a.seed = seed; a.salt = salt;
-  const size_t lds = (size_t)(2 * L * 33 + MHA_MAXL * (L + 1)) * sizeof(float);
+  const size_t lds = (size_t)(2 * L * MHA_P + MHA_MAXL * (L + 1)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
   if (!attr_done) {
@@ -221,7 +235,7 @@ extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, cons
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.probs = const_cast<float*>(probs);
   a.B = B; a.M = M; a.L = L; a.scale = scale; a.pdrop = pdrop; a.seed = seed; a.salt = salt;
   a.dout = dout; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-  const size_t lds = (size_t)(4 * L * 33 + MHA_MAXL * (L + 1)) * sizeof(float);
+  const size_t lds = (size_t)(4 * L * MHA_P + MHA_MAXL * (L + 1)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {

@@ -46,12 +46,23 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 }
 
 // result[0] = mean loss over non-ignored pixels, result[1] = count
-__global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ result) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one block: fp64 tree reduction of the per-block partial (loss, count) pairs (a single-thread loop over up to 4096
+// partials took 70 us of dependent loads)
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ result) {
+  __shared__ double ra[256], rb[256];
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblk; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
-  result[0] = (float)(a / b);
-  result[1] = (float)b;
+  for (int i = threadIdx.x; i < nblk; i += 256) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+  ra[threadIdx.x] = a;
+  rb[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ra[threadIdx.x] += ra[threadIdx.x + o]; rb[threadIdx.x] += rb[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    result[0] = (float)(ra[0] / rb[0]);
+    result[1] = (float)rb[0];
+  }
 }
 
 // dlogits = weight * upstream * (softmax - onehot) / count     (upstream: device scalar or null == 1)
@@ -95,7 +106,7 @@ extern "C" int emrt_softmax_ce_fwd(const float* logits, const long long* labels,
   if (grid < 1) grid = 1;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, N, C, (long long)H * W, ignore_index, (float*)workspace);
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, grid, result);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, result);
   return check_launch("emrt_softmax_ce_fwd");
 }
 
@@ -136,13 +147,21 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 }
 
 // state[0] = clip scale (clip / max(norm, clip), or 1 when clip <= 0), state[1] = global grad norm
-__global__ void clip_scale_kernel(const float* __restrict__ partial, int nblk, float clip, float* __restrict__ state) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void clip_scale_kernel(const float* __restrict__ partial, int nblk, float clip, float* __restrict__ state) {
+  __shared__ double red[256];
   double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += partial[i];
-  const float norm = (float)sqrt(s);
-  state[1] = norm;
-  state[0] = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
+    state[1] = norm;
+    state[0] = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
+  }
 }
 
 struct SgdArgs {
@@ -191,7 +210,7 @@ extern "C" int emrt_grad_clip_scale(const float* grads, long long n, float clip,
   if (grid < 1) grid = 1;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(grid), dim3(256), 0, st, grads, n, (float*)workspace);
-  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, grid, clip, state);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, clip, state);
   return check_launch("emrt_grad_clip_scale");
 }
 

@@ -427,16 +427,20 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxPoolArgs a) {
   }
 }
 
-template <class T>
+// VEC = 4: four channels per thread (one 4-byte load of argmax slots, one 8/16-byte load of dout per window)
+template <class T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
-  const long long total = (long long)a.N * a.H * a.W * a.C;
+  const int cv = a.C / VEC;
+  const long long total = (long long)a.N * a.H * a.W * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % a.C);
-    long long r = idx / a.C;
+    const int c = (int)(idx % cv) * VEC;
+    long long r = idx / cv;
     const int w = (int)(r % a.W); r /= a.W;
     const int h = (int)(r % a.H);
     const int n = (int)(r / a.H);
-    float acc = 0.f;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     // output windows that contain (h, w): oh in [ceil((h+pad-k+1)/s), floor((h+pad)/s)]
     int oh_lo = (h + a.pad - a.k + 1 + a.stride - 1);
     oh_lo = oh_lo > 0 ? oh_lo / a.stride : 0;
@@ -450,9 +454,25 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
         const long long o = (((long long)n * a.OH + oh) * a.OW + ow) * a.C + c;
         const int slot = (h - (oh * a.stride - a.pad)) * a.k + (w - (ow * a.stride - a.pad));
-        if ((int)a.arg[o] == slot) acc += to_f32(((const T*)a.dout)[o]);
+        if (VEC == 4) {
+          const unsigned packed = *reinterpret_cast<const unsigned*>(a.arg + o);
+          if (((packed & 0xffu) == (unsigned)slot) | (((packed >> 8) & 0xffu) == (unsigned)slot) | (((packed >> 16) & 0xffu) == (unsigned)slot) |
+              ((packed >> 24) == (unsigned)slot)) {
+            float g[4];
+            Vec4<T>::load((const T*)a.dout + o, g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (((packed >> (8 * e)) & 0xffu) == (unsigned)slot) acc[e] += g[e];
+          }
+        } else if ((int)a.arg[o] == slot) acc[0] += to_f32(((const T*)a.dout)[o]);
       }
-    ((T*)a.din)[idx] = from_f32<T>(acc);
+    T* dp = (T*)a.din + (((long long)n * a.H + h) * a.W + w) * a.C + c;
+    if (VEC == 4) {
+      float w4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w4[e] = acc[e < VEC ? e : 0];
+      Vec4<T>::store(dp, w4);
+    } else dp[0] = from_f32<T>(acc[0]);
   }
 }
 
@@ -616,8 +636,16 @@ extern "C" int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, v
   a.pad = pad;
   a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ew_grid((long long)N * H * W * C);
-  DT2(dtype, maxpool_bwd_kernel, grid, a);
+  const bool v4 = C % 4 == 0 && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)din % 16 == 0) && ((uintptr_t)argmax % 4 == 0);
+  if (v4) {
+    const int grid = ew_grid((long long)N * H * W * (C / 4));
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    const int grid = ew_grid((long long)N * H * W * C);
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float, 1>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, a);
+  }
   return check_launch("emrt_maxpool_bwd");
 }
 
