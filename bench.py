@@ -43,6 +43,11 @@ def conv_flops(name, a):
         if mode == 0:
             return 2.0 * N * OH * OW * OC * KH * KW * C
         return 2.0 * N * H * W * C * KH * KW * OC          # dgrad: useful MACs = those of the forward conv
+    if name == "emrt_conv2d_bwd":           # data gradient + weight gradient of one layer
+        N, H, W, C = a[6:10]
+        OH, OW, OC = a[12:15]
+        KH, KW = a[17:19]
+        return 4.0 * N * OH * OW * OC * KH * KW * C
     N, H, W, C = a[3:7]
     OH, OW, OC = a[9:12]
     KH, KW = a[14:16]
@@ -144,6 +149,8 @@ def main():
                     extra = ""
                     if name == "emrt_conv2d":
                         extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
+                    elif name == "emrt_conv2d_bwd":
+                        extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[6], vals[7], vals[8], vals[9], vals[12], vals[13], vals[14], vals[17], vals[19], conv_flops(name, vals) / 1e9)
                     elif name == "emrt_conv2d_wgrad":
                         extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
                     else:       # integer arguments only: enough to recognise the layer
@@ -154,7 +161,7 @@ def main():
             f = fam.setdefault(name, [0, 0.0, 0.0])
             f[0] += 1
             f[1] += ms
-            if name in ("emrt_conv2d", "emrt_conv2d_wgrad"):
+            if name in ("emrt_conv2d", "emrt_conv2d_wgrad", "emrt_conv2d_bwd"):
                 f[2] += conv_flops(name, [x.value if hasattr(x, "value") else x for x in a])
         total_ms = sum(v[1] for v in fam.values())
         top = sorted(fam.items(), key=lambda kv: -kv[1][1])
@@ -162,20 +169,25 @@ def main():
         for name, (cnt, ms, fl) in top[:12]:
             log("    %-28s %5d calls %9.3f ms %5.1f%%%s" % (name, cnt, ms, 100 * ms / total_ms, "  %.1f TFLOP/s" % (fl / ms / 1e9) if fl else ""))
         peak = PEAK_BF16_TFLOPS if dtype == BF16 else PEAK_F32_MFMA_TFLOPS
-        dom_name = "emrt_conv2d" if fam.get("emrt_conv2d", [0, 0, 0])[1] >= fam.get("emrt_conv2d_wgrad", [0, 0, 0])[1] else "emrt_conv2d_wgrad"
+        gemm_fams = {"emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
+                     "emrt_conv2d_bwd": "igemm_kernel + wgrad_kernel (emrt_conv2d_bwd: data + weight gradients, paired launch for small layers)",
+                     "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)"}
+        dom_name = max(gemm_fams, key=lambda k: fam.get(k, [0, 0.0, 0.0])[1])
         cnt, ms, fl = fam[dom_name]
         ach = fl / ms / 1e9
-        roofline = {"kernel": "igemm_kernel (emrt_conv2d fwd+dgrad)" if dom_name == "emrt_conv2d" else "wgrad_kernel (emrt_conv2d_wgrad)",
-                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
+        all_ms = sum(fam.get(k, [0, 0.0, 0.0])[1] for k in gemm_fams)
+        all_fl = sum(fam.get(k, [0, 0.0, 0.0])[2] for k in gemm_fams)
+        roofline = {"kernel": gemm_fams[dom_name], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
                     "algorithmic_gflop_per_step": round(fl / 1e9, 1), "share_of_step_kernel_time": round(ms / total_ms, 3),
+                    "all_gemm_tflops": round(all_fl / all_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_ms / total_ms, 3),
                     "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch"}
         # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot profile itself); bf16 B=8 256^2 only
         pmc, pmc_src = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_pmc_traffic.json")
         if os.path.exists(pmc_src) and dtype == BF16 and B == 8 and S == 256:
             with open(pmc_src) as f:
                 pmc = json.load(f)
-            key = "igemm_kernel" if dom_name == "emrt_conv2d" else "wgrad_kernel"
+            key = "wgrad_kernel" if dom_name == "emrt_conv2d_wgrad" else "igemm_kernel"
             roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
             roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, average over the step's launches)"
             roofline["traffic_source"] = "profiles/r1d_pmc_traffic.json: " + pmc["method"]

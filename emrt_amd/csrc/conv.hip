@@ -104,14 +104,13 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // those are prologue / epilogue dominated, so it is held to 128 registers = 4 blocks per CU (measured: 180 registers, i.e.
 // 2 blocks per CU, cost 25-35 % on those shapes).
 template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G>
-__global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void igemm_kernel(ConvArgs p) {
+__device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id, const int block_count, unsigned char* smem_all) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
   constexpr int PITCH = 144;
   constexpr int AR = BM / 32, BR = BN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * PITCH;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
 
   const int grp = G == 1 ? 0 : (int)threadIdx.x >> 8;
   unsigned char* smem = smem_all + grp * 2 * STAGE_BYTES;
@@ -120,8 +119,8 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
   const int tiles_n = (p.OC + BN - 1) / BN;
   // consecutive workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of tiles so that the
   // tiles that share an activation row block (same bm) hit the same L2
-  int bid = blockIdx.x;
-  const int nblk = gridDim.x;
+  int bid = block_id;
+  const int nblk = block_count;
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
   const int bm = bid / tiles_n, bn = bid % tiles_n;
   const int OHW = p.OH * p.OW;
@@ -406,6 +405,12 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
   }
 }
 
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G>
+__global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void igemm_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  igemm_body<T, TM, TN, WR, WC, MODE, VEC, NST, G>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[oc][k] += sum_m dy[m][oc] * xcol[m][k], 128(oc) x 128(k) tile per block, reduction over
 // pixels m split across blockIdx.z, fp32 atomics into dW.  Both operands are pixel-major in memory, so
@@ -440,20 +445,19 @@ struct WgradCfg<float> {
 // accumulators are summed through LDS before the atomic epilogue: half the reduction slices (fp32 atomic traffic into dW,
 // ~14 MB per launch by WRITE_SIZE) for the same number of waves.  Kept for experiments; the dispatcher uses G = 1.
 template <class T, bool VEC, int G>
-__global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD (<= 256 registers)
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x, const int block_y, const int block_z, unsigned char* smem_all) {
   using Cfg = WgradCfg<T>;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int CPR = Cfg::CPR, RPP = Cfg::RPP, BKM = Cfg::BKM, PITCH = Cfg::PITCH;
   constexpr int NST = VEC ? 3 : 1;               // pixel tiles in flight in registers (8 x 16 B each per thread)
   constexpr int STAGE_BYTES = 2 * BKM * PITCH;   // dy tile [BKM][128 oc] + x tile [BKM][128 k]
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
 
   const int grp = G == 1 ? 0 : (int)threadIdx.x >> 8;
   unsigned char* smem = smem_all + grp * 2 * STAGE_BYTES;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = p.KH * p.KW * p.C;
-  const int oc0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+  const int oc0 = block_y * 128, k0 = block_x * 128;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)BUF_RANGE, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)BUF_RANGE, 0x00020000);
 
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const long long mt_begin = (long long)blockIdx.z * p.tiles_per_split;
+  const long long mt_begin = (long long)block_z * p.tiles_per_split;
   const long long mt_total = ((long long)p.N * p.OH * p.OW + BKM - 1) / BKM;
   long long mt_end = mt_begin + p.tiles_per_split;
   if (mt_end > mt_total) mt_end = mt_total;
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
     }
   };
 
-  const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
+  const bool do_bias = p.dbias != nullptr && block_x == 0;
   float bsum[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) bsum[e] = 0.f;
@@ -708,6 +712,30 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
     }
 }
 
+template <class T, bool VEC, int G>
+__global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD (<= 256 registers)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  wgrad_body<T, VEC, G>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem_all);
+}
+
+// Backward pair: ONE launch runs the data-gradient tiles (blocks [0, n_dgrad)) and the weight-gradient tiles (the rest)
+// of a layer.  For the ~100 small layers of the step either kernel alone leaves most CUs idle and spends about half of
+// its duration in launch / ramp / tail; side by side the two grids fill the machine and share one launch.  Both bodies
+// run 256-thread blocks; the block takes the larger LDS / register budget of the two (wgrad's), which is why large
+// grids, where dgrad wants its 4 blocks per CU, are still launched separately.
+template <class T, int TM, int TN, int WR, int WC, int NST>
+__global__ __launch_bounds__(256, 2) void bwd_pair_kernel(ConvArgs pd, WgradArgs pw, int n_dgrad, int wtx, int wty) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  if ((int)blockIdx.x < n_dgrad) {
+    igemm_body<T, TM, TN, WR, WC, 1, true, NST, 1>(pd, (int)blockIdx.x, n_dgrad, smem_all);
+  } else {
+    int r = (int)blockIdx.x - n_dgrad;
+    const int bx = r % wtx;
+    r /= wtx;
+    wgrad_body<T, true, 1>(pw, bx, r % wty, r / wty, smem_all);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
@@ -806,25 +834,26 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   return mode == 0 ? conv_dispatch<bf16_t, 0>(a, st) : conv_dispatch<bf16_t, 1>(a, st);
 }
 
+// vector path eligibility of a weight-gradient problem
 template <class T>
-static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
-  using Cfg = WgradCfg<T>;
+static bool wgrad_is_vec(const WgradArgs& a) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  WgradArgs a = a0;
+  return (a.C % EPC == 0) && (a.OC % EPC == 0) && (a.ldx % EPC == 0) && (a.lddy % EPC == 0) && (a.x_bs % EPC == 0) && (a.dy_bs % EPC == 0) &&
+         (((uintptr_t)a.x) % 16 == 0) && (((uintptr_t)a.dy) % 16 == 0);
+}
+
+// Split of the pixel reduction over blockIdx.z; fills a.tiles_per_split and returns the grid (tx, ty, S).
+// Cost model fitted to tools/bench_conv.py on MI355X:
+//   t(S) = tiles_per_block * 1 us * max(1, blocks / 1024)  +  S * |dW| / 1.3 TB/s (every slice re-adds dW atomically)
+// i.e. a lone 4-wave block needs ~1 us per pixel tile, up to ~4 blocks per CU overlap for free, fp32 atomics run at ~1.3 TB/s.
+template <class T>
+static void wgrad_plan(WgradArgs& a, int& tx, int& ty, int& S_out) {
+  using Cfg = WgradCfg<T>;
   const int K = a.KH * a.KW * a.C;
   const long long M = (long long)a.N * a.OH * a.OW;
-  const bool vec = (a.C % EPC == 0) && (a.OC % EPC == 0) && (a.ldx % EPC == 0) && (a.lddy % EPC == 0) &&
-                   (a.x_bs % EPC == 0) && (a.dy_bs % EPC == 0) && (((uintptr_t)a.x) % 16 == 0) && (((uintptr_t)a.dy) % 16 == 0);
-  const int tx = (K + 127) / 128, ty = (a.OC + 127) / 128;
+  tx = (K + 127) / 128;
+  ty = (a.OC + 127) / 128;
   const long long mt_total = (M + Cfg::BKM - 1) / Cfg::BKM;
-  // Split of the pixel reduction over blockIdx.z.  Cost model fitted to tools/bench_conv.py on MI355X:
-  //   t(S) = tiles_per_block * t_tile * max(1, blocks / 1024)  +  S * |dW| / 1.3 TB/s (every slice re-adds dW atomically)
-  // i.e. a lone 4-wave group needs ~1 us per pixel tile (t_tile = 1 us / G), up to ~4 groups per CU overlap for free,
-  // fp32 atomics run at ~1.3 TB/s.
-  // wave groups per block on the vector path (wgrad_kernel).  G = 2 measured SLOWER than two independent G = 1 blocks per
-  // CU on every EMRT shape but one (coupled barriers, 160 KB of LDS per block), so 1 it is.
-  constexpr int G = 1;
-  const int gv = vec ? G : 1;
   const double atom_us = (double)tx * 128.0 * (double)ty * 128.0 * 4.0 / 1.3e6;
   long long S = 1;
   double best = 1e30;
@@ -833,8 +862,8 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
     const long long sc = cand[ci];
     if (sc > mt_total) break;
     if (sc > 1 && (long long)tx * ty >= 256) break;      // already one block per CU and a large dW: slices only add atomics
-    const double per = (double)((mt_total + sc - 1) / sc) / gv;
-    const double nblk = (double)tx * ty * sc * gv;
+    const double per = (double)((mt_total + sc - 1) / sc);
+    const double nblk = (double)tx * ty * sc;
     const double t = per * (nblk > 1024.0 ? nblk / 1024.0 : 1.0) + sc * atom_us;
     if (t < best) { best = t; S = sc; }
   }
@@ -843,7 +872,20 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
     if (v > 0) S = v < mt_total ? v : mt_total;
   }
   a.tiles_per_split = (int)((mt_total + S - 1) / S);
-  S = (mt_total + a.tiles_per_split - 1) / a.tiles_per_split;
+  S_out = (int)((mt_total + a.tiles_per_split - 1) / a.tiles_per_split);
+}
+
+template <class T>
+static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
+  using Cfg = WgradCfg<T>;
+  WgradArgs a = a0;
+  const bool vec = wgrad_is_vec<T>(a);
+  int tx, ty, S;
+  wgrad_plan<T>(a, tx, ty, S);
+  // wave groups per block on the vector path (wgrad_kernel).  G = 2 measured SLOWER than two independent G = 1 blocks per
+  // CU on every EMRT shape but one (coupled barriers, 160 KB of LDS per block), so 1 it is.
+  constexpr int G = 1;
+  const int gv = vec ? G : 1;
   const size_t lds = (size_t)gv * 2 * 2 * Cfg::BKM * Cfg::PITCH;      // per group: two stages of (dy tile + x tile)
   static bool attr_done = false;      // one flag per element type
   if (!attr_done) {
@@ -881,4 +923,76 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.tiles_per_split = 0; a.dbias = dbias;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? wgrad_dispatch<float>(a, st) : wgrad_dispatch<bf16_t>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of one conv / linear layer in one call: dx = dgrad(dy, W^T) [masked by y > 0 with BatchNorm sums, see
+// ConvArgs::mask_y] and dW += wgrad(x, dy) [+ dbias].  Small layers go out as ONE launch (bwd_pair_kernel); large
+// grids and non-vector shapes as the two separate kernels.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t st) {
+  using Cfg = WgradCfg<T>;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  WgradArgs w = w0;
+  const bool vec_d = (d.C % EPC == 0) && (d.ldin % EPC == 0) && (d.in_bs % EPC == 0) && (((uintptr_t)d.in) % 16 == 0) && (((uintptr_t)d.w) % 16 == 0);
+  const bool vec_w = wgrad_is_vec<T>(w);
+  const long long Md = (long long)d.N * d.OH * d.OW;
+  const long long nd = ((Md + 63) / 64) * ((d.OC + 63) / 64);                 // 64x64 dgrad tiles
+  const int nkt = (d.KH * d.KW * d.C + BK - 1) / BK;
+  const bool big_tile = d.OC > 64 && nkt >= 16 && ((Md + 127) / 128) * ((d.OC + 127) / 128) >= 256;   // conv_pick_tile would take 128x128
+  int tx = 0, ty = 0, S = 0;
+  if (vec_w) wgrad_plan<T>(w, tx, ty, S);
+  const long long nw = (long long)tx * ty * S;
+  static const long long pair_max = getenv("EMRT_PAIR_MAX") ? atoll(getenv("EMRT_PAIR_MAX")) : 1536;   // measured: 0 -> 15.03 ms, 384 -> 14.46, 768 -> 14.42, 1536 -> 14.35, 3072+ -> 14.43
+  if (vec_d && vec_w && d.OC > 32 && !big_tile && nd + nw <= pair_max) {
+    auto kern = bwd_pair_kernel<T, 1, 1, 2, 2, 6>;
+    const size_t lds_d = (size_t)2 * 128 * 144, lds_w = (size_t)4 * Cfg::BKM * Cfg::PITCH;
+    const size_t lds = lds_d > lds_w ? lds_d : lds_w;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail("emrt_conv2d_bwd", "cannot raise the dynamic LDS limit");
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nd + nw)), dim3(256), lds, st, d, w, (int)nd, tx, ty);
+    return check_launch("emrt_conv2d_bwd");
+  }
+  int rc = wgrad_dispatch<T>(w0, st);
+  if (rc) return rc;
+  return conv_dispatch<T, 1>(d, st);
+}
+
+extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, float* dw, float* dbias,
+                               int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs,
+                               int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
+                               int dtype, void* stream) {
+  EMRT_REQUIRE(x && dy && w_bwd_packed && dx && dw, "null pointer");
+  EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
+  EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
+  EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
+  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  {
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long x_ext = ((long long)(N - 1) * x_bs + ((long long)H * W - 1) * ldx + C) * esz;
+    const long long dy_ext = ((long long)(N - 1) * dy_bs + ((long long)OH * OW - 1) * lddy + OC) * esz;
+    const long long w_ext = (long long)OC * KH * KW * C * esz;
+    EMRT_REQUIRE(x_bs >= 0 && dy_bs >= 0 && x_ext < (1ll << 31) && dy_ext < (1ll << 31) && w_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
+    EMRT_REQUIRE((long long)H * W < (1 << 24) && (long long)ldx * esz < (1 << 24) && stride < (1 << 12), "map too large for the 24-bit address arithmetic");
+  }
+  ConvArgs d;       // dgrad: a convolution of dy with the transposed weights, output = dx (dense NHWC)
+  d.in = dy; d.w = w_bwd_packed; d.out = dx; d.bias = nullptr; d.res = nullptr;
+  d.N = N; d.H = OH; d.W = OW; d.C = OC; d.ldin = lddy; d.in_bs = dy_bs;
+  d.OH = H; d.OW = W; d.OC = C; d.ldout = C; d.out_bs = (long long)H * W * C;
+  d.ldres = 0; d.res_bs = 0;
+  d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
+  d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs;
+  WgradArgs w;
+  w.x = x; w.dy = dy; w.dw = dw;
+  w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
+  w.OH = OH; w.OW = OW; w.OC = OC; w.lddy = lddy; w.dy_bs = dy_bs;
+  w.KH = KH; w.KW = KW; w.stride = stride; w.pad = pad; w.tiles_per_split = 0; w.dbias = dbias;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? conv_bwd_dispatch<float>(d, w, st) : conv_bwd_dispatch<bf16_t>(d, w, st);
 }

@@ -306,12 +306,11 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 _L().call("emrt_mask_bwd", P(dy), P(out), P(dm), dy.numel(), 0.0, None, 0, 0, 1, 1, c.dtype, c.stream)
                 dy = dm
             _, _, _, _, lddy, dy_bs = _check_map(dy)
-            # the weight gradient and the data gradient only share their inputs: with overlap on, wgrad goes to the side
-            # stream and runs next to dgrad (most of these launches are too small to fill the GPU on their own)
-            side = c.fork(x, dy) if need_dx else None
-            _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
-                      w.KH, w.KW, stride, pad, P(w.bias_grad) if w.bias is not None else None, c.dtype, side or c.stream)
-            if need_dx:
+            dbias = P(w.bias_grad) if w.bias is not None else None
+            if not need_dx:
+                _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
+                          w.KH, w.KW, stride, pad, dbias, c.dtype, c.stream)
+            else:
                 dx = c.empty(tuple(x.shape))
                 ysums = ymask = None
                 if bn_rec is not None and c.training:
@@ -319,13 +318,21 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                     # the BatchNorm's own reduction pass is skipped when this turns out to be its only gradient
                     ysums = c.zeros_f64(BN_REPLICAS * 2 * C)
                     ymask = x
-                _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
-                          H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
-                          in_bs if ymask is not None else 0, c.dtype, c.stream)
+                side = c.fork(x, dy)
+                if side is None:
+                    # one call for both gradients: small layers run their dgrad and wgrad tiles in ONE launch
+                    _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), P(w.grad), dbias, N, H, W, C, ldin, in_bs,
+                              OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, P(ysums), P(ymask), ldin if ymask is not None else 0,
+                              in_bs if ymask is not None else 0, c.dtype, c.stream)
+                else:       # two-stream experiment (Context.overlap): wgrad on the side stream next to dgrad
+                    _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
+                              w.KH, w.KW, stride, pad, dbias, c.dtype, side)
+                    _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
+                              H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
+                              in_bs if ymask is not None else 0, c.dtype, c.stream)
+                    c.join()
                 if ymask is not None:
                     bn_rec["dx"], bn_rec["sums"] = dx, ysums
-            if side is not None:
-                c.join()
             if residual is not None:
                 tape.add_grad(residual, dy)
             if need_dx:

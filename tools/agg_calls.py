@@ -17,7 +17,7 @@ for line in open(path):
     desc = parts[3].strip() if len(parts) > 3 else ""
     per[name] += ms
     cnt[name] += 1
-    if name not in ("emrt_conv2d", "emrt_conv2d_wgrad"):
+    if name not in ("emrt_conv2d", "emrt_conv2d_wgrad", "emrt_conv2d_bwd"):
         continue
     d = re.sub(r" gflop.*", "", desc)
     g = float(re.search(r"gflop ([\d.]+)", desc).group(1)) if "gflop" in desc else 0
