@@ -44,9 +44,9 @@ def conv_flops(name, a):
             return 2.0 * N * OH * OW * OC * KH * KW * C
         return 2.0 * N * H * W * C * KH * KW * OC          # dgrad: useful MACs = those of the forward conv
     if name == "emrt_conv2d_bwd":           # data gradient + weight gradient of one layer
-        N, H, W, C = a[6:10]
-        OH, OW, OC = a[12:15]
-        KH, KW = a[17:19]
+        N, H, W, C = a[9:13]
+        OH, OW, OC = a[15:18]
+        KH, KW = a[20:22]
         return 4.0 * N * OH * OW * OC * KH * KW * C
     N, H, W, C = a[3:7]
     OH, OW, OC = a[9:12]
@@ -150,7 +150,7 @@ def main():
                     if name == "emrt_conv2d":
                         extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
                     elif name == "emrt_conv2d_bwd":
-                        extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[6], vals[7], vals[8], vals[9], vals[12], vals[13], vals[14], vals[17], vals[19], conv_flops(name, vals) / 1e9)
+                        extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
                     elif name == "emrt_conv2d_wgrad":
                         extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
                     else:       # integer arguments only: enough to recognise the layer

@@ -926,8 +926,9 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of one conv / linear layer in one call: dx = dgrad(dy, W^T) [masked by y > 0 with BatchNorm sums, see
-// ConvArgs::mask_y] and dW += wgrad(x, dy) [+ dbias].  Small layers go out as ONE launch (bwd_pair_kernel); large
+// Backward of one conv / linear layer in one call: dx (= or +=, any NHWC strides: a token slab or channel slice of a
+// gradient buffer is written in place) = dgrad(dy, W^T) [masked by y > 0 with BatchNorm sums, see ConvArgs::mask_y]
+// and dW += wgrad(x, dy) [+ dbias].  Small layers go out as ONE launch (bwd_pair_kernel); large
 // grids and non-vector shapes as the two separate kernels.
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -964,7 +965,8 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   return conv_dispatch<T, 1>(d, st);
 }
 
-extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, float* dw, float* dbias,
+extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs,
+                               int accumulate, float* dw, float* dbias,
                                int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs,
                                int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
                                int dtype, void* stream) {
@@ -984,8 +986,11 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   ConvArgs d;       // dgrad: a convolution of dy with the transposed weights, output = dx (dense NHWC)
   d.in = dy; d.w = w_bwd_packed; d.out = dx; d.bias = nullptr; d.res = nullptr;
   d.N = N; d.H = OH; d.W = OW; d.C = OC; d.ldin = lddy; d.in_bs = dy_bs;
-  d.OH = H; d.OW = W; d.OC = C; d.ldout = C; d.out_bs = (long long)H * W * C;
+  d.OH = H; d.OW = W; d.OC = C; d.ldout = lddx; d.out_bs = dx_bs;
   d.ldres = 0; d.res_bs = 0;
+  if (accumulate) { d.res = dx; d.ldres = lddx; d.res_bs = dx_bs; }      // dx += : every element is read and written by the same thread
+  EMRT_REQUIRE(lddx >= C && dx_bs >= 0, "bad dx strides");
+  EMRT_REQUIRE(!(accumulate && mask_y), "the fused ReLU mask / BatchNorm sums need dx to be this layer's only gradient");
   d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
   d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs;
   WgradArgs w;

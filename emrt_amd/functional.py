@@ -311,9 +311,11 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
                           w.KH, w.KW, stride, pad, dbias, c.dtype, c.stream)
             else:
-                dx = c.empty(tuple(x.shape))
+                slot = tape.grad_slot(x)          # accumulate straight into an existing gradient / a slice of the base buffer
+                dx = slot if slot is not None else c.empty(tuple(x.shape))
+                _, _, _, _, lddx, dx_bs = _check_map(dx)
                 ysums = ymask = None
-                if bn_rec is not None and c.training:
+                if bn_rec is not None and c.training and slot is None:
                     # dgrad also applies that BatchNorm's ReLU mask and accumulates its backward sums (sum dy', sum dy'*y):
                     # the BatchNorm's own reduction pass is skipped when this turns out to be its only gradient
                     ysums = c.zeros_f64(BN_REPLICAS * 2 * C)
@@ -321,21 +323,23 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 side = c.fork(x, dy)
                 if side is None:
                     # one call for both gradients: small layers run their dgrad and wgrad tiles in ONE launch
-                    _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), P(w.grad), dbias, N, H, W, C, ldin, in_bs,
+                    _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), lddx, dx_bs, int(slot is not None), P(w.grad), dbias,
+                              N, H, W, C, ldin, in_bs,
                               OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, P(ysums), P(ymask), ldin if ymask is not None else 0,
                               in_bs if ymask is not None else 0, c.dtype, c.stream)
                 else:       # two-stream experiment (Context.overlap): wgrad on the side stream next to dgrad
                     _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
                               w.KH, w.KW, stride, pad, dbias, c.dtype, side)
-                    _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, None, N, OH, OW, w.OC, lddy, dy_bs,
-                              H, W, C, C, H * W * C, 0, 0, w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
+                    _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, P(dx) if slot is not None else None,
+                              N, OH, OW, w.OC, lddy, dy_bs, H, W, C, lddx, dx_bs, lddx if slot is not None else 0, dx_bs if slot is not None else 0,
+                              w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
                               in_bs if ymask is not None else 0, c.dtype, c.stream)
                     c.join()
                 if ymask is not None:
                     bn_rec["dx"], bn_rec["sums"] = dx, ysums
             if residual is not None:
                 tape.add_grad(residual, dy)
-            if need_dx:
+            if need_dx and slot is None:
                 tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return out

@@ -73,6 +73,28 @@ class Tape:
             e[0], e[1] = priv, True
         return e[0]
 
+    def grad_slot(self, t):
+        """Where a producer may ACCUMULATE its gradient for t in place instead of handing over a fresh tensor: a view
+        of the (zero-initialised or already populated) buffer when t is a view into a base tensor, or t's existing
+        tape-owned gradient.  None when t has no gradient yet (the producer should then add_grad(..., owned=True)).
+        The caller must add into the returned tensor; the contribution is counted here."""
+        a = self.alias.get(id(t))
+        if a is not None:
+            root = a[0]
+            while id(root) in self.alias:
+                root = self.alias[id(root)][0]
+            if id(root) not in self.grads:
+                self.keep.append(root)
+                self.grads[id(root)] = [ctx().zeros(tuple(root.shape)), True, 0]
+            else:
+                self._own(root)
+            return self.grad(t)
+        e = self.grads.get(id(t))
+        if e is not None and e[1]:
+            e[2] += 1
+            return e[0]
+        return None
+
     def add_grad(self, t, g, owned=False):
         """Accumulate gradient g (same shape as t) into t's gradient.
         owned=True: g is a fresh buffer that the caller hands over (nobody else reads it afterwards), so the tape may

@@ -42,9 +42,9 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
 int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream);
-/* backward of one conv / linear layer in one call (dx dense NHWC [N,H,W,C]; dW += ; dbias += when given; optional fused
+/* backward of one conv / linear layer in one call (dx NHWC with strides lddx / dx_bs, overwritten or accumulated into; dW += ; dbias += when given; optional fused
  * BatchNorm-backward sums as in emrt_conv2d): small layers are ONE launch that runs the dgrad and wgrad tiles side by side */
-int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
+int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
 
 /* ---- BatchNorm / SyncBatchNorm (train: fp64 sums [from the conv epilogue or emrt_bn_stats] -> [all-reduce of sums across
  * ranks] -> apply; eval: running statistics).  replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add):

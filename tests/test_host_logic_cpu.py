@@ -71,8 +71,9 @@ def test_train_step_launch_sequence(fake, backbone):
     assert sum(1 for a in fwd_convs if a[25] is not None) == n_bn     # forward statistics fused into the conv epilogue
     # BatchNorm -> ReLU -> conv chains: the conv's dgrad carries the ReLU mask and the BatchNorm's backward sums, and the
     # separate reduction pass only remains for the other BatchNorms (residual joins, multi-consumer outputs, no ReLU)
-    n_fused = sum(1 for a in dgrads if a[22] is not None)
-    assert all((a[21] is not None) == (a[22] is not None) for a in dgrads)
+    n_fused = sum(1 for a in dgrads if a[25] is not None)
+    assert all((a[24] is not None) == (a[25] is not None) for a in dgrads)
+    assert not any(a[6] and a[25] is not None for a in dgrads)       # in-place accumulation and the fused mask exclude each other
     fused_dx = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[20] is not None)
     assert fused_dx + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_dx <= n_fused
     assert fused_dx >= n_bn // 3, (fused_dx, n_bn)
@@ -82,7 +83,7 @@ def test_train_step_launch_sequence(fake, backbone):
     assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
     # wgrad destinations are distinct slices inside the trainable gradient range
     g0 = st.grad.data_ptr()
-    dws = [a[2].value - g0 for n, a in fake.calls if n == "emrt_conv2d_wgrad"] + [a[4].value - g0 for n, a in fake.calls if n == "emrt_conv2d_bwd"]
+    dws = [a[2].value - g0 for n, a in fake.calls if n == "emrt_conv2d_wgrad"] + [a[7].value - g0 for n, a in fake.calls if n == "emrt_conv2d_bwd"]
     assert len(set(dws)) == len(dws) and all(0 <= d < 4 * st.n_train for d in dws)
     # every device pointer handed to a conv is 2-byte aligned at least and non-null
     for n, a in fake.calls:
