@@ -471,6 +471,133 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const T* __restrict__ x,
   }
 }
 
+// ---- single-launch GroupNorm for small maps: one block per (image, group) --------------------------------------------
+// The split kernels above need two launches each way; at the EMRT sizes (<= 32x32 pixels per level, 8 channels per
+// group) a whole (image, group) slice is 16 KB, so one block can take it in two passes over L1/L2-hot data and the layer
+// costs one launch.  Threads = QG channel quads x (256 / QG) pixel lanes.
+template <class T>
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ res,
+                                                           int ldres, long long res_bs, T* __restrict__ out, int ldout, long long out_bs,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, int HW, int C, int G,
+                                                           float eps, int gelu) {
+  __shared__ double red[2][4];
+  const int cpg = C / G, qg = cpg / 4, lanes = 256 / qg;
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int q = threadIdx.x % qg, ty = threadIdx.x / qg;
+  const int c = g * cpg + q * 4;
+  const T* xp = x + (long long)n * x_bs + c;
+  float s0 = 0.f, s1 = 0.f;
+  if (ty < lanes)
+    for (int p = ty; p < HW; p += lanes) {
+      float v[4];
+      Vec4<T>::load(xp + (long long)p * ldx, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0 += v[e]; s1 = fmaf(v[e], v[e], s1); }
+    }
+  double a = (double)wave_sum(s0), b = (double)wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double cnt = (double)HW * cpg;
+  const double mu_d = a / cnt;
+  double var = b / cnt - mu_d * mu_d;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (mean_out && threadIdx.x == 0) { mean_out[n * G + g] = mu; rstd_out[n * G + g] = rs; }
+  if (ty >= lanes) return;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = rs * gamma[c + e]; sh[e] = beta[c + e] - mu * sc[e]; }
+  for (int p = ty; p < HW; p += lanes) {
+    float v[4], o[4];
+    Vec4<T>::load(xp + (long long)p * ldx, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = fmaf(v[e], sc[e], sh[e]);
+      o[e] = gelu ? gelu_f(u) : u;
+    }
+    if (res) {
+      float w[4];
+      Vec4<T>::load(res + (long long)n * res_bs + (long long)p * ldres + c, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += w[e];
+    }
+    Vec4<T>::store(out + (long long)n * out_bs + (long long)p * ldout + c, o);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy,
+                                                           int lddy, long long dy_bs, T* __restrict__ dx, int lddx, long long dx_bs,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int HW, int C, int G, int gelu) {
+  __shared__ float chs[256 * 8];       // per-thread (sum dy', sum dy'*xhat) for its 4 channels
+  __shared__ float grp[2];
+  const int cpg = C / G, qg = cpg / 4, lanes = 256 / qg;
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int q = threadIdx.x % qg, ty = threadIdx.x / qg;
+  const int c = g * cpg + q * 4;
+  const float mu = mean[n * G + g], rs = rstd[n * G + g];
+  float ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
+  const T* xp = x + (long long)n * x_bs + c;
+  const T* gp = dy + (long long)n * dy_bs + c;
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (ty < lanes)
+    for (int p = ty; p < HW; p += lanes) {
+      float v[4], d[4];
+      Vec4<T>::load(xp + (long long)p * ldx, v);
+      Vec4<T>::load(gp + (long long)p * lddy, d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[e] - mu) * rs;
+        const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+        s0[e] += dd;
+        s1[e] = fmaf(dd, xh, s1[e]);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { chs[threadIdx.x * 8 + e] = s0[e]; chs[threadIdx.x * 8 + 4 + e] = s1[e]; }
+  __syncthreads();
+  __shared__ float gsum[256 * 2];      // gamma-weighted channel sums (separate array: the columns of chs are still being read)
+  if ((int)threadIdx.x < cpg) {        // channel cc of the group: column sums over the pixel lanes, in fp64
+    const int cc = threadIdx.x, qq = cc / 4, e = cc % 4;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < lanes; ++t) { a += chs[(t * qg + qq) * 8 + e]; b += chs[(t * qg + qq) * 8 + 4 + e]; }
+    if (dbeta) atomicAdd(dbeta + g * cpg + cc, (float)a);
+    if (dgamma) atomicAdd(dgamma + g * cpg + cc, (float)b);
+    gsum[cc * 2] = (float)((double)gamma[g * cpg + cc] * a);
+    gsum[cc * 2 + 1] = (float)((double)gamma[g * cpg + cc] * b);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) { a += gsum[cc * 2]; b += gsum[cc * 2 + 1]; }
+    const double inv = 1.0 / ((double)HW * cpg);
+    grp[0] = (float)(a * inv);
+    grp[1] = (float)(b * inv);
+  }
+  __syncthreads();
+  if (ty >= lanes) return;
+  const float A = grp[0], Bq = grp[1];
+  for (int p = ty; p < HW; p += lanes) {
+    float v[4], d[4], o[4];
+    Vec4<T>::load(xp + (long long)p * ldx, v);
+    Vec4<T>::load(gp + (long long)p * lddy, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      o[e] = rs * (ga[e] * dd - A - xh * Bq);
+    }
+    Vec4<T>::store(dx + (long long)n * dx_bs + (long long)p * lddx + c, o);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim C (C % 4 == 0, C <= 1024) with fused residual add:
 //   z = a (+ b);  out = LN(z)*gamma + beta (+ post)        one wave per row, 4 rows per 256-thread block.
@@ -740,6 +867,12 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   return check_launch("emrt_colsum_acc");
 }
 
+// one block per (image, group) when the slice is small enough for two cheap passes and the group is 4..256 channels wide
+static inline bool gn_use_fused(int HW, int C, int G) {
+  const int cpg = C / G;
+  return HW <= 4096 && cpg % 4 == 0 && cpg / 4 <= 64 && 256 % (cpg / 4) == 0 && (cpg / 4) * 64 >= 64;
+}
+
 static inline int gn_geom(int HW, int C, int* pix_per_block) {
   const int lanes = 256 / (C / 4);
   int ppb = lanes * 8;                       // each thread walks ~8 pixels
@@ -756,9 +889,15 @@ extern "C" int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const 
   EMRT_REQUIRE(x && out && gamma && beta && workspace, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 256 && C % G == 0 && (C / G) % 4 == 0, "unsupported C/G");
   EMRT_REQUIRE(ldx % 4 == 0 && ldout % 4 == 0 && x_bs % 4 == 0 && out_bs % 4 == 0, "strides must be multiples of 4");
+  hipStream_t st = (hipStream_t)stream;
+  if (gn_use_fused(HW, C, G)) {
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((gn_fused_fwd_kernel<float>), dim3(N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu),
+              hipLaunchKernelGGL((gn_fused_fwd_kernel<bf16_t>), dim3(N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu));
+    return check_launch("emrt_groupnorm_fwd");
+  }
   int ppb;
   const int blocks = gn_geom(HW, C, &ppb);
-  hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((gn_stats_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, workspace, HW, C, G, ppb),
             hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, workspace, HW, C, G, ppb));
@@ -775,9 +914,15 @@ extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const 
                                   int gelu, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd && workspace, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 256 && C % G == 0 && (C / G) % 4 == 0, "unsupported C/G");
+  hipStream_t st = (hipStream_t)stream;
+  if (gn_use_fused(HW, C, G)) {
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((gn_fused_bwd_kernel<float>), dim3(N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, gamma, beta, mean, rstd, dgamma, dbeta, HW, C, G, gelu),
+              hipLaunchKernelGGL((gn_fused_bwd_kernel<bf16_t>), dim3(N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, gamma, beta, mean, rstd, dgamma, dbeta, HW, C, G, gelu));
+    return check_launch("emrt_groupnorm_bwd");
+  }
   int ppb;
   const int blocks = gn_geom(HW, C, &ppb);
-  hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((gn_bwd_reduce_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, gamma, beta, mean, rstd, workspace, HW, C, G, gelu, ppb),
             hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, gamma, beta, mean, rstd, workspace, HW, C, G, gelu, ppb));
