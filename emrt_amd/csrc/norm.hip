@@ -680,36 +680,57 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long long row = r0 + wv; row < r1; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[4][4], gd[4][4];
-    float s0 = 0.f, s1 = 0.f;
+  // two rows per wave and iteration: the kernel is bound by the latency of the per-row load -> wave reduction -> store chain,
+  // two independent chains in one basic block let the scheduler overlap them
+  for (long long rowA = r0 + wv; rowA < r1; rowA += 8) {
+    const long long rowB_raw = rowA + 4;
+    const bool okB = rowB_raw < r1;
+    const long long rowB = okB ? rowB_raw : rowA;
+    const float wB = okB ? 1.f : 0.f;
+    const float muA = mean[rowA], rsA = rstd[rowA], muB = mean[rowB], rsB = rstd[rowB];
+    float xhA[4][4], gdA[4][4], xhB[4][4], gdB[4][4];
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     for (int j = 0; j < nq; ++j) {
       const int c = j * 256 + lane * 4;
       if (c < C) {
-        float zz[4], d[4];
-        Vec4<T>::load(z + row * C + c, zz);
-        Vec4<T>::load(dy + row * C + c, d);
+        float zA[4], dA[4], zB[4], dB[4];
+        Vec4<T>::load(z + rowA * C + c, zA);
+        Vec4<T>::load(dy + rowA * C + c, dA);
+        Vec4<T>::load(z + rowB * C + c, zB);
+        Vec4<T>::load(dy + rowB * C + c, dB);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[j][e] = (zz[e] - mu) * rs;
-          gd[j][e] = gamma[c + e] * d[e];
-          s0 += gd[j][e];
-          s1 = fmaf(gd[j][e], xh[j][e], s1);
-          dg[j][e] = fmaf(d[e], xh[j][e], dg[j][e]);
-          db[j][e] += d[e];
+          const float gm = gamma[c + e];
+          xhA[j][e] = (zA[e] - muA) * rsA;
+          gdA[j][e] = gm * dA[e];
+          a0 += gdA[j][e];
+          a1 = fmaf(gdA[j][e], xhA[j][e], a1);
+          xhB[j][e] = (zB[e] - muB) * rsB;
+          gdB[j][e] = gm * dB[e];
+          b0 += gdB[j][e];
+          b1 = fmaf(gdB[j][e], xhB[j][e], b1);
+          dg[j][e] = fmaf(dA[e], xhA[j][e], dg[j][e]);
+          db[j][e] += dA[e];
+          dg[j][e] = fmaf(wB * dB[e], xhB[j][e], dg[j][e]);
+          db[j][e] = fmaf(wB, dB[e], db[j][e]);
         }
       }
     }
-    s0 = wave_sum(s0) / (float)C;
-    s1 = wave_sum(s1) / (float)C;
+    a0 = wave_sum(a0) / (float)C;
+    a1 = wave_sum(a1) / (float)C;
+    b0 = wave_sum(b0) / (float)C;
+    b1 = wave_sum(b1) / (float)C;
     for (int j = 0; j < nq; ++j) {
       const int c = j * 256 + lane * 4;
       if (c < C) {
-        float o[4];
+        float oA[4], oB[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gd[j][e] - s0 - xh[j][e] * s1);
-        Vec4<T>::store(dz + row * C + c, o);
+        for (int e = 0; e < 4; ++e) {
+          oA[e] = rsA * (gdA[j][e] - a0 - xhA[j][e] * a1);
+          oB[e] = rsB * (gdB[j][e] - b0 - xhB[j][e] * b1);
+        }
+        Vec4<T>::store(dz + rowA * C + c, oA);
+        if (okB) Vec4<T>::store(dz + rowB * C + c, oB);
       }
     }
   }
@@ -946,22 +967,25 @@ extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post
   return check_launch("emrt_layernorm_fwd");
 }
 
-extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
+// blocks of the LayerNorm backward: ~32 rows (8 per wave) each, at most 512 partial-sum rows for the finalize
+static inline long long ln_bwd_blocks(long long rows) {
   long long blocks = (rows + 31) / 32;
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  return ((size_t)blocks * 2 * C + 2 * (size_t)C) * sizeof(float);
+  return blocks;
+}
+
+extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
+  return ((size_t)(ln_bwd_blocks(rows) + 1) * 2 * C + 2 * (size_t)C) * sizeof(float);
 }
 
 extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
                                   float* dgamma, float* dbeta, long long rows, int C, void* workspace, int dtype, void* stream) {
   EMRT_REQUIRE(z && dy && dz && gamma && mean && rstd && workspace, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
-  long long blocks = (rows + 31) / 32;
-  if (blocks > 512) blocks = 512;
-  if (blocks < 1) blocks = 1;
+  long long blocks = ln_bwd_blocks(rows);
   int rpb = (int)((rows + blocks - 1) / blocks);
-  rpb = (rpb + 3) / 4 * 4;
+  rpb = (rpb + 7) / 8 * 8;
   blocks = (rows + rpb - 1) / rpb;
   float* partial = (float*)workspace;
   const size_t lds = (size_t)8 * C * sizeof(float);

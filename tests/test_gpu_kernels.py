@@ -386,11 +386,12 @@ def test_msda_fwd_bwd(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_mha_fwd_bwd(dtype):
+@pytest.mark.parametrize("L", [110, 128, 37])      # 110: the EMRT decoder; 128: backward without the LDS copy of P; 37: ragged quads
+def test_mha_fwd_bwd(dtype, L):
     c = init(dtype)
     c.training = False   # no dropout
     g = torch.Generator().manual_seed(9)
-    B, L, E, Mh = 3, 110, 256, 8
+    B, E, Mh = 3, 256, 8
     qk = rnd(torch.randn(B, L, 2 * E, generator=g))
     v = rnd(torch.randn(B, L, E, generator=g))
     qkr, vr = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
@@ -412,6 +413,33 @@ def test_mha_fwd_bwd(dtype):
     dqk, dv = run_bwd(tape, [(y, dev(dy))], [qd, vd])
     close("mha dqk", host(dqk), qkr.grad, dtype)
     close("mha dv", host(dv), vr.grad, dtype)
+
+
+def test_mha_dropout_backward_consistent_with_forward():
+    """Dropout on the attention weights (layers.py:297): with the mask fixed (same device seed and salt) the output is
+    linear in V, so <dy, o(V + d) - o(V)> must equal <dV, d> exactly -- this ties the backward's re-derived mask to the
+    forward's."""
+    c = init(F32)
+    c.training = True
+    g = torch.Generator().manual_seed(19)
+    B, L, E, Mh = 2, 110, 256, 8
+    qk, v, d = (torch.randn(B, L, n, generator=g) for n in (2 * E, E, E))
+    dy = torch.randn(B, L, E, generator=g)
+    qd, vd, v2d = dev(qk), dev(v), dev(v + d)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.mha(qd, vd, Mh, 0.5, 7)
+    c.tape = None
+    tape.watch(vd)
+    y2 = Fn.mha(qd, v2d, Mh, 0.5, 7)
+    y0 = None
+    c.training = False
+    y0 = Fn.mha(qd, vd, Mh, 0.5, 7)
+    assert (host(y) - host(y0)).abs().max() > 1e-2                  # the mask really drops something
+    dv, = run_bwd(tape, [(y, dev(dy))], [vd])
+    lhs = ((host(y2) - host(y)) * dy).sum().item()
+    rhs = (host(dv) * d).sum().item()
+    assert abs(lhs - rhs) < 2e-3 * max(1.0, abs(lhs)), (lhs, rhs)
 
 
 # -----------------------------------------------------------------------------------------------------------------
