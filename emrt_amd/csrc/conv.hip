@@ -946,8 +946,11 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   int tx = 0, ty = 0, S = 0;
   if (vec_w) wgrad_plan<T>(w, tx, ty, S);
   const long long nw = (long long)tx * ty * S;
-  static const long long pair_max = getenv("EMRT_PAIR_MAX") ? atoll(getenv("EMRT_PAIR_MAX")) : 1536;   // measured: 0 -> 15.03 ms, 384 -> 14.46, 768 -> 14.42, 1536 -> 14.35, 3072+ -> 14.43
-  if (vec_d && vec_w && d.OC > 32 && !big_tile && nd + nw <= pair_max) {
+  // pairing pays while the dgrad grid is small (measured per shape, tools/bench_conv.py bwd: 16x16 / 8x8 layers -30..-40 %,
+  // token linears -5..-10 %; from ~1000 dgrad tiles on, dgrad misses its 4 blocks per CU and the pair is 5-20 % slower)
+  const char* pm_env = getenv("EMRT_PAIR_MAX");      // developer knob; read per call so a sweep can flip it
+  const long long pair_max = pm_env ? atoll(pm_env) : 768;   // measured: 0 -> 15.03 ms, 384 -> 14.46, 768 -> 14.42, 1536 -> 14.35, 3072+ -> 14.43
+  if (vec_d && vec_w && d.OC > 32 && !big_tile && nd <= pair_max && nd + nw <= 4096) {
     auto kern = bwd_pair_kernel<T, 1, 1, 2, 2, 6>;
     const size_t lds_d = (size_t)2 * 128 * 144, lds_w = (size_t)4 * Cfg::BKM * Cfg::PITCH;
     const size_t lds = lds_d > lds_w ? lds_d : lds_w;

@@ -81,7 +81,20 @@ def main():
             L._raw_emrt_conv2d_wgrad(P(x), P(y), P(dw), N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
                                      k, k, s, pad, None, 1, stream)
 
+        def bwd():
+            L._raw_emrt_conv2d_bwd(P(x), P(y), P(wb), P(dx), C, H * W * C, 0, P(dw), None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
+                                   k, k, s, pad, None, None, 0, 0, 1, stream)
+
         line = "N%d %dx%dx%d->%d k%d  %6.2f GF |" % (N, H, W, C, OC, k, gf)
+        if which == "bwd":
+            res = []
+            for pm in (0, 1 << 30):
+                os.environ["EMRT_PAIR_MAX"] = str(pm)
+                res.append(timed(bwd))
+            os.environ.pop("EMRT_PAIR_MAX")
+            Md = N * H * W
+            nd = ((Md + 63) // 64) * ((C + 63) // 64)
+            line += " bwd separate %.1f paired %.1f   (dgrad 64x64 tiles %d)" % (res[0], res[1], nd)
         if which in ("all", "conv"):
             for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
                 res = []
