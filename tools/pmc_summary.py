@@ -44,12 +44,16 @@ def main():
         return {"dispatches": len(fs), "fetch_mb_raw": round(sum(fs) / len(fs) / 1e3, 3), "write_mb": round(sum(ws) / len(ws) / 1e3, 3),
                 "traffic_mb_corrected": round((2 * sum(fs) / len(fs) + sum(ws) / len(ws)) / 1e3, 3)}
 
-    enc_grid = max(x[1] for k, v in fetch.items() if "msda_fwd_kernel" in k for x in v)
+    enc_name = max((k for k in fetch if "msda_fwd" in k), key=lambda k: max(x[1] for x in fetch[k]))    # the encoder call: largest grid
+    enc_grid = max(x[1] for x in fetch[enc_name])
     js = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 0 --no-graph`; "
                     "per-dispatch averages; corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B reads as 64 B)",
           "igemm_kernel": family(lambda k: "igemm_kernel" in k),
           "wgrad_kernel": family(lambda k: "wgrad_kernel" in k),
-          "msda_fwd_kernel_encoder": family(lambda k: "msda_fwd_kernel" in k, enc_grid)}
+          "msda_fwd_kernel_encoder": family(lambda k: k == enc_name, enc_grid)}
+    if any("bwd_pair_kernel" in k for k in fetch):
+        js["bwd_pair_kernel"] = family(lambda k: "bwd_pair_kernel" in k)
+    js["msda_fwd_kernel_encoder"]["kernel"] = enc_name
     json.dump(js, open(dst + ".json", "w"), indent=1)
     print(json.dumps(js, indent=1))
 
