@@ -43,6 +43,9 @@ def conv_flops(name, a):
         if mode == 0:
             return 2.0 * N * OH * OW * OC * KH * KW * C
         return 2.0 * N * H * W * C * KH * KW * OC          # dgrad: useful MACs = those of the forward conv
+    if name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group"):      # a[0]: ctypes array of descriptors, a[1]: how many
+        f = 2.0 if name == "emrt_conv2d_group" else 4.0
+        return sum(f * d.N * d.OH * d.OW * d.OC * d.KH * d.KW * d.C for d in list(a[0])[:a[1]])
     if name == "emrt_conv2d_bwd":           # data gradient + weight gradient of one layer
         N, H, W, C = a[9:13]
         OH, OW, OC = a[15:18]
@@ -153,6 +156,8 @@ def main():
                         extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
                     elif name == "emrt_conv2d_wgrad":
                         extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
+                    elif name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group"):
+                        extra = "n=%d " % vals[1] + " ".join("%dx%dx%d->%d k%d" % (d.H, d.W, d.C, d.OC, d.KH) for d in list(vals[0])[:vals[1]]) + " gflop %.2f" % (conv_flops(name, vals) / 1e9)
                     else:       # integer arguments only: enough to recognise the layer
                         extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))
                     f.write("%-26s %9.4f ms  %s\n" % (name, ms, extra))
@@ -161,7 +166,7 @@ def main():
             f = fam.setdefault(name, [0, 0.0, 0.0])
             f[0] += 1
             f[1] += ms
-            if name in ("emrt_conv2d", "emrt_conv2d_wgrad", "emrt_conv2d_bwd"):
+            if name in ("emrt_conv2d", "emrt_conv2d_wgrad", "emrt_conv2d_bwd", "emrt_conv2d_group", "emrt_conv2d_bwd_group"):
                 f[2] += conv_flops(name, [x.value if hasattr(x, "value") else x for x in a])
         total_ms = sum(v[1] for v in fam.values())
         top = sorted(fam.items(), key=lambda kv: -kv[1][1])
@@ -169,7 +174,9 @@ def main():
         for name, (cnt, ms, fl) in top[:12]:
             log("    %-28s %5d calls %9.3f ms %5.1f%%%s" % (name, cnt, ms, 100 * ms / total_ms, "  %.1f TFLOP/s" % (fl / ms / 1e9) if fl else ""))
         peak = PEAK_BF16_TFLOPS if dtype == BF16 else PEAK_F32_MFMA_TFLOPS
-        gemm_fams = {"emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
+        gemm_fams = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: per-level encoder convs)",
+                     "emrt_conv2d_bwd_group": "bwd_group_kernel (emrt_conv2d_bwd_group)",
+                     "emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
                      "emrt_conv2d_bwd": "igemm_kernel + wgrad_kernel (emrt_conv2d_bwd: data + weight gradients, paired launch for small layers)",
                      "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)"}
         dom_name = max(gemm_fams, key=lambda k: fam.get(k, [0, 0.0, 0.0])[1])
@@ -187,7 +194,7 @@ def main():
         if os.path.exists(pmc_src) and dtype == BF16 and B == 8 and S == 256:
             with open(pmc_src) as f:
                 pmc = json.load(f)
-            key = {"emrt_conv2d": "igemm_kernel", "emrt_conv2d_bwd": "bwd_pair_kernel", "emrt_conv2d_wgrad": "wgrad_kernel"}[dom_name]
+            key = {"emrt_conv2d": "igemm_kernel", "emrt_conv2d_bwd": "bwd_pair_kernel", "emrt_conv2d_wgrad": "wgrad_kernel"}.get(dom_name, "igemm_kernel")
             if key not in pmc:
                 key = "igemm_kernel"
             roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)

@@ -1004,3 +1004,183 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? conv_bwd_dispatch<float>(d, w, st) : conv_bwd_dispatch<bf16_t>(d, w, st);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Grouped launches: up to 4 independent small problems (the per-level 3x3 convs of an encoder layer, ...) in ONE launch.
+// Each problem alone is a 10-30 us, latency-bound launch that fills a fraction of the GPU; their tiles side by side
+// share the launch and hide each other's latency.  Plain-C descriptors (include/emrt_hip.h).
+// ------------------------------------------------------------------------------------------------
+#define EMRT_MAX_GROUP 4
+struct EmrtConvDesc {
+  const void* in; const void* w_packed; void* out; const float* bias; const void* residual;
+  int N, H, W, C, ldin; long long in_bs;
+  int OH, OW, OC, ldout; long long out_bs;
+  int ldres; long long res_bs;
+  int KH, KW, stride, pad, relu;
+  double* bn_stats;
+};
+struct EmrtConvBwdDesc {
+  const void* x; const void* dy; const void* w_bwd_packed; void* dx; int lddx; long long dx_bs; int accumulate; float* dw; float* dbias;
+  int N, H, W, C, ldx; long long x_bs; int OH, OW, OC, lddy; long long dy_bs; int KH, KW, stride, pad;
+};
+struct ConvGroupArgs { ConvArgs p[EMRT_MAX_GROUP]; int first[EMRT_MAX_GROUP + 1]; };
+struct BwdGroupArgs {
+  ConvArgs d[EMRT_MAX_GROUP];
+  WgradArgs w[EMRT_MAX_GROUP];
+  int first[EMRT_MAX_GROUP + 1];      // block range of problem i: [first[i], first[i+1]); inside it nd[i] dgrad tiles, then wgrad
+  int nd[EMRT_MAX_GROUP], wtx[EMRT_MAX_GROUP], wty[EMRT_MAX_GROUP];
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 4) void igemm_group_kernel(ConvGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < EMRT_MAX_GROUP; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
+  igemm_body<T, 1, 1, 2, 2, 0, true, 4, 1>(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], smem_all);
+}
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void bwd_group_kernel(BwdGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < EMRT_MAX_GROUP; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
+  const int local = (int)blockIdx.x - g.first[i];
+  if (local < g.nd[i]) {
+    igemm_body<T, 1, 1, 2, 2, 1, true, 6, 1>(g.d[i], local, g.nd[i], smem_all);
+  } else {
+    int r = local - g.nd[i];
+    const int bx = r % g.wtx[i];
+    r /= g.wtx[i];
+    wgrad_body<T, true, 1>(g.w[i], bx, r % g.wty[i], r / g.wty[i], smem_all);
+  }
+}
+
+static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
+  a.in = d.in; a.w = d.w_packed; a.out = d.out; a.bias = d.bias; a.res = d.residual;
+  a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldin = d.ldin; a.in_bs = d.in_bs;
+  a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
+  a.ldres = d.ldres; a.res_bs = d.res_bs;
+  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.relu = d.relu; a.out_f32 = 0; a.stats = d.bn_stats;
+  a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0;
+}
+
+template <class T>
+static bool conv_desc_is_vec(const ConvArgs& a) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  return (a.C % EPC == 0) && (a.ldin % EPC == 0) && (a.in_bs % EPC == 0) && (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.w) % 16 == 0);
+}
+
+template <class T>
+static int conv_group_dispatch(const EmrtConvDesc* descs, int n, hipStream_t st) {
+  ConvGroupArgs g;
+  bool groupable = true;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    conv_args_from_desc(g.p[i], descs[i]);
+    const long long M = (long long)g.p[i].N * g.p[i].OH * g.p[i].OW;
+    g.first[i] = (int)total;
+    total += ((M + 63) / 64) * ((g.p[i].OC + 63) / 64);
+    groupable = groupable && conv_desc_is_vec<T>(g.p[i]) && g.p[i].OC > 32;
+  }
+  for (int i = n; i <= EMRT_MAX_GROUP; ++i) g.first[i] = (int)total;
+  for (int i = n; i < EMRT_MAX_GROUP; ++i) g.p[i] = g.p[0];
+  if (!groupable || total > 4096) {        // not the small vector problems this launch is for: one launch each
+    for (int i = 0; i < n; ++i) {
+      const int rc = conv_dispatch<T, 0>(g.p[i], st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const size_t lds = (size_t)2 * 128 * 144;
+  hipLaunchKernelGGL((igemm_group_kernel<T>), dim3((unsigned)total), dim3(256), lds, st, g);
+  return check_launch("emrt_conv2d_group");
+}
+
+extern "C" int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream) {
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..4 problems");
+  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  for (int i = 0; i < n; ++i) {
+    const EmrtConvDesc& d = descs[i];
+    EMRT_REQUIRE(d.in && d.w_packed && d.out, "null pointer");
+    EMRT_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.OC > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad >= 0, "bad dims");
+    EMRT_REQUIRE(d.OH == (d.H + 2 * d.pad - d.KH) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.KW) / d.stride + 1, "output size mismatch");
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long in_ext = ((long long)(d.N - 1) * d.in_bs + ((long long)d.H * d.W - 1) * d.ldin + d.C) * esz;
+    EMRT_REQUIRE(d.in_bs >= 0 && in_ext < (1ll << 31) && (long long)d.OC * d.KH * d.KW * d.C * esz < (1ll << 31), "operand spans 2 GiB or more");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? conv_group_dispatch<float>(descs, n, st) : conv_group_dispatch<bf16_t>(descs, n, st);
+}
+
+template <class T>
+static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStream_t st) {
+  using Cfg = WgradCfg<T>;
+  BwdGroupArgs g;
+  bool groupable = true;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const EmrtConvBwdDesc& b = descs[i];
+    ConvArgs& d = g.d[i];
+    d.in = b.dy; d.w = b.w_bwd_packed; d.out = b.dx; d.bias = nullptr; d.res = b.accumulate ? b.dx : nullptr;
+    d.N = b.N; d.H = b.OH; d.W = b.OW; d.C = b.OC; d.ldin = b.lddy; d.in_bs = b.dy_bs;
+    d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
+    d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
+    d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.relu = 0; d.out_f32 = 0; d.stats = nullptr;
+    d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0;
+    WgradArgs& w = g.w[i];
+    w.x = b.x; w.dy = b.dy; w.dw = b.dw;
+    w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;
+    w.OH = b.OH; w.OW = b.OW; w.OC = b.OC; w.lddy = b.lddy; w.dy_bs = b.dy_bs;
+    w.KH = b.KH; w.KW = b.KW; w.stride = b.stride; w.pad = b.pad; w.tiles_per_split = 0; w.dbias = b.dbias;
+    const bool vec = conv_desc_is_vec<T>(d) && wgrad_is_vec<T>(w) && d.OC > 32;
+    groupable = groupable && vec;
+    int tx = 1, ty = 1, S = 1;
+    if (vec) wgrad_plan<T>(w, tx, ty, S);
+    const long long Md = (long long)d.N * d.OH * d.OW;
+    g.nd[i] = (int)(((Md + 63) / 64) * ((d.OC + 63) / 64));
+    g.wtx[i] = tx; g.wty[i] = ty;
+    g.first[i] = (int)total;
+    total += g.nd[i] + (long long)tx * ty * S;
+  }
+  for (int i = n; i <= EMRT_MAX_GROUP; ++i) g.first[i] = (int)total;
+  for (int i = n; i < EMRT_MAX_GROUP; ++i) { g.d[i] = g.d[0]; g.w[i] = g.w[0]; g.nd[i] = 0; g.wtx[i] = 1; g.wty[i] = 1; }
+  if (!groupable || total > 4096) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = conv_bwd_dispatch<T>(g.d[i], g.w[i], st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  auto kern = bwd_group_kernel<T>;
+  const size_t lds_d = (size_t)2 * 128 * 144, lds_w = (size_t)4 * Cfg::BKM * Cfg::PITCH;
+  const size_t lds = lds_d > lds_w ? lds_d : lds_w;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("emrt_conv2d_bwd_group", "cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, st, g);
+  return check_launch("emrt_conv2d_bwd_group");
+}
+
+extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream) {
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..4 problems");
+  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  for (int i = 0; i < n; ++i) {
+    const EmrtConvBwdDesc& b = descs[i];
+    EMRT_REQUIRE(b.x && b.dy && b.w_bwd_packed && b.dx && b.dw, "null pointer");
+    EMRT_REQUIRE(b.N > 0 && b.H > 0 && b.W > 0 && b.C > 0 && b.OC > 0 && b.KH > 0 && b.KW > 0 && b.stride > 0 && b.pad >= 0, "bad dims");
+    EMRT_REQUIRE(b.OH == (b.H + 2 * b.pad - b.KH) / b.stride + 1 && b.OW == (b.W + 2 * b.pad - b.KW) / b.stride + 1, "output size mismatch");
+    EMRT_REQUIRE(b.lddx >= b.C && b.dx_bs >= 0, "bad dx strides");
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long x_ext = ((long long)(b.N - 1) * b.x_bs + ((long long)b.H * b.W - 1) * b.ldx + b.C) * esz;
+    const long long dy_ext = ((long long)(b.N - 1) * b.dy_bs + ((long long)b.OH * b.OW - 1) * b.lddy + b.OC) * esz;
+    EMRT_REQUIRE(b.x_bs >= 0 && b.dy_bs >= 0 && x_ext < (1ll << 31) && dy_ext < (1ll << 31), "operand spans 2 GiB or more");
+    EMRT_REQUIRE((long long)b.H * b.W < (1 << 24) && (long long)b.ldx * esz < (1 << 24) && b.stride < (1 << 12), "map too large for the 24-bit address arithmetic");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? conv_bwd_group_dispatch<float>(descs, n, st) : conv_bwd_group_dispatch<bf16_t>(descs, n, st);
+}

@@ -7,6 +7,7 @@
 // nn.GroupNorm(32,256)+nn.GELU (transformer_encoder_decoder.py:125-144,378), nn.LayerNorm(256)
 // (transformer_encoder_decoder.py:116,123,251,256,264).
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace emrt;
 
@@ -598,6 +599,155 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const T* __restrict__
   }
 }
 
+// ---- GroupNorm over several levels of one token tensor in ONE launch -------------------------------------------------
+// x / res / out / dy / dx are [N][Lv][C]-shaped token tensors (row stride ld, batch stride bs); level l owns the rows
+// [start[l], start[l] + hw[l]) and has its own gamma / beta (and gradient) vectors.  One block per (level, image, group),
+// same two-pass body as the single-map kernels above.
+#define GN_MAX_LEVELS 4
+struct GnLevels {
+  int L;
+  int start[GN_MAX_LEVELS], hw[GN_MAX_LEVELS];
+  const float* gamma[GN_MAX_LEVELS];
+  const float* beta[GN_MAX_LEVELS];
+  float* dgamma[GN_MAX_LEVELS];
+  float* dbeta[GN_MAX_LEVELS];
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_levels_fwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ res,
+                                                            int ldres, long long res_bs, T* __restrict__ out, int ldout, long long out_bs,
+                                                            GnLevels lv, float* __restrict__ mean_out, float* __restrict__ rstd_out, int N,
+                                                            int C, int G, float eps, int gelu) {
+  __shared__ double red[2][4];
+  const int per_level = N * G;
+  const int l = blockIdx.x / per_level, rem = blockIdx.x % per_level;
+  const int n = rem / G, g = rem % G;
+  int HW = lv.hw[0], row0 = lv.start[0];
+  const float* gam = lv.gamma[0];
+  const float* bet = lv.beta[0];
+#pragma unroll
+  for (int k = 1; k < GN_MAX_LEVELS; ++k)
+    if (l == k) { HW = lv.hw[k]; row0 = lv.start[k]; gam = lv.gamma[k]; bet = lv.beta[k]; }
+  const int cpg = C / G, qg = cpg / 4, lanes = 256 / qg;
+  const int q = threadIdx.x % qg, ty = threadIdx.x / qg;
+  const int c = g * cpg + q * 4;
+  const T* xp = x + (long long)n * x_bs + (long long)row0 * ldx + c;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = ty; p < HW; p += lanes) {
+    float v[4];
+    Vec4<T>::load(xp + (long long)p * ldx, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s0 += v[e]; s1 = fmaf(v[e], v[e], s1); }
+  }
+  double a = (double)wave_sum(s0), b = (double)wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double cnt = (double)HW * cpg;
+  const double mu_d = a / cnt;
+  double var = b / cnt - mu_d * mu_d;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (mean_out && threadIdx.x == 0) { mean_out[blockIdx.x] = mu; rstd_out[blockIdx.x] = rs; }      // [level][n][g]
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = rs * gam[c + e]; sh[e] = bet[c + e] - mu * sc[e]; }
+  for (int p = ty; p < HW; p += lanes) {
+    float v[4], o[4];
+    Vec4<T>::load(xp + (long long)p * ldx, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = fmaf(v[e], sc[e], sh[e]);
+      o[e] = gelu ? gelu_f(u) : u;
+    }
+    if (res) {
+      float w[4];
+      Vec4<T>::load(res + (long long)n * res_bs + (long long)(row0 + p) * ldres + c, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += w[e];
+    }
+    Vec4<T>::store(out + (long long)n * out_bs + (long long)(row0 + p) * ldout + c, o);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_levels_bwd_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy,
+                                                            int lddy, long long dy_bs, T* __restrict__ dx, int lddx, long long dx_bs,
+                                                            GnLevels lv, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int N, int C, int G, int gelu) {
+  __shared__ float chs[256 * 8];
+  __shared__ float gsum[256 * 2];
+  __shared__ float grp[2];
+  const int per_level = N * G;
+  const int l = blockIdx.x / per_level, rem = blockIdx.x % per_level;
+  const int n = rem / G, g = rem % G;
+  int HW = lv.hw[0], row0 = lv.start[0];
+  const float* gam = lv.gamma[0];
+  const float* bet = lv.beta[0];
+  float* dgam = lv.dgamma[0];
+  float* dbet = lv.dbeta[0];
+#pragma unroll
+  for (int k = 1; k < GN_MAX_LEVELS; ++k)
+    if (l == k) { HW = lv.hw[k]; row0 = lv.start[k]; gam = lv.gamma[k]; bet = lv.beta[k]; dgam = lv.dgamma[k]; dbet = lv.dbeta[k]; }
+  const int cpg = C / G, qg = cpg / 4, lanes = 256 / qg;
+  const int q = threadIdx.x % qg, ty = threadIdx.x / qg;
+  const int c = g * cpg + q * 4;
+  const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+  float ga[4], be[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { ga[e] = gam[c + e]; be[e] = bet[c + e]; }
+  const T* xp = x + (long long)n * x_bs + (long long)row0 * ldx + c;
+  const T* gp = dy + (long long)n * dy_bs + (long long)row0 * lddy + c;
+  float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  for (int p = ty; p < HW; p += lanes) {
+    float v[4], d[4];
+    Vec4<T>::load(xp + (long long)p * ldx, v);
+    Vec4<T>::load(gp + (long long)p * lddy, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      s0[e] += dd;
+      s1[e] = fmaf(dd, xh, s1[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { chs[threadIdx.x * 8 + e] = s0[e]; chs[threadIdx.x * 8 + 4 + e] = s1[e]; }
+  __syncthreads();
+  if ((int)threadIdx.x < cpg) {
+    const int cc = threadIdx.x, qq = cc / 4, e = cc % 4;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < lanes; ++t) { a += chs[(t * qg + qq) * 8 + e]; b += chs[(t * qg + qq) * 8 + 4 + e]; }
+    if (dbet) atomicAdd(dbet + g * cpg + cc, (float)a);
+    if (dgam) atomicAdd(dgam + g * cpg + cc, (float)b);
+    gsum[cc * 2] = (float)((double)gam[g * cpg + cc] * a);
+    gsum[cc * 2 + 1] = (float)((double)gam[g * cpg + cc] * b);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) { a += gsum[cc * 2]; b += gsum[cc * 2 + 1]; }
+    const double inv = 1.0 / ((double)HW * cpg);
+    grp[0] = (float)(a * inv);
+    grp[1] = (float)(b * inv);
+  }
+  __syncthreads();
+  const float A = grp[0], Bq = grp[1];
+  for (int p = ty; p < HW; p += lanes) {
+    float v[4], d[4], o[4];
+    Vec4<T>::load(xp + (long long)p * ldx, v);
+    Vec4<T>::load(gp + (long long)p * lddy, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      o[e] = rs * (ga[e] * dd - A - xh * Bq);
+    }
+    Vec4<T>::store(dx + (long long)n * dx_bs + (long long)(row0 + p) * lddx + c, o);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim C (C % 4 == 0, C <= 1024) with fused residual add:
 //   z = a (+ b);  out = LN(z)*gamma + beta (+ post)        one wave per row, 4 rows per 256-thread block.
@@ -777,8 +927,15 @@ static inline bool bn_rowgeom(long long M, int C, int& threads, int& rows_per_pa
   if (quads <= 256) { if (256 % quads) return false; threads = 256; rows_per_pass = 256 / quads; }
   else if (quads <= 512) { threads = quads; rows_per_pass = 1; }          // C = 2048 -> 512 threads
   else return false;
-  long long g = (M + (long long)rows_per_pass * 4 - 1) / ((long long)rows_per_pass * 4);
-  if (g > 2048) g = 2048;
+  // every block first derives the per-channel constants (C x 16 fp64 loads + fp64 math, ~2 us of latency), so it should
+  // then stream a decent amount of data: ~32 KB of input per block, between 64 and 1024 blocks
+  const char* ov = getenv("EMRT_BN_BLOCK_KB");
+  const long long per_block = (ov ? atoll(ov) : 8) * 1024;
+  long long g = (M * C * 2 + per_block - 1) / per_block;
+  const long long gmax = (M + rows_per_pass - 1) / rows_per_pass;
+  if (g < 64) g = 64;
+  if (g > 4096) g = 4096;
+  if (g > gmax) g = gmax;
   if (g < 1) g = 1;
   grid = (int)g;
   return true;
@@ -995,4 +1152,51 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
             hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb));
   hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
+}
+
+static int gn_fill_levels(GnLevels& lv, const int* level_start, const int* level_hw, int L, const float* const* gamma, const float* const* beta,
+                          float* const* dgamma, float* const* dbeta) {
+  if (L < 1 || L > GN_MAX_LEVELS) return -1;
+  lv.L = L;
+  for (int l = 0; l < GN_MAX_LEVELS; ++l) {
+    const int s = l < L ? l : 0;
+    lv.start[l] = level_start[s]; lv.hw[l] = level_hw[s];
+    lv.gamma[l] = gamma[s]; lv.beta[l] = beta[s];
+    lv.dgamma[l] = dgamma ? dgamma[s] : nullptr; lv.dbeta[l] = dbeta ? dbeta[s] : nullptr;
+    if (!lv.gamma[l] || !lv.beta[l] || lv.hw[l] < 1 || lv.hw[l] > 4096 || lv.start[l] < 0) return -1;
+  }
+  return 0;
+}
+
+// GroupNorm (+GELU) (+residual) of L level slabs of token tensors [N][Lv][C] in one launch; mean/rstd are [L][N*G].
+extern "C" int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out,
+                                         int ldout, long long out_bs, const float* const* gamma, const float* const* beta, float* mean,
+                                         float* rstd, const int* level_start, const int* level_hw, int L, int N, int C, int G, float eps,
+                                         int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE(x && out && gamma && beta && level_start && level_hw, "null pointer");
+  EMRT_REQUIRE(G > 0 && C % G == 0 && gn_use_fused(1, C, G), "unsupported C / G for the one-block-per-group kernel");
+  EMRT_REQUIRE(ldx % 4 == 0 && ldout % 4 == 0 && x_bs % 4 == 0 && out_bs % 4 == 0 && (!res || (ldres % 4 == 0 && res_bs % 4 == 0)), "strides must be multiples of 4");
+  GnLevels lv;
+  EMRT_REQUIRE(gn_fill_levels(lv, level_start, level_hw, L, gamma, beta, nullptr, nullptr) == 0, "1..4 levels of at most 4096 rows");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_levels_fwd_kernel<float>), dim3(L * N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu),
+            hipLaunchKernelGGL((gn_levels_fwd_kernel<bf16_t>), dim3(L * N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu));
+  return check_launch("emrt_groupnorm_levels_fwd");
+}
+
+extern "C" int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx,
+                                         int lddx, long long dx_bs, const float* const* gamma, const float* const* beta,
+                                         const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta,
+                                         const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, int dtype,
+                                         void* stream) {
+  EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd && level_start && level_hw, "null pointer");
+  EMRT_REQUIRE(G > 0 && C % G == 0 && gn_use_fused(1, C, G), "unsupported C / G for the one-block-per-group kernel");
+  GnLevels lv;
+  EMRT_REQUIRE(gn_fill_levels(lv, level_start, level_hw, L, gamma, beta, dgamma, dbeta) == 0, "1..4 levels of at most 4096 rows");
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_levels_bwd_kernel<float>), dim3(L * N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, lv, mean, rstd, N, C, G, gelu),
+            hipLaunchKernelGGL((gn_levels_bwd_kernel<bf16_t>), dim3(L * N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, lv, mean, rstd, N, C, G, gelu));
+  return check_launch("emrt_groupnorm_levels_bwd");
 }

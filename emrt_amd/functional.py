@@ -491,6 +491,93 @@ def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residu
     return out
 
 
+class _ConvDesc(ctypes.Structure):        # EmrtConvDesc (include/emrt_hip.h)
+    _fields_ = [("inp", ctypes.c_void_p), ("w_packed", ctypes.c_void_p), ("out", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int),
+                ("ldin", ctypes.c_int), ("in_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int),
+                ("ldout", ctypes.c_int), ("out_bs", ctypes.c_longlong), ("ldres", ctypes.c_int), ("res_bs", ctypes.c_longlong),
+                ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int), ("relu", ctypes.c_int),
+                ("bn_stats", ctypes.c_void_p)]
+
+
+class _ConvBwdDesc(ctypes.Structure):     # EmrtConvBwdDesc
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("w_bwd_packed", ctypes.c_void_p), ("dx", ctypes.c_void_p),
+                ("lddx", ctypes.c_int), ("dx_bs", ctypes.c_longlong), ("accumulate", ctypes.c_int), ("dw", ctypes.c_void_p),
+                ("dbias", ctypes.c_void_p), ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int),
+                ("ldx", ctypes.c_int), ("x_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int),
+                ("lddy", ctypes.c_int), ("dy_bs", ctypes.c_longlong), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int),
+                ("pad", ctypes.c_int)]
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
+    """The conv branch of an encoder layer (transformer_encoder_decoder.py:125-144, 163-182) over ALL levels at once:
+        out[:, level l] = GELU(GroupNorm_l(conv3x3_l(src[:, level l] as an h_l x w_l map))) + src[:, level l]
+    src: dense tokens [B, Lv, C]; convs: GemmWeight per level (3x3, stride 1, pad 1, no bias); gns: (gamma, beta, dgamma,
+    dbeta) per level.  Two launches forward (grouped conv, multi-level GroupNorm) and two backward instead of six each:
+    the per-level problems are small, latency-bound launches on their own."""
+    c = ctx()
+    assert src.is_contiguous() and src.dim() == 3
+    B, Lv, C = src.shape
+    L = len(convs)
+    assert L == len(gns) == len(spatial_shapes) == len(level_spans) and 1 <= L <= 4
+    assert all(w.C == C and w.OC == C and w.KH == w.KW == 3 and w.bias is None for w in convs)
+    esz = src.element_size()
+    y = c.empty((B, Lv, C))
+    out = c.empty((B, Lv, C))
+    fd = (_ConvDesc * L)()
+    for l, (w, (h, wd), (s0, n)) in enumerate(zip(convs, spatial_shapes, level_spans)):
+        assert n == h * wd
+        d = fd[l]
+        d.inp, d.w_packed, d.out = src.data_ptr() + s0 * C * esz, w.fwd_ptr, y.data_ptr() + s0 * C * esz
+        d.bias = d.residual = d.bn_stats = None
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, h, wd, C, C, Lv * C
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = h, wd, C, C, Lv * C
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu = 0, 0, 3, 3, 1, 1, 0
+    _L().call("emrt_conv2d_group", fd, L, c.dtype, c.stream)
+    starts = (ctypes.c_int * L)(*[s0 for s0, _ in level_spans])
+    hws = (ctypes.c_int * L)(*[n for _, n in level_spans])
+    gam = (ctypes.c_void_p * L)(*[g[0].data_ptr() for g in gns])
+    bet = (ctypes.c_void_p * L)(*[g[1].data_ptr() for g in gns])
+    mean = c.empty((L * B * G,), torch.float32)
+    rstd = c.empty((L * B * G,), torch.float32)
+    _L().call("emrt_groupnorm_levels_fwd", P(y), C, Lv * C, P(src), C, Lv * C, P(out), C, Lv * C, gam, bet, P(mean), P(rstd), starts, hws, L,
+              B, C, G, eps, 1, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dout = tape.pop_grad(out)
+            if dout is None:
+                return
+            assert dout.is_contiguous()
+            dy = c.empty((B, Lv, C))
+            dgam = (ctypes.c_void_p * L)(*[_dp(g[2]) for g in gns])
+            dbet = (ctypes.c_void_p * L)(*[_dp(g[3]) for g in gns])
+            _L().call("emrt_groupnorm_levels_bwd", P(y), C, Lv * C, P(dout), C, Lv * C, P(dy), C, Lv * C, gam, bet, P(mean), P(rstd), dgam, dbet,
+                      starts, hws, L, B, C, G, 1, c.dtype, c.stream)
+            slot = tape.grad_slot(src)            # accumulate the data gradients straight into src's gradient when it has one
+            dx = slot if slot is not None else c.empty((B, Lv, C))
+            assert dx.is_contiguous()
+            bd = (_ConvBwdDesc * L)()
+            for l, (w, (h, wd), (s0, n)) in enumerate(zip(convs, spatial_shapes, level_spans)):
+                d = bd[l]
+                off = s0 * C * esz
+                d.x, d.dy, d.w_bwd_packed, d.dx = src.data_ptr() + off, dy.data_ptr() + off, w.bwd_ptr, dx.data_ptr() + off
+                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = C, Lv * C, int(slot is not None), w.grad.data_ptr(), None
+                d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, h, wd, C, C, Lv * C
+                d.OH, d.OW, d.OC, d.lddy, d.dy_bs = h, wd, C, C, Lv * C
+                d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+            _L().call("emrt_conv2d_bwd_group", bd, L, c.dtype, c.stream)
+            if slot is None:
+                tape.add_grad(src, dx, owned=True)
+            tape.add_grad(src, dout)              # the residual path of every level: one add over the whole token tensor
+        tape.record(bwd)
+    return out
+
+
 def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5):
     """out = LN(a + b) * gamma + beta (+ post);  a, b, post contiguous [.., C]."""
     c = ctx()

@@ -242,11 +242,18 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
 
     def forward(self, src, reference_points, spatial_shapes, level_spans, pos, pos_bgrad):  # :184-204
         B, Lv, C = src.shape
-        src_flatten = ctx().empty((B, Lv, C))
-        for (h, w), (s0, n), seq in zip(spatial_shapes, level_spans, (self.conv0, self.conv1, self.conv2)):
-            x_l = Fn.tokens_as_map(Fn.narrow(src, 1, s0, n), h, w)
-            y = seq[0](x_l)
-            seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
+        seqs = (self.conv0, self.conv1, self.conv2)
+        if src.is_contiguous() and all(n == h * w and n <= 4096 for (h, w), (_, n) in zip(spatial_shapes, level_spans)):
+            # all levels in one grouped conv launch + one multi-level GroupNorm launch (Fn.level_conv_gn)
+            src_flatten = Fn.level_conv_gn(src, [seq[0].gw for seq in seqs],
+                                           [(seq[1].weight.data, seq[1].bias.data, seq[1].weight.grad, seq[1].bias.grad) for seq in seqs],
+                                           spatial_shapes, level_spans)
+        else:
+            src_flatten = ctx().empty((B, Lv, C))
+            for (h, w), (s0, n), seq in zip(spatial_shapes, level_spans, seqs):
+                x_l = Fn.tokens_as_map(Fn.narrow(src, 1, s0, n), h, w)
+                y = seq[0](x_l)
+                seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
         q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
         src2 = self.self_attn(q, reference_points, src, spatial_shapes)
         src2 = Fn.dropout(src2, self.p, self.salts[0])

@@ -42,6 +42,23 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
 int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream);
+/* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE
+ * launch; problems that are not small vector-path ones are launched one by one instead.  Descriptors are host arrays. */
+typedef struct EmrtConvDesc {            /* the arguments of emrt_conv2d, mode 0, compute-dtype output */
+  const void* in; const void* w_packed; void* out; const float* bias; const void* residual;
+  int N, H, W, C, ldin; long long in_bs;
+  int OH, OW, OC, ldout; long long out_bs;
+  int ldres; long long res_bs;
+  int KH, KW, stride, pad, relu;
+  double* bn_stats;
+} EmrtConvDesc;
+typedef struct EmrtConvBwdDesc {         /* the arguments of emrt_conv2d_bwd without the fused BatchNorm sums */
+  const void* x; const void* dy; const void* w_bwd_packed; void* dx; int lddx; long long dx_bs; int accumulate; float* dw; float* dbias;
+  int N, H, W, C, ldx; long long x_bs; int OH, OW, OC, lddy; long long dy_bs; int KH, KW, stride, pad;
+} EmrtConvBwdDesc;
+int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream);
+int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream);
+
 /* backward of one conv / linear layer in one call (dx NHWC with strides lddx / dx_bs, overwritten or accumulated into; dW += ; dbias += when given; optional fused
  * BatchNorm-backward sums as in emrt_conv2d): small layers are ONE launch that runs the dgrad and wgrad tiles side by side */
 int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
@@ -63,6 +80,11 @@ int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long 
  * workspace: PRE-ZEROED fp64, [N*G*2] for fwd (group sums), [N*C*2] for bwd (per-image channel sums). */
 int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd, double* workspace, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream);
 int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean, const float* rstd, float* dgamma, float* dbeta, double* workspace, int N, int HW, int C, int G, int gelu, int dtype, void* stream);
+/* the same over L <= 4 level slabs (rows [level_start[l], +level_hw[l]), hw <= 4096) of token tensors [N][Lv][C], each with
+ * its own gamma / beta, in ONE launch: the per-level conv branch of an encoder layer (transformer_encoder_decoder.py:125-144,
+ * 163-182).  gamma / beta / dgamma / dbeta / level_* are HOST arrays of L entries; mean / rstd are [L][N*G]. */
+int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* const* gamma, const float* const* beta, float* mean, float* rstd, const int* level_start, const int* level_hw, int L, int N, int C, int G, float eps, int gelu, int dtype, void* stream);
+int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* const* gamma, const float* const* beta, const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta, const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, int dtype, void* stream);
 
 /* ---- residual add + LayerNorm (+ post add): transformer_encoder_decoder.py:199-203,159-160,285-291,278-279
  * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward. */

@@ -61,7 +61,9 @@ def test_train_step_launch_sequence(fake, backbone):
     opt.step()
     cnt = collections.Counter(n for n, _ in fake.calls)
     assert n_fwd > n_eval                                              # training adds dropout / statistics launches
-    assert cnt["emrt_conv2d_wgrad"] + cnt["emrt_conv2d_bwd"] == len(st.gemms)     # every GEMM weight gets exactly one weight gradient
+    n_grouped = sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_bwd_group")     # problems inside grouped backward launches
+    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 12       # 4 encoder layers x 3 levels
+    assert cnt["emrt_conv2d_wgrad"] + cnt["emrt_conv2d_bwd"] + n_grouped == len(st.gemms)     # every GEMM weight gets exactly one weight gradient
     assert cnt["emrt_conv2d_wgrad"] <= 4                               # alone only where no data gradient is needed (image-fed convs)
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
     assert cnt["emrt_bn_apply"] == cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
@@ -78,12 +80,14 @@ def test_train_step_launch_sequence(fake, backbone):
     assert fused_dx + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_dx <= n_fused
     assert fused_dx >= n_bn // 3, (fused_dx, n_bn)
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
-    assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14 and cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 15
+    assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14
+    assert cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 3 and cnt["emrt_groupnorm_levels_fwd"] == cnt["emrt_groupnorm_levels_bwd"] == 4
     assert cnt["emrt_softmax_ce_fwd"] == cnt["emrt_softmax_ce_bwd"] == 2
     assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
     # wgrad destinations are distinct slices inside the trainable gradient range
     g0 = st.grad.data_ptr()
     dws = [a[2].value - g0 for n, a in fake.calls if n == "emrt_conv2d_wgrad"] + [a[7].value - g0 for n, a in fake.calls if n == "emrt_conv2d_bwd"]
+    dws += [a[0][i].dw - g0 for n, a in fake.calls if n == "emrt_conv2d_bwd_group" for i in range(a[1])]
     assert len(set(dws)) == len(dws) and all(0 <= d < 4 * st.n_train for d in dws)
     # every device pointer handed to a conv is 2-byte aligned at least and non-null
     for n, a in fake.calls:
