@@ -578,6 +578,75 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
     return out
 
 
+def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
+    """input_proj of the encoder-decoder (transformer_encoder_decoder.py:375-379, 424-428) for all levels at once:
+        src[:, level l] = GroupNorm_l(conv1x1_l(feats[l]) + bias_l)          feats[l]: dense [B, h_l, w_l, C_l]
+    -> dense tokens [B, sum h_l w_l, OC].  One grouped conv launch + one multi-level GroupNorm launch each way."""
+    c = ctx()
+    L = len(feats)
+    assert L == len(convs) == len(gns) and 1 <= L <= 4
+    B = feats[0].shape[0]
+    OC = convs[0].OC
+    assert all(f.is_contiguous() and f.dim() == 4 and f.shape[0] == B for f in feats)
+    assert all(w.OC == OC and w.KH == w.KW == 1 and w.C == f.shape[3] for w, f in zip(convs, feats))
+    spans, s0 = [], 0
+    for f in feats:
+        spans.append((s0, f.shape[1] * f.shape[2]))
+        s0 += f.shape[1] * f.shape[2]
+    Lv = s0
+    esz = feats[0].element_size()
+    y = c.empty((B, Lv, OC))
+    src = c.empty((B, Lv, OC))
+    fd = (_ConvDesc * L)()
+    for l, (w, f, (a, n)) in enumerate(zip(convs, feats, spans)):
+        _, h, wd, Cl = f.shape
+        d = fd[l]
+        d.inp, d.w_packed, d.out, d.bias = f.data_ptr(), w.fwd_ptr, y.data_ptr() + a * OC * esz, _dp(w.bias)
+        d.residual = d.bn_stats = None
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, h, wd, Cl, Cl, h * wd * Cl
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = h, wd, OC, OC, Lv * OC
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu = 0, 0, 1, 1, 1, 0, 0
+    _L().call("emrt_conv2d_group", fd, L, c.dtype, c.stream)
+    starts = (ctypes.c_int * L)(*[a for a, _ in spans])
+    hws = (ctypes.c_int * L)(*[n for _, n in spans])
+    gam = (ctypes.c_void_p * L)(*[g[0].data_ptr() for g in gns])
+    bet = (ctypes.c_void_p * L)(*[g[1].data_ptr() for g in gns])
+    mean = c.empty((L * B * G,), torch.float32)
+    rstd = c.empty((L * B * G,), torch.float32)
+    _L().call("emrt_groupnorm_levels_fwd", P(y), OC, Lv * OC, None, 0, 0, P(src), OC, Lv * OC, gam, bet, P(mean), P(rstd), starts, hws, L,
+              B, OC, G, eps, 0, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dsrc = tape.pop_grad(src)
+            if dsrc is None:
+                return
+            assert dsrc.is_contiguous()
+            dy = c.empty((B, Lv, OC))
+            dgam = (ctypes.c_void_p * L)(*[_dp(g[2]) for g in gns])
+            dbet = (ctypes.c_void_p * L)(*[_dp(g[3]) for g in gns])
+            _L().call("emrt_groupnorm_levels_bwd", P(y), OC, Lv * OC, P(dsrc), OC, Lv * OC, P(dy), OC, Lv * OC, gam, bet, P(mean), P(rstd), dgam,
+                      dbet, starts, hws, L, B, OC, G, 0, c.dtype, c.stream)
+            slots = [tape.grad_slot(f) for f in feats]
+            dxs = [s_ if s_ is not None else c.empty(tuple(f.shape)) for s_, f in zip(slots, feats)]
+            bd = (_ConvBwdDesc * L)()
+            for l, (w, f, (a, n), dx) in enumerate(zip(convs, feats, spans, dxs)):
+                _, h, wd, Cl = f.shape
+                _, _, _, _, lddx, dx_bs = _check_map(dx)
+                d = bd[l]
+                d.x, d.dy, d.w_bwd_packed, d.dx = f.data_ptr(), dy.data_ptr() + a * OC * esz, w.bwd_ptr, dx.data_ptr()
+                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = lddx, dx_bs, int(slots[l] is not None), w.grad.data_ptr(), _dp(w.bias_grad) if w.bias is not None else None
+                d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, h, wd, Cl, Cl, h * wd * Cl
+                d.OH, d.OW, d.OC, d.lddy, d.dy_bs = h, wd, OC, OC, Lv * OC
+                d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+            _L().call("emrt_conv2d_bwd_group", bd, L, c.dtype, c.stream)
+            for s_, f, dx in zip(slots, feats, dxs):
+                if s_ is None:
+                    tape.add_grad(f, dx, owned=True)
+        tape.record(bwd)
+    return src, spans
+
+
 def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5):
     """out = LN(a + b) * gamma + beta (+ post);  a, b, post contiguous [.., C]."""
     c = ctx()

@@ -389,19 +389,40 @@ class EncoderDecoder(hnn.HipLayer):  # :337-473
             spans.append((s0, h * w))
             s0 += h * w
         Lv = s0
-        src = c.empty((B, Lv, C))
-        for f, (h, w), (a, n), proj in zip(src_feats, spatial_shapes, spans, self.input_proj):
-            y = proj[0](f)                                                       # 1x1 conv + bias
-            proj[1](y, out=Fn.tokens_as_map(Fn.narrow(src, 1, a, n), h, w))      # GroupNorm straight into the token slab
+        if all(f.is_contiguous() and n <= 4096 for f, (_, n) in zip(src_feats, spans)) and len(src_feats) <= 4:
+            # 1x1 conv + bias and GroupNorm of every level: one grouped conv launch + one multi-level GroupNorm launch
+            src, _ = Fn.level_proj_gn(list(src_feats), [p_[0].gw for p_ in self.input_proj],
+                                      [(p_[1].weight.data, p_[1].bias.data, p_[1].weight.grad, p_[1].bias.grad) for p_ in self.input_proj])
+        else:
+            src = c.empty((B, Lv, C))
+            for f, (h, w), (a, n), proj in zip(src_feats, spatial_shapes, spans, self.input_proj):
+                y = proj[0](f)                                                       # 1x1 conv + bias
+                proj[1](y, out=Fn.tokens_as_map(Fn.narrow(src, 1, a, n), h, w))      # GroupNorm straight into the token slab
         sine, ref_enc = self._constants(spatial_shapes)
         pos = c.empty((Lv, C))
         lvl = self.level_embed.weight
         for l, (a, n) in enumerate(spans):                                       # pos = sine + level_embed[l]  (:447-448)
             Fn._L().call("emrt_add_f32row", Fn.P(sine[a:a + n]), Fn.P(lvl.data[l]), Fn.P(pos[a:a + n]), n * C, C, c.dtype, c.stream)
 
-        def pos_bgrad(g):   # d level_embed[l] += sum over batch and the level's tokens
-            for l, (a, n) in enumerate(spans):
-                Fn.colsum_acc(g.narrow(1, a, n), lvl.grad[l])
+        # d level_embed[l] = sum over layers, batch and the level's tokens of the query gradients: the layers' gradients are
+        # first summed (one add each) and reduced once, by the tape entry below, which runs after every layer's backward
+        pos_acc = []
+
+        def pos_bgrad(g):
+            if not pos_acc:
+                pos_acc.append([g, False])
+            elif pos_acc[0][1]:
+                Fn.add_into(pos_acc[0][0], g)
+            else:
+                pos_acc[0] = [Fn.add_maps(pos_acc[0][0], g), True]
+
+        if c.tape is not None:
+            def pos_reduce():
+                if pos_acc:
+                    for l, (a, n) in enumerate(spans):
+                        Fn.colsum_acc(pos_acc[0][0].narrow(1, a, n), lvl.grad[l])
+                    pos_acc.clear()
+            c.tape.record(pos_reduce)
 
         memory = src
         for layer in self.encoder.layers:

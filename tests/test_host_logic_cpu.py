@@ -62,7 +62,7 @@ def test_train_step_launch_sequence(fake, backbone):
     cnt = collections.Counter(n for n, _ in fake.calls)
     assert n_fwd > n_eval                                              # training adds dropout / statistics launches
     n_grouped = sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_bwd_group")     # problems inside grouped backward launches
-    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 12       # 4 encoder layers x 3 levels
+    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15       # (4 encoder layers + input_proj) x 3 levels
     assert cnt["emrt_conv2d_wgrad"] + cnt["emrt_conv2d_bwd"] + n_grouped == len(st.gemms)     # every GEMM weight gets exactly one weight gradient
     assert cnt["emrt_conv2d_wgrad"] <= 4                               # alone only where no data gradient is needed (image-fed convs)
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
@@ -81,7 +81,7 @@ def test_train_step_launch_sequence(fake, backbone):
     assert fused_dx >= n_bn // 3, (fused_dx, n_bn)
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
     assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14
-    assert cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 3 and cnt["emrt_groupnorm_levels_fwd"] == cnt["emrt_groupnorm_levels_bwd"] == 4
+    assert cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 0 and cnt["emrt_groupnorm_levels_fwd"] == cnt["emrt_groupnorm_levels_bwd"] == 5
     assert cnt["emrt_softmax_ce_fwd"] == cnt["emrt_softmax_ce_bwd"] == 2
     assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
     # wgrad destinations are distinct slices inside the trainable gradient range
