@@ -758,10 +758,14 @@ template <class T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ post,
                                                      T* __restrict__ z, T* __restrict__ out, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ mean_out,
-                                                     float* __restrict__ rstd_out, long long rows, int C, float eps) {
+                                                     float* __restrict__ rstd_out, long long rows, int C, float eps, float pdrop,
+                                                     const unsigned long long* __restrict__ seed, unsigned salt) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  // optional inverted dropout on the branch input b (element key = its linear index, as emrt_dropout_fwd mode 0)
+  const unsigned long long sd = pdrop > 0.f ? seed[0] : 0ull;
+  const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
   const int nq = C / 256 + ((C % 256) ? 1 : 0);
   float v[4][4];
   float s = 0.f;
@@ -772,6 +776,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
       if (b) {
         float w[4];
         Vec4<T>::load(b + row * C + c, w);
+        if (pdrop > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the dropped value is rounded through T exactly as a separate dropout kernel would store it
+            const float d = uniform01(sd, salt, (unsigned long long)(row * C + c + e)) >= pdrop ? w[e] * ks : 0.f;
+            w[e] = to_f32(from_f32<T>(d));
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[j][e] += w[e];
       }
@@ -818,7 +830,11 @@ template <class T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
-                                                     int C, int rows_per_block) {
+                                                     int C, int rows_per_block, T* __restrict__ dzb, float pdrop,
+                                                     const unsigned long long* __restrict__ seed, unsigned salt) {
+  // dzb (optional): gradient of the dropped branch input, dz * mask / (1 - p)
+  const unsigned long long sd = (dzb && pdrop > 0.f) ? seed[0] : 0ull;
+  const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
   extern __shared__ float sm[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nq = C / 256 + ((C % 256) ? 1 : 0);
@@ -881,6 +897,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
         }
         Vec4<T>::store(dz + rowA * C + c, oA);
         if (okB) Vec4<T>::store(dz + rowB * C + c, oB);
+        if (dzb) {
+          if (pdrop > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // the mask is applied to the STORED dz (rounded through T), as a separate mask kernel would read it
+              oA[e] = uniform01(sd, salt, (unsigned long long)(rowA * C + c + e)) >= pdrop ? to_f32(from_f32<T>(oA[e])) * ks : 0.f;
+              oB[e] = uniform01(sd, salt, (unsigned long long)(rowB * C + c + e)) >= pdrop ? to_f32(from_f32<T>(oB[e])) * ks : 0.f;
+            }
+          }
+          Vec4<T>::store(dzb + rowA * C + c, oA);
+          if (okB) Vec4<T>::store(dzb + rowB * C + c, oB);
+        }
       }
     }
   }
@@ -1112,15 +1140,16 @@ extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const 
 }
 
 extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma,
-                                  const float* beta, float* mean, float* rstd, long long rows, int C, float eps, int dtype,
-                                  void* stream) {
+                                  const float* beta, float* mean, float* rstd, long long rows, int C, float eps, float pdrop,
+                                  const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
   EMRT_REQUIRE(a && out && gamma && beta, "null pointer");
+  EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && b)), "dropout needs 0 <= p < 1, a device seed and a branch input b");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)((rows + 3) / 4);
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)post, (float*)z, (float*)out, gamma, beta, mean, rstd, rows, C, eps),
-            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps));
+            hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)post, (float*)z, (float*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt),
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt));
   return check_launch("emrt_layernorm_fwd");
 }
 
@@ -1137,8 +1166,10 @@ extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
 }
 
 extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
-                                  float* dgamma, float* dbeta, long long rows, int C, void* workspace, int dtype, void* stream) {
+                                  float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop,
+                                  const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
   EMRT_REQUIRE(z && dy && dz && gamma && mean && rstd && workspace, "null pointer");
+  EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && dz_branch)), "dropout needs 0 <= p < 1, a device seed and dz_branch");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
   long long blocks = ln_bwd_blocks(rows);
   int rpb = (int)((rows + blocks - 1) / blocks);
@@ -1148,8 +1179,8 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   const size_t lds = (size_t)8 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb),
-            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb));
+            hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb, (float*)dz_branch, pdrop, seed, salt),
+            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb, (bf16_t*)dz_branch, pdrop, seed, salt));
   hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }

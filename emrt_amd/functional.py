@@ -647,18 +647,22 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
     return src, spans
 
 
-def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5):
-    """out = LN(a + b) * gamma + beta (+ post);  a, b, post contiguous [.., C]."""
+def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0, drop_salt=0):
+    """out = LN(a + dropout(b)) * gamma + beta (+ post);  a, b, post contiguous [.., C].  The inverted dropout on the branch
+    input b (every residual LayerNorm of the transformer has one in front: t_e_d.py:199,202,287,291,294) runs inside the
+    LayerNorm kernels: the forward drops b on the fly, the backward emits dz for a and the masked dz for b."""
     c = ctx()
     assert a.is_contiguous() and (b is None or b.is_contiguous()) and (post is None or post.is_contiguous())
     C = a.shape[-1]
     rows = a.numel() // C
     out = c.empty(tuple(a.shape))
     keep = c.tape is not None
+    p = float(drop_p) if (c.training and b is not None) else 0.0
     z = c.empty(tuple(a.shape)) if (keep and b is not None) else None
     mean = c.empty((rows,), torch.float32) if keep else None
     rstd = c.empty((rows,), torch.float32) if keep else None
-    _L().call("emrt_layernorm_fwd", P(a), P(b), P(post), P(z), P(out), P(gamma), P(beta), P(mean), P(rstd), rows, C, eps, c.dtype, c.stream)
+    _L().call("emrt_layernorm_fwd", P(a), P(b), P(post), P(z), P(out), P(gamma), P(beta), P(mean), P(rstd), rows, C, eps, p,
+              c.seed_ptr if p > 0 else None, drop_salt, c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         zz = z if z is not None else a
@@ -669,11 +673,16 @@ def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5):
                 return
             assert dy.is_contiguous()
             dz = c.empty(tuple(a.shape))
+            dzb = c.empty(tuple(a.shape)) if (b is not None and p > 0) else None
             ws = c.workspace(_L().query("emrt_layernorm_bwd_workspace_bytes", rows, C))
-            _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), c.dtype, c.stream)
+            _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), P(dzb), p,
+                      c.seed_ptr if p > 0 else None, drop_salt, c.dtype, c.stream)
             tape.add_grad(a, dz)
             if b is not None:
-                tape.add_grad(b, dz)
+                if dzb is not None:
+                    tape.add_grad(b, dzb, owned=True)
+                else:
+                    tape.add_grad(b, dz)
             if post is not None:
                 tape.add_grad(post, dy)
         tape.record(bwd)

@@ -256,12 +256,11 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
                 seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
         q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
         src2 = self.self_attn(q, reference_points, src, spatial_shapes)
-        src2 = Fn.dropout(src2, self.p, self.salts[0])
-        src = self.norm1(src, src2)
+        src = self.norm1(src, src2, drop_p=self.p, drop_salt=self.salts[0])       # LN(src + dropout1(src2)), dropout inside the LN kernels
         h1 = self.linear1(src, relu=True)
         h1 = Fn.dropout(h1, self.p, self.salts[1])
-        ff = Fn.dropout(self.linear2(h1), self.p, self.salts[2])
-        return self.norm2(src, ff, post=src_flatten)    # LN(src + ffn) + conv-branch tokens (:202-203)
+        ff = self.linear2(h1)
+        return self.norm2(src, ff, post=src_flatten, drop_p=self.p, drop_salt=self.salts[2])    # LN(src + dropout(ffn)) + conv-branch tokens (:202-203)
 
 
 class TransformerEncoder(hnn.HipLayer):  # :207-239
@@ -297,14 +296,12 @@ class TransformerDecoderLayer(hnn.HipLayer):  # :242-295
     def forward(self, tgt, reference_points, memory, spatial_shapes, query_pos, qpos_bgrad):  # :282-295
         Lq, C = tgt.shape[1], tgt.shape[2]
         q = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
-        tgt2 = Fn.dropout(self.self_attn(q, tgt), self.p, self.salts[0])
-        tgt = self.norm1(tgt, tgt2)
+        tgt = self.norm1(tgt, self.self_attn(q, tgt), drop_p=self.p, drop_salt=self.salts[0])        # dropout inside the LN kernels
         q2 = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
         tgt2 = self.cross_attn(q2, reference_points, memory, spatial_shapes, need_dref=True)
-        tgt = self.norm2(tgt, Fn.dropout(tgt2, self.p, self.salts[1]))
+        tgt = self.norm2(tgt, tgt2, drop_p=self.p, drop_salt=self.salts[1])
         h1 = Fn.dropout(self.linear1(tgt, relu=True), self.p, self.salts[2])
-        ff = Fn.dropout(self.linear2(h1), self.p, self.salts[3])
-        return self.norm3(tgt, ff)
+        return self.norm3(tgt, self.linear2(h1), drop_p=self.p, drop_salt=self.salts[3])
 
 
 class TransformerDecoder(hnn.HipLayer):  # :298-334

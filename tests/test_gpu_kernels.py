@@ -336,6 +336,37 @@ def test_layer_norm_residual_post(dtype):
     close("ln dbeta", host(ln.bias.grad), ber.grad, dtype, sc)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layer_norm_with_fused_branch_dropout(dtype):
+    """LN(a + dropout(b)) with the dropout inside the LayerNorm kernels must equal the composition of the stand-alone
+    dropout kernel (same device seed and salt => same mask) and the plain LayerNorm, forward and backward."""
+    c = init(dtype)
+    c.training = True
+    g = torch.Generator().manual_seed(8)
+    B, L, C = 2, 57, 256
+    a, b = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(2))
+    dy = rnd(torch.randn(B, L, C, generator=g))
+    res = {}
+    for mode in ("fused", "composed"):
+        ln = hnn.LayerNorm(C)
+        with torch.no_grad():
+            ln.weight.copy_(torch.linspace(0.5, 1.5, C))
+            ln.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        Holder(ln=ln).place()
+        ad, bd = dev(a), dev(b)
+        tape = Tape()
+        c.tape = tape
+        y = ln(ad, bd, drop_p=0.3, drop_salt=11) if mode == "fused" else ln(ad, Fn.dropout(bd, 0.3, 11))
+        c.tape = None
+        tape.watch(ad)
+        tape.watch(bd)
+        da, db = run_bwd(tape, [(y, dev(dy))], [ad, bd])
+        res[mode] = [host(t) for t in (y, da, db)] + [host(ln.weight.grad), host(ln.bias.grad)]
+    assert (res["fused"][2] == 0).float().mean() > 0.2                       # the branch gradient really is masked
+    for u, v, name in zip(res["fused"], res["composed"], ("y", "da", "db", "dgamma", "dbeta")):
+        assert (u - v).abs().max().item() <= 1e-6 * max(1.0, v.abs().max().item()), name
+
+
 # -----------------------------------------------------------------------------------------------------------------
 def _msda_ref(value, offw, ref, shapes, M, L, Pn):
     from oracle.emrt_torch import deformable_attention_core_func
