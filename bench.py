@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--overlap", default="", choices=["", "pair", "deferred"], help="wgrad on a second stream (A/B experiment)")
+    ap.add_argument("--two-phase", action="store_true", help="run the N>1 step structure (graphs around RCCL all-reduce) in a 1-rank group")
+    ap.add_argument("--no-early-exchange", action="store_true", help="N>1: one all-reduce after the whole backward (A/B experiment)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
 
@@ -97,7 +99,12 @@ def main():
     model.to_hip(str(dev), dtype, seed=1234 + rank)
     opt = Momentum(model, PolynomialDecay(0.01, 160000, 0.0, 0.9), momentum=0.9, weight_decay=1e-4, grad_clip=1.0)
     loss_fn = MixSoftmaxCrossEntropyLoss(ignore_index=255, aux=True, aux_weight=0.4)
-    eng = TrainEngine(model, opt, loss_fn, world, use_graph=not args.no_graph, overlap=args.overlap or False)
+    if args.two_phase and world == 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    eng = TrainEngine(model, opt, loss_fn, world, use_graph=not args.no_graph, overlap=args.overlap or False,
+                      two_phase=True if args.two_phase else None, early_exchange=not args.no_early_exchange)
     g = torch.Generator().manual_seed(1234 + rank)
     B, S = args.batch, args.size
     images = torch.randn(B, 3, S, S, generator=g).to(dev)
@@ -233,6 +240,7 @@ def main():
         }
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -28,9 +28,9 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
-def bucket_slices(n, bucket_elems):
-    """Contiguous [start, end) slices covering [0, n)."""
-    out, s = [], 0
+def bucket_slices(n, bucket_elems, start=0):
+    """Contiguous [start, end) slices covering [start, n)."""
+    out, s = [], start
     while s < n:
         e = min(n, s + bucket_elems)
         out.append((s, e))
@@ -44,16 +44,19 @@ class FlatGradReducer:
 
     def __init__(self, flat_grad, n, world_size, bucket_elems=32 * 1024 * 1024, always=False):
         self.flat, self.n, self.world = flat_grad, n, world_size
+        self.bucket = bucket_elems
         self.slices = bucket_slices(n, bucket_elems)
         self.handles = []
         self.always = always        # issue the collectives even in a 1-rank group (single-GPU test of the N > 1 path)
 
-    def launch(self):
-        self.handles = []
+    def launch(self, ranges=None):
+        """ranges=None: the whole buffer.  Otherwise a list of [start, end) element ranges (each bucketed); handles
+        accumulate until wait(), so an early launch(early_ranges) can overlap the rest of backward."""
         if self.world <= 1 and not self.always:
             return
         use_avg = self.flat.is_cuda
-        for s, e in self.slices:
+        slices = self.slices if ranges is None else [b for a, e in ranges for b in bucket_slices(e, self.bucket, a)]
+        for s, e in slices:
             t = self.flat[s:e]
             if use_avg:
                 self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True), None))

@@ -4,8 +4,10 @@
 
 Every kernel of the step is launched on torch's current stream, so after a few eager warm-up steps the whole step is
 captured into a hipGraph (torch.cuda.CUDAGraph) and replayed: ~1.5k launches cost one graph launch on the host.
-With world_size > 1 the step is captured as two graphs around the gradient all-reduce (graph A: zero/fwd/loss/bwd;
-eager: bucketed all-reduce(AVG) of the flat gradient buffer over RCCL; graph B: optimizer), and the five SyncBatchNorm
+With world_size > 1 the step is captured as three graphs around the gradient exchange: graph A1 (zero/fwd/loss/backward
+down to the ResNet layer4 input) -> launch the bucketed RCCL all-reduce(AVG) of the flat-gradient ranges that are final
+by then (heads, transformer, layer4) -> graph A2 (backward of layer3..conv1, overlapping the collective) -> all-reduce
+of the remaining ranges -> graph B (clip + optimizer); early_exchange=False keeps one graph A and one exchange.  The five SyncBatchNorm
 layers use per-rank statistics inside the captured region (documented deviation, DESIGN.md "Multi-GPU"); in eager mode
 (use_graph=False) they all-reduce their statistics as the reference's nn.SyncBatchNorm does.
 """
@@ -21,7 +23,7 @@ _SEED_STRIDE = 0x2545F4914F6CDD1D
 
 class TrainEngine:
     def __init__(self, model, optimizer, loss_fn, world_size=1, use_graph=True, warmup_eager=2, bucket_elems=32 * 1024 * 1024,
-                 overlap=False, two_phase=None):
+                 overlap=False, two_phase=None, early_exchange=True):
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.world = world_size
         self.use_graph = use_graph
@@ -38,23 +40,54 @@ class TrainEngine:
         self.two_phase = (world_size > 1) if two_phase is None else bool(two_phase)
         self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems,
                                        always=self.two_phase) if self.two_phase else None
+        # early exchange: backward runs in two parts around the model's split mark (ResNet.forward, before layer4); the
+        # gradients that are final after the first part (heads, transformer, layer4: ~80 % of the elements) are
+        # all-reduced on RCCL's stream while the second part (layer3 .. conv1, ~half of backward's time) still runs
+        late = getattr(model, "late_grad_prefixes", None)
+        self.early_ranges = self.late_ranges = None
+        if self.two_phase and early_exchange and late:
+            self.early_ranges, self.late_ranges = model.store.split_ranges(late)
+        self.graph_a2 = None
 
     # -- pieces ------------------------------------------------------------------------------------
-    def _fwd_bwd(self, images, labels):
+    def _fwd_bwd(self, images, labels, split=False):
+        """split=False: the whole forward + backward, returns the loss tensor.  split=True: stops backward at the model's
+        split mark and returns (loss tensor, rest) where rest() runs the remaining backward ops."""
         c = ctx()
         _lib.lib().call("emrt_counter_add", Fn.P(c._seed), _SEED_STRIDE & 0x7FFFFFFFFFFFFFFF, c.stream)   # fresh dropout masks
         self.model.clear_gradients()
         out = self.model(images)
         loss = self.loss_fn(out, labels)
+        if split:
+            rest = loss.backward_until_split()
+
+            def finish():
+                rest()
+                ctx().join_all()
+            return loss.tensor, finish
         loss.backward()
         ctx().join_all()               # side-stream weight gradients (if any) land before the reducer / optimizer
         return loss.tensor
 
+    def _exchange(self, finish_backward):
+        """Gradient all-reduce around the second part of backward (finish_backward: callable or graph replay)."""
+        if self.early_ranges is None:
+            self.reducer.allreduce()
+            return
+        self.reducer.launch(self.early_ranges)      # RCCL stream picks up after everything enqueued so far
+        finish_backward()
+        self.reducer.launch(self.late_ranges)
+        self.reducer.wait()
+
     def _eager_step(self, images, labels):
         ctx().sync_bn = True
-        loss_t = self._fwd_bwd(images, labels)
-        if self.reducer is not None:
-            self.reducer.allreduce()
+        if self.early_ranges is not None:
+            loss_t, finish = self._fwd_bwd(images, labels, split=True)
+            self._exchange(finish)
+        else:
+            loss_t = self._fwd_bwd(images, labels)
+            if self.reducer is not None:
+                self.reducer.allreduce()
         self.opt.step()
         return loss_t
 
@@ -65,14 +98,24 @@ class TrainEngine:
         self.labels = labels.clone()
         c.workspace(64 << 20)
         torch.cuda.synchronize()
+        # with a process group alive, ProcessGroupNCCL's watchdog thread polls events while we capture: the default
+        # "global" capture mode turns such a foreign-thread call into a capture error (seen as a watchdog abort)
+        mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.loss_t = self._fwd_bwd(self.images, self.labels)
-            if self.reducer is None:
-                self.opt.step()
+        if self.early_ranges is not None:
+            with torch.cuda.graph(self.graph_a, **mode):
+                self.loss_t, finish = self._fwd_bwd(self.images, self.labels, split=True)
+            self.graph_a2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool(), **mode):
+                finish()
+        else:
+            with torch.cuda.graph(self.graph_a, **mode):
+                self.loss_t = self._fwd_bwd(self.images, self.labels)
+                if self.reducer is None:
+                    self.opt.step()
         if self.reducer is not None:
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **mode):
                 self.opt.step()
 
     # -- public ------------------------------------------------------------------------------------
@@ -90,7 +133,7 @@ class TrainEngine:
                 self.labels.copy_(labels, non_blocking=True)
             self.graph_a.replay()
             if self.reducer is not None:
-                self.reducer.allreduce()
+                self._exchange(self.graph_a2.replay if self.graph_a2 is not None else None)
                 self.graph_b.replay()
             loss_t = self.loss_t
         self.opt._learning_rate.step()       # host mirror of the device step counter (train.py:156-158)

@@ -75,6 +75,7 @@ class ParamStore:
             p.grad = gview
             p.requires_grad_(False)
             self.views[n] = (a, cnt)
+        self.train_order = order[:self.n_trainable_names]
         self.lr_ranges = [(self.offsets[n], self.offsets[n] + by_name[n].numel()) for n in lr_mult_names]
         self.lr_mult = lr_mult
         # buffers (BN running statistics): one flat fp32 buffer
@@ -94,6 +95,20 @@ class ParamStore:
         self.desc = None
         self.total_tiles = 0
         self.dirty = True
+
+    def split_ranges(self, late_prefixes):
+        """Partition [0, n_train) of the flat buffers into (early, late) lists of [start, end): `late` holds the parameters
+        whose name starts with one of `late_prefixes`, `early` everything else; alignment padding goes with the run before."""
+        runs = []
+        for n in self.train_order:
+            late = n.startswith(tuple(late_prefixes))
+            if not runs or runs[-1][0] != late:
+                runs.append([late, self.offsets[n]])
+        early, late = [], []
+        for i, (is_late, start) in enumerate(runs):
+            end = runs[i + 1][1] if i + 1 < len(runs) else self.n_train
+            (late if is_late else early).append((start, end))
+        return early, late
 
     # ---- GEMM weights ---------------------------------------------------------------------------
     def make_gemm(self, offset, OC, C, KH=1, KW=1, bias_offset=None, need_bwd=True):

@@ -27,6 +27,7 @@ class Tape:
         self.alias = {}     # id(view) -> (base, slicer)
         self.watched = {}   # id(t) -> t : tensors whose gradient survives backward() (tests / debugging)
         self.results = {}
+        self.split = 0      # len(ops) when the model reached its early-exchange point (0 = no split recorded)
 
     def watch(self, t):
         self.keep.append(t)
@@ -131,10 +132,14 @@ class Tape:
         else:
             e[0], e[1] = Fn.add_maps(e[0], g), True
 
-    def backward(self):
+    def backward(self, stop_at=0):
+        """Run the recorded closures newest-first.  stop_at > 0 stops once only the first `stop_at` ops are left (the
+        engine's early gradient exchange: everything recorded after `self.split` first, the rest in a second call)."""
         _CTX.tape = None            # backward kernels must not record
-        for fn in reversed(self.ops):
-            fn()
+        while len(self.ops) > stop_at:
+            self.ops.pop()()
+        if stop_at > 0:
+            return
         self.results = {k: self.grad(t) for k, t in self.watched.items()}
         self.ops = []
         self.grads = {}
@@ -160,6 +165,7 @@ class Context:
         self._arena_live = False
         self.overlap = False      # run independent backward kernels (wgrad next to dgrad) on a second HIP stream
         self._side = None
+        self._main = None         # the stream every launch of this runtime goes to (torch's current stream after init_device)
 
     # ---- second stream -------------------------------------------------------------------------------------------
     # overlap = False | "pair" | "deferred".  fork() returns the side stream (C handle) ordered after everything issued so
@@ -194,6 +200,14 @@ class Context:
         _lib.lib()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
+        # One explicitly created stream carries all work and becomes torch's current stream.  On the NULL stream,
+        # back-to-back hipGraph launches (graph A -> graph B -> graph A ... of the multi-GPU step) were measured to lose
+        # their ordering whenever the host was not running ahead of the GPU (DESIGN.md "Multi-GPU"); a created stream
+        # orders them as it should.
+        if self._main is None or self._main.device != self.device:
+            self._main = torch.cuda.Stream(device=self.device)
+        self._main.wait_stream(torch.cuda.default_stream(self.device))
+        torch.cuda.set_stream(self._main)
         self.dtype = dtype
         self._ws = torch.empty(8 << 20, dtype=torch.uint8, device=self.device)
         self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)

@@ -16,6 +16,17 @@ class LossValue:
         self.tape.backward()
         self.tape = None
 
+    def backward_until_split(self):
+        """First part of backward(): every op recorded after the model's split mark.  Returns a callable that runs the rest."""
+        if self.tape is None:
+            raise RuntimeError("loss was computed in eval mode; nothing to differentiate")
+        tape, self.tape = self.tape, None
+        if tape.split <= 0:
+            tape.backward()
+            return lambda: None
+        tape.backward(stop_at=tape.split)
+        return tape.backward
+
     def item(self):
         return float(self.tensor[0].item())
 

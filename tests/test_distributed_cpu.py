@@ -33,6 +33,20 @@ def _worker(rank, world, port, q):
         want = torch.arange(n + 24, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
         assert torch.allclose(flat[:n], want[:n])
         assert torch.equal(flat[n:], torch.arange(n, n + 24, dtype=torch.float32) * (rank + 1))
+        # 1b. early exchange: two ranged launches (the second after "more backward" has filled the late range), one wait
+        flat = torch.zeros(n + 24)
+        flat[:300] = rank + 1.0
+        flat[700:n] = 10.0 * (rank + 1)
+        red = FlatGradReducer(flat, n, world, bucket_elems=128)
+        red.launch([(0, 300), (700, n)])
+        red_handles = len(red.handles)
+        flat[300:700] = 100.0 * (rank + 1)          # written after the first launch, exchanged by the second
+        red.launch([(300, 700)])
+        assert red_handles == 3 + 3 and len(red.handles) == red_handles + 4
+        red.wait()
+        m = sum(range(1, world + 1)) / world
+        assert torch.allclose(flat[:300], torch.full((300,), m)) and torch.allclose(flat[300:700], torch.full((400,), 100 * m))
+        assert torch.allclose(flat[700:n], torch.full((300,), 10 * m)) and not flat[n:].any() and not red.handles
         # 2. DP identity on a BN-free piece of the oracle (decoder layer): mean of per-rank grads == full-batch grads
         from oracle.emrt_torch import TransformerDecoderLayer
         torch.manual_seed(0)
@@ -85,3 +99,4 @@ def test_bucket_slices():
     assert bucket_slices(10, 4) == [(0, 4), (4, 8), (8, 10)]
     assert bucket_slices(8, 8) == [(0, 8)]
     assert bucket_slices(0, 8) == []
+    assert bucket_slices(10, 4, 3) == [(3, 7), (7, 10)]

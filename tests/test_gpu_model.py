@@ -234,20 +234,100 @@ def test_two_phase_dp_step_over_rccl_matches_single_graph():
         x = torch.randn(B, 3, S, S, generator=g)
         labels = torch.randint(0, 6, (B, S, S), generator=g)
         losses = {}
-        for mode in ("single", "two_phase"):
+        for mode in ("single", "two_phase", "one_exchange"):
             ref, model = build_pair("resnet18", x)
             cfg = make_config("resnet18", iters=100)
             opt = get_optimizer(model, get_scheduler(cfg), cfg)
-            eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=True, warmup_eager=1, two_phase=(mode == "two_phase"),
-                              bucket_elems=4 * 1024 * 1024)
+            eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=True, warmup_eager=1, two_phase=(mode != "single"),
+                              bucket_elems=4 * 1024 * 1024, early_exchange=(mode == "two_phase"))
             losses[mode] = [eng.step(x.cuda(), labels.cuda()).item() for _ in range(4)]
-            if mode == "two_phase":
+            if mode != "single":
                 assert eng.graph_b is not None and eng.reducer is not None and len(eng.reducer.slices) > 1
-        for a, b in zip(losses["single"], losses["two_phase"]):
-            assert abs(a - b) < 1e-3 * max(1.0, abs(a)), losses
+                assert (eng.graph_a2 is not None) == (mode == "two_phase")
+        for mode in ("two_phase", "one_exchange"):
+            for a, b in zip(losses["single"], losses[mode]):
+                assert abs(a - b) < 1e-3 * max(1.0, abs(a)), losses
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_split_graphs_keep_their_order_when_the_host_waits_each_step():
+    """Regression: with the step captured as several hipGraphs (A1 / A2 / B around the gradient exchange) and the host
+    synchronising every step (so each graph is launched while its predecessor is still RUNNING rather than queued),
+    launches on the NULL stream lost their ordering -- the optimizer read half-written gradients and the loss blew up
+    within ~10 steps at this size.  runtime.Context.init_device therefore moves all work to a created stream.  bf16
+    ResNet-50 at 256x256 (the size it showed at), dropout off, three-graph engine vs the single-graph engine."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        g = torch.Generator().manual_seed(3)
+        B, S = 8, 256
+        x = torch.randn(B, 3, S, S, generator=g)
+        labels = torch.randint(0, 6, (B, S, S), generator=g)
+        traces = {}
+        for mode in ("single", "split"):
+            torch.manual_seed(7)
+            cfg = make_config("resnet50", iters=1000)
+            model = get_model(cfg)
+            model.to_hip("cuda:0", BF16, seed=11)
+            model.set_dropout(0.0)
+            assert torch.cuda.current_stream().cuda_stream != 0, "the runtime must not run on the NULL stream"
+            opt = get_optimizer(model, get_scheduler(cfg), cfg)
+            eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=True, warmup_eager=1, two_phase=(mode == "split"))
+            xs, ls = x.cuda(), labels.cuda()
+            tr = []
+            for _ in range(24):
+                tr.append(eng.step(xs, ls).item())          # .item(): the host waits for the step, then launches the next
+            traces[mode] = tr
+            assert (eng.graph_a2 is not None) == (mode == "split")
+        for a, b in zip(traces["single"], traces["split"]):
+            assert b == b and abs(a - b) < 0.02 * max(1.0, abs(a)), traces
+        assert traces["split"][-1] < traces["split"][0]
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backbone", ["resnet18", "resnet50"])
+def test_early_exchange_ranges_are_final_at_the_split(backbone):
+    """The early gradient exchange (engine.py) all-reduces `early_ranges` of the flat gradient buffer while the second
+    part of backward still runs.  That is only correct if the second part never writes them: run the two parts eagerly
+    and compare the buffer before / after -- early ranges bit-identical, late ranges zero before and filled after,
+    the two sets tiling [0, n_train) exactly."""
+    g = torch.Generator().manual_seed(5)
+    B, S = 2, 64
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    ref, model = build_pair(backbone, x)
+    cfg = make_config(backbone, iters=100)
+    opt = get_optimizer(model, get_scheduler(cfg), cfg)
+    eng = TrainEngine(model, opt, get_loss_function(cfg), 1, use_graph=False)
+    early, late = model.store.split_ranges(model.late_grad_prefixes)
+    cover = sorted(early + late)
+    assert cover[0][0] == 0 and cover[-1][1] == model.store.n_train
+    assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and late
+    model.train()
+    _, finish = eng._fwd_bwd(x.cuda(), labels.cuda(), split=True)
+    torch.cuda.synchronize()
+    before = model.store.grad.clone()
+    for a, e in late:
+        assert not before[a:e].any(), "a late-range gradient was written before the split"
+    assert sum(float(before[a:e].abs().sum()) for a, e in early) > 0
+    finish()
+    torch.cuda.synchronize()
+    after = model.store.grad
+    for a, e in early:
+        assert torch.equal(before[a:e], after[a:e]), "backward's second part wrote an early-range gradient"
+    names = [n for n in model.store.train_order if n.startswith(model.late_grad_prefixes) and n.endswith("weight")]
+    for n in names:
+        a, cnt = model.store.views[n]
+        assert after[a:a + cnt].abs().sum() > 0, n
 
 
 def test_bf16_path_is_sane():
