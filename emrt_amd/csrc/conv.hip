@@ -926,6 +926,232 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Thin backward: 1x1, stride 1, OC <= 8 (the per-pixel classifier, 256 -> num_classes at 128x128).  As GEMMs its dgrad has
+// K = OC and its wgrad a OC x C output: MFMA tiles would be > 80 % padding and the two kernels would stream x, y and dx
+// separately.  Here ONE pass reads x (which is also the ReLU-mask source y when they coincide) and dy once and writes dx
+// once: a thread owns 8 channels of one pixel, its W^T slice and its dW partial stay in registers; the block reduces
+// dW / dbias / the BatchNorm sums through LDS and issues one atomic per value.  Same arithmetic order as the igemm
+// epilogue: accumulate -> mask -> round -> statistics of the rounded value.
+// ------------------------------------------------------------------------------------------------
+struct ThinBwdArgs {
+  const void* x; const void* dy; const void* wd; void* dx; float* dw; float* dbias; double* stats; const void* mask_y;
+  int HW, C, OC, ldx, lddy, lddx, ldy, accumulate, pix_per_block, cg_shift;
+  long long x_bs, dy_bs, dx_bs, y_bs, M;
+};
+
+// MASK: 0 no ReLU mask, 1 the mask source is x itself (y = relu(bn(.)) feeds this conv), 2 a separate tensor.  ACC: dx +=.
+// CH channels per thread (4: 128 registers, 4 blocks per CU; 8: 16-byte bf16 accesses, 2 blocks per CU).
+template <class T, int CH>
+struct VecN;
+template <class T>
+struct VecN<T, 4> : Vec4<T> {};
+template <class T>
+struct VecN<T, 8> : Vec8<T> {};
+
+template <class T, int CH, int MASK, bool ACC>
+__global__ __launch_bounds__(256, CH == 4 ? 4 : 2) void thin_bwd_kernel(ThinBwdArgs p) {
+  constexpr int U = 2;              // pixels in flight per thread
+  using V = VecN<T, CH>;
+  __shared__ float red[32 * 256];
+  const T* x = (const T*)p.x;
+  const T* dy = (const T*)p.dy;
+  const T* wd = (const T*)p.wd;
+  const T* ym = (const T*)p.mask_y;
+  T* dx = (T*)p.dx;
+  const int tid = threadIdx.x;
+  const int CG = 1 << p.cg_shift, ppb = 256 >> p.cg_shift;
+  const int cg = tid & (CG - 1), pl = tid >> p.cg_shift;
+  const int c0 = (int)blockIdx.y * (CH << p.cg_shift) + cg * CH;     // blockIdx.y: channel chunk
+  // the dy row of a pixel (OC <= 8 values) is fetched by the first OC lanes of each lane group working on that pixel
+  // (ONE load instruction per wave) and handed round with ds_bpermute: eight same-address scalar loads per pixel
+  // were what bound the first version of this kernel (the texture-address path, not HBM)
+  const int lane = tid & 63;
+  const int grp = CG < 64 ? CG : 64;
+  const int gpos = lane & (grp - 1), gbase = lane - gpos;
+  float w[8][CH], dwa[8][CH], ss[CH], sq[CH], db[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    db[o] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      w[o][j] = o < p.OC ? to_f32(wd[(c0 + j) * p.OC + o]) : 0.f;
+      dwa[o][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { ss[j] = 0.f; sq[j] = 0.f; }
+  // 32-bit element offsets throughout (thin_bwd_ok checks that every operand stays below 2^31 elements)
+  const int xbs = (int)p.x_bs, dybs = (int)p.dy_bs, dxbs = (int)p.dx_bs, ybs = (int)p.y_bs, M = (int)p.M;
+  const int m0 = (int)blockIdx.x * p.pix_per_block;
+  const int m1 = m0 + p.pix_per_block < M ? m0 + p.pix_per_block : M;
+  // mb is uniform per lane group, so ok[u] is too and the shuffles below stay inside converged groups
+  for (int mb = m0 + pl; mb < m1; mb += U * ppb) {
+    float xv[U][CH], yv[U][CH], old[U][CH], mydy[U];
+    bool ok[U];
+    int oo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {            // all loads of the U pixels first
+      const int m = mb + u * ppb;
+      ok[u] = m < m1;
+      mydy[u] = 0.f;
+      if (!ok[u]) continue;
+      const int nb = m / p.HW;
+      const int pix = m - nb * p.HW;
+      oo[u] = nb * dxbs + pix * p.lddx + c0;
+      V::load(x + (nb * xbs + pix * p.ldx + c0), xv[u]);
+      if (MASK == 2) V::load(ym + (nb * ybs + pix * p.ldy + c0), yv[u]);
+      if (ACC) V::load(dx + oo[u], old[u]);
+      if (gpos < p.OC) mydy[u] = to_f32(dy[nb * dybs + pix * p.lddy + gpos]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float dyv[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) dyv[o] = __shfl(mydy[u], gbase + o, 64);     // executed by every lane (0 for the dead tail)
+      if (!ok[u]) continue;
+      float v[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) a = fmaf(dyv[o], w[o][j], a);
+        if (ACC) a += old[u][j];
+        float second = 0.f;
+        if (MASK) {
+          second = MASK == 1 ? xv[u][j] : yv[u][j];
+          a = second > 0.f ? a : 0.f;
+        }
+        v[j] = a;
+        const float q = to_f32(from_f32<T>(a));
+        ss[j] += q;
+        sq[j] = fmaf(q, MASK ? second : q, sq[j]);
+      }
+      V::store(dx + oo[u], v);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) dwa[o][j] = fmaf(dyv[o], xv[u][j], dwa[o][j]);
+        if (cg == 0 && blockIdx.y == 0) db[o] += dyv[o];
+      }
+    }
+  }
+  // dW through red[k][tid] in rounds of 32 values (k = o * CH + j); thread t then owns channel group t % CG and every
+  // ppb-th k of the round
+#pragma unroll
+  for (int rnd = 0; rnd < CH / 4; ++rnd) {
+    if (rnd * 32 >= p.OC * CH) break;
+    if (rnd) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; ++k) red[k * 256 + tid] = dwa[(rnd * 32 + k) / CH][(rnd * 32 + k) % CH];
+    __syncthreads();
+    for (int k = pl; k < 32; k += ppb) {
+      const int kk = rnd * 32 + k;
+      if (kk >= p.OC * CH) break;
+      float a = 0.f;
+      for (int q = 0; q < ppb; ++q) a += red[k * 256 + q * CG + cg];
+      atomicAdd(p.dw + (kk / CH) * p.C + c0 + (kk % CH), a);
+    }
+  }
+  if (p.stats || p.dbias) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      red[k * 256 + tid] = ss[k];
+      red[(CH + k) * 256 + tid] = sq[k];
+    }
+    if (cg == 0) {      // (zeros from the channel chunks other than the first)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[(2 * CH + k) * 256 + pl] = db[k];
+    }
+    __syncthreads();
+    if (p.stats) {
+      double* rep = p.stats + (long long)(blockIdx.x & 7) * 2 * p.C;
+      for (int k = pl; k < 2 * CH; k += ppb) {
+        float a = 0.f;
+        for (int q = 0; q < ppb; ++q) a += red[k * 256 + q * CG + cg];
+        atomicAdd(rep + (k / CH) * p.C + c0 + (k % CH), (double)a);
+      }
+    }
+    if (p.dbias && tid < p.OC) {
+      float a = 0.f;
+      for (int q = 0; q < ppb; ++q) a += red[(2 * CH + tid) * 256 + q];
+      atomicAdd(p.dbias + tid, a);
+    }
+  }
+}
+
+template <class T>
+static bool thin_bwd_ok(const ConvArgs& d, const WgradArgs& w) {
+  constexpr int EPC = 4;                  // a thread moves 4 channels: 16 B (f32) / 8 B (bf16)
+  const int C = w.C;
+  if (w.KH != 1 || w.KW != 1 || w.stride != 1 || w.pad != 0 || w.OC > 8) return false;
+  if (C < 32 || C > 1024 || (C & (C - 1))) return false;
+  const long long px = (long long)w.H * w.W - 1, LIM = 1ll << 31;
+  if ((long long)w.N * w.H * w.W >= LIM || (w.N - 1) * w.x_bs + px * w.ldx + C >= LIM || (w.N - 1) * d.out_bs + px * d.ldout + C >= LIM ||
+      (w.N - 1) * w.dy_bs + px * w.lddy + w.OC >= LIM || (d.mask_y && (w.N - 1) * d.y_bs + px * d.ldy + C >= LIM)) return false;
+  auto al = [](const void* q) { return ((uintptr_t)q) % 16 == 0; };
+  if (!al(w.x) || !al(d.out) || (d.mask_y && !al(d.mask_y))) return false;
+  if (w.ldx % EPC || w.x_bs % EPC || d.ldout % EPC || d.out_bs % EPC) return false;
+  if (d.mask_y && (d.ldy % EPC || d.y_bs % EPC)) return false;
+  return true;
+}
+
+template <class T, int CH>
+static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t st) {
+  ThinBwdArgs a;
+  a.x = w.x; a.dy = w.dy; a.wd = d.w; a.dx = d.out; a.dw = w.dw; a.dbias = w.dbias; a.stats = d.stats; a.mask_y = d.mask_y;
+  a.HW = w.H * w.W; a.C = w.C; a.OC = w.OC; a.ldx = w.ldx; a.lddy = w.lddy; a.lddx = d.ldout; a.ldy = d.ldy;
+  a.accumulate = d.res != nullptr;
+  a.x_bs = w.x_bs; a.dy_bs = w.dy_bs; a.dx_bs = d.out_bs; a.y_bs = d.y_bs;
+  a.M = (long long)w.N * w.H * w.W;
+  // Grid = pixel chunks x channel chunks.  Every block ends with OC * (its channels) fp32 atomics into dW, and those are
+  // what bounds the kernel (measured on 8x128x128x256 -> 6: one channel chunk with 1024 pixel chunks 155 us, 256 chunks 90 us, without the atomics
+  // 47-60 us; 4 channel chunks x 128 pixel chunks 46 us; the MFMA pair before it 214 us): few, long pixel
+  // chunks keep the atomic count down, the channel chunks (whole 128-byte lines per pixel) restore the block count.
+  const char* ec = getenv("EMRT_THIN_CBLK");       // developer knobs
+  const char* eb = getenv("EMRT_THIN_BLOCKS");
+  int cblk = ec ? atoi(ec) : 64;
+  if (cblk < 8 * CH) cblk = 8 * CH;               // a lane group must hold the OC <= 8 lanes that fetch the dy row
+  if (cblk > w.C) cblk = w.C;
+  if (cblk > 256 * CH) cblk = 256 * CH;
+  int sh = 0;
+  while ((CH << sh) < cblk) ++sh;
+  a.cg_shift = sh;
+  const int cchunks = w.C / (CH << sh);
+  const int ppb = 256 >> sh;
+  const long long want_chunks = eb ? atoll(eb) : 128;
+  long long per = (a.M + want_chunks - 1) / want_chunks;
+  per = (per + 2 * ppb - 1) / (2 * ppb) * (2 * ppb);
+  if (per < 8 * ppb) per = 8 * ppb;
+  a.pix_per_block = (int)per;
+  const long long blocks = (a.M + per - 1) / per;
+  const bool same = d.mask_y && d.mask_y == w.x && d.ldy == w.ldx && d.y_bs == w.x_bs;
+  const int mask = !d.mask_y ? 0 : (same ? 1 : 2);
+  const dim3 grid((unsigned)blocks, (unsigned)cchunks), block(256);
+  if (a.accumulate) {      // (the C-ABI excludes accumulate together with a mask)
+    hipLaunchKernelGGL((thin_bwd_kernel<T, CH, 0, true>), grid, block, 0, st, a);
+  } else if (mask == 0) {
+    hipLaunchKernelGGL((thin_bwd_kernel<T, CH, 0, false>), grid, block, 0, st, a);
+  } else if (mask == 1) {
+    hipLaunchKernelGGL((thin_bwd_kernel<T, CH, 1, false>), grid, block, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((thin_bwd_kernel<T, CH, 2, false>), grid, block, 0, st, a);
+  }
+  return check_launch("emrt_conv2d_bwd");
+}
+
+template <class T>
+static int thin_bwd_launch(const ConvArgs& d, const WgradArgs& w, hipStream_t st) {
+  const char* e = getenv("EMRT_THIN_CH");     // developer knob
+  const int want = e ? atoi(e) : 8;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const bool can8 = w.C >= 64 && w.ldx % 8 == 0 && w.x_bs % 8 == 0 && d.ldout % 8 == 0 && d.out_bs % 8 == 0 &&
+                    (!d.mask_y || (d.ldy % 8 == 0 && d.y_bs % 8 == 0)) && EPC <= 8;
+  if (want == 8 && can8) return thin_bwd_launch_ch<T, 8>(d, w, st);
+  return thin_bwd_launch_ch<T, 4>(d, w, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward of one conv / linear layer in one call: dx (= or +=, any NHWC strides: a token slab or channel slice of a
 // gradient buffer is written in place) = dgrad(dy, W^T) [masked by y > 0 with BatchNorm sums, see ConvArgs::mask_y]
 // and dW += wgrad(x, dy) [+ dbias].  Small layers go out as ONE launch (bwd_pair_kernel); large
@@ -943,6 +1169,7 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   const long long nd = ((Md + 63) / 64) * ((d.OC + 63) / 64);                 // 64x64 dgrad tiles
   const int nkt = (d.KH * d.KW * d.C + BK - 1) / BK;
   const bool big_tile = d.OC > 64 && nkt >= 16 && ((Md + 127) / 128) * ((d.OC + 127) / 128) >= 256;   // conv_pick_tile would take 128x128
+  if (thin_bwd_ok<T>(d, w0) && !getenv("EMRT_NO_THIN_BWD")) return thin_bwd_launch<T>(d, w0, st);
   int tx = 0, ty = 0, S = 0;
   if (vec_w) wgrad_plan<T>(w, tx, ty, S);
   const long long nw = (long long)tx * ty * S;

@@ -35,6 +35,7 @@ CONV_CASES = [
     (2, 32, 32, 3, 64, 7, 2, 3, False),
     (2, 16, 16, 3, 64, 3, 1, 1, False),
     (2, 24, 24, 256, 6, 1, 1, 0, True),
+    (3, 17, 19, 512, 7, 1, 1, 0, True),      # thin_bwd_kernel: ragged pixel count, 7 classes
     (1, 40, 40, 64, 192, 3, 1, 1, True),
     (2, 8, 8, 512, 128, 3, 1, 1, False),
 ]
@@ -188,7 +189,8 @@ def test_batch_norm_train(dtype, shape, relu, with_res):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, True), (2, 12, 12, 256, 128, 1, 0, True), (2, 16, 16, 64, 64, 3, 1, False)])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, True), (2, 12, 12, 256, 128, 1, 0, True), (2, 16, 16, 64, 64, 3, 1, False),
+                                  (2, 24, 24, 256, 6, 1, 0, True), (3, 13, 11, 64, 7, 1, 0, True), (2, 9, 9, 128, 6, 1, 0, False)])   # last three: thin_bwd_kernel (OC <= 8)
 def test_bn_relu_conv_chain_backward_fused_in_dgrad(dtype, case):
     """x -> BatchNorm -> ReLU -> conv: the conv's dgrad applies the ReLU mask and accumulates the BatchNorm's backward sums
     (sum dy', sum dy'*y; xhat = (y - beta) / gamma where y > 0), so emrt_bn_bwd_reduce is not launched.  With a second

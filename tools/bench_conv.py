@@ -56,8 +56,31 @@ def timed(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+def thin():
+    """The thin backward kernel (OC <= 8, 1x1) on the classifier shape: block count / channels per thread sweep."""
+    N, H, W, C, OC = 8, 128, 128, 256, 6
+    x = torch.randn(N, H, W, C, device=dev).bfloat16()
+    dy = torch.randn(N, H, W, OC, device=dev).bfloat16()
+    wb = (torch.randn(C, OC, device=dev) * 0.05).bfloat16()
+    dx = torch.empty_like(x)
+    dw = torch.zeros(OC, C, device=dev, dtype=torch.float32)
+    db = torch.zeros(OC, device=dev, dtype=torch.float32)
+    stats = torch.zeros(8 * 2 * C, device=dev, dtype=torch.float64)
+
+    def run(mask):
+        L._raw_emrt_conv2d_bwd(P(x), P(dy), P(wb), P(dx), C, H * W * C, 0, P(dw), P(db), N, H, W, C, C, H * W * C, H, W, OC, OC, H * W * OC,
+                               1, 1, 1, 0, P(stats) if mask else None, P(x) if mask else None, C if mask else 0, H * W * C if mask else 0, 1, stream)
+    for ch in (8, 4):
+        for cblk in (64, 128, 256):
+            for blocks in (64, 128, 256, 512):
+                os.environ.update(EMRT_THIN_CH=str(ch), EMRT_THIN_BLOCKS=str(blocks), EMRT_THIN_CBLK=str(cblk))
+                print("CH %d cblk %3d pixel chunks %4d: masked+stats %.1f us  plain %.1f us" % (ch, cblk, blocks, timed(lambda: run(True)), timed(lambda: run(False))), flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "thin":
+        return thin()
     for (N, H, W, C, OC, k, s, pad) in SHAPES:
         OH = (H + 2 * pad - k) // s + 1
         OW = (W + 2 * pad - k) // s + 1
