@@ -44,6 +44,7 @@ struct ConvArgs {
   // statistics become (sum v, sum v * mask_y).  dgrad of a conv whose input is y = relu(BatchNorm(x)) uses it to produce
   // the masked dy AND that BatchNorm's backward sums in one pass: where y > 0, xhat = (y - beta) / gamma.
   const void* mask_y;
+  float mask_scale;   // kept outputs are multiplied by this (1 for a ReLU; 1/(1-p) for dropout(relu(.)))
   int ldy;
   long long y_bs;
 };
@@ -377,7 +378,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
         float second = 0.f;              // what the second statistic multiplies v with
         if (ymask) {
           second = to_f32(ymask[ybase + n]);
-          v = second > 0.f ? v : 0.f;
+          v = second > 0.f ? v * p.mask_scale : 0.f;
         }
         if (p.out_f32) ((float*)p.out)[obase + n] = v;
         else {
@@ -827,7 +828,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
-  a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs;
+  a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f;
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
@@ -936,6 +937,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
 struct ThinBwdArgs {
   const void* x; const void* dy; const void* wd; void* dx; float* dw; float* dbias; double* stats; const void* mask_y;
   int HW, C, OC, ldx, lddy, lddx, ldy, accumulate, pix_per_block, cg_shift;
+  float mask_scale;
   long long x_bs, dy_bs, dx_bs, y_bs, M;
 };
 
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(256, CH == 4 ? 4 : 2) void thin_bwd_kernel(ThinBwdA
         float second = 0.f;
         if (MASK) {
           second = MASK == 1 ? xv[u][j] : yv[u][j];
-          a = second > 0.f ? a : 0.f;
+          a = second > 0.f ? a * p.mask_scale : 0.f;
         }
         v[j] = a;
         const float q = to_f32(from_f32<T>(a));
@@ -1102,6 +1104,7 @@ static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t
   a.x = w.x; a.dy = w.dy; a.wd = d.w; a.dx = d.out; a.dw = w.dw; a.dbias = w.dbias; a.stats = d.stats; a.mask_y = d.mask_y;
   a.HW = w.H * w.W; a.C = w.C; a.OC = w.OC; a.ldx = w.ldx; a.lddy = w.lddy; a.lddx = d.ldout; a.ldy = d.ldy;
   a.accumulate = d.res != nullptr;
+  a.mask_scale = d.mask_scale;
   a.x_bs = w.x_bs; a.dy_bs = w.dy_bs; a.dx_bs = d.out_bs; a.y_bs = d.y_bs;
   a.M = (long long)w.N * w.H * w.W;
   // Grid = pixel chunks x channel chunks.  Every block ends with OC * (its channels) fp32 atomics into dW, and those are
@@ -1199,7 +1202,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
                                int accumulate, float* dw, float* dbias,
                                int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs,
                                int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
-                               int dtype, void* stream) {
+                               float mask_scale, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && w_bwd_packed && dx && dw, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
@@ -1222,7 +1225,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(lddx >= C && dx_bs >= 0, "bad dx strides");
   EMRT_REQUIRE(!(accumulate && mask_y), "the fused ReLU mask / BatchNorm sums need dx to be this layer's only gradient");
   d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
-  d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs;
+  d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale;
   WgradArgs w;
   w.x = x; w.dy = dy; w.dw = dw;
   w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
@@ -1290,7 +1293,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
   a.ldres = d.ldres; a.res_bs = d.res_bs;
   a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.relu = d.relu; a.out_f32 = 0; a.stats = d.bn_stats;
-  a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0;
+  a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f;
 }
 
 template <class T>
@@ -1355,7 +1358,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
     d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.relu = 0; d.out_f32 = 0; d.stats = nullptr;
-    d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0;
+    d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f;
     WgradArgs& w = g.w[i];
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;
     w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;

@@ -233,8 +233,12 @@ def cast_to_f32(x):
     return out
 
 
-def dropout(x, p, salt, mode=0, hw=1):
-    """Inverted dropout (mode 0) / Dropout2D on NHWC (mode 1); identity unless training."""
+def dropout(x, p, salt, mode=0, hw=1, sole_consumer_is_linear=False):
+    """Inverted dropout (mode 0) / Dropout2D on NHWC (mode 1); identity unless training.
+    sole_consumer_is_linear: the caller promises that x is a fresh conv2d/linear(relu=True) output and that the result
+    feeds exactly one conv2d/linear (the FFN: linear2(dropout(relu(linear1(.))))).  That consumer's data gradient then
+    comes out already multiplied by this dropout's mask and the ReLU's (one test `y > 0`, scale 1/(1-p), in its dgrad
+    epilogue), and neither this op nor the producer's ReLU runs a mask pass of its own."""
     c = ctx()
     if not c.training or p <= 0.0:
         return x
@@ -243,10 +247,19 @@ def dropout(x, p, salt, mode=0, hw=1):
     C = x.shape[-1]
     _L().call("emrt_dropout_fwd", P(x), P(y), x.numel(), float(p), c.seed_ptr, salt, mode, hw, C, c.dtype, c.stream)
     tape = c.tape
+    rec = None
+    if tape is not None and sole_consumer_is_linear and mode == 0:
+        rec = {"scale": 1.0 / (1.0 - float(p)), "dx": None}
+        y._drop_rec = rec
     if tape is not None:
         def bwd():
-            g = tape.pop_grad(y)
+            g, ncontrib = tape.pop_grad(y, with_count=True)
             if g is None:
+                return
+            if rec is not None and rec["dx"] is not None:
+                assert ncontrib == 1 and rec["dx"] is g, "dropout(sole_consumer_is_linear=True) output had another consumer"
+                x._premasked = g                  # the producer's ReLU backward is done too (y > 0 implies relu input > 0)
+                tape.add_grad(x, g, owned=True)
                 return
             assert g.is_contiguous()
             dx = c.empty(tuple(x.shape), x.dtype)
@@ -293,6 +306,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
               c.dtype, c.stream)
     tape = c.tape
     bn_rec = getattr(x, "_bn_rec", None)      # x = relu(BatchNorm(.)) fresh from batch_norm(): see the dgrad call below
+    drop_rec = getattr(x, "_drop_rec", None)  # x = dropout(relu(linear(.))) with this layer as its only consumer
     if tape is not None:
         def bwd():
             dy = tape.pop_grad(out)
@@ -300,7 +314,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 return
             if out_f32:
                 dy = cast_from_f32(dy)
-            if relu:
+            if relu and getattr(out, "_premasked", None) is not dy:
                 assert dy.is_contiguous() and out.is_contiguous()
                 dm = c.empty(tuple(dy.shape), dy.dtype)
                 _L().call("emrt_mask_bwd", P(dy), P(out), P(dm), dy.numel(), 0.0, None, 0, 0, 1, 1, c.dtype, c.stream)
@@ -315,6 +329,9 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 dx = slot if slot is not None else c.empty(tuple(x.shape))
                 _, _, _, _, lddx, dx_bs = _check_map(dx)
                 ysums = ymask = None
+                mscale = 1.0
+                if drop_rec is not None and bn_rec is None and slot is None and not c.overlap:
+                    ymask, mscale = x, drop_rec["scale"]
                 if bn_rec is not None and c.training and slot is None:
                     # dgrad also applies that BatchNorm's ReLU mask and accumulates its backward sums (sum dy', sum dy'*y):
                     # the BatchNorm's own reduction pass is skipped when this turns out to be its only gradient
@@ -326,7 +343,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                     _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), lddx, dx_bs, int(slot is not None), P(w.grad), dbias,
                               N, H, W, C, ldin, in_bs,
                               OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, P(ysums), P(ymask), ldin if ymask is not None else 0,
-                              in_bs if ymask is not None else 0, c.dtype, c.stream)
+                              in_bs if ymask is not None else 0, float(mscale), c.dtype, c.stream)
                 else:       # two-stream experiment (Context.overlap): wgrad on the side stream next to dgrad
                     _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
                               w.KH, w.KW, stride, pad, dbias, c.dtype, side)
@@ -335,8 +352,10 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                               w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
                               in_bs if ymask is not None else 0, c.dtype, c.stream)
                     c.join()
-                if ymask is not None:
+                if ysums is not None:
                     bn_rec["dx"], bn_rec["sums"] = dx, ysums
+                elif ymask is not None:
+                    drop_rec["dx"] = dx
             if residual is not None:
                 tape.add_grad(residual, dy)
             if need_dx and slot is None:

@@ -60,8 +60,10 @@ int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream)
 int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream);
 
 /* backward of one conv / linear layer in one call (dx NHWC with strides lddx / dx_bs, overwritten or accumulated into; dW += ; dbias += when given; optional fused
- * BatchNorm-backward sums as in emrt_conv2d): small layers are ONE launch that runs the dgrad and wgrad tiles side by side */
-int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
+ * BatchNorm-backward sums as in emrt_conv2d): small layers are ONE launch that runs the dgrad and wgrad tiles side by side.
+ * With mask_y, dx = mask_y > 0 ? mask_scale * dgrad : 0: mask_scale = 1 for a ReLU, 1/(1-p) when mask_y is the output of
+ * dropout(relu(.)) -- the FFN's dropout and ReLU backward cost no pass of their own */
+int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, float mask_scale, int dtype, void* stream);
 
 /* ---- BatchNorm / SyncBatchNorm (train: fp64 sums [from the conv epilogue or emrt_bn_stats] -> [all-reduce of sums across
  * ranks] -> apply; eval: running statistics).  replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add):

@@ -369,6 +369,66 @@ def test_layer_norm_with_fused_branch_dropout(dtype):
         assert (u - v).abs().max().item() <= 1e-6 * max(1.0, v.abs().max().item()), name
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dims", [(2, 57, 256, 1024), (3, 110, 64, 96)])
+def test_ffn_dropout_relu_masks_fused_into_linear2_dgrad(dtype, dims):
+    """linear2(dropout(relu(linear1(x)))) with sole_consumer_is_linear=True: linear2's dgrad applies both masks (one test
+    on its input, scale 1/(1-p)) and no emrt_mask_bwd runs.  Reference: torch autograd with the mask read back from the
+    device's own dropout output, and the unfused composition on the device (identical seed => identical mask)."""
+    from emrt_amd import _lib
+    B, Lq, C, Hd = dims
+    c = init(dtype)
+    c.training = True
+    p = 0.3
+    g = torch.Generator().manual_seed(77)
+    x = rnd(torch.randn(B, Lq, C, generator=g))
+    dy = rnd(torch.randn(B, Lq, C, generator=g))
+    w1, b1 = rnd(torch.randn(Hd, C, generator=g) / math.sqrt(C)), torch.randn(Hd, generator=g) * 0.1
+    w2, b2 = rnd(torch.randn(C, Hd, generator=g) / math.sqrt(Hd)), torch.randn(C, generator=g) * 0.1
+    res, names = {}, {}
+    for mode in ("fused", "composed"):
+        l1, l2 = hnn.Linear(C, Hd), hnn.Linear(Hd, C)
+        with torch.no_grad():
+            l1.weight.copy_(w1)
+            l1.bias.copy_(b1)
+            l2.weight.copy_(w2)
+            l2.bias.copy_(b2)
+        Holder(l1=l1, l2=l2).place()
+        xd = dev(x)
+        tape = Tape()
+        c.tape = tape
+        h = l1(xd, relu=True)
+        hd = Fn.dropout(h, p, 23, sole_consumer_is_linear=(mode == "fused"))
+        o = l2(hd)
+        c.tape = None
+        tape.watch(xd)
+        L = _lib.lib()
+        L.start_record()
+        dx, = run_bwd(tape, [(o, dev(dy))], [xd])
+        names[mode] = [n for n, _ in L.stop_record()]
+        res[mode] = [host(t) for t in (o, dx, l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad)] + [host(h), host(hd)]
+    assert "emrt_mask_bwd" not in names["fused"] and names["composed"].count("emrt_mask_bwd") == 2
+    for u, v, name in zip(res["fused"][:6], res["composed"][:6], ("o", "dx", "dw1", "db1", "dw2", "db2")):
+        close("ffn fused vs composed " + name, u, v, dtype, max(1.0, v.abs().max().item()) * (0.01 if dtype == F32 else 1.0))
+    # torch reference with the device's mask
+    hh, hdd = res["fused"][6], res["fused"][7]
+    keep = ((hdd != 0) | (hh <= 0)).float()
+    assert 0.6 < keep[hh > 0].mean() < 0.8
+    xr = x.clone().requires_grad_(True)
+    W1 = w1.clone().requires_grad_(True)
+    B1, W2, B2 = b1.clone().requires_grad_(True), w2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    hr = F.relu(F.linear(xr, W1, B1))
+    if dtype == BF16:
+        hr = hr + (rnd(hr.detach()) - hr.detach())            # the device stores h in bf16 before the dropout scales it
+    orf = F.linear(hr * keep / (1 - p), W2, B2)
+    (orf * dy).sum().backward()
+    sc = math.sqrt(B * Lq)
+    close("ffn o", res["fused"][0], orf.detach(), dtype, 2.0)
+    close("ffn dx", res["fused"][1], xr.grad, dtype, 3.0 * (1.0 if dtype == F32 else 0.3))
+    close("ffn db1", res["fused"][3], B1.grad, dtype, sc * (1.0 if dtype == F32 else 0.5))
+    close("ffn db2", res["fused"][5], B2.grad, dtype, sc)
+
+
 # -----------------------------------------------------------------------------------------------------------------
 def _msda_ref(value, offw, ref, shapes, M, L, Pn):
     from oracle.emrt_torch import deformable_attention_core_func

@@ -73,8 +73,14 @@ def test_train_step_launch_sequence(fake, backbone):
     assert sum(1 for a in fwd_convs if a[25] is not None) == n_bn     # forward statistics fused into the conv epilogue
     # BatchNorm -> ReLU -> conv chains: the conv's dgrad carries the ReLU mask and the BatchNorm's backward sums, and the
     # separate reduction pass only remains for the other BatchNorms (residual joins, multi-consumer outputs, no ReLU)
-    n_fused = sum(1 for a in dgrads if a[25] is not None)
-    assert all((a[24] is not None) == (a[25] is not None) for a in dgrads)
+    n_fused = sum(1 for a in dgrads if a[24] is not None)
+    assert all(a[25] is not None and a[28] == 1.0 for a in dgrads if a[24] is not None)
+    # FFNs: linear2's dgrad applies the dropout mask and the ReLU mask of dropout(relu(linear1)) (mask source = its input,
+    # scale 1/(1-p)); no separate mask pass is left for them
+    n_ffn = sum(1 for mod in m.modules() if type(mod).__name__ in ("TransformerEncoderLayer", "TransformerDecoderLayer"))
+    ffn = [a for a in dgrads if a[25] is not None and a[24] is None]
+    assert len(ffn) == n_ffn > 0 and all(abs(a[28] - 1.0 / 0.9) < 1e-6 and a[25].value == a[0].value for a in ffn)
+    assert cnt["emrt_mask_bwd"] == cnt["emrt_dropout_fwd"] - n_ffn
     assert not any(a[6] and a[25] is not None for a in dgrads)       # in-place accumulation and the fused mask exclude each other
     fused_dx = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[20] is not None)
     assert fused_dx + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_dx <= n_fused
