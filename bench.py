@@ -93,6 +93,8 @@ def main():
     if world != args.gpus:
         log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     dtype = BF16 if args.dtype == "bf16" else F32
+    if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(1234)
     model = EMRT(num_classes=6, backbone="resnet50")

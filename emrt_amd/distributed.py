@@ -20,7 +20,9 @@ def init_process_group(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # EMRT_DIST_BACKEND=gloo: test aid -- several ranks can then share ONE GPU (RCCL refuses duplicate devices), which is
+        # how the multi-rank step is exercised on a single-GPU box (tests/test_gpu_dp2.py)
+        backend = backend or os.environ.get("EMRT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
@@ -54,13 +56,13 @@ class FlatGradReducer:
         accumulate until wait(), so an early launch(early_ranges) can overlap the rest of backward."""
         if self.world <= 1 and not self.always:
             return
-        use_avg = self.flat.is_cuda
+        use_avg = dist.get_backend() == "nccl"
         slices = self.slices if ranges is None else [b for a, e in ranges for b in bucket_slices(e, self.bucket, a)]
         for s, e in slices:
             t = self.flat[s:e]
             if use_avg:
                 self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True), None))
-            else:   # gloo has no AVG: sum then scale (CPU tests only)
+            else:   # gloo has no AVG: sum then scale (CPU tests, single-GPU multi-rank test)
                 self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t))
 
     def wait(self):

@@ -1,0 +1,109 @@
+"""-m gpu: the data-parallel step with TWO real ranks on ONE GPU.  RCCL refuses two ranks on one device, so the ranks talk
+over gloo (EMRT_DIST_BACKEND=gloo, device tensors staged through the host by the backend): everything above the transport
+-- engine structure (three hipGraphs, early gradient exchange), FlatGradReducer on the device buffer, SyncBatchNorm's
+statistics all-reduce in eager mode, per-rank dropout streams -- is the code that runs at N > 1 on a multi-GPU node."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      EMRT_DIST_BACKEND="gloo")
+    import argparse
+    import torch.distributed as dist
+    from emrt_amd.config import get_config, update_config
+    from emrt_amd.distributed import init_process_group
+    from emrt_amd.engine import TrainEngine
+    from emrt_amd.runtime import F32
+    from emrt_amd.src.models import get_model
+    from emrt_amd.src.models.losses import get_loss_function
+    from emrt_amd.src.models.solver import get_optimizer, get_scheduler
+    here = os.path.dirname(os.path.abspath(__file__))
+    r, _, w = init_process_group()
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    try:
+        cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(here, "..", "emrt_amd", "configs", "EMRT", "EMRT_256x256_160k_potsdam.yaml")))
+        cfg.MODEL.ENCODER.TYPE = "resnet18"
+        cfg.TRAIN.ITERS = 100
+        g = torch.Generator().manual_seed(100 + rank)          # every rank its own tiles
+        B, S = 2, 64
+        x = torch.randn(B, 3, S, S, generator=g).cuda()
+        labels = torch.randint(0, 6, (B, S, S), generator=g).cuda()
+
+        def build():
+            torch.manual_seed(5)                               # identical initial weights on every rank
+            model = get_model(cfg)
+            model.to_hip("cuda:0", F32, seed=9 + rank)
+            model.set_dropout(0.0)
+            return model, get_optimizer(model, get_scheduler(cfg), cfg)
+
+        # 1. the reducer on the real device buffer: averaged flat gradient == mean of the ranks' local gradients
+        model, opt = build()
+        eng = TrainEngine(model, opt, get_loss_function(cfg), world, use_graph=False, early_exchange=False)
+        model.train()
+        eng._fwd_bwd(x, labels)
+        n = model.store.n_train
+        local = model.store.grad[:n].clone()
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        eng.reducer.allreduce()
+        torch.cuda.synchronize()
+        want = sum(gathered) / world
+        assert (gathered[0] - gathered[1]).abs().max() > 1e-6, "ranks should see different tiles"
+        assert torch.allclose(model.store.grad[:n], want, rtol=1e-6, atol=1e-7)
+
+        # 2. step structures: eager + one exchange (reference behaviour) vs eager + early exchange vs three hipGraphs
+        traces, sums = {}, {}
+        for mode in ("eager_plain", "eager_early", "graph_early"):
+            model, opt = build()
+            eng = TrainEngine(model, opt, get_loss_function(cfg), world, use_graph=(mode == "graph_early"), warmup_eager=1,
+                              early_exchange=(mode != "eager_plain"), bucket_elems=4 * 1024 * 1024)
+            assert eng.two_phase and (eng.early_ranges is not None) == (mode != "eager_plain")
+            traces[mode] = [eng.step(x, labels).item() for _ in range(5)]
+            torch.cuda.synchronize()
+            chk = model.store.master[:n].double().sum().reshape(1)
+            allchk = [torch.empty_like(chk) for _ in range(world)]
+            dist.all_gather(allchk, chk)
+            assert allchk[0].item() == allchk[1].item(), "ranks diverged in mode %s: %r" % (mode, [c.item() for c in allchk])
+            sums[mode] = chk.item()
+            if mode == "graph_early":
+                assert eng.graph_a is not None and eng.graph_a2 is not None and eng.graph_b is not None
+        for a, b in zip(traces["eager_plain"], traces["eager_early"]):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), traces
+        assert abs(sums["eager_plain"] - sums["eager_early"]) <= 1e-6 * abs(sums["eager_plain"]), sums
+        # inside the graphs the five SyncBatchNorm layers use per-rank statistics: close, not equal
+        for a, b in zip(traces["eager_plain"], traces["graph_early"]):
+            assert abs(a - b) <= 3e-2 * max(1.0, abs(a)), traces
+        assert traces["graph_early"][-1] < traces["graph_early"][0]
+        q.put((rank, "ok", traces["graph_early"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_over_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert [g[:2] for g in got] == [(0, "ok"), (1, "ok")]
+    assert got[0][2] != got[1][2], "per-rank losses should differ (different tiles)"
