@@ -329,16 +329,121 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
           for (int r = 0; r < 16; ++r) park[((grp - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
     }
     __syncthreads();
-    if (grp > 0) return;
+    if (grp == 0) {
 #pragma unroll
-    for (int g = 1; g < G; ++g)
+      for (int g = 1; g < G; ++g)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += park[((g - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += park[((g - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid];
+    }
   }
+
+  // ---- epilogue, row-vectorised ----------------------------------------------------------------------------------
+  // The C/D layout of the 32x32 MFMA gives a lane one COLUMN (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):
+  // storing from it means 2-byte accesses in 64-byte runs, 16 store instructions per wave tile, and the same again for
+  // a residual or a mask (measured: the stores were 12-30 % of a 64x64-tile kernel, a 22 MB residual read +15 us).
+  // So the block's accumulators go through LDS (free after the k loop) into a row-major fp32 tile, and every thread
+  // handles 8 consecutive channels of a row: 16-byte loads / stores in runs of BN channels.
+  {
+    constexpr int CP = BN + 8;                       // fp32 tile pitch: rows 16-B aligned, half-waves on disjoint banks
+    constexpr int CGR = BN / 8;                      // 8-channel groups per row
+    constexpr int NT = 256 * G;
+    constexpr int RP = NT / CGR;                     // rows per pass
+    const bool al16 = (((uintptr_t)p.out) & 15) == 0 && (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.mask_y || (((uintptr_t)p.mask_y) & 15) == 0);
+    const int eo = p.out_f32 ? 4 : EPC;              // elements per 16 bytes of the output
+    const bool vec_ok = al16 && p.ldout % eo == 0 && p.out_bs % eo == 0 && (p.OC % 8 == 0) &&
+                        (!p.res || (p.ldres % EPC == 0 && p.res_bs % EPC == 0)) && (!p.mask_y || (p.ldy % EPC == 0 && p.y_bs % EPC == 0));
+    if (vec_ok) {
+      float* tile = reinterpret_cast<float*>(smem_all);
+      __syncthreads();                               // every wave is done with the k-tile buffers / the parked accumulators
+      if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              tile[((wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * CP + (wc * TN + j) * 32 + frow] = acc[i][j][r];
+      }
+      __syncthreads();
+      const int t = (int)threadIdx.x;
+      const int cg = t % CGR, rr = t / CGR;
+      const int n0 = bn * BN + cg * 8;
+      const bool col_ok = n0 < p.OC;                 // OC % 8 == 0: a group is all in or all out
+      float bv[8], ss[8], sq[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && col_ok) ? p.bias[n0 + e] : 0.f; ss[e] = 0.f; sq[e] = 0.f; }
+      const T* resp = (const T*)p.res;
+      const T* ymask = (const T*)p.mask_y;
+#pragma unroll 2
+      for (int row = rr; row < BM; row += RP) {
+        const long long m = (long long)bm * BM + row;
+        if (m >= M || !col_ok) continue;
+        const int e_nb = (int)(m / OHW);
+        const int e_pix = (int)(m - (long long)e_nb * OHW);
+        float v[8];
+        {
+          const float4 a = *reinterpret_cast<const float4*>(tile + row * CP + cg * 8);
+          const float4 b = *reinterpret_cast<const float4*>(tile + row * CP + cg * 8 + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        if (resp) {
+          float w8[8];
+          Vec8<T>::load(resp + (long long)e_nb * p.res_bs + (long long)e_pix * p.ldres + n0, w8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += w8[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        float second[8];
+        if (ymask) {
+          Vec8<T>::load(ymask + (long long)e_nb * p.y_bs + (long long)e_pix * p.ldy + n0, second);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = second[e] > 0.f ? v[e] * p.mask_scale : 0.f;
+        }
+        const long long obase = (long long)e_nb * p.out_bs + (long long)e_pix * p.ldout + n0;
+        if (p.out_f32) {
+          Vec8<float>::store((float*)p.out + obase, v);
+        } else {
+          Vec8<T>::store((T*)p.out + obase, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = to_f32(from_f32<T>(v[e]));      // statistics of what the next kernel will read
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ss[e] += v[e];
+          sq[e] = fmaf(v[e], ymask ? second[e] : v[e], sq[e]);
+        }
+      }
+      if (p.stats) {
+        // column sums: [RP][BN] partials per statistic through LDS (the tile is consumed), one atomic per column
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[rr * BN + cg * 8 + e] = ss[e];
+          red[(RP + rr) * BN + cg * 8 + e] = sq[e];
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+          const int which = t / BN, col = t % BN;
+          const int n = bn * BN + col;
+          float a = 0.f;
+          for (int q = 0; q < RP; ++q) a += red[(which * RP + q) * BN + col];
+          if (n < p.OC) atomicAdd(p.stats + (long long)(bm & 7) * 2 * p.OC + (long long)which * p.OC + n, (double)a);
+        }
+      }
+      return;
+    }
+  }
+  if (grp > 0) return;
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Rows are visited in
   // increasing order, so (image, pixel) is carried along instead of divided out per row.

@@ -186,6 +186,15 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
+  // A block only streams ~8 KB, so its time is latency: the first row's loads go out BEFORE the per-channel preamble
+  // (fp64 replica sums -> scale/shift -> LDS -> barrier) and every later row is fetched one iteration ahead.
+  const long long rstep = (long long)gridDim.x * rows_per_pass;
+  long long r = (long long)blockIdx.x * rows_per_pass + lane_row;
+  float v[4], w[4];
+  if (r < M) {
+    Vec4<T>::load(x + r * ldx + c, v);
+    if (res) Vec4<T>::load(res + r * ldres + c, w);
+  }
   // per-channel scale/shift computed cooperatively (one channel per thread) and shared through LDS
   extern __shared__ float bn_lds[];          // [2][C]
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
@@ -209,14 +218,16 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
   float sc[4], sh[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e]; }
-  for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {
-    float v[4], o[4];
-    Vec4<T>::load(x + r * ldx + c, v);
+  while (r < M) {
+    const long long rn = r + rstep;
+    float vn[4], wn[4], o[4];
+    if (rn < M) {
+      Vec4<T>::load(x + rn * ldx + c, vn);
+      if (res) Vec4<T>::load(res + rn * ldres + c, wn);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], sc[e], sh[e]);
     if (res) {
-      float w[4];
-      Vec4<T>::load(res + r * ldres + c, w);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += w[e];
     }
@@ -225,6 +236,9 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
     }
     Vec4<T>::store(y + r * ldy + c, o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = vn[e]; w[e] = wn[e]; }
+    r = rn;
   }
 }
 
@@ -241,6 +255,15 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
+  // as in bn_apply_kernel: first row fetched before the preamble, later rows one iteration ahead
+  const long long rstep = (long long)gridDim.x * rows_per_pass;
+  long long r = (long long)blockIdx.x * rows_per_pass + lane_row;
+  float v[4], g[4], yy[4];
+  if (r < M) {
+    Vec4<T>::load(x + r * ldx + c, v);
+    Vec4<T>::load(dy + r * lddy + c, g);
+    if (y) Vec4<T>::load(y + r * ldy + c, yy);
+  }
   extern __shared__ float bn_lds[];          // [2][C]: sum_dy/count, sum_dyxhat/count
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const double t0 = rep_sum(sums, C, ch);
@@ -266,13 +289,15 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     k0[e] = bn_lds[c + e];
     k1[e] = bn_lds[C + c + e];
   }
-  for (long long r = (long long)blockIdx.x * rows_per_pass + lane_row; r < M; r += (long long)gridDim.x * rows_per_pass) {
-    float v[4], g[4], o[4];
-    Vec4<T>::load(x + r * ldx + c, v);
-    Vec4<T>::load(dy + r * lddy + c, g);
+  while (r < M) {
+    const long long rn = r + rstep;
+    float vn[4], gn[4], yn[4], o[4];
+    if (rn < M) {
+      Vec4<T>::load(x + rn * ldx + c, vn);
+      Vec4<T>::load(dy + rn * lddy + c, gn);
+      if (y) Vec4<T>::load(y + rn * ldy + c, yn);
+    }
     if (y) {
-      float yy[4];
-      Vec4<T>::load(y + r * ldy + c, yy);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
     }
@@ -280,6 +305,9 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     for (int e = 0; e < 4; ++e) o[e] = gi[e] * (g[e] - k0[e] - (v[e] - mu[e]) * is[e] * k1[e]);
     Vec4<T>::store(dx + r * lddx + c, o);
     if (dres) Vec4<T>::store(dres + r * lddres + c, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = vn[e]; g[e] = gn[e]; yy[e] = yn[e]; }
+    r = rn;
   }
 }
 
