@@ -45,6 +45,11 @@ struct ConvArgs {
   // the masked dy AND that BatchNorm's backward sums in one pass: where y > 0, xhat = (y - beta) / gamma.
   const void* mask_y;
   float mask_scale;   // kept outputs are multiplied by this (1 for a ReLU; 1/(1-p) for dropout(relu(.)))
+  // optional: the second statistic multiplies with this tensor instead of mask_y (same geometry, own strides): the
+  // BatchNorm INPUT when mask_y is the output of relu(BatchNorm(x) + residual), whose xhat cannot be recovered from y
+  const void* stat_x;
+  int ldsx;
+  long long sx_bs;
   int ldy;
   long long y_bs;
 };
@@ -352,10 +357,12 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     constexpr int CGR = BN / 8;                      // 8-channel groups per row
     constexpr int NT = 256 * G;
     constexpr int RP = NT / CGR;                     // rows per pass
-    const bool al16 = (((uintptr_t)p.out) & 15) == 0 && (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.mask_y || (((uintptr_t)p.mask_y) & 15) == 0);
+    const bool al16 = (((uintptr_t)p.out) & 15) == 0 && (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.mask_y || (((uintptr_t)p.mask_y) & 15) == 0) &&
+                      (!p.stat_x || (((uintptr_t)p.stat_x) & 15) == 0);
     const int eo = p.out_f32 ? 4 : EPC;              // elements per 16 bytes of the output
     const bool vec_ok = al16 && p.ldout % eo == 0 && p.out_bs % eo == 0 && (p.OC % 8 == 0) &&
-                        (!p.res || (p.ldres % EPC == 0 && p.res_bs % EPC == 0)) && (!p.mask_y || (p.ldy % EPC == 0 && p.y_bs % EPC == 0));
+                        (!p.res || (p.ldres % EPC == 0 && p.res_bs % EPC == 0)) && (!p.mask_y || (p.ldy % EPC == 0 && p.y_bs % EPC == 0)) &&
+                        (!p.stat_x || (p.ldsx % EPC == 0 && p.sx_bs % EPC == 0));
     if (vec_ok) {
       float* tile = reinterpret_cast<float*>(smem_all);
       __syncthreads();                               // every wave is done with the k-tile buffers / the parked accumulators
@@ -407,6 +414,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
           Vec8<T>::load(ymask + (long long)e_nb * p.y_bs + (long long)e_pix * p.ldy + n0, second);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = second[e] > 0.f ? v[e] * p.mask_scale : 0.f;
+          if (p.stat_x) Vec8<T>::load((const T*)p.stat_x + (long long)e_nb * p.sx_bs + (long long)e_pix * p.ldsx + n0, second);
         }
         const long long obase = (long long)e_nb * p.out_bs + (long long)e_pix * p.ldout + n0;
         if (p.out_f32) {
@@ -484,6 +492,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
         if (ymask) {
           second = to_f32(ymask[ybase + n]);
           v = second > 0.f ? v * p.mask_scale : 0.f;
+          if (p.stat_x) second = to_f32(((const T*)p.stat_x)[(long long)e_nb * p.sx_bs + (long long)e_pix * p.ldsx + n]);
         }
         if (p.out_f32) ((float*)p.out)[obase + n] = v;
         else {
@@ -933,7 +942,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
-  a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f;
+  a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
@@ -1192,6 +1201,7 @@ static bool thin_bwd_ok(const ConvArgs& d, const WgradArgs& w) {
   constexpr int EPC = 4;                  // a thread moves 4 channels: 16 B (f32) / 8 B (bf16)
   const int C = w.C;
   if (w.KH != 1 || w.KW != 1 || w.stride != 1 || w.pad != 0 || w.OC > 8) return false;
+  if (d.stat_x || (d.res && d.mask_y) || (d.res && d.res != d.out)) return false;      // the generic path handles those
   if (C < 32 || C > 1024 || (C & (C - 1))) return false;
   const long long px = (long long)w.H * w.W - 1, LIM = 1ll << 31;
   if ((long long)w.N * w.H * w.W >= LIM || (w.N - 1) * w.x_bs + px * w.ldx + C >= LIM || (w.N - 1) * d.out_bs + px * d.ldout + C >= LIM ||
@@ -1307,7 +1317,8 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
                                int accumulate, float* dw, float* dbias,
                                int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs,
                                int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
-                               float mask_scale, int dtype, void* stream) {
+                               float mask_scale, const void* stat_x, int ldsx, long long sx_bs, const void* addend, int ldadd, long long add_bs,
+                               int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && w_bwd_packed && dx && dw, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
@@ -1327,10 +1338,12 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   d.OH = H; d.OW = W; d.OC = C; d.ldout = lddx; d.out_bs = dx_bs;
   d.ldres = 0; d.res_bs = 0;
   if (accumulate) { d.res = dx; d.ldres = lddx; d.res_bs = dx_bs; }      // dx += : every element is read and written by the same thread
+  else if (addend) { d.res = addend; d.ldres = ldadd; d.res_bs = add_bs; }      // dx = dgrad + addend (gradient contributions made so far)
   EMRT_REQUIRE(lddx >= C && dx_bs >= 0, "bad dx strides");
-  EMRT_REQUIRE(!(accumulate && mask_y), "the fused ReLU mask / BatchNorm sums need dx to be this layer's only gradient");
+  EMRT_REQUIRE(!(accumulate && addend), "accumulate adds into dx itself; addend is a different tensor");
+  EMRT_REQUIRE(!stat_x || mask_y, "stat_x replaces the mask tensor in the second statistic: it needs mask_y");
   d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
-  d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale;
+  d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale; d.stat_x = stat_x; d.ldsx = ldsx; d.sx_bs = sx_bs;
   WgradArgs w;
   w.x = x; w.dy = dy; w.dw = dw;
   w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
@@ -1398,7 +1411,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
   a.ldres = d.ldres; a.res_bs = d.res_bs;
   a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.relu = d.relu; a.out_f32 = 0; a.stats = d.bn_stats;
-  a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f;
+  a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
 }
 
 template <class T>
@@ -1463,7 +1476,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
     d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.relu = 0; d.out_f32 = 0; d.stats = nullptr;
-    d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f;
+    d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
     WgradArgs& w = g.w[i];
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;
     w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;

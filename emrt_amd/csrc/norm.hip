@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const double* __restrict__ sums, const double* __restrict__ lsums,
                                                         double inv_count, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        long long M, int C, int rows_per_pass, const float* __restrict__ beta_y) {
+                                                        long long M, int C, int rows_per_pass, const float* __restrict__ beta_y, int sums_vs_x) {
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
       const double gm = (double)gamma[ch];
       t1 = gm != 0.0 ? (t1 - (double)beta_y[ch] * t0) / gm : 0.0;
     }
+    if (sums_vs_x) t1 = (t1 - (double)mean[ch] * t0) * (double)invstd[ch];      // (sum dy', sum dy' * x): xhat = (x - mean) * invstd
     bn_lds[ch] = (float)(t0 * inv_count);
     bn_lds[C + ch] = (float)(t1 * inv_count);
     if (blockIdx.x == 0) {
@@ -1046,18 +1047,19 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
 // dx formula uses the rank-summed `sums` with the global count, the parameter gradients use this rank's sums) else from `sums`.
 // beta_y_moments != null: `sums` hold (sum dy', sum dy' * y) as accumulated by emrt_conv2d(mask_y = y) -- the dgrad of the
 // conv that consumes y = relu(BN(x)) -- and are converted with xhat = (y - beta) / gamma; emrt_bn_bwd_reduce is then not needed.
+// sums_vs_x != 0: they hold (sum dy', sum dy' * x) (emrt_conv2d_bwd with stat_x = x: the relu(BN(x) + residual) joins).
 extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
                               void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
                               const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M,
-                              int C, const float* beta_y_moments, int dtype, void* stream) {
+                              int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
   int threads, rpp, grid;
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments),
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments));
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x));
   return check_launch("emrt_bn_bwd_dx");
 }
 

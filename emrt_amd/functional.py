@@ -307,6 +307,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     tape = c.tape
     bn_rec = getattr(x, "_bn_rec", None)      # x = relu(BatchNorm(.)) fresh from batch_norm(): see the dgrad call below
     drop_rec = getattr(x, "_drop_rec", None)  # x = dropout(relu(linear(.))) with this layer as its only consumer
+    res_rec = getattr(x, "_bnres_rec", None)  # x = relu(BatchNorm(.) + residual): a residual join, several consumers
     if tape is not None:
         def bwd():
             dy = tape.pop_grad(out)
@@ -326,24 +327,37 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                           w.KH, w.KW, stride, pad, dbias, c.dtype, c.stream)
             else:
                 slot = tape.grad_slot(x)          # accumulate straight into an existing gradient / a slice of the base buffer
+                # contributions other consumers made so far that are not ours to write into: the kernel reads them as an
+                # addend (dx = dgrad + addend) instead of a separate accumulate pass afterwards
+                addend = tape.unowned_grad(x) if (slot is None and not c.overlap) else None
                 dx = slot if slot is not None else c.empty(tuple(x.shape))
                 _, _, _, _, lddx, dx_bs = _check_map(dx)
-                ysums = ymask = None
+                ldadd, add_bs = _check_map(addend)[4:6] if addend is not None else (0, 0)
+                ysums = ymask = stat = None
+                ldsx = sx_bs = 0
                 mscale = 1.0
-                if drop_rec is not None and bn_rec is None and slot is None and not c.overlap:
+                if drop_rec is not None and bn_rec is None and slot is None and addend is None and not c.overlap:
                     ymask, mscale = x, drop_rec["scale"]
-                if bn_rec is not None and c.training and slot is None:
+                if bn_rec is not None and c.training and slot is None and addend is None:
                     # dgrad also applies that BatchNorm's ReLU mask and accumulates its backward sums (sum dy', sum dy'*y):
                     # the BatchNorm's own reduction pass is skipped when this turns out to be its only gradient
                     ysums = c.zeros_f64(BN_REPLICAS * 2 * C)
                     ymask = x
+                elif res_rec is not None and c.training and not c.overlap and ymask is None and x.dim() == 4:
+                    # residual join: this dgrad (+ what was accumulated before it) is masked by x > 0 and summed against
+                    # the BatchNorm's INPUT; if it turns out to be the last contribution, the join's backward needs
+                    # neither its reduction pass nor the accumulate (batch_norm checks the contribution count)
+                    ysums = c.zeros_f64(BN_REPLICAS * 2 * C)
+                    ymask, stat = x, res_rec["x"]
+                    ldsx, sx_bs = _check_map(stat)[4:6]
                 side = c.fork(x, dy)
                 if side is None:
                     # one call for both gradients: small layers run their dgrad and wgrad tiles in ONE launch
                     _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), lddx, dx_bs, int(slot is not None), P(w.grad), dbias,
                               N, H, W, C, ldin, in_bs,
                               OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, P(ysums), P(ymask), ldin if ymask is not None else 0,
-                              in_bs if ymask is not None else 0, float(mscale), c.dtype, c.stream)
+                              in_bs if ymask is not None else 0, float(mscale), P(stat), ldsx, sx_bs, P(addend), ldadd, add_bs,
+                              c.dtype, c.stream)
                 else:       # two-stream experiment (Context.overlap): wgrad on the side stream next to dgrad
                     _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
                               w.KH, w.KW, stride, pad, dbias, c.dtype, side)
@@ -352,14 +366,18 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                               w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
                               in_bs if ymask is not None else 0, c.dtype, c.stream)
                     c.join()
-                if ysums is not None:
+                if addend is not None:
+                    tape.replace_grad(x, dx)
+                elif slot is None:
+                    tape.add_grad(x, dx, owned=True)
+                if stat is not None:
+                    res_rec["dx"], res_rec["sums"], res_rec["n"] = dx, ysums, tape.grad_count(x)
+                elif ysums is not None:
                     bn_rec["dx"], bn_rec["sums"] = dx, ysums
                 elif ymask is not None:
                     drop_rec["dx"] = dx
             if residual is not None:
                 tape.add_grad(residual, dy)
-            if need_dx and slot is None:
-                tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return out
 
@@ -432,10 +450,14 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
                   P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     tape = c.tape
     rec = None
-    if tape is not None and c.training and relu and residual is None and out.dim() == 4:
+    if tape is not None and c.training and relu and out.dim() == 4:
         # lets a conv that consumes this tensor fold the backward reduction into its dgrad (functional.conv2d)
-        rec = {"dx": None, "sums": None}
-        out._bn_rec = rec
+        if residual is None:
+            rec = {"dx": None, "sums": None}
+            out._bn_rec = rec
+        else:
+            rec = {"dx": None, "sums": None, "n": 0, "x": x}
+            out._bnres_rec = rec
     if tape is not None:
         assert c.training, "backward through eval-mode BatchNorm is not supported"
 
@@ -448,9 +470,11 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
             yv = out if relu else None
             sync = bn.sync and c.world_size > 1 and c.sync_bn
             # the consumer conv's dgrad already produced the sums when its dx is the one and only gradient of `out`
-            fused = rec is not None and ncontrib == 1 and rec["dx"] is dy and not sync
+            # ... or, for a residual join, when that dgrad was the LAST of its contributions (it folded the earlier ones in)
+            fused = rec is not None and rec["dx"] is dy and not sync and ncontrib == (1 if residual is None else rec["n"])
             if fused:
                 sums2 = rec["sums"]
+                yv = None                 # dy is already masked
             else:
                 sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
                 _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), c.dtype, c.stream)
@@ -461,9 +485,10 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
                 _L().call("emrt_cast", P(sums2), P(local), BN_REPLICAS * 4 * C, 0, F32, c.stream)     # raw 8-byte copy as 2 x f32
                 _allreduce_sums(sums2, M)
             dx = c.empty(tuple(x.shape))
-            dres = c.empty(tuple(x.shape)) if (residual is not None and relu) else None
+            dres = c.empty(tuple(x.shape)) if (residual is not None and relu and not fused) else None
             _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
-                      P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C, P(bn.beta) if fused else None, c.dtype, c.stream)
+                      P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C,
+                      P(bn.beta) if (fused and residual is None) else None, int(fused and residual is not None), c.dtype, c.stream)
             tape.add_grad(x, dx, owned=True)
             if residual is not None:
                 tape.add_grad(residual, dres if dres is not None else dy, owned=dres is not None)

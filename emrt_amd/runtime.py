@@ -96,6 +96,25 @@ class Tape:
             return e[0]
         return None
 
+    def unowned_grad(self, t):
+        """The gradient accumulated for t so far when it is NOT tape-owned (shared with another target, so nobody may
+        write into it) and t is no view: a producer whose kernel can compute `new = its gradient + addend` reads it as the
+        addend and then calls replace_grad() -- the accumulate pass disappears.  None otherwise."""
+        if id(t) in self.alias:
+            return None
+        e = self.grads.get(id(t))
+        return e[0] if e is not None and not e[1] else None
+
+    def replace_grad(self, t, g):
+        """g (fresh, handed over) already contains t's previous gradient (see unowned_grad) plus one more contribution."""
+        e = self.grads[id(t)]
+        e[0], e[1] = g, True
+        e[2] += 1
+
+    def grad_count(self, t):
+        e = self.grads.get(id(t))
+        return 0 if e is None else e[2]
+
     def add_grad(self, t, g, owned=False):
         """Accumulate gradient g (same shape as t) into t's gradient.
         owned=True: g is a fresh buffer that the caller hands over (nobody else reads it afterwards), so the tape may

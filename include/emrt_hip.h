@@ -62,8 +62,11 @@ int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* 
 /* backward of one conv / linear layer in one call (dx NHWC with strides lddx / dx_bs, overwritten or accumulated into; dW += ; dbias += when given; optional fused
  * BatchNorm-backward sums as in emrt_conv2d): small layers are ONE launch that runs the dgrad and wgrad tiles side by side.
  * With mask_y, dx = mask_y > 0 ? mask_scale * dgrad : 0: mask_scale = 1 for a ReLU, 1/(1-p) when mask_y is the output of
- * dropout(relu(.)) -- the FFN's dropout and ReLU backward cost no pass of their own */
-int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, float mask_scale, int dtype, void* stream);
+ * dropout(relu(.)) -- the FFN's dropout and ReLU backward cost no pass of their own.  addend (same geometry as dx, own strides):
+ * dx = dgrad + addend before the mask, i.e. the gradient contributions other consumers made so far are folded in without
+ * an accumulate pass; stat_x: the second statistic becomes sum dx * stat_x (the BatchNorm input) instead of sum dx * mask_y,
+ * which is what a relu(BatchNorm(x) + residual) join needs -- its reduction pass then disappears too */
+int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, float mask_scale, const void* stat_x, int ldsx, long long sx_bs, const void* addend, int ldadd, long long add_bs, int dtype, void* stream);
 
 /* ---- BatchNorm / SyncBatchNorm (train: fp64 sums [from the conv epilogue or emrt_bn_stats] -> [all-reduce of sums across
  * ranks] -> apply; eval: running statistics).  replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add):
@@ -74,7 +77,7 @@ size_t emrt_colreduce_workspace_bytes(long long M, int C);
 int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream);
 int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
 int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, int dtype, void* stream);
-int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int dtype, void* stream);
+int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
 

@@ -239,6 +239,88 @@ def test_bn_relu_conv_chain_backward_fused_in_dgrad(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("scenario", ["addend", "two_convs", "late_add"])
+def test_residual_join_backward_fused_into_consumer_dgrad(dtype, scenario):
+    """out = relu(BatchNorm(x) + r) with several consumers (a ResNet block boundary).  The dgrad of a conv that consumes
+    `out` folds the contributions made so far in (addend / in place), masks with out > 0 and accumulates the join's
+    BatchNorm sums against x; when it was the last contribution the join's backward skips its reduction pass.
+      addend    : an external gradient (the next block's identity path) arrives first, then the conv's   -> fused, addend
+      two_convs : two convs consume `out`; the second to run accumulates in place                        -> fused
+      late_add  : a non-conv consumer contributes AFTER the conv                                         -> falls back, same numbers"""
+    from emrt_amd import _lib
+    N, H, W, C, OC = 2, 12, 12, 64, 128
+    c = init(dtype)
+    g = torch.Generator().manual_seed(41)
+    x = rnd(torch.randn(N, C, H, W, generator=g) * 1.3 + 0.1)
+    r = rnd(torch.randn(N, C, H, W, generator=g))
+    other = rnd(torch.randn(N, C, H, W, generator=g))
+    bn = hnn.BatchNorm2D(C)
+    conv_b = hnn.Conv2D(C, OC, 1, 1, 0, bias=False)
+    conv_c = hnn.Conv2D(C, OC, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        conv_b.weight.copy_(rnd(torch.randn(OC, C, 1, 1, generator=g) / math.sqrt(C)))
+        conv_c.weight.copy_(rnd(torch.randn(OC, C, 3, 3, generator=g) / math.sqrt(9 * C)))
+    gam, bet, wb, wc = (t.detach().clone() for t in (bn.weight, bn.bias, conv_b.weight, conv_c.weight))
+    Holder(bn=bn, conv_b=conv_b, conv_c=conv_c).place()
+    dyb = rnd(torch.randn(N, OC, H, W, generator=g))
+    dyc = rnd(torch.randn(N, OC, H, W, generator=g))
+    extra = rnd(torch.randn(N, C, H, W, generator=g))
+
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    gr, br_, wbr, wcr = (t.clone().requires_grad_(True) for t in (gam, bet, wb, wc))
+    out_r = F.relu(F.batch_norm(xr, None, None, gr, br_, True, 0.1, 1e-5) + rr)
+    loss = (F.conv2d(out_r, wbr) * dyb).sum()
+    if scenario == "addend":
+        loss = loss + (out_r * extra).sum()
+    elif scenario == "two_convs":
+        loss = loss + (F.conv2d(out_r, wcr, padding=1) * dyc).sum()
+    else:
+        loss = loss + ((out_r + other) * extra).sum()
+    loss.backward()
+
+    xd, rd = dev_map(x), dev_map(r)
+    tape = Tape()
+    c.tape = tape
+    out = bn(xd, relu=True, residual=rd)
+    grads = []
+    if scenario == "late_add":
+        s_ = Fn.add(out, dev_map(other))            # recorded before conv_b => its gradient reaches `out` after conv_b's
+        grads.append((s_, dev_map(extra)))
+    if scenario == "two_convs":
+        oc = conv_c(out)
+        grads.append((oc, dev_map(dyc)))
+    ob = conv_b(out)
+    grads.append((ob, dev_map(dyb)))
+    if scenario == "addend":
+        grads.append((out, dev_map(extra)))
+    c.tape = None
+    tape.watch(xd)
+    tape.watch(rd)
+    L = _lib.lib()
+    L.start_record()
+    dx, dr = run_bwd(tape, grads, [xd, rd])
+    calls = L.stop_record()
+    names = [n for n, _ in calls]
+    assert ("emrt_bn_bwd_reduce" in names) == (scenario == "late_add"), names
+    bwd = [a for n, a in calls if n == "emrt_conv2d_bwd"]
+    assert all(a[29] is not None for a in bwd)                       # every consumer conv tries the join fusion
+    if scenario == "addend":
+        assert bwd[0][32] is not None and "emrt_acc3d" not in names and "emrt_add" not in names
+    if scenario == "two_convs":
+        assert bwd[0][6] == 0 and bwd[1][6] == 1
+    sc = math.sqrt(N * H * W)
+    ksc = math.sqrt(OC) * (2.0 if scenario == "two_convs" else 1.0)
+    f = 1.0 if dtype == F32 else 0.3
+    close("join dx", host_map(dx), xr.grad, dtype, 3.0 * ksc * f)
+    close("join dres", host_map(dr), rr.grad, dtype, 2.0 * ksc * f)
+    close("join dgamma", host(bn.weight.grad), gr.grad, dtype, sc * ksc * (1.0 if dtype == F32 else 0.5))
+    close("join dbeta", host(bn.bias.grad), br_.grad, dtype, sc * ksc * (1.0 if dtype == F32 else 0.5))
+    close("join dw_b", host(conv_b.weight.grad), wbr.grad, dtype, sc * f)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_batch_norm_eval_and_slice_output(dtype):
     c = init(dtype)
     c.training = False

@@ -81,10 +81,21 @@ def test_train_step_launch_sequence(fake, backbone):
     ffn = [a for a in dgrads if a[25] is not None and a[24] is None]
     assert len(ffn) == n_ffn > 0 and all(abs(a[28] - 1.0 / 0.9) < 1e-6 and a[25].value == a[0].value for a in ffn)
     assert cnt["emrt_mask_bwd"] == cnt["emrt_dropout_fwd"] - n_ffn
-    assert not any(a[6] and a[25] is not None for a in dgrads)       # in-place accumulation and the fused mask exclude each other
-    fused_dx = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[20] is not None)
-    assert fused_dx + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_dx <= n_fused
-    assert fused_dx >= n_bn // 3, (fused_dx, n_bn)
+    # residual joins relu(BatchNorm(x) + residual): the dgrad of a conv that consumes the join folds the earlier
+    # contributions in (addend a[32], or in place a[6]), masks with the join's output and sums against the BatchNorm INPUT
+    # (stat_x a[29]); the join's backward then runs without its reduction pass (sums_vs_x a[21] of emrt_bn_bwd_dx)
+    joins = [a for a in dgrads if a[29] is not None]
+    assert joins and all(a[24] is not None and a[25] is not None and a[25].value == a[0].value for a in joins)
+    assert any(a[32] is not None for a in joins) and all(not (a[6] and a[32] is not None) for a in dgrads)
+    assert all(a[29] is None for a in dgrads if a[25] is None)
+    fused_y = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[20] is not None)
+    fused_x = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[21] == 1)
+    assert not any(a[20] is not None and a[21] == 1 for n, a in fake.calls if n == "emrt_bn_bwd_dx")
+    assert all(a[4] is None for n, a in fake.calls if n == "emrt_bn_bwd_dx" and (a[20] is not None or a[21] == 1))     # fused: dy arrives masked
+    assert fused_y + fused_x + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_y + fused_x <= n_fused
+    n_join_bn = sum(1 for n, a in fake.calls if n == "emrt_bn_apply" and a[2] is not None and a[18] == 1)
+    assert 0 < fused_x <= n_join_bn and fused_x >= n_join_bn - 4, (fused_x, n_join_bn)     # every join inside the backbone stages
+    assert fused_y >= n_bn // 3, (fused_y, n_bn)
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
     assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14
     assert cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 0 and cnt["emrt_groupnorm_levels_fwd"] == cnt["emrt_groupnorm_levels_bwd"] == 5

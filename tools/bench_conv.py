@@ -69,7 +69,7 @@ def thin():
 
     def run(mask):
         L._raw_emrt_conv2d_bwd(P(x), P(dy), P(wb), P(dx), C, H * W * C, 0, P(dw), P(db), N, H, W, C, C, H * W * C, H, W, OC, OC, H * W * OC,
-                               1, 1, 1, 0, P(stats) if mask else None, P(x) if mask else None, C if mask else 0, H * W * C if mask else 0, 1.0, 1, stream)
+                               1, 1, 1, 0, P(stats) if mask else None, P(x) if mask else None, C if mask else 0, H * W * C if mask else 0, 1.0, None, 0, 0, None, 0, 0, 1, stream)
     for ch in (8, 4):
         for cblk in (64, 128, 256):
             for blocks in (64, 128, 256, 512):
@@ -106,7 +106,7 @@ def main():
 
         def bwd():
             L._raw_emrt_conv2d_bwd(P(x), P(y), P(wb), P(dx), C, H * W * C, 0, P(dw), None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
-                                   k, k, s, pad, None, None, 0, 0, 1.0, 1, stream)
+                                   k, k, s, pad, None, None, 0, 0, 1.0, None, 0, 0, None, 0, 0, 1, stream)
 
         line = "N%d %dx%dx%d->%d k%d  %6.2f GF |" % (N, H, W, C, OC, k, gf)
         if which == "bwd":
