@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
                                                          const T* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, long long M, int C, int tx_n,
                                                          float* __restrict__ partial, long long rpb, long long bs,
-                                                         double* __restrict__ dsums) {
+                                                         double* __restrict__ dsums, float* __restrict__ facc) {
   __shared__ float red[256 * 8];
   const int ty_n = 256 / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
       double* rep = dsums + (long long)(blockIdx.x & 7) * 2 * C;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { atomicAdd(rep + c + e, (double)s0[e]); atomicAdd(rep + C + c + e, (double)s1[e]); }
+    } else if (facc) {    // bias / embedding gradients: fp32 atomics straight into the gradient (no combine launch)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < C) atomicAdd(facc + c + e, s0[e]);
     } else {
       float* pp = partial + (long long)blockIdx.x * 2 * C;
 #pragma unroll
@@ -860,7 +864,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
                                                      int C, int rows_per_block, T* __restrict__ dzb, float pdrop,
-                                                     const unsigned long long* __restrict__ seed, unsigned salt) {
+                                                     const unsigned long long* __restrict__ seed, unsigned salt,
+                                                     float* __restrict__ dgamma_direct, float* __restrict__ dbeta_direct) {
   // dzb (optional): gradient of the dropped branch input, dz * mask / (1 - p)
   const unsigned long long sd = (dzb && pdrop > 0.f) ? seed[0] : 0ull;
   const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
@@ -952,8 +957,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
   for (int c = threadIdx.x; c < C; c += 256) {
     float b0 = 0.f, g0 = 0.f;
     for (int w = 0; w < 4; ++w) { b0 += sm[(w * 2 + 0) * C + c]; g0 += sm[(w * 2 + 1) * C + c]; }
-    partial[(long long)blockIdx.x * 2 * C + c] = b0;       // slot 0: dbeta  (matches bn_bwd_finalize: sums[c] -> dbeta)
-    partial[(long long)blockIdx.x * 2 * C + C + c] = g0;   // slot 1: dgamma
+    if (dgamma_direct || dbeta_direct) {
+      // <= 512 blocks x 2C fp32 atomics straight into the parameter gradients: they drain while other blocks still run,
+      // and the separate finalize launch (a kernel boundary, ~9 us for a few hundred KB) disappears
+      if (dbeta_direct) atomicAdd(dbeta_direct + c, b0);
+      if (dgamma_direct) atomicAdd(dgamma_direct + c, g0);
+    } else {
+      partial[(long long)blockIdx.x * 2 * C + c] = b0;       // slot 0: dbeta  (matches bn_bwd_finalize: sums[c] -> dbeta)
+      partial[(long long)blockIdx.x * 2 * C + C + c] = g0;   // slot 1: dgamma
+    }
   }
 }
 
@@ -1006,8 +1018,8 @@ extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, double*
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 0>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, nullptr, M, 0LL, sums),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, nullptr, M, 0LL, sums));
+            hipLaunchKernelGGL((col_reduce_kernel<float, 0>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, nullptr, M, 0LL, sums, nullptr),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, nullptr, M, 0LL, sums, nullptr));
   return check_launch("emrt_bn_stats");
 }
 
@@ -1038,8 +1050,8 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums));
+            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr));
   return check_launch("emrt_bn_bwd_reduce");
 }
 
@@ -1096,10 +1108,12 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
+  const char* ea = getenv("EMRT_LN_ATOMIC");       // developer knob shared with emrt_layernorm_bwd: 0 = partials + finalize launch
+  const bool direct = !(ea && atoi(ea) == 0);
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr));
-  hipLaunchKernelGGL(partials_acc_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, gx, C, (float*)nullptr, dbias);   // slot 0 only
+            hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr, direct ? dbias : nullptr),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr, direct ? dbias : nullptr));
+  if (!direct) hipLaunchKernelGGL(partials_acc_kernel, dim3((C + 31) / 32), dim3(256), 0, st, partial, gx, C, (float*)nullptr, dbias);   // slot 0 only
   return check_launch("emrt_colsum_acc");
 }
 
@@ -1206,12 +1220,14 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   rpb = (rpb + 7) / 8 * 8;
   blocks = (rows + rpb - 1) / rpb;
   float* partial = (float*)workspace;
+  const char* ea = getenv("EMRT_LN_ATOMIC");       // developer knob: 0 = partials + finalize launch
+  const bool direct = (dgamma || dbeta) && !(ea && atoi(ea) == 0);
   const size_t lds = (size_t)8 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb, (float*)dz_branch, pdrop, seed, salt),
-            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb, (bf16_t*)dz_branch, pdrop, seed, salt));
-  hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
+            hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb, (float*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr),
+            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb, (bf16_t*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr));
+  if (!direct) hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }
 
