@@ -155,8 +155,12 @@ class Tape:
         """Run the recorded closures newest-first.  stop_at > 0 stops once only the first `stop_at` ops are left (the
         engine's early gradient exchange: everything recorded after `self.split` first, the rest in a second call)."""
         _CTX.tape = None            # backward kernels must not record
-        while len(self.ops) > stop_at:
-            self.ops.pop()()
+        _CTX._in_backward = True
+        try:
+            while len(self.ops) > stop_at:
+                self.ops.pop()()
+        finally:
+            _CTX._in_backward = False
         if stop_at > 0:
             return
         self.results = {k: self.grad(t) for k, t in self.watched.items()}
@@ -184,6 +188,7 @@ class Context:
         self._arena_live = False
         self.overlap = False      # run independent backward kernels (wgrad next to dgrad) on a second HIP stream
         self._side = None
+        self._in_backward = False # Tape.backward() is running (step-scoped allocations allowed)
         self._main = None         # the stream every launch of this runtime goes to (torch's current stream after init_device)
 
     # ---- second stream -------------------------------------------------------------------------------------------
@@ -257,6 +262,21 @@ class Context:
         return t
 
     def zeros(self, shape, dtype=None):
+        dt = dtype or self.tdtype
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dt).element_size()
+        # (only inside a recorded forward or a backward: nothing allocated there outlives the step, so the next step's
+        # clear cannot pull the rug from under a persistent buffer)
+        if self._arena_live and (self.tape is not None or self._in_backward) and self.keepalive is None and 0 < nbytes <= (1 << 20):
+            # small zero buffers come out of the arena that is cleared ONCE per step (a memset launch costs ~5 us in the
+            # graph whatever its size, and a step asks for a dozen of these)
+            n8 = (nbytes + 15) // 16 * 2
+            if self._arena_off + n8 <= self._arena.numel():
+                raw = self._arena[self._arena_off:self._arena_off + n8]
+                self._arena_off += n8
+                return raw.view(dt)[:n].view(tuple(shape))
         t = self.empty(shape, dtype)
         _lib.lib().call("emrt_memset", ctypes.c_void_p(t.data_ptr()), 0, t.numel() * t.element_size(), self.stream)
         return t
