@@ -173,6 +173,54 @@ def test_train_forward_and_gradients_match_oracle():
         assert (b.cpu() - refb[n].float()).abs().max().item() < 1e-3 * (1 + refb[n].abs().max().item()), n
 
 
+def test_full_size_train_step_matches_oracle():
+    """The benchmark workload itself (BASELINE configs[1]: ResNet-50, batch 8, 256x256, 6 classes), one train-mode
+    forward + loss + backward in fp32 against the fp32 CPU oracle: logits, loss, the whole gradient as one vector
+    (norm and direction) and the per-parameter relative errors."""
+    g = torch.Generator().manual_seed(17)
+    B, S = 8, 256
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
+    ref, model = build_pair("resnet50", x, perturb=True)
+    ref.train()
+    out_r = ref(x)
+    loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
+    loss_r.backward()
+    model.train()
+    model.clear_gradients()
+    out = model(x.cuda())
+    loss = get_loss_function(make_config("resnet50"))(out, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (out[0].cpu() - out_r[0].detach()).abs().max().item() < 2e-3
+    assert (out[1].cpu() - out_r[1].detach()).abs().max().item() < 2e-3
+    assert abs(loss.item() - loss_r.item()) < 2e-4 * max(1.0, abs(loss_r.item()))
+    refp = dict(ref.named_parameters())
+    gmax = max(float(q.grad.norm()) for q in refp.values() if q.grad is not None)
+    errs, dot, n_hip, n_ref = [], 0.0, 0.0, 0.0
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None:
+            continue
+        if gr.norm().item() < 1e-5 * gmax:     # conv biases in front of a BatchNorm: mathematically zero, rounding noise on both sides
+            assert p.grad.norm().item() < 1e-4 * gmax, n
+            continue
+        gg = p.grad.cpu().double()
+        gr = gr.double()
+        dot += float((gg * gr).sum())
+        n_hip += float((gg * gg).sum())
+        n_ref += float((gr * gr).sum())
+        errs.append((((gg - gr).norm() / gr.norm()).item(), n))
+    cos = dot / (n_hip ** 0.5 * n_ref ** 0.5)
+    errs.sort(reverse=True)
+    med = errs[len(errs) // 2][0]
+    print("full-size gradient: cosine %.6f, norm ratio %.5f, per-parameter rel err median %.4f, worst %s" % (
+        cos, (n_hip / n_ref) ** 0.5, med, errs[:3]))
+    assert cos > 0.9995 and abs((n_hip / n_ref) ** 0.5 - 1.0) < 1e-2
+    assert med < 2e-2 and errs[0][0] < 0.15, errs[:5]
+
+
 def test_three_step_training_trace_matches_oracle():
     g = torch.Generator().manual_seed(11)
     B, S = 2, 64
