@@ -4,10 +4,11 @@
 
 Every kernel of the step is launched on torch's current stream, so after a few eager warm-up steps the whole step is
 captured into a hipGraph (torch.cuda.CUDAGraph) and replayed: ~1.5k launches cost one graph launch on the host.
-With world_size > 1 the step is captured as three graphs around the gradient exchange: graph A1 (zero/fwd/loss/backward
+With world_size > 1 the step is captured as four graphs around the gradient exchange: graph A1 (zero/fwd/loss/backward
 down to the ResNet layer4 input) -> launch the bucketed RCCL all-reduce(AVG) of the flat-gradient ranges that are final
-by then (heads, transformer, layer4) -> graph A2 (backward of layer3..conv1, overlapping the collective) -> all-reduce
-of the remaining ranges -> graph B (clip + optimizer); early_exchange=False keeps one graph A and one exchange.  The five SyncBatchNorm
+by then (heads, transformer, layer4) -> graph A2 (backward of layer3) -> all-reduce of layer3's range -> graph A3
+(backward of layer2..conv1; both collectives overlap it) -> all-reduce of the rest (3 % of the elements: the only exposed
+one) -> graph B (clip + optimizer); early_exchange=False keeps one graph A and one exchange.  The five SyncBatchNorm
 layers use per-rank statistics inside the captured region (documented deviation, DESIGN.md "Multi-GPU"); in eager mode
 (use_graph=False) they all-reduce their statistics as the reference's nn.SyncBatchNorm does.
 """
@@ -40,50 +41,68 @@ class TrainEngine:
         self.two_phase = (world_size > 1) if two_phase is None else bool(two_phase)
         self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems,
                                        always=self.two_phase) if self.two_phase else None
-        # early exchange: backward runs in two parts around the model's split mark (ResNet.forward, before layer4); the
-        # gradients that are final after the first part (heads, transformer, layer4: ~80 % of the elements) are
-        # all-reduced on RCCL's stream while the second part (layer3 .. conv1, ~half of backward's time) still runs
-        late = getattr(model, "late_grad_prefixes", None)
+        # early exchange: backward runs in segments between the model's marks (ResNet.forward: before layer3 and before
+        # layer4); the gradients a segment completes are all-reduced on RCCL's stream while the next segments still run:
+        #   segment 1 (heads, transformer, layer4: ~84 % of the elements) -> exchanged under layer3 .. conv1's backward
+        #   segment 2 (layer3: 13 %)                                      -> exchanged under layer2 .. conv1's backward
+        #   segment 3 (conv1, layer1, layer2: 3 %)                        -> the only exposed collective
+        segs = getattr(model, "grad_segment_prefixes", None)
+        self.seg_ranges = None
         self.early_ranges = self.late_ranges = None
-        if self.two_phase and early_exchange and late:
-            self.early_ranges, self.late_ranges = model.store.split_ranges(late)
-        self.graph_a2 = None
+        if self.two_phase and early_exchange and segs:
+            self.seg_ranges = model.store.segment_ranges(segs)
+            self.early_ranges = self.seg_ranges[0]
+            self.late_ranges = [r for seg in self.seg_ranges[1:] for r in seg]
+        self.graph_rest = []         # hipGraphs of backward segments 2.. (graph_a holds forward + segment 1)
+
+    @property
+    def graph_a2(self):
+        return self.graph_rest[0] if self.graph_rest else None
 
     # -- pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, images, labels, split=False):
-        """split=False: the whole forward + backward, returns the loss tensor.  split=True: stops backward at the model's
-        split mark and returns (loss tensor, rest) where rest() runs the remaining backward ops."""
+        """split=False: the whole forward + backward, returns the loss tensor.  split=True: runs backward's first segment
+        only and returns (loss tensor, [callable per remaining segment])."""
         c = ctx()
         _lib.lib().call("emrt_counter_add", Fn.P(c._seed), _SEED_STRIDE & 0x7FFFFFFFFFFFFFFF, c.stream)   # fresh dropout masks
         self.model.clear_gradients()
         out = self.model(images)
         loss = self.loss_fn(out, labels)
         if split:
-            rest = loss.backward_until_split()
+            rest = loss.backward_until_split(segments=True)
+            if rest:
+                last = rest[-1]
 
-            def finish():
-                rest()
-                ctx().join_all()
-            return loss.tensor, finish
+                def finish_last():
+                    last()
+                    ctx().join_all()
+                rest[-1] = finish_last
+            return loss.tensor, rest
         loss.backward()
         ctx().join_all()               # side-stream weight gradients (if any) land before the reducer / optimizer
         return loss.tensor
 
-    def _exchange(self, finish_backward):
-        """Gradient all-reduce around the second part of backward (finish_backward: callable or graph replay)."""
-        if self.early_ranges is None:
+    def _exchange(self, segments):
+        """Gradient all-reduce around the remaining backward segments (callables or graph replays)."""
+        if self.seg_ranges is None:
             self.reducer.allreduce()
             return
-        self.reducer.launch(self.early_ranges)      # RCCL stream picks up after everything enqueued so far
-        finish_backward()
-        self.reducer.launch(self.late_ranges)
+        self.reducer.launch(self.seg_ranges[0])      # RCCL stream picks up after everything enqueued so far
+        done = 1
+        for seg in segments:
+            seg()
+            if done < len(self.seg_ranges):
+                self.reducer.launch(self.seg_ranges[done])
+            done += 1
+        for ranges in self.seg_ranges[done:]:        # (a model that recorded fewer marks than it declared segments)
+            self.reducer.launch(ranges)
         self.reducer.wait()
 
     def _eager_step(self, images, labels):
         ctx().sync_bn = True
-        if self.early_ranges is not None:
-            loss_t, finish = self._fwd_bwd(images, labels, split=True)
-            self._exchange(finish)
+        if self.seg_ranges is not None:
+            loss_t, rest = self._fwd_bwd(images, labels, split=True)
+            self._exchange(rest)
         else:
             loss_t = self._fwd_bwd(images, labels)
             if self.reducer is not None:
@@ -102,12 +121,15 @@ class TrainEngine:
         # "global" capture mode turns such a foreign-thread call into a capture error (seen as a watchdog abort)
         mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
         self.graph_a = torch.cuda.CUDAGraph()
-        if self.early_ranges is not None:
+        if self.seg_ranges is not None:
             with torch.cuda.graph(self.graph_a, **mode):
-                self.loss_t, finish = self._fwd_bwd(self.images, self.labels, split=True)
-            self.graph_a2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_a2, pool=self.graph_a.pool(), **mode):
-                finish()
+                self.loss_t, rest = self._fwd_bwd(self.images, self.labels, split=True)
+            self.graph_rest = []
+            for seg in rest:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph_a.pool(), **mode):
+                    seg()
+                self.graph_rest.append(g)
         else:
             with torch.cuda.graph(self.graph_a, **mode):
                 self.loss_t = self._fwd_bwd(self.images, self.labels)
@@ -133,7 +155,7 @@ class TrainEngine:
                 self.labels.copy_(labels, non_blocking=True)
             self.graph_a.replay()
             if self.reducer is not None:
-                self._exchange(self.graph_a2.replay if self.graph_a2 is not None else None)
+                self._exchange([g.replay for g in self.graph_rest])
                 self.graph_b.replay()
             loss_t = self.loss_t
         self.opt._learning_rate.step()       # host mirror of the device step counter (train.py:156-158)

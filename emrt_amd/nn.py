@@ -96,18 +96,29 @@ class ParamStore:
         self.total_tiles = 0
         self.dirty = True
 
-    def split_ranges(self, late_prefixes):
-        """Partition [0, n_train) of the flat buffers into (early, late) lists of [start, end): `late` holds the parameters
-        whose name starts with one of `late_prefixes`, `early` everything else; alignment padding goes with the run before."""
+    def segment_ranges(self, segment_prefixes):
+        """Partition [0, n_train) of the flat buffers by parameter-name prefix: returns [ranges_0, ranges_1, ...] where
+        ranges_i (i >= 1) holds the parameters whose name starts with one of segment_prefixes[i-1] and ranges_0 everything
+        else; each a list of [start, end).  Alignment padding goes with the run before it."""
+        def seg_of(n):
+            for i, pre in enumerate(segment_prefixes):
+                if n.startswith(tuple(pre)):
+                    return i + 1
+            return 0
         runs = []
         for n in self.train_order:
-            late = n.startswith(tuple(late_prefixes))
-            if not runs or runs[-1][0] != late:
-                runs.append([late, self.offsets[n]])
-        early, late = [], []
-        for i, (is_late, start) in enumerate(runs):
+            k = seg_of(n)
+            if not runs or runs[-1][0] != k:
+                runs.append([k, self.offsets[n]])
+        out = [[] for _ in range(len(segment_prefixes) + 1)]
+        for i, (k, start) in enumerate(runs):
             end = runs[i + 1][1] if i + 1 < len(runs) else self.n_train
-            (late if is_late else early).append((start, end))
+            out[k].append((start, end))
+        return out
+
+    def split_ranges(self, late_prefixes):
+        """(early, late): segment_ranges with one segment."""
+        early, late = self.segment_ranges([tuple(late_prefixes)])
         return early, late
 
     # ---- GEMM weights ---------------------------------------------------------------------------

@@ -27,7 +27,13 @@ class Tape:
         self.alias = {}     # id(view) -> (base, slicer)
         self.watched = {}   # id(t) -> t : tensors whose gradient survives backward() (tests / debugging)
         self.results = {}
-        self.split = 0      # len(ops) when the model reached its early-exchange point (0 = no split recorded)
+        self.splits = []    # len(ops) at the model's gradient-exchange marks, in forward order (engine.py: backward runs in
+                            # segments between them, newest first, and exchanges the gradients each segment completes)
+
+    @property
+    def split(self):
+        """The mark backward reaches first (0 = none recorded)."""
+        return self.splits[-1] if self.splits else 0
 
     def watch(self, t):
         self.keep.append(t)

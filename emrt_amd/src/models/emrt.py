@@ -29,6 +29,8 @@ NOGRAD_PARAMS = ("backbone.fc.weight", "backbone.fc.bias", "model.tgt_embed.weig
 # parameters whose gradient is only final after the ops recorded before the tape's split mark (ResNet.forward) have run
 # backward; everything else can be exchanged between ranks while those run (engine.TrainEngine, two-phase step)
 LATE_GRAD_PREFIXES = ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2.", "backbone.layer3.")
+# the same per backward segment (two marks: before layer3 and before layer4): what the 2nd / 3rd segment complete
+GRAD_SEGMENT_PREFIXES = (("backbone.layer3.",), ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2."))
 
 
 def _salt():
@@ -108,9 +110,9 @@ class ResNet(hnn.HipLayer):  # :152-257
         x = Fn.maxpool(x, 3, 2, 1)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            if layer is self.layer4 and ctx().tape is not None:
-                ctx().tape.split = len(ctx().tape.ops)     # engine.py: gradients of everything from here on are
-                                                            # final once backward is back at this point
+            if (layer is self.layer3 or layer is self.layer4) and ctx().tape is not None:
+                ctx().tape.splits.append(len(ctx().tape.ops))     # engine.py: the gradients of everything recorded from here
+                                                                   # on are final once backward is back at this point
             for blk in layer._modules.values():
                 x = blk(x)
             feats.append(x)
@@ -602,6 +604,7 @@ class EMRT(hnn.HipLayer):  # :184-304
         hnn.bind_all(self, self.store)
         self.store.pack()
         self.late_grad_prefixes = LATE_GRAD_PREFIXES
+        self.grad_segment_prefixes = GRAD_SEGMENT_PREFIXES
         return self
 
     def set_dropout(self, p):

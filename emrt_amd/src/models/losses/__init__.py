@@ -16,16 +16,21 @@ class LossValue:
         self.tape.backward()
         self.tape = None
 
-    def backward_until_split(self):
-        """First part of backward(): every op recorded after the model's split mark.  Returns a callable that runs the rest."""
+    def backward_until_split(self, segments=False):
+        """First part of backward(): every op recorded after the model's last exchange mark.  Returns a callable that
+        runs the rest -- or, with segments=True, one callable per remaining segment (between the marks, newest first)."""
         if self.tape is None:
             raise RuntimeError("loss was computed in eval mode; nothing to differentiate")
         tape, self.tape = self.tape, None
-        if tape.split <= 0:
+        marks = list(tape.splits)
+        if not marks:
             tape.backward()
-            return lambda: None
-        tape.backward(stop_at=tape.split)
-        return tape.backward
+            return [] if segments else (lambda: None)
+        tape.backward(stop_at=marks[-1])
+        if not segments:
+            return tape.backward
+        stops = list(reversed(marks[:-1])) + [0]
+        return [(lambda s_=s_: tape.backward(s_)) for s_ in stops]
 
     def item(self):
         return float(self.tensor[0].item())

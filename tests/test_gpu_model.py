@@ -361,17 +361,27 @@ def test_early_exchange_ranges_are_final_at_the_split(backbone):
     assert cover[0][0] == 0 and cover[-1][1] == model.store.n_train
     assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and late
     model.train()
-    _, finish = eng._fwd_bwd(x.cuda(), labels.cuda(), split=True)
+    seg_ranges = model.store.segment_ranges(model.grad_segment_prefixes)
+    assert seg_ranges[0] == early and len(seg_ranges) == 3
+    _, rest = eng._fwd_bwd(x.cuda(), labels.cuda(), split=True)
+    assert len(rest) == 2
     torch.cuda.synchronize()
-    before = model.store.grad.clone()
+    snaps = [model.store.grad.clone()]
+    for seg in rest:
+        seg()
+        torch.cuda.synchronize()
+        snaps.append(model.store.grad.clone())
     for a, e in late:
-        assert not before[a:e].any(), "a late-range gradient was written before the split"
-    assert sum(float(before[a:e].abs().sum()) for a, e in early) > 0
-    finish()
-    torch.cuda.synchronize()
-    after = model.store.grad
-    for a, e in early:
-        assert torch.equal(before[a:e], after[a:e]), "backward's second part wrote an early-range gradient"
+        assert not snaps[0][a:e].any(), "a late-range gradient was written before the first mark"
+    assert sum(float(snaps[0][a:e].abs().sum()) for a, e in early) > 0
+    # ranges_i are final after segment i: later segments leave them bit-identical; ranges_j (j > i) are still zero
+    for i, ranges in enumerate(seg_ranges):
+        for a, e in ranges:
+            for later in snaps[i + 1:]:
+                assert torch.equal(snaps[i][a:e], later[a:e]), "segment %d's gradients changed afterwards" % i
+            for earlier in snaps[:i]:
+                assert not earlier[a:e].any(), "segment %d's gradients were written early" % i
+    after = snaps[-1]
     names = [n for n in model.store.train_order if n.startswith(model.late_grad_prefixes) and n.endswith("weight")]
     for n in names:
         a, cnt = model.store.views[n]

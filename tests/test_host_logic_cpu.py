@@ -224,3 +224,23 @@ def test_backward_split_keeps_early_gradient_ranges_final(fake, backbone):
     assert len(first) > 50 and len(second) > 20
     assert all(inside(off, early) for _, off in first), [x for x in first if not inside(x[1], early)][:5]
     assert all(inside(off, late) for _, off in second), [x for x in second if not inside(x[1], late)][:5]
+
+    # the engine's finer segmentation (marks before layer3 and before layer4): segment i only touches ranges_i
+    from emrt_amd.src.models.emrt import GRAD_SEGMENT_PREFIXES
+    seg_ranges = st.segment_ranges(GRAD_SEGMENT_PREFIXES)
+    allr = sorted(r for seg in seg_ranges for r in seg)
+    assert allr[0][0] == 0 and allr[-1][1] == st.n_train and all(a[1] == b[0] for a, b in zip(allr, allr[1:]))
+    assert seg_ranges[0] == early and sum(e - a for seg in seg_ranges[1:] for a, e in seg) == sum(e - a for a, e in late)
+    m.clear_gradients()
+    out = m(x)
+    loss = MixSoftmaxCrossEntropyLoss()(out, lab)
+    fake.calls.clear()
+    segs = loss.backward_until_split(segments=True)
+    touched = [grad_offsets(fake.calls)]
+    for seg in segs:
+        fake.calls.clear()
+        seg()
+        touched.append(grad_offsets(fake.calls))
+    assert len(touched) == len(seg_ranges) == 3 and all(len(t) > 5 for t in touched)
+    for i, (t, ranges) in enumerate(zip(touched, seg_ranges)):
+        assert all(inside(off, ranges) for _, off in t), (i, [x for x in t if not inside(x[1], ranges)][:5])
