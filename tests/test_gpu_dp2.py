@@ -1,6 +1,6 @@
 """-m gpu: the data-parallel step with TWO real ranks on ONE GPU.  RCCL refuses two ranks on one device, so the ranks talk
 over gloo (EMRT_DIST_BACKEND=gloo, device tensors staged through the host by the backend): everything above the transport
--- engine structure (three hipGraphs, early gradient exchange), FlatGradReducer on the device buffer, SyncBatchNorm's
+-- engine structure (several hipGraphs, staged early gradient exchange), FlatGradReducer on the device buffer, SyncBatchNorm's
 statistics all-reduce in eager mode, per-rank dropout streams -- is the code that runs at N > 1 on a multi-GPU node."""
 import os
 import socket
@@ -66,7 +66,7 @@ def _worker(rank, world, port, q):
         assert (gathered[0] - gathered[1]).abs().max() > 1e-6, "ranks should see different tiles"
         assert torch.allclose(model.store.grad[:n], want, rtol=1e-6, atol=1e-7)
 
-        # 2. step structures: eager + one exchange (reference behaviour) vs eager + early exchange vs three hipGraphs
+        # 2. step structures: eager + one exchange (reference behaviour) vs eager + early exchange vs the multi-graph step
         traces, sums = {}, {}
         for mode in ("eager_plain", "eager_early", "graph_early"):
             model, opt = build()

@@ -301,11 +301,11 @@ def test_two_phase_dp_step_over_rccl_matches_single_graph():
 
 
 def test_split_graphs_keep_their_order_when_the_host_waits_each_step():
-    """Regression: with the step captured as several hipGraphs (A1 / A2 / B around the gradient exchange) and the host
+    """Regression: with the step captured as several hipGraphs (A1 / A2 / A3 / B around the gradient exchange) and the host
     synchronising every step (so each graph is launched while its predecessor is still RUNNING rather than queued),
     launches on the NULL stream lost their ordering -- the optimizer read half-written gradients and the loss blew up
     within ~10 steps at this size.  runtime.Context.init_device therefore moves all work to a created stream.  bf16
-    ResNet-50 at 256x256 (the size it showed at), dropout off, three-graph engine vs the single-graph engine."""
+    ResNet-50 at 256x256 (the size it showed at), dropout off, multi-graph engine vs the single-graph engine."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29534")
