@@ -224,12 +224,15 @@ __global__ __launch_bounds__(RBW_THREADS) void resize_bwd_wide_kernel(ResizeBwdA
   axis_range(a.ay, ih, a.OH, ylo, yhi);
   axis_range(a.ax, iw, a.OW, xlo, xhi);
   const int bw = xhi - xlo + 1, npix = (yhi - ylo + 1) * bw;
-  const int cq = a.C / 4;                          // host guarantees C % 4 == 0 and cq <= RBW_THREADS
+  // blockIdx.y: channel chunk (a 1x1 or 3x3 source map has only 8 / 72 pixels in the batch: splitting the channels over
+  // gridDim.y blocks gives each block fewer quads, hence more phases over the 1024-pixel window and more blocks in flight)
+  const int cq = a.C / 4 / (int)gridDim.y;         // host guarantees C % 4 == 0, gridDim.y | C/4 and cq <= RBW_THREADS
   const int phases = RBW_THREADS / cq;
   const int q = (int)threadIdx.x % cq, ph = (int)threadIdx.x / cq;
+  const int qg = (int)blockIdx.y * cq + q;         // global channel quad
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (ph < phases) {
-    const T* gimg = (const T*)a.dout + (long long)n * a.do_bs + q * 4;
+    const T* gimg = (const T*)a.dout + (long long)n * a.do_bs + qg * 4;
     for (int pxi = ph; pxi < npix; pxi += phases) {
       const int oh = ylo + pxi / bw, ow = xlo + pxi % bw;
       const float wgt = axis_weight(a.ay, oh, a.IH, ih) * axis_weight(a.ax, ow, a.IW, iw);
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(RBW_THREADS) void resize_bwd_wide_kernel(ResizeBwdA
     for (int o = 1; o < phases; ++o)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] += red[(threadIdx.x + o * cq) * 4 + e];
-    Vec4<T>::store((T*)a.din + (long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + q * 4, acc);
+    Vec4<T>::store((T*)a.din + (long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + qg * 4, acc);
   }
 }
 
@@ -596,8 +599,11 @@ extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int d
   const bool v4 = C % 4 == 0 && do_ld % 4 == 0 && di_ld % 4 == 0 && do_bs % 4 == 0 && di_bs % 4 == 0 &&
                   ((uintptr_t)dout % 16 == 0) && ((uintptr_t)din % 16 == 0);
   if (v4 && C / 4 <= RBW_THREADS && ((long long)OH * OW >= 16ll * IH * IW)) {     // >= x4 per axis: block per source pixel
-    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_wide_kernel<float>), dim3(N * IH * IW), dim3(RBW_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((resize_bwd_wide_kernel<bf16_t>), dim3(N * IH * IW), dim3(RBW_THREADS), 0, st, a);
+    int chunks = 1;
+    while (chunks < 8 && (long long)N * IH * IW * chunks < 256 && (C / 4) % (chunks * 2) == 0 && (C / 4) / (chunks * 2) >= 8) chunks *= 2;
+    const dim3 grid((unsigned)(N * IH * IW), (unsigned)chunks);
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_wide_kernel<float>), grid, dim3(RBW_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((resize_bwd_wide_kernel<bf16_t>), grid, dim3(RBW_THREADS), 0, st, a);
     return check_launch("emrt_resize_bilinear_bwd");
   }
   if (v4) {
