@@ -199,7 +199,7 @@ def main():
                     "all_gemm_tflops": round(all_fl / all_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_ms / total_ms, 3),
                     "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch"}
         # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot profile itself); bf16 B=8 256^2 only
-        pmc, pmc_src = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1j_pmc_traffic.json")
+        pmc, pmc_src = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1k_pmc_traffic.json")
         if os.path.exists(pmc_src) and dtype == BF16 and B == 8 and S == 256:
             with open(pmc_src) as f:
                 pmc = json.load(f)
@@ -209,7 +209,7 @@ def main():
             roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
             roofline["traffic_kernel"] = key
             roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, average over the step's launches)"
-            roofline["traffic_source"] = "profiles/r1j_pmc_traffic.json: " + pmc["method"]
+            roofline["traffic_source"] = "profiles/r1k_pmc_traffic.json: " + pmc["method"]
         esz = 2 if dtype == BF16 else 4
         enc = [(a, ms) for name, a, ms in calls if name == "emrt_msda_fwd" and (a[9].value if hasattr(a[9], "value") else a[9]) > 0]
         enc = [(a, ms) for a, ms in enc if a[10] == a[11]]     # Lq == Lv: encoder self-attention calls
@@ -227,7 +227,7 @@ def main():
                 roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)
                 roofline_msda["traffic_unit"] = ("bytes per launch, FETCH_SIZE + WRITE_SIZE as counted; the gfx950 x2 read correction "
                                                  "(valid for 16-B/lane streams) gives the upper bound %d" % int(m["traffic_mb_corrected"] * 1e6))
-                roofline_msda["traffic_source"] = "profiles/r1j_pmc_traffic.json"
+                roofline_msda["traffic_source"] = "profiles/r1k_pmc_traffic.json"
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(B, S, args.cpu_threads)
