@@ -41,6 +41,19 @@ struct ResizeArgs {
   int out_nchw_f32;   // out is float [N][C][OH][OW]
 };
 
+// VEC elements per access: 1 (scalar), 4 (8 B bf16 / 16 B f32) or 8 (16 B bf16 / 32 B f32)
+template <class T, int VEC>
+struct VecIO;
+template <class T>
+struct VecIO<T, 1> {
+  __device__ static __forceinline__ void load(const T* p, float (&o)[1]) { o[0] = to_f32(p[0]); }
+  __device__ static __forceinline__ void store(T* p, const float (&o)[1]) { p[0] = from_f32<T>(o[0]); }
+};
+template <class T>
+struct VecIO<T, 4> : Vec4<T> {};
+template <class T>
+struct VecIO<T, 8> : Vec8<T> {};
+
 template <class T, int VEC>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs a) {
   const int cv = a.C / VEC;
@@ -57,38 +70,28 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs a) {
     axis_src(a.ax, ow, a.IW, x0, x1, wx0, wx1);
     const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
     float o[VEC];
-    if (VEC == 4) {
-      float v00[4], v01[4], v10[4], v11[4];
-      Vec4<T>::load(ip + ((long long)y0 * a.IW + x0) * a.in_ld, v00);
-      Vec4<T>::load(ip + ((long long)y0 * a.IW + x1) * a.in_ld, v01);
-      Vec4<T>::load(ip + ((long long)y1 * a.IW + x0) * a.in_ld, v10);
-      Vec4<T>::load(ip + ((long long)y1 * a.IW + x1) * a.in_ld, v11);
+    {
+      float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+      VecIO<T, VEC>::load(ip + ((long long)y0 * a.IW + x0) * a.in_ld, v00);
+      VecIO<T, VEC>::load(ip + ((long long)y0 * a.IW + x1) * a.in_ld, v01);
+      VecIO<T, VEC>::load(ip + ((long long)y1 * a.IW + x0) * a.in_ld, v10);
+      VecIO<T, VEC>::load(ip + ((long long)y1 * a.IW + x1) * a.in_ld, v11);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
-    } else {
-      o[0] = wy0 * (wx0 * to_f32(ip[((long long)y0 * a.IW + x0) * a.in_ld]) + wx1 * to_f32(ip[((long long)y0 * a.IW + x1) * a.in_ld])) +
-             wy1 * (wx0 * to_f32(ip[((long long)y1 * a.IW + x0) * a.in_ld]) + wx1 * to_f32(ip[((long long)y1 * a.IW + x1) * a.in_ld]));
     }
     if (a.add) {
       const T* ap = (const T*)a.add + (long long)n * a.add_bs + ((long long)oh * a.OW + ow) * a.add_ld + c;
-      if (VEC == 4) {
-        float q[4];
-        Vec4<T>::load(ap, q);
+      float q[VEC];
+      VecIO<T, VEC>::load(ap, q);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] += q[e];
-      } else o[0] += to_f32(ap[0]);
+      for (int e = 0; e < VEC; ++e) o[e] += q[e];
     }
     if (a.out_nchw_f32) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) ((float*)a.out)[(((long long)n * a.C + c + e) * a.OH + oh) * a.OW + ow] = o[e];
     } else {
       T* op = (T*)a.out + (long long)n * a.out_bs + ((long long)oh * a.OW + ow) * a.out_ld + c;
-      if (VEC == 4) {
-        float w4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = o[e < VEC ? e : 0];
-        Vec4<T>::store(op, w4);
-      } else op[0] = from_f32<T>(o[0]);
+      VecIO<T, VEC>::store(op, o);
     }
   }
 }
@@ -176,12 +179,10 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
         for (int j = 0; j < RB_WIN; ++j) {
           if (wxa[j] == 0.f) continue;
           const float wgt = wy * wxa[j];
-          if (VEC == 4) {
-            float g[4];
-            Vec4<T>::load(grow + (long long)j * a.do_ld, g);
+          float g[VEC];
+          VecIO<T, VEC>::load(grow + (long long)j * a.do_ld, g);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
-          } else acc[0] = fmaf(wgt, to_f32(grow[(long long)j * a.do_ld]), acc[0]);
+          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
         }
       }
     } else {
@@ -193,22 +194,15 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
           if (wx == 0.f) continue;
           const float wgt = wy * wx;
           const T* gp = gimg + ((long long)oh * a.OW + ow) * a.do_ld;
-          if (VEC == 4) {
-            float g[4];
-            Vec4<T>::load(gp, g);
+          float g[VEC];
+          VecIO<T, VEC>::load(gp, g);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
-          } else acc[0] = fmaf(wgt, to_f32(gp[0]), acc[0]);
+          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
         }
       }
     }
     T* dp = (T*)a.din + (long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + c;
-    if (VEC == 4) {
-      float w4[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w4[e] = acc[e < VEC ? e : 0];
-      Vec4<T>::store(dp, w4);
-    } else dp[0] = from_f32<T>(acc[0]);
+    VecIO<T, VEC>::store(dp, acc);
   }
 }
 
@@ -562,7 +556,12 @@ extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_
   const bool v4 = C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && in_bs % 4 == 0 && out_bs % 4 == 0 &&
                   (!add || (add_ld % 4 == 0 && add_bs % 4 == 0)) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                   (!add || (uintptr_t)add % 16 == 0);
-  if (v4) {
+  const bool v8 = v4 && dtype != EMRT_F32 && C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && in_bs % 8 == 0 && out_bs % 8 == 0 &&
+                  (!add || (add_ld % 8 == 0 && add_bs % 8 == 0));      // bf16: 16-byte accesses
+  if (v8) {
+    const int grid = ew_grid((long long)N * OH * OW * (C / 8));
+    hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, a);
+  } else if (v4) {
     const int grid = ew_grid((long long)N * OH * OW * (C / 4));
     if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
@@ -606,7 +605,11 @@ extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int d
     else hipLaunchKernelGGL((resize_bwd_wide_kernel<bf16_t>), grid, dim3(RBW_THREADS), 0, st, a);
     return check_launch("emrt_resize_bilinear_bwd");
   }
-  if (v4) {
+  const bool v8 = v4 && dtype != EMRT_F32 && C % 8 == 0 && do_ld % 8 == 0 && di_ld % 8 == 0 && do_bs % 8 == 0 && di_bs % 8 == 0;
+  if (v8) {
+    const int grid = ew_grid((long long)N * IH * IW * (C / 8));
+    hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, a);
+  } else if (v4) {
     const int grid = ew_grid((long long)N * IH * IW * (C / 4));
     if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
