@@ -357,6 +357,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     constexpr int CGR = BN / 8;                      // 8-channel groups per row
     constexpr int NT = 256 * G;
     constexpr int RP = NT / CGR;                     // rows per pass
+    static_assert(2 * BN <= NT, "the statistics reduction assigns one thread per (statistic, column)");
     const bool al16 = (((uintptr_t)p.out) & 15) == 0 && (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.mask_y || (((uintptr_t)p.mask_y) & 15) == 0) &&
                       (!p.stat_x || (((uintptr_t)p.stat_x) & 15) == 0);
     const int eo = p.out_f32 ? 4 : EPC;              // elements per 16 bytes of the output
