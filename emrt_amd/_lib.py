@@ -133,6 +133,13 @@ class _Lib:
             import torch
             torch.cuda.synchronize()
 
+    def set_tuning(self, name, value):
+        """Developer / test knob of the kernel dispatchers (include/emrt_hip.h: emrt_set_tuning); returns the old value."""
+        old = ctypes.c_int(0)
+        if self._raw_emrt_get_tuning(name.encode(), ctypes.byref(old)) != 0 or self._raw_emrt_set_tuning(name.encode(), int(value)) != 0:
+            raise EmrtHipError(self.last_error())
+        return old.value
+
     def query(self, name, *args):
         return getattr(self, "_raw_" + name)(*args)
 

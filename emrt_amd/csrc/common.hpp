@@ -29,6 +29,23 @@ inline int check_launch(const char* fn) {
     if (!(cond)) return emrt::fail(__func__, msg); \
   } while (0)
 
+// ---- tuning knobs (developer / test aids) -----------------------------------------------------
+// Read ONCE from the environment when the library is loaded (EMRT_<NAME IN CAPITALS>) and changeable afterwards through
+// emrt_set_tuning(): the dispatchers only ever read these plain ints, no getenv() on a launch path.
+struct Tuning {
+  int conv_tile;        // 0 = the dispatcher's choice; 1..6 force an igemm tile (tools/bench_conv.py)
+  int wgrad_split;      // 0 = cost model; > 0 forces the number of pixel-reduction slices
+  int thin_cblk;        // thin classifier backward: channels per block (64)
+  int thin_blocks;      // ... pixel chunks (128)
+  int thin_ch;          // ... channels per thread (8)
+  int no_thin_bwd;      // 1 = the classifier backward runs as two GEMMs
+  int pair_max;         // largest dgrad grid that is paired with its wgrad in one launch (768)
+  int msda_fwd_global;  // 1 = never use the LDS-staged MSDA forward
+  int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
+  int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
+};
+extern Tuning g_tune;
+
 // ---- element types ---------------------------------------------------------------------------
 struct bf16_t {
   unsigned short v;

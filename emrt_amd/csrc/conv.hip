@@ -880,8 +880,8 @@ template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
   const long long M = (long long)a.N * a.OH * a.OW;
   auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
-  if (const char* ov = getenv("EMRT_CONV_TILE")) {     // developer knob for tools/bench_conv.py; unset in production
-    switch (atoi(ov)) {
+  if (g_tune.conv_tile) {                               // developer knob for tools/bench_conv.py; 0 in production
+    switch (g_tune.conv_tile) {
       case 1: return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);
       case 2: return launch_igemm<T, 2, 1, 2, 2, MODE, VEC>(a, st);
       case 3: return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
@@ -983,10 +983,7 @@ static void wgrad_plan(WgradArgs& a, int& tx, int& ty, int& S_out) {
     const double t = per * (nblk > 1024.0 ? nblk / 1024.0 : 1.0) + sc * atom_us;
     if (t < best) { best = t; S = sc; }
   }
-  if (const char* ov = getenv("EMRT_WGRAD_SPLIT")) {   // developer knob for tools/bench_conv.py
-    const long long v = atoll(ov);
-    if (v > 0) S = v < mt_total ? v : mt_total;
-  }
+  if (g_tune.wgrad_split > 0) S = g_tune.wgrad_split < mt_total ? g_tune.wgrad_split : mt_total;   // developer knob (tools/bench_conv.py)
   a.tiles_per_split = (int)((mt_total + S - 1) / S);
   S_out = (int)((mt_total + a.tiles_per_split - 1) / a.tiles_per_split);
 }
@@ -1227,9 +1224,7 @@ static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t
   // what bounds the kernel (measured on 8x128x128x256 -> 6: one channel chunk with 1024 pixel chunks 155 us, 256 chunks 90 us, without the atomics
   // 47-60 us; 4 channel chunks x 128 pixel chunks 46 us; the MFMA pair before it 214 us): few, long pixel
   // chunks keep the atomic count down, the channel chunks (whole 128-byte lines per pixel) restore the block count.
-  const char* ec = getenv("EMRT_THIN_CBLK");       // developer knobs
-  const char* eb = getenv("EMRT_THIN_BLOCKS");
-  int cblk = ec ? atoi(ec) : 64;
+  int cblk = g_tune.thin_cblk;                     // developer knobs (defaults 64 / 128)
   if (cblk < 8 * CH) cblk = 8 * CH;               // a lane group must hold the OC <= 8 lanes that fetch the dy row
   if (cblk > w.C) cblk = w.C;
   if (cblk > 256 * CH) cblk = 256 * CH;
@@ -1238,7 +1233,7 @@ static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t
   a.cg_shift = sh;
   const int cchunks = w.C / (CH << sh);
   const int ppb = 256 >> sh;
-  const long long want_chunks = eb ? atoll(eb) : 128;
+  const long long want_chunks = g_tune.thin_blocks > 0 ? g_tune.thin_blocks : 128;
   long long per = (a.M + want_chunks - 1) / want_chunks;
   per = (per + 2 * ppb - 1) / (2 * ppb) * (2 * ppb);
   if (per < 8 * ppb) per = 8 * ppb;
@@ -1261,8 +1256,7 @@ static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t
 
 template <class T>
 static int thin_bwd_launch(const ConvArgs& d, const WgradArgs& w, hipStream_t st) {
-  const char* e = getenv("EMRT_THIN_CH");     // developer knob
-  const int want = e ? atoi(e) : 8;
+  const int want = g_tune.thin_ch;            // developer knob (default 8)
   constexpr int EPC = 16 / (int)sizeof(T);
   const bool can8 = w.C >= 64 && w.ldx % 8 == 0 && w.x_bs % 8 == 0 && d.ldout % 8 == 0 && d.out_bs % 8 == 0 &&
                     (!d.mask_y || (d.ldy % 8 == 0 && d.y_bs % 8 == 0)) && EPC <= 8;
@@ -1288,14 +1282,13 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   const long long nd = ((Md + 63) / 64) * ((d.OC + 63) / 64);                 // 64x64 dgrad tiles
   const int nkt = (d.KH * d.KW * d.C + BK - 1) / BK;
   const bool big_tile = d.OC > 64 && nkt >= 16 && ((Md + 127) / 128) * ((d.OC + 127) / 128) >= 256;   // conv_pick_tile would take 128x128
-  if (thin_bwd_ok<T>(d, w0) && !getenv("EMRT_NO_THIN_BWD")) return thin_bwd_launch<T>(d, w0, st);
+  if (thin_bwd_ok<T>(d, w0) && !g_tune.no_thin_bwd) return thin_bwd_launch<T>(d, w0, st);
   int tx = 0, ty = 0, S = 0;
   if (vec_w) wgrad_plan<T>(w, tx, ty, S);
   const long long nw = (long long)tx * ty * S;
   // pairing pays while the dgrad grid is small (measured per shape, tools/bench_conv.py bwd: 16x16 / 8x8 layers -30..-40 %,
   // token linears -5..-10 %; from ~1000 dgrad tiles on, dgrad misses its 4 blocks per CU and the pair is 5-20 % slower)
-  const char* pm_env = getenv("EMRT_PAIR_MAX");      // developer knob; read per call so a sweep can flip it
-  const long long pair_max = pm_env ? atoll(pm_env) : 768;   // measured: 0 -> 15.03 ms, 384 -> 14.46, 768 -> 14.42, 1536 -> 14.35, 3072+ -> 14.43
+  const long long pair_max = g_tune.pair_max;                // developer knob, default 768; measured: 0 -> 15.03 ms, 384 -> 14.46, 768 -> 14.42, 1536 -> 14.35, 3072+ -> 14.43
   if (vec_d && vec_w && d.OC > 32 && !big_tile && nd <= pair_max && nd + nw <= 4096) {
     auto kern = bwd_pair_kernel<T, 1, 1, 2, 2, 6>;
     const size_t lds_d = (size_t)2 * 128 * 144, lds_w = (size_t)4 * Cfg::BKM * Cfg::PITCH;

@@ -2,13 +2,52 @@
 // sigmoid, dtype casts, memset.  Reference sites: with_pos_embed (transformer_encoder_decoder.py:154-155,273-274),
 // nn.Dropout / nn.Dropout2D (:115,119,122,250,255,261,263; paddle_EMRT.py:208; fcn_head.py:65), F.sigmoid (:466).
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace emrt;
 
 thread_local char emrt::g_err[512] = {0};
 
 extern "C" const char* emrt_last_error(void) { return emrt::g_err; }
-extern "C" int emrt_abi_version(void) { return 1; }
+extern "C" int emrt_abi_version(void) { return 2; }
+
+// ---- tuning knobs: one table, environment read once at load time --------------------------------------------------
+namespace {
+struct TuneEntry { const char* name; int emrt::Tuning::*field; int def; };
+const TuneEntry kTune[] = {
+    {"conv_tile", &emrt::Tuning::conv_tile, 0},         {"wgrad_split", &emrt::Tuning::wgrad_split, 0},
+    {"thin_cblk", &emrt::Tuning::thin_cblk, 64},        {"thin_blocks", &emrt::Tuning::thin_blocks, 128},
+    {"thin_ch", &emrt::Tuning::thin_ch, 8},             {"no_thin_bwd", &emrt::Tuning::no_thin_bwd, 0},
+    {"pair_max", &emrt::Tuning::pair_max, 768},         {"msda_fwd_global", &emrt::Tuning::msda_fwd_global, 0},
+    {"bn_block_kb", &emrt::Tuning::bn_block_kb, 8},     {"ln_atomic", &emrt::Tuning::ln_atomic, 1},
+};
+emrt::Tuning tuning_from_env() {
+  emrt::Tuning t;
+  for (const TuneEntry& e : kTune) {
+    char env[64] = "EMRT_";
+    size_t n = strlen(env);
+    for (const char* c = e.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+    env[n] = 0;
+    const char* v = getenv(env);
+    t.*(e.field) = v ? atoi(v) : e.def;
+  }
+  return t;
+}
+}  // namespace
+emrt::Tuning emrt::g_tune = tuning_from_env();
+
+extern "C" int emrt_set_tuning(const char* name, int value) {
+  EMRT_REQUIRE(name, "null name");
+  for (const TuneEntry& e : kTune)
+    if (strcmp(e.name, name) == 0) { emrt::g_tune.*(e.field) = value; return 0; }
+  return emrt::fail("emrt_set_tuning", "unknown knob");
+}
+extern "C" int emrt_get_tuning(const char* name, int* value) {
+  EMRT_REQUIRE(name && value, "null pointer");
+  for (const TuneEntry& e : kTune)
+    if (strcmp(e.name, name) == 0) { *value = emrt::g_tune.*(e.field); return 0; }
+  return emrt::fail("emrt_get_tuning", "unknown knob");
+}
 
 static inline int ew_grid(long long total) {
   long long g = (total + 255) / 256;

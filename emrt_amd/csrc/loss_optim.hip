@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    result[0] = (float)(ra[0] / rb[0]);
+    // Paddle's cross_entropy divides by count + (count == 0): a batch whose pixels are all ignore_index gives loss 0, not 0/0
+    result[0] = (float)(ra[0] / (rb[0] > 0.0 ? rb[0] : 1.0));
     result[1] = (float)rb[0];
   }
 }
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
                                                      float weight, int N, int C, long long HW, int ignore_index,
                                                      float* __restrict__ dlogits) {
   const long long total = (long long)N * HW;
-  const float g = weight * (upstream ? upstream[0] : 1.f) / result[1];
+  const float g = weight * (upstream ? upstream[0] : 1.f) / fmaxf(result[1], 1.f);      // (all-ignored batch: zero gradient)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long lab = labels[idx];
     const long long n = idx / HW, p = idx - n * HW;

@@ -595,7 +595,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   hipStream_t st = (hipStream_t)stream;
   a.Lv = Lv;
   const size_t slab = (size_t)Lv * MSDA_FWD_PITCH;
-  if (dtype == EMRT_BF16 && slab <= 150 * 1024 && (long long)B * M * Lq >= 8192 && !getenv("EMRT_MSDA_FWD_GLOBAL")) {       // LDS-staged slab (see msda_fwd_lds_kernel)
+  if (dtype == EMRT_BF16 && slab <= 150 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {       // LDS-staged slab (see msda_fwd_lds_kernel)
     int chunks = (512 + B * M - 1) / (B * M);                  // ~2 blocks per CU
     if (chunks > (Lq + 255) / 256) chunks = (Lq + 255) / 256;  // at least one 256-query pass per block
     if (chunks < 1) chunks = 1;

@@ -998,8 +998,7 @@ static inline bool bn_rowgeom(long long M, int C, int& threads, int& rows_per_pa
   else return false;
   // every block first derives the per-channel constants (C x 16 fp64 loads + fp64 math, ~2 us of latency), so it should
   // then stream a decent amount of data: ~32 KB of input per block, between 64 and 1024 blocks
-  const char* ov = getenv("EMRT_BN_BLOCK_KB");
-  const long long per_block = (ov ? atoll(ov) : 8) * 1024;
+  const long long per_block = (long long)(g_tune.bn_block_kb > 0 ? g_tune.bn_block_kb : 8) * 1024;
   long long g = (M * C * 2 + per_block - 1) / per_block;
   const long long gmax = (M + rows_per_pass - 1) / rows_per_pass;
   if (g < 64) g = 64;
@@ -1108,8 +1107,7 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  const char* ea = getenv("EMRT_LN_ATOMIC");       // developer knob shared with emrt_layernorm_bwd: 0 = partials + finalize launch
-  const bool direct = !(ea && atoi(ea) == 0);
+  const bool direct = g_tune.ln_atomic != 0;       // developer knob shared with emrt_layernorm_bwd: 0 = partials + finalize launch
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((col_reduce_kernel<float, 2>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr, direct ? dbias : nullptr),
             hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 2>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, tx, partial, rows_per_batch, x_bs, nullptr, direct ? dbias : nullptr));
@@ -1220,8 +1218,7 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   rpb = (rpb + 7) / 8 * 8;
   blocks = (rows + rpb - 1) / rpb;
   float* partial = (float*)workspace;
-  const char* ea = getenv("EMRT_LN_ATOMIC");       // developer knob: 0 = partials + finalize launch
-  const bool direct = (dgamma || dbeta) && !(ea && atoi(ea) == 0);
+  const bool direct = (dgamma || dbeta) && g_tune.ln_atomic != 0;       // developer knob: 0 = partials + finalize launch
   const size_t lds = (size_t)8 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,

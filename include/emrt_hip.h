@@ -30,6 +30,12 @@ extern "C" {
 const char* emrt_last_error(void);
 int emrt_abi_version(void);
 int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len);
+/* Developer / test knobs of the dispatchers (forced tile shapes, kernel variants).  The table is filled ONCE from the
+ * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
+ * conv_tile, wgrad_split, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, bn_block_kb, ln_atomic.
+ * Not thread-safe against concurrent launches; production code never calls these. */
+int emrt_set_tuning(const char* name, int value);
+int emrt_get_tuning(const char* name, int* value);
 
 /* ---- convolution / linear as implicit GEMM (MFMA 32x32) ---------------------------------------------------
  * replaces nn.Conv2D: backbones/paddle_vision_resnet.py:108-123,192-198,226-233; paddle_EMRT.py:16-23,63,85-91,

@@ -1,0 +1,299 @@
+"""-m gpu parity tests AT THE BENCHMARK'S OWN SHAPES AND DTYPE (bf16, BASELINE configs[1] and configs[2]).
+
+The kernel-level cases of test_gpu_kernels.py are small, so the dispatchers route them to the small-problem kernels; the
+kernels bench.py actually times are selected by size:
+  * msda_fwd_lds_kernel      -- bf16, B*M*Lq >= 8192 and the (batch, head) slab fits in LDS (msda.hip: emrt_msda_fwd)
+  * igemm_kernel 128x128 bf16 -- OC > 64, >= 16 k-tiles, >= 256 blocks (conv.hip: conv_pick_tile)
+  * wgrad_kernel<bf16> with the pixel reduction split over blockIdx.z (wgrad_plan), bwd_pair_kernel on the 16x16 / 32x32 maps
+Each is compared here with the oracle's torch-CPU expression of the same reference operator on bf16-rounded inputs
+(reference arithmetic: EMRT_utils/utils.py:64-97, paddle_EMRT.py:134-138,201-209), the two MSDA forward kernels with each
+other bit for bit, and the whole bf16 model at batch 8 / 256x256 / ResNet-50 with the fp32 oracle under stated bounds.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from emrt_amd import _lib                       # noqa: E402
+from emrt_amd import functional as Fn          # noqa: E402
+from emrt_amd import nn as hnn                  # noqa: E402
+from emrt_amd.runtime import ctx, F32, BF16, Tape   # noqa: E402
+from tests.hip_utils import init, dev_map, host_map, dev, host, rnd, Holder, close   # noqa: E402
+from tests.test_gpu_kernels import _msda_ref, run_bwd   # noqa: E402
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# MSDA at the encoder-call shapes of cfg2 (B=8, 256^2 -> Lv=1344) and cfg3 (B=4, 512^2 -> Lv=5376)
+# -----------------------------------------------------------------------------------------------------------------
+MSDA_BENCH = [
+    dict(name="cfg2-encoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=None, lds=True),
+    dict(name="cfg2-decoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=110, lds=False),    # B*M*Lq = 7040 < 8192: global kernel
+    dict(name="cfg3-encoder", B=4, shapes=[(64, 64), (32, 32), (16, 16)], Lq=None, lds=False),   # slab 430 KB: global kernel
+]
+
+
+def _msda_inputs(cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    M, L, Pn = 8, 3, 6
+    shapes = cfg["shapes"]
+    Lv = sum(h * w for h, w in shapes)
+    B = cfg["B"]
+    Lq = cfg["Lq"] or Lv
+    tp = M * L * Pn
+    value = rnd(torch.randn(B, Lv, M * 32, generator=g))
+    # offsets of a few pixels (the trained regime: |off| <~ 6 px in the level's own units) and O(1) logits
+    offw = torch.cat([torch.randn(B, Lq, 2 * tp, generator=g) * 2.5, torch.randn(B, Lq, tp, generator=g)], -1)
+    if cfg["Lq"] is None:      # encoder: pixel-centre reference points, shared by the batch, one per level (identical)
+        from emrt_amd.src.models.emrt import encoder_reference_points
+        ref = encoder_reference_points(shapes)
+    else:
+        ref = torch.rand(1, Lq, 1, 2, generator=g)
+    return value, offw, ref, shapes, (B, Lq, Lv, M, L, Pn)
+
+
+@pytest.mark.parametrize("cfg", MSDA_BENCH, ids=[c["name"] for c in MSDA_BENCH])
+def test_msda_bench_shape_bf16_vs_oracle(cfg):
+    c = init(BF16)
+    L_ = _lib.lib()
+    value, offw, ref, shapes, (B, Lq, Lv, M, L, Pn) = _msda_inputs(cfg, 31)
+    vr, orq = value.clone().requires_grad_(True), offw.clone().requires_grad_(True)
+    out_r = _msda_ref(vr, orq, ref, shapes, M, L, Pn)
+    dy = rnd(torch.randn(out_r.shape, generator=torch.Generator().manual_seed(32)))
+    out_r.backward(dy)
+    vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
+    tape = Tape()
+    c.tape = tape
+    y = Fn.msda(vd, od, rd, shapes, M, Pn)
+    c.tape = None
+    tape.watch(vd)
+    tape.watch(od)
+    # which kernel ran is decided by the same rule the dispatcher uses (msda.hip: emrt_msda_fwd)
+    uses_lds = Lv * 80 <= 150 * 1024 and B * M * Lq >= 8192
+    assert uses_lds == cfg["lds"], "the test case no longer selects the kernel it was written for"
+    # bf16 output of an fp32 accumulation over bf16 values: one rounding of the result (2^-9 relative) + accumulation noise
+    close("msda fwd (bench shape)", host(y), out_r.detach(), BF16, atol=2e-2, rtol=1e-2)
+    rel = ((host(y) - out_r.detach()).norm() / out_r.detach().norm()).item()
+    assert rel < 4e-3, "relative L2 error %.4g" % rel
+    # the same call on the other forward kernel must be BIT-identical (msda.hip states the two share arithmetic and order)
+    old = L_.set_tuning("msda_fwd_global", 1)
+    try:
+        y_glob = Fn.msda(vd, od, rd, shapes, M, Pn)
+    finally:
+        L_.set_tuning("msda_fwd_global", old)
+    assert torch.equal(y_glob, y), "LDS-staged and global MSDA forward differ: max |diff| %.3g" % (y_glob.float() - y.float()).abs().max().item()
+    dv, do = run_bwd(tape, [(y, dev(dy))], [vd, od])
+    gv, go = vr.grad, orq.grad
+    rel_v = ((host(dv) - gv).norm() / gv.norm()).item()
+    rel_o = ((host(do) - go).norm() / go.norm()).item()
+    print("msda %s: fwd rel %.2e, dvalue rel %.2e, doffw rel %.2e" % (cfg["name"], rel, rel_v, rel_o))
+    # dvalue: fixed-point LDS scatter then ONE bf16 rounding; doffw: fp32 from bf16 operands
+    assert rel_v < 6e-3 and rel_o < 6e-3, (rel_v, rel_o)
+    close("msda dvalue (bench shape)", host(dv), gv, BF16, atol=6e-2 * float(gv.abs().max()) / 8, rtol=2e-2)
+
+
+def test_msda_lds_scatter_is_bit_reproducible():
+    """The value gradient is an integer (fixed-point) LDS scatter: two launches on the same inputs must agree bit for bit
+    (DESIGN.md 4); the fp32 offset / logit gradients have no atomics at all."""
+    c = init(BF16)
+    value, offw, ref, shapes, (B, Lq, Lv, M, L, Pn) = _msda_inputs(MSDA_BENCH[0], 33)
+    vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
+    dy = dev(rnd(torch.randn(B, Lq, M * 32, generator=torch.Generator().manual_seed(34))))
+    res = []
+    for _ in range(2):
+        tape = Tape()
+        c.tape = tape
+        y = Fn.msda(vd, od, rd, shapes, M, Pn)
+        c.tape = None
+        tape.watch(vd)
+        tape.watch(od)
+        res.append(run_bwd(tape, [(y, dy)], [vd, od]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# convolutions at the shapes that carry the step's FLOPs
+# -----------------------------------------------------------------------------------------------------------------
+CONV_BENCH = [
+    # name, N, H, W, Cin, Cout, k, stride, pad, bias, expected forward path
+    ("uphead-128", 8, 128, 128, 256, 256, 3, 1, 1, True, "128x128"),      # paddle_EMRT.py:136 (conv_2), 77 GFLOP forward
+    ("uphead-64", 8, 64, 64, 256, 256, 3, 1, 1, True, "128x128"),         # :135 (conv_1)
+    ("cls_psp-0", 8, 32, 32, 1536, 512, 3, 1, 1, False, "128x128"),       # :201-203, K = 13 824
+    ("layer4-1x1", 8, 8, 8, 2048, 512, 1, 1, 0, False, "ksplit"),         # paddle_vision_resnet.py:108 at 8x8
+    ("layer3-3x3", 8, 16, 16, 256, 256, 3, 1, 1, False, "pair"),          # :111-119 at 16x16: dgrad+wgrad pair launch
+    ("efp-3x3", 8, 32, 32, 256, 256, 3, 1, 1, False, "pair"),             # paddle_EMRT.py:16-23 at 32x32
+    ("ffn-linear1", 8, 1, 1344, 256, 1024, 1, 1, 0, True, "pair"),        # transformer_encoder_decoder.py:118 over [8,1344,256]
+]
+
+
+def _expected_paths(N, H, W, Cin, Cout, k, stride, pad):
+    """What conv.hip's dispatchers pick for a bf16 problem (mirrors conv_pick_tile / conv_bwd_dispatch)."""
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = N * OH * OW
+    nkt = (k * k * Cin + 63) // 64
+    blocks128 = ((M + 127) // 128) * ((Cout + 127) // 128)
+    fwd_big = Cout > 64 and nkt >= 16 and blocks128 >= 256
+    Md = N * H * W
+    nd = ((Md + 63) // 64) * ((Cin + 63) // 64)
+    nkt_d = (k * k * Cout + 63) // 64
+    dgrad_big = Cin > 64 and nkt_d >= 16 and ((Md + 127) // 128) * ((Cin + 127) // 128) >= 256
+    pair = Cin > 32 and not dgrad_big and nd <= 768
+    return fwd_big, dgrad_big, pair
+
+
+@pytest.mark.parametrize("case", CONV_BENCH, ids=[c[0] for c in CONV_BENCH])
+def test_conv_bench_shape_bf16_vs_torch(case):
+    name, N, H, W, Cin, Cout, k, stride, pad, bias, path = case
+    fwd_big, dgrad_big, pair = _expected_paths(N, H, W, Cin, Cout, k, stride, pad)
+    assert {"128x128": fwd_big and dgrad_big and not pair, "pair": pair, "ksplit": not fwd_big}[path], \
+        "the case no longer reaches the kernel it was written for: %s" % ((fwd_big, dgrad_big, pair),)
+    c = init(BF16)
+    g = torch.Generator().manual_seed(41)
+    x = rnd(torch.randn(N, Cin, H, W, generator=g))
+    conv = hnn.Conv2D(Cin, Cout, k, stride, pad, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)))
+        if bias:
+            conv.bias.copy_(torch.randn(Cout, generator=g))
+    w_ref, b_ref = conv.weight.detach().clone(), (conv.bias.detach().clone() if bias else None)
+    Holder(conv=conv).place()
+    xr = x.clone().requires_grad_(True)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    dy = rnd(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    xd = dev_map(x)
+    tape = Tape()
+    c.tape = tape
+    y = conv(xd)
+    c.tape = None
+    tape.watch(xd)
+    yh = host_map(y)
+    rel = ((yh - yr.detach()).norm() / yr.detach().norm()).item()
+    # outputs are O(1); a bf16 store is 2^-9 relative, the fp32 accumulation over K <= 13 824 terms adds ~1e-3 absolute
+    close("conv fwd " + name, yh, yr.detach(), BF16, atol=2e-2, rtol=1e-2)
+    assert rel < 4e-3, rel
+    dx, = run_bwd(tape, [(y, dev_map(dy))], [xd])
+    dxh = host_map(dx)
+    rel_dx = ((dxh - xr.grad).norm() / xr.grad.norm()).item()
+    rel_dw = ((host(conv.weight.grad) - wr.grad).norm() / wr.grad.norm()).item()
+    print("conv %s: fwd rel %.2e, dgrad rel %.2e, wgrad rel %.2e" % (name, rel, rel_dx, rel_dw))
+    assert rel_dx < 4e-3, rel_dx          # one bf16 rounding of the stored dx
+    assert rel_dw < 1e-3, rel_dw          # fp32 atomics over bf16 operands: only summation-order noise
+    kscale = math.sqrt(Cout * k * k / (stride * stride)) / math.sqrt(Cin * k * k)      # typical |dx|
+    close("conv dgrad " + name, dxh, xr.grad, BF16, atol=3e-2 * kscale, rtol=1e-2)
+    if bias:
+        rel_db = ((host(conv.bias.grad) - br.grad).norm() / br.grad.norm()).item()
+        assert rel_db < 1e-3, rel_db
+
+
+def test_wgrad_fp32_atomics_run_to_run_spread_is_bounded():
+    """The weight gradient is summed with fp32 atomics over blockIdx.z slices (atomics-based backward): the
+    order of the adds differs between launches, so results are NOT bit-reproducible; the spread must stay at fp32
+    rounding level (relative 1e-6 of the gradient norm), three orders below the bf16 noise of the operands."""
+    c = init(BF16)
+    g = torch.Generator().manual_seed(43)
+    N, H, W, Cin, Cout = 8, 64, 64, 256, 256
+    conv = hnn.Conv2D(Cin, Cout, 3, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(Cout, Cin, 3, 3, generator=g) / 48))
+    Holder(conv=conv).place()
+    xd = dev_map(rnd(torch.randn(N, Cin, H, W, generator=g)))
+    dyd = dev_map(rnd(torch.randn(N, Cout, H, W, generator=g)))
+    grads = []
+    for _ in range(2):
+        conv.weight.grad.zero_()
+        conv.bias.grad.zero_()
+        tape = Tape()
+        c.tape = tape
+        y = conv(xd)
+        c.tape = None
+        tape.add_grad(y, dyd)
+        tape.backward()
+        torch.cuda.synchronize()
+        grads.append((conv.weight.grad.clone(), conv.bias.grad.clone()))
+    dw = (grads[0][0] - grads[1][0]).norm().item() / grads[0][0].norm().item()
+    db = (grads[0][1] - grads[1][1]).norm().item() / grads[0][1].norm().item()
+    print("wgrad run-to-run relative spread: dW %.2e, dbias %.2e" % (dw, db))
+    assert dw < 2e-6 and db < 2e-6, (dw, db)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# the whole model in bf16 -- the benchmark's dtype -- at the benchmark's size, against the fp32 oracle
+# -----------------------------------------------------------------------------------------------------------------
+# Bounds (measured values are printed; see DESIGN.md "Parity results"):
+BF16_LOGIT_REL_L2 = 3e-2        # ||logits_bf16 - logits_ref|| / ||logits_ref||, main and aux head
+BF16_ARGMAX_AGREE = 0.97        # fraction of pixels with the same argmax class (all pixels, near-ties included)
+BF16_DECISIVE_AGREE = 0.999     # ... among pixels whose fp32 top-2 margin exceeds 10 % of the logit range
+BF16_LOSS_REL = 1e-2
+BF16_GRAD_COSINE = 0.97         # cosine between the whole bf16 gradient vector and the fp32 oracle's
+BF16_GRAD_NORM_RATIO = 0.05     # | ||g_bf16|| / ||g_ref|| - 1 |
+
+
+def test_full_size_bf16_model_vs_fp32_oracle():
+    """BASELINE configs[1] (ResNet-50, batch 8, 256x256, 6 classes) in bf16 storage / fp32 accumulation against the fp32
+    CPU oracle (the reference is fp32 throughout, train.py:141-159): eval-mode logits and argmax masks, then one
+    train-mode forward + loss + backward (dropout off: the oracle cannot share the device's mask stream)."""
+    from tests.test_gpu_model import build_pair, make_config
+    from emrt_amd.src.models.losses import get_loss_function
+    from oracle import train_ref
+    g = torch.Generator().manual_seed(17)
+    B, S = 8, 256
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
+    ref, model = build_pair("resnet50", x, dtype=BF16, perturb=True)
+    # ---- eval-mode logits (running statistics calibrated on this batch) ---------------------------------------------
+    ref.eval()
+    model.eval()
+    with torch.no_grad():
+        want = ref(x)
+    got = model(x.cuda())
+    for name, a, b in (("main", got[0].cpu(), want[0]), ("aux", got[1].cpu(), want[1])):
+        rel = ((a - b).norm() / b.norm()).item()
+        agree = (a.argmax(1) == b.argmax(1)).float().mean().item()
+        top2 = b.topk(2, dim=1).values
+        margin = top2[:, 0] - top2[:, 1]
+        decisive = margin > 0.1 * (b.max() - b.min())
+        agree_dec = (a.argmax(1) == b.argmax(1))[decisive].float().mean().item()
+        print("bf16 eval %s logits: rel L2 %.4f, max |diff| %.4f (|ref| max %.3f), argmax agreement %.5f, among %d decisive pixels %.6f" % (
+            name, rel, (a - b).abs().max().item(), b.abs().max().item(), agree, int(decisive.sum()), agree_dec))
+        assert rel < BF16_LOGIT_REL_L2, (name, rel)
+        assert agree >= BF16_ARGMAX_AGREE, (name, agree)
+        assert agree_dec >= BF16_DECISIVE_AGREE, (name, agree_dec)
+    # ---- one training step's forward / loss / backward ------------------------------------------------------------------
+    ref.train()
+    out_r = ref(x)
+    loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
+    loss_r.backward()
+    model.train()
+    model.clear_gradients()
+    out = model(x.cuda())
+    loss = get_loss_function(make_config("resnet50"))(out, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    rel_main = ((out[0].cpu() - out_r[0].detach()).norm() / out_r[0].detach().norm()).item()
+    rel_loss = abs(loss.item() - loss_r.item()) / abs(loss_r.item())
+    refp = dict(ref.named_parameters())
+    dot = n_hip = n_ref = 0.0
+    per = []
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None:
+            continue
+        gg, gr = p.grad.cpu().double(), gr.double()
+        dot += float((gg * gr).sum())
+        n_hip += float((gg * gg).sum())
+        n_ref += float((gr * gr).sum())
+        if gr.norm() > 0:
+            per.append((float((gg * gr).sum() / (gg.norm() * gr.norm() + 1e-300)), n))
+    cos = dot / (n_hip ** 0.5 * n_ref ** 0.5)
+    ratio = (n_hip / n_ref) ** 0.5
+    per.sort()
+    print("bf16 train step: logits rel L2 %.4f, loss %.5f vs %.5f (rel %.2e), gradient cosine %.5f, norm ratio %.4f, worst per-parameter cosines %s" % (
+        rel_main, loss.item(), loss_r.item(), rel_loss, cos, ratio, per[:4]))
+    assert rel_main < BF16_LOGIT_REL_L2 and rel_loss < BF16_LOSS_REL
+    assert cos > BF16_GRAD_COSINE and abs(ratio - 1.0) < BF16_GRAD_NORM_RATIO, (cos, ratio)

@@ -73,7 +73,7 @@ def thin():
     for ch in (8, 4):
         for cblk in (64, 128, 256):
             for blocks in (64, 128, 256, 512):
-                os.environ.update(EMRT_THIN_CH=str(ch), EMRT_THIN_BLOCKS=str(blocks), EMRT_THIN_CBLK=str(cblk))
+                L.set_tuning("thin_ch", ch), L.set_tuning("thin_blocks", blocks), L.set_tuning("thin_cblk", cblk)
                 print("CH %d cblk %3d pixel chunks %4d: masked+stats %.1f us  plain %.1f us" % (ch, cblk, blocks, timed(lambda: run(True)), timed(lambda: run(False))), flush=True)
 
 
@@ -112,9 +112,9 @@ def main():
         if which == "bwd":
             res = []
             for pm in (0, 1 << 30):
-                os.environ["EMRT_PAIR_MAX"] = str(pm)
+                old = L.set_tuning("pair_max", pm)
                 res.append(timed(bwd))
-            os.environ.pop("EMRT_PAIR_MAX")
+                L.set_tuning("pair_max", old)
             Md = N * H * W
             nd = ((Md + 63) // 64) * ((C + 63) // 64)
             line += " bwd separate %.1f paired %.1f   (dgrad 64x64 tiles %d)" % (res[0], res[1], nd)
@@ -122,17 +122,16 @@ def main():
             for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
                 res = []
                 for tile in (0, 1, 5, 6, 3):
-                    os.environ["EMRT_CONV_TILE"] = str(tile)
+                    L.set_tuning("conv_tile", tile)
                     res.append(timed(fn))
-                os.environ.pop("EMRT_CONV_TILE")
+                L.set_tuning("conv_tile", 0)
                 line += " %s auto %.1f 64x64 %.1f ksplit2 %.1f ksplit4 %.1f 128x128 %.1f |" % (name, *res)
         if which in ("all", "wgrad"):
             res = []
             for sp in (0, 1, 2, 4, 8, 16, 32):
-                if sp:
-                    os.environ["EMRT_WGRAD_SPLIT"] = str(sp)
+                L.set_tuning("wgrad_split", sp)
                 res.append(timed(wgrad))
-            os.environ.pop("EMRT_WGRAD_SPLIT")
+            L.set_tuning("wgrad_split", 0)
             line += " wgrad auto %.1f S1 %.1f S2 %.1f S4 %.1f S8 %.1f S16 %.1f S32 %.1f" % tuple(res)
         print(line, flush=True)
 
