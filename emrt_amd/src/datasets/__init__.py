@@ -80,32 +80,46 @@ def get_dataset(config, data_transform, mode="train"):
 
 class TileLoader:
     """Iteration-based training loader (utils/dataloader.py:22-49): `sampler` yields index lists (DistributedTileSampler);
-    `workers` threads decode + augment tiles (PIL and numpy release the GIL for the heavy parts) and a bounded queue of
-    ready batches is staged on `device` as (fp32 [B,3,H,W], int64 [B,H,W]) so the training stream never waits on the host
-    unless the readers cannot keep up."""
+    `workers` threads decode + augment tiles (PIL and numpy release the GIL for the heavy parts) into PINNED host batches;
+    at most `prefetch` finished batches exist at any time (a worker takes a slot before it starts a batch and the consumer
+    returns it when it pops one).  The host->device copy is issued by the CONSUMER thread on the training stream (torch's
+    current stream there): every later kernel on that stream is ordered after the copy, and the caching allocator ties the
+    device block to that stream, so a batch can never be recycled under a queued kernel (a reader thread's `.to(device)`
+    would run on that thread's own NULL stream, with nothing ordering it against the training stream)."""
 
     def __init__(self, dataset, sampler, device, workers=4, prefetch=4):
-        self.dataset, self.sampler, self.device, self.workers, self.prefetch = dataset, sampler, device, max(1, workers), prefetch
+        self.dataset, self.sampler, self.device, self.workers, self.prefetch = dataset, sampler, device, max(1, workers), max(1, prefetch)
+        self.pin = torch.cuda.is_available() and torch.device(device).type == "cuda"
 
     def _batch(self, idx):
+        """Decoded, augmented host batch (fp32 [B,3,H,W], int64 [B,H,W]), page-locked when it is going to a GPU."""
         items = [self.dataset[i] for i in idx]
         imgs = torch.from_numpy(np.stack([it[0] for it in items]))
         labs = torch.from_numpy(np.stack([it[1] for it in items]).astype(np.int64))
-        return imgs.to(self.device, non_blocking=True), labs.to(self.device, non_blocking=True)
+        if self.pin:
+            imgs, labs = imgs.pin_memory(), labs.pin_memory()
+        return imgs, labs
 
     def epochs(self, start_epoch=0):
         """Endless generator of device batches, reshuffling per epoch."""
         todo, done = queue.Queue(maxsize=self.prefetch * 2), {}
-        lock, cv, stop = threading.Lock(), threading.Condition(), threading.Event()
+        cv, stop = threading.Condition(), threading.Event()
+        slots = threading.Semaphore(self.prefetch)       # finished-but-unconsumed batches (+ the ones being built)
+        turn = [0]                                        # batches are built in order: slot n is taken before slot n + 1
 
         def feed():
             ep, n = start_epoch, 0
             while not stop.is_set():
                 self.sampler.set_epoch(ep)
                 for idx in self.sampler:
+                    while not stop.is_set():
+                        try:
+                            todo.put((n, idx), timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
                     if stop.is_set():
                         return
-                    todo.put((n, idx))
                     n += 1
                 ep += 1
 
@@ -115,6 +129,17 @@ class TileLoader:
                     n, idx = todo.get(timeout=0.2)
                 except queue.Empty:
                     continue
+                # wait for this batch's turn, then for a free slot: the batch the consumer is waiting for always gets one
+                with cv:
+                    while turn[0] != n and not stop.is_set():
+                        cv.wait(timeout=0.2)
+                while not stop.is_set() and not slots.acquire(timeout=0.2):
+                    pass
+                with cv:
+                    turn[0] = n + 1
+                    cv.notify_all()
+                if stop.is_set():
+                    return
                 b = self._batch(idx)
                 with cv:
                     done[n] = b
@@ -129,8 +154,10 @@ class TileLoader:
                 with cv:
                     while n not in done:
                         cv.wait(timeout=1.0)
-                    b = done.pop(n)
+                    imgs, labs = done.pop(n)
+                slots.release()
                 n += 1
-                yield b
+                # consumer thread, training stream: see the class docstring
+                yield imgs.to(self.device, non_blocking=True), labs.to(self.device, non_blocking=True)
         finally:
             stop.set()

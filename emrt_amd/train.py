@@ -42,6 +42,8 @@ def parse_args(argv=None):
     p.add_argument("--resume", default=None, help="checkpoint written by this script")
     p.add_argument("--save_dir", default=None, help="override SAVE_DIR of the yaml (the reference's yamls point at the authors' disks)")
     p.add_argument("--pretrained_backbone", default=None, help="weights to start from (.pdparams or torch): whole model or ResNet backbone")
+    p.add_argument("--no-eval", action="store_true", help="skip the periodic evaluation (train.py:187-195) and best_model.pdparams")
+    p.add_argument("--val_tiles", type=int, default=16, help="--data synthetic / .npz without val arrays: how many held-out tiles to evaluate on")
     return p.parse_args(argv)
 
 
@@ -96,7 +98,11 @@ def main(argv=None):
         # ResNet file as paddle.vision saves it (keys without the "backbone." prefix; detected from the key names)
         from .src.utils.checkpoint import load_pretrained_model, load_pdparams
         path = config.MODEL.PRETRAINED
-        keys = load_pdparams(path).keys() if path.endswith(".pdparams") else torch.load(path, map_location="cpu").get("model", {}).keys()
+        if path.endswith(".pdparams"):
+            keys = load_pdparams(path).keys()
+        else:       # a checkpoint of this script ({"model": state, ...}) or a bare torch state dict
+            ck = torch.load(path, map_location="cpu")
+            keys = ck.get("model", ck).keys()
         prefix = "" if any(k.startswith("backbone.") or k.startswith("model.") for k in keys) else "backbone."
         load_pretrained_model(model, path, prefix=prefix)
     model.to_hip("cuda:%d" % local_rank, BF16 if args.dtype == "bf16" else F32, seed=args.seed + rank)   # per-rank dropout streams
@@ -134,8 +140,38 @@ def main(argv=None):
         start_iter = ck["iter"]
     engine = TrainEngine(model, optimizer, loss_func, nranks, use_graph=not args.no_graph)
     if rank == 0:
-        os.makedirs(config.SAVE_DIR, exist_ok=True) if os.access(os.path.dirname(config.SAVE_DIR) or ".", os.W_OK) else None
+        # the shipped yamls carry the reference authors' own disks as SAVE_DIR: a run that cannot checkpoint must say so
+        # at once, not after 160k iterations (train.py:197-220 writes there unconditionally)
+        try:
+            os.makedirs(config.SAVE_DIR, exist_ok=True)
+            if not os.access(config.SAVE_DIR, os.W_OK):
+                raise PermissionError(config.SAVE_DIR)
+        except OSError as e:
+            fallback = os.path.abspath(os.path.join("output", os.path.basename(os.path.normpath(config.SAVE_DIR)) or "emrt"))
+            print("[WARNING] SAVE_DIR {!r} cannot be created or written ({}); checkpoints go to {!r} instead "
+                  "(pass --save_dir to choose)".format(config.SAVE_DIR, e, fallback), flush=True)
+            os.makedirs(fallback, exist_ok=True)        # failing here is fatal: no silent run without checkpoints
+            config.SAVE_DIR = fallback
         print("train_cfg: {}\ntrain_model_name: {}\ntrain_datatset: {}".format(args.cfg, config.MODEL.NAME, config.DATA.DATASET))
+    # ---- validation set for the periodic evaluation (train.py:88-100, 187-195; val_in_train.py:19-125) ---------------------
+    val_images = val_labels = None
+    if not args.no_eval:
+        if args.data == "dataset":
+            from .src.transforms import get_val_transforms
+            ds_val = get_dataset(config, data_transform=get_val_transforms(config), mode="val")
+            items = [ds_val[i] for i in range(len(ds_val))]
+            val_images = [torch.from_numpy(a).float().to(dev) for a, _ in items]
+            val_labels = [torch.from_numpy(np.ascontiguousarray(b[0])).long().to(dev) for _, b in items]
+        elif args.data != "synthetic" and "val_images" in z.files:
+            val_images = [torch.from_numpy(a).float().to(dev) for a in z["val_images"]]
+            val_labels = [torch.from_numpy(a).long().to(dev) for a in z["val_labels"]]
+        else:       # held-out seeded tiles (synthetic) / the first tiles of the file
+            vi, vl = (synthetic_tiles(args.val_tiles, config.DATA.CROP_SIZE, config.DATA.NUM_CLASSES, args.seed + 7919, dev)
+                      if args.data == "synthetic" else (images[:args.val_tiles], labels[:args.val_tiles]))
+            val_images, val_labels = list(vi), list(vl)
+        if list(config.VAL.STRIDE_SIZE) == [320, 320] and list(config.VAL.CROP_SIZE)[0] < 320:
+            config.VAL.STRIDE_SIZE = list(config.VAL.CROP_SIZE)   # the default stride > crop leaves NaN stripes
+    best_mean_iou, best_acc, best_model_iter = -1.0, -1.0, -1
     iters_per_epoch = max(len(sampler), 1)
     total_epoch = iters // iters_per_epoch
     reader_cost, batch_cost = TimeAverager(), TimeAverager()
@@ -169,18 +205,38 @@ def main(argv=None):
                         reader_cost.get_average(), batch_cost.get_ips_average() * nranks, calculate_eta(iters - cur_iter, batch_cost.get_average())), flush=True)
                 reader_cost.reset()
                 batch_cost.reset()
-            if (cur_iter % config.SAVE_FREQ_CHECKPOINT == 0 or cur_iter == iters) and rank == 0 and os.path.isdir(config.SAVE_DIR):
+            checkpoint_now = cur_iter % config.SAVE_FREQ_CHECKPOINT == 0 or cur_iter == iters
+            mean_iou = None
+            if checkpoint_now and val_images is not None:       # every rank takes part (train.py:187-195)
+                from .val import evaluate
+                val_time_cost, mean_iou, acc, kap, class_iou, class_acc, class_f1, mean_f1 = evaluate(model, val_images, val_labels, config, rank, nranks)
+                if rank == 0:
+                    print("Val_time_cost:   {}".format(val_time_cost))
+                    print("In this val: mIoU {:.4f},  Acc: {:.4f}, F1-Score:{:.4f}".format(mean_iou, acc, mean_f1))
+                    print("Current best_mIoU: {:.4f},  Acc: {:.4f}, iter: {}".format(best_mean_iou, best_acc, best_model_iter), flush=True)
+                model.train()
+            if checkpoint_now and rank == 0:
                 path = os.path.join(config.SAVE_DIR, "iter_{}_state.pt".format(cur_iter))
                 torch.save({"model": {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()},
                             "optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()},
                             "iter": cur_iter}, path)
                 # and the weights alone in the reference's own format (train.py:200-203: iter_{n}_model_state.pdparams)
                 from .src.utils.checkpoint import save_pdparams
-                save_pdparams(model.state_dict(), os.path.join(config.SAVE_DIR, "iter_{}_model_state.pdparams".format(cur_iter)))
-                save_models.append(path)
-                print("saving the weights of model to {}".format(path))
-                if len(save_models) > config.KEEP_CHECKPOINT_MAX > 0:
-                    os.remove(save_models.popleft())
+                pd_path = os.path.join(config.SAVE_DIR, "iter_{}_model_state.pdparams".format(cur_iter))
+                save_pdparams(model.state_dict(), pd_path)
+                save_models.append((path, pd_path))
+                print("saving the weights of model to {}".format(pd_path))
+                if len(save_models) > config.KEEP_CHECKPOINT_MAX > 0:      # both files of the oldest checkpoint (train.py:210-213)
+                    for old in save_models.popleft():
+                        os.remove(old)
+                if mean_iou is not None and mean_iou > best_mean_iou:       # train.py:215-229
+                    best_mean_iou, best_acc, best_model_iter = mean_iou, acc, cur_iter
+                    save_pdparams(model.state_dict(), os.path.join(config.SAVE_DIR, "best_model.pdparams"))
+                    print("\n[EVAL] The model with the best validation mIoU ({:.4f}) was saved at iter {}.".format(best_mean_iou, best_model_iter))
+                    print("[EVAL] Images: {}  mIoU: {:.4f}  Acc: {:.4f}  Kappa: {:.4f}  mean_f1: {:.4f}".format(len(val_images), mean_iou, acc, kap, mean_f1))
+                    print("[EVAL] Class IoU: " + str(np.round(class_iou, 4)))
+                    print("[EVAL] Class Acc: " + str(np.round(class_acc, 4)))
+                    print("[EVAL] Class F1-score: " + str(np.round(class_f1, 4)) + "\n", flush=True)
             batch_start = time.time()
     torch.cuda.synchronize()
     total = sum(int(np.prod(p.shape)) for p in model.parameters())

@@ -91,3 +91,26 @@ def test_tile_loader_batches(tmp_path):
         x, y = next(it)
         assert x.shape == (4, 3, 32, 32) and x.dtype == torch.float32 and y.shape == (4, 32, 32) and y.dtype == torch.int64
     it.close()
+
+
+def test_tile_loader_never_holds_more_than_prefetch_ready_batches(tmp_path):
+    """A slow consumer must not let the reader threads pile up finished batches (they become device memory in training)."""
+    import time
+    root = str(tmp_path / "potsdam")
+    _make_potsdam(root, n=8, size=48)
+    cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(CFG_DIR, "EMRT_256x256_160k_potsdam.yaml")))
+    cfg.DATA.DATA_PATH = root
+    cfg.DATA.CROP_SIZE = [32, 32]
+    ds = get_dataset(cfg, T.get_transforms(cfg), "train")
+    sampler = DistributedTileSampler(len(ds), 2, 0, 1, shuffle=False, drop_last=True, seed=1)
+    loader = TileLoader(ds, sampler, torch.device("cpu"), workers=3, prefetch=2)
+    built = []
+    orig = loader._batch
+    loader._batch = lambda idx: (built.append(1), orig(idx))[1]
+    it = loader.epochs()
+    next(it)
+    time.sleep(1.0)                          # consumer stalls: the workers may only fill the free slots
+    assert len(built) <= 1 + 2, "%d batches were built while at most prefetch = 2 may wait" % len(built)
+    seen = [next(it) for _ in range(6)]      # and the stream keeps flowing in order afterwards
+    assert all(x.shape == (2, 3, 32, 32) for x, _ in seen)
+    it.close()
