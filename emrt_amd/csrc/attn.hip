@@ -242,6 +242,7 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(MhaArgs a) {
 extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs,
                             int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt,
                             int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(q && k && v && o && probs, "null pointer");
   EMRT_REQUIRE(D == MHA_D, "head dim must be 32");
   EMRT_REQUIRE(L >= 1 && L <= MHA_MAXL, "sequence length must be <= 128");
@@ -257,10 +258,12 @@ extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, cons
   if (!attr_done) {
     hipFuncSetAttribute((const void*)mha_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     hipFuncSetAttribute((const void*)mha_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    hipFuncSetAttribute((const void*)mha_fwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     attr_done = true;
   }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_fwd_kernel<float>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
-  else hipLaunchKernelGGL((mha_fwd_kernel<bf16_t>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((mha_fwd_kernel<bf16_t>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
+  else hipLaunchKernelGGL((mha_fwd_kernel<f16_t>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
   return check_launch("emrt_mha_fwd");
 }
 
@@ -268,6 +271,7 @@ extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, cons
                             const void* dout, int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int M,
                             int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype,
                             void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(q && k && v && probs && dout && dq && dk && dv, "null pointer");
   EMRT_REQUIRE(D == MHA_D, "head dim must be 32");
   EMRT_REQUIRE(L >= 1 && L <= MHA_MAXL, "sequence length must be <= 128");

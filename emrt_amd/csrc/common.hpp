@@ -7,6 +7,7 @@
 
 #define EMRT_F32 0
 #define EMRT_BF16 1
+#define EMRT_F16 2   /* IEEE half storage, fp32 accumulation: inference (forward) entry points only */
 
 namespace emrt {
 
@@ -50,10 +51,15 @@ extern Tuning g_tune;
 struct bf16_t {
   unsigned short v;
 };
+struct f16_t {     // IEEE binary16 storage (the sliding-window inference configuration, src/api/infer.py:22-80 in fp16)
+  unsigned short v;
+};
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)__builtin_bit_cast(_Float16, x.v); }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t lo16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)lo16); }
 
 template <class T>
 __device__ __forceinline__ T from_f32(float f);
@@ -67,6 +73,23 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {
   bf16_t r;
   r.v = __builtin_bit_cast(unsigned short, b);
   return r;
+}
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float f) {
+  f16_t r;
+  r.v = __builtin_bit_cast(unsigned short, (_Float16)f);   // v_cvt_f16_f32: round-to-nearest-even, overflow -> inf
+  return r;
+}
+typedef __attribute__((ext_vector_type(2))) _Float16 emrt_half2_t;
+typedef __attribute__((ext_vector_type(2))) float emrt_float2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  emrt_half2_t h = __builtin_convertvector((emrt_float2_t){lo, hi}, emrt_half2_t);      // v_cvt_pk(rtz is NOT used: plain RNE converts)
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ void unpack_f16x2(uint32_t w, float& lo, float& hi) {
+  const emrt_half2_t h = __builtin_bit_cast(emrt_half2_t, w);
+  lo = (float)h.x;
+  hi = (float)h.y;
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)from_f32<bf16_t>(lo).v | ((uint32_t)from_f32<bf16_t>(hi).v << 16);
@@ -96,6 +119,21 @@ struct Vec4<bf16_t> {
     uint2 v;
     v.x = pack_bf16x2(o[0], o[1]);
     v.y = pack_bf16x2(o[2], o[3]);
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+};
+
+template <>
+struct Vec4<f16_t> {
+  __device__ static __forceinline__ void load(const f16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    unpack_f16x2(v.x, o[0], o[1]);
+    unpack_f16x2(v.y, o[2], o[3]);
+  }
+  __device__ static __forceinline__ void store(f16_t* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = pack_f16x2(o[0], o[1]);
+    v.y = pack_f16x2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
   }
 };
@@ -133,6 +171,21 @@ struct Vec8<bf16_t> {
   }
 };
 
+template <>
+struct Vec8<f16_t> {
+  __device__ static __forceinline__ void load(const f16_t* p, float (&o)[8]) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    unpack_f16x2(v.x, o[0], o[1]); unpack_f16x2(v.y, o[2], o[3]);
+    unpack_f16x2(v.z, o[4], o[5]); unpack_f16x2(v.w, o[6], o[7]);
+  }
+  __device__ static __forceinline__ void store(f16_t* p, const float (&o)[8]) {
+    uint4 v;
+    v.x = pack_f16x2(o[0], o[1]); v.y = pack_f16x2(o[2], o[3]);
+    v.z = pack_f16x2(o[4], o[5]); v.w = pack_f16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+};
+
 // ---- wave / block reductions (wave = 64 lanes on gfx950) ---------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -156,6 +209,10 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t salt, uint64_
   uint32_t h = mix32(a ^ (b + 0x9E3779B9U + (a << 6) + (a >> 2)));
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
+
+// entry points with a backward / training-only meaning accept f32 and bf16; fp16 (dtype 2) is inference-only
+#define EMRT_REQUIRE_TRAIN_DTYPE(dtype) EMRT_REQUIRE((dtype) == EMRT_F32 || (dtype) == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16): fp16 (2) is inference-only")
+#define EMRT_REQUIRE_FWD_DTYPE(dtype) EMRT_REQUIRE((dtype) == EMRT_F32 || (dtype) == EMRT_BF16 || (dtype) == EMRT_F16, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)")
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -60,6 +60,11 @@ template <>
 __device__ __forceinline__ void mma_chunk<bf16_t>(f32x16_t& acc, const uint4& a, const uint4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <>
+__device__ __forceinline__ void mma_chunk<f16_t>(f32x16_t& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
 template <>
 __device__ __forceinline__ void mma_chunk<float>(f32x16_t& acc, const uint4& a, const uint4& b) {
   // lane (r, h) holds 4 consecutive k of its row; MFMA e pairs k-slot h with element e of both operands.
@@ -84,6 +89,10 @@ template <class T>
 __device__ __forceinline__ uint32_t buf_load_elem(__amdgpu_buffer_rsrc_t rs, unsigned off);   // element bits, zero-extended
 template <>
 __device__ __forceinline__ uint32_t buf_load_elem<bf16_t>(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+}
+template <>
+__device__ __forceinline__ uint32_t buf_load_elem<f16_t>(__amdgpu_buffer_rsrc_t rs, unsigned off) {
   return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
 }
 template <>
@@ -925,7 +934,8 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
   EMRT_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fwd) or 1 (dgrad)");
-  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
+  EMRT_REQUIRE(dtype != EMRT_F16 || mode == 0, "fp16 (dtype 2) is inference-only: forward convolution (mode 0)");
   if (mode == 0) {
     EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "fwd: output size mismatch");
   } else {
@@ -947,6 +957,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
+  if (dtype == EMRT_F16) return conv_dispatch<f16_t, 0>(a, st);
   return mode == 0 ? conv_dispatch<bf16_t, 0>(a, st) : conv_dispatch<bf16_t, 1>(a, st);
 }
 
@@ -1021,7 +1032,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   EMRT_REQUIRE(x && dy && dw, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
-  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
     const long long x_ext = ((long long)(N - 1) * x_bs + ((long long)H * W - 1) * ldx + C) * esz;
@@ -1317,7 +1328,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
   EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
-  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
     const long long x_ext = ((long long)(N - 1) * x_bs + ((long long)H * W - 1) * ldx + C) * esz;
@@ -1442,7 +1453,7 @@ static int conv_group_dispatch(const EmrtConvDesc* descs, int n, hipStream_t st)
 
 extern "C" int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream) {
   EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..4 problems");
-  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   for (int i = 0; i < n; ++i) {
     const EmrtConvDesc& d = descs[i];
     EMRT_REQUIRE(d.in && d.w_packed && d.out, "null pointer");
@@ -1453,6 +1464,7 @@ extern "C" int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, vo
     EMRT_REQUIRE(d.in_bs >= 0 && in_ext < (1ll << 31) && (long long)d.OC * d.KH * d.KW * d.C * esz < (1ll << 31), "operand spans 2 GiB or more");
   }
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F16) return conv_group_dispatch<f16_t>(descs, n, st);
   return dtype == EMRT_F32 ? conv_group_dispatch<float>(descs, n, st) : conv_group_dispatch<bf16_t>(descs, n, st);
 }
 
@@ -1510,7 +1522,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
 
 extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream) {
   EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..4 problems");
-  EMRT_REQUIRE(dtype == EMRT_F32 || dtype == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16)");
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   for (int i = 0; i < n; ++i) {
     const EmrtConvBwdDesc& b = descs[i];
     EMRT_REQUIRE(b.x && b.dy && b.w_bwd_packed && b.dx && b.dw, "null pointer");

@@ -192,48 +192,57 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO
   } while (0)
 
 extern "C" int emrt_add(const void* a, const void* b, void* out, long long n, long long period, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(a && b && out, "null pointer");
   EMRT_REQUIRE(n % 4 == 0 && period % 4 == 0 && period > 0, "n and period must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) hipLaunchKernelGGL((add_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / 4, period / 4);
-  else hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 4, period / 4);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 4, period / 4);
+  else hipLaunchKernelGGL((add_kernel<f16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (f16_t*)out, n / 4, period / 4);
   return check_launch("emrt_add");
 }
 
 extern "C" int emrt_add3d(const void* a, long long a_bs, long long a_rs, const void* b, long long b_bs, long long b_rs, void* out,
                           long long out_bs, long long out_rs, long long B, long long rows, long long cols, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(a && b && out, "null pointer");
   EMRT_REQUIRE(cols % 4 == 0 && a_rs % 4 == 0 && b_rs % 4 == 0 && out_rs % 4 == 0 && a_bs % 4 == 0 && b_bs % 4 == 0 && out_bs % 4 == 0,
                "cols and strides must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid(B * rows * (cols / 4));
   if (dtype == EMRT_F32) hipLaunchKernelGGL((add3d_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, a_bs, a_rs, (const float*)b, b_bs, b_rs, (float*)out, out_bs, out_rs, B, rows, cols / 4);
-  else hipLaunchKernelGGL((add3d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, a_bs, a_rs, (const bf16_t*)b, b_bs, b_rs, (bf16_t*)out, out_bs, out_rs, B, rows, cols / 4);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((add3d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, a_bs, a_rs, (const bf16_t*)b, b_bs, b_rs, (bf16_t*)out, out_bs, out_rs, B, rows, cols / 4);
+  else hipLaunchKernelGGL((add3d_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)a, a_bs, a_rs, (const f16_t*)b, b_bs, b_rs, (f16_t*)out, out_bs, out_rs, B, rows, cols / 4);
   return check_launch("emrt_add3d");
 }
 
 extern "C" int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const void* src, long long src_bs, long long src_rs, long long B,
                           long long rows, long long cols, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(dst && src, "null pointer");
   EMRT_REQUIRE(cols % 4 == 0 && dst_rs % 4 == 0 && src_rs % 4 == 0 && dst_bs % 4 == 0 && src_bs % 4 == 0, "cols and strides must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid(B * rows * (cols / 4));
   if (dtype == EMRT_F32) hipLaunchKernelGGL((acc3d_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, dst_bs, dst_rs, (const float*)src, src_bs, src_rs, B, rows, cols / 4);
-  else hipLaunchKernelGGL((acc3d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, dst_bs, dst_rs, (const bf16_t*)src, src_bs, src_rs, B, rows, cols / 4);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((acc3d_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (bf16_t*)dst, dst_bs, dst_rs, (const bf16_t*)src, src_bs, src_rs, B, rows, cols / 4);
+  else hipLaunchKernelGGL((acc3d_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (f16_t*)dst, dst_bs, dst_rs, (const f16_t*)src, src_bs, src_rs, B, rows, cols / 4);
   return check_launch("emrt_acc3d");
 }
 
 extern "C" int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(a && row && out, "null pointer");
   EMRT_REQUIRE(n % 4 == 0 && period % 4 == 0 && period > 0, "n and period must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) hipLaunchKernelGGL((add_f32row_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)a, row, (float*)out, n / 4, period / 4);
-  else hipLaunchKernelGGL((add_f32row_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, row, (bf16_t*)out, n / 4, period / 4);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((add_f32row_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, row, (bf16_t*)out, n / 4, period / 4);
+  else hipLaunchKernelGGL((add_f32row_kernel<f16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const f16_t*)a, row, (f16_t*)out, n / 4, period / 4);
   return check_launch("emrt_add_f32row");
 }
 
 extern "C" int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode,
                                 long long hw, int C, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && y && seed, "null pointer");
   EMRT_REQUIRE(n % 4 == 0 && p >= 0.f && p < 1.f, "n must be a multiple of 4, 0 <= p < 1");
   EMRT_REQUIRE(mode == 0 || (hw > 0 && C > 0), "channel mode needs hw and C");
@@ -245,6 +254,7 @@ extern "C" int emrt_dropout_fwd(const void* x, void* y, long long n, float p, co
 
 extern "C" int emrt_mask_bwd(const void* dy, const void* relu_out, void* dx, long long n, float p, const unsigned long long* seed,
                              unsigned salt, int mode, long long hw, int C, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(dy && dx, "null pointer");
   EMRT_REQUIRE(n % 4 == 0 && p >= 0.f && p < 1.f, "n must be a multiple of 4, 0 <= p < 1");
   EMRT_REQUIRE(p == 0.f || seed, "dropout needs a device seed");
@@ -267,12 +277,15 @@ extern "C" int emrt_sigmoid_bwd(const float* y, const float* dy, float* dx, long
 
 // direction 0: f32 -> dtype ; 1: dtype -> f32
 extern "C" int emrt_cast(const void* in, void* out, long long n, int direction, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid(n);
   if (dtype == EMRT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, n);
-  else if (direction == 0) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, n);
-  else hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out, n);
+  else if (dtype == EMRT_BF16 && direction == 0) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, n);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out, n);
+  else if (direction == 0) hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (f16_t*)out, n);
+  else hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(grid), dim3(256), 0, st, (const f16_t*)in, (float*)out, n);
   return check_launch("emrt_cast");
 }
 

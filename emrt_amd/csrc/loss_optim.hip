@@ -287,10 +287,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 extern "C" int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles,
                                  int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(master && packed && desc_dev, "null pointer");
   EMRT_REQUIRE(ndesc > 0 && total_tiles > 0 && total_tiles < 2147483647LL, "bad descriptor table");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (float*)packed, desc_dev, ndesc);
-  else hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc);
+  else hipLaunchKernelGGL((pack_weights_kernel<f16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (f16_t*)packed, desc_dev, ndesc);
   return check_launch("emrt_pack_weights");
 }

@@ -547,6 +547,41 @@ static int msda_launch(const MsdaArgs& a, int L, int P, int mode /*0 fwd, 1 bwd 
   return fail("emrt_msda", "unsupported (levels, points): built for (3,6), (4,4), (3,4), (1,4)");
 }
 
+// forward only (the one MSDA kernel fp16 inference needs)
+template <class T>
+static int msda_launch_fwd(const MsdaArgs& a, int L, int P, hipStream_t st) {
+  const long long pairs = (long long)a.B * a.Lq * a.M;
+  const unsigned grid = (unsigned)((pairs + 63) / 64);
+#define MSDA_FWD_CASE(LL, PP)                                                                                 \
+  if (L == LL && P == PP) {                                                                                   \
+    hipLaunchKernelGGL((msda_fwd_kernel<T, LL, PP>), dim3(grid), dim3(256), 0, st, a);                        \
+    return check_launch("emrt_msda_fwd");                                                                     \
+  }
+  MSDA_FWD_CASE(3, 6)
+  MSDA_FWD_CASE(4, 4)
+  MSDA_FWD_CASE(3, 4)
+  MSDA_FWD_CASE(1, 4)
+#undef MSDA_FWD_CASE
+  return fail("emrt_msda_fwd", "unsupported (levels, points): built for (3,6), (4,4), (3,4), (1,4)");
+}
+
+template <class T>
+static int msda_launch_fwd_lds(const MsdaArgs& a, int L, int P, int chunks, int qpb, size_t slab, hipStream_t st) {
+#define MSDA_FWD_LDS_CASE(LL, PP)                                                                                         \
+  if (L == LL && P == PP) {                                                                                             \
+    static bool attr = false;                                                                                           \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_fwd_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_fwd_lds_kernel<T, LL, PP>), dim3(a.B * a.M, chunks), dim3(1024), slab, st, a, qpb);          \
+    return check_launch("emrt_msda_fwd(lds)");                                                                          \
+  }
+  MSDA_FWD_LDS_CASE(3, 6)
+  MSDA_FWD_LDS_CASE(4, 4)
+  MSDA_FWD_LDS_CASE(3, 4)
+  MSDA_FWD_LDS_CASE(1, 4)
+#undef MSDA_FWD_LDS_CASE
+  return fail("emrt_msda_fwd", "unsupported (levels, points): built for (3,6), (4,4), (3,4), (1,4)");
+}
+
 template <class T>
 static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t lds, hipStream_t st) {
 #define MSDA_LDS_CASE(LL, PP)                                                                                 \
@@ -581,6 +616,7 @@ static int msda_fill(MsdaArgs& a, const int* shapes_hw, int L, int Lv) {
 extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
                              long long ref_bs, int ref_L, void* out, int B, int Lq, int Lv, int M, int D, int L, int P,
                              const int* shapes_hw /*host, [L][2]*/, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
   EMRT_REQUIRE(value && offw && ref && out && shapes_hw, "null pointer");
   EMRT_REQUIRE(D == 32, "head dim must be 32");
@@ -595,26 +631,16 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   hipStream_t st = (hipStream_t)stream;
   a.Lv = Lv;
   const size_t slab = (size_t)Lv * MSDA_FWD_PITCH;
-  if (dtype == EMRT_BF16 && slab <= 150 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {       // LDS-staged slab (see msda_fwd_lds_kernel)
+  if (dtype != EMRT_F32 && slab <= 150 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {       // LDS-staged slab (see msda_fwd_lds_kernel)
     int chunks = (512 + B * M - 1) / (B * M);                  // ~2 blocks per CU
     if (chunks > (Lq + 255) / 256) chunks = (Lq + 255) / 256;  // at least one 256-query pass per block
     if (chunks < 1) chunks = 1;
     const int qpb = (Lq + chunks - 1) / chunks;
     chunks = (Lq + qpb - 1) / qpb;
-#define MSDA_FWD_LDS_CASE(LL, PP)                                                                                         \
-    if (L == LL && P == PP) {                                                                                           \
-      static bool attr = false;                                                                                         \
-      if (!attr) { (void)hipFuncSetAttribute((const void*)msda_fwd_lds_kernel<bf16_t, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
-      hipLaunchKernelGGL((msda_fwd_lds_kernel<bf16_t, LL, PP>), dim3(B * M, chunks), dim3(1024), slab, st, a, qpb);       \
-      return check_launch("emrt_msda_fwd(lds)");                                                                        \
-    }
-    MSDA_FWD_LDS_CASE(3, 6)
-    MSDA_FWD_LDS_CASE(4, 4)
-    MSDA_FWD_LDS_CASE(3, 4)
-    MSDA_FWD_LDS_CASE(1, 4)
-#undef MSDA_FWD_LDS_CASE
+    return dtype == EMRT_BF16 ? msda_launch_fwd_lds<bf16_t>(a, L, P, chunks, qpb, slab, st) : msda_launch_fwd_lds<f16_t>(a, L, P, chunks, qpb, slab, st);
   }
-  return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 0, st) : msda_launch<bf16_t>(a, L, P, 0, st);
+  if (dtype == EMRT_F16) return msda_launch_fwd<f16_t>(a, L, P, st);
+  return dtype == EMRT_F32 ? msda_launch_fwd<float>(a, L, P, st) : msda_launch_fwd<bf16_t>(a, L, P, st);
 }
 
 // dvalue: when emrt_msda_bwd_uses_lds(shapes) it is [B][Lv][M*D] in the COMPUTE dtype and fully overwritten (workspace
@@ -622,6 +648,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
 extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
                              long long ref_bs, int ref_L, const void* dout, void* dvalue, float* doffw, float* dref, int B, int Lq,
                              int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
   EMRT_REQUIRE(value && offw && ref && dout && dvalue && doffw && shapes_hw, "null pointer");
   EMRT_REQUIRE(D == 32, "head dim must be 32");

@@ -976,6 +976,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
   do {                                        \
     if ((dtype) == EMRT_F32) { EXPR_F32; } else { EXPR_BF16; } \
   } while (0)
+// forward (inference-capable) entry points also take fp16
+#define DT_SWITCH3(dtype, EXPR_F32, EXPR_BF16, EXPR_F16) \
+  do {                                                   \
+    if ((dtype) == EMRT_F32) { EXPR_F32; } else if ((dtype) == EMRT_BF16) { EXPR_BF16; } else { EXPR_F16; } \
+  } while (0)
 
 static inline int ew_grid(long long total) {
   long long g = (total + 255) / 256;
@@ -1011,6 +1016,7 @@ static inline bool bn_rowgeom(long long M, int C, int& threads, int& rows_per_pa
 
 // BatchNorm statistics when the producer could not fuse them: sums[2C] (fp64, PRE-ZEROED by the caller) += (sum x, sum x^2)
 extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0, "C and ld must be multiples of 4");
   int tx, gx, gy;
@@ -1027,6 +1033,7 @@ extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, double*
 extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count,
                              float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
                              const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(x && y && gamma && beta, "null pointer");
   EMRT_REQUIRE(sums ? (mean && invstd) : (run_mean && run_var), "training needs mean/invstd outputs, eval needs running statistics");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0), "C and ld must be multiples of 4");
@@ -1034,15 +1041,17 @@ extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres,
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   const double inv_count = sums ? 1.0 / count : 0.0;
-  DT_SWITCH(dtype,
+  DT_SWITCH3(dtype,
             hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
-            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
+            hipLaunchKernelGGL((bn_apply_kernel<f16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const f16_t*)x, ldx, (const f16_t*)res, ldres, (f16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
   return check_launch("emrt_bn_apply");
 }
 
 // BN backward step 1: sums[2C] (fp64, PRE-ZEROED) += (sum dy', sum dy'*xhat); y (post-ReLU output) may be null when no ReLU was fused.
 extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean,
                                   const float* invstd, long long M, int C, double* sums, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && mean && invstd && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!y || ldy % 4 == 0), "C and ld must be multiples of 4");
   int tx, gx, gy;
@@ -1063,6 +1072,7 @@ extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, 
                               void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
                               const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M,
                               int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
   int threads, rpp, grid;
@@ -1095,6 +1105,7 @@ __global__ __launch_bounds__(256) void colsum_scalar_kernel(const T* __restrict_
 // x + (r / rows_per_batch) * x_bs + (r % rows_per_batch) * ldx   (rows_per_batch == M, x_bs == 0 for a dense matrix)
 extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias,
                                void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(rows_per_batch > 0, "bad batch geometry");
   EMRT_REQUIRE(x && dbias && workspace, "null pointer");
   if (C % 4 != 0 || ldx % 4 != 0 || x_bs % 4 != 0) {
@@ -1134,24 +1145,28 @@ static inline int gn_geom(int HW, int C, int* pix_per_block) {
 extern "C" int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out,
                                   int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd,
                                   double* workspace, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(x && out && gamma && beta && workspace, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 256 && C % G == 0 && (C / G) % 4 == 0, "unsupported C/G");
   EMRT_REQUIRE(ldx % 4 == 0 && ldout % 4 == 0 && x_bs % 4 == 0 && out_bs % 4 == 0, "strides must be multiples of 4");
   hipStream_t st = (hipStream_t)stream;
   if (gn_use_fused(HW, C, G)) {
-    DT_SWITCH(dtype,
+    DT_SWITCH3(dtype,
               hipLaunchKernelGGL((gn_fused_fwd_kernel<float>), dim3(N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu),
-              hipLaunchKernelGGL((gn_fused_fwd_kernel<bf16_t>), dim3(N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu));
+              hipLaunchKernelGGL((gn_fused_fwd_kernel<bf16_t>), dim3(N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu),
+              hipLaunchKernelGGL((gn_fused_fwd_kernel<f16_t>), dim3(N * G), dim3(256), 0, st, (const f16_t*)x, ldx, x_bs, (const f16_t*)res, ldres, res_bs, (f16_t*)out, ldout, out_bs, gamma, beta, mean, rstd, HW, C, G, eps, gelu));
     return check_launch("emrt_groupnorm_fwd");
   }
   int ppb;
   const int blocks = gn_geom(HW, C, &ppb);
-  DT_SWITCH(dtype,
+  DT_SWITCH3(dtype,
             hipLaunchKernelGGL((gn_stats_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, workspace, HW, C, G, ppb),
-            hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, workspace, HW, C, G, ppb));
-  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, workspace, HW, C, G, ppb),
+            hipLaunchKernelGGL((gn_stats_kernel<f16_t>), dim3(blocks, N), dim3(256), 0, st, (const f16_t*)x, ldx, x_bs, workspace, HW, C, G, ppb));
+  DT_SWITCH3(dtype,
             hipLaunchKernelGGL((gn_apply_kernel<float>), dim3(blocks, N), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, gamma, beta, workspace, mean, rstd, HW, C, G, eps, gelu, ppb),
-            hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, workspace, mean, rstd, HW, C, G, eps, gelu, ppb));
+            hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), dim3(blocks, N), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, gamma, beta, workspace, mean, rstd, HW, C, G, eps, gelu, ppb),
+            hipLaunchKernelGGL((gn_apply_kernel<f16_t>), dim3(blocks, N), dim3(256), 0, st, (const f16_t*)x, ldx, x_bs, (const f16_t*)res, ldres, res_bs, (f16_t*)out, ldout, out_bs, gamma, beta, workspace, mean, rstd, HW, C, G, eps, gelu, ppb));
   return check_launch("emrt_groupnorm_fwd");
 }
 
@@ -1160,6 +1175,7 @@ extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const 
                                   int lddx, long long dx_bs, const float* gamma, const float* beta, const float* mean,
                                   const float* rstd, float* dgamma, float* dbeta, double* workspace, int N, int HW, int C, int G,
                                   int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd && workspace, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && (C / 4) <= 256 && 256 % (C / 4) == 0 && G > 0 && G <= 256 && C % G == 0 && (C / G) % 4 == 0, "unsupported C/G");
   hipStream_t st = (hipStream_t)stream;
@@ -1184,14 +1200,16 @@ extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const 
 extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma,
                                   const float* beta, float* mean, float* rstd, long long rows, int C, float eps, float pdrop,
                                   const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(a && out && gamma && beta, "null pointer");
   EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && b)), "dropout needs 0 <= p < 1, a device seed and a branch input b");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)((rows + 3) / 4);
-  DT_SWITCH(dtype,
+  DT_SWITCH3(dtype,
             hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)post, (float*)z, (float*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt),
-            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt));
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt),
+            hipLaunchKernelGGL((ln_fwd_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (const f16_t*)post, (f16_t*)z, (f16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt));
   return check_launch("emrt_layernorm_fwd");
 }
 
@@ -1210,6 +1228,7 @@ extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
 extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
                                   float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop,
                                   const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(z && dy && dz && gamma && mean && rstd && workspace, "null pointer");
   EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && dz_branch)), "dropout needs 0 <= p < 1, a device seed and dz_branch");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
@@ -1247,15 +1266,17 @@ extern "C" int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs,
                                          int ldout, long long out_bs, const float* const* gamma, const float* const* beta, float* mean,
                                          float* rstd, const int* level_start, const int* level_hw, int L, int N, int C, int G, float eps,
                                          int gelu, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(x && out && gamma && beta && level_start && level_hw, "null pointer");
   EMRT_REQUIRE(G > 0 && C % G == 0 && gn_use_fused(1, C, G), "unsupported C / G for the one-block-per-group kernel");
   EMRT_REQUIRE(ldx % 4 == 0 && ldout % 4 == 0 && x_bs % 4 == 0 && out_bs % 4 == 0 && (!res || (ldres % 4 == 0 && res_bs % 4 == 0)), "strides must be multiples of 4");
   GnLevels lv;
   EMRT_REQUIRE(gn_fill_levels(lv, level_start, level_hw, L, gamma, beta, nullptr, nullptr) == 0, "1..4 levels of at most 4096 rows");
   hipStream_t st = (hipStream_t)stream;
-  DT_SWITCH(dtype,
+  DT_SWITCH3(dtype,
             hipLaunchKernelGGL((gn_levels_fwd_kernel<float>), dim3(L * N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu),
-            hipLaunchKernelGGL((gn_levels_fwd_kernel<bf16_t>), dim3(L * N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu));
+            hipLaunchKernelGGL((gn_levels_fwd_kernel<bf16_t>), dim3(L * N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu),
+            hipLaunchKernelGGL((gn_levels_fwd_kernel<f16_t>), dim3(L * N * G), dim3(256), 0, st, (const f16_t*)x, ldx, x_bs, (const f16_t*)res, ldres, res_bs, (f16_t*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu));
   return check_launch("emrt_groupnorm_levels_fwd");
 }
 
@@ -1264,6 +1285,7 @@ extern "C" int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs,
                                          const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta,
                                          const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, int dtype,
                                          void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd && level_start && level_hw, "null pointer");
   EMRT_REQUIRE(G > 0 && C % G == 0 && gn_use_fused(1, C, G), "unsupported C / G for the one-block-per-group kernel");
   GnLevels lv;

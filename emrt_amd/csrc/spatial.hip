@@ -530,6 +530,12 @@ static inline int ew_grid(long long total) {
   return (int)g;
 }
 
+#define DT3(dtype, KERNEL, GRID, ...)                                                                 \
+  do {                                                                                                \
+    if ((dtype) == EMRT_F32) hipLaunchKernelGGL((KERNEL<float>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
+    else if ((dtype) == EMRT_BF16) hipLaunchKernelGGL((KERNEL<bf16_t>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<f16_t>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__);               \
+  } while (0)
 #define DT2(dtype, KERNEL, GRID, ...)                                                                 \
   do {                                                                                                \
     if ((dtype) == EMRT_F32) hipLaunchKernelGGL((KERNEL<float>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
@@ -539,6 +545,7 @@ static inline int ew_grid(long long total) {
 extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs,
                                         int out_ld, int OH, int OW, const void* add, long long add_bs, int add_ld, int N, int C,
                                         int align_corners, int out_nchw_f32, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out, "null pointer");
   EMRT_REQUIRE(N > 0 && C > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "bad dims");
   EMRT_REQUIRE(!(out_nchw_f32 && add), "addend not supported with NCHW output");
@@ -550,7 +557,7 @@ extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_
   hipStream_t st = (hipStream_t)stream;
   if (out_nchw_f32) {
     const int grid = ew_grid((long long)N * C * OH * OW);
-    DT2(dtype, resize_fwd_nchw_kernel, grid, a);
+    DT3(dtype, resize_fwd_nchw_kernel, grid, a);
     return check_launch("emrt_resize_bilinear_fwd");
   }
   const bool v4 = C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && in_bs % 4 == 0 && out_bs % 4 == 0 &&
@@ -560,15 +567,18 @@ extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_
                   (!add || (add_ld % 8 == 0 && add_bs % 8 == 0));      // bf16: 16-byte accesses
   if (v8) {
     const int grid = ew_grid((long long)N * OH * OW * (C / 8));
-    hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, a);
+    if (dtype == EMRT_BF16) hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_fwd_kernel<f16_t, 8>), dim3(grid), dim3(256), 0, st, a);
   } else if (v4) {
     const int grid = ew_grid((long long)N * OH * OW * (C / 4));
     if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_kernel<float, 4>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
+    else if (dtype == EMRT_BF16) hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_fwd_kernel<f16_t, 4>), dim3(grid), dim3(256), 0, st, a);
   } else {
     const int grid = ew_grid((long long)N * OH * OW * C);
     if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_kernel<float, 1>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (dtype == EMRT_BF16) hipLaunchKernelGGL((resize_fwd_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resize_fwd_kernel<f16_t, 1>), dim3(grid), dim3(256), 0, st, a);
   }
   return check_launch("emrt_resize_bilinear_fwd");
 }
@@ -580,6 +590,7 @@ extern "C" size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, 
 extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs,
                                         int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32,
                                         void* workspace, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(dout && din, "null pointer");
   ResizeBwdArgs a;
   a.dout = dout; a.do_bs = do_bs; a.do_ld = do_ld; a.OH = OH; a.OW = OW;
@@ -634,18 +645,21 @@ static int fill_pool(PoolArgs& a, const int* scales, int nscales) {
 // out tokens [N][sum k^2][C] (row stride out_ld, batch stride out_bs)
 extern "C" int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs,
                                          int out_ld, int N, int C, const int* scales /*host*/, int nscales, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out && scales, "null pointer");
   PoolArgs a;
   a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.N = N; a.C = C;
   EMRT_REQUIRE(fill_pool(a, scales, nscales) == 0, "1..4 scales supported");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) hipLaunchKernelGGL((adaptive_pool_fwd_kernel<float>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
-  else hipLaunchKernelGGL((adaptive_pool_fwd_kernel<bf16_t>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((adaptive_pool_fwd_kernel<bf16_t>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((adaptive_pool_fwd_kernel<f16_t>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
   return check_launch("emrt_adaptive_avgpool_fwd");
 }
 
 extern "C" int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void* din, long long di_bs, int di_ld, int H,
                                          int W, int N, int C, const int* scales, int nscales, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(dout && din && scales, "null pointer");
   PoolArgs a;
   a.in = din; a.in_bs = di_bs; a.in_ld = di_ld; a.H = H; a.W = W; a.out = const_cast<void*>(dout); a.out_bs = do_bs; a.out_ld = do_ld;
@@ -667,6 +681,7 @@ extern "C" int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int 
 
 extern "C" int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad,
                                 int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out, "null pointer");
   EMRT_REQUIRE(k > 0 && k <= 15 && stride > 0 && pad >= 0 && pad < k, "bad window");
   MaxPoolArgs a;
@@ -675,12 +690,13 @@ extern "C" int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax
   a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid((long long)N * a.OH * a.OW * C);
-  DT2(dtype, maxpool_fwd_kernel, grid, a);
+  DT3(dtype, maxpool_fwd_kernel, grid, a);
   return check_launch("emrt_maxpool_fwd");
 }
 
 extern "C" int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, int N, int H, int W, int C, int k, int stride,
                                 int pad, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(argmax && dout && din, "null pointer");
   EMRT_REQUIRE(k > 0 && k <= 15 && stride > 0 && pad >= 0 && pad < k, "bad window");
   MaxPoolArgs a;
@@ -703,11 +719,13 @@ extern "C" int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, v
 }
 
 extern "C" int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid((long long)N * C * H * W);
   if (dtype == EMRT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, in, (float*)out, N, C, H, W);
-  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t>), dim3(grid), dim3(256), 0, st, in, (f16_t*)out, N, C, H, W);
   return check_launch("emrt_nchw_to_nhwc");
 }
 

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from .runtime import ctx, F32, BF16
+from .runtime import ctx, dtype_of, F32, BF16, F16
 
 
 def _L():
@@ -138,7 +138,7 @@ def add_into(dst, src):
     """dst += src (dense tensors, token slabs or channel slices in any combination)."""
     c = ctx()
     assert dst.dtype == src.dtype, (dst.dtype, src.dtype)
-    dt = F32 if dst.dtype == torch.float32 else BF16
+    dt = dtype_of(dst)
     B, R, Cc, (sd, ss) = _geom3(dst, src)
     _L().call("emrt_acc3d", P(dst), sd[0], sd[1], P(src), ss[0], ss[1], B, R, Cc, dt, c.stream)
 
@@ -151,7 +151,7 @@ def add(a, b, period=None, bgrad=None):
     out = c.empty(tuple(a.shape), a.dtype)
     n = a.numel()
     per = n if period is None else period
-    dt = F32 if a.dtype == torch.float32 else BF16
+    dt = dtype_of(a)
     _L().call("emrt_add", P(a), P(b), P(out), n, per, dt, c.stream)
     tape = c.tape
     if tape is not None:
@@ -174,7 +174,7 @@ def add_maps(a, b):
     assert a.shape == b.shape and a.dtype == b.dtype
     out = c.empty(tuple(a.shape), a.dtype)
     B, R, Cc, (sa, sb, so) = _geom3(a, b, out)
-    dt = F32 if a.dtype == torch.float32 else BF16
+    dt = dtype_of(a)
     _L().call("emrt_add3d", P(a), sa[0], sa[1], P(b), sb[0], sb[1], P(out), so[0], so[1], B, R, Cc, dt, c.stream)
     tape = c.tape
     if tape is not None:
@@ -392,7 +392,7 @@ def colsum_acc(x, dst_f32):
     c = ctx()
     N, H, W, C, ld, bs = _check_map(x)
     assert dst_f32.dtype == torch.float32 and dst_f32.is_contiguous() and dst_f32.numel() == C
-    dt = F32 if x.dtype == torch.float32 else BF16
+    dt = dtype_of(x)
     ws = c.workspace(_L().query("emrt_colreduce_workspace_bytes", N * H * W, C))
     _L().call("emrt_colsum_acc", P(x), ld, H * W, bs, N * H * W, C, P(dst_f32), P(ws), dt, c.stream)
 

@@ -16,7 +16,7 @@ import torch.nn as tnn
 
 from . import _lib
 from . import functional as Fn
-from .runtime import ctx, F32, BF16
+from .runtime import ctx, F32, BF16, _TORCH_DTYPE
 
 
 def _align(n, a):
@@ -152,7 +152,7 @@ class ParamStore:
                 continue
             rows.append([g.offset, fo, bo, g.OC, g.KH * g.KW, g.C, tiles, 0])
             tiles += g.KH * g.KW * ((g.OC + 31) // 32) * ((g.C + 31) // 32)
-        self.packed = torch.zeros(max(off, 8), dtype=torch.float32 if self.dtype == F32 else torch.bfloat16, device=self.device)
+        self.packed = torch.zeros(max(off, 8), dtype=_TORCH_DTYPE[self.dtype], device=self.device)
         base = self.packed.data_ptr()
         for g in self.gemms:
             g.fwd_ptr = self.master.data_ptr() + 4 * g.offset if g._fo < 0 else base + esz * g._fo

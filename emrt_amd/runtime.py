@@ -15,8 +15,14 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
-_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+F32, BF16, F16 = 0, 1, 2          # include/emrt_hip.h: EMRT_DTYPE_*; F16 is inference-only
+_TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+_DTYPE_OF_TORCH = {v: k for k, v in _TORCH_DTYPE.items()}
+
+
+def dtype_of(t):
+    """C-ABI dtype code of a tensor's element type."""
+    return _DTYPE_OF_TORCH[t.dtype]
 
 
 class Tape:

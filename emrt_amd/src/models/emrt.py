@@ -596,7 +596,8 @@ class EMRT(hnn.HipLayer):  # :184-304
         return names + ["model.reference_points.weight", "model.reference_points.bias"]
 
     def to_hip(self, device="cuda:0", dtype=F32, seed=1234):
-        """Move the model onto the GPU: flat parameter store + packed GEMM weights.  dtype: runtime.F32 / runtime.BF16."""
+        """Move the model onto the GPU: flat parameter store + packed GEMM weights.  dtype: runtime.F32 / runtime.BF16, or
+        runtime.F16 for inference (the kernels' backward entry points reject it; train() then fails at the first launch)."""
         c = ctx()
         c.init_device(device, dtype, seed)
         self.store = hnn.ParamStore(self, c.device, dtype, nograd_names=NOGRAD_PARAMS, fused_groups=self.fused_groups(),

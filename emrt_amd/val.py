@@ -15,7 +15,7 @@ import torch
 
 from .config import get_config, update_config
 from .distributed import init_process_group
-from .runtime import BF16, F32
+from .runtime import BF16, F16, F32
 from .src.api import infer
 from .src.models import get_model
 from .src.utils import metrics
@@ -29,7 +29,7 @@ def parse_args(argv=None):
     p.add_argument("--multi_scales", action="store_true", help="multi-scale (VAL.SCALE_RATIOS) + horizontal-flip inference, infer.py:160-260")
     p.add_argument("--data", default="synthetic", help="'synthetic', 'dataset' (DATA.DATASET under DATA.DATA_PATH) or a .npz")
     p.add_argument("--data_path", default=None, help="override DATA.DATA_PATH of the yaml")
-    p.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"])
+    p.add_argument("--dtype", default="fp32", choices=["bf16", "fp16", "fp32"])
     return p.parse_args(argv)
 
 
@@ -69,7 +69,9 @@ def main(argv=None):
     if args.model_path:                 # a .pdparams written by the reference / by train.py, or a torch checkpoint
         from .src.utils.checkpoint import load_entire_model
         load_entire_model(model, args.model_path)
-    model.to_hip("cuda:%d" % local_rank, BF16 if args.dtype == "bf16" else F32)
+    model.to_hip("cuda:%d" % local_rank, {"bf16": BF16, "fp16": F16, "fp32": F32}[args.dtype])
+    if args.dtype == "fp16":
+        model.compute_aux_in_eval = False      # the auxiliary head is computed and thrown away in eval (paddle_EMRT.py:300-302, infer.py:66)
     dev = torch.device("cuda", local_rank)
     if args.data == "synthetic":
         g = torch.Generator().manual_seed(0)

@@ -12,7 +12,9 @@
  *  - the library never allocates, frees or synchronises: work is enqueued on `stream` (a hipStream_t; 0 = default),
  *    so calls can be captured in a hipGraph; workspaces are sized by the *_workspace_bytes queries;
  *  - returns 0 on success, negative on error; emrt_last_error() gives a thread-local message;
- *  - dtype: 0 = float32, 1 = bfloat16 (storage type of activations / packed weights; accumulation is always fp32);
+ *  - dtype: 0 = float32, 1 = bfloat16, 2 = float16 (storage type of activations / packed weights; accumulation is always
+ *    fp32).  float16 is inference-only (the sliding-window configuration, src/api/infer.py:22-80): the forward entry points
+ *    take it, every backward / training entry point returns an error for it;
  *  - activations are NHWC: `ld` = pixel (row) stride in elements, `bs` = batch stride in elements, so a level slab
  *    of the [B, Lv, C] token tensor or a channel slice of a concat buffer is addressed in place.
  */
@@ -26,6 +28,7 @@ extern "C" {
 
 #define EMRT_DTYPE_F32 0
 #define EMRT_DTYPE_BF16 1
+#define EMRT_DTYPE_F16 2
 
 const char* emrt_last_error(void);
 int emrt_abi_version(void);
