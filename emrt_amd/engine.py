@@ -9,8 +9,9 @@ down to the ResNet layer4 input) -> launch the bucketed RCCL all-reduce(AVG) of 
 by then (heads, transformer, layer4) -> graph A2 (backward of layer3) -> all-reduce of layer3's range -> graph A3
 (backward of layer2..conv1; both collectives overlap it) -> all-reduce of the rest (3 % of the elements: the only exposed
 one) -> graph B (clip + optimizer); early_exchange=False keeps one graph A and one exchange.  The five SyncBatchNorm
-layers use per-rank statistics inside the captured region (documented deviation, DESIGN.md "Multi-GPU"); in eager mode
-(use_graph=False) they all-reduce their statistics as the reference's nn.SyncBatchNorm does.
+layers (paddle_EMRT.py:64, fcn_head.py:53) all-reduce their statistics in every mode, as the reference's nn.SyncBatchNorm
+does: inside a captured stretch the graph is cut at each of those collectives (GraphSequence) and the all-reduce is issued
+eagerly between the two pieces, forward and backward.
 """
 import torch
 
@@ -20,6 +21,69 @@ from .runtime import ctx
 from .distributed import FlatGradReducer
 
 _SEED_STRIDE = 0x2545F4914F6CDD1D
+
+
+class GraphSequence:
+    """A stretch of the training step captured as hipGraphs with eager interludes between them.
+
+    capture(fn) runs fn under stream capture; whenever fn reaches a host-issued collective (runtime.Context.collective: the
+    SyncBatchNorm statistics all-reduces) the current graph is ended, the collective is called eagerly -- at capture time and
+    again at every replay -- and capture resumes in a new graph that shares the first one's memory pool.  replay() launches
+    graphs and interludes in the captured order.  Without interludes this is exactly one torch.cuda.CUDAGraph."""
+
+    def __init__(self, pool=None, mode=None):
+        self.items = []            # torch.cuda.CUDAGraph | callable
+        self._pool = pool
+        self.mode = dict(mode or {})
+        self._cm = self._g = None
+
+    def pool(self):
+        return self._pool
+
+    @property
+    def n_graphs(self):
+        return sum(isinstance(it, torch.cuda.CUDAGraph) for it in self.items)
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        kw = dict(self.mode)
+        if self._pool is not None:
+            kw["pool"] = self._pool
+        self._cm = torch.cuda.graph(self._g, **kw)
+        self._cm.__enter__()
+
+    def _end(self):
+        cm, self._cm = self._cm, None
+        cm.__exit__(None, None, None)
+        self.items.append(self._g)
+        if self._pool is None:
+            self._pool = self._g.pool()
+
+    def capture(self, fn):
+        c = ctx()
+        assert c.capture is None, "nested step capture"
+        c.capture = self
+        self._begin()
+        try:
+            out = fn()
+        finally:
+            c.capture = None
+            if self._cm is not None:
+                self._end()
+        return out
+
+    def interlude(self, fn):
+        self._end()
+        fn()
+        self.items.append(fn)
+        self._begin()
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
 
 
 class TrainEngine:
@@ -35,10 +99,12 @@ class TrainEngine:
         self.loss_t = None
         c = ctx()
         c.world_size = world_size
+        c.sync_bn = True
         c.overlap = overlap            # False | "pair" | "deferred": wgrad on a second stream (runtime.Context.fork)
         # two_phase=True with world_size == 1 runs the N > 1 structure (graph A / RCCL all-reduce / graph B, per-rank BN
         # statistics inside the capture) in a 1-rank process group: the single-GPU test of the multi-GPU path
         self.two_phase = (world_size > 1) if two_phase is None else bool(two_phase)
+        c.sync_always = self.two_phase and world_size == 1      # 1-rank group: still issue the SyncBatchNorm collectives
         self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems,
                                        always=self.two_phase) if self.two_phase else None
         # early exchange: backward runs in segments between the model's marks (ResNet.forward: before layer3 and before
@@ -99,7 +165,6 @@ class TrainEngine:
         self.reducer.wait()
 
     def _eager_step(self, images, labels):
-        ctx().sync_bn = True
         if self.seg_ranges is not None:
             loss_t, rest = self._fwd_bwd(images, labels, split=True)
             self._exchange(rest)
@@ -112,7 +177,6 @@ class TrainEngine:
 
     def _capture(self, images, labels):
         c = ctx()
-        c.sync_bn = not self.two_phase
         self.images = images.clone()
         self.labels = labels.clone()
         c.workspace(64 << 20)
@@ -120,25 +184,25 @@ class TrainEngine:
         # with a process group alive, ProcessGroupNCCL's watchdog thread polls events while we capture: the default
         # "global" capture mode turns such a foreign-thread call into a capture error (seen as a watchdog abort)
         mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
-        self.graph_a = torch.cuda.CUDAGraph()
+        # every stretch is a GraphSequence: one hipGraph, or several around the SyncBatchNorm statistics all-reduces
+        self.graph_a = GraphSequence(mode=mode)
         if self.seg_ranges is not None:
-            with torch.cuda.graph(self.graph_a, **mode):
-                self.loss_t, rest = self._fwd_bwd(self.images, self.labels, split=True)
+            self.loss_t, rest = self.graph_a.capture(lambda: self._fwd_bwd(self.images, self.labels, split=True))
             self.graph_rest = []
             for seg in rest:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.graph_a.pool(), **mode):
-                    seg()
+                g = GraphSequence(pool=self.graph_a.pool(), mode=mode)
+                g.capture(seg)
                 self.graph_rest.append(g)
         else:
-            with torch.cuda.graph(self.graph_a, **mode):
-                self.loss_t = self._fwd_bwd(self.images, self.labels)
+            def whole():
+                loss_t = self._fwd_bwd(self.images, self.labels)
                 if self.reducer is None:
                     self.opt.step()
+                return loss_t
+            self.loss_t = self.graph_a.capture(whole)
         if self.reducer is not None:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), **mode):
-                self.opt.step()
+            self.graph_b = GraphSequence(pool=self.graph_a.pool(), mode=mode)
+            self.graph_b.capture(self.opt.step)
 
     # -- public ------------------------------------------------------------------------------------
     def step(self, images, labels):

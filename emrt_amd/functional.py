@@ -411,10 +411,17 @@ class BNState:
 BN_REPLICAS = 8     # fp64 BatchNorm sums are [8][2C]: producers spread atomics over replicas, consumers add them
 
 
+def _sync_active(bn):
+    """This BatchNorm all-reduces its statistics over ranks (nn.SyncBatchNorm: paddle_EMRT.py:64, fcn_head.py:53)."""
+    c = ctx()
+    return bool(bn.sync and c.sync_bn and (c.world_size > 1 or c.sync_always))
+
+
 def _allreduce_sums(sums, count):
-    """SyncBatchNorm: sum the per-rank fp64 (sum, sumsq) vectors and the row count over ranks (RCCL all-reduce)."""
+    """SyncBatchNorm: sum the per-rank fp64 (sum, sumsq) vectors over ranks (RCCL all-reduce); returns the global row count.
+    Inside a captured step the collective is issued between two hipGraphs (runtime.Context.collective)."""
     import torch.distributed as dist
-    dist.all_reduce(sums)
+    ctx().collective(lambda: dist.all_reduce(sums))
     return count * dist.get_world_size()
 
 
@@ -441,7 +448,7 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
         if sums is None:
             sums = c.zeros_f64(BN_REPLICAS * 2 * C)
             _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), c.dtype, c.stream)
-        if bn.sync and c.world_size > 1 and c.sync_bn:
+        if _sync_active(bn):
             count = _allreduce_sums(sums, M)
         _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd),
                   P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
@@ -468,7 +475,7 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             assert dy_bs == H * W * lddy
             yv = out if relu else None
-            sync = bn.sync and c.world_size > 1 and c.sync_bn
+            sync = _sync_active(bn)
             # the consumer conv's dgrad already produced the sums when its dx is the one and only gradient of `out`
             # ... or, for a residual join, when that dgrad was the LAST of its contributions (it folded the earlier ones in)
             fused = rec is not None and rec["dx"] is dy and not sync and ncontrib == (1 if residual is None else rec["n"])

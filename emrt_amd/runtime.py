@@ -202,6 +202,19 @@ class Context:
         self._side = None
         self._in_backward = False # Tape.backward() is running (step-scoped allocations allowed)
         self._main = None         # the stream every launch of this runtime goes to (torch's current stream after init_device)
+        self.capture = None       # engine.GraphSequence while a step is being captured: collective() then breaks the graph
+        self.sync_always = False  # issue the SyncBatchNorm collectives even in a 1-rank group (single-GPU test of the N > 1 path)
+
+    def collective(self, fn):
+        """Run a host-issued collective (fn enqueues it on the current stream's timeline) at this point of the step.  Eager:
+        just call it.  While the step is being captured into hipGraphs: end the current graph, call it -- now and on every
+        replay -- between the graphs, and continue capturing in a new graph (engine.GraphSequence.interlude).  The transports
+        differ in what they can capture (gloo stages through the host; RCCL kernels can be captured but then cost graph-side
+        cross-stream edges), an eager call between two graph launches is right for all of them."""
+        if self.capture is not None:
+            self.capture.interlude(fn)
+        else:
+            fn()
 
     # ---- second stream -------------------------------------------------------------------------------------------
     # overlap = False | "pair" | "deferred".  fork() returns the side stream (C handle) ordered after everything issued so

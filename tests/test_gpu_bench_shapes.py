@@ -229,13 +229,13 @@ def test_wgrad_fp32_atomics_run_to_run_spread_is_bounded():
 # with absolute bounds, and (2) always next to the yardstick "torch's own CPU bf16 autocast of the same fp32 oracle": the HIP
 # path stores activations in bf16 exactly where autocast does, so it must not be further from fp32 than autocast is.
 # Bounds (measured values are printed; see DESIGN.md "Parity results"):
-BF16_LOGIT_REL_L2 = 0.08        # ||logits_bf16 - logits_ref|| / ||logits_ref||, main and aux head (conditioned weights)
+BF16_LOGIT_REL_L2 = 0.06        # ||logits_bf16 - logits_ref|| / ||logits_ref||, main and aux head (conditioned weights)
 BF16_ARGMAX_AGREE = 0.95        # fraction of pixels with the same argmax class (all pixels, near-ties included)
 BF16_DECISIVE_AGREE = 0.999     # ... among pixels whose fp32 top-2 margin exceeds 10 % of the logit range
 BF16_VS_AUTOCAST = 1.25         # HIP error <= 1.25 x (torch CPU bf16 autocast error) + 0.005, both vs the fp32 oracle
-BF16_LOSS_REL = 2e-2
-BF16_GRAD_COSINE = 0.90         # cosine between the whole bf16 gradient vector and the fp32 oracle's
-BF16_GRAD_NORM_RATIO = 0.10     # | ||g_bf16|| / ||g_ref|| - 1 |
+BF16_LOSS_REL = 2e-3
+BF16_GRAD_COSINE = 0.985        # cosine between the whole bf16 gradient vector and the fp32 oracle's
+BF16_GRAD_NORM_RATIO = 0.02     # | ||g_bf16|| / ||g_ref|| - 1 |
 
 
 def test_full_size_bf16_model_vs_fp32_oracle():

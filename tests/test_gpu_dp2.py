@@ -85,13 +85,114 @@ def _worker(rank, world, port, q):
         for a, b in zip(traces["eager_plain"], traces["eager_early"]):
             assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), traces
         assert abs(sums["eager_plain"] - sums["eager_early"]) <= 1e-6 * abs(sums["eager_plain"]), sums
-        # inside the graphs the five SyncBatchNorm layers use per-rank statistics: close, not equal
+        # the captured step cuts its graphs at the five SyncBatchNorm collectives (engine.GraphSequence): same arithmetic
         for a, b in zip(traces["eager_plain"], traces["graph_early"]):
-            assert abs(a - b) <= 3e-2 * max(1.0, abs(a)), traces
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), traces
+        assert abs(sums["eager_plain"] - sums["graph_early"]) <= 1e-6 * abs(sums["eager_plain"]), sums
+        assert eng.graph_a.n_graphs > 1, "the forward + first backward segment must have been cut at the SyncBatchNorm all-reduces"
         assert traces["graph_early"][-1] < traces["graph_early"][0]
         q.put((rank, "ok", traces["graph_early"]))
     finally:
         dist.destroy_process_group()
+
+
+def _identity_worker(rank, world, port, q):
+    """N ranks x B tiles  ==  1 rank x (N*B) tiles on the concatenated batch, on the real model.
+    The reference's plain BatchNorm2D layers use per-rank statistics, so the identity can only hold when EVERY BatchNorm is a
+    SyncBatchNorm: the test flips them all to sync (the same code path the five real SyncBatchNorm layers take), equal
+    non-ignored pixel counts per rank (mean-of-means == global mean), dropout off."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      EMRT_DIST_BACKEND="gloo")
+    import argparse
+    import torch.distributed as dist
+    from emrt_amd import nn as hnn
+    from emrt_amd.config import get_config, update_config
+    from emrt_amd.distributed import init_process_group
+    from emrt_amd.engine import TrainEngine
+    from emrt_amd.runtime import F32, ctx
+    from emrt_amd.src.models import get_model
+    from emrt_amd.src.models.losses import get_loss_function
+    from emrt_amd.src.models.solver import get_optimizer, get_scheduler
+    here = os.path.dirname(os.path.abspath(__file__))
+    init_process_group()
+    try:
+        cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(here, "..", "emrt_amd", "configs", "EMRT", "EMRT_256x256_160k_potsdam.yaml")))
+        cfg.MODEL.ENCODER.TYPE = "resnet18"
+        cfg.TRAIN.ITERS = 100
+        B, S, steps = 2, 64, 3
+        tiles = []
+        for r in range(world):                                  # every rank knows every rank's tiles (for the 1-rank run)
+            g = torch.Generator().manual_seed(200 + r)
+            tiles.append((torch.randn(B, 3, S, S, generator=g).cuda(), torch.randint(0, 6, (B, S, S), generator=g).cuda()))
+        x, labels = tiles[rank]
+        xcat, lcat = torch.cat([t[0] for t in tiles]), torch.cat([t[1] for t in tiles])
+
+        def build():
+            torch.manual_seed(5)
+            model = get_model(cfg)
+            model.to_hip("cuda:0", F32, seed=9)
+            model.set_dropout(0.0)
+            for m in model.modules():
+                if isinstance(m, hnn.BatchNorm2D):
+                    m.state.sync = True
+            return model, get_optimizer(model, get_scheduler(cfg), cfg)
+
+        def run(world_size, use_graph, xs, ls):
+            model, opt = build()
+            eng = TrainEngine(model, opt, get_loss_function(cfg), world_size, use_graph=use_graph, warmup_eager=1, bucket_elems=4 * 1024 * 1024)
+            n = model.store.n_train
+            out = {"loss": [], "grad": None, "logits": None}
+            for i in range(steps):
+                out["loss"].append(eng.step(xs, ls).item())
+                if i == 0:
+                    torch.cuda.synchronize()
+                    out["grad"] = model.store.grad[:n].clone()          # averaged over ranks by the reducer, untouched by the optimizer
+            torch.cuda.synchronize()
+            out["weights"] = model.store.master[:n].clone()
+            model.eval()
+            out["logits"] = model(xs)[0].clone()                        # eval forward with the trained weights AND running statistics
+            if use_graph:
+                out["n_graphs"] = eng.graph_a.n_graphs
+            return out
+
+        ref = run(1, False, xcat, lcat)                                   # one rank, the concatenated batch
+        assert ctx().world_size == 1
+        res = {"eager": run(world, False, x, labels), "graph": run(world, True, x, labels)}
+        for mode, r in res.items():
+            losses = torch.tensor(r["loss"], dtype=torch.float64).cuda()
+            dist.all_reduce(losses)
+            losses = (losses / world).tolist()
+            for a, b in zip(losses, ref["loss"]):
+                assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (mode, losses, ref["loss"])
+            ge = (r["grad"] - ref["grad"]).norm().item() / ref["grad"].norm().item()
+            we = (r["weights"] - ref["weights"]).abs().max().item()
+            le = (r["logits"] - ref["logits"][rank * B:(rank + 1) * B]).abs().max().item()
+            print("rank %d %s: mean-of-ranks loss trace %s vs 1-rank %s; grad rel err %.2e; weights max |diff| %.2e; eval logits max |diff| %.2e" % (
+                rank, mode, ["%.6f" % v for v in losses], ["%.6f" % v for v in ref["loss"]], ge, we, le), flush=True)
+            assert ge < 1e-4, (mode, ge)
+            assert we < 1e-5 and le < 1e-3, (mode, we, le)
+        assert res["graph"]["n_graphs"] > 20, res["graph"]["n_graphs"]     # every BatchNorm cut the captured forward and backward
+        q.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_workers(fn, timeout=900):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return sorted(q.get(timeout=5) for _ in range(world))
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
+    got = _run_workers(_identity_worker)
+    assert [g[:2] for g in got] == [(0, "ok"), (1, "ok")]
 
 
 def test_two_ranks_on_one_gpu_over_gloo():
