@@ -46,147 +46,244 @@ struct MsdaArgs {
 template <class T>
 __device__ __forceinline__ void load8(const T* p, float (&o)[8]) { Vec8<T>::load(p, o); }
 
+// ---- forward -------------------------------------------------------------------------------------------------------
+// A quad (4 lanes x 8 channels) owns one (query, head) pair.  Everything that does not depend on the channel -- the
+// softmax over the L*P logits, the sample coordinates, the four bilinear corner weights with the attention probability
+// and the zero padding folded in -- is computed ONCE per pair: lane `sub` of the quad takes samples sub, sub + 4, ...
+// (the first version had all four lanes repeat all of it: 3/4 of ~900 instructions per pair wasted in a kernel that is
+// bound by VALU issue), and every sample's five values (4 corner weights + pixel index) are then broadcast inside the
+// quad with DPP quad_perm moves -- register to register, no LDS, no barrier.  A corner whose weight is 0 (outside the
+// map: grid_sample's zero padding, utils.py:87-88) contributes fma(0, v, acc) = acc exactly, so "skip it" (global
+// kernel) and "read a harmless address" (LDS kernel) give bit-identical sums.
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {        // value of lane K of every quad
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, false);
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float quad_add(float v) {          // same value in all four lanes (order fixed: (a+b)+(c+d))
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  return v;
+}
+
+// The samples lane `sub` of a quad prepares for its pair: slot j holds sample sub + 4 j.
+template <int L, int P>
+struct MsdaPrep {
+  static constexpr int LP = L * P;
+  static constexpr int NS = (LP + 3) / 4;          // slots per lane
+  float w00[NS], w01[NS], w10[NS], w11[NS];        // corner weights (probability * bilinear weight, 0 outside the map)
+  int idx[NS];                                     // y0 * W + x0 of the sample's level (0 when no corner is inside)
+
+  // row: the pair's fp32 [M*LP*2 offsets | M*LP logits] row; refp: its reference point(s); live: false for tail lanes
+  __device__ __forceinline__ void run(const MsdaArgs& a, const float* row, const float* refp, int m, int sub, bool live) {
+    const float* offp = row + m * LP * 2;
+    const float* logp = row + a.M * LP * 2 + m * LP;
+    float lg[NS];
+    float2 of[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {                 // all loads first: one round trip
+      const int smp = sub + 4 * j;
+      const bool has = live && smp < LP;
+      lg[j] = has ? logp[smp] : -3.0e38f;
+      of[j] = has ? *reinterpret_cast<const float2*>(offp + smp * 2) : make_float2(0.f, 0.f);
+    }
+    float rx[L], ry[L];
+    const int rls = a.ref_L == 1 ? 0 : 2;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { rx[l] = live ? refp[l * rls] : 0.f; ry[l] = live ? refp[l * rls + 1] : 0.f; }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) mx = fmaxf(mx, lg[j]);
+    mx = quad_max(mx);
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) { lg[j] = (sub + 4 * j < LP) ? __expf(lg[j] - mx) : 0.f; den += lg[j]; }
+    den = quad_add(den);
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      // level of sample sub + 4 j: the division is by a compile-time P, the level-dependent constants are selected
+      const int smp = sub + 4 * j;
+      int l = 0;
+#pragma unroll
+      for (int t = 1; t < L; ++t) l += smp >= t * P ? 1 : 0;
+      int H = a.h[0], W = a.w[0];
+      float ih = a.inv_h[0], iw = a.inv_w[0], rxl = rx[0], ryl = ry[0];
+#pragma unroll
+      for (int t = 1; t < L; ++t)
+        if (l == t) { H = a.h[t]; W = a.w[t]; ih = a.inv_h[t]; iw = a.inv_w[t]; rxl = rx[t]; ryl = ry[t]; }
+      const float x = (rxl + of[j].x * iw) * (float)W - 0.5f;
+      const float y = (ryl + of[j].y * ih) * (float)H - 0.5f;
+      const float xf = floorf(x), yf = floorf(y);
+      const float lx = x - xf, ly = y - yf;
+      // samples far outside would overflow the int conversion: clamp (any value below -1 / above the map is "outside")
+      const int x0 = (int)fminf(fmaxf(xf, -2.f), 16777216.f), y0 = (int)fminf(fmaxf(yf, -2.f), 16777216.f);
+      const float aw = lg[j] * inv;
+      const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+      const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+      w00[j] = (vy0 && vx0) ? aw * (1.f - ly) * (1.f - lx) : 0.f;
+      w01[j] = (vy0 && vx1) ? aw * (1.f - ly) * lx : 0.f;
+      w10[j] = (vy1 && vx0) ? aw * ly * (1.f - lx) : 0.f;
+      w11[j] = (vy1 && vx1) ? aw * ly * lx : 0.f;
+      // with at least one corner inside, y0 is in [-1, H-1] and x0 in [-1, W-1]: the four corner indices stay within
+      // [-(W+1), H*W + W] of the level -- the range the LDS slab's guard bands cover
+      idx[j] = ((vy0 || vy1) && (vx0 || vx1) && smp < LP) ? y0 * W + x0 : 0;
+    }
+  }
+};
+
+// the five values of sample SMP (compile-time), broadcast from the lane of the quad that prepared it
+#define MSDA_BCAST5(PP, SMP, C00, C01, C10, C11, ID)                                                     \
+  do {                                                                                                   \
+    constexpr int K_ = (SMP) & 3, J_ = (SMP) >> 2;                                                       \
+    C00 = quad_bcast<K_>((PP).w00[J_]); C01 = quad_bcast<K_>((PP).w01[J_]); C10 = quad_bcast<K_>((PP).w10[J_]); \
+    C11 = quad_bcast<K_>((PP).w11[J_]); ID = quad_bcast<K_>((PP).idx[J_]);                               \
+  } while (0)
+
+// acc += w * v over the lane's 8 channels (v: 16 raw bytes of T / 32 of float)
+template <class T>
+__device__ __forceinline__ void axpy8(float (&acc)[8], float w, const float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+}
+
+#define MSDA_FWD_PITCH 80        /* bytes per LDS row of the staged forward slab: 64 B of data + 16 B pad */
+template <class T, int L, int P, int SMP>
+__device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const T* vb, float (&acc)[8]) {
+  if constexpr (SMP < L * P) {
+    constexpr int l = SMP / P;
+    float c00, c01, c10, c11;
+    int id;
+    MSDA_BCAST5(pp, SMP, c00, c01, c10, c11, id);
+    const int W = a.w[l];
+    const T* p00 = vb + ((long long)a.start[l] + id) * a.ldv;
+    float v[8];
+    if (c00 != 0.f) { load8<T>(p00, v); axpy8<T>(acc, c00, v); }
+    if (c01 != 0.f) { load8<T>(p00 + a.ldv, v); axpy8<T>(acc, c01, v); }
+    if (c10 != 0.f) { load8<T>(p00 + (long long)W * a.ldv, v); axpy8<T>(acc, c10, v); }
+    if (c11 != 0.f) { load8<T>(p00 + (long long)(W + 1) * a.ldv, v); axpy8<T>(acc, c11, v); }
+    msda_gather_global<T, L, P, SMP + 1>(a, pp, vb, acc);
+  }
+}
+
+template <class T, int L, int P, int SMP>
+__device__ __forceinline__ void msda_gather_lds(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const unsigned char* vslab_sub, float (&acc)[8]) {
+  if constexpr (SMP < L * P) {
+    constexpr int l = SMP / P;
+    float c00, c01, c10, c11;
+    int id;
+    MSDA_BCAST5(pp, SMP, c00, c01, c10, c11, id);
+    const unsigned char* p00 = vslab_sub + (a.start[l] + id) * MSDA_FWD_PITCH;
+    const unsigned char* p10 = p00 + a.w[l] * MSDA_FWD_PITCH;
+    float v[8];
+    load8<T>(reinterpret_cast<const T*>(p00), v); axpy8<T>(acc, c00, v);
+    load8<T>(reinterpret_cast<const T*>(p00 + MSDA_FWD_PITCH), v); axpy8<T>(acc, c01, v);
+    load8<T>(reinterpret_cast<const T*>(p10), v); axpy8<T>(acc, c10, v);
+    load8<T>(reinterpret_cast<const T*>(p10 + MSDA_FWD_PITCH), v); axpy8<T>(acc, c11, v);
+    msda_gather_lds<T, L, P, SMP + 1>(a, pp, vslab_sub, acc);
+  }
+}
+
+// Gather straight from global memory (L2): fp32 maps, slabs that do not fit in LDS (512x512 tiles), small launches.
 template <class T, int L, int P>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
   constexpr int LP = L * P;
   const int lane = threadIdx.x & 63;
-  const long long pair = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+  const long long pair_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
   const long long total = (long long)a.B * a.Lq * a.M;
-  if (pair >= total) return;
+  const bool live = pair_raw < total;
+  const long long pair = live ? pair_raw : total - 1;   // tail lanes shadow a live pair: the quad shuffles stay defined
   const int sub = lane & 3;
   const int m = (int)(pair % a.M);
   const long long bq = pair / a.M;
   const int b = (int)(bq / a.Lq);
   const int q = (int)(bq - (long long)b * a.Lq);
-
-  const float* row = a.offw + bq * a.ldo;
-  const float* offp = row + m * LP * 2;
-  const float* logp = row + a.M * LP * 2 + m * LP;
-  float lg[LP];
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int i = 0; i < LP; ++i) { lg[i] = logp[i]; mx = fmaxf(mx, lg[i]); }
-  float den = 0.f;
-#pragma unroll
-  for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
-  const float inv = 1.f / den;
-
+  MsdaPrep<L, P> pp;
+  pp.run(a, a.offw + bq * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2, m, sub, live);
   const T* vb = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8;
-  const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2;
-  const int rls = a.ref_L == 1 ? 0 : 2;
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int H = a.h[l], W = a.w[l];
-    const float rx = refp[l * rls], ry = refp[l * rls + 1];
-    const T* vl = vb + (long long)a.start[l] * a.ldv;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const float2 o = *reinterpret_cast<const float2*>(offp + (l * P + p) * 2);
-      const float x = (rx + o.x * a.inv_w[l]) * (float)W - 0.5f;
-      const float y = (ry + o.y * a.inv_h[l]) * (float)H - 0.5f;
-      const float xf = floorf(x), yf = floorf(y);
-      const float lx = x - xf, ly = y - yf;
-      const int x0 = (int)xf, y0 = (int)yf;
-      const float aw = lg[l * P + p] * inv;
-      const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
-      const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-      float v[8];
-      if (vy0 && vx0) { load8<T>(vl + ((long long)y0 * W + x0) * a.ldv, v); const float c = aw * (1.f - ly) * (1.f - lx);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-      if (vy0 && vx1) { load8<T>(vl + ((long long)y0 * W + x0 + 1) * a.ldv, v); const float c = aw * (1.f - ly) * lx;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-      if (vy1 && vx0) { load8<T>(vl + ((long long)(y0 + 1) * W + x0) * a.ldv, v); const float c = aw * ly * (1.f - lx);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-      if (vy1 && vx1) { load8<T>(vl + ((long long)(y0 + 1) * W + x0 + 1) * a.ldv, v); const float c = aw * ly * lx;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-    }
-  }
-  Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
+  msda_gather_global<T, L, P, 0>(a, pp, vb, acc);
+  if (live) Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
 }
 
 // Forward with the (batch, head) value slab staged in LDS: one block per (batch, head, chunk of queries).  The global
-// kernel above gathers 64-byte head slices from L2 (396 MB of L2->CU traffic per encoder call for 5.5 MB of value); here
-// every block copies its head's [Lv][32] slab once (rows padded to 80 B so that random pixels spread over the banks) and
-// the 4 x 18 corner reads of a query are ds_read_b128.  Same arithmetic in the same order as msda_fwd_kernel, so the two
-// are bit-identical.  Used when the slab fits (bf16 up to Lv = 1894, i.e. 256^2 tiles; fp32 maps fall back).
-#define MSDA_FWD_PITCH 80        /* bytes per LDS row: 64 B of bf16 data + 16 B pad */
+// kernel gathers 64-byte head slices from L2 through the texture path (396 MB of L2 -> CU traffic per encoder call for
+// 5.5 MB of value, ~64 B/clk/CU); from LDS the same corner reads are ds_read_b128 at up to 256 B/clk/CU.
+//  * slab layout: [guard | Lv rows | guard], MSDA_FWD_PITCH bytes per pixel row (64 B of data + 16 B pad so that random
+//    pixels spread over the banks), zero guard bands of `guard` rows on both sides: a corner with weight 0 is still READ
+//    (branch-free inner loop) and may fall up to W + 1 pixels outside its level -- into a neighbouring level's rows or a
+//    guard band, always finite data, times 0;
+//  * staging: every thread issues all its 16-byte global loads before the first LDS store (one memory round trip for
+//    the whole slab instead of one per loop iteration), and the first pass's per-sample preparation (global loads of
+//    the offsets / logits, softmax, coordinates) runs while they are in flight;
+//  * block -> (batch, head, chunk): consecutive block ids go to the 8 XCDs round-robin, so the map sends the chunks of
+//    one slab and the heads of one batch element to ONE XCD: the slab and the offset rows are fetched into one L2.
+// Same arithmetic in the same order as msda_fwd_kernel: the two are bit-identical (tests/test_gpu_bench_shapes.py).
+#define MSDA_STAGE_MAX 8         /* 16-byte chunks a thread may stage: slabs up to 8 * 1024 * 16 B = 128 KB of data */
 template <class T, int L, int P>
-__global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_per_block) {
+__global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_per_block, int chunks, int guard) {
   static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
   constexpr int LP = L * P;
-  extern __shared__ __attribute__((aligned(16))) unsigned char vslab[];
-  const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
-  {
-    const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32;
-    for (int i = threadIdx.x; i < a.Lv * 4; i += blockDim.x) {
-      const int pix = i >> 2, part = i & 3;
-      *reinterpret_cast<uint4*>(vslab + pix * MSDA_FWD_PITCH + part * 16) = *reinterpret_cast<const uint4*>(src + (long long)pix * a.ldv + part * 8);
-    }
-  }
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) unsigned char vslab_raw[];
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int bm = bid / chunks, chunk = bid - bm * chunks;
+  const int b = bm / a.M, m = bm - b * a.M;
+  unsigned char* vslab = vslab_raw + guard * MSDA_FWD_PITCH;       // row 0 of the value tensor
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3;
-  const int q_begin = blockIdx.y * q_per_block;
+  const int q_begin = chunk * q_per_block;
   int q_end = q_begin + q_per_block;
   if (q_end > a.Lq) q_end = a.Lq;
-  for (int q = q_begin + wave * 16 + (lane >> 2); q < q_end; q += 16 * 16) {
-    const long long bq = (long long)b * a.Lq + q;
-    const float* row = a.offw + bq * a.ldo;
-    const float* offp = row + m * LP * 2;
-    const float* logp = row + a.M * LP * 2 + m * LP;
-    float lg[LP];
-    float mx = -3.0e38f;
+
+  // ---- stage: all loads in flight, then the first pass's preparation, then the LDS stores ----
+  uint4 st[MSDA_STAGE_MAX];
+  const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32;
+  const int n16 = a.Lv * 4;
 #pragma unroll
-    for (int i = 0; i < LP; ++i) { lg[i] = logp[i]; mx = fmaxf(mx, lg[i]); }
-    float den = 0.f;
+  for (int k = 0; k < MSDA_STAGE_MAX; ++k) {
+    const int i = (int)threadIdx.x + k * 1024;
+    if (i < n16) st[k] = *reinterpret_cast<const uint4*>(src + (long long)(i >> 2) * a.ldv + (i & 3) * 8);
+  }
+  for (int i = threadIdx.x; i < guard * (MSDA_FWD_PITCH / 16); i += 1024) {       // zero guard bands
+    *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(vslab + a.Lv * MSDA_FWD_PITCH + i * 16) = make_uint4(0, 0, 0, 0);
+  }
+  MsdaPrep<L, P> pp;
+  int qw = q_begin + wave * 16;                   // this wave's first query of the pass (wave-uniform)
+  auto prepare = [&]() {
+    const int q = qw + (lane >> 2);
+    const bool live = q < q_end;
+    const int qq = live ? q : q_end - 1;          // tail lanes shadow the last query: the quad shuffles stay defined
+    pp.run(a, a.offw + ((long long)b * a.Lq + qq) * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2, m, sub, live);
+  };
+  if (qw < q_end) prepare();
 #pragma unroll
-    for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
-    const float inv = 1.f / den;
-    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2;
-    const int rls = a.ref_L == 1 ? 0 : 2;
+  for (int k = 0; k < MSDA_STAGE_MAX; ++k) {
+    const int i = (int)threadIdx.x + k * 1024;
+    if (i < n16) *reinterpret_cast<uint4*>(vslab + (i >> 2) * MSDA_FWD_PITCH + (i & 3) * 16) = st[k];
+  }
+  __syncthreads();
+  const unsigned char* vslab_sub = vslab + sub * 16;
+  while (qw < q_end) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const int H = a.h[l], W = a.w[l];
-      const float rx = refp[l * rls], ry = refp[l * rls + 1];
-      const unsigned char* vl = vslab + a.start[l] * MSDA_FWD_PITCH + sub * 16;
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const float2 o = *reinterpret_cast<const float2*>(offp + (l * P + p) * 2);
-        const float x = (rx + o.x * a.inv_w[l]) * (float)W - 0.5f;
-        const float y = (ry + o.y * a.inv_h[l]) * (float)H - 0.5f;
-        const float xf = floorf(x), yf = floorf(y);
-        const float lx = x - xf, ly = y - yf;
-        const int x0 = (int)xf, y0 = (int)yf;
-        const float aw = lg[l * P + p] * inv;
-        const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
-        const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-        float v[8];
-        const unsigned char* p00 = vl + (y0 * W + x0) * MSDA_FWD_PITCH;
-        if (vy0 && vx0) { load8<T>(reinterpret_cast<const T*>(p00), v); const float c = aw * (1.f - ly) * (1.f - lx);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-        if (vy0 && vx1) { load8<T>(reinterpret_cast<const T*>(p00 + MSDA_FWD_PITCH), v); const float c = aw * (1.f - ly) * lx;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-        if (vy1 && vx0) { load8<T>(reinterpret_cast<const T*>(p00 + W * MSDA_FWD_PITCH), v); const float c = aw * ly * (1.f - lx);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-        if (vy1 && vx1) { load8<T>(reinterpret_cast<const T*>(p00 + (W + 1) * MSDA_FWD_PITCH), v); const float c = aw * ly * lx;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] = fmaf(c, v[e], acc[e]); }
-      }
-    }
-    Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
+    msda_gather_lds<T, L, P, 0>(a, pp, vslab_sub, acc);
+    const int q = qw + (lane >> 2);
+    if (q < q_end) Vec8<T>::store((T*)a.out + ((long long)b * a.Lq + q) * (a.M * 32) + m * 32 + sub * 8, acc);
+    qw += 16 * 16;
+    if (qw < q_end) prepare();
   }
 }
 
@@ -566,12 +663,12 @@ static int msda_launch_fwd(const MsdaArgs& a, int L, int P, hipStream_t st) {
 }
 
 template <class T>
-static int msda_launch_fwd_lds(const MsdaArgs& a, int L, int P, int chunks, int qpb, size_t slab, hipStream_t st) {
+static int msda_launch_fwd_lds(const MsdaArgs& a, int L, int P, int chunks, int qpb, int guard, size_t slab, hipStream_t st) {
 #define MSDA_FWD_LDS_CASE(LL, PP)                                                                                         \
   if (L == LL && P == PP) {                                                                                             \
     static bool attr = false;                                                                                           \
     if (!attr) { (void)hipFuncSetAttribute((const void*)msda_fwd_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
-    hipLaunchKernelGGL((msda_fwd_lds_kernel<T, LL, PP>), dim3(a.B * a.M, chunks), dim3(1024), slab, st, a, qpb);          \
+    hipLaunchKernelGGL((msda_fwd_lds_kernel<T, LL, PP>), dim3(a.B * a.M * chunks), dim3(1024), slab, st, a, qpb, chunks, guard); \
     return check_launch("emrt_msda_fwd(lds)");                                                                          \
   }
   MSDA_FWD_LDS_CASE(3, 6)
@@ -630,14 +727,18 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
   hipStream_t st = (hipStream_t)stream;
   a.Lv = Lv;
-  const size_t slab = (size_t)Lv * MSDA_FWD_PITCH;
-  if (dtype != EMRT_F32 && slab <= 150 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {       // LDS-staged slab (see msda_fwd_lds_kernel)
-    int chunks = (512 + B * M - 1) / (B * M);                  // ~2 blocks per CU
-    if (chunks > (Lq + 255) / 256) chunks = (Lq + 255) / 256;  // at least one 256-query pass per block
+  int wmax = 1;
+  for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
+  const int guard = wmax + 2;                                  // zero rows on both sides of the staged slab (msda_fwd_lds_kernel)
+  const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
+  if (dtype != EMRT_F32 && slab <= 159 * 1024 && Lv * 4 <= MSDA_STAGE_MAX * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {
+    // one block per CU (the slab takes most of its LDS): as close to 256 blocks as whole chunks of >= 128 queries allow
+    int chunks = (256 + B * M / 2) / (B * M);
+    if (chunks > (Lq + 127) / 128) chunks = (Lq + 127) / 128;
     if (chunks < 1) chunks = 1;
     const int qpb = (Lq + chunks - 1) / chunks;
     chunks = (Lq + qpb - 1) / qpb;
-    return dtype == EMRT_BF16 ? msda_launch_fwd_lds<bf16_t>(a, L, P, chunks, qpb, slab, st) : msda_launch_fwd_lds<f16_t>(a, L, P, chunks, qpb, slab, st);
+    return dtype == EMRT_BF16 ? msda_launch_fwd_lds<bf16_t>(a, L, P, chunks, qpb, guard, slab, st) : msda_launch_fwd_lds<f16_t>(a, L, P, chunks, qpb, guard, slab, st);
   }
   if (dtype == EMRT_F16) return msda_launch_fwd<f16_t>(a, L, P, st);
   return dtype == EMRT_F32 ? msda_launch_fwd<float>(a, L, P, st) : msda_launch_fwd<bf16_t>(a, L, P, st);
