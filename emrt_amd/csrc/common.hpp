@@ -154,6 +154,14 @@ struct Vec8<float> {
 };
 template <>
 struct Vec8<bf16_t> {
+  __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[8]) {      // 16 raw bytes already in registers
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = bf16_bits_to_f32(w[i] & 0xffffu);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
   __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
     uint4 v = *reinterpret_cast<const uint4*>(p);
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -173,6 +181,10 @@ struct Vec8<bf16_t> {
 
 template <>
 struct Vec8<f16_t> {
+  __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[8]) {
+    unpack_f16x2(v.x, o[0], o[1]); unpack_f16x2(v.y, o[2], o[3]);
+    unpack_f16x2(v.z, o[4], o[5]); unpack_f16x2(v.w, o[6], o[7]);
+  }
   __device__ static __forceinline__ void load(const f16_t* p, float (&o)[8]) {
     uint4 v = *reinterpret_cast<const uint4*>(p);
     unpack_f16x2(v.x, o[0], o[1]); unpack_f16x2(v.y, o[2], o[3]);

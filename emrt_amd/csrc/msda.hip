@@ -155,7 +155,7 @@ __device__ __forceinline__ void axpy8(float (&acc)[8], float w, const float (&v)
   for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, v[e], acc[e]);
 }
 
-#define MSDA_FWD_PITCH 80        /* bytes per LDS row of the staged forward slab: 64 B of data + 16 B pad */
+#define MSDA_FWD_PITCH 64        /* bytes per LDS row of the staged forward slab (unpadded: see msda_fwd_lds_kernel) */
 template <class T, int L, int P, int SMP>
 __device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const T* vb, float (&acc)[8]) {
   if constexpr (SMP < L * P) {
@@ -174,21 +174,51 @@ __device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const Msda
   }
 }
 
-template <class T, int L, int P, int SMP>
-__device__ __forceinline__ void msda_gather_lds(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const unsigned char* vslab_sub, float (&acc)[8]) {
-  if constexpr (SMP < L * P) {
-    constexpr int l = SMP / P;
-    float c00, c01, c10, c11;
-    int id;
-    MSDA_BCAST5(pp, SMP, c00, c01, c10, c11, id);
-    const unsigned char* p00 = vslab_sub + (a.start[l] + id) * MSDA_FWD_PITCH;
-    const unsigned char* p10 = p00 + a.w[l] * MSDA_FWD_PITCH;
-    float v[8];
-    load8<T>(reinterpret_cast<const T*>(p00), v); axpy8<T>(acc, c00, v);
-    load8<T>(reinterpret_cast<const T*>(p00 + MSDA_FWD_PITCH), v); axpy8<T>(acc, c01, v);
-    load8<T>(reinterpret_cast<const T*>(p10), v); axpy8<T>(acc, c10, v);
-    load8<T>(reinterpret_cast<const T*>(p10 + MSDA_FWD_PITCH), v); axpy8<T>(acc, c11, v);
-    msda_gather_lds<T, L, P, SMP + 1>(a, pp, vslab_sub, acc);
+// The LDS gather: a RUNTIME loop over the prepared slots, four samples (one per preparing lane of the quad) per iteration,
+// with the slot registers shifted down after each iteration so that every DPP broadcast reads slot 0.  (Fully unrolled --
+// 4 * L * P branch-free ds_read_b128 -- the compiler hoists the reads to the top, wants ~350 registers under the
+// 128-register cap of a 16-wave block and spills hundreds of them; a scheduling barrier per sample made it worse.)
+template <class T, int L, int P>
+__device__ __forceinline__ void msda_gather_lds(const MsdaArgs& a, MsdaPrep<L, P>& pp, const unsigned char* vslab_sub, float (&acc)[8]) {
+  constexpr int LP = L * P, NS = MsdaPrep<L, P>::NS;
+#pragma unroll 1
+  for (int j = 0; j < NS; ++j) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int smp = 4 * j + k;                       // wave-uniform
+      if (smp < LP) {
+        int l = 0;
+#pragma unroll
+        for (int t = 1; t < L; ++t) l += smp >= t * P ? 1 : 0;
+        int start = a.start[0], W = a.w[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t)
+          if (l == t) { start = a.start[t]; W = a.w[t]; }
+        float c00, c01, c10, c11;
+        int id;
+        switch (k) {
+          case 0: MSDA_BCAST5(pp, 0, c00, c01, c10, c11, id); break;
+          case 1: MSDA_BCAST5(pp, 1, c00, c01, c10, c11, id); break;
+          case 2: MSDA_BCAST5(pp, 2, c00, c01, c10, c11, id); break;
+          default: MSDA_BCAST5(pp, 3, c00, c01, c10, c11, id); break;
+        }
+        const unsigned char* p00 = vslab_sub + (start + id) * MSDA_FWD_PITCH;
+        const unsigned char* p10 = p00 + W * MSDA_FWD_PITCH;
+        const uint4 r00 = *reinterpret_cast<const uint4*>(p00);
+        const uint4 r01 = *reinterpret_cast<const uint4*>(p00 + MSDA_FWD_PITCH);
+        const uint4 r10 = *reinterpret_cast<const uint4*>(p10);
+        const uint4 r11 = *reinterpret_cast<const uint4*>(p10 + MSDA_FWD_PITCH);
+        float v[8];
+        Vec8<T>::unpack(r00, v); axpy8<T>(acc, c00, v);
+        Vec8<T>::unpack(r01, v); axpy8<T>(acc, c01, v);
+        Vec8<T>::unpack(r10, v); axpy8<T>(acc, c10, v);
+        Vec8<T>::unpack(r11, v); axpy8<T>(acc, c11, v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i + 1 < NS; ++i) {                // next slot becomes slot 0
+      pp.w00[i] = pp.w00[i + 1]; pp.w01[i] = pp.w01[i + 1]; pp.w10[i] = pp.w10[i + 1]; pp.w11[i] = pp.w11[i + 1]; pp.idx[i] = pp.idx[i + 1];
+    }
   }
 }
 
@@ -219,21 +249,23 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
 // Forward with the (batch, head) value slab staged in LDS: one block per (batch, head, chunk of queries).  The global
 // kernel gathers 64-byte head slices from L2 through the texture path (396 MB of L2 -> CU traffic per encoder call for
 // 5.5 MB of value, ~64 B/clk/CU); from LDS the same corner reads are ds_read_b128 at up to 256 B/clk/CU.
-//  * slab layout: [guard | Lv rows | guard], MSDA_FWD_PITCH bytes per pixel row (64 B of data + 16 B pad so that random
-//    pixels spread over the banks), zero guard bands of `guard` rows on both sides: a corner with weight 0 is still READ
-//    (branch-free inner loop) and may fall up to W + 1 pixels outside its level -- into a neighbouring level's rows or a
-//    guard band, always finite data, times 0;
-//  * staging: every thread issues all its 16-byte global loads before the first LDS store (one memory round trip for
-//    the whole slab instead of one per loop iteration), and the first pass's per-sample preparation (global loads of
-//    the offsets / logits, softmax, coordinates) runs while they are in flight;
+//  * slab layout: [guard | Lv rows | guard], 64 bytes per pixel row, UNPADDED: a quad's 64-byte corner read covers one
+//    aligned quarter of the 64 banks, so two of the four random pixels a ds_read_b128 lane group touches collide with
+//    probability 1/4 -- with the 80-byte pitch of the first version the bank windows were unaligned and overlapped with
+//    probability 7/16.  Zero guard bands of `guard` rows on both sides: a corner with weight 0 is still READ (branch-free
+//    inner loop) and may fall up to W + 1 pixels outside its level -- into a neighbouring level's rows or a guard band,
+//    always finite data, times 0;
+//  * staging by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 16 pixel rows per wave instruction, no staging registers, the
+//    whole slab in flight at once -- the first version's load/store loop paid one memory round trip per iteration), and
+//    the first pass's per-sample preparation (global loads of the offsets / logits, softmax, coordinates) overlaps it;
 //  * block -> (batch, head, chunk): consecutive block ids go to the 8 XCDs round-robin, so the map sends the chunks of
 //    one slab and the heads of one batch element to ONE XCD: the slab and the offset rows are fetched into one L2.
 // Same arithmetic in the same order as msda_fwd_kernel: the two are bit-identical (tests/test_gpu_bench_shapes.py).
-#define MSDA_STAGE_MAX 8         /* 16-byte chunks a thread may stage: slabs up to 8 * 1024 * 16 B = 128 KB of data */
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 template <class T, int L, int P>
 __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_per_block, int chunks, int guard) {
   static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
-  constexpr int LP = L * P;
   extern __shared__ __attribute__((aligned(16))) unsigned char vslab_raw[];
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
@@ -241,23 +273,24 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
   const int bm = bid / chunks, chunk = bid - bm * chunks;
   const int b = bm / a.M, m = bm - b * a.M;
   unsigned char* vslab = vslab_raw + guard * MSDA_FWD_PITCH;       // row 0 of the value tensor
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, nwave = blockDim.x >> 6;
   const int q_begin = chunk * q_per_block;
   int q_end = q_begin + q_per_block;
   if (q_end > a.Lq) q_end = a.Lq;
 
-  // ---- stage: all loads in flight, then the first pass's preparation, then the LDS stores ----
-  uint4 st[MSDA_STAGE_MAX];
-  const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32;
-  const int n16 = a.Lv * 4;
-#pragma unroll
-  for (int k = 0; k < MSDA_STAGE_MAX; ++k) {
-    const int i = (int)threadIdx.x + k * 1024;
-    if (i < n16) st[k] = *reinterpret_cast<const uint4*>(src + (long long)(i >> 2) * a.ldv + (i & 3) * 8);
-  }
-  for (int i = threadIdx.x; i < guard * (MSDA_FWD_PITCH / 16); i += 1024) {       // zero guard bands
-    *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(vslab + a.Lv * MSDA_FWD_PITCH + i * 16) = make_uint4(0, 0, 0, 0);
+  // ---- stage: piece k = pixels [16 k, 16 k + 16), lane i carries 16-byte part (i & 3) of pixel 16 k + (i >> 2) ----
+  {
+    const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32 + (lane & 3) * 8;
+    const int npiece = (a.Lv + 15) >> 4;
+    for (int k = wave; k < npiece; k += nwave) {
+      const int pix = k * 16 + (lane >> 2);
+      if (pix < a.Lv)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (long long)pix * a.ldv), (lds_ptr_t)(vslab + k * 1024), 16, 0, 0);
+    }
+    for (int i = threadIdx.x; i < guard * (MSDA_FWD_PITCH / 16); i += blockDim.x) {       // zero guard bands
+      *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(vslab + a.Lv * MSDA_FWD_PITCH + i * 16) = make_uint4(0, 0, 0, 0);
+    }
   }
   MsdaPrep<L, P> pp;
   int qw = q_begin + wave * 16;                   // this wave's first query of the pass (wave-uniform)
@@ -268,21 +301,16 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
     pp.run(a, a.offw + ((long long)b * a.Lq + qq) * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2, m, sub, live);
   };
   if (qw < q_end) prepare();
-#pragma unroll
-  for (int k = 0; k < MSDA_STAGE_MAX; ++k) {
-    const int i = (int)threadIdx.x + k * 1024;
-    if (i < n16) *reinterpret_cast<uint4*>(vslab + (i >> 2) * MSDA_FWD_PITCH + (i & 3) * 16) = st[k];
-  }
-  __syncthreads();
+  __syncthreads();                                // (drains the LDS-DMA: vmcnt(0) in front of the barrier)
   const unsigned char* vslab_sub = vslab + sub * 16;
   while (qw < q_end) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    msda_gather_lds<T, L, P, 0>(a, pp, vslab_sub, acc);
+    msda_gather_lds<T, L, P>(a, pp, vslab_sub, acc);
     const int q = qw + (lane >> 2);
     if (q < q_end) Vec8<T>::store((T*)a.out + ((long long)b * a.Lq + q) * (a.M * 32) + m * 32 + sub * 8, acc);
-    qw += 16 * 16;
+    qw += nwave * 16;
     if (qw < q_end) prepare();
   }
 }
@@ -731,7 +759,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
   const int guard = wmax + 2;                                  // zero rows on both sides of the staged slab (msda_fwd_lds_kernel)
   const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
-  if (dtype != EMRT_F32 && slab <= 159 * 1024 && Lv * 4 <= MSDA_STAGE_MAX * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {
+  if (dtype != EMRT_F32 && slab <= 159 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {
     // one block per CU (the slab takes most of its LDS): as close to 256 blocks as whole chunks of >= 128 queries allow
     int chunks = (256 + B * M / 2) / (B * M);
     if (chunks > (Lq + 127) / 128) chunks = (Lq + 127) / 128;
