@@ -42,6 +42,9 @@ struct Tuning {
   int no_thin_bwd;      // 1 = the classifier backward runs as two GEMMs
   int pair_max;         // largest dgrad grid that is paired with its wgrad in one launch (768)
   int msda_fwd_global;  // 1 = never use the LDS-staged MSDA forward
+  int msda_fwd_chunks;  // LDS-staged MSDA forward: query chunks per (batch, head) slab (0 = automatic)
+  int msda_fwd_threads; // ... threads per block (1024)
+  int msda_fwd_probe;   // timing experiments only (results are WRONG): 1 = no gather, 2 = no staging, 4 = no preparation
   int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
 };

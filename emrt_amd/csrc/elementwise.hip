@@ -20,6 +20,8 @@ const TuneEntry kTune[] = {
     {"thin_ch", &emrt::Tuning::thin_ch, 8},             {"no_thin_bwd", &emrt::Tuning::no_thin_bwd, 0},
     {"pair_max", &emrt::Tuning::pair_max, 768},         {"msda_fwd_global", &emrt::Tuning::msda_fwd_global, 0},
     {"bn_block_kb", &emrt::Tuning::bn_block_kb, 8},     {"ln_atomic", &emrt::Tuning::ln_atomic, 1},
+    {"msda_fwd_chunks", &emrt::Tuning::msda_fwd_chunks, 0}, {"msda_fwd_threads", &emrt::Tuning::msda_fwd_threads, 1024},
+    {"msda_fwd_probe", &emrt::Tuning::msda_fwd_probe, 0},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 template <class T, int L, int P>
-__global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_per_block, int chunks, int guard) {
+__global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_per_block, int chunks, int guard, int probe) {
   static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
   extern __shared__ __attribute__((aligned(16))) unsigned char vslab_raw[];
   int bid = blockIdx.x;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
     const int npiece = (a.Lv + 15) >> 4;
     for (int k = wave; k < npiece; k += nwave) {
       const int pix = k * 16 + (lane >> 2);
-      if (pix < a.Lv)
+      if (pix < a.Lv && !(probe & 2))
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (long long)pix * a.ldv), (lds_ptr_t)(vslab + k * 1024), 16, 0, 0);
     }
     for (int i = threadIdx.x; i < guard * (MSDA_FWD_PITCH / 16); i += blockDim.x) {       // zero guard bands
@@ -298,8 +298,12 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
     const int q = qw + (lane >> 2);
     const bool live = q < q_end;
     const int qq = live ? q : q_end - 1;          // tail lanes shadow the last query: the quad shuffles stay defined
-    pp.run(a, a.offw + ((long long)b * a.Lq + qq) * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2, m, sub, live);
+    if (!(probe & 4)) pp.run(a, a.offw + ((long long)b * a.Lq + qq) * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2, m, sub, live);
   };
+  if (probe & 4) {
+#pragma unroll
+    for (int j = 0; j < MsdaPrep<L, P>::NS; ++j) { pp.w00[j] = 0.25f; pp.w01[j] = 0.25f; pp.w10[j] = 0.25f; pp.w11[j] = 0.25f; pp.idx[j] = (lane * 37 + j * 101) & 63; }
+  }
   if (qw < q_end) prepare();
   __syncthreads();                                // (drains the LDS-DMA: vmcnt(0) in front of the barrier)
   const unsigned char* vslab_sub = vslab + sub * 16;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    msda_gather_lds<T, L, P>(a, pp, vslab_sub, acc);
+    if (!(probe & 1)) msda_gather_lds<T, L, P>(a, pp, vslab_sub, acc);
     const int q = qw + (lane >> 2);
     if (q < q_end) Vec8<T>::store((T*)a.out + ((long long)b * a.Lq + q) * (a.M * 32) + m * 32 + sub * 8, acc);
     qw += nwave * 16;
@@ -692,11 +696,13 @@ static int msda_launch_fwd(const MsdaArgs& a, int L, int P, hipStream_t st) {
 
 template <class T>
 static int msda_launch_fwd_lds(const MsdaArgs& a, int L, int P, int chunks, int qpb, int guard, size_t slab, hipStream_t st) {
+  int threads = g_tune.msda_fwd_threads;
+  if (threads < 64 || threads > 1024 || (threads & 63)) threads = 1024;
 #define MSDA_FWD_LDS_CASE(LL, PP)                                                                                         \
   if (L == LL && P == PP) {                                                                                             \
     static bool attr = false;                                                                                           \
     if (!attr) { (void)hipFuncSetAttribute((const void*)msda_fwd_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
-    hipLaunchKernelGGL((msda_fwd_lds_kernel<T, LL, PP>), dim3(a.B * a.M * chunks), dim3(1024), slab, st, a, qpb, chunks, guard); \
+    hipLaunchKernelGGL((msda_fwd_lds_kernel<T, LL, PP>), dim3(a.B * a.M * chunks), dim3(threads), slab, st, a, qpb, chunks, guard, g_tune.msda_fwd_probe); \
     return check_launch("emrt_msda_fwd(lds)");                                                                          \
   }
   MSDA_FWD_LDS_CASE(3, 6)
@@ -762,6 +768,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   if (dtype != EMRT_F32 && slab <= 159 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {
     // one block per CU (the slab takes most of its LDS): as close to 256 blocks as whole chunks of >= 128 queries allow
     int chunks = (256 + B * M / 2) / (B * M);
+    if (g_tune.msda_fwd_chunks > 0) chunks = g_tune.msda_fwd_chunks;
     if (chunks > (Lq + 127) / 128) chunks = (Lq + 127) / 128;
     if (chunks < 1) chunks = 1;
     const int qpb = (Lq + chunks - 1) / chunks;
