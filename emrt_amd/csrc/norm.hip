@@ -176,45 +176,22 @@ __device__ __forceinline__ BnChan bn_chan(const double* __restrict__ sums, const
   return o;
 }
 
-// Per-channel constants of one BatchNorm layer, ONCE per layer (one thread per channel): scale_shift[2][C] such that
-// y = x * scale + shift.  Training (sums != null): mean / invstd come from the fp64 replica sums, are saved for backward and
-// the running statistics are updated (Paddle convention: momentum 0.9 => running = 0.9*running + 0.1*batch, biased
-// variance); eval: from the running statistics.  The first version derived these in the prologue of EVERY block of the
-// apply kernel (C x 16 fp64 loads + fp64 sqrt / divide per block for ~8 KB of payload): every BatchNorm launch of the step
-// took 14-16 us whatever its size (2 MB maps included) -- the layer's few KB of statistics were re-read hundreds of times.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, double inv_count, float eps, float momentum,
-                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ scale_shift, int C) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= C) return;
-  const BnChan k = bn_chan(sums, run_mean, run_var, C, ch, inv_count, eps);
-  const float scale = k.invstd * gamma[ch];
-  scale_shift[ch] = scale;
-  scale_shift[C + ch] = beta[ch] - k.mean * scale;
-  if (sums) {
-    mean_out[ch] = k.mean;
-    invstd_out[ch] = k.invstd;
-    if (run_mean) {
-      const double mu = rep_sum(sums, C, ch) * inv_count;
-      double var = rep_sum(sums, C, C + ch) * inv_count - mu * mu;
-      if (var < 0.0) var = 0.0;
-      run_mean[ch] = momentum * run_mean[ch] + (1.f - momentum) * (float)mu;
-      run_var[ch] = momentum * run_var[ch] + (1.f - momentum) * (float)var;
-    }
-  }
-}
-
-// y = [relu](x * scale + shift [+ res]).  Threads own a fixed channel quad: its 8 constants are loaded once, the row loop is a
-// pure streaming fma with the next row's loads one iteration ahead.
+// y = [relu]((x - mean) * invstd * gamma + beta [+ res]).  Training (sums != null): mean/invstd come from the fp64
+// sums; block 0 also saves them for backward and updates the running statistics (Paddle convention: momentum 0.9 =>
+// running = 0.9*running + 0.1*batch, biased variance).  Threads own a fixed channel quad, so the per-channel constants
+// are computed once per thread and the row loop is a pure streaming fma.
 template <class T>
 __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ res, int ldres,
-                                                       T* __restrict__ y, int ldy, const float* __restrict__ scale_shift, long long M, int C,
-                                                       int relu, int rows_per_pass) {
+                                                       T* __restrict__ y, int ldy, const double* __restrict__ sums, double inv_count,
+                                                       float eps, float momentum, float* __restrict__ mean_out,
+                                                       float* __restrict__ invstd_out, float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long M, int C, int relu, int rows_per_pass) {
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
+  // A block only streams ~8 KB, so its time is latency: the first row's loads go out BEFORE the per-channel preamble
+  // (fp64 replica sums -> scale/shift -> LDS -> barrier) and every later row is fetched one iteration ahead.
   const long long rstep = (long long)gridDim.x * rows_per_pass;
   long long r = (long long)blockIdx.x * rows_per_pass + lane_row;
   float v[4], w[4];
@@ -222,9 +199,29 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
     Vec4<T>::load(x + r * ldx + c, v);
     if (res) Vec4<T>::load(res + r * ldres + c, w);
   }
+  // per-channel scale/shift computed cooperatively (one channel per thread) and shared through LDS
+  extern __shared__ float bn_lds[];          // [2][C]
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const BnChan k = bn_chan(sums, run_mean, run_var, C, ch, inv_count, eps);
+    const float scale = k.invstd * gamma[ch];
+    bn_lds[ch] = scale;
+    bn_lds[C + ch] = beta[ch] - k.mean * scale;
+    if (sums && blockIdx.x == 0) {
+      mean_out[ch] = k.mean;
+      invstd_out[ch] = k.invstd;
+      if (run_mean) {
+        const double mu = rep_sum(sums, C, ch) * inv_count;
+        double var = rep_sum(sums, C, C + ch) * inv_count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        run_mean[ch] = momentum * run_mean[ch] + (1.f - momentum) * (float)mu;
+        run_var[ch] = momentum * run_var[ch] + (1.f - momentum) * (float)var;
+      }
+    }
+  }
+  __syncthreads();
   float sc[4], sh[4];
-  Vec4<float>::load(scale_shift + c, sc);
-  Vec4<float>::load(scale_shift + C + c, sh);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e]; }
   while (r < M) {
     const long long rn = r + rstep;
     float vn[4], wn[4], o[4];
@@ -249,48 +246,20 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
-// BatchNorm backward, per-channel part, ONCE per layer: coef[2][C] = (sum dy' / count, sum dy' * xhat / count) from the fp64
-// replica sums (in whichever of the three forms the producer accumulated them, see emrt_bn_bwd_finalize), and the parameter
-// gradients dgamma += sum dy' * xhat, dbeta += sum dy' (from this rank's own sums under SyncBatchNorm).
-__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restrict__ sums, const double* __restrict__ lsums, double inv_count,
-                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta_y, int sums_vs_x,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int C) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= C) return;
-  auto second = [&](const double* sm, double t0) {      // sum dy' * xhat from the stored second statistic
-    double t1 = rep_sum(sm, C, C + ch);
-    if (beta_y) {      // (sum dy', sum dy' * y) from the consumer's dgrad epilogue: xhat = (y - beta) / gamma where y > 0
-      const double gm = (double)gamma[ch];
-      t1 = gm != 0.0 ? (t1 - (double)beta_y[ch] * t0) / gm : 0.0;
-    }
-    if (sums_vs_x) t1 = (t1 - (double)mean[ch] * t0) * (double)invstd[ch];      // (sum dy', sum dy' * x): xhat = (x - mean) * invstd
-    return t1;
-  };
-  const double t0 = rep_sum(sums, C, ch);
-  const double t1 = second(sums, t0);
-  coef[ch] = (float)(t0 * inv_count);
-  coef[C + ch] = (float)(t1 * inv_count);
-  if (lsums) {
-    const double l0 = rep_sum(lsums, C, ch);
-    if (dbeta) dbeta[ch] += (float)l0;
-    if (dgamma) dgamma[ch] += (float)second(lsums, l0);
-  } else {
-    if (dbeta) dbeta[ch] += (float)t0;
-    if (dgamma) dgamma[ch] += (float)t1;
-  }
-}
-
+// dx = gamma*invstd*(dy' - sum_dy/count - xhat*sum_dyxhat/count); optional dres = dy' (gradient of the fused residual);
+// block 0 accumulates dgamma += sum dy'*xhat, dbeta += sum dy' (from this rank's `lsums` when given: SyncBN).
 template <class T>
 __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                         const T* __restrict__ y, int ldy, T* __restrict__ dx, int lddx,
                                                         T* __restrict__ dres, int lddres, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ coef, long long M, int C, int rows_per_pass) {
+                                                        const double* __restrict__ sums, const double* __restrict__ lsums,
+                                                        double inv_count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        long long M, int C, int rows_per_pass, const float* __restrict__ beta_y, int sums_vs_x) {
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
-  // first row fetched before the per-channel constants, later rows one iteration ahead
+  // as in bn_apply_kernel: first row fetched before the preamble, later rows one iteration ahead
   const long long rstep = (long long)gridDim.x * rows_per_pass;
   long long r = (long long)blockIdx.x * rows_per_pass + lane_row;
   float v[4], g[4], yy[4];
@@ -299,14 +268,32 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     Vec4<T>::load(dy + r * lddy + c, g);
     if (y) Vec4<T>::load(y + r * ldy + c, yy);
   }
+  extern __shared__ float bn_lds[];          // [2][C]: sum_dy/count, sum_dyxhat/count
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const double t0 = rep_sum(sums, C, ch);
+    double t1 = rep_sum(sums, C, C + ch);
+    if (beta_y) {      // the sums are (sum dy', sum dy' * y) from the consumer's dgrad epilogue: xhat = (y - beta) / gamma where y > 0
+      const double gm = (double)gamma[ch];
+      t1 = gm != 0.0 ? (t1 - (double)beta_y[ch] * t0) / gm : 0.0;
+    }
+    if (sums_vs_x) t1 = (t1 - (double)mean[ch] * t0) * (double)invstd[ch];      // (sum dy', sum dy' * x): xhat = (x - mean) * invstd
+    bn_lds[ch] = (float)(t0 * inv_count);
+    bn_lds[C + ch] = (float)(t1 * inv_count);
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[ch] += (float)(lsums ? rep_sum(lsums, C, ch) : t0);
+      if (dgamma) dgamma[ch] += (float)(lsums ? rep_sum(lsums, C, C + ch) : t1);
+    }
+  }
+  __syncthreads();
   float mu[4], is[4], k0[4], k1[4], gi[4];
-  Vec4<float>::load(mean + c, mu);
-  Vec4<float>::load(invstd + c, is);
-  Vec4<float>::load(gamma + c, gi);
-  Vec4<float>::load(coef + c, k0);
-  Vec4<float>::load(coef + C + c, k1);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) gi[e] *= is[e];
+  for (int e = 0; e < 4; ++e) {
+    mu[e] = mean[c + e];
+    is[e] = invstd[c + e];
+    gi[e] = gamma[c + e] * is[e];
+    k0[e] = bn_lds[c + e];
+    k1[e] = bn_lds[C + c + e];
+  }
   while (r < M) {
     const long long rn = r + rstep;
     float vn[4], gn[4], yn[4], o[4];
@@ -1041,33 +1028,23 @@ extern "C" int emrt_bn_stats(const void* x, int ldx, long long M, int C, double*
   return check_launch("emrt_bn_stats");
 }
 
-// Per-channel constants of one BatchNorm layer (one tiny launch per layer and step): scale_shift[2C] for emrt_bn_apply.
-// sums != null: training -- statistics = sums / count (count may be the global row count after a cross-rank all-reduce of
-// sums for SyncBatchNorm); mean/invstd are saved and run_* updated.  sums == null: eval -- run_* are used.
-extern "C" int emrt_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean,
-                                float* run_var, const float* gamma, const float* beta, float* scale_shift, int C, void* stream) {
-  EMRT_REQUIRE(gamma && beta && scale_shift && C > 0, "null pointer");
-  EMRT_REQUIRE(sums ? (mean && invstd) : (run_mean && run_var), "training needs mean/invstd outputs, eval needs running statistics");
-  const double inv_count = sums ? 1.0 / count : 0.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, inv_count, eps, momentum, mean, invstd,
-                     run_mean, run_var, gamma, beta, scale_shift, C);
-  return check_launch("emrt_bn_finalize");
-}
-
-// y = [relu](x * scale + shift [+ res]) with scale_shift[2C] from emrt_bn_finalize
-extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const float* scale_shift, long long M, int C,
-                             int relu, int dtype, void* stream) {
+// y = [relu](BN(x) [+ res]).  sums != null: training -- statistics = sums / count (count may be the global row count after a
+// cross-rank all-reduce of sums for SyncBatchNorm); mean/invstd are saved and run_* updated.  sums == null: eval -- run_* are used.
+extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count,
+                             float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+                             const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
-  EMRT_REQUIRE(x && y && scale_shift, "null pointer");
+  EMRT_REQUIRE(x && y && gamma && beta, "null pointer");
+  EMRT_REQUIRE(sums ? (mean && invstd) : (run_mean && run_var), "training needs mean/invstd outputs, eval needs running statistics");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0), "C and ld must be multiples of 4");
-  EMRT_REQUIRE((((uintptr_t)scale_shift) & 15) == 0, "scale_shift must be 16-byte aligned");
   int threads, rpp, grid;
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
+  const double inv_count = sums ? 1.0 / count : 0.0;
   DT_SWITCH3(dtype,
-             hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), 0, st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, scale_shift, M, C, relu, rpp),
-             hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, scale_shift, M, C, relu, rpp),
-             hipLaunchKernelGGL((bn_apply_kernel<f16_t>), dim3(grid), dim3(threads), 0, st, (const f16_t*)x, ldx, (const f16_t*)res, ldres, (f16_t*)y, ldy, scale_shift, M, C, relu, rpp));
+            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
+            hipLaunchKernelGGL((bn_apply_kernel<f16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const f16_t*)x, ldx, (const f16_t*)res, ldres, (f16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
   return check_launch("emrt_bn_apply");
 }
 
@@ -1086,35 +1063,24 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
   return check_launch("emrt_bn_bwd_reduce");
 }
 
-// BN backward step 2a, per channel (one tiny launch): coef[2C] for emrt_bn_bwd_dx; dgamma += , dbeta += from `local_sums`
-// when given (SyncBN: the dx formula uses the rank-summed `sums` with the global count, the parameter gradients use this
-// rank's sums) else from `sums`.
+// BN backward step 2: dx (and optional dres = masked dy); dgamma += , dbeta += from `local_sums` when given (SyncBN: the
+// dx formula uses the rank-summed `sums` with the global count, the parameter gradients use this rank's sums) else from `sums`.
 // beta_y_moments != null: `sums` hold (sum dy', sum dy' * y) as accumulated by emrt_conv2d(mask_y = y) -- the dgrad of the
 // conv that consumes y = relu(BN(x)) -- and are converted with xhat = (y - beta) / gamma; emrt_bn_bwd_reduce is then not needed.
 // sums_vs_x != 0: they hold (sum dy', sum dy' * x) (emrt_conv2d_bwd with stat_x = x: the relu(BN(x) + residual) joins).
-extern "C" int emrt_bn_bwd_finalize(const double* sums, const double* local_sums, double count, const float* mean, const float* invstd,
-                                    const float* gamma, const float* beta_y_moments, int sums_vs_x, float* dgamma, float* dbeta, float* coef,
-                                    int C, void* stream) {
-  EMRT_REQUIRE(sums && mean && invstd && gamma && coef && C > 0, "null pointer");
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, local_sums, 1.0 / count, mean, invstd, gamma,
-                     beta_y_moments, sums_vs_x, dgamma, dbeta, coef, C);
-  return check_launch("emrt_bn_bwd_finalize");
-}
-
-// BN backward step 2b: dx = gamma * invstd * (dy' - coef0 - xhat * coef1) (and optional dres = masked dy)
 extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
                               void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
-                              const float* coef, long long M, int C, int dtype, void* stream) {
+                              const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M,
+                              int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
-  EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && coef, "null pointer");
+  EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
-  EMRT_REQUIRE(((((uintptr_t)mean) | ((uintptr_t)invstd) | ((uintptr_t)gamma) | ((uintptr_t)coef)) & 15) == 0, "per-channel vectors must be 16-byte aligned");
   int threads, rpp, grid;
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, coef, M, C, rpp),
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, coef, M, C, rpp));
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x));
   return check_launch("emrt_bn_bwd_dx");
 }
 

@@ -442,8 +442,6 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
         assert r_bs == H * W * ldres
     count = M
     mean = invstd = None
-    # per-channel constants once per layer (emrt_bn_finalize), then the streaming apply
-    ss = c.empty((2 * C,), torch.float32)
     if c.training:
         mean = c.empty((C,), torch.float32)
         invstd = c.empty((C,), torch.float32)
@@ -452,12 +450,11 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
             _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), c.dtype, c.stream)
         if _sync_active(bn):
             count = _allreduce_sums(sums, M)
-        _L().call("emrt_bn_finalize", P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd), P(bn.run_mean), P(bn.run_var), P(bn.gamma),
-                  P(bn.beta), P(ss), C, c.stream)
+        _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd),
+                  P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     else:
-        _L().call("emrt_bn_finalize", None, 1.0, bn.eps, bn.momentum, None, None, P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), P(ss), C,
-                  c.stream)
-    _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(ss), M, C, int(relu), c.dtype, c.stream)
+        _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, None, 1.0, bn.eps, bn.momentum, None, None,
+                  P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     tape = c.tape
     rec = None
     if tape is not None and c.training and relu and out.dim() == 4:
@@ -496,12 +493,9 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
                 _allreduce_sums(sums2, M)
             dx = c.empty(tuple(x.shape))
             dres = c.empty(tuple(x.shape)) if (residual is not None and relu and not fused) else None
-            coef = c.empty((2 * C,), torch.float32)
-            _L().call("emrt_bn_bwd_finalize", P(sums2), P(local), float(count), P(mean), P(invstd), P(bn.gamma),
-                      P(bn.beta) if (fused and residual is None) else None, int(fused and residual is not None), P(bn.dgamma), P(bn.dbeta), P(coef),
-                      C, c.stream)
-            _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma), P(coef), M, C,
-                      c.dtype, c.stream)
+            _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
+                      P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C,
+                      P(bn.beta) if (fused and residual is None) else None, int(fused and residual is not None), c.dtype, c.stream)
             tape.add_grad(x, dx, owned=True)
             if residual is not None:
                 tape.add_grad(residual, dres if dres is not None else dy, owned=dres is not None)

@@ -85,14 +85,9 @@ int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, voi
  * zeroed by the caller before the producing kernel runs. */
 size_t emrt_colreduce_workspace_bytes(long long M, int C);
 int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream);
-/* per-channel constants, once per layer: scale_shift fp32 [2C] (y = x * scale + shift); training (sums != NULL) also saves
- * mean / invstd and updates the running statistics, eval (sums == NULL) derives them from the running statistics */
-int emrt_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, float* scale_shift, int C, void* stream);
-int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const float* scale_shift, long long M, int C, int relu, int dtype, void* stream);
+int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
 int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, int dtype, void* stream);
-/* backward, per channel, once per layer: coef fp32 [2C] = (sum dy' / count, sum dy' xhat / count); dgamma += , dbeta += */
-int emrt_bn_bwd_finalize(const double* sums, const double* local_sums, double count, const float* mean, const float* invstd, const float* gamma, const float* beta_y_moments, int sums_vs_x, float* dgamma, float* dbeta, float* coef, int C, void* stream);
-int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const float* coef, long long M, int C, int dtype, void* stream);
+int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
 

@@ -67,7 +67,6 @@ def test_train_step_launch_sequence(fake, backbone):
     assert cnt["emrt_conv2d_wgrad"] <= 4                               # alone only where no data gradient is needed (image-fed convs)
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
     assert cnt["emrt_bn_apply"] == cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
-    assert cnt["emrt_bn_finalize"] == cnt["emrt_bn_bwd_finalize"] == n_bn     # per-channel constants: one tiny launch per layer each way
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
     assert not any(n == "emrt_conv2d" and a[22] == 1 for n, a in fake.calls)      # data gradients go through emrt_conv2d_bwd
     dgrads = [a for n, a in fake.calls if n == "emrt_conv2d_bwd"]
@@ -84,19 +83,17 @@ def test_train_step_launch_sequence(fake, backbone):
     assert cnt["emrt_mask_bwd"] == cnt["emrt_dropout_fwd"] - n_ffn
     # residual joins relu(BatchNorm(x) + residual): the dgrad of a conv that consumes the join folds the earlier
     # contributions in (addend a[32], or in place a[6]), masks with the join's output and sums against the BatchNorm INPUT
-    # (stat_x a[29]); the join's backward then runs without its reduction pass (sums_vs_x a[7] of emrt_bn_bwd_finalize)
+    # (stat_x a[29]); the join's backward then runs without its reduction pass (sums_vs_x a[21] of emrt_bn_bwd_dx)
     joins = [a for a in dgrads if a[29] is not None]
     assert joins and all(a[24] is not None and a[25] is not None and a[25].value == a[0].value for a in joins)
     assert any(a[32] is not None for a in joins) and all(not (a[6] and a[32] is not None) for a in dgrads)
     assert all(a[29] is None for a in dgrads if a[25] is None)
-    bn_bwd = [(fake.calls[i][1], fake.calls[i + 1][1]) for i in range(len(fake.calls) - 1) if fake.calls[i][0] == "emrt_bn_bwd_finalize"]
-    assert all(fake.calls[i + 1][0] == "emrt_bn_bwd_dx" for i in range(len(fake.calls) - 1) if fake.calls[i][0] == "emrt_bn_bwd_finalize")
-    fused_y = sum(1 for f, d in bn_bwd if f[6] is not None)
-    fused_x = sum(1 for f, d in bn_bwd if f[7] == 1)
-    assert not any(f[6] is not None and f[7] == 1 for f, d in bn_bwd)
-    assert all(d[4] is None for f, d in bn_bwd if (f[6] is not None or f[7] == 1))     # fused: dy arrives masked
+    fused_y = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[20] is not None)
+    fused_x = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[21] == 1)
+    assert not any(a[20] is not None and a[21] == 1 for n, a in fake.calls if n == "emrt_bn_bwd_dx")
+    assert all(a[4] is None for n, a in fake.calls if n == "emrt_bn_bwd_dx" and (a[20] is not None or a[21] == 1))     # fused: dy arrives masked
     assert fused_y + fused_x + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_y + fused_x <= n_fused
-    n_join_bn = sum(1 for n, a in fake.calls if n == "emrt_bn_apply" and a[2] is not None and a[9] == 1)
+    n_join_bn = sum(1 for n, a in fake.calls if n == "emrt_bn_apply" and a[2] is not None and a[18] == 1)
     assert 0 < fused_x <= n_join_bn and fused_x >= n_join_bn - 4, (fused_x, n_join_bn)     # every join inside the backbone stages
     assert fused_y >= n_bn // 3, (fused_y, n_bn)
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
