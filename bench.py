@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- training tiles/sec of the EMRT hot path on MI355X (BASELINE.json metric).
+"""bench.py -- tiles/sec of the EMRT hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py [--gpus 1] [--steps 50] [--warmup 10]                     # BASELINE configs[1]: the headline line
+    python bench.py --config cfg3                                             # configs[2]: LoveDA 512x512, 7 classes, batch 4
+    python bench.py --config cfg5                                             # configs[4]: 1024x1024 sliding-window inference, fp16
+    python bench.py --dtype fp32                                              # cfg2 in the reference's own precision
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One step = forward + CE/aux-CE loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm clip + SGD-momentum
-+ weight re-pack, on a synthetic batch of 8 normalised 256x256x3 tiles per GPU that is already resident in HBM
-(workload = BASELINE.json configs[1]: EMRT ResNet-50, Potsdam 256x256, 6 classes, batch 8, bf16 storage / fp32
-accumulate).  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline       -- the dominant kernel of the step (the MFMA implicit-GEMM convolution), algorithmic FLOPs / HIP-event time
-  roofline_msda  -- the deformable-attention gather kernel against the HBM roofline (BASELINE north_star's 85 % target)
+Training configs: one step = forward + CE/aux-CE loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm clip +
+SGD-momentum + weight re-pack on a synthetic batch that is already resident in HBM.  cfg5: one step = one 1024x1024 image =
+16 windows of 256x256 evaluated as ONE batch through the fp16 model + the window glue kernels, replayed from a hipGraph.
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline       -- the dominant kernel family of the step (MFMA implicit-GEMM convolutions), algorithmic FLOPs / HIP-event time
+  roofline_msda  -- the deformable-attention gather kernel (encoder call of THIS config) against the HBM roofline
   cpu_baseline   -- the oracle (torch-CPU fp32 restatement of the reference) timed on the host cores, rank 0, N = 1 only
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -24,10 +28,22 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-FLOP_PER_TILE_FWD_BWD = 235.0e9   # 78.34 GFLOP forward, x3 for forward + backward, 256x256, 6 classes
-PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PEAK_F32_MFMA_TFLOPS = 157.3
+# forward GFLOP per tile; training = 3x (forward + backward)
+CONFIGS = {
+    "cfg2": dict(batch=8, size=256, ncls=6, mode="train", dtype="bf16", fwd_gflop=78.34,
+                 name="EMRT ResNet50, Potsdam 256x256, 6 classes, batch 8 per GPU, fwd+bwd+SGD step (BASELINE configs[1])"),
+    "cfg3": dict(batch=4, size=512, ncls=7, mode="train", dtype="bf16", fwd_gflop=312.0,
+                 name="EMRT ResNet50, LoveDA 512x512, 7 classes, batch 4 per GPU, fwd+bwd+SGD step (BASELINE configs[2])"),
+    "cfg5": dict(batch=16, size=256, ncls=6, mode="infer", dtype="fp16", fwd_gflop=78.34 - 1.21, image=1024,
+                 name="EMRT ResNet50, 1024x1024 image, sliding window crop 256 stride 256 = 16 windows as one batch, eval (BASELINE configs[4])"),
+}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
+GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: per-level encoder convs)",
+                 "emrt_conv2d_bwd_group": "bwd_group_kernel (emrt_conv2d_bwd_group)",
+                 "emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
+                 "emrt_conv2d_bwd": "igemm_kernel + wgrad_kernel (emrt_conv2d_bwd: data + weight gradients, paired launch for small layers)",
+                 "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)"}
 
 
 def log(*a):
@@ -64,14 +80,128 @@ def msda_bytes(a, esz):
     return B * (Lv * M * D * esz + Lq * tp * 2 * 4 + Lq * tp * 4 + Lq * M * D * esz) + Lq * 2 * 4
 
 
+def vals_of(a):
+    return [x.value if hasattr(x, "value") else x for x in a]
+
+
+def family_table(calls):
+    fam = {}
+    for name, a, ms in calls:
+        f = fam.setdefault(name, [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += ms
+        if name in GEMM_FAMILIES:
+            f[2] += conv_flops(name, vals_of(a))
+    return fam
+
+
+def dump_calls(path, calls):
+    with open(path, "w") as f:
+        for name, a, ms in calls:
+            vals = vals_of(a)
+            if name == "emrt_conv2d":
+                extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
+            elif name == "emrt_conv2d_bwd":
+                extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
+            elif name == "emrt_conv2d_wgrad":
+                extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
+            elif name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group"):
+                extra = "n=%d " % vals[1] + " ".join("%dx%dx%d->%d k%d" % (d.H, d.W, d.C, d.OC, d.KH) for d in list(vals[0])[:vals[1]]) + " gflop %.2f" % (conv_flops(name, vals) / 1e9)
+            else:       # integer arguments only: enough to recognise the layer
+                extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))
+            f.write("%-26s %9.4f ms  %s\n" % (name, ms, extra))
+
+
+def rooflines(calls, dtype_name, cfg_key, train):
+    """-> (roofline of the dominant GEMM family, roofline of the MSDA encoder call, per-family log lines)."""
+    fam = family_table(calls)
+    total_ms = sum(v[1] for v in fam.values())
+    lines = ["[bench] per-launch HIP-event time of one replayed %s: %.2f ms over %d launches" % ("step" if train else "image", total_ms, len(calls))]
+    for name, (cnt, ms, fl) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:12]:
+        lines.append("    %-28s %5d calls %9.3f ms %5.1f%%%s" % (name, cnt, ms, 100 * ms / total_ms, "  %.1f TFLOP/s" % (fl / ms / 1e9) if fl else ""))
+    peak = PEAK_TFLOPS[dtype_name]
+    dom = max(GEMM_FAMILIES, key=lambda k: fam.get(k, [0, 0.0, 0.0])[1])
+    cnt, ms, fl = fam[dom]
+    ach = fl / ms / 1e9
+    all_ms = sum(fam.get(k, [0, 0.0, 0.0])[1] for k in GEMM_FAMILIES)
+    all_fl = sum(fam.get(k, [0, 0.0, 0.0])[2] for k in GEMM_FAMILIES)
+    # what a HIP-event pair costs around a launch that does nothing: the per-launch figures above all contain it
+    trivial = [ms for name, a, ms in calls if name in ("emrt_counter_add", "emrt_scalar_axpby")]
+    roofline = {"kernel": GEMM_FAMILIES[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
+                "algorithmic_gflop_per_step": round(fl / 1e9, 1), "share_of_step_kernel_time": round(ms / total_ms, 3),
+                "all_gemm_tflops": round(all_fl / all_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_ms / total_ms, 3),
+                "event_timed_trivial_launch_us": round(1e3 * min(trivial), 2) if trivial else None,
+                "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch "
+                          "(event_timed_trivial_launch_us = what the same pair reads around a one-thread kernel: included in every figure)"}
+    pmc = None
+    for tag in ("r2", "r1k"):
+        src = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, "" if cfg_key == "cfg2" else "_" + cfg_key))
+        if os.path.exists(src) and (cfg_key != "cfg2" or dtype_name == "bf16"):
+            with open(src) as f:
+                pmc = json.load(f)
+            pmc_src = os.path.relpath(src, ROOT)
+            break
+    if pmc is not None:
+        key = {"emrt_conv2d": "igemm_kernel", "emrt_conv2d_bwd": "bwd_pair_kernel", "emrt_conv2d_wgrad": "wgrad_kernel"}.get(dom, "igemm_kernel")
+        if key not in pmc:
+            key = "igemm_kernel"
+        if key in pmc:
+            roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
+            roofline["traffic_kernel"] = key
+            roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, average over the step's launches)"
+            roofline["traffic_source"] = pmc_src + ": " + pmc.get("method", "")
+    esz = 4 if dtype_name == "fp32" else 2
+    enc = [(vals_of(a), ms) for name, a, ms in calls if name == "emrt_msda_fwd"]
+    enc = [(v, ms) for v, ms in enc if v[10] == v[11]]     # Lq == Lv: encoder self-attention calls
+    roofline_msda = None
+    if enc:
+        v = enc[0][0]
+        by = msda_bytes(v, esz)
+        avg_ms = sum(ms for _, ms in enc) / len(enc)
+        ideal_us = by / PEAK_HBM_GBPS / 1e3
+        roofline_msda = {"kernel": "msda_fwd_lds_kernel / msda_fwd_kernel (encoder call, B=%d Lq=Lv=%d, %s)" % (v[9], v[10], dtype_name), "bound": "hbm",
+                         "achieved": round(by / avg_ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(by / avg_ms / 1e6 / PEAK_HBM_GBPS, 4), "traffic": None,
+                         "algorithmic_mbytes_per_launch": round(by / 1e6, 2), "avg_launch_us": round(1e3 * avg_ms, 2),
+                         "ideal_us_at_peak": round(ideal_us, 2),
+                         "note": "a launch that moves nothing already reads event_timed_trivial_launch_us (roofline) on this clock: at %.1f MB the HBM "
+                                 "time is %.1f us, so frac is bounded well below 1 by the launch itself; see DESIGN.md 5 for the per-shape table" % (by / 1e6, ideal_us)}
+        if pmc is not None and "msda_fwd_kernel_encoder" in pmc:
+            m = pmc["msda_fwd_kernel_encoder"]
+            roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)
+            roofline_msda["traffic_unit"] = ("bytes per launch, FETCH_SIZE + WRITE_SIZE as counted; the gfx950 x2 read correction "
+                                             "(valid for 16-B/lane streams) gives the upper bound %d" % int(m["traffic_mb_corrected"] * 1e6))
+            roofline_msda["traffic_source"] = pmc_src
+    return roofline, roofline_msda, lines
+
+
+def timed_replay(record_fn, world=1):
+    """Record the C-ABI launches of record_fn(), replay them behind a backlog with a HIP-event pair around each."""
+    from emrt_amd import _lib
+    from emrt_amd.runtime import ctx
+    L = _lib.lib()
+    c = ctx()
+    c.keepalive = []                       # nothing allocated during the recorded step is freed until the replay is done
+    L.start_record()
+    record_fn()
+    rec = L.stop_record()
+    torch.cuda.synchronize()
+    L.replay(rec)                          # backlog: the host gets ~20 ms ahead of the GPU
+    calls = L.replay(rec, timed=True)      # HIP events on the launch stream around every launch
+    c.keepalive = None
+    return calls
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=8, help="tiles per GPU (BASELINE config: 8)")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json config: cfg2 = configs[1] (headline), cfg3 = configs[2], cfg5 = configs[4]")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (default: the config's)")
+    ap.add_argument("--size", type=int, default=0)
+    ap.add_argument("--dtype", default="", choices=["", "bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -80,11 +210,20 @@ def main():
     ap.add_argument("--no-early-exchange", action="store_true", help="N>1: one all-reduce after the whole backward (A/B experiment)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    if args.size:
+        cfg["size"] = args.size
+    dtype_name = args.dtype or cfg["dtype"]
+    if cfg["mode"] == "infer":
+        return main_infer(args, cfg, dtype_name)
+    if dtype_name == "fp16":
+        raise SystemExit("fp16 is inference-only (include/emrt_hip.h); training configs run in bf16 or fp32")
 
-    from emrt_amd import _lib
     from emrt_amd.distributed import init_process_group
     from emrt_amd.engine import TrainEngine
-    from emrt_amd.runtime import BF16, F32, ctx
+    from emrt_amd.runtime import BF16, F32
     from emrt_amd.src.models.emrt import EMRT
     from emrt_amd.src.models.losses import MixSoftmaxCrossEntropyLoss
     from emrt_amd.src.models.solver import Momentum, PolynomialDecay
@@ -92,12 +231,13 @@ def main():
     rank, local_rank, world = init_process_group()
     if world != args.gpus:
         log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
-    dtype = BF16 if args.dtype == "bf16" else F32
+    dtype = BF16 if dtype_name == "bf16" else F32
     if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
         local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(1234)
-    model = EMRT(num_classes=6, backbone="resnet50")
+    B, S, ncls = cfg["batch"], cfg["size"], cfg["ncls"]
+    model = EMRT(num_classes=ncls, backbone="resnet50")
     model.to_hip(str(dev), dtype, seed=1234 + rank)
     opt = Momentum(model, PolynomialDecay(0.01, 160000, 0.0, 0.9), momentum=0.9, weight_decay=1e-4, grad_clip=1.0)
     loss_fn = MixSoftmaxCrossEntropyLoss(ignore_index=255, aux=True, aux_weight=0.4)
@@ -108,9 +248,8 @@ def main():
     eng = TrainEngine(model, opt, loss_fn, world, use_graph=not args.no_graph, overlap=args.overlap or False,
                       two_phase=True if args.two_phase else None, early_exchange=not args.no_early_exchange)
     g = torch.Generator().manual_seed(1234 + rank)
-    B, S = args.batch, args.size
     images = torch.randn(B, 3, S, S, generator=g).to(dev)
-    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    labels = torch.randint(0, ncls, (B, S, S), generator=g)
     labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
     labels = labels.to(dev)
 
@@ -142,102 +281,25 @@ def main():
     result = None
     if rank == 0:
         # ---- live per-kernel timing: one extra eager step with a HIP event pair around every C-ABI launch --------------
-        L = _lib.lib()
         eng_prof = TrainEngine(model, opt, loss_fn, 1, use_graph=False, overlap=False)   # serialised: per-kernel durations
         eng_prof.reducer = None
-        c = ctx()
-        c.keepalive = []                       # nothing allocated during the recorded step is freed until the replay is done
-        L.start_record()
-        eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels)
-        rec = L.stop_record()
-        torch.cuda.synchronize()
-        L.replay(rec)                          # backlog: the host gets ~20 ms ahead of the GPU
-        calls = L.replay(rec, timed=True)      # HIP events on the launch stream around every launch
-        c.keepalive = None
+        calls = timed_replay(lambda: eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels))
         if args.dump_calls:
-            with open(args.dump_calls, "w") as f:
-                for name, a, ms in calls:
-                    vals = [x.value if hasattr(x, "value") else x for x in a]
-                    extra = ""
-                    if name == "emrt_conv2d":
-                        extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
-                    elif name == "emrt_conv2d_bwd":
-                        extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
-                    elif name == "emrt_conv2d_wgrad":
-                        extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
-                    elif name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group"):
-                        extra = "n=%d " % vals[1] + " ".join("%dx%dx%d->%d k%d" % (d.H, d.W, d.C, d.OC, d.KH) for d in list(vals[0])[:vals[1]]) + " gflop %.2f" % (conv_flops(name, vals) / 1e9)
-                    else:       # integer arguments only: enough to recognise the layer
-                        extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))
-                    f.write("%-26s %9.4f ms  %s\n" % (name, ms, extra))
-        fam = {}
-        for name, a, ms in calls:
-            f = fam.setdefault(name, [0, 0.0, 0.0])
-            f[0] += 1
-            f[1] += ms
-            if name in ("emrt_conv2d", "emrt_conv2d_wgrad", "emrt_conv2d_bwd", "emrt_conv2d_group", "emrt_conv2d_bwd_group"):
-                f[2] += conv_flops(name, [x.value if hasattr(x, "value") else x for x in a])
-        total_ms = sum(v[1] for v in fam.values())
-        top = sorted(fam.items(), key=lambda kv: -kv[1][1])
-        log("[bench] per-launch HIP-event time of one replayed step: %.2f ms over %d launches" % (total_ms, len(calls)))
-        for name, (cnt, ms, fl) in top[:12]:
-            log("    %-28s %5d calls %9.3f ms %5.1f%%%s" % (name, cnt, ms, 100 * ms / total_ms, "  %.1f TFLOP/s" % (fl / ms / 1e9) if fl else ""))
-        peak = PEAK_BF16_TFLOPS if dtype == BF16 else PEAK_F32_MFMA_TFLOPS
-        gemm_fams = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: per-level encoder convs)",
-                     "emrt_conv2d_bwd_group": "bwd_group_kernel (emrt_conv2d_bwd_group)",
-                     "emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
-                     "emrt_conv2d_bwd": "igemm_kernel + wgrad_kernel (emrt_conv2d_bwd: data + weight gradients, paired launch for small layers)",
-                     "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)"}
-        dom_name = max(gemm_fams, key=lambda k: fam.get(k, [0, 0.0, 0.0])[1])
-        cnt, ms, fl = fam[dom_name]
-        ach = fl / ms / 1e9
-        all_ms = sum(fam.get(k, [0, 0.0, 0.0])[1] for k in gemm_fams)
-        all_fl = sum(fam.get(k, [0, 0.0, 0.0])[2] for k in gemm_fams)
-        roofline = {"kernel": gemm_fams[dom_name], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
-                    "algorithmic_gflop_per_step": round(fl / 1e9, 1), "share_of_step_kernel_time": round(ms / total_ms, 3),
-                    "all_gemm_tflops": round(all_fl / all_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_ms / total_ms, 3),
-                    "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch"}
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot profile itself); bf16 B=8 256^2 only
-        pmc, pmc_src = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1k_pmc_traffic.json")
-        if os.path.exists(pmc_src) and dtype == BF16 and B == 8 and S == 256:
-            with open(pmc_src) as f:
-                pmc = json.load(f)
-            key = {"emrt_conv2d": "igemm_kernel", "emrt_conv2d_bwd": "bwd_pair_kernel", "emrt_conv2d_wgrad": "wgrad_kernel"}.get(dom_name, "igemm_kernel")
-            if key not in pmc:
-                key = "igemm_kernel"
-            roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
-            roofline["traffic_kernel"] = key
-            roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, average over the step's launches)"
-            roofline["traffic_source"] = "profiles/r1k_pmc_traffic.json: " + pmc["method"]
-        esz = 2 if dtype == BF16 else 4
-        enc = [(a, ms) for name, a, ms in calls if name == "emrt_msda_fwd" and (a[9].value if hasattr(a[9], "value") else a[9]) > 0]
-        enc = [(a, ms) for a, ms in enc if a[10] == a[11]]     # Lq == Lv: encoder self-attention calls
-        roofline_msda = None
-        if enc:
-            vals = [x.value if hasattr(x, "value") else x for x in enc[0][0]]
-            by = msda_bytes(vals, esz)
-            avg_ms = sum(ms for _, ms in enc) / len(enc)
-            roofline_msda = {"kernel": "msda_fwd_kernel (encoder call, B=%d Lq=Lv=%d)" % (vals[9], vals[10]), "bound": "hbm",
-                             "achieved": round(by / avg_ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                             "frac": round(by / avg_ms / 1e6 / PEAK_HBM_GBPS, 4), "traffic": None,
-                             "algorithmic_mbytes_per_launch": round(by / 1e6, 2), "avg_launch_us": round(1e3 * avg_ms, 2)}
-            if pmc is not None:
-                m = pmc["msda_fwd_kernel_encoder"]
-                roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)
-                roofline_msda["traffic_unit"] = ("bytes per launch, FETCH_SIZE + WRITE_SIZE as counted; the gfx950 x2 read correction "
-                                                 "(valid for 16-B/lane streams) gives the upper bound %d" % int(m["traffic_mb_corrected"] * 1e6))
-                roofline_msda["traffic_source"] = "profiles/r1k_pmc_traffic.json"
+            dump_calls(args.dump_calls, calls)
+        roofline, roofline_msda, lines = rooflines(calls, dtype_name, args.config if (B, S) == (CONFIGS[args.config]["batch"], CONFIGS[args.config]["size"]) else "custom", True)
+        for ln in lines:
+            log(ln)
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = run_cpu_baseline(B, S, args.cpu_threads)
+            cpu_baseline = run_cpu_baseline_train(B, S, ncls, args.cpu_threads, timed_steps=3 if args.config == "cfg2" else 2)
+        flop_tile = 3.0 * cfg["fwd_gflop"] * 1e9 * (S * S) / (CONFIGS[args.config]["size"] ** 2)
         result = {
-            "metric": "training tiles/sec at 256x256", "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world,
+            "metric": "training tiles/sec at %dx%d" % (S, S), "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "EMRT ResNet50, Potsdam 256x256, 6 classes, batch %d per GPU %s, fwd+bwd+SGD step (BASELINE configs[1])" % (B, args.dtype),
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": cfg["name"].replace("batch %d" % CONFIGS[args.config]["batch"], "batch %d" % B) + ", " + dtype_name,
                        "global_batch": world * B, "tile": [S, S, 3], "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
-            "end_to_end_tflops": round(tiles_per_s * FLOP_PER_TILE_FWD_BWD / 1e12, 2), "final_loss": round(loss_val, 4),
+            "end_to_end_tflops": round(tiles_per_s * flop_tile / 1e12, 2), "final_loss": round(loss_val, 4),
             "roofline": roofline, "roofline_msda": roofline_msda, "cpu_baseline": cpu_baseline,
         }
     if world > 1:
@@ -248,26 +310,125 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def run_cpu_baseline(B, S, threads):
-    """The oracle's train step (fwd + loss + bwd + clip + SGD-momentum) on the host cores: 1 warm-up + 2 timed steps."""
+def main_infer(args, cfg, dtype_name):
+    """cfg5: sliding-window inference of 1024x1024 images (replicas only: --gpus N runs N independent replicas, no collective)."""
+    from emrt_amd.distributed import init_process_group
+    from emrt_amd.runtime import BF16, F16, F32
+    from emrt_amd.src.api.infer import SlidingWindowEngine, slide_inference
+    from emrt_amd.src.models.emrt import EMRT
+
+    rank, local_rank, world = init_process_group()
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(1234)
+    ncls, crop, img_size = cfg["ncls"], cfg["size"], cfg["image"]
+    model = EMRT(num_classes=ncls, backbone="resnet50")
+    model.to_hip(str(dev), {"bf16": BF16, "fp16": F16, "fp32": F32}[dtype_name], seed=1234 + rank)
+    model.eval()
+    model.compute_aux_in_eval = False        # every inference caller discards the auxiliary logits (infer.py:66)
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(3, img_size, img_size, generator=g).to(dev)
+    # BatchNorm running statistics from one pass in train-mode arithmetic would need fp16 backward entry points; the
+    # throughput does not depend on their values: they stay at their initial (0, 1)
+    eng = SlidingWindowEngine(model, (3, img_size, img_size), (crop, crop), (crop, crop), ncls, warmup=0 if args.no_graph else 1)
+    if args.no_graph:
+        eng.warmup = 1 << 30
+    nwin = (img_size // crop) ** 2
+    for _ in range(3):
+        eng(img)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        eng(img)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred = eng(img)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tiles_per_s = world * nwin * args.steps / elapsed
+    result = None
+    if rank == 0:
+        assert tuple(pred.shape) == (1, 1, img_size, img_size) and pred.dtype == torch.int32
+        calls = timed_replay(lambda: slide_inference(model, [img], (crop, crop), (crop, crop), ncls))
+        if args.dump_calls:
+            dump_calls(args.dump_calls, calls)
+        roofline, roofline_msda, lines = rooflines(calls, dtype_name, args.config, False)
+        for ln in lines:
+            log(ln)
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_baseline = run_cpu_baseline_infer(ncls, crop, nwin, args.cpu_threads)
+        result = {
+            "metric": "inference tiles/sec at %dx%d (sliding window over %dx%d images)" % (crop, crop, img_size, img_size),
+            "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": cfg["name"] + ", " + dtype_name, "windows_per_step": nwin, "image": [img_size, img_size, 3], "tile": [crop, crop, 3],
+                       "parallelism": "replicas%d" % world, "hipgraph": not args.no_graph},
+            "end_to_end_tflops": round(tiles_per_s * cfg["fwd_gflop"] * 1e9 / 1e12, 2),
+            "roofline": roofline, "roofline_msda": roofline_msda, "cpu_baseline": cpu_baseline,
+        }
+    if world > 1:
+        torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def run_cpu_baseline_train(B, S, ncls, threads, timed_steps=3):
+    """The oracle's train step (fwd + loss + bwd + clip + SGD-momentum) on the host cores: 1 warm-up + `timed_steps` timed
+    steps, the MEDIAN step time is reported (>= 3 timed steps for the headline config)."""
     from oracle.emrt_torch import EMRT as OracleEMRT
     from oracle import train_ref
     n = threads or min(os.cpu_count() or 1, 64)
     torch.set_num_threads(n)
     torch.manual_seed(1234)
-    ref = OracleEMRT(6, "resnet50").train()
+    ref = OracleEMRT(ncls, "resnet50").train()
     opt = train_ref.MomentumRef(list(ref.named_parameters()), 0.9, 1e-4, 1.0)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, 3, S, S, generator=g)
-    lab = torch.randint(0, 6, (B, S, S), generator=g)
+    lab = torch.randint(0, ncls, (B, S, S), generator=g)
     train_ref.train_step(ref, opt, x, lab, 0)
-    t0 = time.perf_counter()
-    steps = 2
-    for i in range(steps):
+    times = []
+    for i in range(timed_steps):
+        t0 = time.perf_counter()
         train_ref.train_step(ref, opt, x, lab, i + 1)
-    dt = time.perf_counter() - t0
-    return {"value": round(B * steps / dt, 3), "unit": "tiles/s", "cores": n, "kind": "port",
-            "sample": "%d full train steps (fwd+bwd+clip+SGD) of the torch-CPU fp32 oracle at batch %d, %dx%d, after 1 warm-up step; %.1f s" % (steps, B, S, S, dt)}
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(B / med, 3), "unit": "tiles/s", "cores": n, "kind": "port",
+            "sample": "median of %d full train steps (fwd+bwd+clip+SGD) of the torch-CPU fp32 oracle at batch %d, %dx%d, after 1 warm-up step; "
+                      "step times %s s" % (timed_steps, B, S, S, ["%.2f" % t for t in times])}
+
+
+def run_cpu_baseline_infer(ncls, crop, nwin, threads):
+    """The oracle's eval forward over the 16 windows of one image (fp32, the reference's precision), median of 3 after 1 warm-up."""
+    from oracle.emrt_torch import EMRT as OracleEMRT
+    n = threads or min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(n)
+    torch.manual_seed(1234)
+    ref = OracleEMRT(ncls, "resnet50").eval()
+    x = torch.randn(nwin, 3, crop, crop, generator=torch.Generator().manual_seed(1234))
+    times = []
+    with torch.no_grad():
+        ref(x)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ref(x)
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(nwin / med, 3), "unit": "tiles/s", "cores": n, "kind": "port",
+            "sample": "median of 3 eval forwards of the torch-CPU fp32 oracle over the %d windows of one image (one batch of %d), after 1 warm-up; "
+                      "times %s s" % (nwin, nwin, ["%.2f" % t for t in times])}
 
 
 if __name__ == "__main__":

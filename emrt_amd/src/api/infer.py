@@ -146,3 +146,45 @@ def ms_inference(model, img, ori_shape, is_slide, base_size, stride_size, crop_s
     pred = c.empty((1, 1, H, W), torch.int32)
     L.call("emrt_argmax_nchw", Fn.P(final), Fn.P(pred), 1, num_classes, H, W, c.stream)
     return pred
+
+
+class SlidingWindowEngine:
+    """ss_inference(is_slide=True) for ONE fixed image shape as a replayable hipGraph (the inference counterpart of
+    engine.TrainEngine): crop the windows -> model -> accumulate / count -> normalise -> argmax, ~700 launches per image,
+    captured once and replayed, so the host costs one graph launch per image instead of ~5 ms of Python.
+
+        eng = SlidingWindowEngine(model, (3, 1024, 1024), crop_size=(256, 256), stride_size=(256, 256), num_classes=6)
+        pred = eng(img)          # img fp32 [3, H, W] on the device -> int32 [1, 1, H, W]; eng.logits holds [1, ncls, H, W]
+
+    The arithmetic is exactly slide_inference + the argmax of ss_inference (reference: src/api/infer.py:22-80,149-154)."""
+
+    def __init__(self, model, image_shape, crop_size, stride_size, num_classes, warmup=1):
+        self.model, self.shape = model, tuple(int(v) for v in image_shape)
+        self.crop, self.stride, self.ncls, self.warmup = tuple(crop_size), tuple(stride_size), num_classes, warmup
+        self.calls, self.graph = 0, None
+        self.image = self.logits = self.pred = None
+
+    def _run(self, img):
+        logits = slide_inference(self.model, [img], self.crop, self.stride, self.ncls)[0]
+        n, ncls, hh, ww = logits.shape
+        pred = ctx().empty((n, 1, hh, ww), torch.int32)
+        Fn._L().call("emrt_argmax_nchw", Fn.P(logits), Fn.P(pred), n, ncls, hh, ww, ctx().stream)
+        return logits, pred
+
+    def __call__(self, img):
+        assert tuple(img.shape) == self.shape and img.dtype == torch.float32
+        self.model.eval()
+        self.calls += 1
+        if self.calls <= self.warmup:
+            self.logits, self.pred = self._run(img.contiguous())
+            return self.pred
+        if self.graph is None:
+            self.image = img.contiguous().clone()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.logits, self.pred = self._run(self.image)
+        if img.data_ptr() != self.image.data_ptr():
+            self.image.copy_(img, non_blocking=True)
+        self.graph.replay()
+        return self.pred
