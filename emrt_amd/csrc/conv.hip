@@ -37,6 +37,7 @@ struct ConvArgs {
   int ldres;
   long long res_bs;
   int KH, KW, stride, pad;
+  int dil;         // dilation of the kernel taps (resnet50c's dilated stages, backbones/resnet.py:65-66); 1 everywhere else
   int relu, out_f32;
   double* stats;   // optional [8][2*OC]: per-channel sum / sum of squares of the STORED outputs (BatchNorm statistics);
                    // fp64 atomics spread over 8 replicas (by M-tile index) so that blocks do not pile onto one address
@@ -179,9 +180,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   auto a_pixel = [&](int i, int kh, int kw) -> unsigned {
     int hi, wi;
     bool ok = a_ok[i];
-    if (MODE == 0) { hi = a_h[i] + kh; wi = a_w[i] + kw; }
+    if (MODE == 0) { hi = a_h[i] + kh * p.dil; wi = a_w[i] + kw * p.dil; }
     else {
-      const int th = a_h[i] - kh, tw = a_w[i] - kw;
+      const int th = a_h[i] - kh * p.dil, tw = a_w[i] - kw * p.dil;
       if (p.stride == 1) { hi = th; wi = tw; }                 // (negative values fail the range test below)
       else if (p.stride == 2) { hi = th >> 1; wi = tw >> 1; ok = ok && ((th | tw) & 1) == 0; }
       else {
@@ -551,6 +552,7 @@ struct WgradArgs {
   int OH, OW, OC, lddy;
   long long dy_bs;
   int KH, KW, stride, pad;
+  int dil;              // dilation of the kernel taps
   int tiles_per_split;  // number of BKm pixel tiles each z-slice processes
   float* dbias;         // optional [OC]: += sum_m dy[m][oc] (bias gradient), accumulated by the k-tile-0 blocks from the dy tiles they stream
 };
@@ -653,7 +655,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x
   const unsigned x_bs_b = (unsigned)(p.x_bs * (long long)ESZ);
   const unsigned dy_adv = dy_step + (unsigned)adv_n * dy_wrap, x_adv = (unsigned)adv_n * x_bs_b;
   const unsigned ldx_b = (unsigned)p.ldx * ESZ, cq_b = (unsigned)cq * ESZ, ocp_b = (unsigned)ocp * ESZ;
-  const int hi0 = kh - p.pad, wi0 = kw - p.pad;
+  const int hi0 = kh * p.dil - p.pad, wi0 = kw * p.dil - p.pad;
   int ld_t = grp;                                                   // tile (relative to mt_begin) fetched next
 
   uint4 rp[NST][4], rq[NST][4];
@@ -675,7 +677,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
           const uint32_t vp = buf_load_elem<T>(rs_dy, (r_dy[i] | m_bad | e_pbad[e]) + (unsigned)(ocp + e) * ESZ);
-          const int hi = r_oh[i] * p.stride - p.pad + e_kh[e], wi = r_ow[i] * p.stride - p.pad + e_kw[e];
+          const int hi = r_oh[i] * p.stride - p.pad + e_kh[e] * p.dil, wi = r_ow[i] * p.stride - p.pad + e_kw[e] * p.dil;
           const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
           const unsigned off = r_ximg[i] + (unsigned)((hi * p.W + wi) * p.ldx + e_c[e]) * ESZ;
           const uint32_t vq = buf_load_elem<T>(rs_x, inb ? (off | m_bad | e_qbad[e]) : BUF_OOB);
@@ -929,17 +931,17 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
                            int ldres, long long res_bs,
                            int KH, int KW, int stride, int pad,
                            int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
-                           int dtype, void* stream) {
+                           int dilation, int dtype, void* stream) {
   EMRT_REQUIRE(in && w_packed && out, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
-  EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
+  EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
   EMRT_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fwd) or 1 (dgrad)");
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(dtype != EMRT_F16 || mode == 0, "fp16 (dtype 2) is inference-only: forward convolution (mode 0)");
   if (mode == 0) {
-    EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "fwd: output size mismatch");
+    EMRT_REQUIRE(OH == (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && OW == (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "fwd: output size mismatch");
   } else {
-    EMRT_REQUIRE(H == (OH + 2 * pad - KH) / stride + 1 && W == (OW + 2 * pad - KW) / stride + 1, "dgrad: size mismatch");
+    EMRT_REQUIRE(H == (OH + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && W == (OW + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "dgrad: size mismatch");
   }
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
@@ -952,7 +954,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
-  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
   a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
@@ -1028,10 +1030,10 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
 extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
                                  int N, int H, int W, int C, int ldx, long long x_bs,
                                  int OH, int OW, int OC, int lddy, long long dy_bs,
-                                 int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream) {
+                                 int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && dw, "null pointer");
-  EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
-  EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
+  EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0 && dilation >= 1, "bad dims");
+  EMRT_REQUIRE(OH == (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && OW == (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "output size mismatch");
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
@@ -1044,7 +1046,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.x_bs = x_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.lddy = lddy; a.dy_bs = dy_bs;
-  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.tiles_per_split = 0; a.dbias = dbias;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.tiles_per_split = 0; a.dbias = dbias;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? wgrad_dispatch<float>(a, st) : wgrad_dispatch<bf16_t>(a, st);
 }
@@ -1323,11 +1325,11 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
                                int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs,
                                int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
                                float mask_scale, const void* stat_x, int ldsx, long long sx_bs, const void* addend, int ldadd, long long add_bs,
-                               int dtype, void* stream) {
+                               int dilation, int dtype, void* stream) {
   EMRT_REQUIRE(x && dy && w_bwd_packed && dx && dw, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
-  EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0, "bad kernel geometry");
-  EMRT_REQUIRE(OH == (H + 2 * pad - KH) / stride + 1 && OW == (W + 2 * pad - KW) / stride + 1, "output size mismatch");
+  EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
+  EMRT_REQUIRE(OH == (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && OW == (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "output size mismatch");
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
@@ -1347,13 +1349,13 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(lddx >= C && dx_bs >= 0, "bad dx strides");
   EMRT_REQUIRE(!(accumulate && addend), "accumulate adds into dx itself; addend is a different tensor");
   EMRT_REQUIRE(!stat_x || mask_y, "stat_x replaces the mask tensor in the second statistic: it needs mask_y");
-  d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
+  d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dilation; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
   d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale; d.stat_x = stat_x; d.ldsx = ldsx; d.sx_bs = sx_bs;
   WgradArgs w;
   w.x = x; w.dy = dy; w.dw = dw;
   w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
   w.OH = OH; w.OW = OW; w.OC = OC; w.lddy = lddy; w.dy_bs = dy_bs;
-  w.KH = KH; w.KW = KW; w.stride = stride; w.pad = pad; w.tiles_per_split = 0; w.dbias = dbias;
+  w.KH = KH; w.KW = KW; w.stride = stride; w.pad = pad; w.dil = dilation; w.tiles_per_split = 0; w.dbias = dbias;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? conv_bwd_dispatch<float>(d, w, st) : conv_bwd_dispatch<bf16_t>(d, w, st);
 }
@@ -1415,7 +1417,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldin = d.ldin; a.in_bs = d.in_bs;
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
   a.ldres = d.ldres; a.res_bs = d.res_bs;
-  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.relu = d.relu; a.out_f32 = 0; a.stats = d.bn_stats;
+  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = 0; a.stats = d.bn_stats;
   a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
 }
 
@@ -1481,13 +1483,13 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     d.N = b.N; d.H = b.OH; d.W = b.OW; d.C = b.OC; d.ldin = b.lddy; d.in_bs = b.dy_bs;
     d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
-    d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.relu = 0; d.out_f32 = 0; d.stats = nullptr;
+    d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.stats = nullptr;
     d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
     WgradArgs& w = g.w[i];
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;
     w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;
     w.OH = b.OH; w.OW = b.OW; w.OC = b.OC; w.lddy = b.lddy; w.dy_bs = b.dy_bs;
-    w.KH = b.KH; w.KW = b.KW; w.stride = b.stride; w.pad = b.pad; w.tiles_per_split = 0; w.dbias = b.dbias;
+    w.KH = b.KH; w.KW = b.KW; w.stride = b.stride; w.pad = b.pad; w.dil = 1; w.tiles_per_split = 0; w.dbias = b.dbias;
     const bool vec = conv_desc_is_vec<T>(d) && wgrad_is_vec<T>(w) && d.OC > 32;
     groupable = groupable && vec;
     int tx = 1, ty = 1, S = 1;

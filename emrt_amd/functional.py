@@ -286,13 +286,14 @@ class GemmWeight:
         self.need_bwd = True
 
 
-def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None):
+def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1):
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice)."""
     c = ctx()
     N, H, W, C, ldin, in_bs = _check_map(x)
     assert C == w.C, (C, w.C)
-    OH = (H + 2 * pad - w.KH) // stride + 1
-    OW = (W + 2 * pad - w.KW) // stride + 1
+    dil = int(dilation)
+    OH = (H + 2 * pad - dil * (w.KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (w.KW - 1) - 1) // stride + 1
     if out is None:
         oshape = (N, OH, OW, w.OC) if x.dim() == 4 else _like_shape(x, w.OC)
         out = c.empty(oshape, torch.float32 if out_f32 else None)
@@ -303,7 +304,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
         _, _, _, _, ldres, res_bs = _check_map(residual)
     _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
               OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), None, 0, 0,
-              c.dtype, c.stream)
+              dil, c.dtype, c.stream)
     tape = c.tape
     bn_rec = getattr(x, "_bn_rec", None)      # x = relu(BatchNorm(.)) fresh from batch_norm(): see the dgrad call below
     drop_rec = getattr(x, "_drop_rec", None)  # x = dropout(relu(linear(.))) with this layer as its only consumer
@@ -324,7 +325,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
             dbias = P(w.bias_grad) if w.bias is not None else None
             if not need_dx:
                 _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
-                          w.KH, w.KW, stride, pad, dbias, c.dtype, c.stream)
+                          w.KH, w.KW, stride, pad, dbias, dil, c.dtype, c.stream)
             else:
                 slot = tape.grad_slot(x)          # accumulate straight into an existing gradient / a slice of the base buffer
                 # contributions other consumers made so far that are not ours to write into: the kernel reads them as an
@@ -357,14 +358,14 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                               N, H, W, C, ldin, in_bs,
                               OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, P(ysums), P(ymask), ldin if ymask is not None else 0,
                               in_bs if ymask is not None else 0, float(mscale), P(stat), ldsx, sx_bs, P(addend), ldadd, add_bs,
-                              c.dtype, c.stream)
+                              dil, c.dtype, c.stream)
                 else:       # two-stream experiment (Context.overlap): wgrad on the side stream next to dgrad
                     _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
-                              w.KH, w.KW, stride, pad, dbias, c.dtype, side)
+                              w.KH, w.KW, stride, pad, dbias, dil, c.dtype, side)
                     _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, P(dx) if slot is not None else None,
                               N, OH, OW, w.OC, lddy, dy_bs, H, W, C, lddx, dx_bs, lddx if slot is not None else 0, dx_bs if slot is not None else 0,
                               w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
-                              in_bs if ymask is not None else 0, c.dtype, c.stream)
+                              in_bs if ymask is not None else 0, dil, c.dtype, c.stream)
                     c.join()
                 if addend is not None:
                     tape.replace_grad(x, dx)
@@ -507,7 +508,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
     """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training)."""
     c = ctx()
     sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
-    y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums)
+    y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums, dilation=getattr(conv, "dilation", 1))
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 
 

@@ -181,9 +181,10 @@ class HipLayer(tnn.Module):
 
 
 class Conv2D(HipLayer):
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, need_dx=True):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, need_dx=True, dilation=1):
         super().__init__()
         self.cin, self.cout, self.k, self.stride, self.padding, self.need_dx = cin, cout, k, stride, padding, need_dx
+        self.dilation = dilation
         self.weight = tnn.Parameter(torch.empty(cout, cin, k, k))
         self.bias = tnn.Parameter(torch.zeros(cout)) if bias else None
         self.gw = None
@@ -193,7 +194,8 @@ class Conv2D(HipLayer):
                                   store.offsets[prefix + "bias"] if self.bias is not None else None, need_bwd=self.need_dx)
 
     def forward(self, x, relu=False, residual=None, out=None, out_f32=False):
-        return Fn.conv2d(x, self.gw, self.stride, self.padding, relu=relu, residual=residual, out=out, out_f32=out_f32, need_dx=self.need_dx)
+        return Fn.conv2d(x, self.gw, self.stride, self.padding, relu=relu, residual=residual, out=out, out_f32=out_f32, need_dx=self.need_dx,
+                         dilation=self.dilation)
 
 
 class Linear(HipLayer):

@@ -28,7 +28,7 @@ from ...runtime import ctx, Tape, F32, BF16
 NOGRAD_PARAMS = ("backbone.fc.weight", "backbone.fc.bias", "model.tgt_embed.weight")
 # parameters whose gradient is only final after the ops recorded before the tape's split mark (ResNet.forward) have run
 # backward; everything else can be exchanged between ranks while those run (engine.TrainEngine, two-phase step)
-LATE_GRAD_PREFIXES = ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2.", "backbone.layer3.")
+LATE_GRAD_PREFIXES = ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2.", "backbone.layer3.")   # (conv1.* also covers resnet50c's conv1.0 / .3 / .6)
 # the same per backward segment (two marks: before layer3 and before layer4): what the 2nd / 3rd segment complete
 GRAD_SEGMENT_PREFIXES = (("backbone.layer3.",), ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2."))
 
@@ -113,6 +113,68 @@ class ResNet(hnn.HipLayer):  # :152-257
             if (layer is self.layer3 or layer is self.layer4) and ctx().tape is not None:
                 ctx().tape.splits.append(len(ctx().tape.ops))     # engine.py: the gradients of everything recorded from here
                                                                    # on are final once backward is back at this point
+            for blk in layer._modules.values():
+                x = blk(x)
+            feats.append(x)
+        return feats
+
+
+class BottleneckV1b(hnn.HipLayer):  # backbones/resnet.py:61-99 (stride and dilation on conv2, padding = dilation)
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = hnn.Conv2D(inplanes, planes, 1, bias=False)
+        self.bn1 = hnn.BatchNorm2D(planes)
+        self.conv2 = hnn.Conv2D(planes, planes, 3, stride, dilation, bias=False, dilation=dilation)
+        self.bn2 = hnn.BatchNorm2D(planes)
+        self.conv3 = hnn.Conv2D(planes, planes * 4, 1, bias=False)
+        self.bn3 = hnn.BatchNorm2D(planes * 4)
+        self.downsample = downsample
+
+    forward = BottleneckBlock.forward
+
+
+class ResNetV1c(hnn.HipLayer):  # backbones/resnet.py:102-221 with deep_stem=True (resnet50c, :224-234), multi_grid off
+    def __init__(self, layers=(3, 4, 6, 3), output_stride=32, num_classes=1000):
+        super().__init__()
+        if output_stride not in (8, 16, 32):
+            raise NotImplementedError
+        dilations, strides = {32: ([1, 1], [2, 2]), 16: ([1, 2], [2, 1]), 8: ([2, 4], [1, 1])}[output_stride]
+        self.inplanes = 128
+        # nn.Sequential(conv, bn, relu, conv, bn, relu, conv): state-dict indices 0, 1, 3, 4, 6 (:124-134)
+        self.conv1 = hnn.Sequential(hnn.Conv2D(3, 64, 3, 2, 1, bias=False, need_dx=False), hnn.BatchNorm2D(64), None,
+                                    hnn.Conv2D(64, 64, 3, 1, 1, bias=False), hnn.BatchNorm2D(64), None,
+                                    hnn.Conv2D(64, 128, 3, 1, 1, bias=False))
+        self.bn1 = hnn.BatchNorm2D(128)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=strides[0], dilation=dilations[0])
+        self.layer4 = self._make_layer(512, layers[3], stride=strides[1], dilation=dilations[1])
+        self.fc = hnn.Linear(2048, num_classes)
+        self.fc.standalone = False
+
+    def _make_layer(self, planes, blocks, stride=1, dilation=1):  # :175-207
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = hnn.Sequential(hnn.Conv2D(self.inplanes, planes * 4, 1, stride, 0, bias=False), hnn.BatchNorm2D(planes * 4))
+        if dilation not in (1, 2, 4):
+            raise RuntimeError("=> unknown dilation size: {}".format(dilation))
+        mods = [BottleneckV1b(self.inplanes, planes, stride, dilation=2 if dilation == 4 else 1, downsample=downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            mods.append(BottleneckV1b(self.inplanes, planes, dilation=dilation))
+        return hnn.Sequential(*mods)
+
+    def forward(self, x):  # :209-221
+        x = Fn.conv_bn(self.conv1[0], self.conv1[1], x, relu=True)
+        x = Fn.conv_bn(self.conv1[3], self.conv1[4], x, relu=True)
+        x = Fn.conv_bn(self.conv1[6], self.bn1, x, relu=True)
+        x = Fn.maxpool(x, 3, 2, 1)
+        feats = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            if (layer is self.layer3 or layer is self.layer4) and ctx().tape is not None:
+                ctx().tape.splits.append(len(ctx().tape.ops))
             for blk in layer._modules.values():
                 x = blk(x)
             feats.append(x)
@@ -546,8 +608,11 @@ class EMRT(hnn.HipLayer):  # :184-304
             num_classes = config.DATA.NUM_CLASSES
             backbone = config.MODEL.ENCODER.TYPE.lower()
         depth = int(backbone.replace("resnet", "")) if backbone.startswith("resnet") and backbone[6:].isdigit() else None
+        if backbone == "resnet50c":
+            depth = 50
         if depth not in ResNet.layer_cfg:
-            raise NotImplementedError("EMRT HIP path supports resnet18/34/50/101/152 backbones, got %r" % backbone)
+            raise NotImplementedError("EMRT HIP path supports resnet18/34/50/50c/101/152 backbones, got %r" % backbone)
+        output_stride = int(config.MODEL.OUTPUT_STRIDE) if config is not None else 32
         self.nclass = num_classes
         # resnet18/34: build-side extension (the reference hard-codes [512,1024,2048], paddle_EMRT.py:188-192)
         self.backbone_num_channels = [128, 256, 512] if depth in (18, 34) else [512, 1024, 2048]
@@ -566,11 +631,19 @@ class EMRT(hnn.HipLayer):  # :184-304
             for m in self.modules():
                 if isinstance(m, hnn.Conv2D):
                     tnn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="relu")
-        self.backbone = ResNet(depth)
-        with torch.no_grad():   # reference downloads ImageNet weights (:231-232); offline => Paddle default init
-            for m in self.backbone.modules():
-                if isinstance(m, hnn.Conv2D):
-                    _paddle_conv_default_(m)
+        if backbone == "resnet50c":      # :227-228: deep stem, dilation from MODEL.OUTPUT_STRIDE (backbones/resnet.py)
+            self.backbone = ResNetV1c(output_stride=output_stride)
+            with torch.no_grad():        # resnet.py:151-160: KaimingNormal on every conv
+                for m in self.backbone.modules():
+                    if isinstance(m, hnn.Conv2D):
+                        tnn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="relu")
+        else:
+            self.backbone = ResNet(depth)
+            with torch.no_grad():   # reference downloads ImageNet weights (:231-232); offline => Paddle default init
+                for m in self.backbone.modules():
+                    if isinstance(m, hnn.Conv2D):
+                        _paddle_conv_default_(m)
+        with torch.no_grad():
             tnn.init.xavier_uniform_(self.backbone.fc.weight)
             tnn.init.zeros_(self.backbone.fc.bias)
         self.model = EncoderDecoder(backbone_num_channels=self.backbone_num_channels, hidden_dim=256, dim_feedforward=1024,

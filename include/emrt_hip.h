@@ -45,13 +45,14 @@ int emrt_get_tuning(const char* name, int* value);
  * replaces nn.Conv2D: backbones/paddle_vision_resnet.py:108-123,192-198,226-233; paddle_EMRT.py:16-23,63,85-91,
  * 134-138,201-209; decoders/fcn_head.py:52,66; EMRT_utils/transformer_encoder_decoder.py:125-144,374-378
  * and nn.Linear / F.linear: transformer_encoder_decoder.py:36-42,118-121,259-262,371; EMRT_utils/layers.py:221-229,306.
+ * dilation: spacing of the kernel taps (1 = dense; the dilated stages of the resnet50c backbone, backbones/resnet.py:65-66,112-124).
  * mode 0: out = conv(in, W) [+bias][+residual][relu];  w_packed = [OC][KH][KW][C]  (dims N,H,W,C describe `in`)
  * mode 1: data gradient; `in` is dY (N,H,W,C = its dims), out is dX (OH,OW,OC), w_packed = [Cin][KH][KW][Cout].
  * bn_stats (nullable): fp64 [8][2*OC] (8 replicas, see BatchNorm below), pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
  * (the BatchNorm statistics of the layer that follows, fused so the activation is not re-read). */
-int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dtype, void* stream);
+int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dilation, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
-int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dtype, void* stream);
+int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream);
 /* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE
  * launch; problems that are not small vector-path ones are launched one by one instead.  Descriptors are host arrays. */
 typedef struct EmrtConvDesc {            /* the arguments of emrt_conv2d, mode 0, compute-dtype output */
@@ -76,7 +77,7 @@ int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* 
  * dx = dgrad + addend before the mask, i.e. the gradient contributions other consumers made so far are folded in without
  * an accumulate pass; stat_x: the second statistic becomes sum dx * stat_x (the BatchNorm input) instead of sum dx * mask_y,
  * which is what a relu(BatchNorm(x) + residual) join needs -- its reduction pass then disappears too */
-int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, float mask_scale, const void* stat_x, int ldsx, long long sx_bs, const void* addend, int ldadd, long long add_bs, int dtype, void* stream);
+int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs, int accumulate, float* dw, float* dbias, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs, float mask_scale, const void* stat_x, int ldsx, long long sx_bs, const void* addend, int ldadd, long long add_bs, int dilation, int dtype, void* stream);
 
 /* ---- BatchNorm / SyncBatchNorm (train: fp64 sums [from the conv epilogue or emrt_bn_stats] -> [all-reduce of sums across
  * ranks] -> apply; eval: running statistics).  replaces nn.BatchNorm2D / nn.SyncBatchNorm (+ReLU, + residual add):

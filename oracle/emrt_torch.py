@@ -262,6 +262,80 @@ class MSDeformableAttention(nn.Module):  # t_e_d.py:21-107
 
 
 # --------------------------------------------------------------------------------------
+# resnet50c: deep-stem, optionally dilated ResNet-50 (backbones/resnet.py:61-99 BottleneckV1b, :102-221 ResNetV1,
+# :224-234 resnet50c; selected by MODEL.ENCODER.TYPE "resnet50c", paddle_EMRT.py:227-228)
+# --------------------------------------------------------------------------------------
+class BottleneckV1b(nn.Module):  # resnet.py:61-99 (stride AND dilation on conv2, padding = dilation)
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1, bias=False)
+        self.bn1 = BatchNorm2D(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
+        self.bn2 = BatchNorm2D(planes)
+        self.conv3 = _conv(planes, planes * 4, 1, bias=False)
+        self.bn3 = BatchNorm2D(planes * 4)
+        self.relu = nn.ReLU()
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNetV1c(nn.Module):  # resnet.py:102-221 with deep_stem=True, multi_grid=False (every EMRT yaml), scale 1.0
+    def __init__(self, layers=(3, 4, 6, 3), output_stride=32, num_classes=1000):
+        super().__init__()
+        dilations, strides = {32: ([1, 1], [2, 2]), 16: ([1, 2], [2, 1]), 8: ([2, 4], [1, 1])}[output_stride]     # :109-120
+        self.inplanes = 128
+        self.conv1 = nn.Sequential(_conv(3, 64, 3, 2, 1, bias=False), BatchNorm2D(64), nn.ReLU(),                  # :124-134
+                                   _conv(64, 64, 3, 1, 1, bias=False), BatchNorm2D(64), nn.ReLU(),
+                                   _conv(64, 128, 3, 1, 1, bias=False))
+        self.bn1 = BatchNorm2D(128)
+        self.relu = nn.ReLU()
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=strides[0], dilation=dilations[0])
+        self.layer4 = self._make_layer(512, layers[3], stride=strides[1], dilation=dilations[1])
+        self.fc = nn.Linear(2048, num_classes)
+        with torch.no_grad():                                                                                       # :151-160
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="relu")
+
+    def _make_layer(self, planes, blocks, stride=1, dilation=1):  # :175-207
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(_conv(self.inplanes, planes * 4, 1, stride, 0, bias=False), BatchNorm2D(planes * 4))
+        if dilation in (1, 2):
+            first = 1
+        elif dilation == 4:
+            first = 2
+        else:
+            raise RuntimeError("=> unknown dilation size: {}".format(dilation))
+        layers = [BottleneckV1b(self.inplanes, planes, stride, dilation=first, downsample=downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(BottleneckV1b(self.inplanes, planes, dilation=dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):  # :209-221
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        c1 = self.layer1(x)
+        c2 = self.layer2(c1)
+        c3 = self.layer3(c2)
+        c4 = self.layer4(c3)
+        return c1, c2, c3, c4
+
+
+# --------------------------------------------------------------------------------------
 # MultiHeadAttention (layers.py:144-311) -- packed in-proj, softmax(QK^T/sqrt(d)), dropout on weights
 # --------------------------------------------------------------------------------------
 class MultiHeadAttention(nn.Module):
@@ -601,9 +675,9 @@ class EMRT(nn.Module):  # :184-304
     """`backbone` in {"resnet18","resnet34","resnet50","resnet101"}.  resnet18/34 are build-side
     extensions with channels [128,256,512] (the reference hard-codes [512,1024,2048], :188-192)."""
 
-    def __init__(self, num_classes=6, backbone="resnet50"):
+    def __init__(self, num_classes=6, backbone="resnet50", output_stride=32):
         super().__init__()
-        depth = int(backbone.replace("resnet", ""))
+        depth = 50 if backbone == "resnet50c" else int(backbone.replace("resnet", ""))
         self.nclass = num_classes
         self.backbone_num_channels = [128, 256, 512] if depth in (18, 34) else [512, 1024, 2048]
         self.hidden_dim = 256
@@ -620,11 +694,15 @@ class EMRT(nn.Module):  # :184-304
             for m in self.modules():
                 if isinstance(m, nn.Conv2d):
                     nn.init.kaiming_normal_(m.weight, a=0, mode="fan_in", nonlinearity="relu")
-        self.backbone = ResNet(depth)   # reference downloads ImageNet weights (:231-232); offline => Paddle defaults
+        if backbone == "resnet50c":     # :227-228 get_segmentation_backbone: deep stem, dilation by MODEL.OUTPUT_STRIDE
+            self.backbone = ResNetV1c(output_stride=output_stride)
+        else:
+            self.backbone = ResNet(depth)   # reference downloads ImageNet weights (:231-232); offline => Paddle defaults
+            with torch.no_grad():
+                for m in self.backbone.modules():
+                    if isinstance(m, nn.Conv2d):
+                        _paddle_conv_default_(m)
         with torch.no_grad():
-            for m in self.backbone.modules():
-                if isinstance(m, nn.Conv2d):
-                    _paddle_conv_default_(m)
             nn.init.xavier_uniform_(self.backbone.fc.weight)
             nn.init.zeros_(self.backbone.fc.bias)
         self.model = EncoderDecoder(backbone_num_channels=self.backbone_num_channels, hidden_dim=256,

@@ -69,7 +69,7 @@ def thin():
 
     def run(mask):
         L._raw_emrt_conv2d_bwd(P(x), P(dy), P(wb), P(dx), C, H * W * C, 0, P(dw), P(db), N, H, W, C, C, H * W * C, H, W, OC, OC, H * W * OC,
-                               1, 1, 1, 0, P(stats) if mask else None, P(x) if mask else None, C if mask else 0, H * W * C if mask else 0, 1.0, None, 0, 0, None, 0, 0, 1, stream)
+                               1, 1, 1, 0, P(stats) if mask else None, P(x) if mask else None, C if mask else 0, H * W * C if mask else 0, 1.0, None, 0, 0, None, 0, 0, 1, 1, stream)
     for ch in (8, 4):
         for cblk in (64, 128, 256):
             for blocks in (64, 128, 256, 512):
@@ -94,19 +94,19 @@ def main():
 
         def fwd():
             L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC, 0, 0,
-                               k, k, s, pad, 0, 0, 0, None, None, 0, 0, 1, stream)
+                               k, k, s, pad, 0, 0, 0, None, None, 0, 0, 1, 1, stream)
 
         def dgrad():
             L._raw_emrt_conv2d(P(y), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0,
-                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, stream)
+                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, 1, stream)
 
         def wgrad():
             L._raw_emrt_conv2d_wgrad(P(x), P(y), P(dw), N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
-                                     k, k, s, pad, None, 1, stream)
+                                     k, k, s, pad, None, 1, 1, stream)
 
         def bwd():
             L._raw_emrt_conv2d_bwd(P(x), P(y), P(wb), P(dx), C, H * W * C, 0, P(dw), None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
-                                   k, k, s, pad, None, None, 0, 0, 1.0, None, 0, 0, None, 0, 0, 1, stream)
+                                   k, k, s, pad, None, None, 0, 0, 1.0, None, 0, 0, None, 0, 0, 1, 1, stream)
 
         line = "N%d %dx%dx%d->%d k%d  %6.2f GF |" % (N, H, W, C, OC, k, gf)
         if which == "bwd":
