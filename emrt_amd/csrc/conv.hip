@@ -571,12 +571,14 @@ struct WgradCfg<float> {
 // G = 2: two groups of 4 waves per block take alternate pixel tiles of the block's range (own LDS buffers) and their
 // accumulators are summed through LDS before the atomic epilogue: half the reduction slices (fp32 atomic traffic into dW,
 // ~14 MB per launch by WRITE_SIZE) for the same number of waves.  Kept for experiments; the dispatcher uses G = 1.
-template <class T, bool VEC, int G>
+template <class T, bool VEC, int G, int NSTW = 2>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x, const int block_y, const int block_z, unsigned char* smem_all) {
   using Cfg = WgradCfg<T>;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int CPR = Cfg::CPR, RPP = Cfg::RPP, BKM = Cfg::BKM, PITCH = Cfg::PITCH;
-  constexpr int NST = VEC ? 3 : 1;               // pixel tiles in flight in registers (8 x 16 B each per thread)
+  // pixel tiles in flight in registers (8 x 16 B each per thread).  Two, not three: with three the kernel needs ~320 registers
+  // against the 256 of a 2-waves-per-SIMD block and spilled 58-63 of them into the loop (wgrad, pair and group kernels alike)
+  constexpr int NST = VEC ? NSTW : 1;
   constexpr int STAGE_BYTES = 2 * BKM * PITCH;   // dy tile [BKM][128 oc] + x tile [BKM][128 k]
 
   const int grp = G == 1 ? 0 : (int)threadIdx.x >> 8;
@@ -839,10 +841,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x
     }
 }
 
-template <class T, bool VEC, int G>
+template <class T, bool VEC, int G, int NSTW = 2>
 __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD (<= 256 registers)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-  wgrad_body<T, VEC, G>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem_all);
+  wgrad_body<T, VEC, G, NSTW>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem_all);
 }
 
 // Backward pair: ONE launch runs the data-gradient tiles (blocks [0, n_dgrad)) and the weight-gradient tiles (the rest)
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2
 // its duration in launch / ramp / tail; side by side the two grids fill the machine and share one launch.  Both bodies
 // run 256-thread blocks; the block takes the larger LDS / register budget of the two (wgrad's), which is why large
 // grids, where dgrad wants its 4 blocks per CU, are still launched separately.
-template <class T, int TM, int TN, int WR, int WC, int NST>
+template <class T, int TM, int TN, int WR, int WC, int NST, int NSTW = 2>
 __global__ __launch_bounds__(256, 2) void bwd_pair_kernel(ConvArgs pd, WgradArgs pw, int n_dgrad, int wtx, int wty) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   if ((int)blockIdx.x < n_dgrad) {
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void bwd_pair_kernel(ConvArgs pd, WgradArgs
     int r = (int)blockIdx.x - n_dgrad;
     const int bx = r % wtx;
     r /= wtx;
-    wgrad_body<T, true, 1>(pw, bx, r % wty, r / wty, smem_all);
+    wgrad_body<T, true, 1, NSTW>(pw, bx, r % wty, r / wty, smem_all);
   }
 }
 
@@ -1022,7 +1024,11 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
       return fail("emrt_conv2d_wgrad", "cannot raise the dynamic LDS limit");
     attr_done = true;
   }
-  if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true, G>), dim3(tx, ty, (unsigned)S), dim3(256 * G), lds, st, a);
+  if (vec && g_tune.wgrad_nst == 3) {       // A/B knob: the spilling three-stage ring
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, true, G, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)G * 4 * Cfg::BKM * Cfg::PITCH)); attr3 = true; }
+    hipLaunchKernelGGL((wgrad_kernel<T, true, G, 3>), dim3(tx, ty, (unsigned)S), dim3(256 * G), lds, st, a);
+  } else if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true, G>), dim3(tx, ty, (unsigned)S), dim3(256 * G), lds, st, a);
   else hipLaunchKernelGGL((wgrad_kernel<T, false, 1>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
   return check_launch("emrt_conv2d_wgrad");
 }
@@ -1304,15 +1310,18 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   const long long pair_max = g_tune.pair_max;                // developer knob, default 768; measured: 0 -> 15.03 ms, 384 -> 14.46, 768 -> 14.42, 1536 -> 14.35, 3072+ -> 14.43
   if (vec_d && vec_w && d.OC > 32 && !big_tile && nd <= pair_max && nd + nw <= 4096) {
     auto kern = bwd_pair_kernel<T, 1, 1, 2, 2, 6>;
+    auto kern3 = bwd_pair_kernel<T, 1, 1, 2, 2, 6, 3>;
     const size_t lds_d = (size_t)2 * 128 * 144, lds_w = (size_t)4 * Cfg::BKM * Cfg::PITCH;
     const size_t lds = lds_d > lds_w ? lds_d : lds_w;
     static bool attr_done = false;
     if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return fail("emrt_conv2d_bwd", "cannot raise the dynamic LDS limit");
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nd + nw)), dim3(256), lds, st, d, w, (int)nd, tx, ty);
+    if (g_tune.wgrad_nst == 3) hipLaunchKernelGGL(kern3, dim3((unsigned)(nd + nw)), dim3(256), lds, st, d, w, (int)nd, tx, ty);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)(nd + nw)), dim3(256), lds, st, d, w, (int)nd, tx, ty);
     return check_launch("emrt_conv2d_bwd");
   }
   int rc = wgrad_dispatch<T>(w0, st);

@@ -21,7 +21,7 @@ const TuneEntry kTune[] = {
     {"pair_max", &emrt::Tuning::pair_max, 768},         {"msda_fwd_global", &emrt::Tuning::msda_fwd_global, 0},
     {"bn_block_kb", &emrt::Tuning::bn_block_kb, 8},     {"ln_atomic", &emrt::Tuning::ln_atomic, 1},
     {"msda_fwd_chunks", &emrt::Tuning::msda_fwd_chunks, 0}, {"msda_fwd_threads", &emrt::Tuning::msda_fwd_threads, 1024},
-    {"msda_fwd_probe", &emrt::Tuning::msda_fwd_probe, 0},
+    {"msda_fwd_probe", &emrt::Tuning::msda_fwd_probe, 0}, {"wgrad_nst", &emrt::Tuning::wgrad_nst, 2},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;
