@@ -183,11 +183,9 @@ def timed_replay(record_fn, world=1):
     L = _lib.lib()
     c = ctx()
     c.keepalive = []                       # nothing allocated during the recorded step is freed until the replay is done
-    branch, c.use_branch = c.use_branch, False     # per-kernel durations: every launch on the one stream the events are on
     L.start_record()
     record_fn()
     rec = L.stop_record()
-    c.use_branch = branch
     torch.cuda.synchronize()
     L.replay(rec)                          # backlog: the host gets ~20 ms ahead of the GPU
     calls = L.replay(rec, timed=True)      # HIP events on the launch stream around every launch
@@ -210,7 +208,6 @@ def main():
     ap.add_argument("--overlap", default="", choices=["", "pair", "deferred"], help="wgrad on a second stream (A/B experiment)")
     ap.add_argument("--two-phase", action="store_true", help="run the N>1 step structure (graphs around RCCL all-reduce) in a 1-rank group")
     ap.add_argument("--no-early-exchange", action="store_true", help="N>1: one all-reduce after the whole backward (A/B experiment)")
-    ap.add_argument("--no-branch", action="store_true", help="spatial branch on the main stream instead of a second one (A/B experiment)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -231,8 +228,6 @@ def main():
     from emrt_amd.src.models.losses import MixSoftmaxCrossEntropyLoss
     from emrt_amd.src.models.solver import Momentum, PolynomialDecay
 
-    from emrt_amd.runtime import ctx
-    ctx().use_branch = not args.no_branch
     rank, local_rank, world = init_process_group()
     if world != args.gpus:
         log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))

@@ -35,7 +35,6 @@ class Tape:
         self.results = {}
         self.splits = []    # len(ops) at the model's gradient-exchange marks, in forward order (engine.py: backward runs in
                             # segments between them, newest first, and exchanges the gradients each segment completes)
-        self._branch_buf = None   # ops recorded while a side branch is being issued (Context.branch): spliced in at its join
 
     @property
     def split(self):
@@ -51,23 +50,7 @@ class Tape:
         return self.results.get(id(t))
 
     def record(self, fn):
-        if self._branch_buf is not None:
-            fn._emrt_branch = True       # runs on the branch stream in backward() as well
-            self._branch_buf.append(fn)
-        else:
-            self.ops.append(fn)
-
-    def begin_branch(self):
-        self._branch_buf = []
-
-    def end_branch(self):
-        """Stop diverting; returns the diverted closures for splice_branch() (called where the branch is joined, so that in
-        backward they run -- newest first -- right after everything that consumed the branch's outputs)."""
-        buf, self._branch_buf = self._branch_buf, None
-        return buf
-
-    def splice_branch(self, buf):
-        self.ops.extend(buf)
+        self.ops.append(fn)
 
     def register_alias(self, view, base, slicer):
         self.keep.append(view)
@@ -85,12 +68,6 @@ class Tape:
     def pop_grad(self, t, with_count=False):
         """Gradient accumulated for t (None if none).  with_count=True -> (gradient, number of contributions it sums; 0 for
         views, whose gradient lives in a slice of their base)."""
-        r = self._pop_grad(t, with_count)
-        if _CTX._in_branch:      # produced on the main stream, read by branch-stream kernels: alive until the join
-            _CTX._branch_hold.append(r)
-        return r
-
-    def _pop_grad(self, t, with_count=False):
         if id(t) in self.alias:
             g = self.grad(t)
             return (g, 0) if with_count else g
@@ -191,24 +168,10 @@ class Tape:
         engine's early gradient exchange: everything recorded after `self.split` first, the rest in a second call)."""
         _CTX.tape = None            # backward kernels must not record
         _CTX._in_backward = True
-        forked = False
         try:
             while len(self.ops) > stop_at:
-                fn = self.ops.pop()
-                if getattr(fn, "_emrt_branch", False) and _CTX.branch_enabled:
-                    # a side branch of the forward (EMRT.forward: the spatial branch) runs its backward on the branch stream too:
-                    # nothing later on this tape consumes its results (they are parameter gradients), so the main stream goes on
-                    # with the backbone's backward meanwhile and joins at the end of this call
-                    if not forked:
-                        _CTX.branch_fork()
-                        forked = True
-                    with _CTX.on_branch():
-                        fn()
-                else:
-                    fn()
+                self.ops.pop()()
         finally:
-            if forked:
-                _CTX.branch_join()
             _CTX._in_backward = False
         if stop_at > 0:
             return
@@ -239,11 +202,6 @@ class Context:
         self._side = None
         self._in_backward = False # Tape.backward() is running (step-scoped allocations allowed)
         self._main = None         # the stream every launch of this runtime goes to (torch's current stream after init_device)
-        self._branch = None       # second stream for a coarse side branch of the step (EMRT.forward: the spatial branch)
-        self._in_branch = False
-        self._branch_hold = []
-        self._ws_branch = None
-        self.use_branch = True    # False: everything on the one main stream (A/B knob; CPU stand-in tests have no streams)
         self.capture = None       # engine.GraphSequence while a step is being captured: collective() then breaks the graph
         self.sync_always = False  # issue the SyncBatchNorm collectives even in a 1-rank group (single-GPU test of the N > 1 path)
 
@@ -283,27 +241,6 @@ class Context:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_keep = []
 
-    # ---- coarse side branch --------------------------------------------------------------------------------------------
-    # ONE fork / join pair per direction and step (unlike the per-layer `overlap` experiment above, whose ~100 cross-stream
-    # edges per step cost more than they gained): a sub-network that shares nothing with the main chain until its output is
-    # consumed runs on a second stream, so its GPU-filling kernels overlap the main chain's small latency-bound ones.
-    @property
-    def branch_enabled(self):
-        return bool(self.use_branch and self.device is not None and self.device.type == "cuda")
-
-    def branch_fork(self):
-        """Order the branch stream after everything issued so far on the current (main) stream."""
-        if self._branch is None or self._branch.device != self.device:
-            self._branch = torch.cuda.Stream(device=self.device)
-        self._branch.wait_stream(torch.cuda.current_stream())
-
-    def on_branch(self):
-        return _BranchScope(self)
-
-    def branch_join(self):
-        torch.cuda.current_stream().wait_stream(self._branch)
-        self._branch_hold = []
-
     # ---- device / dtype -------------------------------------------------------------------------
     def init_device(self, device="cuda:0", dtype=F32, seed=1234):
         if not torch.cuda.is_available():
@@ -335,10 +272,6 @@ class Context:
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def workspace(self, nbytes):
-        if self._in_branch:      # kernels of the two streams may run at the same time: separate scratch
-            if self._ws_branch is None or self._ws_branch.numel() < nbytes:
-                self._ws_branch = torch.empty(max(int(nbytes * 1.5), 1 << 20), dtype=torch.uint8, device=self.device)
-            return self._ws_branch
         if self._ws.numel() < nbytes:
             self._ws = torch.empty(int(nbytes * 1.5), dtype=torch.uint8, device=self.device)
         return self._ws
@@ -396,20 +329,6 @@ class Context:
     def next_salt(self):
         self.salt_counter += 1
         return self.salt_counter
-
-
-class _BranchScope:
-    def __init__(self, c):
-        self.c = c
-
-    def __enter__(self):
-        self.cm = torch.cuda.stream(self.c._branch)
-        self.cm.__enter__()
-        self.c._in_branch = True
-
-    def __exit__(self, *exc):
-        self.c._in_branch = False
-        return self.cm.__exit__(*exc)
 
 
 _CTX = Context()

@@ -105,13 +105,11 @@ class ResNet(hnn.HipLayer):  # :152-257
             mods.append(block(self.inplanes, planes))
         return hnn.Sequential(*mods)
 
-    def forward(self, x, after_layer2=None):
+    def forward(self, x):
         x = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
         x = Fn.maxpool(x, 3, 2, 1)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            if layer is self.layer3 and after_layer2 is not None:
-                after_layer2()          # EMRT.forward forks its side branch here: next to the small maps of layer3 / layer4
             if (layer is self.layer3 or layer is self.layer4) and ctx().tape is not None:
                 ctx().tape.splits.append(len(ctx().tape.ops))     # engine.py: the gradients of everything recorded from here
                                                                    # on are final once backward is back at this point
@@ -168,15 +166,13 @@ class ResNetV1c(hnn.HipLayer):  # backbones/resnet.py:102-221 with deep_stem=Tru
             mods.append(BottleneckV1b(self.inplanes, planes, dilation=dilation))
         return hnn.Sequential(*mods)
 
-    def forward(self, x, after_layer2=None):  # :209-221
+    def forward(self, x):  # :209-221
         x = Fn.conv_bn(self.conv1[0], self.conv1[1], x, relu=True)
         x = Fn.conv_bn(self.conv1[3], self.conv1[4], x, relu=True)
         x = Fn.conv_bn(self.conv1[6], self.bn1, x, relu=True)
         x = Fn.maxpool(x, 3, 2, 1)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            if layer is self.layer3 and after_layer2 is not None:
-                after_layer2()
             if (layer is self.layer3 or layer is self.layer4) and ctx().tape is not None:
                 ctx().tape.splits.append(len(ctx().tape.ops))
             for blk in layer._modules.values():
@@ -735,32 +731,10 @@ class EMRT(hnn.HipLayer):  # :184-304
             "EMRT expects fp32 NCHW images whose H and W are multiples of 32 (paddle_EMRT.py:293)"
         x = Fn.nchw_to_nhwc(inputs.contiguous())
         B, H, W, _ = x.shape
+        c1, c2, c3, c4 = self.backbone(x)
         S = H // 8
         psp_cat = c.empty((B, S, S, 256 * (2 + len(self.psp_scale))))
-        ctx_out = Fn.narrow(psp_cat, 3, 0, 256)
-        if c.branch_enabled:
-            # The spatial branch (paddle_EMRT.py:99-113, 261) shares nothing with the backbone but the input image: it is
-            # issued on a second stream once the backbone has reached layer3, so that its large-map kernels (128^2 .. 32^2,
-            # each filling the GPU) run beside the ~90 small latency-bound launches of layer3 / layer4 (16^2 / 8^2 maps) instead
-            # of after them; joined before the pyramid pooling consumes its output.  One fork / join pair per direction.
-            side = {}
-
-            def launch_spatial_branch():
-                if c.tape is not None:
-                    c.tape.begin_branch()
-                c.branch_fork()
-                with c.on_branch():
-                    side["out"] = self.spatial_branch(x, out=ctx_out)
-                if c.tape is not None:
-                    side["ops"] = c.tape.end_branch()
-            c1, c2, c3, c4 = self.backbone(x, after_layer2=launch_spatial_branch)
-            c.branch_join()
-            if c.tape is not None:
-                c.tape.splice_branch(side["ops"])
-            x_context = side["out"]
-        else:
-            c1, c2, c3, c4 = self.backbone(x)
-            x_context = self.spatial_branch(x, out=ctx_out)
+        x_context = self.spatial_branch(x, out=Fn.narrow(psp_cat, 3, 0, 256))
         x_psp = self.psp_module(x_context)
         hs, memory, shapes, spans = self.model([c2, c3, c4], x_psp)
         maps = [Fn.tokens_as_map(Fn.narrow(memory, 1, a, n), h, w) for (h, w), (a, n) in zip(shapes, spans)]
