@@ -40,6 +40,7 @@ struct Tuning {
   int thin_blocks;      // ... pixel chunks (128)
   int thin_ch;          // ... channels per thread (8)
   int no_thin_bwd;      // 1 = the classifier backward runs as two GEMMs
+  int igemm64_nst;      // 3 (default) / 4: register ring depth of the 64x64-tile igemm loop (A/B knob)
   int wgrad_nst;        // 2 (default) / 3: register ring depth of the weight-gradient loop (A/B knob)
   int pair_max;         // largest dgrad grid that is paired with its wgrad in one launch (768)
   int msda_fwd_global;  // 1 = never use the LDS-staged MSDA forward

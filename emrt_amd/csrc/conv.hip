@@ -868,12 +868,9 @@ __global__ __launch_bounds__(256, 2) void bwd_pair_kernel(ConvArgs pd, WgradArgs
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int G = 1>
-static int launch_igemm(const ConvArgs& a, hipStream_t st) {
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int G, int NST>
+static int launch_igemm_nst(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-  // ring depth: ~96 VGPRs of loads in flight per thread whatever the tile (16 B x (BM + BN) / 32 per stage)
-  // (a 1024-thread block, G = 4, has 128 registers per thread: 4 stages)
-  constexpr int NST = VEC ? (G >= 4 ? 4 : (BM + BN) / 32 <= 4 ? (G == 1 ? 4 : 6) : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long grid = ((M + BM - 1) / BM) * ((a.OC + BN - 1) / BN);
   size_t lds = (size_t)G * 2 * (BM + BN) * 144;
@@ -887,6 +884,19 @@ static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * G), lds, st, a);
   return check_launch("emrt_conv2d");
+}
+
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int G = 1>
+static int launch_igemm(const ConvArgs& a, hipStream_t st) {
+  constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+  // ring depth: ~96 VGPRs of loads in flight per thread whatever the tile (16 B x (BM + BN) / 32 per stage)
+  // (a 1024-thread block, G = 4, has 128 registers per thread: 4 stages)
+  // (the 64x64 tile at 128 registers: 3 stages; with 4 it spilled 2-4 registers into the loop: 705 -> 710 tiles/s)
+  constexpr int NST = VEC ? (G >= 4 ? 4 : (BM + BN) / 32 <= 4 ? (G == 1 ? 3 : 6) : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
+  if constexpr (VEC && G == 1 && BM + BN == 128) {
+    if (g_tune.igemm64_nst == 4) return launch_igemm_nst<T, TM, TN, WR, WC, MODE, VEC, G, 4>(a, st);     // A/B knob: the four-stage ring
+  }
+  return launch_igemm_nst<T, TM, TN, WR, WC, MODE, VEC, G, NST>(a, st);
 }
 
 template <class T, int MODE, bool VEC>
@@ -1401,7 +1411,7 @@ __global__ __launch_bounds__(256, 4) void igemm_group_kernel(ConvGroupArgs g) {
   int i = 0;
 #pragma unroll
   for (int k = 1; k < EMRT_MAX_GROUP; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
-  igemm_body<T, 1, 1, 2, 2, 0, true, 4, 1>(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], smem_all);
+  igemm_body<T, 1, 1, 2, 2, 0, true, 3, 1>(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], smem_all);
 }
 
 template <class T>
