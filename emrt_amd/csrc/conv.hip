@@ -890,9 +890,9 @@ template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int G = 1
 static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   // ring depth: ~96 VGPRs of loads in flight per thread whatever the tile (16 B x (BM + BN) / 32 per stage)
-  // (a 1024-thread block, G = 4, has 128 registers per thread: 4 stages)
+  // (a 1024-thread block, G = 4, has 128 registers per thread: 3 stages fit without spills)
   // (the 64x64 tile at 128 registers: 3 stages; with 4 it spilled 2-4 registers into the loop: 705 -> 710 tiles/s)
-  constexpr int NST = VEC ? (G >= 4 ? 4 : (BM + BN) / 32 <= 4 ? (G == 1 ? 3 : 6) : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
+  constexpr int NST = VEC ? (G >= 4 ? 3 : (BM + BN) / 32 <= 4 ? (G == 1 ? 3 : 6) : (BM + BN) / 32 <= 6 ? 4 : 3) : 2;
   if constexpr (VEC && G == 1 && BM + BN == 128) {
     if (g_tune.igemm64_nst == 4) return launch_igemm_nst<T, TM, TN, WR, WC, MODE, VEC, G, 4>(a, st);     // A/B knob: the four-stage ring
   }
