@@ -512,6 +512,70 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 
 
+def conv_bn_group(convs, bns, xs, relu=True):
+    """[conv_i -> SyncBatchNorm_i (-> ReLU)] for several INDEPENDENT branches (the four pyramid-pooling branches,
+    paddle_EMRT.py:61-66,70-78) with ONE cross-rank all-reduce of all their statistics per direction instead of one per
+    branch: inside a captured multi-GPU step every collective is a cut between two hipGraphs (runtime.Context.collective),
+    so the five SyncBatchNorm layers cost 4 cuts per step instead of 10.  Without ranks to talk to it is conv_bn per branch."""
+    c = ctx()
+    n = len(convs)
+    states = [b.state for b in bns]
+    if not (c.training and any(_sync_active(st) for st in states)):
+        return [conv_bn(cv, b, x, relu=relu) for cv, b, x in zip(convs, bns, xs)]
+    assert all(_sync_active(st) for st in states)
+    sizes = [BN_REPLICAS * 2 * st.C for st in states]
+    sums_all = c.zeros_f64(sum(sizes))
+    offs = [sum(sizes[:i]) for i in range(n)]
+    ys, geo = [], []
+    for cv, x, o, sz in zip(convs, xs, offs, sizes):
+        ys.append(conv2d(x, cv.gw, cv.stride, cv.padding, need_dx=cv.need_dx, bn_stats=sums_all[o:o + sz], dilation=getattr(cv, "dilation", 1)))
+    Ms = []
+    for y in ys:
+        N, H, W, C, ldx, x_bs = _check_map(y)
+        assert x_bs == H * W * ldx
+        Ms.append(N * H * W)
+        geo.append((C, ldx))
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    c.collective(lambda: dist.all_reduce(sums_all))
+    outs, saved = [], []
+    for y, st, o, sz, M, (C, ldx) in zip(ys, states, offs, sizes, Ms, geo):
+        out = c.empty(tuple(y.shape))
+        mean, invstd = c.empty((C,), torch.float32), c.empty((C,), torch.float32)
+        _L().call("emrt_bn_apply", P(y), ldx, None, 0, P(out), C, P(sums_all[o:o + sz]), float(M * world), st.eps, st.momentum, P(mean), P(invstd),
+                  P(st.run_mean), P(st.run_var), P(st.gamma), P(st.beta), M, C, int(relu), c.dtype, c.stream)
+        outs.append(out)
+        saved.append((mean, invstd))
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dys = [tape.pop_grad(o_) for o_ in outs]
+            live = [i for i in range(n) if dys[i] is not None]
+            if not live:
+                return
+            sums2 = c.zeros_f64(sum(sizes))
+            for i in live:
+                C, ldx = geo[i]
+                lddy = _check_map(dys[i])[4]
+                _L().call("emrt_bn_bwd_reduce", P(ys[i]), ldx, P(dys[i]), lddy, P(outs[i]) if relu else None, C, P(saved[i][0]), P(saved[i][1]), Ms[i], C,
+                          P(sums2[offs[i]:offs[i] + sizes[i]]), c.dtype, c.stream)
+            # dgamma / dbeta from this rank's own sums (the gradient all-reduce combines ranks), dx from the rank-summed ones
+            local = c.empty((sum(sizes),), torch.float64)
+            _L().call("emrt_cast", P(sums2), P(local), 2 * sum(sizes), 0, F32, c.stream)       # raw 8-byte copy as 2 x f32
+            c.collective(lambda: dist.all_reduce(sums2))
+            for i in live:
+                C, ldx = geo[i]
+                st = states[i]
+                lddy = _check_map(dys[i])[4]
+                dx = c.empty(tuple(ys[i].shape))
+                _L().call("emrt_bn_bwd_dx", P(ys[i]), ldx, P(dys[i]), lddy, P(outs[i]) if relu else None, C, P(dx), C, None, C, P(saved[i][0]), P(saved[i][1]),
+                          P(st.gamma), P(sums2[offs[i]:offs[i] + sizes[i]]), P(local[offs[i]:offs[i] + sizes[i]]), float(Ms[i] * world), P(st.dgamma),
+                          P(st.dbeta), Ms[i], C, None, 0, c.dtype, c.stream)
+                tape.add_grad(ys[i], dx, owned=True)
+        tape.record(bwd)
+    return outs
+
+
 def group_norm(x, gamma, beta, dgamma, dbeta, G=32, eps=1e-5, gelu=False, residual=None, out=None):
     """out = [gelu](GN(x)) [+ residual];  x [N,H,W,C] view."""
     c = ctx()

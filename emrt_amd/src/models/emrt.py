@@ -547,11 +547,12 @@ class PyramidPoolingModule(hnn.HipLayer):  # :50-78
 
     def forward(self, x):
         tokens = Fn.adaptive_avgpool_tokens(x, self.pool_scales)       # all four pools in one launch -> [B, 110, C]
-        parts, s0 = [], 0
-        for k, br in zip(self.pool_scales, self.pool_branches):
-            t = Fn.narrow(tokens, 1, s0, k * k)
-            parts.append(Fn.conv_bn(br[1], br[2], t, relu=True))
+        slices, s0 = [], 0
+        for k in self.pool_scales:
+            slices.append(Fn.narrow(tokens, 1, s0, k * k))
             s0 += k * k
+        # the four SyncBatchNorm branches share one statistics all-reduce per direction (Fn.conv_bn_group)
+        parts = Fn.conv_bn_group([br[1] for br in self.pool_branches], [br[2] for br in self.pool_branches], slices, relu=True)
         return Fn.concat_tokens(parts)
 
 

@@ -41,6 +41,8 @@ def main():
     def family(pred, grid=None):
         fs = [x[0] for k, v in fetch.items() if pred(k) for x in v if grid is None or x[1] == grid]
         ws = [x[0] for k, v in write.items() if pred(k) for x in v if grid is None or x[1] == grid]
+        if not fs or not ws:
+            return None
         return {"dispatches": len(fs), "fetch_mb_raw": round(sum(fs) / len(fs) / 1e3, 3), "write_mb": round(sum(ws) / len(ws) / 1e3, 3),
                 "traffic_mb_corrected": round((2 * sum(fs) / len(fs) + sum(ws) / len(ws)) / 1e3, 3)}
 
@@ -50,9 +52,9 @@ def main():
                     "per-dispatch averages; corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B reads as 64 B)",
           "igemm_kernel": family(lambda k: "igemm_kernel" in k),
           "wgrad_kernel": family(lambda k: "wgrad_kernel" in k),
-          "msda_fwd_kernel_encoder": family(lambda k: k == enc_name, enc_grid)}
-    if any("bwd_pair_kernel" in k for k in fetch):
-        js["bwd_pair_kernel"] = family(lambda k: "bwd_pair_kernel" in k)
+          "msda_fwd_kernel_encoder": family(lambda k: k == enc_name, enc_grid),
+          "bwd_pair_kernel": family(lambda k: "bwd_pair_kernel" in k)}
+    js = {k: v for k, v in js.items() if v is not None}        # (inference profiles have no backward kernels)
     js["msda_fwd_kernel_encoder"]["kernel"] = enc_name
     json.dump(js, open(dst + ".json", "w"), indent=1)
     print(json.dumps(js, indent=1))
