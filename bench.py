@@ -134,14 +134,15 @@ def rooflines(calls, dtype_name, cfg_key, train):
                 "event_timed_trivial_launch_us": round(1e3 * min(trivial), 2) if trivial else None,
                 "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch "
                           "(event_timed_trivial_launch_us = what the same pair reads around a one-thread kernel: included in every figure)"}
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this config (bench.py cannot profile itself): newest round
     pmc = None
-    for tag in ("r2", "r1k"):
-        src = os.path.join(ROOT, "profiles", "%s_pmc_traffic%s.json" % (tag, "" if cfg_key == "cfg2" else "_" + cfg_key))
-        if os.path.exists(src) and (cfg_key != "cfg2" or dtype_name == "bf16"):
-            with open(src) as f:
-                pmc = json.load(f)
-            pmc_src = os.path.relpath(src, ROOT)
-            break
+    import glob
+    suffix = "" if cfg_key == "cfg2" else "_" + cfg_key
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic%s.json" % suffix)))
+    if cands and cfg_key in CONFIGS and dtype_name == CONFIGS[cfg_key]["dtype"]:
+        with open(cands[-1]) as f:
+            pmc = json.load(f)
+        pmc_src = os.path.relpath(cands[-1], ROOT)
     if pmc is not None:
         key = {"emrt_conv2d": "igemm_kernel", "emrt_conv2d_bwd": "bwd_pair_kernel", "emrt_conv2d_wgrad": "wgrad_kernel"}.get(dom, "igemm_kernel")
         if key not in pmc:
