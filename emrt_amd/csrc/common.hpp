@@ -44,6 +44,7 @@ struct Tuning {
   int wgrad_nst;        // 2 (default) / 3: register ring depth of the weight-gradient loop (A/B knob)
   int pair_max;         // largest dgrad grid that is paired with its wgrad in one launch (768)
   int msda_fwd_global;  // 1 = never use the LDS-staged MSDA forward
+  int msda_bwd_global;  // 1 = never use the LDS-staged MSDA gradient kernel
   int msda_fwd_chunks;  // LDS-staged MSDA forward: query chunks per (batch, head) slab (0 = automatic)
   int msda_fwd_threads; // ... threads per block (1024)
   int msda_fwd_probe;   // timing experiments only (results are WRONG): 1 = no gather, 2 = no staging, 4 = no preparation

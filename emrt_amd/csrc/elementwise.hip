@@ -22,7 +22,7 @@ const TuneEntry kTune[] = {
     {"bn_block_kb", &emrt::Tuning::bn_block_kb, 8},     {"ln_atomic", &emrt::Tuning::ln_atomic, 1},
     {"msda_fwd_chunks", &emrt::Tuning::msda_fwd_chunks, 0}, {"msda_fwd_threads", &emrt::Tuning::msda_fwd_threads, 1024},
     {"msda_fwd_probe", &emrt::Tuning::msda_fwd_probe, 0}, {"wgrad_nst", &emrt::Tuning::wgrad_nst, 2},
-    {"igemm64_nst", &emrt::Tuning::igemm64_nst, 3},
+    {"igemm64_nst", &emrt::Tuning::igemm64_nst, 3}, {"msda_bwd_global", &emrt::Tuning::msda_bwd_global, 0},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;

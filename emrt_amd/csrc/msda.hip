@@ -507,6 +507,181 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   }
 }
 
+// Gradient kernel with the (batch, head) value slab staged in LDS -- the backward counterpart of msda_fwd_lds_kernel, same
+// slab (LDS-DMA, unpadded rows, zero guard bands), same block -> (batch, head, chunk) map, same quad-cooperative layout:
+//   * lane `sub` of a quad prepares samples sub, sub + 4, ... of its (query, head) pair: probability, bilinear fractions,
+//     validity of the four corners, pixel index;
+//   * for every sample all four lanes read their 8 channels of the four corners from LDS (branch-free; invalid corners are
+//     read from harmless addresses and dropped by the owner) and dot them with their 8 channels of dout (v_dot2 on the packed
+//     bf16), four DPP quad reductions give every lane the four corner dots, and the OWNER lane keeps them;
+//   * after the loop each lane turns its own samples' dots into d prob, d x, d y, the quad reduces sum_i p_i dA_i for the
+//     softmax backward, and each lane writes its samples' offset / logit gradients and probabilities.
+// The first version (msda_bwd_kernel, still used for fp32 maps, slabs that do not fit and the decoder's dref) gathers the
+// corners from L2 through the texture path and repeats the per-sample arithmetic in all four lanes.
+template <class T, int L, int P>
+__global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_per_block, int chunks, int guard) {
+  static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
+  constexpr int LP = L * P, NS = (LP + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vslab_raw[];
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int bm = bid / chunks, chunk = bid - bm * chunks;
+  const int b = bm / a.M, m = bm - b * a.M;
+  unsigned char* vslab = vslab_raw + guard * MSDA_FWD_PITCH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, nwave = blockDim.x >> 6;
+  const int q_begin = chunk * q_per_block;
+  int q_end = q_begin + q_per_block;
+  if (q_end > a.Lq) q_end = a.Lq;
+  {
+    const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32 + (lane & 3) * 8;
+    const int npiece = (a.Lv + 15) >> 4;
+    for (int k = wave; k < npiece; k += nwave) {
+      const int pix = k * 16 + (lane >> 2);
+      if (pix < a.Lv)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (long long)pix * a.ldv), (lds_ptr_t)(vslab + k * 1024), 16, 0, 0);
+    }
+    for (int i = threadIdx.x; i < guard * (MSDA_FWD_PITCH / 16); i += blockDim.x) {
+      *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(vslab + a.Lv * MSDA_FWD_PITCH + i * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  const unsigned char* vslab_sub = vslab + sub * 16;
+  const int rls = a.ref_L == 1 ? 0 : 2;
+  bool staged = false;
+  for (int qw = q_begin + wave * 16; qw < q_end; qw += nwave * 16) {
+    const int q = qw + (lane >> 2);
+    const bool live = q < q_end;
+    const long long bq = (long long)b * a.Lq + (live ? q : q_end - 1);      // tail lanes shadow the last query
+    const float* row = a.offw + bq * a.ldo;
+    const float* offp = row + m * LP * 2;
+    const float* logp = row + a.M * LP * 2 + m * LP;
+    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)(live ? q : q_end - 1) * a.ref_L * 2;
+    // ---- this lane's samples ----
+    float pr[NS], lx[NS], ly[NS];
+    int idx[NS], vmask[NS];          // vmask: bit0 (y0,x0) bit1 (y0,x0+1) bit2 (y0+1,x0) bit3 (y0+1,x0+1) inside the map
+    {
+      float lg[NS];
+      float2 of[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int smp = sub + 4 * j;
+        const bool has = smp < LP;
+        lg[j] = has ? logp[smp] : -3.0e38f;
+        of[j] = has ? *reinterpret_cast<const float2*>(offp + smp * 2) : make_float2(0.f, 0.f);
+      }
+      float rx[L], ry[L];
+#pragma unroll
+      for (int l = 0; l < L; ++l) { rx[l] = refp[l * rls]; ry[l] = refp[l * rls + 1]; }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) mx = fmaxf(mx, lg[j]);
+      mx = quad_max(mx);
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) { lg[j] = (sub + 4 * j < LP) ? __expf(lg[j] - mx) : 0.f; den += lg[j]; }
+      den = quad_add(den);
+      const float inv = 1.f / den;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int smp = sub + 4 * j;
+        int l = 0;
+#pragma unroll
+        for (int t = 1; t < L; ++t) l += smp >= t * P ? 1 : 0;
+        int H = a.h[0], W = a.w[0];
+        float ih = a.inv_h[0], iw = a.inv_w[0], rxl = rx[0], ryl = ry[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t)
+          if (l == t) { H = a.h[t]; W = a.w[t]; ih = a.inv_h[t]; iw = a.inv_w[t]; rxl = rx[t]; ryl = ry[t]; }
+        const float x = (rxl + of[j].x * iw) * (float)W - 0.5f;
+        const float y = (ryl + of[j].y * ih) * (float)H - 0.5f;
+        const float xf = floorf(x), yf = floorf(y);
+        lx[j] = x - xf; ly[j] = y - yf;
+        const int x0 = (int)fminf(fmaxf(xf, -2.f), 16777216.f), y0 = (int)fminf(fmaxf(yf, -2.f), 16777216.f);
+        pr[j] = lg[j] * inv;
+        const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+        const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+        vmask[j] = smp < LP ? ((vy0 && vx0) ? 1 : 0) | ((vy0 && vx1) ? 2 : 0) | ((vy1 && vx0) ? 4 : 0) | ((vy1 && vx1) ? 8 : 0) : 0;
+        idx[j] = vmask[j] ? y0 * W + x0 : 0;
+      }
+    }
+    const uint4 go = live ? *reinterpret_cast<const uint4*>((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8) : make_uint4(0, 0, 0, 0);
+    if (!staged) { __syncthreads(); staged = true; }       // (drains the LDS-DMA; every wave has at least one pass: chunks hold >= 16 * nwave queries or the block's waves beyond the chunk skip the loop -- see below)
+    // ---- corner dots of every sample, kept by the owner lane ----
+    float d00[NS], d01[NS], d10[NS], d11[NS];
+    int idx_run[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) idx_run[j] = idx[j];
+#pragma unroll 1
+    for (int j = 0; j < NS; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int smp = 4 * j + k;                       // wave-uniform
+        if (smp < LP) {
+          int l = 0;
+#pragma unroll
+          for (int t = 1; t < L; ++t) l += smp >= t * P ? 1 : 0;
+          int start = a.start[0], W = a.w[0];
+#pragma unroll
+          for (int t = 1; t < L; ++t)
+            if (l == t) { start = a.start[t]; W = a.w[t]; }
+          int id;
+          switch (k) {
+            case 0: id = quad_bcast<0>(idx_run[0]); break;
+            case 1: id = quad_bcast<1>(idx_run[0]); break;
+            case 2: id = quad_bcast<2>(idx_run[0]); break;
+            default: id = quad_bcast<3>(idx_run[0]); break;
+          }
+          const unsigned char* p00 = vslab_sub + (start + id) * MSDA_FWD_PITCH;
+          const unsigned char* p10 = p00 + W * MSDA_FWD_PITCH;
+          const float e00 = quad_add(Dot8<T>::dot(go, *reinterpret_cast<const uint4*>(p00)));
+          const float e01 = quad_add(Dot8<T>::dot(go, *reinterpret_cast<const uint4*>(p00 + MSDA_FWD_PITCH)));
+          const float e10 = quad_add(Dot8<T>::dot(go, *reinterpret_cast<const uint4*>(p10)));
+          const float e11 = quad_add(Dot8<T>::dot(go, *reinterpret_cast<const uint4*>(p10 + MSDA_FWD_PITCH)));
+          if (sub == k) { d00[NS - 1] = e00; d01[NS - 1] = e01; d10[NS - 1] = e10; d11[NS - 1] = e11; }
+        }
+      }
+      // rotate: slot 0 of idx_run is always the current one; the dots land in slot NS-1 and move down with the rotation, so
+      // after NS iterations slot j holds the dots of sample sub + 4 j
+#pragma unroll
+      for (int i = 0; i + 1 < NS; ++i) { idx_run[i] = idx_run[i + 1]; }
+      if (j + 1 < NS) {
+#pragma unroll
+        for (int i = 0; i + 1 < NS; ++i) { d00[i] = d00[i + 1]; d01[i] = d01[i + 1]; d10[i] = d10[i + 1]; d11[i] = d11[i + 1]; }
+      }
+    }
+    // ---- per-sample gradients of this lane's samples ----
+    float dA[NS], gx[NS], gy[NS];
+    float dotp = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const float c00 = (vmask[j] & 1) ? d00[j] : 0.f, c01 = (vmask[j] & 2) ? d01[j] : 0.f;
+      const float c10 = (vmask[j] & 4) ? d10[j] : 0.f, c11 = (vmask[j] & 8) ? d11[j] : 0.f;
+      dA[j] = (1.f - ly[j]) * ((1.f - lx[j]) * c00 + lx[j] * c01) + ly[j] * ((1.f - lx[j]) * c10 + lx[j] * c11);
+      gx[j] = pr[j] * ((1.f - ly[j]) * (c01 - c00) + ly[j] * (c11 - c10));
+      gy[j] = pr[j] * ((1.f - lx[j]) * (c10 - c00) + lx[j] * (c11 - c01));
+      dotp = fmaf(pr[j], dA[j], dotp);
+    }
+    dotp = quad_add(dotp);
+    if (live) {
+      float* drow = a.doffw + bq * a.ldo;
+      float* doff = drow + m * LP * 2;
+      float* dlog = drow + a.M * LP * 2 + m * LP;
+      float* pp = a.probs + bq * (a.M * LP) + m * LP;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int smp = sub + 4 * j;
+        if (smp < LP) {
+          *reinterpret_cast<float2*>(doff + smp * 2) = make_float2(gx[j], gy[j]);
+          dlog[smp] = pr[j] * (dA[j] - dotp);
+          pp[smp] = pr[j];
+        }
+      }
+    }
+  }
+  if (!staged) __syncthreads();        // waves without a query still take part in the block's one barrier
+}
+
 // d value via LDS-privatised scatter.  Float LDS atomics run at ~1 lane / 4 clk on gfx950 (measured: 245 clk per
 // wave-level ds_add_f32) while integer LDS atomics are native rate, so contributions are accumulated in 32-bit fixed
 // point.  The scale is safe by construction: a query adds at most |g| to any (pixel, channel) (its sample weights are
@@ -714,6 +889,23 @@ static int msda_launch_fwd_lds(const MsdaArgs& a, int L, int P, int chunks, int 
 }
 
 template <class T>
+static int msda_launch_bwd_grad_lds(const MsdaArgs& a, int L, int P, int chunks, int qpb, int guard, size_t slab, hipStream_t st) {
+#define MSDA_BWD_GLDS_CASE(LL, PP)                                                                                        \
+  if (L == LL && P == PP) {                                                                                             \
+    static bool attr = false;                                                                                           \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_bwd_lds_kernel<T, LL, PP>), dim3(a.B * a.M * chunks), dim3(1024), slab, st, a, qpb, chunks, guard); \
+    return check_launch("emrt_msda_bwd(lds gradients)");                                                                \
+  }
+  MSDA_BWD_GLDS_CASE(3, 6)
+  MSDA_BWD_GLDS_CASE(4, 4)
+  MSDA_BWD_GLDS_CASE(3, 4)
+  MSDA_BWD_GLDS_CASE(1, 4)
+#undef MSDA_BWD_GLDS_CASE
+  return fail("emrt_msda_bwd", "unsupported (levels, points)");
+}
+
+template <class T>
 static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t lds, hipStream_t st) {
 #define MSDA_LDS_CASE(LL, PP)                                                                                 \
   if (L == LL && P == PP) {                                                                                   \
@@ -807,7 +999,22 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     EMRT_REQUIRE(ng > 0, "value map rows too long for the LDS slab");
     int npix_max = 0;
     for (int g = 0; g < ng; ++g) npix_max = a.g_npix[g] > npix_max ? a.g_npix[g] : npix_max;
-    int rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
+    // offset / logit gradients: from the LDS-staged slab when it fits (same conditions and launch shape as the forward)
+    int wmax = 1;
+    for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
+    const int guard = wmax + 2;
+    const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
+    int rc;
+    if (dtype == EMRT_BF16 && !dref && slab <= 159 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_bwd_global) {
+      int chunks = (256 + B * M / 2) / (B * M);
+      if (chunks > (Lq + 127) / 128) chunks = (Lq + 127) / 128;
+      if (chunks < 1) chunks = 1;
+      const int qpb = (Lq + chunks - 1) / chunks;
+      chunks = (Lq + qpb - 1) / qpb;
+      rc = msda_launch_bwd_grad_lds<bf16_t>(a, L, P, chunks, qpb, guard, slab, st);
+    } else {
+      rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
+    }
     if (rc) return rc;
     a.g_npix_max = (npix_max + 3) & ~3;          // keeps the records 16-byte aligned
     const size_t lds = (size_t)a.g_npix_max * MSDA_SLAB_PITCH * sizeof(int) + 32 * 32 * (sizeof(float4) + sizeof(int));

@@ -92,6 +92,21 @@ def test_msda_bench_shape_bf16_vs_oracle(cfg):
     # dvalue: fixed-point LDS scatter then ONE bf16 rounding; doffw: fp32 from bf16 operands
     assert rel_v < 6e-3 and rel_o < 6e-3, (rel_v, rel_o)
     close("msda dvalue (bench shape)", host(dv), gv, BF16, atol=6e-2 * float(gv.abs().max()) / 8, rtol=2e-2)
+    # the LDS-staged gradient kernel (encoder calls) against the global-gather one: same math, other summation order
+    old = L_.set_tuning("msda_bwd_global", 1)
+    try:
+        tape = Tape()
+        c.tape = tape
+        y2 = Fn.msda(vd, od, rd, shapes, M, Pn)
+        c.tape = None
+        tape.watch(vd)
+        tape.watch(od)
+        dv2, do2 = run_bwd(tape, [(y2, dev(dy))], [vd, od])
+    finally:
+        L_.set_tuning("msda_bwd_global", old)
+    rel_k = ((host(do) - host(do2)).norm() / host(do2).norm()).item()
+    assert rel_k < 1e-5, rel_k
+    assert (host(dv) - host(dv2)).abs().max().item() <= 2e-2 * float(gv.abs().max())       # one bf16 ulp where the probabilities differ in the last bit
 
 
 def test_msda_lds_scatter_is_bit_reproducible():
