@@ -29,6 +29,8 @@ struct ConvArgs {
   const void* w;
   void* out;
   const float* bias;
+  const float* scale;   // optional per-output-channel factor applied to the accumulator before the bias: an eval-mode BatchNorm folded
+                        // into the convolution (y = conv * gamma / sqrt(var + eps) + (beta - mean * gamma / sqrt(var + eps)))
   const void* res;
   int N, H, W, C, ldin;
   long long in_bs;
@@ -391,9 +393,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       const int cg = t % CGR, rr = t / CGR;
       const int n0 = bn * BN + cg * 8;
       const bool col_ok = n0 < p.OC;                 // OC % 8 == 0: a group is all in or all out
-      float bv[8], ss[8], sq[8];
+      float bv[8], sv[8], ss[8], sq[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && col_ok) ? p.bias[n0 + e] : 0.f; ss[e] = 0.f; sq[e] = 0.f; }
+      for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && col_ok) ? p.bias[n0 + e] : 0.f; sv[e] = (p.scale && col_ok) ? p.scale[n0 + e] : 1.f; ss[e] = 0.f; sq[e] = 0.f; }
       const T* resp = (const T*)p.res;
       const T* ymask = (const T*)p.mask_y;
 #pragma unroll 2
@@ -409,7 +411,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sv[e], bv[e]);
         if (resp) {
           float w8[8];
           Vec8<T>::load(resp + (long long)e_nb * p.res_bs + (long long)e_pix * p.ldres + n0, w8);
@@ -469,12 +471,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   const T* resp = (const T*)p.res;
   const T* ymask = (const T*)p.mask_y;
   float st_s[TN], st_q[TN];
-  float bias_v[TN];
+  float bias_v[TN], scale_v[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     st_s[j] = 0.f; st_q[j] = 0.f;
     const int n = bn * BN + (wc * TN + j) * 32 + frow;
     bias_v[j] = (p.bias && n < p.OC) ? p.bias[n] : 0.f;
+    scale_v[j] = (p.scale && n < p.OC) ? p.scale[n] : 1.f;
   }
   long long m_cur = (long long)bm * BM + wr * TM * 32 + 4 * fh;
   int e_nb = (int)(m_cur / OHW);
@@ -496,7 +499,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       for (int j = 0; j < TN; ++j) {
         const int n = bn * BN + (wc * TN + j) * 32 + frow;
         if (n >= p.OC) continue;
-        float v = acc[i][j][r] + bias_v[j];
+        float v = fmaf(acc[i][j][r], scale_v[j], bias_v[j]);
         if (resp) v += to_f32(resp[rbase + n]);
         if (p.relu) v = fmaxf(v, 0.f);
         float second = 0.f;              // what the second statistic multiplies v with
@@ -943,7 +946,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
                            int ldres, long long res_bs,
                            int KH, int KW, int stride, int pad,
                            int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
-                           int dilation, int dtype, void* stream) {
+                           int dilation, const float* out_scale, int dtype, void* stream) {
   EMRT_REQUIRE(in && w_packed && out, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
@@ -962,7 +965,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
     EMRT_REQUIRE(in_bs >= 0 && in_ext < (1ll << 31) && w_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
   }
   ConvArgs a;
-  a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.res = residual;
+  a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.scale = out_scale; a.res = residual;
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
@@ -1359,7 +1362,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
     EMRT_REQUIRE((long long)H * W < (1 << 24) && (long long)ldx * esz < (1 << 24) && stride < (1 << 12), "map too large for the 24-bit address arithmetic");
   }
   ConvArgs d;       // dgrad: a convolution of dy with the transposed weights, output = dx (dense NHWC)
-  d.in = dy; d.w = w_bwd_packed; d.out = dx; d.bias = nullptr; d.res = nullptr;
+  d.in = dy; d.w = w_bwd_packed; d.out = dx; d.bias = nullptr; d.scale = nullptr; d.res = nullptr;
   d.N = N; d.H = OH; d.W = OW; d.C = OC; d.ldin = lddy; d.in_bs = dy_bs;
   d.OH = H; d.OW = W; d.OC = C; d.ldout = lddx; d.out_bs = dx_bs;
   d.ldres = 0; d.res_bs = 0;
@@ -1432,7 +1435,7 @@ __global__ __launch_bounds__(256, 2) void bwd_group_kernel(BwdGroupArgs g) {
 }
 
 static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
-  a.in = d.in; a.w = d.w_packed; a.out = d.out; a.bias = d.bias; a.res = d.residual;
+  a.in = d.in; a.w = d.w_packed; a.out = d.out; a.bias = d.bias; a.scale = nullptr; a.res = d.residual;
   a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldin = d.ldin; a.in_bs = d.in_bs;
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
   a.ldres = d.ldres; a.res_bs = d.res_bs;
@@ -1498,7 +1501,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
   for (int i = 0; i < n; ++i) {
     const EmrtConvBwdDesc& b = descs[i];
     ConvArgs& d = g.d[i];
-    d.in = b.dy; d.w = b.w_bwd_packed; d.out = b.dx; d.bias = nullptr; d.res = b.accumulate ? b.dx : nullptr;
+    d.in = b.dy; d.w = b.w_bwd_packed; d.out = b.dx; d.bias = nullptr; d.scale = nullptr; d.res = b.accumulate ? b.dx : nullptr;
     d.N = b.N; d.H = b.OH; d.W = b.OW; d.C = b.OC; d.ldin = b.lddy; d.in_bs = b.dy_bs;
     d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;

@@ -1048,6 +1048,33 @@ extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres,
   return check_launch("emrt_bn_apply");
 }
 
+// Eval-mode BatchNorm as a per-channel affine map, for every BatchNorm of a model in one launch: block i handles row i of
+// desc = [n][7] int64 (gamma, beta offsets into `params`; running mean, variance offsets into `buffers`; C; offset into `out`; offset
+// of the producing convolution's own bias in `params` or -1) and writes out[o .. o+C) = s = gamma / sqrt(var + eps),
+// out[o+C .. o+2C) = beta + (conv_bias - mean) * s.  The pair is folded into the producing
+// convolution's epilogue (emrt_conv2d: out_scale / bias), so inference launches no BatchNorm kernel and writes no pre-BN tensor.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ params, const float* __restrict__ buffers,
+                                                      const long long* __restrict__ desc, float eps, float* __restrict__ out) {
+  const long long* d = desc + 7 * (long long)blockIdx.x;
+  const float* gamma = params + d[0];
+  const float* beta = params + d[1];
+  const float* mean = buffers + d[2];
+  const float* var = buffers + d[3];
+  const int C = (int)d[4];
+  float* o = out + d[5];
+  const float* cbias = d[6] >= 0 ? params + d[6] : nullptr;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float sc = gamma[c] * rsqrtf(var[c] + eps);
+    o[c] = sc;
+    o[C + c] = beta[c] + ((cbias ? cbias[c] : 0.f) - mean[c]) * sc;
+  }
+}
+extern "C" int emrt_bn_fold(const float* params, const float* buffers, const long long* desc, int n, float eps, float* out, void* stream) {
+  EMRT_REQUIRE(params && buffers && desc && out && n > 0, "null pointer");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, params, buffers, desc, eps, out);
+  return check_launch("emrt_bn_fold");
+}
+
 // BN backward step 1: sums[2C] (fp64, PRE-ZEROED) += (sum dy', sum dy'*xhat); y (post-ReLU output) may be null when no ReLU was fused.
 extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean,
                                   const float* invstd, long long M, int C, double* sums, int dtype, void* stream) {

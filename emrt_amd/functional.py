@@ -286,8 +286,10 @@ class GemmWeight:
         self.need_bwd = True
 
 
-def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1):
-    """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice)."""
+def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1,
+           out_scale=None, out_shift=None):
+    """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice).
+    out_scale / out_shift (fp32 [OC], inference only): out = conv * out_scale + out_shift -- an eval-mode BatchNorm folded in."""
     c = ctx()
     N, H, W, C, ldin, in_bs = _check_map(x)
     assert C == w.C, (C, w.C)
@@ -302,9 +304,10 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     ldres = res_bs = 0
     if residual is not None:
         _, _, _, _, ldres, res_bs = _check_map(residual)
-    _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
+    assert out_scale is None or c.tape is None, "BatchNorm folding is inference only"     # (out_shift already holds w.bias * scale)
+    _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(out_shift) if out_scale is not None else P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
               OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), None, 0, 0,
-              dil, c.dtype, c.stream)
+              dil, P(out_scale), c.dtype, c.stream)
     tape = c.tape
     bn_rec = getattr(x, "_bn_rec", None)      # x = relu(BatchNorm(.)) fresh from batch_norm(): see the dgrad call below
     drop_rec = getattr(x, "_drop_rec", None)  # x = dropout(relu(linear(.))) with this layer as its only consumer
@@ -365,7 +368,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                     _L().call("emrt_conv2d", P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), None, P(dx) if slot is not None else None,
                               N, OH, OW, w.OC, lddy, dy_bs, H, W, C, lddx, dx_bs, lddx if slot is not None else 0, dx_bs if slot is not None else 0,
                               w.KH, w.KW, stride, pad, 1, 0, 0, P(ysums), P(ymask), ldin if ymask is not None else 0,
-                              in_bs if ymask is not None else 0, dil, c.dtype, c.stream)
+                              in_bs if ymask is not None else 0, dil, None, c.dtype, c.stream)
                     c.join()
                 if addend is not None:
                     tape.replace_grad(x, dx)
@@ -407,6 +410,8 @@ class BNState:
     def __init__(self, C, eps=1e-5, momentum=0.9, sync=False):
         self.C, self.eps, self.momentum, self.sync = C, eps, momentum, sync
         self.gamma = self.beta = self.dgamma = self.dbeta = self.run_mean = self.run_var = None
+        self.fold_scale = self.fold_shift = None     # eval-mode affine form, views of ParamStore.bn_fold
+        self.fold_conv = None                        # the biased conv whose bias the fold absorbs (nn.BatchNorm2D(after=))
 
 
 BN_REPLICAS = 8     # fp64 BatchNorm sums are [8][2C]: producers spread atomics over replicas, consumers add them
@@ -505,8 +510,13 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
 
 
 def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
-    """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training)."""
+    """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training).  Inference: the BatchNorm is
+    an affine map of running statistics and is folded into the conv's epilogue -- no BatchNorm launch, no intermediate tensor."""
     c = ctx()
+    if c.fold_live and not c.training and c.tape is None and (conv.gw.bias is None or bn.state.fold_conv is conv):
+        scale, shift = bn.state.fold_scale, bn.state.fold_shift      # ParamStore.fold_bn(): refreshed at the top of every eval forward
+        return conv2d(x, conv.gw, conv.stride, conv.padding, relu=relu, residual=residual, out=out, need_dx=False,
+                      dilation=getattr(conv, "dilation", 1), out_scale=scale, out_shift=shift)
     sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
     y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums, dilation=getattr(conv, "dilation", 1))
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)

@@ -95,6 +95,7 @@ class ParamStore:
         self.desc = None
         self.total_tiles = 0
         self.dirty = True
+        self.bn_states, self.bn_fold, self.bn_desc = [], None, None
 
     def segment_ranges(self, segment_prefixes):
         """Partition [0, n_train) of the flat buffers by parameter-name prefix: returns [ranges_0, ranges_1, ...] where
@@ -162,6 +163,31 @@ class ParamStore:
         self.ndesc, self.total_tiles = len(rows), tiles
         self.dirty = True
 
+    def register_bn(self, st):
+        self.bn_states.append(st)
+
+    def fold_bn(self):
+        """Inference: every BatchNorm as (scale, shift) of its running statistics, one launch at the top of each eval forward (so a
+        state-dict load, an optimizer step or a direct edit of the buffers is always seen); conv_bn folds them into the conv."""
+        if not self.bn_states:
+            return
+        if self.bn_desc is None:
+            rows, off = [], 0
+            m0, b0 = self.master.data_ptr(), self.buffers.data_ptr()
+            for st in self.bn_states:
+                assert st.eps == self.bn_states[0].eps
+                cb = st.fold_conv.gw.bias if st.fold_conv is not None else None
+                rows.append([(st.gamma.data_ptr() - m0) // 4, (st.beta.data_ptr() - m0) // 4, (st.run_mean.data_ptr() - b0) // 4,
+                             (st.run_var.data_ptr() - b0) // 4, st.C, off, (cb.data_ptr() - m0) // 4 if cb is not None else -1])
+                off += 2 * st.C
+            assert all(0 <= r[0] < self.master.numel() and 0 <= r[2] < self.buffers.numel() for r in rows)
+            self.bn_fold = torch.empty(off, dtype=torch.float32, device=self.device)
+            self.bn_desc = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            for st, r in zip(self.bn_states, rows):
+                st.fold_scale, st.fold_shift = self.bn_fold[r[5]:r[5] + st.C], self.bn_fold[r[5] + st.C:r[5] + 2 * st.C]
+        _lib.lib().call("emrt_bn_fold", Fn.P(self.master), Fn.P(self.buffers), Fn.P(self.bn_desc), len(self.bn_states),
+                        self.bn_states[0].eps, Fn.P(self.bn_fold), ctx().stream)
+
     def pack(self):
         if self.desc is not None:
             _lib.lib().call("emrt_pack_weights", Fn.P(self.master), Fn.P(self.packed), Fn.P(self.desc), self.ndesc, self.total_tiles,
@@ -222,7 +248,8 @@ class BatchNorm2D(HipLayer):
     """Paddle-semantics BN (momentum 0.9 => running = 0.9*running + 0.1*batch; biased running variance); buffers keep
     Paddle's names `_mean` / `_variance`.  sync=True marks the reference's nn.SyncBatchNorm layers."""
 
-    def __init__(self, c, sync=False):
+    def __init__(self, c, sync=False, after=None):
+        """after: the Conv2D feeding this layer when that conv has a bias of its own (the eval-mode fold absorbs it)."""
         super().__init__()
         self.c = self.C = c
         self.weight = tnn.Parameter(torch.ones(c))
@@ -230,12 +257,14 @@ class BatchNorm2D(HipLayer):
         self.register_buffer("_mean", torch.zeros(c))
         self.register_buffer("_variance", torch.ones(c))
         self.state = Fn.BNState(c, 1e-5, 0.9, sync)
+        self.state.fold_conv = after          # on the plain state object: not a sub-module, not in the state dict
 
     def bind(self, store, prefix):
         st = self.state
         st.gamma, st.beta = self.weight.data.view(-1), self.bias.data.view(-1)
         st.dgamma, st.dbeta = self.weight.grad.view(-1), self.bias.grad.view(-1)
         st.run_mean, st.run_var = self._buffers["_mean"], self._buffers["_variance"]
+        store.register_bn(st)
 
     def forward(self, x, relu=False, residual=None, out=None, sums=None):
         return Fn.batch_norm(x, self.state, relu=relu, residual=residual, out=out, sums=sums)

@@ -202,6 +202,8 @@ class Context:
         self._side = None
         self._in_backward = False # Tape.backward() is running (step-scoped allocations allowed)
         self._main = None         # the stream every launch of this runtime goes to (torch's current stream after init_device)
+        self.fold_eval_bn = True  # inference: BatchNorm folded into the producing conv's epilogue (False: separate emrt_bn_apply, A/B knob)
+        self.fold_live = False    # True inside an eval forward whose ParamStore.fold_bn() has just run (the folds are fresh)
         self.capture = None       # engine.GraphSequence while a step is being captured: collective() then breaks the graph
         self.sync_always = False  # issue the SyncBatchNorm collectives even in a 1-rank group (single-GPU test of the N > 1 path)
 

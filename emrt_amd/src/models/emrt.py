@@ -585,7 +585,8 @@ class UpHead(hnn.HipLayer):  # :115-181 (num_conv == 3)
         self.conv_1 = hnn.Conv2D(256, 256, 3, 1, 1)
         self.conv_2 = hnn.Conv2D(256, 256, 3, 1, 1)
         self.conv_3 = hnn.Conv2D(256, num_classes, 1)
-        self.syncbn_fc_0, self.syncbn_fc_1, self.syncbn_fc_2 = hnn.BatchNorm2D(256), hnn.BatchNorm2D(256), hnn.BatchNorm2D(256)
+        self.syncbn_fc_0, self.syncbn_fc_1, self.syncbn_fc_2 = (hnn.BatchNorm2D(256, after=self.conv_0), hnn.BatchNorm2D(256, after=self.conv_1),
+                                                                hnn.BatchNorm2D(256, after=self.conv_2))
 
     def forward(self, x):  # :164-180
         x = Fn.conv_bn(self.conv_0, self.syncbn_fc_0, x, relu=True)
@@ -716,12 +717,16 @@ class EMRT(hnn.HipLayer):  # :184-304
         c.training = self.training
         if self.training:
             c.begin_step()
+        elif c.fold_eval_bn:
+            self.store.fold_bn()
+            c.fold_live = True
         tape = Tape() if self.training else None
         c.tape = tape
         try:
             out = self.forward(images)
         finally:
             c.tape = None
+            c.fold_live = False
         res = LogitsTuple(out)
         res.tape = tape
         return res

@@ -46,11 +46,13 @@ int emrt_get_tuning(const char* name, int* value);
  * 134-138,201-209; decoders/fcn_head.py:52,66; EMRT_utils/transformer_encoder_decoder.py:125-144,374-378
  * and nn.Linear / F.linear: transformer_encoder_decoder.py:36-42,118-121,259-262,371; EMRT_utils/layers.py:221-229,306.
  * dilation: spacing of the kernel taps (1 = dense; the dilated stages of the resnet50c backbone, backbones/resnet.py:65-66,112-124).
- * mode 0: out = conv(in, W) [+bias][+residual][relu];  w_packed = [OC][KH][KW][C]  (dims N,H,W,C describe `in`)
+ * out_scale (nullable, fp32 [OC]): the accumulator is multiplied by it before the bias -- an eval-mode BatchNorm folded into the
+ * convolution (emrt_bn_fold gives scale and shift; the shift goes in as `bias`), so inference launches no BatchNorm kernel.
+ * mode 0: out = conv(in, W) * out_scale [+bias][+residual][relu];  w_packed = [OC][KH][KW][C]  (dims N,H,W,C describe `in`)
  * mode 1: data gradient; `in` is dY (N,H,W,C = its dims), out is dX (OH,OW,OC), w_packed = [Cin][KH][KW][Cout].
  * bn_stats (nullable): fp64 [8][2*OC] (8 replicas, see BatchNorm below), pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
  * (the BatchNorm statistics of the layer that follows, fused so the activation is not re-read). */
-int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dilation, int dtype, void* stream);
+int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dilation, const float* out_scale, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream);
 /* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE
@@ -87,6 +89,11 @@ int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, voi
 size_t emrt_colreduce_workspace_bytes(long long M, int C);
 int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream);
 int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
+/* eval: every BatchNorm of a model as an affine map, one launch.  desc: device int64 [n][7] = (gamma offset, beta offset) into
+ * `params`, (running mean offset, running variance offset) into `buffers`, C, offset into `out`, offset in `params` of the bias of
+ * the convolution feeding this BatchNorm or -1; writes out[o..o+C) = s = gamma / sqrt(var + eps) and
+ * out[o+C..o+2C) = beta + (conv_bias - mean) * s: emrt_conv2d's out_scale / bias. */
+int emrt_bn_fold(const float* params, const float* buffers, const long long* desc, int n, float eps, float* out, void* stream);
 int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, int dtype, void* stream);
 int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */

@@ -94,11 +94,11 @@ def main():
 
         def fwd():
             L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC, 0, 0,
-                               k, k, s, pad, 0, 0, 0, None, None, 0, 0, 1, 1, stream)
+                               k, k, s, pad, 0, 0, 0, None, None, 0, 0, 1, None, 1, stream)
 
         def dgrad():
             L._raw_emrt_conv2d(P(y), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0,
-                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, 1, stream)
+                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, None, 1, stream)
 
         def wgrad():
             L._raw_emrt_conv2d_wgrad(P(x), P(y), P(dw), N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC,
