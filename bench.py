@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--overlap", default="", choices=["", "pair", "deferred"], help="wgrad on a second stream (A/B experiment)")
     ap.add_argument("--two-phase", action="store_true", help="run the N>1 step structure (graphs around RCCL all-reduce) in a 1-rank group")
     ap.add_argument("--no-early-exchange", action="store_true", help="N>1: one all-reduce after the whole backward (A/B experiment)")
+    ap.add_argument("--two-phase-no-syncbn", action="store_true", help="--two-phase without the SyncBatchNorm collectives (A/B: what the graph cuts cost)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -248,6 +249,9 @@ def main():
         torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     eng = TrainEngine(model, opt, loss_fn, world, use_graph=not args.no_graph, overlap=args.overlap or False,
                       two_phase=True if args.two_phase else None, early_exchange=not args.no_early_exchange)
+    if args.two_phase_no_syncbn:
+        from emrt_amd.runtime import ctx as _ctx
+        _ctx().sync_always = False
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.randn(B, 3, S, S, generator=g).to(dev)
     labels = torch.randint(0, ncls, (B, S, S), generator=g)

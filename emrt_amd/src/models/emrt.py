@@ -738,8 +738,8 @@ class EMRT(hnn.HipLayer):  # :184-304
         x = Fn.nchw_to_nhwc(inputs.contiguous())
         B, H, W, _ = x.shape
         c1, c2, c3, c4 = self.backbone(x)
-        S = H // 8
-        psp_cat = c.empty((B, S, S, 256 * (2 + len(self.psp_scale))))
+        SH, SW = H // 8, W // 8                 # x_context.shape[2:] (:283-288); tiles need not be square
+        psp_cat = c.empty((B, SH, SW, 256 * (2 + len(self.psp_scale))))
         x_context = self.spatial_branch(x, out=Fn.narrow(psp_cat, 3, 0, 256))
         x_psp = self.psp_module(x_context)
         hs, memory, shapes, spans = self.model([c2, c3, c4], x_psp)
@@ -749,11 +749,11 @@ class EMRT(hnn.HipLayer):  # :184-304
         idx = 0
         for i, k in enumerate(self.psp_scale):  # :281-291
             pooled = Fn.tokens_as_map(Fn.narrow(hs, 1, idx, k * k), k, k)
-            Fn.resize_bilinear(pooled, S, S, True, out=Fn.narrow(psp_cat, 3, 256 * (1 + i), 256))
+            Fn.resize_bilinear(pooled, SH, SW, True, out=Fn.narrow(psp_cat, 3, 256 * (1 + i), 256))
             idx += k * k
         o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True)
         o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
-        o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=S * S)
+        o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW)
         logits = self.uphead(o)
         if self.training or self.compute_aux_in_eval:
             aux = self.auxlayer(c3)      # x16 bilinear; the reference's final align_corners=True resize is the identity here

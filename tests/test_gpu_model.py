@@ -539,3 +539,50 @@ def test_multi_scale_flip_inference_matches_oracle():
     margin = (top2[:, 0] - top2[:, 1])[0]
     bad = (pred.cpu()[0, 0] != want_pred[0, 0]) & (margin > 2e-3)
     assert not bad.any(), int(bad.sum())
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 96, 160), (3, 160, 64)])
+def test_non_square_tiles_match_oracle(B, H, W):
+    """The reference takes any H, W that are multiples of 32 (paddle_EMRT.py:293); every tile the configs use is square, so a
+    swapped height / width in a kernel's geometry would go unseen.  Ragged case: odd batch, H != W, three different level
+    shapes (12x20 / 6x10 / 3x5 ...), a quarter of the labels ignored: eval logits, then train-mode loss and the whole
+    gradient against the float64 oracle."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, H, W, generator=g)
+    labels = torch.randint(0, 6, (B, H, W), generator=g)
+    labels[torch.rand(B, H, W, generator=g) < 0.25] = 255
+    ref, model = build_pair("resnet18", x, perturb=True)
+    ref.double().eval()
+    model.eval()
+    with torch.no_grad():
+        want = ref(x.double())
+    got = model(x.cuda())
+    for a, b in zip(got, want):
+        assert a.shape == (B, 6, H, W)
+        assert (a.cpu() - b.float()).abs().max().item() < 1e-3
+    ref.train()
+    model.train()
+    out_r = ref(x.double())
+    loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
+    loss_r.backward()
+    model.clear_gradients()
+    out = model(x.cuda())
+    loss = get_loss_function(make_config("resnet18"))(out, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (out[0].cpu() - out_r[0].detach().float()).abs().max().item() < 1e-3
+    assert abs(loss.item() - loss_r.item()) < 1e-4 * max(1.0, abs(loss_r.item()))
+    refp = dict(ref.named_parameters())
+    num = den = dot = 0.0
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None:
+            continue
+        gr, gg = gr.double(), p.grad.cpu().double()
+        num += float(((gg - gr) ** 2).sum())
+        den += float((gr ** 2).sum())
+        dot += float((gg * gr).sum())
+    gn = sum(float((p.grad.cpu().double() ** 2).sum()) for n, p in model.named_parameters() if refp[n].grad is not None)
+    cos = dot / (den ** 0.5 * gn ** 0.5)
+    print("non-square %dx%dx%d: whole-gradient rel err %.3g, cosine %.6f" % (B, H, W, (num / den) ** 0.5, cos))
+    assert cos > 0.999 and (num / den) ** 0.5 < 0.05
