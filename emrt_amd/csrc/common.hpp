@@ -50,6 +50,10 @@ struct Tuning {
   int msda_fwd_probe;   // timing experiments only (results are WRONG): 1 = no gather, 2 = no staging, 4 = no preparation
   int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
+  int gn_group_blocks;  // 1 = multi-level GroupNorm with one block per (image, group) instead of the row-major stats + apply pair
+  int gn_stat_rows;     // row-major GroupNorm: token rows per block of the forward statistics launch (32)
+  int gn_bwd_stat_rows; // ... of the backward sums launch (32; each block also adds 2 C parameter-gradient atomics)
+  int gn_apply_rows;    // ... of the apply / dx launches (8)
 };
 extern Tuning g_tune;
 

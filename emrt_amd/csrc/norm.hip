@@ -781,6 +781,198 @@ __global__ __launch_bounds__(256) void gn_levels_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- row-major multi-level GroupNorm (8 channels per group: the EMRT case, GroupNorm(32, 256)) ------------------------------------
+// The one-block-per-(image, group) kernels above read 16 bytes out of every 512-byte token row: 2 KB in flight per block and one
+// dependent load per iteration (44 us at B = 16 for 33 MB of traffic).  Here a thread owns one GROUP of one row (8 channels = one
+// 16-byte access for bf16 / fp16), 256 / G rows per pass, so a block reads whole rows; the statistics become a separate launch:
+//   stats:  block = (image, level, chunk of rows) -> per-group partial sums, fp64 atomics into ws[(level, image, group)][2]
+//   apply:  every thread re-derives mean / rstd of its group from ws (the block of chunk 0 records them for the backward)
+// and the same split backward (sums of dy*gamma, dy*gamma*xhat per group + dgamma / dbeta per channel, then dx).
+struct GnRows {
+  GnLevels lv;
+  int rows_per_block;
+  int nblk[GN_MAX_LEVELS];       // blocks per image of each level
+  int per_image;
+};
+__device__ __forceinline__ void gn_rows_locate(const GnRows& g, int& n, int& l, int& r0, int& r1, int& HW, int& row0) {
+  n = blockIdx.x / g.per_image;
+  int b = blockIdx.x % g.per_image;
+  l = 0;
+#pragma unroll
+  for (int k = 0; k < GN_MAX_LEVELS - 1; ++k)
+    if (l == k && b >= g.nblk[k]) { b -= g.nblk[k]; l = k + 1; }
+  HW = g.lv.hw[0]; row0 = g.lv.start[0];
+#pragma unroll
+  for (int k = 1; k < GN_MAX_LEVELS; ++k)
+    if (l == k) { HW = g.lv.hw[k]; row0 = g.lv.start[k]; }
+  r0 = b * g.rows_per_block;
+  r1 = r0 + g.rows_per_block;
+  if (r1 > HW) r1 = HW;
+}
+template <int K>
+__device__ __forceinline__ const float* gn_pick(const float* const (&a)[GN_MAX_LEVELS], int l) {
+  const float* p = a[0];
+#pragma unroll
+  for (int k = 1; k < GN_MAX_LEVELS; ++k)
+    if (l == k) p = a[k];
+  return p;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_rows_stats_kernel(const T* __restrict__ x, int ldx, long long x_bs, GnRows gr, double* __restrict__ ws,
+                                                            int N, int G) {
+  __shared__ float red[256][2];
+  int n, l, r0, r1, HW, row0;
+  gn_rows_locate(gr, n, l, r0, r1, HW, row0);
+  const int g = threadIdx.x % G, rl = threadIdx.x / G, nrl = 256 / G;
+  const T* xp = x + (long long)n * x_bs + (long long)row0 * ldx + g * 8;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = r0 + rl; p < r1; p += nrl) {
+    float v[8];
+    Vec8<T>::load(xp + (long long)p * ldx, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0 += v[e]; s1 = fmaf(v[e], v[e], s1); }
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * G) {
+    const int gg = threadIdx.x >> 1, w = threadIdx.x & 1;
+    double a = 0.0;
+    for (int t = 0; t < nrl; ++t) a += (double)red[t * G + gg][w];
+    atomicAdd(&ws[(((long long)l * N + n) * G + gg) * 2 + w], a);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_rows_apply_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ res, int ldres,
+                                                            long long res_bs, T* __restrict__ out, int ldout, long long out_bs, GnRows gr,
+                                                            const double* __restrict__ ws, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int N, int G, float eps, int gelu) {
+  int n, l, r0, r1, HW, row0;
+  gn_rows_locate(gr, n, l, r0, r1, HW, row0);
+  const int g = threadIdx.x % G, rl = threadIdx.x / G, nrl = 256 / G;
+  const long long sidx = ((long long)l * N + n) * G + g;
+  const double cnt = (double)HW * 8.0;
+  const double mu_d = ws[sidx * 2] / cnt;
+  double var = ws[sidx * 2 + 1] / cnt - mu_d * mu_d;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (mean_out && r0 == 0 && rl == 0) { mean_out[sidx] = mu; rstd_out[sidx] = rs; }      // [level][n][g]
+  const float* gam = gn_pick<0>(gr.lv.gamma, l) + g * 8;
+  const float* bet = gn_pick<0>(gr.lv.beta, l) + g * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = rs * gam[e]; sh[e] = bet[e] - mu * sc[e]; }
+  const T* xp = x + (long long)n * x_bs + (long long)row0 * ldx + g * 8;
+  for (int p = r0 + rl; p < r1; p += nrl) {
+    float v[8], o[8];
+    Vec8<T>::load(xp + (long long)p * ldx, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float u = fmaf(v[e], sc[e], sh[e]);
+      o[e] = gelu ? gelu_f(u) : u;
+    }
+    if (res) {
+      float w[8];
+      Vec8<T>::load(res + (long long)n * res_bs + (long long)(row0 + p) * ldres + g * 8, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += w[e];
+    }
+    Vec8<T>::store(out + (long long)n * out_bs + (long long)(row0 + p) * ldout + g * 8, o);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_rows_bwd_stats_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy, int lddy,
+                                                                long long dy_bs, GnRows gr, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, double* __restrict__ ws, int N, int G, int gelu) {
+  __shared__ float chs[256][17];        // [thread][8 x (sum dd, sum dd*xhat)], padded against bank conflicts in the column read below
+  int n, l, r0, r1, HW, row0;
+  gn_rows_locate(gr, n, l, r0, r1, HW, row0);
+  const int g = threadIdx.x % G, rl = threadIdx.x / G, nrl = 256 / G;
+  const long long sidx = ((long long)l * N + n) * G + g;
+  const float mu = mean[sidx], rs = rstd[sidx];
+  const float* gam = gn_pick<0>(gr.lv.gamma, l);
+  const float* bet = gn_pick<0>(gr.lv.beta, l);
+  float ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ga[e] = gam[g * 8 + e]; be[e] = bet[g * 8 + e]; }
+  const T* xp = x + (long long)n * x_bs + (long long)row0 * ldx + g * 8;
+  const T* gp = dy + (long long)n * dy_bs + (long long)row0 * lddy + g * 8;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  for (int p = r0 + rl; p < r1; p += nrl) {
+    float v[8], d[8];
+    Vec8<T>::load(xp + (long long)p * ldx, v);
+    Vec8<T>::load(gp + (long long)p * lddy, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      s0[e] += dd;
+      s1[e] = fmaf(dd, xh, s1[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { chs[threadIdx.x][e] = s0[e]; chs[threadIdx.x][8 + e] = s1[e]; }
+  __syncthreads();
+  // thread c = channel c of the row (C = 8 G <= 256): sum over the row lanes, parameter gradients, then the group's two sums
+  const int C = G * 8;
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x, gg = c >> 3, e = c & 7;
+    float a = 0.f, b = 0.f;
+    for (int t = 0; t < nrl; ++t) { a += chs[t * G + gg][e]; b += chs[t * G + gg][8 + e]; }
+    float* dgam = nullptr; float* dbet = nullptr;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_LEVELS; ++k)
+      if (l == k) { dgam = gr.lv.dgamma[k]; dbet = gr.lv.dbeta[k]; }
+    if (dbet) atomicAdd(dbet + c, a);
+    if (dgam) atomicAdd(dgam + c, b);
+    float wa = gam[c] * a, wb = gam[c] * b;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { wa += __shfl_xor(wa, o, 64); wb += __shfl_xor(wb, o, 64); }
+    if (e == 0) {
+      const long long si = ((long long)l * N + n) * G + gg;
+      atomicAdd(&ws[si * 2], (double)wa);
+      atomicAdd(&ws[si * 2 + 1], (double)wb);
+    }
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_rows_bwd_dx_kernel(const T* __restrict__ x, int ldx, long long x_bs, const T* __restrict__ dy, int lddy,
+                                                             long long dy_bs, T* __restrict__ dx, int lddx, long long dx_bs, GnRows gr,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const double* __restrict__ ws, int N, int G, int gelu) {
+  int n, l, r0, r1, HW, row0;
+  gn_rows_locate(gr, n, l, r0, r1, HW, row0);
+  const int g = threadIdx.x % G, rl = threadIdx.x / G, nrl = 256 / G;
+  const long long sidx = ((long long)l * N + n) * G + g;
+  const float mu = mean[sidx], rs = rstd[sidx];
+  const double inv = 1.0 / ((double)HW * 8.0);
+  const float A = (float)(ws[sidx * 2] * inv), Bq = (float)(ws[sidx * 2 + 1] * inv);
+  const float* gam = gn_pick<0>(gr.lv.gamma, l) + g * 8;
+  const float* bet = gn_pick<0>(gr.lv.beta, l) + g * 8;
+  float ga[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ga[e] = gam[e]; be[e] = bet[e]; }
+  const T* xp = x + (long long)n * x_bs + (long long)row0 * ldx + g * 8;
+  const T* gp = dy + (long long)n * dy_bs + (long long)row0 * lddy + g * 8;
+  for (int p = r0 + rl; p < r1; p += nrl) {
+    float v[8], d[8], o[8];
+    Vec8<T>::load(xp + (long long)p * ldx, v);
+    Vec8<T>::load(gp + (long long)p * lddy, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (v[e] - mu) * rs;
+      const float dd = gelu ? d[e] * gelu_grad_f(xh * ga[e] + be[e]) : d[e];
+      o[e] = rs * (ga[e] * dd - A - xh * Bq);
+    }
+    Vec8<T>::store(dx + (long long)n * dx_bs + (long long)(row0 + p) * lddx + g * 8, o);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim C (C % 4 == 0, C <= 1024) with fused residual add:
 //   z = a (+ b);  out = LN(z)*gamma + beta (+ post)        one wave per row, 4 rows per 256-thread block.
@@ -1289,10 +1481,24 @@ static int gn_fill_levels(GnLevels& lv, const int* level_start, const int* level
 }
 
 // GroupNorm (+GELU) (+residual) of L level slabs of token tensors [N][Lv][C] in one launch; mean/rstd are [L][N*G].
+static int gn_rows_plan(GnRows& gr, int rows_per_block) {
+  gr.rows_per_block = rows_per_block;
+  gr.per_image = 0;
+  for (int l = 0; l < GN_MAX_LEVELS; ++l) {
+    gr.nblk[l] = l < gr.lv.L ? (gr.lv.hw[l] + rows_per_block - 1) / rows_per_block : 0;
+    gr.per_image += gr.nblk[l];
+  }
+  return gr.per_image;
+}
+// the row-major path: 8 channels per group, a whole number of rows per 256-thread pass, 16-byte aligned groups
+static inline bool gn_rows_ok(int C, int G, int ld0, int ld1, int ld2, long long bs0, long long bs1, long long bs2) {
+  return C == 8 * G && 256 % G == 0 && C <= 256 && ld0 % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && bs0 % 8 == 0 && bs1 % 8 == 0 && bs2 % 8 == 0;
+}
+
 extern "C" int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out,
                                          int ldout, long long out_bs, const float* const* gamma, const float* const* beta, float* mean,
                                          float* rstd, const int* level_start, const int* level_hw, int L, int N, int C, int G, float eps,
-                                         int gelu, int dtype, void* stream) {
+                                         int gelu, double* stat_ws, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(x && out && gamma && beta && level_start && level_hw, "null pointer");
   EMRT_REQUIRE(G > 0 && C % G == 0 && gn_use_fused(1, C, G), "unsupported C / G for the one-block-per-group kernel");
@@ -1300,6 +1506,20 @@ extern "C" int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs,
   GnLevels lv;
   EMRT_REQUIRE(gn_fill_levels(lv, level_start, level_hw, L, gamma, beta, nullptr, nullptr) == 0, "1..4 levels of at most 4096 rows");
   hipStream_t st = (hipStream_t)stream;
+  if (stat_ws && mean && rstd && !g_tune.gn_group_blocks && gn_rows_ok(C, G, ldx, res ? ldres : 8, ldout, x_bs, res ? res_bs : 8, out_bs)) {
+    GnRows gs, ga;
+    gs.lv = lv; ga.lv = lv;
+    const unsigned bs = (unsigned)(gn_rows_plan(gs, g_tune.gn_stat_rows) * N), ba = (unsigned)(gn_rows_plan(ga, g_tune.gn_apply_rows) * N);
+    DT_SWITCH3(dtype,
+              hipLaunchKernelGGL((gn_rows_stats_kernel<float>), dim3(bs), dim3(256), 0, st, (const float*)x, ldx, x_bs, gs, stat_ws, N, G),
+              hipLaunchKernelGGL((gn_rows_stats_kernel<bf16_t>), dim3(bs), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, gs, stat_ws, N, G),
+              hipLaunchKernelGGL((gn_rows_stats_kernel<f16_t>), dim3(bs), dim3(256), 0, st, (const f16_t*)x, ldx, x_bs, gs, stat_ws, N, G));
+    DT_SWITCH3(dtype,
+              hipLaunchKernelGGL((gn_rows_apply_kernel<float>), dim3(ba), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, ga, stat_ws, mean, rstd, N, G, eps, gelu),
+              hipLaunchKernelGGL((gn_rows_apply_kernel<bf16_t>), dim3(ba), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, ga, stat_ws, mean, rstd, N, G, eps, gelu),
+              hipLaunchKernelGGL((gn_rows_apply_kernel<f16_t>), dim3(ba), dim3(256), 0, st, (const f16_t*)x, ldx, x_bs, (const f16_t*)res, ldres, res_bs, (f16_t*)out, ldout, out_bs, ga, stat_ws, mean, rstd, N, G, eps, gelu));
+    return check_launch("emrt_groupnorm_levels_fwd");
+  }
   DT_SWITCH3(dtype,
             hipLaunchKernelGGL((gn_levels_fwd_kernel<float>), dim3(L * N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)res, ldres, res_bs, (float*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu),
             hipLaunchKernelGGL((gn_levels_fwd_kernel<bf16_t>), dim3(L * N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)res, ldres, res_bs, (bf16_t*)out, ldout, out_bs, lv, mean, rstd, N, C, G, eps, gelu),
@@ -1310,14 +1530,26 @@ extern "C" int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs,
 extern "C" int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx,
                                          int lddx, long long dx_bs, const float* const* gamma, const float* const* beta,
                                          const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta,
-                                         const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, int dtype,
-                                         void* stream) {
+                                         const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, double* stat_ws,
+                                         int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && dx && gamma && beta && mean && rstd && level_start && level_hw, "null pointer");
   EMRT_REQUIRE(G > 0 && C % G == 0 && gn_use_fused(1, C, G), "unsupported C / G for the one-block-per-group kernel");
   GnLevels lv;
   EMRT_REQUIRE(gn_fill_levels(lv, level_start, level_hw, L, gamma, beta, dgamma, dbeta) == 0, "1..4 levels of at most 4096 rows");
   hipStream_t st = (hipStream_t)stream;
+  if (stat_ws && !g_tune.gn_group_blocks && gn_rows_ok(C, G, ldx, lddy, lddx, x_bs, dy_bs, dx_bs)) {
+    GnRows gs, ga;
+    gs.lv = lv; ga.lv = lv;
+    const unsigned bs = (unsigned)(gn_rows_plan(gs, g_tune.gn_bwd_stat_rows) * N), ba = (unsigned)(gn_rows_plan(ga, g_tune.gn_apply_rows) * N);
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((gn_rows_bwd_stats_kernel<float>), dim3(bs), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, gs, mean, rstd, stat_ws, N, G, gelu),
+              hipLaunchKernelGGL((gn_rows_bwd_stats_kernel<bf16_t>), dim3(bs), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, gs, mean, rstd, stat_ws, N, G, gelu));
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((gn_rows_bwd_dx_kernel<float>), dim3(ba), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, ga, mean, rstd, stat_ws, N, G, gelu),
+              hipLaunchKernelGGL((gn_rows_bwd_dx_kernel<bf16_t>), dim3(ba), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, ga, mean, rstd, stat_ws, N, G, gelu));
+    return check_launch("emrt_groupnorm_levels_bwd");
+  }
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((gn_levels_bwd_kernel<float>), dim3(L * N * G), dim3(256), 0, st, (const float*)x, ldx, x_bs, (const float*)dy, lddy, dy_bs, (float*)dx, lddx, dx_bs, lv, mean, rstd, N, C, G, gelu),
             hipLaunchKernelGGL((gn_levels_bwd_kernel<bf16_t>), dim3(L * N * G), dim3(256), 0, st, (const bf16_t*)x, ldx, x_bs, (const bf16_t*)dy, lddy, dy_bs, (bf16_t*)dx, lddx, dx_bs, lv, mean, rstd, N, C, G, gelu));

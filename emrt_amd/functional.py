@@ -671,7 +671,7 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
     mean = c.empty((L * B * G,), torch.float32)
     rstd = c.empty((L * B * G,), torch.float32)
     _L().call("emrt_groupnorm_levels_fwd", P(y), C, Lv * C, P(src), C, Lv * C, P(out), C, Lv * C, gam, bet, P(mean), P(rstd), starts, hws, L,
-              B, C, G, eps, 1, c.dtype, c.stream)
+              B, C, G, eps, 1, P(c.zeros_f64(L * B * G * 2)), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
@@ -683,7 +683,7 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             dgam = (ctypes.c_void_p * L)(*[_dp(g[2]) for g in gns])
             dbet = (ctypes.c_void_p * L)(*[_dp(g[3]) for g in gns])
             _L().call("emrt_groupnorm_levels_bwd", P(y), C, Lv * C, P(dout), C, Lv * C, P(dy), C, Lv * C, gam, bet, P(mean), P(rstd), dgam, dbet,
-                      starts, hws, L, B, C, G, 1, c.dtype, c.stream)
+                      starts, hws, L, B, C, G, 1, P(c.zeros_f64(L * B * G * 2)), c.dtype, c.stream)
             slot = tape.grad_slot(src)            # accumulate the data gradients straight into src's gradient when it has one
             dx = slot if slot is not None else c.empty((B, Lv, C))
             assert dx.is_contiguous()
@@ -740,7 +740,7 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
     mean = c.empty((L * B * G,), torch.float32)
     rstd = c.empty((L * B * G,), torch.float32)
     _L().call("emrt_groupnorm_levels_fwd", P(y), OC, Lv * OC, None, 0, 0, P(src), OC, Lv * OC, gam, bet, P(mean), P(rstd), starts, hws, L,
-              B, OC, G, eps, 0, c.dtype, c.stream)
+              B, OC, G, eps, 0, P(c.zeros_f64(L * B * G * 2)), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
@@ -752,7 +752,7 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
             dgam = (ctypes.c_void_p * L)(*[_dp(g[2]) for g in gns])
             dbet = (ctypes.c_void_p * L)(*[_dp(g[3]) for g in gns])
             _L().call("emrt_groupnorm_levels_bwd", P(y), OC, Lv * OC, P(dsrc), OC, Lv * OC, P(dy), OC, Lv * OC, gam, bet, P(mean), P(rstd), dgam,
-                      dbet, starts, hws, L, B, OC, G, 0, c.dtype, c.stream)
+                      dbet, starts, hws, L, B, OC, G, 0, P(c.zeros_f64(L * B * G * 2)), c.dtype, c.stream)
             slots = [tape.grad_slot(f) for f in feats]
             dxs = [s_ if s_ is not None else c.empty(tuple(f.shape)) for s_, f in zip(slots, feats)]
             bd = (_ConvBwdDesc * L)()

@@ -316,6 +316,10 @@ class Context:
         self._arena_off = 0
         self._arena_live = True
 
+    def end_step(self):
+        """Outside a training step (eval forward) the arena is not re-zeroed: zeros_f64() must hand out fresh zeroed buffers."""
+        self._arena_live = False
+
     def zeros_f64(self, n):
         """Zeroed fp64 [n] buffer (BatchNorm sums).  Inside a step it is a slice of the pre-zeroed arena."""
         if self._arena_live and self._arena_off + n <= self._arena.numel():

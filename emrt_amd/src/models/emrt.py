@@ -717,9 +717,11 @@ class EMRT(hnn.HipLayer):  # :184-304
         c.training = self.training
         if self.training:
             c.begin_step()
-        elif c.fold_eval_bn:
-            self.store.fold_bn()
-            c.fold_live = True
+        else:
+            c.end_step()
+            if c.fold_eval_bn:
+                self.store.fold_bn()
+                c.fold_live = True
         tape = Tape() if self.training else None
         c.tape = tape
         try:

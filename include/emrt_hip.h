@@ -36,7 +36,8 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
 /* Developer / test knobs of the dispatchers (forced tile shapes, kernel variants).  The table is filled ONCE from the
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
  * conv_tile, wgrad_split, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
- * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic.
+ * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows,
+ * gn_bwd_stat_rows, gn_apply_rows.
  * Not thread-safe against concurrent launches; production code never calls these. */
 int emrt_set_tuning(const char* name, int value);
 int emrt_get_tuning(const char* name, int* value);
@@ -106,8 +107,8 @@ int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const void* dy, i
 /* the same over L <= 4 level slabs (rows [level_start[l], +level_hw[l]), hw <= 4096) of token tensors [N][Lv][C], each with
  * its own gamma / beta, in ONE launch: the per-level conv branch of an encoder layer (transformer_encoder_decoder.py:125-144,
  * 163-182).  gamma / beta / dgamma / dbeta / level_* are HOST arrays of L entries; mean / rstd are [L][N*G]. */
-int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* const* gamma, const float* const* beta, float* mean, float* rstd, const int* level_start, const int* level_hw, int L, int N, int C, int G, float eps, int gelu, int dtype, void* stream);
-int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* const* gamma, const float* const* beta, const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta, const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, int dtype, void* stream);
+int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* const* gamma, const float* const* beta, float* mean, float* rstd, const int* level_start, const int* level_hw, int L, int N, int C, int G, float eps, int gelu, double* stat_ws, int dtype, void* stream);
+int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* const* gamma, const float* const* beta, const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta, const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, double* stat_ws, int dtype, void* stream);
 
 /* ---- residual add + LayerNorm (+ post add): transformer_encoder_decoder.py:199-203,159-160,285-291,278-279
  * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward. */

@@ -49,7 +49,7 @@ def test_loader_binds_all_entry_points(built):
     from emrt_amd import _lib
     _lib._LIB = None
     L = _lib.lib()
-    assert L.query("emrt_abi_version") == 2
+    assert L.query("emrt_abi_version") == 3
     assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
     assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6) == 2 * 10 * 8 * 18 * 4
     assert L.last_error() == "" or isinstance(L.last_error(), str)
