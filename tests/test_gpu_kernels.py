@@ -687,21 +687,22 @@ def test_adaptive_pool_and_maxpool(dtype):
     close("pool fwd", host(y), toks.detach(), dtype)
     dx, = run_bwd(tape, [(y, dev(dy))], [xd])
     close("pool dx", host_map(dx), xr.grad, dtype)
-    # max pool, with ties (post-ReLU style input)
-    x2 = rnd(F.relu(torch.randn(N, C, 17, 19, generator=g)))
-    x2r = x2.clone().requires_grad_(True)
-    m = F.max_pool2d(x2r, 3, 2, 1)
-    dm = rnd(torch.randn(m.shape, generator=g))
-    m.backward(dm)
-    x2d = dev_map(x2)
-    tape = Tape()
-    c.tape = tape
-    y2 = Fn.maxpool(x2d, 3, 2, 1)
-    c.tape = None
-    tape.watch(x2d)
-    close("maxpool fwd", host_map(y2), m.detach(), dtype, atol=0, rtol=0)
-    dx2, = run_bwd(tape, [(y2, dev_map(dm))], [x2d])
-    close("maxpool dx", host_map(dx2), x2r.grad, dtype)
+    # max pool, with ties (post-ReLU style input); C = 64 takes the 8-channel kernel, C = 3 (the image itself, spatial_branch) the scalar one
+    for Cm in (64, 3):
+        x2 = rnd(F.relu(torch.randn(N, Cm, 17, 19, generator=g)))
+        x2r = x2.clone().requires_grad_(True)
+        m = F.max_pool2d(x2r, 3, 2, 1)
+        dm = rnd(torch.randn(m.shape, generator=g))
+        m.backward(dm)
+        x2d = dev_map(x2)
+        tape = Tape()
+        c.tape = tape
+        y2 = Fn.maxpool(x2d, 3, 2, 1)
+        c.tape = None
+        tape.watch(x2d)
+        close("maxpool fwd C=%d" % Cm, host_map(y2), m.detach(), dtype, atol=0, rtol=0)
+        dx2, = run_bwd(tape, [(y2, dev_map(dm))], [x2d])
+        close("maxpool dx C=%d" % Cm, host_map(dx2), x2r.grad, dtype)
 
 
 def test_nchw_ingest_and_elementwise():
