@@ -176,8 +176,10 @@ struct SgdArgs {
   long long r0[32], r1[32];      // element ranges whose learning rate is multiplied by `range_mult`
   float range_mult;
   float* lr_out;                 // optional: lr used this step
+  void* mirror;                  // optional: compute-dtype copy of the parameters, same indexing as p
 };
 
+template <class MT>
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdArgs a) {
   long long t = a.step ? a.step[0] : 0;
   if (t > a.decay_steps) t = a.decay_steps;
@@ -185,15 +187,46 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdArgs a) {
   const float lr = (a.base_lr - a.end_lr) * powf(frac, a.power) + a.end_lr;
   if (a.lr_out && blockIdx.x == 0 && threadIdx.x == 0) a.lr_out[0] = lr;
   const float scale = a.state ? a.state[0] : 1.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
-    float mult = 1.f;
-    for (int r = 0; r < a.nranges; ++r)
-      if (i >= a.r0[r] && i < a.r1[r]) mult = a.range_mult;
-    const float p = a.p[i];
-    const float g = a.g[i] * scale + a.weight_decay * p;
-    const float v = a.momentum * a.v[i] + g;
-    a.v[i] = v;
-    a.p[i] = p - lr * mult * v;
+  MT* mirror = (MT*)a.mirror;
+  // four elements per thread (16-byte accesses on the three fp32 streams); the compute-dtype mirror of the parameters -- the
+  // forward GEMM operand, same index as the master copy -- is written here instead of by a second pass over the master buffer
+  const long long n4 = a.n / 4;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
+    const long long i = i4 * 4;
+    const float4 p4 = reinterpret_cast<const float4*>(a.p)[i4];
+    const float4 g4 = reinterpret_cast<const float4*>(a.g)[i4];
+    const float4 v4 = reinterpret_cast<const float4*>(a.v)[i4];
+    float p[4] = {p4.x, p4.y, p4.z, p4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    bool any = false;
+    for (int r = 0; r < a.nranges; ++r) any |= (i + 3 >= a.r0[r] && i < a.r1[r]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float mult = 1.f;
+      if (any)
+        for (int r = 0; r < a.nranges; ++r)
+          if (i + e >= a.r0[r] && i + e < a.r1[r]) mult = a.range_mult;
+      const float gg = g[e] * scale + a.weight_decay * p[e];
+      v[e] = a.momentum * v[e] + gg;
+      p[e] = p[e] - lr * mult * v[e];
+    }
+    reinterpret_cast<float4*>(a.v)[i4] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(a.p)[i4] = make_float4(p[0], p[1], p[2], p[3]);
+    if (mirror) Vec4<MT>::store(mirror + i, p);
+  }
+  if (blockIdx.x == 0) {
+    for (long long i = n4 * 4 + threadIdx.x; i < a.n; i += blockDim.x) {
+      float mult = 1.f;
+      for (int r = 0; r < a.nranges; ++r)
+        if (i >= a.r0[r] && i < a.r1[r]) mult = a.range_mult;
+      const float p = a.p[i];
+      const float g = a.g[i] * scale + a.weight_decay * p;
+      const float v = a.momentum * a.v[i] + g;
+      a.v[i] = v;
+      const float pn = p - lr * mult * v;
+      a.p[i] = pn;
+      if (mirror) mirror[i] = from_f32<MT>(pn);
+    }
   }
 }
 
@@ -218,8 +251,10 @@ extern "C" int emrt_grad_clip_scale(const float* grads, long long n, float clip,
 extern "C" int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state,
                                       const long long* step, float base_lr, float end_lr, float power, long long decay_steps,
                                       float momentum, float weight_decay, const long long* ranges /*host [nranges][2]*/,
-                                      int nranges, float range_mult, float* lr_out, void* stream) {
+                                      int nranges, float range_mult, float* lr_out, void* mirror, int mirror_dtype, void* stream) {
   EMRT_REQUIRE(params && grads && velocity, "null pointer");
+  EMRT_REQUIRE(!mirror || mirror_dtype == EMRT_BF16 || mirror_dtype == EMRT_F16, "the parameter mirror is bf16 or fp16");
+  EMRT_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)velocity) % 16 == 0 && (!mirror || (uintptr_t)mirror % 8 == 0), "buffers must be 16-byte aligned");
   EMRT_REQUIRE(nranges >= 0 && nranges <= 32 && (nranges == 0 || ranges), "0..32 lr-mult ranges");
   EMRT_REQUIRE(decay_steps > 0, "decay_steps must be positive");
   SgdArgs a;
@@ -227,11 +262,13 @@ extern "C" int emrt_sgd_momentum_step(float* params, const float* grads, float* 
   a.p = params; a.g = grads; a.v = velocity; a.n = n; a.state = clip_state; a.step = step;
   a.base_lr = base_lr; a.end_lr = end_lr; a.power = power; a.decay_steps = decay_steps;
   a.momentum = momentum; a.weight_decay = weight_decay; a.nranges = nranges; a.range_mult = range_mult; a.lr_out = lr_out;
+  a.mirror = mirror;
   for (int r = 0; r < nranges; ++r) { a.r0[r] = ranges[2 * r]; a.r1[r] = ranges[2 * r + 1]; }
-  int grid = (int)((n + 255) / 256);
+  int grid = (int)((n / 4 + 255) / 256);
   if (grid > 8192) grid = 8192;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (mirror && mirror_dtype == EMRT_F16) hipLaunchKernelGGL(sgd_momentum_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(sgd_momentum_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("emrt_sgd_momentum_step");
 }
 
@@ -248,7 +285,7 @@ extern "C" int emrt_counter_add(long long* counter, long long delta, void* strea
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ master, T* __restrict__ packed,
-                                                           const long long* __restrict__ desc, int ndesc) {
+                                                           const long long* __restrict__ desc, int ndesc, int bwd_only) {
   __shared__ float tile[32][33];
   const long long tid = blockIdx.x;
   int lo = 0, hi = ndesc - 1;
@@ -257,7 +294,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     if (desc[mid * 8 + 6] <= tid) lo = mid; else hi = mid - 1;
   }
   const long long* d = desc + lo * 8;
-  const long long src = d[0], fo = d[1], bo = d[2];
+  const long long src = d[0], fo = bwd_only ? -1 : d[1], bo = d[2];
+  if (fo < 0 && bo < 0) return;
+  // bwd_only: the forward copy (the optimizer's mirror) is current -- transpose from it (half the bytes of the fp32 master)
+  const T* mir = (bwd_only && d[1] >= 0) ? packed + d[1] : nullptr;
   const int OC = (int)d[3], taps = (int)d[4], C = (int)d[5];
   const int tc = (C + 31) / 32, toc = (OC + 31) / 32;
   long long local = tid - d[6];
@@ -271,7 +311,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     float v = 0.f;
     if (oc < OC && c < C) {
       const long long idx = ((long long)oc * taps + tap) * C + c;
-      v = master[src + idx];
+      v = mir ? to_f32(mir[idx]) : master[src + idx];
       if (fo >= 0) packed[fo + idx] = from_f32<T>(v);
     }
     tile[ty + 8 * r][tx] = v;
@@ -286,13 +326,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 }
 
 extern "C" int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles,
-                                 int dtype, void* stream) {
+                                 int bwd_only, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(master && packed && desc_dev, "null pointer");
   EMRT_REQUIRE(ndesc > 0 && total_tiles > 0 && total_tiles < 2147483647LL, "bad descriptor table");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EMRT_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (float*)packed, desc_dev, ndesc);
-  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc);
-  else hipLaunchKernelGGL((pack_weights_kernel<f16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (f16_t*)packed, desc_dev, ndesc);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (float*)packed, desc_dev, ndesc, bwd_only);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc, bwd_only);
+  else hipLaunchKernelGGL((pack_weights_kernel<f16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (f16_t*)packed, desc_dev, ndesc, bwd_only);
   return check_launch("emrt_pack_weights");
 }

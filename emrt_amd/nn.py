@@ -19,6 +19,12 @@ from . import functional as Fn
 from .runtime import ctx, F32, BF16, _TORCH_DTYPE
 
 
+# element alignment of weight matrices in the flat buffers / of their transposed copies (measured 8 ... 2048: 729 -> 744 tiles/s;
+# flat from 128 on = 256 bytes of the bf16 mirror; larger only pads the range the optimizer and the all-reduce cover)
+_PARAM_ALIGN = 128
+_BWD_ALIGN = 128
+
+
 def _align(n, a):
     return (n + a - 1) // a * a
 
@@ -48,14 +54,17 @@ class ParamStore:
         for i, n in enumerate(order):
             p = by_name[n]
             if n not in fused_follow:
-                off = _align(off, 4)
+                # 16 bytes in the bf16 / fp16 mirror of this buffer (the GEMMs' 16-byte operand loads); weight matrices start on a
+                # 256-byte boundary of the mirror: with 16-byte alignment only, every k-row of a GEMM operand straddled cache lines
+                # and the weight-bound layers (8x8 / 16x16 maps) ran 10-20 % slower
+                off = _align(off, _PARAM_ALIGN if p.dim() >= 2 else 8)
             else:
-                assert off % 4 == 0, "fused parameter group member %s must start 16-byte aligned" % n
+                assert off % 8 == 0, "fused parameter group member %s must start 16-byte aligned in the compute-dtype mirror" % n
             self.offsets[n] = off
             off += p.numel()
             if i == self.n_trainable_names - 1:
-                self.n_train = _align(off, 4)     # [0, n_train) is what clip / SGD / all-reduce cover
-        self.n_total = _align(off, 4)
+                self.n_train = _align(off, 8)     # [0, n_train) is what clip / SGD / all-reduce cover
+        self.n_total = _align(off, 8)
         self.master = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.velocity = torch.zeros(self.n_total, dtype=torch.float32, device=device)
@@ -138,16 +147,19 @@ class ParamStore:
     def finalize(self):
         """Allocate the packed-weight buffer and the device descriptor table (after every layer registered its GEMMs)."""
         esz = 4 if self.dtype == F32 else 2
-        off, rows, tiles = 0, [], 0
+        # compute-dtype modes: packed = [ mirror of the whole master buffer (same indexing: the forward operand of GEMM g starts
+        # at g.offset, and the optimizer refreshes it in its update pass) | transposed dgrad copies ]; fp32: dgrad copies only
+        off = 0 if self.dtype == F32 else _align(self.n_total, _BWD_ALIGN)
+        self.mirror_elems = off
+        rows, tiles = [], 0
         for g in self.gemms:
             cnt = g.OC * g.KH * g.KW * g.C
             fo = bo = -1
             if self.dtype != F32:
-                fo = off
-                off = _align(off + cnt, 8)
+                fo = g.offset
             if g.need_bwd:
                 bo = off
-                off = _align(off + cnt, 8)
+                off = _align(off + cnt, _BWD_ALIGN)      # 256-byte aligned copies (see the parameter offsets above)
             g._fo, g._bo = fo, bo
             if fo < 0 and bo < 0:
                 continue
@@ -188,11 +200,18 @@ class ParamStore:
         _lib.lib().call("emrt_bn_fold", Fn.P(self.master), Fn.P(self.buffers), Fn.P(self.bn_desc), len(self.bn_states),
                         self.bn_states[0].eps, Fn.P(self.bn_fold), ctx().stream)
 
-    def pack(self):
+    def pack(self, bwd_only=False):
+        """Refresh the compute-dtype weight copies from the master buffer.  bwd_only: only the transposed dgrad copies (the
+        optimizer step has just written the forward mirror itself)."""
         if self.desc is not None:
             _lib.lib().call("emrt_pack_weights", Fn.P(self.master), Fn.P(self.packed), Fn.P(self.desc), self.ndesc, self.total_tiles,
-                            self.dtype, ctx().stream)
+                            int(bool(bwd_only)), self.dtype, ctx().stream)
         self.dirty = False
+
+    @property
+    def mirror(self):
+        """Compute-dtype copy of the master buffer (None in fp32 mode), element i <-> master[i]."""
+        return None if self.dtype == F32 or self.packed is None else self.packed[:self.mirror_elems]
 
     def zero_grad(self):
         _lib.lib().call("emrt_memset", Fn.P(self.grad), 0, self.n_train * 4, ctx().stream)

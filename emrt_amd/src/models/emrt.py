@@ -726,6 +726,10 @@ class EMRT(hnn.HipLayer):  # :184-304
         c.tape = tape
         try:
             out = self.forward(images)
+            if tape is not None:
+                # newest model op = first to run in backward (after the loss's own): transposed dgrad copies of the weights from
+                # the forward operands the optimizer keeps current (ParamStore.pack, solver.Momentum.step)
+                tape.record(lambda: self.store.pack(bwd_only=True))
         finally:
             c.tape = None
             c.fold_live = False

@@ -44,16 +44,20 @@ class Momentum:
         return float(self.clip_state[1].item())
 
     def step(self):
-        """Enqueues clip + update + weight re-pack on the current stream; advances the device step counter."""
+        """Enqueues clip + update (master and compute-dtype mirror) on the current stream; advances the device step counter."""
         c, st, L = ctx(), self.model.store, _lib.lib()
         sch = self._learning_rate
         ws = c.workspace(L.query("emrt_gradnorm_workspace_bytes"))
         L.call("emrt_grad_clip_scale", Fn.P(st.grad), st.n_train, float(self.grad_clip or 0.0), Fn.P(self.clip_state), Fn.P(ws), c.stream)
         L.call("emrt_sgd_momentum_step", Fn.P(st.master), Fn.P(st.grad), Fn.P(st.velocity), st.n_train, Fn.P(self.clip_state),
                Fn.P(c.step_counter), sch.base_lr, sch.end_lr, sch.power, sch.decay_steps, self.momentum, self.weight_decay,
-               ctypes.cast(self.ranges, ctypes.c_void_p), len(st.lr_ranges), st.lr_mult, Fn.P(self.lr_dev), c.stream)
+               ctypes.cast(self.ranges, ctypes.c_void_p), len(st.lr_ranges), st.lr_mult, Fn.P(self.lr_dev), Fn.P(st.mirror), st.dtype, c.stream)
         L.call("emrt_counter_add", Fn.P(c.step_counter), 1, c.stream)
-        st.pack()
+        # the forward operands (fp32 master / its compute-dtype mirror) are current; the transposed dgrad copies are refreshed
+        # where they are next needed, at the start of the next backward (EMRT.__call__ records it): the step then ends with
+        # the mirror as the last thing written, which is what the next forward reads first
+        if st.dirty:
+            st.pack()
 
     def state_dict(self):
         return {"velocity": self.model.store.velocity.clone(), "step": int(ctx().step_counter.item())}

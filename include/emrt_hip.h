@@ -169,14 +169,18 @@ int emrt_scalar_axpby(float* out, const float* a, float wa, const float* b, floa
 /* ---- optimizer: ClipGradByGlobalNorm + L2 decay + Momentum over one flat fp32 buffer, PolynomialDecay evaluated
  * on the device from a step counter: solver/optimizer.py:29-40, solver/lr_scheduler.py:244-248.
  * ranges: HOST int64 [nranges][2] element ranges whose lr is multiplied by range_mult (ParamAttr(learning_rate=0.1),
- * transformer_encoder_decoder.py:36-38,371-372). */
+ * transformer_encoder_decoder.py:36-38,371-372).
+ * mirror (nullable): bf16 / fp16 (mirror_dtype 1 / 2) copy of the parameters with the SAME indexing as `params`, refreshed by the
+ * update itself: the forward GEMMs read their [OC][taps][C] operand straight from it, so the per-step weight re-pack only writes
+ * the transposed dgrad copies (emrt_pack_weights with bwd_only = 1). */
 size_t emrt_gradnorm_workspace_bytes(void);
 int emrt_grad_clip_scale(const float* grads, long long n, float clip, float* state, void* workspace, void* stream);
-int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state, const long long* step, float base_lr, float end_lr, float power, long long decay_steps, float momentum, float weight_decay, const long long* ranges, int nranges, float range_mult, float* lr_out, void* stream);
+int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state, const long long* step, float base_lr, float end_lr, float power, long long decay_steps, float momentum, float weight_decay, const long long* ranges, int nranges, float range_mult, float* lr_out, void* mirror, int mirror_dtype, void* stream);
 int emrt_counter_add(long long* counter, long long delta, void* stream);
 /* fp32 master weights -> compute-dtype forward copy [OC][taps][C] and transposed dgrad copy [C][taps][OC];
- * desc_dev: DEVICE int64 [ndesc][8] = {src_off, fwd_off|-1, bwd_off|-1, OC, taps, C, first_tile, 0}. */
-int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles, int dtype, void* stream);
+ * desc_dev: DEVICE int64 [ndesc][8] = {src_off, fwd_off|-1, bwd_off|-1, OC, taps, C, first_tile, 0}; bwd_only = 1 skips the forward
+ * copies (the optimizer keeps them current through its `mirror`). */
+int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles, int bwd_only, int dtype, void* stream);
 
 /* ---- small streaming ops: with_pos_embed adds, nn.Dropout/nn.Dropout2D (mode 1), ReLU/dropout backward masks,
  * F.sigmoid, casts: transformer_encoder_decoder.py:115-122,154-161,250-263,273-280,466; paddle_EMRT.py:208; fcn_head.py:65 */
