@@ -43,17 +43,29 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s0[e] += v[e]; s1[e] = fmaf(v[e], v[e], s1[e]); }
       } else if (MODE == 1) {
-        float g[4];
-        Vec4<T>::load(x + r * ldx + c, v);
-        Vec4<T>::load(dy + r * lddy + c, g);
-        if (y) {
-          float o[4];
-          Vec4<T>::load(y + r * ldy + c, o);
+        // four rows per iteration, all their loads issued before the first use: one row per trip left 4-6 KB in flight per
+        // block and the kernel at the latency of its load chain (13 us for 33 MB)
+        const long long rs = (long long)gridDim.x * ty_n;
+        float vv[4][4], gg[4][4], oo[4][4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+          const long long ru = r + u * rs < M ? r + u * rs : r;
+          Vec4<T>::load(x + ru * ldx + c, vv[u]);
+          Vec4<T>::load(dy + ru * lddy + c, gg[u]);
+          if (y) Vec4<T>::load(y + ru * ldy + c, oo[u]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], (v[e] - mu[e]) * is[e], s1[e]); }
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = r + u * rs < M;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float g = ok ? gg[u][e] : 0.f;
+            if (y) g = oo[u][e] > 0.f ? g : 0.f;
+            s0[e] += g;
+            s1[e] = fmaf(g, (vv[u][e] - mu[e]) * is[e], s1[e]);
+          }
+        }
+        r += 3 * rs;
       } else {
         const long long bb = r / rpb;   // batch-strided rows: row r = (batch bb, row r - bb*rpb)
         Vec4<T>::load(x + bb * bs + (r - bb * rpb) * ldx + c, v);
