@@ -325,12 +325,79 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
   }
 }
 
+// The per-step form: only the transposed dgrad copies, 64x64 (oc x c) tiles, 16-byte accesses on both sides (the 32x32 kernel above
+// writes 2-byte elements in 64-byte runs: 1.8 TB/s).  Source = the compute-dtype forward copy when the descriptor has one (the
+// optimizer's mirror, current by construction), else the fp32 master.  desc[7] = first 64x64 tile id of the descriptor.
+template <class T>
+__global__ __launch_bounds__(256) void pack_bwd64_kernel(const float* __restrict__ master, T* __restrict__ packed,
+                                                         const long long* __restrict__ desc, int ndesc) {
+  __shared__ float tile[64][65];
+  const long long tid = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid * 8 + 7] <= tid) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + lo * 8;
+  const long long src = d[0], fo = d[1], bo = d[2];
+  if (bo < 0) return;
+  const int OC = (int)d[3], taps = (int)d[4], C = (int)d[5];
+  const int tc = (C + 63) / 64, toc = (OC + 63) / 64;
+  long long local = tid - d[7];
+  const int ct = (int)(local % tc); local /= tc;
+  const int ot = (int)(local % toc);
+  const int tap = (int)(local / toc);
+  if (tap >= taps) return;
+  const T* mir = fo >= 0 ? packed + fo : nullptr;
+  const int sub = threadIdx.x & 7, rw = threadIdx.x >> 3;      // 8 chunks of 8 elements x 32 rows per pass
+  const bool vc = (C % 8) == 0, voc = (OC % 8) == 0;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int ol = rw + 32 * ps, oc = ot * 64 + ol, c0 = ct * 64 + sub * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (oc < OC && c0 < C) {
+      const long long idx = ((long long)oc * taps + tap) * C + c0;
+      if (vc) {
+        if (mir) Vec8<T>::load(mir + idx, v);
+        else Vec8<float>::load(master + src + idx, v);
+      } else {
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < C) v[e] = mir ? to_f32(mir[idx + e]) : master[src + idx + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[ol][sub * 8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int cl = rw + 32 * ps, c = ct * 64 + cl, o0 = ot * 64 + sub * 8;
+    if (c >= C || o0 >= OC) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[sub * 8 + e][cl];
+    T* dst = packed + bo + ((long long)c * taps + tap) * OC + o0;
+    if (voc) Vec8<T>::store(dst, v);
+    else
+      for (int e = 0; e < 8; ++e)
+        if (o0 + e < OC) dst[e] = from_f32<T>(v[e]);
+  }
+}
+
 extern "C" int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles,
-                                 int bwd_only, int dtype, void* stream) {
+                                 long long total_tiles64, int bwd_only, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(master && packed && desc_dev, "null pointer");
-  EMRT_REQUIRE(ndesc > 0 && total_tiles > 0 && total_tiles < 2147483647LL, "bad descriptor table");
+  EMRT_REQUIRE(ndesc > 0 && total_tiles > 0 && total_tiles < 2147483647LL && total_tiles64 >= 0 && total_tiles64 < 2147483647LL, "bad descriptor table");
   hipStream_t st = (hipStream_t)stream;
+  if (bwd_only && total_tiles64 > 0) {
+    if (dtype == EMRT_F32) hipLaunchKernelGGL((pack_bwd64_kernel<float>), dim3((unsigned)total_tiles64), dim3(256), 0, st, master, (float*)packed, desc_dev, ndesc);
+    else if (dtype == EMRT_BF16) hipLaunchKernelGGL((pack_bwd64_kernel<bf16_t>), dim3((unsigned)total_tiles64), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc);
+    else hipLaunchKernelGGL((pack_bwd64_kernel<f16_t>), dim3((unsigned)total_tiles64), dim3(256), 0, st, master, (f16_t*)packed, desc_dev, ndesc);
+    return check_launch("emrt_pack_weights");
+  }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (float*)packed, desc_dev, ndesc, bwd_only);
   else if (dtype == EMRT_BF16) hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (bf16_t*)packed, desc_dev, ndesc, bwd_only);
   else hipLaunchKernelGGL((pack_weights_kernel<f16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, master, (f16_t*)packed, desc_dev, ndesc, bwd_only);

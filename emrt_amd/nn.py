@@ -102,7 +102,7 @@ class ParamStore:
         self.gemms = []
         self.packed = None
         self.desc = None
-        self.total_tiles = 0
+        self.total_tiles = self.total_tiles64 = 0
         self.dirty = True
         self.bn_states, self.bn_fold, self.bn_desc = [], None, None
 
@@ -151,7 +151,7 @@ class ParamStore:
         # at g.offset, and the optimizer refreshes it in its update pass) | transposed dgrad copies ]; fp32: dgrad copies only
         off = 0 if self.dtype == F32 else _align(self.n_total, _BWD_ALIGN)
         self.mirror_elems = off
-        rows, tiles = [], 0
+        rows, tiles, tiles64 = [], 0, 0
         for g in self.gemms:
             cnt = g.OC * g.KH * g.KW * g.C
             fo = bo = -1
@@ -163,8 +163,9 @@ class ParamStore:
             g._fo, g._bo = fo, bo
             if fo < 0 and bo < 0:
                 continue
-            rows.append([g.offset, fo, bo, g.OC, g.KH * g.KW, g.C, tiles, 0])
+            rows.append([g.offset, fo, bo, g.OC, g.KH * g.KW, g.C, tiles, tiles64])
             tiles += g.KH * g.KW * ((g.OC + 31) // 32) * ((g.C + 31) // 32)
+            tiles64 += g.KH * g.KW * ((g.OC + 63) // 64) * ((g.C + 63) // 64)
         self.packed = torch.zeros(max(off, 8), dtype=_TORCH_DTYPE[self.dtype], device=self.device)
         base = self.packed.data_ptr()
         for g in self.gemms:
@@ -172,7 +173,7 @@ class ParamStore:
             g.bwd_ptr = None if g._bo < 0 else base + esz * g._bo
             g._keepalive = (self.packed, self.master, self.grad)   # raw device addresses above point into these
         self.desc = torch.tensor(rows, dtype=torch.int64).to(self.device) if rows else None
-        self.ndesc, self.total_tiles = len(rows), tiles
+        self.ndesc, self.total_tiles, self.total_tiles64 = len(rows), tiles, tiles64
         self.dirty = True
 
     def register_bn(self, st):
@@ -205,7 +206,7 @@ class ParamStore:
         optimizer step has just written the forward mirror itself)."""
         if self.desc is not None:
             _lib.lib().call("emrt_pack_weights", Fn.P(self.master), Fn.P(self.packed), Fn.P(self.desc), self.ndesc, self.total_tiles,
-                            int(bool(bwd_only)), self.dtype, ctx().stream)
+                            self.total_tiles64, int(bool(bwd_only)), self.dtype, ctx().stream)
         self.dirty = False
 
     @property

@@ -178,9 +178,10 @@ int emrt_grad_clip_scale(const float* grads, long long n, float clip, float* sta
 int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state, const long long* step, float base_lr, float end_lr, float power, long long decay_steps, float momentum, float weight_decay, const long long* ranges, int nranges, float range_mult, float* lr_out, void* mirror, int mirror_dtype, void* stream);
 int emrt_counter_add(long long* counter, long long delta, void* stream);
 /* fp32 master weights -> compute-dtype forward copy [OC][taps][C] and transposed dgrad copy [C][taps][OC];
- * desc_dev: DEVICE int64 [ndesc][8] = {src_off, fwd_off|-1, bwd_off|-1, OC, taps, C, first_tile, 0}; bwd_only = 1 skips the forward
- * copies (the optimizer keeps them current through its `mirror`). */
-int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles, int bwd_only, int dtype, void* stream);
+ * desc_dev: DEVICE int64 [ndesc][8] = {src_off, fwd_off|-1, bwd_off|-1, OC, taps, C, first 32x32 tile, first 64x64 tile};
+ * total_tiles / total_tiles64 = sum over descriptors of taps * ceil(OC/32) * ceil(C/32) (resp. /64).  bwd_only = 1 skips the forward
+ * copies (the optimizer keeps them current through its `mirror`) and transposes 64x64 tiles FROM them. */
+int emrt_pack_weights(const float* master, void* packed, const long long* desc_dev, int ndesc, long long total_tiles, long long total_tiles64, int bwd_only, int dtype, void* stream);
 
 /* ---- small streaming ops: with_pos_embed adds, nn.Dropout/nn.Dropout2D (mode 1), ReLU/dropout backward masks,
  * F.sigmoid, casts: transformer_encoder_decoder.py:115-122,154-161,250-263,273-280,466; paddle_EMRT.py:208; fcn_head.py:65 */

@@ -836,6 +836,35 @@ def test_pack_weights_layouts(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_bwd_only_rebuilds_the_dgrad_copies(dtype):
+    """The per-step form of the weight pack (64x64 tiles transposed FROM the forward operand the optimizer keeps current) must
+    reproduce exactly what the full pack writes: shapes with ragged tiles (C = 3, 40; OC = 6, 72, 432), 1x1 / 3x3 / 7x7 taps."""
+    c = init(dtype)
+    g = torch.Generator().manual_seed(17)
+    layers = dict(a=hnn.Conv2D(40, 72, 3, 1, 1, bias=False), b=hnn.Conv2D(3, 64, 7, 2, 3, bias=False), c=hnn.Conv2D(256, 6, 1),
+                  d=hnn.Linear(256, 432), e=hnn.Conv2D(128, 128, 3, 1, 1, bias=False))
+    with torch.no_grad():
+        for m in layers.values():
+            m.weight.copy_(rnd(torch.randn(m.weight.shape, generator=g)))
+    h = Holder(**layers).place()
+    st = h.store
+    torch.cuda.synchronize()
+    want = st.packed.clone()
+    lo = st.mirror_elems if dtype != F32 else 0
+    st.packed[lo:].fill_(7.0)                     # the dgrad copies are garbage; the forward mirror (bf16) / master (fp32) is intact
+    st.pack(bwd_only=True)
+    torch.cuda.synchronize()
+    assert any(g_.bwd_ptr is not None for g_ in st.gemms)
+    for g_ in st.gemms:
+        if g_.bwd_ptr is None:
+            continue
+        esz = 4 if dtype == F32 else 2
+        o = (g_.bwd_ptr - st.packed.data_ptr()) // esz
+        n = g_.OC * g_.KH * g_.KW * g_.C
+        assert torch.equal(st.packed[o:o + n], want[o:o + n]), (g_.OC, g_.C, g_.KH)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_msda_golden_vectors(dtype):
     """The committed golden vectors (numpy-f64 oracle) through the HIP kernel: locations enter as offsets from ref = 0."""
     import os
