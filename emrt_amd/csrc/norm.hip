@@ -1027,7 +1027,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
       if (z) {
         // round z through T so forward and backward see the same LN input
         Vec4<T>::store(z + row * C + c, v[j]);
-        if (sizeof(T) == 2) Vec4<T>::load(z + row * C + c, v[j]);
+        if (sizeof(T) == 2) {      // (in registers: reading the stored value back put a memory round trip on every row's critical path)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = to_f32(from_f32<T>(v[j][e]));
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) s += v[j][e];
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
 
 // LN backward: dz = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  per-block partial dgamma/dbeta
 // -> partial[blk][2][C]; combined by bn_sum_partials_kernel + bn_bwd_finalize_kernel.
-template <class T>
+template <class T, int R, int NQ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
@@ -1075,84 +1078,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
   const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
   extern __shared__ float sm[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nq = C / 256 + ((C % 256) ? 1 : 0);
-  float dg[4][4], db[4][4];
+  const int nq = C / 256 + ((C % 256) ? 1 : 0);       // <= NQ
+  float dg[NQ][4], db[NQ][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NQ; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dg[j][e] = 0.f; db[j][e] = 0.f; }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   long long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  // two rows per wave and iteration: the kernel is bound by the latency of the per-row load -> wave reduction -> store chain,
-  // two independent chains in one basic block let the scheduler overlap them
-  for (long long rowA = r0 + wv; rowA < r1; rowA += 8) {
-    const long long rowB_raw = rowA + 4;
-    const bool okB = rowB_raw < r1;
-    const long long rowB = okB ? rowB_raw : rowA;
-    const float wB = okB ? 1.f : 0.f;
-    const float muA = mean[rowA], rsA = rstd[rowA], muB = mean[rowB], rsB = rstd[rowB];
-    float xhA[4][4], gdA[4][4], xhB[4][4], gdB[4][4];
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-    for (int j = 0; j < nq; ++j) {
-      const int c = j * 256 + lane * 4;
-      if (c < C) {
-        float zA[4], dA[4], zB[4], dB[4];
-        Vec4<T>::load(z + rowA * C + c, zA);
-        Vec4<T>::load(dy + rowA * C + c, dA);
-        Vec4<T>::load(z + rowB * C + c, zB);
-        Vec4<T>::load(dy + rowB * C + c, dB);
+  // R rows per wave and iteration (rows wv, wv + 4, ...): the kernel is bound by the latency of the per-row load -> wave reduction
+  // -> store chain; R independent chains in one basic block let the scheduler overlap them (R = 4 for C <= 256, the EMRT case)
+  for (long long row0 = r0 + wv; row0 < r1; row0 += 4 * R) {
+    long long row[R];
+    bool ok[R];
+    float mu[R], rs[R], s0[R], s1[R];
+    float xh[R][NQ][4], gd[R][NQ][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gm = gamma[c + e];
-          xhA[j][e] = (zA[e] - muA) * rsA;
-          gdA[j][e] = gm * dA[e];
-          a0 += gdA[j][e];
-          a1 = fmaf(gdA[j][e], xhA[j][e], a1);
-          xhB[j][e] = (zB[e] - muB) * rsB;
-          gdB[j][e] = gm * dB[e];
-          b0 += gdB[j][e];
-          b1 = fmaf(gdB[j][e], xhB[j][e], b1);
-          dg[j][e] = fmaf(dA[e], xhA[j][e], dg[j][e]);
-          db[j][e] += dA[e];
-          dg[j][e] = fmaf(wB * dB[e], xhB[j][e], dg[j][e]);
-          db[j][e] = fmaf(wB, dB[e], db[j][e]);
+    for (int k = 0; k < R; ++k) {
+      ok[k] = row0 + 4 * k < r1;
+      row[k] = ok[k] ? row0 + 4 * k : row0;
+      mu[k] = mean[row[k]]; rs[k] = rstd[row[k]];
+      s0[k] = 0.f; s1[k] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (j < nq && c < C) {
+        float zz[R][4], dd[R][4];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          Vec4<T>::load(z + row[k] * C + c, zz[k]);
+          Vec4<T>::load(dy + row[k] * C + c, dd[k]);
+        }
+        float gm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gm[e] = gamma[c + e];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const float wk = ok[k] ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[k][j][e] = (zz[k][e] - mu[k]) * rs[k];
+            gd[k][j][e] = gm[e] * dd[k][e];
+            s0[k] += gd[k][j][e];
+            s1[k] = fmaf(gd[k][j][e], xh[k][j][e], s1[k]);
+            dg[j][e] = fmaf(wk * dd[k][e], xh[k][j][e], dg[j][e]);
+            db[j][e] = fmaf(wk, dd[k][e], db[j][e]);
+          }
         }
       }
     }
-    a0 = wave_sum(a0) / (float)C;
-    a1 = wave_sum(a1) / (float)C;
-    b0 = wave_sum(b0) / (float)C;
-    b1 = wave_sum(b1) / (float)C;
-    for (int j = 0; j < nq; ++j) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) { s0[k] = wave_sum(s0[k]) / (float)C; s1[k] = wave_sum(s1[k]) / (float)C; }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
       const int c = j * 256 + lane * 4;
-      if (c < C) {
-        float oA[4], oB[4];
+      if (j < nq && c < C) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          oA[e] = rsA * (gdA[j][e] - a0 - xhA[j][e] * a1);
-          oB[e] = rsB * (gdB[j][e] - b0 - xhB[j][e] * b1);
-        }
-        Vec4<T>::store(dz + rowA * C + c, oA);
-        if (okB) Vec4<T>::store(dz + rowB * C + c, oB);
-        if (dzb) {
-          if (pdrop > 0.f) {
+        for (int k = 0; k < R; ++k) {
+          if (!ok[k]) continue;
+          float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // the mask is applied to the STORED dz (rounded through T), as a separate mask kernel would read it
-              oA[e] = uniform01(sd, salt, (unsigned long long)(rowA * C + c + e)) >= pdrop ? to_f32(from_f32<T>(oA[e])) * ks : 0.f;
-              oB[e] = uniform01(sd, salt, (unsigned long long)(rowB * C + c + e)) >= pdrop ? to_f32(from_f32<T>(oB[e])) * ks : 0.f;
+          for (int e = 0; e < 4; ++e) o[e] = rs[k] * (gd[k][j][e] - s0[k] - xh[k][j][e] * s1[k]);
+          Vec4<T>::store(dz + row[k] * C + c, o);
+          if (dzb) {
+            if (pdrop > 0.f) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)   // the mask is applied to the STORED dz (rounded through T), as a separate mask kernel would read it
+                o[e] = uniform01(sd, salt, (unsigned long long)(row[k] * C + c + e)) >= pdrop ? to_f32(from_f32<T>(o[e])) * ks : 0.f;
             }
+            Vec4<T>::store(dzb + row[k] * C + c, o);
           }
-          Vec4<T>::store(dzb + rowA * C + c, oA);
-          if (okB) Vec4<T>::store(dzb + rowB * C + c, oB);
         }
       }
     }
   }
-  for (int j = 0; j < nq; ++j) {
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < C) {
+    if (j < nq && c < C) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { sm[(wv * 2 + 0) * C + c + e] = db[j][e]; sm[(wv * 2 + 1) * C + c + e] = dg[j][e]; }
     }
@@ -1465,15 +1470,18 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
   long long blocks = ln_bwd_blocks(rows);
   int rpb = (int)((rows + blocks - 1) / blocks);
-  rpb = (rpb + 7) / 8 * 8;
+  const bool small = C <= 256;                        // four rows in flight per wave (16 per block and iteration), else two
+  const int step = small ? 16 : 8;
+  rpb = (rpb + step - 1) / step * step;
   blocks = (rows + rpb - 1) / rpb;
   float* partial = (float*)workspace;
   const bool direct = (dgamma || dbeta) && g_tune.ln_atomic != 0;       // developer knob: 0 = partials + finalize launch
   const size_t lds = (size_t)8 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  DT_SWITCH(dtype,
-            hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, (const float*)z, (const float*)dy, (float*)dz, gamma, mean, rstd, partial, rows, C, rpb, (float*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr),
-            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, gamma, mean, rstd, partial, rows, C, rpb, (bf16_t*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr));
+#define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr)
+  if (small) DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 4, 1), LN_BWD_LAUNCH(bf16_t, 4, 1));
+  else DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 2, 4), LN_BWD_LAUNCH(bf16_t, 2, 4));
+#undef LN_BWD_LAUNCH
   if (!direct) hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }
