@@ -41,6 +41,8 @@ struct MsdaArgs {
   int Lv;
   int g_level[8], g_pix0[8], g_npix[8];   // scatter blocks: (level, first flat pixel, pixel count) of each LDS slab range
   int g_npix_max;                         // largest g_npix: the per-half-wave sample records sit behind a slab of that size
+  float* gmax;        // [B*M][gmax_n] per-block max |dout| of a (batch, head) slice, left by the LDS gradient kernel for the scatter
+  int gmax_n;         // 0: the scatter scans dout itself
 };
 
 template <class T>
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
   const unsigned char* vslab_sub = vslab + sub * 16;
   const int rls = a.ref_L == 1 ? 0 : 2;
   bool staged = false;
+  unsigned gmax_bits = 0;
   for (int qw = q_begin + wave * 16; qw < q_end; qw += nwave * 16) {
     const int q = qw + (lane >> 2);
     const bool live = q < q_end;
@@ -606,6 +609,15 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
       }
     }
     const uint4 go = live ? *reinterpret_cast<const uint4*>((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8) : make_uint4(0, 0, 0, 0);
+    {   // running max |dout| of this (batch, head) slice for the scatter's fixed-point scale: bf16 magnitudes order like their bits
+      const unsigned w4[4] = {go.x, go.y, go.z, go.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned lo = w4[i] & 0x7fffu, hi = (w4[i] >> 16) & 0x7fffu;
+        gmax_bits = lo > gmax_bits ? lo : gmax_bits;
+        gmax_bits = hi > gmax_bits ? hi : gmax_bits;
+      }
+    }
     if (!staged) { __syncthreads(); staged = true; }       // (drains the LDS-DMA; every wave has at least one pass: chunks hold >= 16 * nwave queries or the block's waves beyond the chunk skip the loop -- see below)
     // ---- corner dots of every sample, kept by the owner lane ----
     float d00[NS], d01[NS], d10[NS], d11[NS];
@@ -680,6 +692,18 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
     }
   }
   if (!staged) __syncthreads();        // waves without a query still take part in the block's one barrier
+  if (a.gmax) {
+    __shared__ unsigned gred[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)gmax_bits, o, 64); gmax_bits = t > gmax_bits ? t : gmax_bits; }
+    if (lane == 0) gred[wave] = gmax_bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned mxb = 0;
+      for (int i = 0; i < nwave; ++i) mxb = gred[i] > mxb ? gred[i] : mxb;
+      a.gmax[bm * a.gmax_n + chunk] = __uint_as_float(mxb << 16);      // (a NaN / Inf magnitude stays NaN / Inf: the scatter writes zeros)
+    }
+  }
 }
 
 // d value via LDS-privatised scatter.  Float LDS atomics run at ~1 lane / 4 clk on gfx950 (measured: 245 clk per
@@ -694,7 +718,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
 // their corner contributions.
 #define MSDA_SLAB_PITCH 33
 template <class T, int L, int P>
-__global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
+__global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, int probe) {
   constexpr int LP = L * P;
   constexpr int QB = 32 / P;          // queries per half-wave iteration
   static_assert(P <= 32, "one lane per sample");
@@ -708,8 +732,14 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
     if (lev == l) { H = a.h[l]; W = a.w[l]; lstart = a.start[l]; }
   for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0;
   const T* gbase = (const T*)a.dout + (long long)b * a.Lq * (a.M * 32) + m * 32;
-  float mx = 0.f;
-  for (int i = threadIdx.x; i < a.Lq * 32; i += blockDim.x) mx = fmaxf(mx, fabsf(to_f32(gbase[(long long)(i >> 5) * (a.M * 32) + (i & 31)])));
+  float mx = (probe & 1) ? 4.f : 0.f;
+  if (a.gmax_n > 0) {        // left by the gradient kernel that has just read all of dout (the scan below costs 12 us of a 60 us kernel)
+    for (int i = threadIdx.x; i < a.gmax_n; i += blockDim.x) {
+      mx = fmaxf(mx, a.gmax[(long long)blockIdx.x * a.gmax_n + i]);
+    }
+  } else if (!(probe & 1)) {
+    for (int i = threadIdx.x; i < a.Lq * 32; i += blockDim.x) mx = fmaxf(mx, fabsf(to_f32(gbase[(long long)(i >> 5) * (a.M * 32) + (i & 31)])));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -731,7 +761,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a) {
   // this replaces three cross-lane shuffles plus the per-lane floor / weight / validity arithmetic of every step
   float4* rec_w = reinterpret_cast<float4*>(slab + a.g_npix_max * MSDA_SLAB_PITCH) + half * 32;
   int* rec_f = reinterpret_cast<int*>(reinterpret_cast<float4*>(slab + a.g_npix_max * MSDA_SLAB_PITCH) + nhalf * 32) + half * 32;
-  for (int q0 = half * QB; q0 < a.Lq; q0 += nhalf * QB) {
+  for (int q0 = half * QB; q0 < ((probe & 2) ? 0 : a.Lq); q0 += nhalf * QB) {
     {
       float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
       int f00 = 0;
@@ -829,7 +859,8 @@ extern "C" int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L) {
 }
 
 extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P) {
-  return (size_t)B * Lq * M * L * P * sizeof(float);
+  // softmax probabilities + the gradient kernel's per-block max |dout| (at most 256 / (B M) + 1 blocks per (batch, head))
+  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M) * sizeof(float);
 }
 
 template <class T>
@@ -911,7 +942,7 @@ static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t 
   if (L == LL && P == PP) {                                                                                   \
     static bool attr = false;                                                                                 \
     if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
-    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, LL, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a); \
+    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, LL, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a, g_tune.msda_fwd_probe >> 4); \
     return check_launch("emrt_msda_bwd(lds scatter)");                                                        \
   }
   MSDA_LDS_CASE(3, 6)
@@ -1011,6 +1042,8 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
       if (chunks < 1) chunks = 1;
       const int qpb = (Lq + chunks - 1) / chunks;
       chunks = (Lq + qpb - 1) / qpb;
+      a.gmax = (float*)workspace + (size_t)B * Lq * M * L * P;
+      a.gmax_n = chunks;
       rc = msda_launch_bwd_grad_lds<bf16_t>(a, L, P, chunks, qpb, guard, slab, st);
     } else {
       rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
