@@ -566,15 +566,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
 
 // fp32 NCHW images -> T NHWC
 template <class T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, int H, int W) {
-  const long long total = (long long)N * H * W * C;
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, int H, int W, int CO) {
+  // CO >= C output channels, the extra ones zero: the 3-channel image as an 8-channel map puts the first convolutions (and their
+  // weight gradients) on the 16-byte vector path of the GEMM kernels
+  const long long total = (long long)N * H * W * CO;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % C);
-    long long r = idx / C;
+    const int c = (int)(idx % CO);
+    long long r = idx / CO;
     const int w = (int)(r % W); r /= W;
     const int h = (int)(r % H);
     const int n = (int)(r / H);
-    out[idx] = from_f32<T>(in[(((long long)n * C + c) * H + h) * W + w]);
+    out[idx] = from_f32<T>(c < C ? in[(((long long)n * C + c) * H + h) * W + w] : 0.f);
   }
 }
 
@@ -779,14 +781,15 @@ extern "C" int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, v
   return check_launch("emrt_maxpool_bwd");
 }
 
-extern "C" int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream) {
+extern "C" int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int c_out, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out, "null pointer");
+  EMRT_REQUIRE(c_out >= C, "the output has at least the input's channels");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = ew_grid((long long)N * C * H * W);
-  if (dtype == EMRT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, in, (float*)out, N, C, H, W);
-  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W);
-  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t>), dim3(grid), dim3(256), 0, st, in, (f16_t*)out, N, C, H, W);
+  const int grid = ew_grid((long long)N * c_out * H * W);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(grid), dim3(256), 0, st, in, (float*)out, N, C, H, W, c_out);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, N, C, H, W, c_out);
+  else hipLaunchKernelGGL((nchw_to_nhwc_kernel<f16_t>), dim3(grid), dim3(256), 0, st, in, (f16_t*)out, N, C, H, W, c_out);
   return check_launch("emrt_nchw_to_nhwc");
 }
 

@@ -898,12 +898,14 @@ def mha(qk, v, n_heads, pdrop, salt):
 # ---------------------------------------------------------------------------------------------------
 # spatial ops
 # ---------------------------------------------------------------------------------------------------
-def nchw_to_nhwc(img):
+def nchw_to_nhwc(img, c_out=None):
+    """fp32 [N,C,H,W] -> compute-dtype [N,H,W,c_out] (c_out >= C, extra channels zero)."""
     c = ctx()
     N, C, H, W = img.shape
     assert img.dtype == torch.float32 and img.is_contiguous()
-    out = c.empty((N, H, W, C))
-    _L().call("emrt_nchw_to_nhwc", P(img), P(out), N, C, H, W, c.dtype, c.stream)
+    co = C if c_out is None else int(c_out)
+    out = c.empty((N, H, W, co))
+    _L().call("emrt_nchw_to_nhwc", P(img), P(out), N, C, H, W, co, c.dtype, c.stream)
     return out
 
 

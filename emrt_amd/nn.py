@@ -51,6 +51,13 @@ class ParamStore:
         self.offsets, off = {}, 0
         fused_follow = {m for grp in fused_groups for m in grp[1:]}
         self.n_train = 0
+        # conv weights stored with MORE input channels than the layer has (Conv2D(pad_cin=)): the extra channels stay zero (zero
+        # input, zero gradient, zero decay) and the parameter is the [:, :cin] slice of the stored tensor
+        self.padded_cin = {}
+        for mname, mod in model.named_modules():
+            if getattr(mod, "pad_cin", None) and isinstance(getattr(mod, "weight", None), tnn.Parameter):
+                self.padded_cin[(mname + "." if mname else "") + "weight"] = int(mod.pad_cin)
+        numel = lambda n: by_name[n].numel() // by_name[n].shape[1] * self.padded_cin[n] if n in self.padded_cin else by_name[n].numel()
         for i, n in enumerate(order):
             p = by_name[n]
             if n not in fused_follow:
@@ -61,7 +68,7 @@ class ParamStore:
             else:
                 assert off % 8 == 0, "fused parameter group member %s must start 16-byte aligned in the compute-dtype mirror" % n
             self.offsets[n] = off
-            off += p.numel()
+            off += numel(n)
             if i == self.n_trainable_names - 1:
                 self.n_train = _align(off, 8)     # [0, n_train) is what clip / SGD / all-reduce cover
         self.n_total = _align(off, 8)
@@ -71,12 +78,13 @@ class ParamStore:
         self.views = {}
         for n in order:
             p = by_name[n]
-            a, cnt = self.offsets[n], p.numel()
+            a, cnt = self.offsets[n], numel(n)
             flat, gflat = self.master[a:a + cnt], self.grad[a:a + cnt]
-            if p.dim() == 4:    # conv weight: logical [OC,C,KH,KW], memory [OC][KH][KW][C]
+            if p.dim() == 4:    # conv weight: logical [OC,C,KH,KW], memory [OC][KH][KW][C (padded)]
                 OC, C, KH, KW = p.shape
-                view = flat.view(OC, KH, KW, C).permute(0, 3, 1, 2)
-                gview = gflat.view(OC, KH, KW, C).permute(0, 3, 1, 2)
+                Cp = self.padded_cin.get(n, C)
+                view = flat.view(OC, KH, KW, Cp).permute(0, 3, 1, 2)[:, :C]
+                gview = gflat.view(OC, KH, KW, Cp).permute(0, 3, 1, 2)[:, :C]
             else:
                 view, gview = flat.view(p.shape), gflat.view(p.shape)
             view.copy_(p.data.to(device=device, dtype=torch.float32))
@@ -85,7 +93,7 @@ class ParamStore:
             p.requires_grad_(False)
             self.views[n] = (a, cnt)
         self.train_order = order[:self.n_trainable_names]
-        self.lr_ranges = [(self.offsets[n], self.offsets[n] + by_name[n].numel()) for n in lr_mult_names]
+        self.lr_ranges = [(self.offsets[n], self.offsets[n] + numel(n)) for n in lr_mult_names]
         self.lr_mult = lr_mult
         # buffers (BN running statistics): one flat fp32 buffer
         bufs = [(n, b) for n, b in model.named_buffers()]
@@ -227,16 +235,19 @@ class HipLayer(tnn.Module):
 
 
 class Conv2D(HipLayer):
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, need_dx=True, dilation=1):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, need_dx=True, dilation=1, pad_cin=None):
+        """pad_cin: the layer is fed maps with pad_cin >= cin channels whose extra channels are zero (the image as an 8-channel
+        map, Fn.nchw_to_nhwc(c_out=)); its weights are stored with that many input channels (ParamStore.padded_cin)."""
         super().__init__()
         self.cin, self.cout, self.k, self.stride, self.padding, self.need_dx = cin, cout, k, stride, padding, need_dx
         self.dilation = dilation
+        self.pad_cin = pad_cin if pad_cin and pad_cin > cin else None
         self.weight = tnn.Parameter(torch.empty(cout, cin, k, k))
         self.bias = tnn.Parameter(torch.zeros(cout)) if bias else None
         self.gw = None
 
     def bind(self, store, prefix):
-        self.gw = store.make_gemm(store.offsets[prefix + "weight"], self.cout, self.cin, self.k, self.k,
+        self.gw = store.make_gemm(store.offsets[prefix + "weight"], self.cout, store.padded_cin.get(prefix + "weight", self.cin), self.k, self.k,
                                   store.offsets[prefix + "bias"] if self.bias is not None else None, need_bwd=self.need_dx)
 
     def forward(self, x, relu=False, residual=None, out=None, out_f32=False):

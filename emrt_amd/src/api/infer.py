@@ -96,7 +96,7 @@ def _resize_nchw_f32(x, h, w):
         return x
     x = x.contiguous()
     nhwc = c.empty((N, H, W, C), torch.float32)
-    L.call("emrt_nchw_to_nhwc", Fn.P(x), Fn.P(nhwc), N, C, H, W, F32, c.stream)
+    L.call("emrt_nchw_to_nhwc", Fn.P(x), Fn.P(nhwc), N, C, H, W, C, F32, c.stream)
     out = c.empty((N, C, h, w), torch.float32)
     L.call("emrt_resize_bilinear_fwd", Fn.P(nhwc), H * W * C, C, H, W, Fn.P(out), 0, 0, h, w, None, 0, 0, N, C, 0, 1, F32, c.stream)
     return out

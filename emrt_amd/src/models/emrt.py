@@ -28,6 +28,11 @@ from ...runtime import ctx, Tape, F32, BF16
 NOGRAD_PARAMS = ("backbone.fc.weight", "backbone.fc.bias", "model.tgt_embed.weight")
 # parameters whose gradient is only final after the ops recorded before the tape's split mark (ResNet.forward) have run
 # backward; everything else can be exchanged between ranks while those run (engine.TrainEngine, two-phase step)
+# The image enters the network as an 8-channel NHWC map (channels 3..7 zero) and the three convolutions that read it (ResNet stem,
+# resnet50c deep stem, spatial_branch.Enc0) store their weights with 8 input channels: their forward and weight-gradient GEMMs then
+# take the 16-byte operand path (element-wise operand assembly at C = 3 cost 0.2 ms of an 10.6 ms step for 1 % of the FLOPs).
+IMAGE_CHANNELS = 8
+
 LATE_GRAD_PREFIXES = ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2.", "backbone.layer3.")   # (conv1.* also covers resnet50c's conv1.0 / .3 / .6)
 # the same per backward segment (two marks: before layer3 and before layer4): what the 2nd / 3rd segment complete
 GRAD_SEGMENT_PREFIXES = (("backbone.layer3.",), ("backbone.conv1.", "backbone.bn1.", "backbone.layer1.", "backbone.layer2."))
@@ -85,7 +90,7 @@ class ResNet(hnn.HipLayer):  # :152-257
         block = BasicBlock if depth in (18, 34) else BottleneckBlock
         layers = self.layer_cfg[depth]
         self.inplanes = 64
-        self.conv1 = hnn.Conv2D(3, 64, 7, 2, 3, bias=False, need_dx=False)
+        self.conv1 = hnn.Conv2D(3, 64, 7, 2, 3, bias=False, need_dx=False, pad_cin=IMAGE_CHANNELS)
         self.bn1 = hnn.BatchNorm2D(64)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], 2)
@@ -143,7 +148,7 @@ class ResNetV1c(hnn.HipLayer):  # backbones/resnet.py:102-221 with deep_stem=Tru
         dilations, strides = {32: ([1, 1], [2, 2]), 16: ([1, 2], [2, 1]), 8: ([2, 4], [1, 1])}[output_stride]
         self.inplanes = 128
         # nn.Sequential(conv, bn, relu, conv, bn, relu, conv): state-dict indices 0, 1, 3, 4, 6 (:124-134)
-        self.conv1 = hnn.Sequential(hnn.Conv2D(3, 64, 3, 2, 1, bias=False, need_dx=False), hnn.BatchNorm2D(64), None,
+        self.conv1 = hnn.Sequential(hnn.Conv2D(3, 64, 3, 2, 1, bias=False, need_dx=False, pad_cin=IMAGE_CHANNELS), hnn.BatchNorm2D(64), None,
                                     hnn.Conv2D(64, 64, 3, 1, 1, bias=False), hnn.BatchNorm2D(64), None,
                                     hnn.Conv2D(64, 128, 3, 1, 1, bias=False))
         self.bn1 = hnn.BatchNorm2D(128)
@@ -560,7 +565,8 @@ class branch_block(hnn.HipLayer):  # :80-97
     def __init__(self, cin, cout, first=False):
         super().__init__()
         self.first = first
-        self.encode = hnn.Sequential(hnn.Conv2D(cin, cout, 3, 1, 1, bias=False, need_dx=not first), hnn.BatchNorm2D(cout), None,
+        self.encode = hnn.Sequential(hnn.Conv2D(cin, cout, 3, 1, 1, bias=False, need_dx=not first, pad_cin=IMAGE_CHANNELS if first else None),
+                                     hnn.BatchNorm2D(cout), None,
                                      hnn.Conv2D(cout, cout, 3, 1, 1, bias=False), hnn.BatchNorm2D(cout), None)
 
     def forward(self, x, out=None):
@@ -741,7 +747,7 @@ class EMRT(hnn.HipLayer):  # :184-304
         c = ctx()
         assert inputs.dim() == 4 and inputs.shape[1] == 3 and inputs.shape[2] % 32 == 0 and inputs.shape[3] % 32 == 0, \
             "EMRT expects fp32 NCHW images whose H and W are multiples of 32 (paddle_EMRT.py:293)"
-        x = Fn.nchw_to_nhwc(inputs.contiguous())
+        x = Fn.nchw_to_nhwc(inputs.contiguous(), c_out=IMAGE_CHANNELS)
         B, H, W, _ = x.shape
         c1, c2, c3, c4 = self.backbone(x)
         SH, SW = H // 8, W // 8                 # x_context.shape[2:] (:283-288); tiles need not be square

@@ -145,8 +145,9 @@ int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void
 /* nn.MaxPool2D(3, 2, 1): paddle_vision_resnet.py:201; paddle_EMRT.py:84 (dense NHWC) */
 int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
 int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
-/* model input: fp32 NCHW images (paddle_EMRT.py:252) -> NHWC compute dtype */
-int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int dtype, void* stream);
+/* model input: fp32 NCHW images (paddle_EMRT.py:252) -> NHWC compute dtype with c_out >= C channels (the extra ones zero: the
+ * 3-channel image as an 8-channel map keeps the first convolutions on the GEMM kernels' 16-byte operand path) */
+int emrt_nchw_to_nhwc(const float* in, void* out, int N, int C, int H, int W, int c_out, int dtype, void* stream);
 
 /* ---- sliding-window inference glue, fp32 NCHW as the reference: src/api/infer.py:60-79 (crop / accumulate / count /
  * divide) and :150-155 (argmax; softmax dropped, it is monotonic).  origins_yx: HOST int[n][2], n <= 64 windows of

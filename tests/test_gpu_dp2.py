@@ -84,11 +84,13 @@ def _worker(rank, world, port, q):
                 assert eng.graph_a is not None and eng.graph_a2 is not None and eng.graph_b is not None
         for a, b in zip(traces["eager_plain"], traces["eager_early"]):
             assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), traces
-        assert abs(sums["eager_plain"] - sums["eager_early"]) <= 1e-6 * abs(sums["eager_plain"]), sums
+        # parameter checksums after 5 steps: the weight gradients are fp32 atomic sums whose order differs from run to run, so two
+        # runs of the SAME mode already differ by ~1e-6 relative; a wrong exchange (a bucket reduced twice or not at all) is 1e-3
+        assert abs(sums["eager_plain"] - sums["eager_early"]) <= 5e-6 * abs(sums["eager_plain"]), sums
         # the captured step cuts its graphs at the five SyncBatchNorm collectives (engine.GraphSequence): same arithmetic
         for a, b in zip(traces["eager_plain"], traces["graph_early"]):
             assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), traces
-        assert abs(sums["eager_plain"] - sums["graph_early"]) <= 1e-6 * abs(sums["eager_plain"]), sums
+        assert abs(sums["eager_plain"] - sums["graph_early"]) <= 5e-6 * abs(sums["eager_plain"]), sums
         assert eng.graph_a.n_graphs > 1, "the forward + first backward segment must have been cut at the SyncBatchNorm all-reduces"
         assert traces["graph_early"][-1] < traces["graph_early"][0]
         q.put((rank, "ok", traces["graph_early"]))

@@ -138,6 +138,43 @@ def test_linear_relu_backward(dtype):
     close("linear db", host(lin.bias.grad), br.grad, dtype, 8.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride,pad", [(7, 2, 3), (3, 1, 1)])
+def test_conv_on_the_padded_image(dtype, k, stride, pad):
+    """Conv2D(3, 64, pad_cin=8) fed the 8-channel image map (ResNet stem, spatial_branch.Enc0: paddle_vision_resnet.py:196,
+    paddle_EMRT.py:84-91): forward and weight gradient equal the 3-channel convolution; the parameter keeps its [64, 3, k, k]
+    shape, the stored padding channels and their gradients stay zero."""
+    c = init(dtype)
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 32, 40
+    img = torch.randn(N, 3, H, W, generator=g)
+    conv = hnn.Conv2D(3, 64, k, stride, pad, bias=False, need_dx=False, pad_cin=8)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(64, 3, k, k, generator=g) / math.sqrt(3 * k * k)))
+    w_ref = conv.weight.detach().clone()
+    h = Holder(conv=conv).place()
+    assert tuple(conv.weight.shape) == (64, 3, k, k) and conv.gw.C == 8
+    assert torch.equal(conv.weight.detach().cpu(), w_ref)
+    xr = rnd(img)
+    wr = w_ref.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad)
+    dy = rnd(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    xd = Fn.nchw_to_nhwc(img.cuda(), c_out=8)
+    tape = Tape()
+    c.tape = tape
+    y = conv(xd)
+    c.tape = None
+    close("padded conv fwd", host_map(y), yr.detach(), dtype)
+    run_bwd(tape, [(y, dev_map(dy))], [])
+    wscale = math.sqrt(N * yr.shape[2] * yr.shape[3])
+    close("padded conv wgrad", host(conv.weight.grad), wr.grad, dtype, wscale * (1.0 if dtype == F32 else 0.3))
+    a, cnt = h.store.views["conv.weight"]
+    stored = h.store.master[a:a + cnt].view(64, k, k, 8)
+    sgrad = h.store.grad[a:a + cnt].view(64, k, k, 8)
+    assert float(stored[..., 3:].abs().max()) == 0.0 and float(sgrad[..., 3:].abs().max()) == 0.0
+
+
 # -----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(4, 16, 16, 64), (2, 8, 8, 512), (8, 3, 3, 256), (2, 32, 32, 2048)])
@@ -712,6 +749,9 @@ def test_nchw_ingest_and_elementwise():
         img = torch.randn(2, 3, 16, 24, generator=g)
         y = Fn.nchw_to_nhwc(img.cuda())
         close("ingest", host_map(y), rnd(img), dtype, atol=0, rtol=0)
+        y8 = Fn.nchw_to_nhwc(img.cuda(), c_out=8)        # the image as an 8-channel map, channels 3..7 zero
+        assert tuple(y8.shape) == (2, 16, 24, 8) and float(y8[..., 3:].float().abs().max()) == 0.0
+        close("ingest padded", host_map(y8[..., :3].contiguous()), rnd(img), dtype, atol=0, rtol=0)
         a, b = rnd(torch.randn(2, 21, 64, generator=g)), rnd(torch.randn(21, 64, generator=g))
         s = Fn.add(dev(a), dev(b), period=21 * 64)
         close("add bcast", host(s), a + b, dtype)

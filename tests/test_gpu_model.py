@@ -427,7 +427,8 @@ def test_bf16_path_is_sane():
             fbf = ref.backbone(x)
     c = ctx()
     c.training, c.tape = True, None
-    feats = model.backbone(Fn.nchw_to_nhwc(x.cuda()))
+    from emrt_amd.src.models.emrt import IMAGE_CHANNELS
+    feats = model.backbone(Fn.nchw_to_nhwc(x.cuda(), c_out=IMAGE_CHANNELS))
     for name, a, b, h in zip(("c1", "c2", "c3", "c4"), f32, fbf, feats):
         h = h.float().cpu().permute(0, 3, 1, 2)
         e_torch = ((a - b.float()).norm() / a.norm()).item()
