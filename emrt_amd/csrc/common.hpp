@@ -45,6 +45,7 @@ struct Tuning {
   int pair_max;         // largest dgrad grid that is paired with its wgrad in one launch (768)
   int msda_fwd_global;  // 1 = never use the LDS-staged MSDA forward
   int msda_bwd_global;  // 1 = never use the LDS-staged MSDA gradient kernel
+  int msda_lds_min_pairs; // smallest B * M * Lq that takes the LDS-staged MSDA kernels (2048: the decoder's 110 queries too, 29 -> 13 us)
   int msda_fwd_chunks;  // LDS-staged MSDA forward: query chunks per (batch, head) slab (0 = automatic)
   int msda_fwd_threads; // ... threads per block (1024)
   int msda_fwd_probe;   // timing experiments only (results are WRONG): 1 = no gather, 2 = no staging, 4 = no preparation

@@ -988,7 +988,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
   const int guard = wmax + 2;                                  // zero rows on both sides of the staged slab (msda_fwd_lds_kernel)
   const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
-  if (dtype != EMRT_F32 && slab <= 159 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_fwd_global) {
+  if (dtype != EMRT_F32 && slab <= 159 * 1024 && (long long)B * M * Lq >= g_tune.msda_lds_min_pairs && !g_tune.msda_fwd_global) {
     // one block per CU (the slab takes most of its LDS): as close to 256 blocks as whole chunks of >= 128 queries allow
     int chunks = (256 + B * M / 2) / (B * M);
     if (g_tune.msda_fwd_chunks > 0) chunks = g_tune.msda_fwd_chunks;
@@ -1036,7 +1036,7 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     const int guard = wmax + 2;
     const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
     int rc;
-    if (dtype == EMRT_BF16 && !dref && slab <= 159 * 1024 && (long long)B * M * Lq >= 8192 && !g_tune.msda_bwd_global) {
+    if (dtype == EMRT_BF16 && !dref && slab <= 159 * 1024 && (long long)B * M * Lq >= g_tune.msda_lds_min_pairs && !g_tune.msda_bwd_global) {
       int chunks = (256 + B * M / 2) / (B * M);
       if (chunks > (Lq + 127) / 128) chunks = (Lq + 127) / 128;
       if (chunks < 1) chunks = 1;

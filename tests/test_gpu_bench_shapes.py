@@ -30,7 +30,8 @@ from tests.test_gpu_kernels import _msda_ref, run_bwd   # noqa: E402
 # -----------------------------------------------------------------------------------------------------------------
 MSDA_BENCH = [
     dict(name="cfg2-encoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=None, lds=True),
-    dict(name="cfg2-decoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=110, lds=False),    # B*M*Lq = 7040 < 8192: global kernel
+    dict(name="cfg2-decoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=110, lds=True),     # B*M*Lq = 7040 >= 2048: LDS kernel too (forward)
+    dict(name="tiny-decoder", B=1, shapes=[(32, 32), (16, 16), (8, 8)], Lq=110, lds=False),    # B*M*Lq = 880: global kernel
     dict(name="cfg3-encoder", B=4, shapes=[(64, 64), (32, 32), (16, 16)], Lq=None, lds=False),   # slab 430 KB: global kernel
 ]
 
@@ -71,7 +72,7 @@ def test_msda_bench_shape_bf16_vs_oracle(cfg):
     tape.watch(vd)
     tape.watch(od)
     # which kernel ran is decided by the same rule the dispatcher uses (msda.hip: emrt_msda_fwd)
-    uses_lds = Lv * 80 <= 150 * 1024 and B * M * Lq >= 8192
+    uses_lds = Lv * 80 <= 150 * 1024 and B * M * Lq >= 2048
     assert uses_lds == cfg["lds"], "the test case no longer selects the kernel it was written for"
     # bf16 output of an fp32 accumulation over bf16 values: one rounding of the result (2^-9 relative) + accumulation noise
     close("msda fwd (bench shape)", host(y), out_r.detach(), BF16, atol=2e-2, rtol=1e-2)
