@@ -34,7 +34,8 @@ struct MsdaArgs {
   const void* dout;
   float* dvalue;      // fp32 [B][Lv][M*32] dense, accumulated with atomics (caller zeroes)
   long long dv_bs;
-  float* doffw;       // fp32 [B*Lq][ldo] (offset + logit gradients), fully overwritten
+  void* doffw;        // [B*Lq][ldo] (offset + logit gradients), fully overwritten: fp32, or the compute dtype T when doffw_t
+  int doffw_t;
   float* dref;        // fp32 [B][Lq][ref_L][2] or null, fully overwritten
   float* probs;       // fp32 [B*Lq][M*L*P] softmax probabilities (written by the gradient kernel, read by the LDS scatter)
   void* dvalue_t;     // LDS path: [B][Lv][M*32] in the compute dtype, fully overwritten
@@ -47,6 +48,22 @@ struct MsdaArgs {
 
 template <class T>
 __device__ __forceinline__ void load8(const T* p, float (&o)[8]) { Vec8<T>::load(p, o); }
+
+// one sample's offset / logit gradients into the [ldo] row: fp32, or rounded to the compute dtype when the consumer (the
+// offsets|logits projection's backward GEMM) reads T anyway (saves the cast launch and half the bytes)
+template <class T>
+__device__ __forceinline__ void store_doffw(const MsdaArgs& a, long long bq, int off_idx, int log_idx, float gx, float gy, float gl) {
+  if (a.doffw_t) {
+    T* row = (T*)a.doffw + bq * a.ldo;
+    row[off_idx] = from_f32<T>(gx);
+    row[off_idx + 1] = from_f32<T>(gy);
+    row[log_idx] = from_f32<T>(gl);
+  } else {
+    float* row = (float*)a.doffw + bq * a.ldo;
+    *reinterpret_cast<float2*>(row + off_idx) = make_float2(gx, gy);
+    row[log_idx] = gl;
+  }
+}
 
 // ---- forward -------------------------------------------------------------------------------------------------------
 // A quad (4 lanes x 8 channels) owns one (query, head) pair.  Everything that does not depend on the channel -- the
@@ -480,14 +497,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
     for (int i = 0; i < LP; ++i) pp[i] = pr[i];
   }
   if (live && sub == 0) {
-    float* drow = a.doffw + bq * a.ldo;
-    float* doff = drow + m * LP * 2;
-    float* dlog = drow + a.M * LP * 2 + m * LP;
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
-      *reinterpret_cast<float2*>(doff + i * 2) = make_float2(gx[i], gy[i]);
-      dlog[i] = pr[i] * (dA[i] - dot);
-    }
+    for (int i = 0; i < LP; ++i) store_doffw<T>(a, bq, (m * LP + i) * 2, a.M * LP * 2 + m * LP + i, gx[i], gy[i], pr[i] * (dA[i] - dot));
   }
   if (a.dref) {
     // loc = ref + off/W  =>  d ref_x = W * d x ; sum over points, then over the 8 heads (lane bits 2..4; needs M == 8)
@@ -676,16 +687,12 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
     }
     dotp = quad_add(dotp);
     if (live) {
-      float* drow = a.doffw + bq * a.ldo;
-      float* doff = drow + m * LP * 2;
-      float* dlog = drow + a.M * LP * 2 + m * LP;
       float* pp = a.probs + bq * (a.M * LP) + m * LP;
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
         const int smp = sub + 4 * j;
         if (smp < LP) {
-          *reinterpret_cast<float2*>(doff + smp * 2) = make_float2(gx[j], gy[j]);
-          dlog[smp] = pr[j] * (dA[j] - dotp);
+          store_doffw<T>(a, bq, (m * LP + smp) * 2, a.M * LP * 2 + m * LP + smp, gx[j], gy[j], pr[j] * (dA[j] - dotp));
           pp[smp] = pr[j];
         }
       }
@@ -1005,8 +1012,8 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
 // dvalue: when emrt_msda_bwd_uses_lds(shapes) it is [B][Lv][M*D] in the COMPUTE dtype and fully overwritten (workspace
 // of emrt_msda_bwd_workspace_bytes required); otherwise fp32, pre-zeroed by the caller, accumulated with global atomics.
 extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
-                             long long ref_bs, int ref_L, const void* dout, void* dvalue, float* doffw, float* dref, int B, int Lq,
-                             int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream) {
+                             long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref,
+                             int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
   EMRT_REQUIRE(value && offw && ref && dout && dvalue && doffw && shapes_hw, "null pointer");
@@ -1017,7 +1024,7 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
   MsdaArgs a;
   memset(&a, 0, sizeof(a));
   a.value = value; a.ldv = ldv; a.v_bs = v_bs; a.offw = offw; a.ldo = ldo; a.ref = ref; a.ref_bs = ref_bs; a.ref_L = ref_L;
-  a.dout = dout; a.dv_bs = (long long)Lv * M * 32; a.doffw = doffw; a.dref = dref;
+  a.dout = dout; a.dv_bs = (long long)Lv * M * 32; a.doffw = doffw; a.doffw_t = (doffw_compute_dtype && dtype != EMRT_F32) ? 1 : 0; a.dref = dref;
   a.B = B; a.Lq = Lq; a.M = M; a.Lv = Lv;
   EMRT_REQUIRE(msda_fill(a, shapes_hw, L, Lv) == 0, "sum(h*w) != Lv");
   hipStream_t st = (hipStream_t)stream;

@@ -317,7 +317,7 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
             dy = tape.pop_grad(out)
             if dy is None:
                 return
-            if out_f32:
+            if out_f32 and dy.dtype == torch.float32:      # (a producer may hand the gradient over in the compute dtype already: Fn.msda)
                 dy = cast_from_f32(dy)
             if relu and getattr(out, "_premasked", None) is not dy:
                 assert dy.is_contiguous() and out.is_contiguous()
@@ -841,7 +841,8 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
                 return
             assert dy.is_contiguous()
             use_lds = bool(_L().query("emrt_msda_bwd_uses_lds", ctypes.cast(arr, ctypes.c_void_p), L))
-            doffw = c.zeros((B, Lq, ldo), torch.float32) if ldo != M * L * Pn * 3 else c.empty((B, Lq, ldo), torch.float32)
+            odt = None if c.dtype != F32 else torch.float32      # compute dtype: the projection's backward GEMM reads it directly
+            doffw = c.zeros((B, Lq, ldo), odt) if ldo != M * L * Pn * 3 else c.empty((B, Lq, ldo), odt)
             dref = c.empty((B, Lq, ref_L, 2), torch.float32) if need_dref else None
             if use_lds:
                 dvalue = c.empty((B, Lv, CC))          # compute dtype, fully overwritten by the LDS scatter
@@ -850,7 +851,7 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
                 dvalue = c.zeros((B, Lv, CC), torch.float32)
                 ws = None
             _L().call("emrt_msda_bwd", P(value), value.stride(1), value.stride(0), P(offw), ldo, P(ref), ref_bs, ref_L, P(dy), P(dvalue), P(doffw),
-                      P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), P(ws), c.dtype, c.stream)
+                      int(c.dtype != F32), P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), P(ws), c.dtype, c.stream)
             tape.add_grad(value, dvalue if use_lds else cast_from_f32(dvalue), owned=True)
             tape.add_grad(offw, doffw, owned=True)
             if need_dref:

@@ -121,13 +121,14 @@ int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gam
  * value [B][Lv][M*D] (D = 32); offw fp32 [B*Lq][ldo] = M*L*P*2 offsets then M*L*P logits per row;
  * ref fp32 [B or 1][Lq][ref_L][2] (ref_bs = 0 broadcasts over batch; ref_L = L, or 1 to share one point across levels); shapes_hw: HOST int [L][2] = (H_l, W_l); out [B][Lq][M*D]. */
 int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, void* out, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream);
-/* Backward.  doffw [B*Lq][ldo] and dref [B][Lq][ref_L][2] (nullable) are overwritten.  dvalue: when
+/* Backward.  doffw [B*Lq][ldo] (fp32, or the compute dtype when doffw_compute_dtype != 0 and dtype is a 2-byte type: what the
+ * offsets|logits projection's backward GEMM reads) and dref [B][Lq][ref_L][2] (nullable) are overwritten.  dvalue: when
  * emrt_msda_bwd_uses_lds(shapes_hw, L) == 1 (every level group's fp32 slab fits in LDS) it is [B][Lv][M*D] in the
  * compute dtype, fully overwritten by an LDS-privatised scatter (needs `workspace` of emrt_msda_bwd_workspace_bytes);
  * otherwise it is fp32, must be zeroed by the caller and is accumulated with global atomics. */
 int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L);
 size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P);
-int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, void* dvalue, float* doffw, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream);
+int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream);
 
 /* ---- fused softmax(QK^T/sqrt(d)) V with dropout on the weights: EMRT_utils/layers.py:283-303 (L <= 128, D = 32) */
 int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);

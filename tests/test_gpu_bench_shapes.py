@@ -90,7 +90,8 @@ def test_msda_bench_shape_bf16_vs_oracle(cfg):
     rel_v = ((host(dv) - gv).norm() / gv.norm()).item()
     rel_o = ((host(do) - go).norm() / go.norm()).item()
     print("msda %s: fwd rel %.2e, dvalue rel %.2e, doffw rel %.2e" % (cfg["name"], rel, rel_v, rel_o))
-    # dvalue: fixed-point LDS scatter then ONE bf16 rounding; doffw: fp32 from bf16 operands
+    # dvalue: fixed-point LDS scatter then ONE bf16 rounding; doffw: fp32 arithmetic on bf16 operands, stored in bf16 (what the
+    # projection's backward GEMM reads: the old fp32 tensor was cast to exactly these values by a separate launch)
     assert rel_v < 6e-3 and rel_o < 6e-3, (rel_v, rel_o)
     close("msda dvalue (bench shape)", host(dv), gv, BF16, atol=6e-2 * float(gv.abs().max()) / 8, rtol=2e-2)
     # the LDS-staged gradient kernel (encoder calls) against the global-gather one: same math, other summation order
@@ -106,7 +107,7 @@ def test_msda_bench_shape_bf16_vs_oracle(cfg):
     finally:
         L_.set_tuning("msda_bwd_global", old)
     rel_k = ((host(do) - host(do2)).norm() / host(do2).norm()).item()
-    assert rel_k < 1e-5, rel_k
+    assert rel_k < 5e-4, rel_k          # bf16 outputs: a last-bit fp32 difference flips a rounding (1 ulp = 4e-3) in a few elements
     assert (host(dv) - host(dv2)).abs().max().item() <= 2e-2 * float(gv.abs().max())       # one bf16 ulp where the probabilities differ in the last bit
 
 
