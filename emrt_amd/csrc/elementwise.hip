@@ -222,6 +222,53 @@ extern "C" int emrt_add3d(const void* a, long long a_bs, long long a_rs, const v
   return check_launch("emrt_add3d");
 }
 
+// ---- token concat / split: [B][n_i][C] dense parts <-> dense [B][sum n_i][C] in ONE launch (the pyramid-pooling tokens of
+// paddle_EMRT.py:70-78 took a memset and four accumulates each way) ----
+#define EMRT_MAX_PARTS 8
+struct ConcatArgs {
+  void* part[EMRT_MAX_PARTS];
+  int n[EMRT_MAX_PARTS], start[EMRT_MAX_PARTS];
+  int nparts, B, C4, total;
+};
+template <class T, int SPLIT>
+__global__ __launch_bounds__(256) void concat_tokens_kernel(ConcatArgs a, T* __restrict__ whole) {
+  const long long count = (long long)a.B * a.total * a.C4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % a.C4);
+    long long r = idx / a.C4;
+    const int row = (int)(r % a.total), b = (int)(r / a.total);
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < EMRT_MAX_PARTS; ++k)
+      if (k < a.nparts && row >= a.start[k]) p = k;
+    T* pp = (T*)a.part[p] + (((long long)b * a.n[p] + (row - a.start[p])) * a.C4 + q) * 4;
+    T* wp = whole + idx * 4;
+    float v[4];
+    if (SPLIT) { Vec4<T>::load(wp, v); Vec4<T>::store(pp, v); }
+    else { Vec4<T>::load(pp, v); Vec4<T>::store(wp, v); }
+  }
+}
+extern "C" int emrt_concat_tokens(void* const* parts, const int* n, int nparts, void* whole, int B, int C, int split, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
+  EMRT_REQUIRE(parts && n && whole && nparts >= 1 && nparts <= EMRT_MAX_PARTS && C % 4 == 0 && B > 0, "1..8 parts, C a multiple of 4");
+  ConcatArgs a;
+  memset(&a, 0, sizeof(a));
+  int total = 0;
+  for (int i = 0; i < nparts; ++i) {
+    EMRT_REQUIRE(parts[i] && n[i] > 0, "null / empty part");
+    a.part[i] = parts[i]; a.n[i] = n[i]; a.start[i] = total;
+    total += n[i];
+  }
+  a.nparts = nparts; a.B = B; a.C4 = C / 4; a.total = total;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid((long long)B * total * (C / 4));
+#define CONCAT_LAUNCH(T) do { if (split) hipLaunchKernelGGL((concat_tokens_kernel<T, 1>), dim3(grid), dim3(256), 0, st, a, (T*)whole); \
+                              else hipLaunchKernelGGL((concat_tokens_kernel<T, 0>), dim3(grid), dim3(256), 0, st, a, (T*)whole); } while (0)
+  if (dtype == EMRT_F32) CONCAT_LAUNCH(float); else if (dtype == EMRT_BF16) CONCAT_LAUNCH(bf16_t); else CONCAT_LAUNCH(f16_t);
+#undef CONCAT_LAUNCH
+  return check_launch("emrt_concat_tokens");
+}
+
 extern "C" int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const void* src, long long src_bs, long long src_rs, long long B,
                           long long rows, long long cols, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);

@@ -189,28 +189,26 @@ def add_maps(a, b):
 
 
 def concat_tokens(parts):
-    """[B, n_i, C] dense parts -> dense [B, sum n_i, C]."""
+    """[B, n_i, C] dense parts -> dense [B, sum n_i, C]: one launch, and one for the backward split."""
     c = ctx()
     B, C = parts[0].shape[0], parts[0].shape[2]
-    total = sum(p_.shape[1] for p_ in parts)
-    out = c.zeros((B, total, C), parts[0].dtype)
-    start = 0
-    spans = []
-    for p_ in parts:
-        n = p_.shape[1]
-        add_into(out.narrow(1, start, n), p_)
-        spans.append((start, n))
-        start += n
+    assert all(p_.is_contiguous() and p_.shape[0] == B and p_.shape[2] == C and p_.dtype == parts[0].dtype for p_ in parts) and len(parts) <= 8
+    ns = [p_.shape[1] for p_ in parts]
+    out = c.empty((B, sum(ns), C), parts[0].dtype)
+    dt = dtype_of(parts[0])
+    n_arr = (ctypes.c_int * len(parts))(*ns)
+    _L().call("emrt_concat_tokens", (ctypes.c_void_p * len(parts))(*[p_.data_ptr() for p_ in parts]), n_arr, len(parts), P(out), B, C, 0, dt, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
             g = tape.pop_grad(out)
             if g is None:
                 return
-            for p_, (s0, n) in zip(parts, spans):
-                gp = c.zeros(tuple(p_.shape), p_.dtype)
-                add_into(gp, g.narrow(1, s0, n))
-                tape.add_grad(p_, gp)
+            assert g.is_contiguous()
+            gps = [c.empty(tuple(p_.shape), p_.dtype) for p_ in parts]
+            _L().call("emrt_concat_tokens", (ctypes.c_void_p * len(parts))(*[g_.data_ptr() for g_ in gps]), n_arr, len(parts), P(g), B, C, 1, dt, c.stream)
+            for p_, gp in zip(parts, gps):
+                tape.add_grad(p_, gp, owned=True)
         tape.record(bwd)
     return out
 
@@ -949,6 +947,41 @@ def resize_bilinear(x, OH, OW, align_corners, add_t=None, out=None, out_nchw_f32
                 tape.add_grad(add_t, dy)
         tape.record(bwd)
     return out
+
+
+def pyramid_tokens_to_maps(tokens, scales, OH, OW, outs):
+    """tokens [B, sum k^2, C] (the decoder's pyramid queries) -> for each scale k its k x k map resized (bilinear,
+    align_corners=True) to OH x OW and written into outs[i] (channel slices of the concat buffer): paddle_EMRT.py:281-291.
+    Forward = one resize launch per scale on token-slab views; the backward writes every scale's gradient straight into its rows
+    of ONE token-gradient buffer (the slabs tile it exactly), instead of a zeroed buffer and one accumulate launch per scale."""
+    c = ctx()
+    B, ntok, C = tokens.shape
+    assert tokens.is_contiguous() and ntok == sum(k * k for k in scales) and len(outs) == len(scales)
+    esz = tokens.element_size()
+    geo, start = [], 0
+    for k, out in zip(scales, outs):
+        _, oh_, ow_, oc_, out_ld, out_bs = _check_map(out)
+        assert (oh_, ow_, oc_) == (OH, OW, C)
+        _L().call("emrt_resize_bilinear_fwd", ctypes.c_void_p(tokens.data_ptr() + start * C * esz), ntok * C, C, k, k, P(out), out_bs, out_ld, OH, OW,
+                  None, 0, 0, B, C, 1, 0, c.dtype, c.stream)
+        geo.append((k, start, out))
+        start += k * k
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dys = [tape.pop_grad(out) for _, _, out in geo]
+            if all(d is None for d in dys):
+                return
+            dtok = c.empty((B, ntok, C)) if all(d is not None for d in dys) else c.zeros((B, ntok, C))
+            for (k, s0, _), dy in zip(geo, dys):
+                if dy is None:
+                    continue
+                _, _, _, _, do_ld, do_bs = _check_map(dy)
+                _L().call("emrt_resize_bilinear_bwd", P(dy), do_bs, do_ld, OH, OW, ctypes.c_void_p(dtok.data_ptr() + s0 * C * esz), ntok * C, C, k, k,
+                          B, C, 1, 0, None, c.dtype, c.stream)
+            tape.add_grad(tokens, dtok, owned=True)
+        tape.record(bwd)
+    return outs
 
 
 def adaptive_avgpool_tokens(x, scales):

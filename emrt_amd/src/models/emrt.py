@@ -758,11 +758,7 @@ class EMRT(hnn.HipLayer):  # :184-304
         maps = [Fn.tokens_as_map(Fn.narrow(memory, 1, a, n), h, w) for (h, w), (a, n) in zip(shapes, spans)]
         nps = len(self.psp_scale)
         self.EFP(maps[0], maps[1], maps[2], out=Fn.narrow(psp_cat, 3, 256 * (1 + nps), 256))
-        idx = 0
-        for i, k in enumerate(self.psp_scale):  # :281-291
-            pooled = Fn.tokens_as_map(Fn.narrow(hs, 1, idx, k * k), k, k)
-            Fn.resize_bilinear(pooled, SH, SW, True, out=Fn.narrow(psp_cat, 3, 256 * (1 + i), 256))
-            idx += k * k
+        Fn.pyramid_tokens_to_maps(hs, self.psp_scale, SH, SW, [Fn.narrow(psp_cat, 3, 256 * (1 + i), 256) for i in range(nps)])  # :281-291
         o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True)
         o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
         o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW)

@@ -189,6 +189,9 @@ int emrt_pack_weights(const float* master, void* packed, const long long* desc_d
  * F.sigmoid, casts: transformer_encoder_decoder.py:115-122,154-161,250-263,273-280,466; paddle_EMRT.py:208; fcn_head.py:65 */
 int emrt_add(const void* a, const void* b, void* out, long long n, long long period, int dtype, void* stream);
 int emrt_add3d(const void* a, long long a_bs, long long a_rs, const void* b, long long b_bs, long long b_rs, void* out, long long out_bs, long long out_rs, long long B, long long rows, long long cols, int dtype, void* stream);
+/* [B][n_i][C] dense parts -> dense whole [B][sum n_i][C] (split = 0) or back (split = 1), one launch; parts / n: HOST arrays (<= 8):
+ * the pyramid-pooling token concat of paddle_EMRT.py:70-78 and its backward */
+int emrt_concat_tokens(void* const* parts, const int* n, int nparts, void* whole, int B, int C, int split, int dtype, void* stream);
 int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const void* src, long long src_bs, long long src_rs, long long B, long long rows, long long cols, int dtype, void* stream);
 int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream);
 int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode, long long hw, int C, int dtype, void* stream);

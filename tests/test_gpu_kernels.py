@@ -771,6 +771,30 @@ def test_nchw_ingest_and_elementwise():
         close("sigmoid", sg.cpu(), torch.sigmoid(torch.linspace(-4, 4, 220)), F32, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_concat_tokens_and_its_split_backward(dtype):
+    """Pyramid-pooling tokens (1 + 9 + 36 + 64 per image, paddle_EMRT.py:70-78): concat in one launch, backward = one split launch."""
+    c = init(dtype)
+    g = torch.Generator().manual_seed(23)
+    B, C = 3, 64
+    parts = [rnd(torch.randn(B, n, C, generator=g)) for n in (1, 9, 36, 64)]
+    pd = [dev(p_) for p_ in parts]
+    tape = Tape()
+    c.tape = tape
+    y = Fn.concat_tokens(pd)
+    c.tape = None
+    for p_ in pd:
+        tape.watch(p_)
+    want = torch.cat(parts, 1)
+    close("concat", host(y), want, dtype, atol=0, rtol=0)
+    dy = rnd(torch.randn(want.shape, generator=g))
+    grads = run_bwd(tape, [(y, dev(dy))], pd)
+    s0 = 0
+    for p_, gp in zip(parts, grads):
+        close("split", host(gp), dy[:, s0:s0 + p_.shape[1]], dtype, atol=0, rtol=0)
+        s0 += p_.shape[1]
+
+
 def test_dropout_statistics_and_determinism():
     c = init(F32)
     x = torch.ones(64, 1024)
