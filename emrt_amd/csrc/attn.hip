@@ -97,51 +97,55 @@ __device__ __forceinline__ void stage8(const T* g8, float* s8) {
   *reinterpret_cast<float4*>(s8 + 4) = make_float4(t[4], t[5], t[6], t[7]);
 }
 
+// Forward: one block per (batch, head, chunk of MHA_FWD_ROWS query rows), 4 lanes per row.  The rows of a head are independent given
+// K and V, so the head is cut into L / 32 blocks: the one-block-per-head version kept 64 of the 256 CUs busy and was bound by its own
+// LDS traffic (every thread re-reads all K rows twice and all V rows once: 5.7 MB of ds_read_b128 per block, ~19 us); a chunk block
+// stages the same K / V (14 KB each) and reads a quarter of that.
+#define MHA_FWD_ROWS 32
 template <class T>
-__global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(MhaArgs a) {
+__global__ __launch_bounds__(4 * MHA_FWD_ROWS) void mha_fwd_kernel(MhaArgs a, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int L = a.L;
   float* sK = sm;                       // [L][MHA_P]
   float* sV = sK + L * MHA_P;           // [L][MHA_P]
-  float* sQ = sV + L * MHA_P;           // [L][MHA_P]
-  float* sS = sQ + L * MHA_P;           // [L][L + 1] scores -> exp -> (dropped) probabilities
-  const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
-  const int i = threadIdx.x >> 2, part = threadIdx.x & 3;
+  float* sQ = sV + L * MHA_P;           // [MHA_FWD_ROWS][MHA_P]
+  float* sS = sQ + MHA_FWD_ROWS * MHA_P;   // [MHA_FWD_ROWS][L + 1] scores -> exp -> (dropped) probabilities
+  const int bm = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const int b = bm / a.M, m = bm % a.M;
+  const int il = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int i = chunk * MHA_FWD_ROWS + il;
   const long long r0 = (long long)b * L;
   const bool live = i < L;
-  if (live) {
-    const long long co = m * MHA_D + 8 * part;
-    stage8<T>((const T*)a.k + (r0 + i) * a.ldk + co, sK + i * MHA_P + 8 * part);
-    stage8<T>((const T*)a.v + (r0 + i) * a.ldv + co, sV + i * MHA_P + 8 * part);
-    stage8<T>((const T*)a.q + (r0 + i) * a.ldq + co, sQ + i * MHA_P + 8 * part);
+  const long long co = m * MHA_D + 8 * part;
+  for (int r = il; r < L; r += MHA_FWD_ROWS) {
+    stage8<T>((const T*)a.k + (r0 + r) * a.ldk + co, sK + r * MHA_P + 8 * part);
+    stage8<T>((const T*)a.v + (r0 + r) * a.ldv + co, sV + r * MHA_P + 8 * part);
   }
+  if (live) stage8<T>((const T*)a.q + (r0 + i) * a.ldq + co, sQ + il * MHA_P + 8 * part);
+  else *reinterpret_cast<float4*>(sQ + il * MHA_P + 8 * part) = *reinterpret_cast<float4*>(sQ + il * MHA_P + 8 * part + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const int ii = live ? i : 0;          // dead rows shadow row 0 so that the quad shuffles stay full; they write nothing
-  float* Si = sS + ii * (L + 1);
+  float* Si = sS + il * (L + 1);
   float qi[MHA_D];
 #pragma unroll
   for (int d = 0; d < MHA_D; d += 4) {
-    const float4 t = *reinterpret_cast<const float4*>(sQ + ii * MHA_P + d);
+    const float4 t = *reinterpret_cast<const float4*>(sQ + il * MHA_P + d);
     qi[d] = t.x; qi[d + 1] = t.y; qi[d + 2] = t.z; qi[d + 3] = t.w;
   }
   float mx = -3.0e38f;
   for (int j = part; j < L; j += 4) {
     const float s = dot_row(qi, sK + j * MHA_P) * a.scale;
-    if (live) Si[j] = s;
+    Si[j] = s;
     mx = fmaxf(mx, s);
   }
   mx = quad_max(mx);
   float den = 0.f;
-  for (int j = part; j < L; j += 4) {
-    const float e = __expf(dot_row(qi, sK + j * MHA_P) * a.scale - mx);      // (recomputed: cheaper than a second LDS round trip)
-    den += e;
-  }
+  for (int j = part; j < L; j += 4) den += __expf(Si[j] - mx);          // (this lane's own scores: no barrier needed)
   den = quad_add(den);
   const float inv = 1.f / den;
-  float* pg = a.probs + (((long long)b * a.M + m) * L + ii) * L;
   const unsigned long long seed = a.pdrop > 0.f ? *a.seed : 0ull;
   const float keep_scale = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
-  if (live)
+  if (live) {
+    float* pg = a.probs + (((long long)b * a.M + m) * L + i) * L;
     for (int j = part; j < L; j += 4) {
       float pj = __expf(Si[j] - mx) * inv;
       pg[j] = pj;
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(MhaArgs a) {
       }
       Si[j] = pj;
     }
+  }
   __syncthreads();
   if (!live) return;
   float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -252,18 +257,12 @@ extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, cons
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.probs = probs;
   a.B = B; a.M = M; a.L = L; a.scale = scale; a.pdrop = pdrop; a.seed = seed; a.salt = salt;
-  const size_t lds = (size_t)(3 * L * MHA_P + L * (L + 1)) * sizeof(float);
+  const size_t lds = (size_t)(2 * L * MHA_P + MHA_FWD_ROWS * MHA_P + MHA_FWD_ROWS * (L + 1)) * sizeof(float);      // <= 58 KB at L = 128
+  const int nchunk = (L + MHA_FWD_ROWS - 1) / MHA_FWD_ROWS;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (gfx950 has 160 KiB per CU)
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)mha_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    hipFuncSetAttribute((const void*)mha_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    hipFuncSetAttribute((const void*)mha_fwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    attr_done = true;
-  }
-  if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_fwd_kernel<float>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
-  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((mha_fwd_kernel<bf16_t>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
-  else hipLaunchKernelGGL((mha_fwd_kernel<f16_t>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_fwd_kernel<float>), dim3(B * M * nchunk), dim3(4 * MHA_FWD_ROWS), lds, st, a, nchunk);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((mha_fwd_kernel<bf16_t>), dim3(B * M * nchunk), dim3(4 * MHA_FWD_ROWS), lds, st, a, nchunk);
+  else hipLaunchKernelGGL((mha_fwd_kernel<f16_t>), dim3(B * M * nchunk), dim3(4 * MHA_FWD_ROWS), lds, st, a, nchunk);
   return check_launch("emrt_mha_fwd");
 }
 
