@@ -23,7 +23,7 @@ const TuneEntry kTune[] = {
     {"msda_fwd_chunks", &emrt::Tuning::msda_fwd_chunks, 0}, {"msda_fwd_threads", &emrt::Tuning::msda_fwd_threads, 1024},
     {"msda_fwd_probe", &emrt::Tuning::msda_fwd_probe, 0}, {"wgrad_nst", &emrt::Tuning::wgrad_nst, 2},
     {"igemm64_nst", &emrt::Tuning::igemm64_nst, 3}, {"msda_bwd_global", &emrt::Tuning::msda_bwd_global, 0},
-    {"msda_lds_min_pairs", &emrt::Tuning::msda_lds_min_pairs, 2048},
+    {"msda_lds_min_pairs", &emrt::Tuning::msda_lds_min_pairs, 2048}, {"msda_bwd_dref_lds", &emrt::Tuning::msda_bwd_dref_lds, 1},
     {"gn_group_blocks", &emrt::Tuning::gn_group_blocks, 0}, {"gn_stat_rows", &emrt::Tuning::gn_stat_rows, 32},
     {"gn_bwd_stat_rows", &emrt::Tuning::gn_bwd_stat_rows, 32}, {"gn_apply_rows", &emrt::Tuning::gn_apply_rows, 8},
 };

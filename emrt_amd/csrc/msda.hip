@@ -697,6 +697,40 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
         }
       }
     }
+    if (a.dref) {
+      // reference-point gradient (decoder cross-attention): loc = ref + off / (W, H)  =>  d ref_x(l) = W_l * sum over the level's points
+      // of d x; this quad holds one head's samples, the 8 heads of a query sit in 8 different blocks: fp32 atomics into the
+      // caller-zeroed dref (8 addends per element)
+      float sx[L], sy[L];
+#pragma unroll
+      for (int l = 0; l < L; ++l) { sx[l] = 0.f; sy[l] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int smp = sub + 4 * j;
+        const int lev = smp / P;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const bool mine = smp < LP && lev == l;
+          sx[l] += mine ? gx[j] : 0.f;
+          sy[l] += mine ? gy[j] : 0.f;
+        }
+      }
+      float tx = 0.f, ty = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        sx[l] = quad_add(sx[l]) * (float)a.w[l];
+        sy[l] = quad_add(sy[l]) * (float)a.h[l];
+        tx += sx[l]; ty += sy[l];
+        if (a.ref_L != 1 && live && sub == 0) {
+          atomicAdd(a.dref + (bq * L + l) * 2, sx[l]);
+          atomicAdd(a.dref + (bq * L + l) * 2 + 1, sy[l]);
+        }
+      }
+      if (a.ref_L == 1 && live && sub == 0) {
+        atomicAdd(a.dref + bq * 2, tx);
+        atomicAdd(a.dref + bq * 2 + 1, ty);
+      }
+    }
   }
   if (!staged) __syncthreads();        // waves without a query still take part in the block's one barrier
   if (a.gmax) {
@@ -1043,7 +1077,7 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     const int guard = wmax + 2;
     const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
     int rc;
-    if (dtype == EMRT_BF16 && !dref && slab <= 159 * 1024 && (long long)B * M * Lq >= g_tune.msda_lds_min_pairs && !g_tune.msda_bwd_global) {
+    if (dtype == EMRT_BF16 && (!dref || g_tune.msda_bwd_dref_lds) && slab <= 159 * 1024 && (long long)B * M * Lq >= g_tune.msda_lds_min_pairs && !g_tune.msda_bwd_global) {
       int chunks = (256 + B * M / 2) / (B * M);
       if (chunks > (Lq + 127) / 128) chunks = (Lq + 127) / 128;
       if (chunks < 1) chunks = 1;

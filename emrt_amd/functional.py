@@ -841,7 +841,7 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
             use_lds = bool(_L().query("emrt_msda_bwd_uses_lds", ctypes.cast(arr, ctypes.c_void_p), L))
             odt = None if c.dtype != F32 else torch.float32      # compute dtype: the projection's backward GEMM reads it directly
             doffw = c.zeros((B, Lq, ldo), odt) if ldo != M * L * Pn * 3 else c.empty((B, Lq, ldo), odt)
-            dref = c.empty((B, Lq, ref_L, 2), torch.float32) if need_dref else None
+            dref = c.zeros((B, Lq, ref_L, 2), torch.float32) if need_dref else None      # zeroed: the LDS gradient kernel accumulates into it
             if use_lds:
                 dvalue = c.empty((B, Lv, CC))          # compute dtype, fully overwritten by the LDS scatter
                 ws = c.empty((_L().query("emrt_msda_bwd_workspace_bytes", B, Lq, M, L, Pn) // 4,), torch.float32)

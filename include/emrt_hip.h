@@ -36,7 +36,7 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
 /* Developer / test knobs of the dispatchers (forced tile shapes, kernel variants).  The table is filled ONCE from the
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
  * conv_tile, wgrad_split, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
- * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs,
+ * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
  * gn_bwd_stat_rows, gn_apply_rows.
  * Not thread-safe against concurrent launches; production code never calls these. */
 int emrt_set_tuning(const char* name, int value);
@@ -122,7 +122,8 @@ int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gam
  * ref fp32 [B or 1][Lq][ref_L][2] (ref_bs = 0 broadcasts over batch; ref_L = L, or 1 to share one point across levels); shapes_hw: HOST int [L][2] = (H_l, W_l); out [B][Lq][M*D]. */
 int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, void* out, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream);
 /* Backward.  doffw [B*Lq][ldo] (fp32, or the compute dtype when doffw_compute_dtype != 0 and dtype is a 2-byte type: what the
- * offsets|logits projection's backward GEMM reads) and dref [B][Lq][ref_L][2] (nullable) are overwritten.  dvalue: when
+ * offsets|logits projection's backward GEMM reads) is overwritten; dref [B][Lq][ref_L][2] (nullable) must be ZEROED by the caller (the
+ * LDS-staged gradient kernel adds the heads' contributions with atomics; the global-gather kernel overwrites it).  dvalue: when
  * emrt_msda_bwd_uses_lds(shapes_hw, L) == 1 (every level group's fp32 slab fits in LDS) it is [B][Lv][M*D] in the
  * compute dtype, fully overwritten by an LDS-privatised scatter (needs `workspace` of emrt_msda_bwd_workspace_bytes);
  * otherwise it is fp32, must be zeroed by the caller and is accumulated with global atomics. */

@@ -566,7 +566,11 @@ def _msda_ref(value, offw, ref, shapes, M, L, Pn):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [dict(B=2, Lq=None, shapes=[(8, 8), (4, 4), (2, 2)], refL=1, shared=True),
                                  dict(B=3, Lq=37, shapes=[(16, 12), (8, 6), (4, 3)], refL=1, shared=True),
-                                 dict(B=2, Lq=21, shapes=[(8, 8), (4, 4), (2, 2)], refL=3, shared=False)])
+                                 dict(B=2, Lq=21, shapes=[(8, 8), (4, 4), (2, 2)], refL=3, shared=False),
+                                 # the decoder's cross-attention at the benchmark size (B*M*Lq = 7040: LDS-staged kernels in bf16,
+                                 # reference-point gradient by atomics over the heads), per-level and shared reference points
+                                 dict(B=8, Lq=110, shapes=[(32, 32), (16, 16), (8, 8)], refL=3, shared=False),
+                                 dict(B=8, Lq=110, shapes=[(32, 32), (16, 16), (8, 8)], refL=1, shared=True)])
 def test_msda_fwd_bwd(dtype, cfg):
     c = init(dtype)
     g = torch.Generator().manual_seed(8)
