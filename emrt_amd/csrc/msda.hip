@@ -747,6 +747,35 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
   }
 }
 
+// max |dout| per (batch, head) for the scatter's fixed-point scale when the gradient kernel that ran before is the global-gather one (it
+// does not leave it): block = (batch, 64 query rows), whole 512-byte rows, one partial per head and block -- the scatter blocks then read
+// Lq / 64 partials instead of scanning Lq * 32 strided values each (50 of 179 us at Lq = 5376).
+template <class T>
+__global__ __launch_bounds__(256) void msda_absmax_kernel(const T* __restrict__ dout, int Lq, int M, int nparts, float* __restrict__ gmax) {
+  __shared__ float red[8][32];
+  const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
+  const int cpr = M * 4;                                   // 8-channel chunks per row
+  const int rows_per_pass = 256 / cpr;
+  const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  float mx = 0.f;
+  if (rl < rows_per_pass)
+    for (int r = part * 64 + rl; r < min(Lq, part * 64 + 64); r += rows_per_pass) {
+      float v[8];
+      Vec8<T>::load(dout + ((long long)b * Lq + r) * (M * 32) + ch * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[e]));
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 2, 64));                   // the 4 chunks of a head
+  if ((ch & 3) == 0 && rl < 8 && rl < rows_per_pass) red[rl][ch >> 2] = mx;
+  __syncthreads();
+  if ((int)threadIdx.x < M) {
+    float m2 = 0.f;
+    for (int k = 0; k < rows_per_pass && k < 8; ++k) m2 = fmaxf(m2, red[k][threadIdx.x]);
+    gmax[((long long)b * M + threadIdx.x) * nparts + part] = m2;
+  }
+}
+
 // d value via LDS-privatised scatter.  Float LDS atomics run at ~1 lane / 4 clk on gfx950 (measured: 245 clk per
 // wave-level ds_add_f32) while integer LDS atomics are native rate, so contributions are accumulated in 32-bit fixed
 // point.  The scale is safe by construction: a query adds at most |g| to any (pixel, channel) (its sample weights are
@@ -900,8 +929,9 @@ extern "C" int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L) {
 }
 
 extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P) {
-  // softmax probabilities + the gradient kernel's per-block max |dout| (at most 256 / (B M) + 1 blocks per (batch, head))
-  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M) * sizeof(float);
+  // softmax probabilities + per-block max |dout| partials (the LDS gradient kernel leaves at most 256 / (B M) + 1 per (batch, head), the
+  // separate scan Lq / 64)
+  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M + (size_t)B * M * ((Lq + 63) / 64)) * sizeof(float);
 }
 
 template <class T>
@@ -1088,6 +1118,12 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
       rc = msda_launch_bwd_grad_lds<bf16_t>(a, L, P, chunks, qpb, guard, slab, st);
     } else {
       rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
+      if (!rc && Lq >= 1024 && M <= 8 && 256 % (M * 4) == 0) {      // long scans only: the extra launch costs ~3 us
+        a.gmax = (float*)workspace + (size_t)B * Lq * M * L * P;
+        a.gmax_n = (Lq + 63) / 64;
+        if (dtype == EMRT_F32) hipLaunchKernelGGL((msda_absmax_kernel<float>), dim3(B * a.gmax_n), dim3(256), 0, st, (const float*)dout, Lq, M, a.gmax_n, a.gmax);
+        else hipLaunchKernelGGL((msda_absmax_kernel<bf16_t>), dim3(B * a.gmax_n), dim3(256), 0, st, (const bf16_t*)dout, Lq, M, a.gmax_n, a.gmax);
+      }
     }
     if (rc) return rc;
     a.g_npix_max = (npix_max + 3) & ~3;          // keeps the records 16-byte aligned

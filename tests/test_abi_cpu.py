@@ -51,7 +51,7 @@ def test_loader_binds_all_entry_points(built):
     L = _lib.lib()
     assert L.query("emrt_abi_version") == 3
     assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
-    assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6) == (2 * 10 * 8 * 18 + 512 + 2 * 2 * 8) * 4     # probabilities + per-block max |dout|
+    assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6) == (2 * 10 * 8 * 18 + 512 + 2 * 2 * 8 + 2 * 8 * 1) * 4     # probabilities + per-block max |dout| partials
     assert L.last_error() == "" or isinstance(L.last_error(), str)
 
 
