@@ -587,3 +587,41 @@ def test_non_square_tiles_match_oracle(B, H, W):
     cos = dot / (den ** 0.5 * gn ** 0.5)
     print("non-square %dx%dx%d: whole-gradient rel err %.3g, cosine %.6f" % (B, H, W, (num / den) ** 0.5, cos))
     assert cos > 0.999 and (num / den) ** 0.5 < 0.05
+
+
+def test_large_tile_train_step_matches_oracle_512():
+    """BASELINE configs[2] geometry (LoveDA: 512x512 tiles, 7 classes, Lv = 5376) in fp32 against the fp32 CPU oracle, one train-mode
+    forward + loss + backward at batch 2: the large-map paths (global-gather MSDA forward and gradient kernels, the |dout| pre-pass,
+    the scatter's four LDS ranges on level 0, 128x128 conv tiles everywhere) at model level, not only kernel by kernel."""
+    g = torch.Generator().manual_seed(19)
+    B, S, ncls = 2, 512, 7
+    x = torch.randn(B, 3, S, S, generator=g)
+    labels = torch.randint(0, ncls, (B, S, S), generator=g)
+    labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
+    ref, model = build_pair("resnet50", x, perturb=True, ncls=ncls)
+    ref.train()
+    out_r = ref(x)
+    loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
+    loss_r.backward()
+    model.train()
+    model.clear_gradients()
+    out = model(x.cuda())
+    loss = get_loss_function(make_config("resnet50", ncls=ncls))(out, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (out[0].cpu() - out_r[0].detach()).abs().max().item() < 2e-3
+    assert (out[1].cpu() - out_r[1].detach()).abs().max().item() < 2e-3
+    assert abs(loss.item() - loss_r.item()) < 2e-4 * max(1.0, abs(loss_r.item()))
+    refp = dict(ref.named_parameters())
+    dot = n_hip = n_ref = 0.0
+    for n, p in model.named_parameters():
+        gr = refp[n].grad
+        if gr is None:
+            continue
+        gg, gr = p.grad.cpu().double(), gr.double()
+        dot += float((gg * gr).sum())
+        n_hip += float((gg * gg).sum())
+        n_ref += float((gr * gr).sum())
+    cos = dot / (n_hip ** 0.5 * n_ref ** 0.5)
+    print("512x512 gradient: cosine %.6f, norm ratio %.5f" % (cos, (n_hip / n_ref) ** 0.5))
+    assert cos > 0.9995 and abs((n_hip / n_ref) ** 0.5 - 1.0) < 1e-2
