@@ -756,6 +756,11 @@ def test_nchw_ingest_and_elementwise():
         y8 = Fn.nchw_to_nhwc(img.cuda(), c_out=8)        # the image as an 8-channel map, channels 3..7 zero
         assert tuple(y8.shape) == (2, 16, 24, 8) and float(y8[..., 3:].float().abs().max()) == 0.0
         close("ingest padded", host_map(y8[..., :3].contiguous()), rnd(img), dtype, atol=0, rtol=0)
+        y4 = Fn.nchw_to_nhwc(img.cuda(), c_out=4)
+        assert float(y4[..., 3:].float().abs().max()) == 0.0
+        close("ingest padded to 4", host_map(y4[..., :3].contiguous()), rnd(img), dtype, atol=0, rtol=0)
+        y5 = Fn.nchw_to_nhwc(img.cuda(), c_out=5)        # neither 4 nor 8: element-wise kernel
+        close("ingest padded to 5", host_map(y5[..., :3].contiguous()), rnd(img), dtype, atol=0, rtol=0)
         a, b = rnd(torch.randn(2, 21, 64, generator=g)), rnd(torch.randn(21, 64, generator=g))
         s = Fn.add(dev(a), dev(b), period=21 * 64)
         close("add bcast", host(s), a + b, dtype)

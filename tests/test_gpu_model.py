@@ -446,7 +446,8 @@ def test_bf16_path_is_sane():
     assert l1 == l1 and l1 < l0, (l0, l1)
 
 
-def test_sliding_window_inference_and_metrics():
+@pytest.mark.parametrize("ih,iw", [(96, 128), (90, 102)])      # (90, 102): window origins / width off the 4-pixel grid -> element-wise accumulate kernel
+def test_sliding_window_inference_and_metrics(ih, iw):
     from emrt_amd.src.api import infer
     from emrt_amd.src.utils import metrics
     from oracle import infer_ref
@@ -455,16 +456,16 @@ def test_sliding_window_inference_and_metrics():
     ref, model = build_pair("resnet18", x)
     ref.eval()
     model.eval()
-    img = torch.randn(3, 96, 128, generator=g)
+    img = torch.randn(3, ih, iw, generator=g)
     with torch.no_grad():
         want = infer_ref.slide_inference(ref, [img], (64, 64), (32, 32), 6)[0]
     got = infer.slide_inference(model, [img.cuda()], (64, 64), (32, 32), 6)[0].cpu()
     assert (got - want).abs().max().item() < 2e-3
-    pred = infer.ss_inference(model, [img.cuda()], [(96, 128)], True, 64, (32, 32), (64, 64), 6)[0]
-    assert pred.dtype == torch.int32 and tuple(pred.shape) == (1, 1, 96, 128)
+    pred = infer.ss_inference(model, [img.cuda()], [(ih, iw)], True, 64, (32, 32), (64, 64), 6)[0]
+    assert pred.dtype == torch.int32 and tuple(pred.shape) == (1, 1, ih, iw)
     assert_argmax_match(got, want, tol=2e-3)
     assert torch.equal(pred.cpu()[0, 0], got.argmax(1)[0].to(torch.int32))
-    lab = torch.randint(0, 6, (96, 128), generator=g)
+    lab = torch.randint(0, 6, (ih, iw), generator=g)
     lab[:4] = 255
     a = metrics.calculate_area(pred, lab.cuda(), 6, 255)
     b = infer_ref.calculate_area(pred.cpu().numpy(), lab.numpy(), 6, 255)     # same predictions -> identical counts
