@@ -36,6 +36,9 @@ CONV_CASES = [
     (2, 16, 16, 3, 64, 3, 1, 1, False),
     (2, 24, 24, 256, 6, 1, 1, 0, True),
     (3, 17, 19, 512, 7, 1, 1, 0, True),      # thin_bwd_kernel: ragged pixel count, 7 classes
+    (2, 48, 48, 256, 6, 1, 1, 0, True),      # >= 4096 pixels: thin_fwd_kernel too (bf16), 32 lanes per pixel
+    (1, 65, 64, 512, 7, 1, 1, 0, True),      # thin_fwd_kernel with 64 lanes per pixel, ragged tail of the 4-pixel groups
+    (1, 80, 80, 64, 6, 1, 1, 0, False),      # thin_fwd_kernel with 8 lanes per pixel, no bias
     (1, 40, 40, 64, 192, 3, 1, 1, True),
     (2, 8, 8, 512, 128, 3, 1, 1, False),
 ]
