@@ -50,7 +50,8 @@ struct Tuning {
                         // decoder): fp32 atomics into the caller-ZEROED dref; 0 = those calls take the global-gather kernel
   int msda_fwd_chunks;  // LDS-staged MSDA forward: query chunks per (batch, head) slab (0 = automatic)
   int msda_fwd_threads; // ... threads per block (1024)
-  int msda_fwd_probe;   // timing experiments only (results are WRONG): 1 = no gather, 2 = no staging, 4 = no preparation
+  int msda_fwd_probe;   // timing experiments only (results are WRONG): forward 1 = no gather, 2 = no staging, 4 = no preparation;
+                        // value-gradient scatter 16 = no |g| scan, 32 = no sample loop (tools/exp/probe_msda_*.sh)
   int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
   int gn_group_blocks;  // 1 = multi-level GroupNorm with one block per (image, group) instead of the row-major stats + apply pair
