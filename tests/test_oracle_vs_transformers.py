@@ -161,3 +161,62 @@ def test_sine_position_embedding_matches_transformers():
         if hasattr(hf.build_sine_position_embedding, "__wrapped__") else hf(torch.Size((2, 256, 7, 5)), "cpu", torch.float32, mask)
     assert a.shape == b.shape == (2, 256, 7, 5)
     assert (a - b).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("depth", [50, 18])
+def test_resnet_backbone_matches_transformers(depth):
+    """The oracle's ResNet (restating paddle_vision_resnet.py:43-257: 7x7/2 stem, 3x3/2 max-pool, bottlenecks with the stride on the
+    3x3 conv, 1x1 strided shortcut on the first block of a stage; BasicBlock for depth 18) against transformers' ResNetModel with the
+    same weights mapped name by name: the four stage outputs c1..c4 in eval mode (running statistics: randomised, so a wrong
+    mean/variance mapping cannot hide), and in train mode (batch statistics)."""
+    from transformers import ResNetConfig, ResNetModel
+    from oracle.emrt_torch import ResNet
+    torch.manual_seed(depth)
+    bottleneck = depth >= 50
+    cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048] if bottleneck else [64, 128, 256, 512],
+                       depths=ResNet.layer_cfg[depth], layer_type="bottleneck" if bottleneck else "basic", hidden_act="relu",
+                       downsample_in_first_stage=False, downsample_in_bottleneck=False)
+    hf = ResNetModel(cfg)
+    ref = ResNet(depth)
+    with torch.no_grad():
+        for n, b in ref.named_buffers():          # non-trivial running statistics
+            b.copy_(torch.rand_like(b) + 0.5 if n.endswith("_variance") else torch.randn_like(b) * 0.3)
+        for n, p in ref.named_parameters():
+            if p.dim() == 1 and "bn" in n or ".downsample.1." in n:
+                p.copy_(torch.rand_like(p) + 0.5 if n.endswith("weight") else torch.randn_like(p) * 0.2)
+    rs = ref.state_dict()
+    mapped = {}
+
+    def bn(dst, src):
+        mapped[dst + ".weight"], mapped[dst + ".bias"] = rs[src + ".weight"], rs[src + ".bias"]
+        mapped[dst + ".running_mean"], mapped[dst + ".running_var"] = rs[src + "._mean"], rs[src + "._variance"]
+    mapped["embedder.embedder.convolution.weight"] = rs["conv1.weight"]
+    bn("embedder.embedder.normalization", "bn1")
+    for s, nblk in enumerate(ResNet.layer_cfg[depth]):
+        for i in range(nblk):
+            src, dst = "layer%d.%d" % (s + 1, i), "encoder.stages.%d.layers.%d" % (s, i)
+            for j in range(3 if bottleneck else 2):
+                mapped["%s.layer.%d.convolution.weight" % (dst, j)] = rs["%s.conv%d.weight" % (src, j + 1)]
+                bn("%s.layer.%d.normalization" % (dst, j), "%s.bn%d" % (src, j + 1))
+            if src + ".downsample.0.weight" in rs:
+                mapped[dst + ".shortcut.convolution.weight"] = rs[src + ".downsample.0.weight"]
+                bn(dst + ".shortcut.normalization", src + ".downsample.1")
+    own = hf.state_dict()
+    missing = [k for k in own if k not in mapped and not k.endswith("num_batches_tracked")]
+    assert not missing, missing[:5]
+    hf.load_state_dict({**{k: v for k, v in own.items() if k.endswith("num_batches_tracked")}, **mapped})
+    assert len(mapped) == sum(1 for k in rs if not k.startswith("fc."))        # every oracle tensor but the unused fc went somewhere
+    x = torch.randn(2, 3, 96, 64)
+    for train in (False, True):
+        ref.train(train)
+        hf.train(train)
+        for m in hf.modules():              # same momentum convention for the side effect; irrelevant to the outputs compared here
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.momentum = 0.1
+        with torch.no_grad():
+            got = ref(x)
+            want = hf(x, output_hidden_states=True).hidden_states[1:]
+        assert len(got) == len(want) == 4
+        for a, b in zip(got, want):
+            assert a.shape == b.shape
+            assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item()), (train, (a - b).abs().max().item())
