@@ -5,7 +5,13 @@
     python bench.py --config cfg3                                             # configs[2]: LoveDA 512x512, 7 classes, batch 4
     python bench.py --config cfg5                                             # configs[4]: 1024x1024 sliding-window inference, fp16
     python bench.py --dtype fp32                                              # cfg2 in the reference's own precision
+    python bench.py --gpus N                                                  # N > 1 without a launcher: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Multi-GPU (reference: paddle.DataParallel with ranks from the launcher, semantic_segmentation/train.py:116-123): one process per
+GPU over RCCL.  Under a launcher (RANK / WORLD_SIZE in the environment) this process IS one rank and WORLD_SIZE must equal --gpus.
+Without one, `--gpus N` makes this process a pure parent: it touches no GPU, starts N fresh children of itself with RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and exits non-zero if any rank fails.
 
 Training configs: one step = forward + CE/aux-CE loss + backward + (RCCL gradient all-reduce when N > 1) + global-norm clip +
 SGD-momentum + weight re-pack on a synthetic batch that is already resident in HBM.  cfg5: one step = one 1024x1024 image =
@@ -194,6 +200,53 @@ def timed_replay(record_fn, world=1):
     return calls
 
 
+def spawn_ranks(n, argv):
+    """Parent of a launcher-less `--gpus N` run: N children of this script, one rank each (emrt_amd.distributed.spawn_ranks).
+    The parent makes no GPU call, relays rank 0's JSON line and fails loudly when a rank fails or when rank 0 reports a group
+    of the wrong size."""
+    from emrt_amd.distributed import spawn_ranks as launch
+    codes, out0 = launch(n, [sys.executable, os.path.abspath(__file__)] + argv, capture_rank0=True, log=log)
+    if any(codes):
+        return codes[0] if all(c == codes[0] for c in codes) and 0 < codes[0] < 128 else 1
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        log("[bench] rank 0 printed no JSON line")
+        return 1
+    got = json.loads(line).get("n_gpus")
+    if got != n:
+        log("[bench] rank 0 reports n_gpus=%r, expected %d" % (got, n))
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def check_world(args):
+    """Under a launcher WORLD_SIZE must be the --gpus the caller asked for: a silently smaller job would be a wrong number.
+    Checked before the rendezvous and before any GPU call."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit("[bench] WORLD_SIZE=%d but --gpus %d: start %d ranks (python bench.py --gpus %d starts them itself)"
+                         % (world, args.gpus, args.gpus, args.gpus))
+
+
+def describe_group(rank, world, dev):
+    """Rank 0: what the process group really is (a SCALE run is then self-evidencing)."""
+    if rank != 0 or not torch.distributed.is_initialized():
+        return
+    backend = torch.distributed.get_backend()
+    ver = ""
+    if backend == "nccl":
+        try:
+            ver = " RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # version query only; never fatal
+            ver = " (RCCL version unavailable: %s)" % e
+    log("[bench] process group: backend %s%s, world size %d, rank 0 on %s, ranks %s" %
+        (backend, ver, torch.distributed.get_world_size(), dev, "share GPU 0 (test aid)" if os.environ.get("EMRT_ALL_RANKS_ON_GPU0") else "one GPU each"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +265,9 @@ def main():
     ap.add_argument("--two-phase-no-syncbn", action="store_true", help="--two-phase without the SyncBatchNorm collectives (A/B: what the graph cuts cost)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    check_world(args)
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["batch"] = args.batch
@@ -230,13 +286,12 @@ def main():
     from emrt_amd.src.models.losses import MixSoftmaxCrossEntropyLoss
     from emrt_amd.src.models.solver import Momentum, PolynomialDecay
 
-    rank, local_rank, world = init_process_group()
-    if world != args.gpus:
-        log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
-    dtype = BF16 if dtype_name == "bf16" else F32
     if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
-        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = init_process_group()
+    dtype = BF16 if dtype_name == "bf16" else F32
     dev = torch.device("cuda", local_rank)
+    describe_group(rank, world, dev)
     torch.manual_seed(1234)
     B, S, ncls = cfg["batch"], cfg["size"], cfg["ncls"]
     model = EMRT(num_classes=ncls, backbone="resnet50")
@@ -322,8 +377,11 @@ def main_infer(args, cfg, dtype_name):
     from emrt_amd.src.api.infer import SlidingWindowEngine, slide_inference
     from emrt_amd.src.models.emrt import EMRT
 
+    if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):
+        os.environ["LOCAL_RANK"] = "0"
     rank, local_rank, world = init_process_group()
     dev = torch.device("cuda", local_rank)
+    describe_group(rank, world, dev)
     torch.manual_seed(1234)
     ncls, crop, img_size = cfg["ncls"], cfg["size"], cfg["image"]
     model = EMRT(num_classes=ncls, backbone="resnet50")

@@ -30,6 +30,54 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
+def spawn_ranks(n, cmd, capture_rank0=False, log=None):
+    """Launcher-less multi-GPU start: run `cmd` (an argv list) as n child processes, one rank each, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set -- what paddle.distributed.launch gives the reference
+    (train.py:116-123 reads the ranks from it).  The CALLER must not have touched the GPU: a process that has initialised the
+    GPU runtime is never forked or replaced; the children are fresh interpreters.  A rank that dies takes the job down at once
+    (the others would otherwise wait in the rendezvous or a collective until a timeout).
+    Returns (exit codes, rank 0's stdout as str or None)."""
+    import socket
+    import subprocess
+    import sys
+    import threading
+    import time
+    log = log or (lambda *a: print(*a, file=sys.stderr, flush=True))
+    if not os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):
+        have = torch.cuda.device_count()            # counts devices without initialising the GPU runtime
+        if have < n:
+            log("[launch] %d ranks requested but this node exposes %d GPU(s)" % (n, have))
+            return [2] * n, None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        out = (subprocess.PIPE if capture_rank0 else None) if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen(list(cmd), env=env, stdout=out))
+    chunks = []
+    reader = None
+    if capture_rank0:
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                  # exactly the processes started above
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    if reader is not None:
+        reader.join(timeout=10)
+    if any(codes):
+        log("[launch] rank exit codes %s" % codes)
+    return codes, (b"".join(chunks).decode() if capture_rank0 else None)
+
+
 def bucket_slices(n, bucket_elems, start=0):
     """Contiguous [start, end) slices covering [start, n)."""
     out, s = [], start

@@ -1,6 +1,7 @@
 """Training entry point with the reference's CLI and step order (semantic_segmentation/train.py:26-266).
 
     python -m emrt_amd.train --config emrt_amd/configs/EMRT/EMRT_256x256_160k_potsdam.yaml [--seed 1234]
+    python -m emrt_amd.train --gpus 8 --config ...          # starts the 8 rank processes itself (one per GPU, RCCL)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m emrt_amd.train --config ...
 
 Per iteration (train.py:141-159): forward -> MixSoftmaxCrossEntropyLoss -> backward (+ RCCL gradient all-reduce when
@@ -43,6 +44,8 @@ def parse_args(argv=None):
     p.add_argument("--save_dir", default=None, help="override SAVE_DIR of the yaml (the reference's yamls point at the authors' disks)")
     p.add_argument("--pretrained_backbone", default=None, help="weights to start from (.pdparams or torch): whole model or ResNet backbone")
     p.add_argument("--no-eval", action="store_true", help="skip the periodic evaluation (train.py:187-195) and best_model.pdparams")
+    p.add_argument("--gpus", type=int, default=0, help="without a launcher (no RANK / WORLD_SIZE in the environment): start this many rank "
+                   "processes, one per GPU (the reference gets its ranks from paddle.distributed.launch, train.py:116-123)")
     p.add_argument("--val_tiles", type=int, default=16, help="--data synthetic / .npz without val arrays: how many held-out tiles to evaluate on")
     return p.parse_args(argv)
 
@@ -84,6 +87,16 @@ def synthetic_tiles(n, crop, ncls, seed, device):
 
 def main(argv=None):
     args = parse_args(argv)
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.gpus > 1 and not launched:          # pure parent: no GPU call in this process, N fresh rank processes
+        import sys
+        from .distributed import spawn_ranks
+        codes, _ = spawn_ranks(args.gpus, [sys.executable, "-m", "emrt_amd.train"] + list(sys.argv[1:] if argv is None else argv))
+        raise SystemExit(1 if any(codes) else 0)
+    if args.gpus and launched and int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        raise SystemExit("[train] WORLD_SIZE=%s but --gpus %d" % (os.environ.get("WORLD_SIZE"), args.gpus))
+    if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
+        os.environ["LOCAL_RANK"] = "0"
     config = update_config(get_config(), args)
     rank, local_rank, nranks = init_process_group()
     torch.manual_seed(args.seed)
