@@ -17,6 +17,7 @@
 // wgrad: dW[oc][tap*C + c] += sum_m dy[m][oc] * x[pix(m,tap)][c]   (fp32 atomics, split over m)
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace emrt;
 
@@ -540,6 +541,8 @@ __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void ige
   igemm_body<T, TM, TN, WR, WC, MODE, VEC, NST, G>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
 }
 
+#include "igemm8p.hpp"
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[oc][k] += sum_m dy[m][oc] * xcol[m][k], 128(oc) x 128(k) tile per block, reduction over
 // pixels m split across blockIdx.z, fp32 atomics into dW.  Both operands are pixel-major in memory, so
@@ -914,6 +917,7 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
       case 4: return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
       case 5: if constexpr (VEC) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 2>(a, st); break;
       case 6: if constexpr (VEC) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 4>(a, st); break;
+      case 7: if constexpr (VEC && sizeof(T) == 2) { if (igemm8p_ok<T>(a)) return launch_igemm8p<T, MODE>(a, st); } break;
       default: break;
     }
   }

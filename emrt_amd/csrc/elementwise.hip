@@ -34,7 +34,9 @@ emrt::Tuning tuning_from_env() {
     size_t n = strlen(env);
     for (const char* c = e.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
     env[n] = 0;
-    const char* v = getenv(env);
+    // the probe knob switches parts of a kernel OFF (wrong results, timing experiments only): never from the environment of a
+    // production process, only through an explicit emrt_set_tuning() call of the experiment script
+    const char* v = strcmp(e.name, "msda_fwd_probe") == 0 ? nullptr : getenv(env);
     t.*(e.field) = v ? atoi(v) : e.def;
   }
   return t;

@@ -752,10 +752,10 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
 // Lq / 64 partials instead of scanning Lq * 32 strided values each (50 of 179 us at Lq = 5376).
 template <class T>
 __global__ __launch_bounds__(256) void msda_absmax_kernel(const T* __restrict__ dout, int Lq, int M, int nparts, float* __restrict__ gmax) {
-  __shared__ float red[8][32];
+  __shared__ float red[64][8];                             // [row lane][head]: rows_per_pass = 256 / (4 M) <= 64 (M = 1), heads <= 8
   const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
   const int cpr = M * 4;                                   // 8-channel chunks per row
-  const int rows_per_pass = 256 / cpr;
+  const int rows_per_pass = 256 / cpr;                     // the host only sends M in {1, 2, 4, 8}: 256 % (4 M) == 0
   const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   float mx = 0.f;
   if (rl < rows_per_pass)
@@ -767,11 +767,11 @@ __global__ __launch_bounds__(256) void msda_absmax_kernel(const T* __restrict__ 
     }
   mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 2, 64));                   // the 4 chunks of a head
-  if ((ch & 3) == 0 && rl < 8 && rl < rows_per_pass) red[rl][ch >> 2] = mx;
+  if ((ch & 3) == 0 && rl < rows_per_pass) red[rl][ch >> 2] = mx;      // EVERY row lane (M = 4: 16 of them; M = 8: 8)
   __syncthreads();
   if ((int)threadIdx.x < M) {
     float m2 = 0.f;
-    for (int k = 0; k < rows_per_pass && k < 8; ++k) m2 = fmaxf(m2, red[k][threadIdx.x]);
+    for (int k = 0; k < rows_per_pass; ++k) m2 = fmaxf(m2, red[k][threadIdx.x]);
     gmax[((long long)b * M + threadIdx.x) * nparts + part] = m2;
   }
 }

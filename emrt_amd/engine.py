@@ -217,6 +217,8 @@ class TrainEngine:
             if images.data_ptr() != self.images.data_ptr():
                 self.images.copy_(images, non_blocking=True)
                 self.labels.copy_(labels, non_blocking=True)
+            if self.model.store.dirty:     # master weights edited since the last step (load_state_dict after the capture): refresh the
+                self.model.store.pack()    # compute-dtype mirror eagerly -- inside the graph only the optimizer's own update writes it
             self.graph_a.replay()
             if self.reducer is not None:
                 self._exchange([g.replay for g in self.graph_rest])

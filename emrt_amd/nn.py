@@ -75,7 +75,7 @@ class ParamStore:
         self.master = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.velocity = torch.zeros(self.n_total, dtype=torch.float32, device=device)
-        self.views = {}
+        self.views, self.shapes = {}, {}
         for n in order:
             p = by_name[n]
             a, cnt = self.offsets[n], numel(n)
@@ -92,6 +92,7 @@ class ParamStore:
             p.grad = gview
             p.requires_grad_(False)
             self.views[n] = (a, cnt)
+            self.shapes[n] = tuple(p.shape)
         self.train_order = order[:self.n_trainable_names]
         self.lr_ranges = [(self.offsets[n], self.offsets[n] + numel(n)) for n in lr_mult_names]
         self.lr_mult = lr_mult
@@ -113,6 +114,16 @@ class ParamStore:
         self.total_tiles = self.total_tiles64 = 0
         self.dirty = True
         self.bn_states, self.bn_fold, self.bn_desc = [], None, None
+
+    def named_view(self, flat, name):
+        """The logical-shape view of parameter `name` inside a flat buffer laid out like master / grad / velocity."""
+        a, cnt = self.views[name]
+        shape = self.shapes[name]
+        if len(shape) == 4:
+            OC, C, KH, KW = shape
+            Cp = self.padded_cin.get(name, C)
+            return flat[a:a + cnt].view(OC, KH, KW, Cp).permute(0, 3, 1, 2)[:, :C]
+        return flat[a:a + cnt].view(shape)
 
     def segment_ranges(self, segment_prefixes):
         """Partition [0, n_train) of the flat buffers by parameter-name prefix: returns [ranges_0, ranges_1, ...] where

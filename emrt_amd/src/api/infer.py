@@ -186,5 +186,7 @@ class SlidingWindowEngine:
                 self.logits, self.pred = self._run(self.image)
         if img.data_ptr() != self.image.data_ptr():
             self.image.copy_(img, non_blocking=True)
+        if self.model.store.dirty:       # weights edited after the capture (load_state_dict of the next checkpoint): the replayed
+            self.model.store.pack()      # kernels read the compute-dtype mirror, which only EMRT.__call__ -- not replay() -- refreshes
         self.graph.replay()
         return self.pred

@@ -621,6 +621,10 @@ class EMRT(hnn.HipLayer):  # :184-304
         if depth not in ResNet.layer_cfg:
             raise NotImplementedError("EMRT HIP path supports resnet18/34/50/50c/101/152 backbones, got %r" % backbone)
         output_stride = int(config.MODEL.OUTPUT_STRIDE) if config is not None else 32
+        if backbone == "resnet50c" and output_stride == 8:
+            # the auxiliary head's x16 upsample (fcn_head.py:80) then lands on 2H x 2W and the reference's final resize to the
+            # input size (paddle_EMRT.py:301) is no longer the identity this path drops; no EMRT yaml uses OUTPUT_STRIDE 8
+            raise NotImplementedError("MODEL.OUTPUT_STRIDE 8 is not supported by the EMRT HIP path (16 and 32 are)")
         self.nclass = num_classes
         # resnet18/34: build-side extension (the reference hard-codes [512,1024,2048], paddle_EMRT.py:188-192)
         self.backbone_num_channels = [128, 256, 512] if depth in (18, 34) else [512, 1024, 2048]

@@ -60,10 +60,31 @@ class Momentum:
             st.pack()
 
     def state_dict(self):
-        return {"velocity": self.model.store.velocity.clone(), "step": int(ctx().step_counter.item())}
+        """Momentum per parameter NAME in the parameter's logical shape (as the reference's .pdopt is keyed, train.py:204-206): the flat
+        buffer's layout (alignment, padded stem channels) is an internal detail that has changed before and must not be the file format."""
+        st = self.model.store
+        return {"velocity": {n: st.named_view(st.velocity, n).detach().clone() for n in st.train_order},
+                "step": int(ctx().step_counter.item()), "format": "per-parameter"}
 
     def set_state_dict(self, sd):
-        self.model.store.velocity.copy_(sd["velocity"])
+        st = self.model.store
+        vel = sd["velocity"]
+        if torch.is_tensor(vel):        # a checkpoint of an earlier version: the raw flat buffer, only valid for the identical layout
+            if vel.numel() != st.velocity.numel():
+                raise ValueError("optimizer checkpoint holds a flat velocity buffer of %d elements but this build lays the parameters out in %d: "
+                                 "the flat format is layout-dependent and cannot be converted; resume from the model weights instead"
+                                 % (vel.numel(), st.velocity.numel()))
+            st.velocity.copy_(vel)
+        else:
+            missing = [n for n in st.train_order if n not in vel]
+            if missing:
+                raise KeyError("optimizer checkpoint lacks momentum for %d parameters, e.g. %s" % (len(missing), missing[:3]))
+            st.velocity.zero_()
+            for n in st.train_order:
+                view = st.named_view(st.velocity, n)
+                if tuple(vel[n].shape) != tuple(view.shape):
+                    raise ValueError("optimizer checkpoint: momentum of %s has shape %s, the parameter %s" % (n, tuple(vel[n].shape), tuple(view.shape)))
+                view.copy_(vel[n].to(view.device))
         ctx().step_counter.fill_(int(sd["step"]))
         self._learning_rate.last_epoch = int(sd["step"])
 

@@ -172,9 +172,9 @@ def main(argv=None):
         if args.data == "dataset":
             from .src.transforms import get_val_transforms
             ds_val = get_dataset(config, data_transform=get_val_transforms(config), mode="val")
-            items = [ds_val[i] for i in range(len(ds_val))]
-            val_images = [torch.from_numpy(a).float().to(dev) for a, _ in items]
-            val_labels = [torch.from_numpy(np.ascontiguousarray(b[0])).long().to(dev) for _, b in items]
+            from .val import ValTiles       # decoded lazily, this rank's shard only, kept on the host between evaluations
+            cache = {}
+            val_images, val_labels = ValTiles(ds_val, 0, cache), ValTiles(ds_val, 1, cache)
         elif args.data != "synthetic" and "val_images" in z.files:
             val_images = [torch.from_numpy(a).float().to(dev) for a in z["val_images"]]
             val_labels = [torch.from_numpy(a).long().to(dev) for a in z["val_labels"]]
@@ -231,7 +231,7 @@ def main(argv=None):
             if checkpoint_now and rank == 0:
                 path = os.path.join(config.SAVE_DIR, "iter_{}_state.pt".format(cur_iter))
                 torch.save({"model": {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()},
-                            "optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()},
+                            "optimizer": {k: ({n: t.cpu() for n, t in v.items()} if isinstance(v, dict) else v) for k, v in optimizer.state_dict().items()},
                             "iter": cur_iter}, path)
                 # and the weights alone in the reference's own format (train.py:200-203: iter_{n}_model_state.pdparams)
                 from .src.utils.checkpoint import save_pdparams

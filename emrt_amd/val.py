@@ -33,12 +33,55 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+class _OnDevice:
+    """Sequence view: element i moved to the device when it is indexed (no-op for device tensors)."""
+
+    def __init__(self, seq, dev):
+        self.seq, self.dev = seq, dev
+
+    def __len__(self):
+        return len(self.seq)
+
+    def __getitem__(self, i):
+        return self.seq[i].to(self.dev, non_blocking=True)
+
+
+class ValTiles:
+    """Lazy validation set over a dataset object: item i is decoded when indexed (and kept on the HOST, pinned when possible, for
+    the next evaluation), so a rank only ever decodes its own shard.  `which` = 0 -> image fp32 [3,h,w], 1 -> label int64 [h,w]."""
+
+    def __init__(self, dataset, which, cache=None):
+        self.ds, self.which = dataset, which
+        self.cache = {} if cache is None else cache
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, i):
+        if i not in self.cache:
+            a, b = self.ds[i]
+            img = torch.from_numpy(np.ascontiguousarray(a)).float()
+            lab = torch.from_numpy(np.ascontiguousarray(b[0])).long()
+            try:
+                img, lab = img.pin_memory(), lab.pin_memory()
+            except RuntimeError:        # no pinned allocator (CPU-only host): pageable memory works too
+                pass
+            self.cache[i] = (img, lab)
+        return self.cache[i][self.which]
+
+
 def evaluate(model, images, labels, config, rank=0, nranks=1, multi_scales=False):
-    """images: list of fp32 [3,h,w] device tensors, labels: list of int64 [h,w].  Returns the reference's metric tuple."""
+    """images: sequence of fp32 [3,h,w] tensors, labels: sequence of int64 [h,w], on the host or on the device (a lazy sequence
+    such as ValTiles decodes on access).  Only this rank's shard (rank, rank + nranks, ...) is ever touched, and a host image is
+    moved to the device when its turn comes -- as the reference streams them through a DataLoader (val.py:95-104) -- instead of
+    the whole validation set living in HBM next to the training graph's pools.  Returns the reference's metric tuple."""
+    from .runtime import ctx
     model.eval()
     ncls = config.DATA.NUM_CLASSES
-    tot = torch.zeros(3, ncls, dtype=torch.int64, device=images[0].device)
+    dev = ctx().device
+    tot = torch.zeros(3, ncls, dtype=torch.int64, device=dev)
     t0 = time.time()
+    images, labels = _OnDevice(images, dev), _OnDevice(labels, dev)
     for i in range(rank, len(images), nranks):
         if multi_scales:            # val.py:168-181: VAL.SCALE_RATIOS + horizontal flip
             pred = infer.ms_inference(model, [images[i]], labels[i].shape[-2:], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
@@ -84,9 +127,8 @@ def main(argv=None):
         if getattr(args, "data_path", None):
             config.DATA.DATA_PATH = args.data_path
         ds = get_dataset(config, data_transform=get_val_transforms(config), mode="val")
-        items = [ds[i] for i in range(len(ds))]
-        images = [torch.from_numpy(a).float().to(dev) for a, _ in items]
-        labels = [torch.from_numpy(np.ascontiguousarray(b[0])).long().to(dev) for _, b in items]
+        cache = {}
+        images, labels = ValTiles(ds, 0, cache), ValTiles(ds, 1, cache)
     else:
         z = np.load(args.data)
         images = [torch.from_numpy(a).float().to(dev) for a in z["images"]]

@@ -166,10 +166,43 @@ def test_conv_bench_shape_bf16_vs_torch(case):
     fwd_big, dgrad_big, pair = _expected_paths(N, H, W, Cin, Cout, k, stride, pad)
     assert {"128x128": fwd_big and dgrad_big and not pair, "pair": pair, "ksplit": not fwd_big}[path], \
         "the case no longer reaches the kernel it was written for: %s" % ((fwd_big, dgrad_big, pair),)
+    _conv_case_vs_torch(case)
+
+
+# the 256 x 256 LDS-DMA kernel (csrc/igemm8p.hpp), forced through the dispatcher knob so that every edge it has is exercised
+# whatever the size heuristics pick: ragged M (rows past the last pixel), ragged OC (weight rows past OC, tile columns past OC),
+# stride 2 forward and its data gradient (stride holes), a 1x1 kernel (one tap), dilation, an odd number of k-tiles (the loop
+# multiplies one all-zero tile), two N tiles, and the three layers it is built for at the benchmark's size
+CONV_8P = [
+    ("8p-uphead-128", 8, 128, 128, 256, 256, 3, 1, 1, True, None),
+    ("8p-uphead-64", 8, 64, 64, 256, 256, 3, 1, 1, True, None),
+    ("8p-cls_psp-0", 8, 32, 32, 1536, 512, 3, 1, 1, False, None),
+    ("8p-ragged-m-oc", 3, 40, 24, 128, 320, 3, 1, 1, True, None),
+    ("8p-stride2", 2, 48, 48, 64, 192, 3, 2, 1, False, None),
+    ("8p-1x1-odd-ktiles", 2, 30, 34, 192, 256, 1, 1, 0, True, None),
+    ("8p-dilated", 2, 32, 32, 64, 64, 3, 1, 2, False, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_8P, ids=[c[0] for c in CONV_8P])
+def test_conv_8phase_kernel_bf16_vs_torch(case):
+    from emrt_amd import _lib
+    L_ = _lib.lib()
+    old = L_.set_tuning("conv_tile", 7)
+    oldp = L_.set_tuning("pair_max", 0)          # the data gradient goes out as its own launch: through the forced tile
+    try:
+        _conv_case_vs_torch(case, dilation=case[10] or 1)
+    finally:
+        L_.set_tuning("conv_tile", old)
+        L_.set_tuning("pair_max", oldp)
+
+
+def _conv_case_vs_torch(case, dilation=1):
+    name, N, H, W, Cin, Cout, k, stride, pad, bias = case[:10]
     c = init(BF16)
     g = torch.Generator().manual_seed(41)
     x = rnd(torch.randn(N, Cin, H, W, generator=g))
-    conv = hnn.Conv2D(Cin, Cout, k, stride, pad, bias=bias)
+    conv = hnn.Conv2D(Cin, Cout, k, stride, pad, bias=bias, dilation=dilation)
     with torch.no_grad():
         conv.weight.copy_(rnd(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)))
         if bias:
@@ -179,7 +212,7 @@ def test_conv_bench_shape_bf16_vs_torch(case):
     xr = x.clone().requires_grad_(True)
     wr = w_ref.clone().requires_grad_(True)
     br = b_ref.clone().requires_grad_(True) if bias else None
-    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dilation)
     dy = rnd(torch.randn(yr.shape, generator=g))
     yr.backward(dy)
     xd = dev_map(x)

@@ -605,6 +605,55 @@ def test_msda_fwd_bwd(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [4, 2])
+def test_msda_bwd_fewer_heads_long_query(dtype, M):
+    """M < 8 heads with Lq >= 1024 and the global-gather gradient kernel: the value-gradient scatter then takes its fixed-point
+    scale from msda_absmax_kernel, whose row-lane reduction used to cover only 8 of the 256 / (4 M) row lanes (max |dout|
+    under-estimated -> int32 overflow in the scatter -> silently wrong dvalue).  The model always runs M = 8."""
+    from emrt_amd import _lib
+    c = init(dtype)
+    g = torch.Generator().manual_seed(21 + M)
+    L, Pn = 3, 6
+    shapes = [(32, 32), (16, 16), (8, 8)]
+    Lv = sum(h * w for h, w in shapes)
+    B, Lq = 2, Lv
+    tp = M * L * Pn
+    value = rnd(torch.randn(B, Lv, M * 32, generator=g))
+    offw = torch.cat([torch.randn(B, Lq, 2 * tp, generator=g) * 2.0, torch.randn(B, Lq, tp, generator=g)], -1)
+    ref = torch.rand(1, Lq, 1, 2, generator=g)
+    vr, orq = value.clone().requires_grad_(True), offw.clone().requires_grad_(True)
+    out_r = _msda_ref(vr, orq, ref, shapes, M, L, Pn)
+    # one very large |dout| per (batch, head), on a row whose lane (row % (256 / (4 M))) is >= 8: exactly what the old reduction
+    # dropped -- the scale 2^30 / (Lq max|g|) was then taken from the 0.01-sized rest and the spike's contributions overflowed int32
+    dy = torch.randn(out_r.shape, generator=g) * 0.01
+    rpp = 256 // (4 * M)
+    for b in range(B):
+        for m in range(M):
+            dy[b, 64 * (3 + m) + rpp - 1, m * 32 + 5] = 1000.0
+    dy = rnd(dy)
+    out_r.backward(dy)
+    vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
+    L_ = _lib.lib()
+    old = L_.set_tuning("msda_bwd_global", 1)
+    try:
+        tape = Tape()
+        c.tape = tape
+        y = Fn.msda(vd, od, rd, shapes, M, Pn)
+        c.tape = None
+        for t in (vd, od):
+            tape.watch(t)
+        close("msda fwd M%d" % M, host(y), out_r.detach(), dtype)
+        dv, do = run_bwd(tape, [(y, dev(dy))], [vd, od])
+    finally:
+        L_.set_tuning("msda_bwd_global", old)
+    rel = (host(dv) - vr.grad).norm() / vr.grad.norm()
+    # (the scatter accumulates in 32-bit fixed point with resolution Lq * max|g| / 2^30 = 1.3e-3 here: a bound on the ABSOLUTE error)
+    assert rel < (1e-3 if dtype == F32 else 6e-3), "msda dvalue M=%d: relative L2 error %g" % (M, rel)
+    assert (host(dv) - vr.grad).abs().max().item() < (0.05 if dtype == F32 else 4.0)
+    close("msda doffw M%d" % M, host(do), orq.grad, dtype, 4.0, atol=(2e-3 if dtype == F32 else 0.2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("L", [110, 128, 37])      # 110: the EMRT decoder; 128: backward without the LDS copy of P; 37: ragged quads
 def test_mha_fwd_bwd(dtype, L):
     c = init(dtype)

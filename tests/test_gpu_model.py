@@ -108,8 +108,36 @@ def build_pair(backbone, x, dtype=F32, perturb=False, ncls=6, condition=None):
     return ref, model
 
 
+def float64_train_forward(ref, x):
+    """Train-mode logits of a float64 copy of the oracle (the exact result of the reference's arithmetic on these inputs); the
+    copy's BatchNorm buffers are its own, so the fp32 oracle is left untouched."""
+    import copy
+    ref64 = copy.deepcopy(ref).double().train()
+    with torch.no_grad():
+        return [t.float() for t in ref64(x.double())]
+
+
+def assert_train_logits(out, out32, out64, what):
+    """north_star: fp32 logits within 1e-3.  Train-mode BatchNorm divides by batch statistics that are themselves fp32 sums over
+    B*H*W values, so the float32 CPU oracle's OWN distance from float64 is measured next to the HIP path's and printed; the HIP
+    path must be within 1e-3 of float64, or -- where fp32 itself cannot be -- no further from it than the fp32 oracle is."""
+    for name, a, b32, b64 in (("main", out[0], out32[0], out64[0]), ("aux", out[1], out32[1], out64[1])):
+        a, b32 = a.cpu(), b32.detach()
+        e64, e32, o32 = (a - b64).abs().max().item(), (a - b32).abs().max().item(), (b32 - b64).abs().max().item()
+        print("%s, %s logits (train mode): |hip-f64| %.3g  |hip-f32 oracle| %.3g  |f32 oracle-f64| %.3g  (|ref| max %.3g)"
+              % (what, name, e64, e32, o32, b64.abs().max().item()))
+        assert e64 < max(1e-3, 1.25 * o32), "%s %s: |hip - float64 oracle| = %.3g (fp32 oracle itself: %.3g)" % (what, name, e64, o32)
+        assert e32 < 2e-3, "%s %s: |hip - float32 oracle| = %.3g" % (what, name, e32)
+
+
 @pytest.mark.parametrize("backbone,B,S,ncls", [("resnet18", 2, 64, 6), ("resnet50", 2, 128, 6), ("resnet50", 1, 256, 6),
-                                                ("resnet50", 1, 512, 7)])      # last: BASELINE configs[2] (LoveDA 512x512, 7 classes, Lv = 5376)
+                                                ("resnet50", 1, 512, 7),      # BASELINE configs[2] geometry (LoveDA 512x512, 7 classes, Lv = 5376)
+                                                # the BASELINE configs at their REAL batch sizes (the kernels are selected by size):
+                                                ("resnet18", 1, 256, 6),      # configs[0]: ResNet-18, one 256x256 tile, on the HIP path
+                                                ("resnet50", 8, 256, 6),      # configs[1]: batch 8
+                                                ("resnet50", 4, 512, 7),      # configs[2]: batch 4
+                                                # the other depths the reference's constructor accepts (paddle_EMRT.py:229-234)
+                                                ("resnet34", 1, 128, 6), ("resnet101", 1, 128, 6)])
 def test_forward_logits_match_oracle_eval(backbone, B, S, ncls):
     """fp32 logits within 1e-3 of the oracle evaluated in float64 (the exact result of the reference's arithmetic; the
     fp32 CPU oracle itself deviates from it by a few 1e-4), and within 2e-3 of the fp32 oracle; argmax masks agree
@@ -205,6 +233,7 @@ def test_full_size_train_step_matches_oracle():
     labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
     ref, model = build_pair("resnet50", x, perturb=True)
     ref.train()
+    out64 = float64_train_forward(ref, x)
     out_r = ref(x)
     loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
     loss_r.backward()
@@ -214,8 +243,7 @@ def test_full_size_train_step_matches_oracle():
     loss = get_loss_function(make_config("resnet50"))(out, labels.cuda())
     loss.backward()
     torch.cuda.synchronize()
-    assert (out[0].cpu() - out_r[0].detach()).abs().max().item() < 2e-3
-    assert (out[1].cpu() - out_r[1].detach()).abs().max().item() < 2e-3
+    assert_train_logits(out, out_r, out64, "256x256 batch 8")
     assert abs(loss.item() - loss_r.item()) < 2e-4 * max(1.0, abs(loss_r.item()))
     refp = dict(ref.named_parameters())
     gmax = max(float(q.grad.norm()) for q in refp.values() if q.grad is not None)
@@ -601,6 +629,7 @@ def test_large_tile_train_step_matches_oracle_512():
     labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
     ref, model = build_pair("resnet50", x, perturb=True, ncls=ncls)
     ref.train()
+    out64 = float64_train_forward(ref, x)
     out_r = ref(x)
     loss_r = train_ref.mix_softmax_ce_loss(out_r, labels)
     loss_r.backward()
@@ -610,8 +639,7 @@ def test_large_tile_train_step_matches_oracle_512():
     loss = get_loss_function(make_config("resnet50", ncls=ncls))(out, labels.cuda())
     loss.backward()
     torch.cuda.synchronize()
-    assert (out[0].cpu() - out_r[0].detach()).abs().max().item() < 2e-3
-    assert (out[1].cpu() - out_r[1].detach()).abs().max().item() < 2e-3
+    assert_train_logits(out, out_r, out64, "512x512 batch 2")
     assert abs(loss.item() - loss_r.item()) < 2e-4 * max(1.0, abs(loss_r.item()))
     refp = dict(ref.named_parameters())
     dot = n_hip = n_ref = 0.0

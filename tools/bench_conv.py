@@ -77,10 +77,55 @@ def thin():
                 print("CH %d cblk %3d pixel chunks %4d: masked+stats %.1f us  plain %.1f us" % (ch, cblk, blocks, timed(lambda: run(True)), timed(lambda: run(False))), flush=True)
 
 
+BIG = [  # the layers that carry the FLOPs, at the sizes of BASELINE configs[1] (batch 8, 256x256), [2] (batch 4, 512x512), [4] (16 windows)
+    ("cfg2 uphead conv_2", 8, 128, 128, 256, 256, 3), ("cfg2 uphead conv_1", 8, 64, 64, 256, 256, 3), ("cfg2 uphead conv_0", 8, 32, 32, 256, 256, 3),
+    ("cfg2 cls_psp.0", 8, 32, 32, 1536, 512, 3), ("cfg2 cls_psp.3", 8, 32, 32, 512, 256, 3),
+    ("cfg3 uphead conv_2", 4, 256, 256, 256, 256, 3), ("cfg3 uphead conv_1", 4, 128, 128, 256, 256, 3), ("cfg3 uphead conv_0", 4, 64, 64, 256, 256, 3),
+    ("cfg3 cls_psp.0", 4, 64, 64, 1536, 512, 3), ("cfg3 cls_psp.3", 4, 64, 64, 512, 256, 3),
+    ("cfg5 uphead conv_2", 16, 128, 128, 256, 256, 3), ("cfg5 cls_psp.0", 16, 32, 32, 1536, 512, 3),
+]
+
+
+def big():
+    """128 x 128 register-staged tile (conv_tile 3) against the 256 x 256 LDS-DMA 8-phase kernel (conv_tile 7): time and agreement."""
+    for (name, N, H, W, C, OC, k) in BIG:
+        pad = k // 2
+        x = torch.randn(N, H, W, C, device=dev).bfloat16()
+        wf = (torch.randn(OC, k, k, C, device=dev) / (k * k * C) ** 0.5).bfloat16()
+        wb = (torch.randn(C, k, k, OC, device=dev) / (k * k * OC) ** 0.5).bfloat16()
+        dy = torch.randn(N, H, W, OC, device=dev).bfloat16()
+        y = torch.empty(N, H, W, OC, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty_like(x)
+        stats = torch.zeros(8 * 2 * max(C, OC), device=dev, dtype=torch.float64)
+        gf = 2.0 * N * H * W * OC * k * k * C / 1e9
+
+        def fwd():
+            L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, H, W, OC, OC, H * W * OC, 0, 0,
+                               k, k, 1, pad, 0, 0, 0, P(stats), None, 0, 0, 1, None, 1, stream)
+
+        def dgrad():
+            L._raw_emrt_conv2d(P(dy), P(wb), P(dx), None, None, N, H, W, OC, OC, H * W * OC, H, W, C, C, H * W * C, 0, 0,
+                               k, k, 1, pad, 1, 0, 0, None, None, 0, 0, 1, None, 1, stream)
+        line = "%-20s N%d %dx%dx%d->%d k%d %7.2f GF |" % (name, N, H, W, C, OC, k, gf)
+        for nm, fn, out in (("fwd", fwd, y), ("dgrad", dgrad, dx)):
+            res, outs = [], []
+            for tile in (0, 3, 7):
+                L.set_tuning("conv_tile", tile)
+                res.append(timed(fn, 20))
+                outs.append(out.float().clone())
+            L.set_tuning("conv_tile", 0)
+            rel = ((outs[2] - outs[1]).norm() / outs[1].norm()).item()
+            line += " %s auto %.1f us (%.0f TF/s)  128x128 %.1f  8-phase %.1f us (%.0f TF/s)  rel diff %.1e |" % (
+                nm, res[0], gf / res[0] * 1e3, res[1], res[2], gf / res[2] * 1e3, rel)
+        print(line, flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "thin":
         return thin()
+    if which == "big":
+        return big()
     for (N, H, W, C, OC, k, s, pad) in SHAPES:
         OH = (H + 2 * pad - k) // s + 1
         OW = (W + 2 * pad - k) // s + 1

@@ -27,6 +27,9 @@ offw = dev(torch.cat([torch.randn(B, Lq, 2 * tp, generator=g) * 2, torch.randn(B
 ref = encoder_reference_points(shapes).cuda()
 dy = dev(torch.randn(B, Lq, 256, generator=g))
 Lb = _lib.lib()
+import os
+if os.environ.get("BENCH_MSDA_PROBE"):       # timing experiments (tools/exp/probe_msda_*.sh): parts of the kernels switched off, results WRONG
+    Lb.set_tuning("msda_fwd_probe", int(os.environ["BENCH_MSDA_PROBE"]))
 esz = 4 if dt == F32 else 2
 alg = B * (Lv * 256 * esz + Lq * tp * 3 * 4 + Lq * 256 * esz)
 
