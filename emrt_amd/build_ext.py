@@ -29,13 +29,13 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    hdr = os.path.join(CSRC, "common.hpp")
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".hpp")]      # common.hpp, igemm8p.hpp (included by conv.hip)
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s, hdr]):
+        if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
 
     def run(cmd):

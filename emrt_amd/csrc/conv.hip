@@ -161,12 +161,14 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   bool a_ok[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    long long m = (long long)bm * BM + row0 + 32 * i;
-    a_ok[i] = m < M;
-    long long mm = a_ok[i] ? m : 0;
-    int nb = (int)(mm / OHW);
-    int r = (int)(mm - (long long)nb * OHW);
-    int oh = r / p.OW, ow = r - oh * p.OW;
+    // 32-bit arithmetic: the host guarantees N * OH * OW < 2^31 (a 64-bit division is ~150 instructions, and there was one per row
+    // here and one per row in the epilogue: ~1 us of every launch of the small layers)
+    const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)(row0 + 32 * i);
+    a_ok[i] = (long long)m < M;
+    const unsigned mm = a_ok[i] ? m : 0u;
+    const int nb = (int)(mm / (unsigned)OHW);
+    const int r = (int)(mm - (unsigned)nb * (unsigned)OHW);
+    const int oh = (int)((unsigned)r / (unsigned)p.OW), ow = r - oh * p.OW;
     a_base[i] = (unsigned)((long long)nb * p.in_bs * (long long)sizeof(T));
     if (MODE == 0) { a_h[i] = oh * p.stride - p.pad; a_w[i] = ow * p.stride - p.pad; }
     else { a_h[i] = oh + p.pad; a_w[i] = ow + p.pad; }
@@ -401,10 +403,10 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       const T* ymask = (const T*)p.mask_y;
 #pragma unroll 2
       for (int row = rr; row < BM; row += RP) {
-        const long long m = (long long)bm * BM + row;
-        if (m >= M || !col_ok) continue;
-        const int e_nb = (int)(m / OHW);
-        const int e_pix = (int)(m - (long long)e_nb * OHW);
+        const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)row;
+        if ((long long)m >= M || !col_ok) continue;
+        const int e_nb = (int)(m / (unsigned)OHW);
+        const int e_pix = (int)(m - (unsigned)e_nb * (unsigned)OHW);
         float v[8];
         {
           const float4 a = *reinterpret_cast<const float4*>(tile + row * CP + cg * 8);
@@ -481,8 +483,8 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     scale_v[j] = (p.scale && n < p.OC) ? p.scale[n] : 1.f;
   }
   long long m_cur = (long long)bm * BM + wr * TM * 32 + 4 * fh;
-  int e_nb = (int)(m_cur / OHW);
-  int e_pix = (int)(m_cur - (long long)e_nb * OHW);
+  int e_nb = (int)((unsigned)m_cur / (unsigned)OHW);
+  int e_pix = (int)((unsigned)m_cur - (unsigned)e_nb * (unsigned)OHW);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -647,10 +649,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x
     const int OHW = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long m = (mt_begin + grp) * BKM + prow + RPP * i;
-      r_nb[i] = (int)(m / OHW);
-      const int pix = (int)(m - (long long)r_nb[i] * OHW);
-      r_oh[i] = pix / p.OW;
+      const unsigned m = (unsigned)((mt_begin + grp) * BKM) + (unsigned)(prow + RPP * i);      // < 2^31 (host-checked): 32-bit divisions
+      r_nb[i] = (int)(m / (unsigned)OHW);
+      const int pix = (int)(m - (unsigned)r_nb[i] * (unsigned)OHW);
+      r_oh[i] = (int)((unsigned)pix / (unsigned)p.OW);
       r_ow[i] = pix - r_oh[i] * p.OW;
       r_dy[i] = (unsigned)(((long long)r_nb[i] * p.dy_bs + (long long)pix * p.lddy) * (long long)ESZ);      // (garbage past the last image: masked)
       r_ximg[i] = (unsigned)((long long)r_nb[i] * p.x_bs * (long long)ESZ);
@@ -922,6 +924,15 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
     }
   }
   if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
+  if constexpr (VEC && sizeof(T) == 2) {
+    // the 256 x 256 LDS-DMA kernel (igemm8p.hpp) wins once its grid covers most of the 256 CUs (one 128 KiB block per CU), or about half
+    // of them with a long k loop; measured with tools/bench_conv.py big: UpHead conv_2 214 -> 149 us, cls_psp.0 dgrad 154 -> 110 us at
+    // batch 8; 256-block grids 98 -> 72 us; 128-block grids tie at 36 k-tiles and win 276 -> 250 us at 216; 64-block grids lose
+    const long long nb256 = blocks(256, 256);
+    const int nkt64 = a.KH * a.KW * a.C / 64;
+    const int minb = g_tune.igemm8p_min_blocks;
+    if (minb > 0 && nkt64 >= 16 && (nb256 >= minb || (nb256 >= (minb * 3) / 5 && nkt64 >= 144)) && igemm8p_ok<T>(a)) return launch_igemm8p<T, MODE>(a, st);
+  }
   // measured on MI355X (tools/bench_conv.py): 128x128 tiles win only when the k loop is long enough to amortise their
   // prologue / epilogue (>= 16 k-tiles) and there is at least one block per CU; everything else is fastest on 64x64
   constexpr int BK = 8 * (16 / (int)sizeof(T));
@@ -955,6 +966,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
   EMRT_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fwd) or 1 (dgrad)");
+  EMRT_REQUIRE((long long)N * OH * OW + 512 < (1ll << 31) && (long long)N * H * W + 512 < (1ll << 31), "more than 2^31 pixels (32-bit pixel arithmetic)");
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(dtype != EMRT_F16 || mode == 0, "fp16 (dtype 2) is inference-only: forward convolution (mode 0)");
   if (mode == 0) {
@@ -1057,6 +1069,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   EMRT_REQUIRE(x && dy && dw, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0 && dilation >= 1, "bad dims");
   EMRT_REQUIRE(OH == (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && OW == (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "output size mismatch");
+  EMRT_REQUIRE((long long)N * OH * OW + 512 < (1ll << 31) && (long long)N * H * W + 512 < (1ll << 31), "more than 2^31 pixels (32-bit pixel arithmetic)");
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
@@ -1356,6 +1369,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
   EMRT_REQUIRE(OH == (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && OW == (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "output size mismatch");
+  EMRT_REQUIRE((long long)N * OH * OW + 512 < (1ll << 31) && (long long)N * H * W + 512 < (1ll << 31), "more than 2^31 pixels (32-bit pixel arithmetic)");
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   {
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
@@ -1487,6 +1501,7 @@ extern "C" int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, vo
     EMRT_REQUIRE(d.in && d.w_packed && d.out, "null pointer");
     EMRT_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.OC > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad >= 0, "bad dims");
     EMRT_REQUIRE(d.OH == (d.H + 2 * d.pad - d.KH) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.KW) / d.stride + 1, "output size mismatch");
+    EMRT_REQUIRE((long long)d.N * d.OH * d.OW + 512 < (1ll << 31) && (long long)d.N * d.H * d.W + 512 < (1ll << 31), "more than 2^31 pixels");
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
     const long long in_ext = ((long long)(d.N - 1) * d.in_bs + ((long long)d.H * d.W - 1) * d.ldin + d.C) * esz;
     EMRT_REQUIRE(d.in_bs >= 0 && in_ext < (1ll << 31) && (long long)d.OC * d.KH * d.KW * d.C * esz < (1ll << 31), "operand spans 2 GiB or more");
@@ -1556,6 +1571,7 @@ extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dt
     EMRT_REQUIRE(b.x && b.dy && b.w_bwd_packed && b.dx && b.dw, "null pointer");
     EMRT_REQUIRE(b.N > 0 && b.H > 0 && b.W > 0 && b.C > 0 && b.OC > 0 && b.KH > 0 && b.KW > 0 && b.stride > 0 && b.pad >= 0, "bad dims");
     EMRT_REQUIRE(b.OH == (b.H + 2 * b.pad - b.KH) / b.stride + 1 && b.OW == (b.W + 2 * b.pad - b.KW) / b.stride + 1, "output size mismatch");
+    EMRT_REQUIRE((long long)b.N * b.OH * b.OW + 512 < (1ll << 31) && (long long)b.N * b.H * b.W + 512 < (1ll << 31), "more than 2^31 pixels");
     EMRT_REQUIRE(b.lddx >= b.C && b.dx_bs >= 0, "bad dx strides");
     const long long esz = dtype == EMRT_F32 ? 4 : 2;
     const long long x_ext = ((long long)(b.N - 1) * b.x_bs + ((long long)b.H * b.W - 1) * b.ldx + b.C) * esz;

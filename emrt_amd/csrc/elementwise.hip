@@ -26,6 +26,7 @@ const TuneEntry kTune[] = {
     {"msda_lds_min_pairs", &emrt::Tuning::msda_lds_min_pairs, 2048}, {"msda_bwd_dref_lds", &emrt::Tuning::msda_bwd_dref_lds, 1},
     {"gn_group_blocks", &emrt::Tuning::gn_group_blocks, 0}, {"gn_stat_rows", &emrt::Tuning::gn_stat_rows, 32},
     {"gn_bwd_stat_rows", &emrt::Tuning::gn_bwd_stat_rows, 32}, {"gn_apply_rows", &emrt::Tuning::gn_apply_rows, 8},
+    {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;
@@ -36,7 +37,7 @@ emrt::Tuning tuning_from_env() {
     env[n] = 0;
     // the probe knob switches parts of a kernel OFF (wrong results, timing experiments only): never from the environment of a
     // production process, only through an explicit emrt_set_tuning() call of the experiment script
-    const char* v = strcmp(e.name, "msda_fwd_probe") == 0 ? nullptr : getenv(env);
+    const char* v = (strcmp(e.name, "msda_fwd_probe") == 0 || strcmp(e.name, "igemm8p_probe") == 0) ? nullptr : getenv(env);
     t.*(e.field) = v ? atoi(v) : e.def;
   }
   return t;

@@ -47,7 +47,13 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned vo
 #endif
 }
 
-template <class T, int MODE>
+// PROBE (timing experiments only, -DEMRT_8P_PROBES builds; results are WRONG): 1 = no DMA issue in the loop, 2 = no fragment reads,
+// 4 = no MFMAs.  The production instantiation is PROBE = 0.
+// Measured and not kept (round 3, tools/bench_conv.py big): a second schedule that keeps the b0 fragments in registers through phase 4
+// (20 instead of 24 fragment reads per k-tile), re-stages every unit TWO phases after its last read (ph1: UB1(t+1), ph2: UA1(t+1),
+// ph3: UA0(t+2), ph4: UB0(t+2), vmcnt(4)) and retires the reads AFTER the first barrier: within 1 % of this one on every shape
+// (147.4 vs 146.6 us on UpHead conv_2) -- the loop is not bound by the fragment reads' latency.
+template <class T, int MODE, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 x 64 KiB k-tile buffers; the epilogue reuses them
   static_assert(sizeof(T) == 2, "bf16 / fp16 only");
@@ -79,12 +85,12 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   bool a_ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {                        // i = 0: UA0 rows 0-63, 1: UA1 64-127, 2: UA0 128-191, 3: UA1 192-255
-    const long long m = (long long)bm * BM + 64 * i + 8 * wave + lrow;
-    a_ok[i] = m < M;
-    const long long mm = a_ok[i] ? m : 0;
-    const int nb = (int)(mm / OHW);
-    const int r = (int)(mm - (long long)nb * OHW);
-    const int oh = r / p.OW, ow = r - oh * p.OW;
+    const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)(64 * i + 8 * wave + lrow);      // < 2^31 (host-checked): 32-bit divisions
+    a_ok[i] = (long long)m < M;
+    const unsigned mm = a_ok[i] ? m : 0u;
+    const int nb = (int)(mm / (unsigned)OHW);
+    const int r = (int)(mm - (unsigned)nb * (unsigned)OHW);
+    const int oh = (int)((unsigned)r / (unsigned)p.OW), ow = r - oh * p.OW;
     a_base[i] = (unsigned)((long long)nb * p.in_bs * 2);
     if (MODE == 0) { a_h[i] = oh * p.stride - p.pad; a_w[i] = ow * p.stride - p.pad; }
     else { a_h[i] = oh + p.pad; a_w[i] = ow + p.pad; }
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
     }
   };
   auto stage_a = [&](int u, int par) {                 // unit UAu of k-tile akt -> buffer par
+    if constexpr ((PROBE & 1) != 0) { if (akt >= 2) return; }
     const unsigned kbad = akt < nkt ? 0u : BUF_OOB;
     const unsigned cb = (unsigned)a_c0 * 2u + chunk_b;
 #pragma unroll
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
     }
   };
   auto stage_b = [&](int u, int par) {                 // unit UBu of k-tile bkt -> buffer par
+    if constexpr ((PROBE & 1) != 0) { if (bkt >= 2) return; }
     const unsigned kbad = bkt < nkt ? 0u : BUF_OOB;
     const unsigned kb = (unsigned)bkt * 128u + chunk_b;
 #pragma unroll
@@ -167,9 +175,12 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   const unsigned a_tile0 = (unsigned)(wr * 128) * 128u;             // this wave's first A row
   const unsigned b_tile0 = AB + (unsigned)(wc * 64) * 128u;         // ... first B row
   uint4 fa[2][4], fb0[4], fb1[4];
-  auto lds16 = [&](unsigned off) -> uint4 { return *reinterpret_cast<const uint4*>(smem + off); };
+  auto lds16 = [&](unsigned off) -> uint4 {
+    if constexpr ((PROBE & 2) != 0) { uint4 v = make_uint4(off, off * 3u, 0x3f803f80u, 0x3f803f80u); asm volatile("" : "+v"(v.x), "+v"(v.y)); return v; }
+    return *reinterpret_cast<const uint4*>(smem + off);
+  };
 
-  // ---- prologue: k-tile 0 whole, then the three units of k-tile 1 that phases 2-4 of "tile -1" would have issued ------------
+  // ---- prologue: k-tile 0 whole, then the units of k-tile 1 that the last phases of "tile -1" would have issued ----------------
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
   advance_a(); ++bkt;
   stage_a(0, 1); stage_b(1, 1); stage_a(1, 1);        // UB0(1) follows in phase 1 of tile 0 (bkt advances there)
@@ -216,7 +227,10 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mma_chunk<T>(acc[AH * 2 + i][BH], fa[i][s], BH ? fb1[s] : fb0[s]);
+      for (int s = 0; s < 4; ++s) {
+        if constexpr ((PROBE & 4) != 0) { asm volatile("" :: "v"(fa[i][s].x), "v"(fb0[s].x), "v"(fb1[s].x)); }
+        else mma_chunk<T>(acc[AH * 2 + i][BH], fa[i][s], BH ? fb1[s] : fb0[s]);
+      }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -258,10 +272,10 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
     __syncthreads();
 #pragma unroll 2
     for (int tr = rr; tr < 64; tr += 16) {
-      const long long m = (long long)bm * BM + (tr >> 5) * 128 + i * 32 + (tr & 31);
-      if (m >= M || !col_ok) continue;
-      const int e_nb = (int)(m / OHW);
-      const int e_pix = (int)(m - (long long)e_nb * OHW);
+      const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)((tr >> 5) * 128 + i * 32 + (tr & 31));
+      if ((long long)m >= M || !col_ok) continue;
+      const int e_nb = (int)(m / (unsigned)OHW);
+      const int e_pix = (int)(m - (unsigned)e_nb * (unsigned)OHW);
       float v[8];
       {
         const float4 a = *reinterpret_cast<const float4*>(tile + tr * CP + cg * 8);
@@ -334,11 +348,24 @@ static bool igemm8p_ok(const ConvArgs& a) {
   return true;
 }
 
-template <class T, int MODE>
+template <class T, int MODE, int PROBE = 0>
 static int launch_igemm8p(const ConvArgs& a, hipStream_t st) {
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long grid = ((M + 255) / 256) * ((a.OC + 255) / 256);
-  auto kern = igemm8p_kernel<T, MODE>;
+#ifdef EMRT_8P_PROBES
+  if constexpr (PROBE == 0 && MODE == 0 && std::is_same<T, bf16_t>::value) {
+    switch (g_tune.igemm8p_probe) {
+      case 1: return launch_igemm8p<T, MODE, 1>(a, st);
+      case 2: return launch_igemm8p<T, MODE, 2>(a, st);
+      case 3: return launch_igemm8p<T, MODE, 3>(a, st);
+      case 4: return launch_igemm8p<T, MODE, 4>(a, st);
+      case 6: return launch_igemm8p<T, MODE, 6>(a, st);
+      case 7: return launch_igemm8p<T, MODE, 7>(a, st);
+      default: break;
+    }
+  }
+#endif
+  auto kern = igemm8p_kernel<T, MODE, PROBE>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)

@@ -854,6 +854,12 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
         w4.z = (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix) ? aw * ly * (1.f - lx) : 0.f;
         w4.w = (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix) ? aw * ly * lx : 0.f;
       }
+      // a wave whose 2 x QB queries put no sample of this level inside the block's pixel range has nothing to add: skip the
+      // dout loads and the sample loop (wave-uniform branch).  Queries are stored row-major per level and sample near their
+      // own reference point, so for a level cut into several ranges most waves of a block skip most of their iterations
+      // (Lv = 5376: level 0 in 4 ranges, every block walked all 5376 queries' samples to keep a quarter of them).
+      const bool hit = w4.x != 0.f || w4.y != 0.f || w4.z != 0.f || w4.w != 0.f;
+      if (__ballot(hit) == 0ull && !(probe & 64)) continue;
       rec_w[ch] = w4;
       rec_f[ch] = f00;
     }

@@ -111,7 +111,7 @@ def big():
             res, outs = [], []
             for tile in (0, 3, 7):
                 L.set_tuning("conv_tile", tile)
-                res.append(timed(fn, 20))
+                res.append(min(timed(fn, 20), timed(fn, 20)))
                 outs.append(out.float().clone())
             L.set_tuning("conv_tile", 0)
             rel = ((outs[2] - outs[1]).norm() / outs[1].norm()).item()

@@ -19,6 +19,9 @@ y = torch.randn(N, OH, OW, OC, device=dev).bfloat16()
 dx = torch.empty_like(x)
 dw = torch.zeros(OC, k, k, C, device=dev, dtype=torch.float32)
 st = c.stream
+import os
+if os.environ.get("CONV_TILE"):          # force an igemm tile (7 = the 256x256 LDS-DMA 8-phase kernel)
+    L.set_tuning("conv_tile", int(os.environ["CONV_TILE"]))
 for _ in range(3):
     L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC, 0, 0, k, k, s, pad, 0, 0, 0, None, None, 0, 0, 1, None, 1, st)
     L._raw_emrt_conv2d(P(y), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0, k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, None, 1, st)
