@@ -9,7 +9,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "emrt_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libemrt_hip.so")
+# EMRT_HIP_LIB: a differently built copy of the same library (developer experiments: tools/exp builds one with -DEMRT_8P_PROBES)
+LIB_PATH = os.environ.get("EMRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libemrt_hip.so")
 
 _TRACE = bool(int(os.environ.get("EMRT_TRACE", "0")))
 

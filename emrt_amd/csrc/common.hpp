@@ -48,6 +48,8 @@ struct Tuning {
   int msda_lds_min_pairs; // smallest B * M * Lq that takes the LDS-staged MSDA kernels (2048: the decoder's 110 queries too, 29 -> 13 us)
   int msda_bwd_dref_lds; // 1 (default): the LDS-staged gradient kernel also serves calls that want the reference-point gradient (the
                         // decoder): fp32 atomics into the caller-ZEROED dref; 0 = those calls take the global-gather kernel
+  int msda_band_halo;   // band MSDA kernels (pyramids too large for one LDS slab): rows staged beyond a band (0 = 7, fewer if LDS is short)
+  int msda_scatter_cuts; // value-gradient scatter: row ranges per level (0 = automatic: about two blocks per CU)
   int msda_fwd_chunks;  // LDS-staged MSDA forward: query chunks per (batch, head) slab (0 = automatic)
   int msda_fwd_threads; // ... threads per block (1024)
   int msda_fwd_probe;   // timing experiments only (results are WRONG): forward 1 = no gather, 2 = no staging, 4 = no preparation;

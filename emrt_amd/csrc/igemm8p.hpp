@@ -48,7 +48,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned vo
 }
 
 // PROBE (timing experiments only, -DEMRT_8P_PROBES builds; results are WRONG): 1 = no DMA issue in the loop, 2 = no fragment reads,
-// 4 = no MFMAs.  The production instantiation is PROBE = 0.
+// 4 = no MFMAs, 8 = no global stores / loads in the epilogue, 16 = no epilogue at all.  The production instantiation is PROBE = 0.
 // Measured and not kept (round 3, tools/bench_conv.py big): a second schedule that keeps the b0 fragments in registers through phase 4
 // (20 instead of 24 fragment reads per k-tile), re-stages every unit TWO phases after its last read (ph1: UB1(t+1), ph2: UA1(t+1),
 // ph3: UA0(t+2), ph4: UB0(t+2), vmcnt(4)) and retires the reads AFTER the first barrier: within 1 % of this one on every shape
@@ -248,6 +248,10 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the trailing (all-zero) stages must land before the epilogue reuses the LDS
   __syncthreads();
 
+  if constexpr ((PROBE & 16) != 0) {
+    if (acc[0][0][0] == 123.456f) ((float*)p.out)[tid] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];      // keeps the accumulators alive
+    return;
+  }
   // ---- epilogue: four passes of 64 rows (pass i = M-tile i of both wave rows) through a row-major fp32 LDS tile ----------------
   // Same arithmetic, order and statistics as igemm_body's row-vectorised epilogue (the host only sends problems that satisfy its
   // vector conditions): accumulate * scale + bias -> + residual -> ReLU -> mask -> store -> statistics of the stored value.
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sv[e], bv[e]);
-      if (resp) {
+      if (resp && !(PROBE & 8)) {
         float w8[8];
         Vec8<T>::load(resp + (long long)e_nb * p.res_bs + (long long)e_pix * p.ldres + n0, w8);
 #pragma unroll
@@ -302,7 +306,9 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
         if (p.stat_x) Vec8<T>::load((const T*)p.stat_x + (long long)e_nb * p.sx_bs + (long long)e_pix * p.ldsx + n0, second);
       }
       const long long obase = (long long)e_nb * p.out_bs + (long long)e_pix * p.ldout + n0;
-      if (p.out_f32) {
+      if constexpr ((PROBE & 8) != 0) {
+        if (v[0] == 123.456f) Vec8<T>::store((T*)p.out + obase, v);
+      } else if (p.out_f32) {
         Vec8<float>::store((float*)p.out + obase, v);
       } else {
         Vec8<T>::store((T*)p.out + obase, v);
@@ -361,6 +367,8 @@ static int launch_igemm8p(const ConvArgs& a, hipStream_t st) {
       case 4: return launch_igemm8p<T, MODE, 4>(a, st);
       case 6: return launch_igemm8p<T, MODE, 6>(a, st);
       case 7: return launch_igemm8p<T, MODE, 7>(a, st);
+      case 8: return launch_igemm8p<T, MODE, 8>(a, st);
+      case 16: return launch_igemm8p<T, MODE, 16>(a, st);
       default: break;
     }
   }

@@ -40,8 +40,10 @@ struct MsdaArgs {
   float* probs;       // fp32 [B*Lq][M*L*P] softmax probabilities (written by the gradient kernel, read by the LDS scatter)
   void* dvalue_t;     // LDS path: [B][Lv][M*32] in the compute dtype, fully overwritten
   int Lv;
-  int g_level[8], g_pix0[8], g_npix[8];   // scatter blocks: (level, first flat pixel, pixel count) of each LDS slab range
-  int g_npix_max;                         // largest g_npix: the per-half-wave sample records sit behind a slab of that size
+  int g_level[16], g_pix0[16], g_npix[16];   // scatter blocks: (level, first flat pixel, pixel count) of each LDS slab range
+  int g_npix_max;                         // largest g_npix (+ the two guard bands): the per-half-wave sample records sit behind a slab of that size
+  int g_guard;                            // zero guard pixels on both sides of a scatter slab (widest level + 2): corners whose weight is 0 are
+                                          // still ADDED (branch-free inner loop) and may fall up to W + 1 pixels outside the block's range
   float* gmax;        // [B*M][gmax_n] per-block max |dout| of a (batch, head) slice, left by the LDS gradient kernel for the scatter
   int gmax_n;         // 0: the scatter scans dout itself
 };
@@ -101,8 +103,17 @@ struct MsdaPrep {
   float w00[NS], w01[NS], w10[NS], w11[NS];        // corner weights (probability * bilinear weight, 0 outside the map)
   int idx[NS];                                     // y0 * W + x0 of the sample's level (0 when no corner is inside)
 
+  // band kernels only: bit j set = slot j's sample has a valid corner outside the rows the block has staged; its weights are zeroed
+  // here (the branch-free LDS loop then adds nothing for it) and the block gathers it from global memory afterwards
+  unsigned miss;
+  float smx, sinv;                                 // softmax max / 1 / denominator of the pair (to re-derive a missed sample)
+
   // row: the pair's fp32 [M*LP*2 offsets | M*LP logits] row; refp: its reference point(s); live: false for tail lanes
-  __device__ __forceinline__ void run(const MsdaArgs& a, const float* row, const float* refp, int m, int sub, bool live) {
+  // BAND: lo / hi = first / one-past-last staged row of every level (msda_fwd_band_kernel); samples outside get idx = lo * W
+  template <bool BAND = false>
+  __device__ __forceinline__ void run(const MsdaArgs& a, const float* row, const float* refp, int m, int sub, bool live,
+                                      const int* lo = nullptr, const int* hi = nullptr) {
+    miss = 0u;
     const float* offp = row + m * LP * 2;
     const float* logp = row + a.M * LP * 2 + m * LP;
     float lg[NS];
@@ -154,8 +165,49 @@ struct MsdaPrep {
       w11[j] = (vy1 && vx1) ? aw * ly * lx : 0.f;
       // with at least one corner inside, y0 is in [-1, H-1] and x0 in [-1, W-1]: the four corner indices stay within
       // [-(W+1), H*W + W] of the level -- the range the LDS slab's guard bands cover
-      idx[j] = ((vy0 || vy1) && (vx0 || vx1) && smp < LP) ? y0 * W + x0 : 0;
+      const bool any_in = (vy0 || vy1) && (vx0 || vx1) && smp < LP;
+      idx[j] = any_in ? y0 * W + x0 : 0;
+      if constexpr (BAND) {
+        int blo = lo[0], bhi = hi[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t)
+          if (l == t) { blo = lo[t]; bhi = hi[t]; }
+        const bool in_band = (!vy0 || (y0 >= blo && y0 < bhi)) && (!vy1 || (y0 + 1 >= blo && y0 + 1 < bhi));
+        if (!any_in || !in_band) {
+          if (any_in && live) miss |= 1u << j;
+          w00[j] = 0.f; w01[j] = 0.f; w10[j] = 0.f; w11[j] = 0.f;
+          idx[j] = blo * W;                        // first staged pixel of the level: a harmless address
+        }
+      }
     }
+    smx = mx; sinv = inv;
+  }
+
+  // the five values of sample smp of this pair again, from global memory (band kernels: a sample that missed the staged rows)
+  __device__ __forceinline__ void one(const MsdaArgs& a, const float* row, const float* refp, int m, int smp, float& c00, float& c01,
+                                      float& c10, float& c11, int& id, int& lev) const {
+    const float* offp = row + m * LP * 2;
+    const float* logp = row + a.M * LP * 2 + m * LP;
+    int l = 0;
+#pragma unroll
+    for (int t = 1; t < L; ++t) l += smp >= t * P ? 1 : 0;
+    lev = l;
+    const int rls = a.ref_L == 1 ? 0 : 2;
+    const int H = a.h[l], W = a.w[l];
+    const float2 of = *reinterpret_cast<const float2*>(offp + smp * 2);
+    const float x = (refp[l * rls] + of.x * a.inv_w[l]) * (float)W - 0.5f;
+    const float y = (refp[l * rls + 1] + of.y * a.inv_h[l]) * (float)H - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float lx = x - xf, ly = y - yf;
+    const int x0 = (int)fminf(fmaxf(xf, -2.f), 16777216.f), y0 = (int)fminf(fmaxf(yf, -2.f), 16777216.f);
+    const float aw = __expf(logp[smp] - smx) * sinv;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    c00 = (vy0 && vx0) ? aw * (1.f - ly) * (1.f - lx) : 0.f;
+    c01 = (vy0 && vx1) ? aw * (1.f - ly) * lx : 0.f;
+    c10 = (vy1 && vx0) ? aw * ly * (1.f - lx) : 0.f;
+    c11 = (vy1 && vx1) ? aw * ly * lx : 0.f;
+    id = y0 * W + x0;
   }
 };
 
@@ -336,6 +388,129 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
     qw += nwave * 16;
     if (qw < q_end) prepare();
   }
+}
+
+// Forward for pyramids whose (batch, head) slab does NOT fit in LDS (Lv = 5376 at 512x512: 344 KB): one block per (batch, head, BAND).
+// Self-attention over the pyramid itself (Lq == Lv, queries stored level by level, row-major -- the encoder,
+// transformer_encoder_decoder.py:230-239): band k of NB owns the query rows [k H_l / NB, (k+1) H_l / NB) of EVERY level, and those queries
+// sample around their own position (sampling offsets are a few pixels: _reset_parameters puts them on a compass grid of radius 1..P),
+// so the block stages, per level, only its rows +- `halo` (whole levels when they are that small): at 512x512 with 8 bands 22 of 64 +
+// 18 of 32 + 16 of 16 rows = 152 KB instead of 344 KB.  Nothing is assumed about the offsets: a sample with a corner outside the staged
+// rows gets weight 0 in the branch-free LDS loop (MsdaPrep::run<true>) and is gathered from global memory afterwards, quad by quad.
+// The value tensor is then read from HBM / L2 once per band (the global kernel re-fetched it through L2 for every query: 1.67x the
+// algorithmic bytes, profiles/r2d_pmc_traffic_cfg3.json) and the 72 corner reads per pair are ds_read_b128.
+// Sums are accumulated in sample order except for missed samples, which come last: bit-identical to msda_fwd_kernel when nothing misses.
+template <class T, int L, int P>
+__global__ __launch_bounds__(1024) void msda_fwd_band_kernel(MsdaArgs a, int NB, int halo, int guard) {
+  static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
+  constexpr int LP = L * P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vslab_raw[];
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);       // the bands of a (batch, head) and the heads of a batch element on one XCD
+  const int bm = bid / NB, band = bid - bm * NB;
+  const int b = bm / a.M, m = bm - b * a.M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, nwave = blockDim.x >> 6;
+  // per level: own query rows [c0, c1), staged rows [lo, hi), slab offset (pixels, multiple of 16 = one DMA piece)
+  int c0[L], c1[L], lo[L], hi[L], soff[L];
+  int npx = guard;
+  MsdaArgs ab = a;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    c0[l] = band * a.h[l] / NB;
+    c1[l] = (band + 1) * a.h[l] / NB;
+    lo[l] = c0[l] - halo < 0 ? 0 : c0[l] - halo;
+    hi[l] = c1[l] + halo > a.h[l] ? a.h[l] : c1[l] + halo;
+    soff[l] = (npx + 15) & ~15;
+    npx = soff[l] + (hi[l] - lo[l]) * a.w[l];
+    ab.start[l] = soff[l] - lo[l] * a.w[l];        // slab pixel of the level's (0, 0): pixel (y, x) sits at start + y W + x for lo <= y < hi
+  }
+  // ---- stage: zero guards + the gaps between levels, DMA the bands (piece = 16 pixels = 1 KiB per wave instruction) ----
+  {
+    const int total16 = ((npx + guard + 15) >> 4);
+    for (int i = threadIdx.x; i < soff[0] * 4; i += blockDim.x) *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);   // front guard (up to the first piece boundary)
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int n = (hi[l] - lo[l]) * a.w[l];
+      const int endpx = soff[l] + n;
+      const int nextpx = l + 1 < L ? ((endpx + 15) & ~15) : (total16 << 4);      // zero [endpx, next level's offset / end of slab)
+      for (int i = endpx * 4 + threadIdx.x; i < nextpx * 4; i += blockDim.x) *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
+      const T* src = (const T*)a.value + (long long)b * a.v_bs + (long long)(a.start[l] + lo[l] * a.w[l]) * a.ldv + m * 32 + (lane & 3) * 8;
+      const int npiece = (n + 15) >> 4;
+      for (int k = wave; k < npiece; k += nwave) {
+        const int pix = k * 16 + (lane >> 2);
+        if (pix < n)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (long long)pix * a.ldv), (lds_ptr_t)(vslab_raw + (soff[l] + k * 16) * MSDA_FWD_PITCH), 16, 0, 0);
+      }
+    }
+  }
+  MsdaPrep<L, P> pp;
+  const unsigned char* vslab_sub = vslab_raw + sub * 16;
+  bool staged = false;
+  // the block's queries: its rows of every level, walked as ONE index space (a wave's 16 queries may straddle two levels)
+  int seg_n[L], seg_q0[L];
+  int nq = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    seg_n[l] = (c1[l] - c0[l]) * a.w[l];
+    seg_q0[l] = a.start[l] + c0[l] * a.w[l];
+    nq += seg_n[l];
+  }
+  {
+    for (int qw = wave * 16; qw < nq; qw += nwave * 16) {
+      const int qi_raw = qw + (lane >> 2);
+      const bool live = qi_raw < nq;
+      const int qi = live ? qi_raw : nq - 1;         // tail lanes shadow the last query: the quad shuffles stay defined
+      int q = seg_q0[0] + qi, rem = qi - seg_n[0];
+#pragma unroll
+      for (int t = 1; t < L; ++t) {
+        if (rem >= 0) q = seg_q0[t] + rem;
+        rem -= seg_n[t];
+      }
+      const int qq = q;
+      const float* row = a.offw + ((long long)b * a.Lq + qq) * a.ldo;
+      const float* refp = a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2;
+      pp.template run<true>(a, row, refp, m, sub, live, lo, hi);
+      unsigned mm = pp.miss;                        // (the gather below shifts the slots down: read the mask first)
+      if (!staged) { __syncthreads(); staged = true; }        // drains the LDS-DMA (vmcnt(0) in front of the barrier)
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      msda_gather_lds<T, L, P>(ab, pp, vslab_sub, acc);
+      // ---- samples that missed the staged rows: from global memory, one per quad and round ----
+      while (__any(mm != 0u)) {
+        // the lowest lane of the quad that still has a miss owns this round
+        const int has = mm != 0u ? 1 : 0;
+        const int h0 = quad_bcast<0>(has), h1 = quad_bcast<1>(has), h2 = quad_bcast<2>(has), h3 = quad_bcast<3>(has);
+        const int owner = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+        const bool quad_has = (h0 | h1 | h2 | h3) != 0;
+        float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+        int id = 0, lev = 0;
+        if (quad_has && sub == owner) {
+          const int j = __ffs((int)mm) - 1;
+          pp.one(a, row, refp, m, sub + 4 * j, c00, c01, c10, c11, id, lev);
+          mm &= mm - 1u;
+        }
+        const int src_lane = (lane & ~3) + owner;
+        c00 = __shfl(c00, src_lane, 64); c01 = __shfl(c01, src_lane, 64); c10 = __shfl(c10, src_lane, 64); c11 = __shfl(c11, src_lane, 64);
+        id = __shfl(id, src_lane, 64); lev = __shfl(lev, src_lane, 64);
+        if (quad_has) {
+          int W = a.w[0], st0 = a.start[0];
+#pragma unroll
+          for (int t = 1; t < L; ++t)
+            if (lev == t) { W = a.w[t]; st0 = a.start[t]; }
+          const T* p00 = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8 + ((long long)st0 + id) * a.ldv;
+          float v[8];
+          if (c00 != 0.f) { load8<T>(p00, v); axpy8<T>(acc, c00, v); }
+          if (c01 != 0.f) { load8<T>(p00 + a.ldv, v); axpy8<T>(acc, c01, v); }
+          if (c10 != 0.f) { load8<T>(p00 + (long long)W * a.ldv, v); axpy8<T>(acc, c10, v); }
+          if (c11 != 0.f) { load8<T>(p00 + (long long)(W + 1) * a.ldv, v); axpy8<T>(acc, c11, v); }
+        }
+      }
+      if (live) Vec8<T>::store((T*)a.out + ((long long)b * a.Lq + q) * (a.M * 32) + m * 32 + sub * 8, acc);
+    }
+  }
+  if (!staged) __syncthreads();
 }
 
 // <dout, value corner> over a lane's 8 channels.  bf16: straight from the packed 16-byte loads with v_dot2c_f32_bf16
@@ -531,7 +706,10 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
 //     softmax backward, and each lane writes its samples' offset / logit gradients and probabilities.
 // The first version (msda_bwd_kernel, still used for fp32 maps, slabs that do not fit and the decoder's dref) gathers the
 // corners from L2 through the texture path and repeats the per-sample arithmetic in all four lanes.
-template <class T, int L, int P>
+// BAND = true: the row-band form of msda_fwd_band_kernel (pyramids whose slab does not fit in LDS; q_per_block = number of bands NB,
+// chunks = halo rows): the block owns the query rows of band k of every level and stages those rows +- halo; a sample with a valid
+// corner outside the staged rows takes its four corner dots from global memory after the LDS pass.
+template <class T, int L, int P, bool BAND = false>
 __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_per_block, int chunks, int guard) {
   static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
   constexpr int LP = L * P, NS = (LP + 3) / 4;
@@ -539,14 +717,53 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-  const int bm = bid / chunks, chunk = bid - bm * chunks;
+  const int nper = BAND ? q_per_block : chunks;       // blocks per (batch, head)
+  const int bm = bid / nper, chunk = bid - bm * nper;
   const int b = bm / a.M, m = bm - b * a.M;
-  unsigned char* vslab = vslab_raw + guard * MSDA_FWD_PITCH;
+  unsigned char* vslab = vslab_raw + (BAND ? 0 : guard * MSDA_FWD_PITCH);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, nwave = blockDim.x >> 6;
-  const int q_begin = chunk * q_per_block;
+  int q_begin = chunk * q_per_block;
   int q_end = q_begin + q_per_block;
   if (q_end > a.Lq) q_end = a.Lq;
-  {
+  // band form: per level own query rows [c0, c1), staged rows [lo, hi), slab offset; ab.start = slab pixel of the level's (0, 0)
+  int lo[L], hi[L], seg_n[L], seg_q0[L];
+  MsdaArgs ab = a;
+  if constexpr (BAND) {
+    const int NB = q_per_block, halo = chunks;
+    int soff[L];
+    int npx = guard;
+    int nq = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int c0 = chunk * a.h[l] / NB, c1 = (chunk + 1) * a.h[l] / NB;
+      lo[l] = c0 - halo < 0 ? 0 : c0 - halo;
+      hi[l] = c1 + halo > a.h[l] ? a.h[l] : c1 + halo;
+      soff[l] = (npx + 15) & ~15;
+      npx = soff[l] + (hi[l] - lo[l]) * a.w[l];
+      ab.start[l] = soff[l] - lo[l] * a.w[l];
+      seg_n[l] = (c1 - c0) * a.w[l];
+      seg_q0[l] = a.start[l] + c0 * a.w[l];
+      nq += seg_n[l];
+    }
+    q_begin = 0;
+    q_end = nq;                                          // the block's queries as one index space (mapped to token rows below)
+    const int total16 = ((npx + guard + 15) >> 4);
+    for (int i = threadIdx.x; i < soff[0] * 4; i += blockDim.x) *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int n = (hi[l] - lo[l]) * a.w[l];
+      const int endpx = soff[l] + n;
+      const int nextpx = l + 1 < L ? ((endpx + 15) & ~15) : (total16 << 4);
+      for (int i = endpx * 4 + threadIdx.x; i < nextpx * 4; i += blockDim.x) *reinterpret_cast<uint4*>(vslab_raw + i * 16) = make_uint4(0, 0, 0, 0);
+      const T* src = (const T*)a.value + (long long)b * a.v_bs + (long long)(a.start[l] + lo[l] * a.w[l]) * a.ldv + m * 32 + (lane & 3) * 8;
+      const int npiece = (n + 15) >> 4;
+      for (int k = wave; k < npiece; k += nwave) {
+        const int pix = k * 16 + (lane >> 2);
+        if (pix < n)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (long long)pix * a.ldv), (lds_ptr_t)(vslab_raw + (soff[l] + k * 16) * MSDA_FWD_PITCH), 16, 0, 0);
+      }
+    }
+  } else {
     const T* src = (const T*)a.value + (long long)b * a.v_bs + m * 32 + (lane & 3) * 8;
     const int npiece = (a.Lv + 15) >> 4;
     for (int k = wave; k < npiece; k += nwave) {
@@ -564,16 +781,28 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
   bool staged = false;
   unsigned gmax_bits = 0;
   for (int qw = q_begin + wave * 16; qw < q_end; qw += nwave * 16) {
-    const int q = qw + (lane >> 2);
-    const bool live = q < q_end;
-    const long long bq = (long long)b * a.Lq + (live ? q : q_end - 1);      // tail lanes shadow the last query
+    const int qi = qw + (lane >> 2);
+    const bool live = qi < q_end;
+    int q = live ? qi : q_end - 1;                                          // tail lanes shadow the last query
+    if constexpr (BAND) {                                                   // band form: index into the block's rows of every level -> token row
+      int rem = q - seg_n[0];
+      q = seg_q0[0] + q;
+#pragma unroll
+      for (int t = 1; t < L; ++t) {
+        if (rem >= 0) q = seg_q0[t] + rem;
+        rem -= seg_n[t];
+      }
+    }
+    const long long bq = (long long)b * a.Lq + q;
     const float* row = a.offw + bq * a.ldo;
     const float* offp = row + m * LP * 2;
     const float* logp = row + a.M * LP * 2 + m * LP;
-    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)(live ? q : q_end - 1) * a.ref_L * 2;
+    const float* refp = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2;
     // ---- this lane's samples ----
     float pr[NS], lx[NS], ly[NS];
     int idx[NS], vmask[NS];          // vmask: bit0 (y0,x0) bit1 (y0,x0+1) bit2 (y0+1,x0) bit3 (y0+1,x0+1) inside the map
+    int idx_g[BAND ? NS : 1];        // band form: y0 * W + x0 of every sample (idx holds a harmless staged pixel for the ones that missed)
+    unsigned miss = 0u;              // band form: bit j = sample sub + 4 j has a valid corner outside the staged rows
     {
       float lg[NS];
       float2 of[NS];
@@ -617,6 +846,18 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
         const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
         vmask[j] = smp < LP ? ((vy0 && vx0) ? 1 : 0) | ((vy0 && vx1) ? 2 : 0) | ((vy1 && vx0) ? 4 : 0) | ((vy1 && vx1) ? 8 : 0) : 0;
         idx[j] = vmask[j] ? y0 * W + x0 : 0;
+        if constexpr (BAND) {
+          int blo = lo[0], bhi = hi[0];
+#pragma unroll
+          for (int t = 1; t < L; ++t)
+            if (l == t) { blo = lo[t]; bhi = hi[t]; }
+          const bool in_band = (!vy0 || (y0 >= blo && y0 < bhi)) && (!vy1 || (y0 + 1 >= blo && y0 + 1 < bhi));
+          idx_g[j] = idx[j];
+          if (!vmask[j] || !in_band) {
+            if (vmask[j] && live) miss |= 1u << j;
+            idx[j] = blo * W;
+          }
+        }
       }
     }
     const uint4 go = live ? *reinterpret_cast<const uint4*>((const T*)a.dout + bq * (a.M * 32) + m * 32 + sub * 8) : make_uint4(0, 0, 0, 0);
@@ -644,10 +885,10 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
           int l = 0;
 #pragma unroll
           for (int t = 1; t < L; ++t) l += smp >= t * P ? 1 : 0;
-          int start = a.start[0], W = a.w[0];
+          int start = ab.start[0], W = a.w[0];           // (ab == a unless BAND: slab pixel of the level's (0, 0))
 #pragma unroll
           for (int t = 1; t < L; ++t)
-            if (l == t) { start = a.start[t]; W = a.w[t]; }
+            if (l == t) { start = ab.start[t]; W = a.w[t]; }
           int id;
           switch (k) {
             case 0: id = quad_bcast<0>(idx_run[0]); break;
@@ -671,6 +912,46 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(MsdaArgs a, int q_pe
       if (j + 1 < NS) {
 #pragma unroll
         for (int i = 0; i + 1 < NS; ++i) { d00[i] = d00[i + 1]; d01[i] = d01[i + 1]; d10[i] = d10[i + 1]; d11[i] = d11[i + 1]; }
+      }
+    }
+    if constexpr (BAND) {
+      // ---- samples that missed the staged rows: their four corner dots from global memory, one per quad and round ----
+      unsigned mm = miss;
+      while (__any(mm != 0u)) {
+        const int has = mm != 0u ? 1 : 0;
+        const int h0 = quad_bcast<0>(has), h1 = quad_bcast<1>(has), h2 = quad_bcast<2>(has), h3 = quad_bcast<3>(has);
+        const int owner = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+        const bool quad_has = (h0 | h1 | h2 | h3) != 0;
+        const bool mine = quad_has && sub == owner;
+        const int jm = mine ? __ffs((int)mm) - 1 : 0;
+        int id = 0, vm = 0;
+#pragma unroll
+        for (int jj = 0; jj < NS; ++jj)
+          if (mine && jj == jm) { id = idx_g[jj]; vm = vmask[jj]; }
+        int lev = 0;
+        {
+          const int smp = sub + 4 * jm;
+#pragma unroll
+          for (int t = 1; t < L; ++t) lev += smp >= t * P ? 1 : 0;
+        }
+        const int src_lane = (lane & ~3) + owner;
+        id = __shfl(id, src_lane, 64); vm = __shfl(vm, src_lane, 64); lev = __shfl(lev, src_lane, 64);
+        int W = a.w[0], st0 = a.start[0];
+#pragma unroll
+        for (int t = 1; t < L; ++t)
+          if (lev == t) { W = a.w[t]; st0 = a.start[t]; }
+        const T* p00 = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8 + ((long long)st0 + id) * a.ldv;
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        const uint4 r00 = (vm & 1) ? *reinterpret_cast<const uint4*>(p00) : z4;
+        const uint4 r01 = (vm & 2) ? *reinterpret_cast<const uint4*>(p00 + a.ldv) : z4;
+        const uint4 r10 = (vm & 4) ? *reinterpret_cast<const uint4*>(p00 + (long long)W * a.ldv) : z4;
+        const uint4 r11 = (vm & 8) ? *reinterpret_cast<const uint4*>(p00 + (long long)(W + 1) * a.ldv) : z4;
+        const float e00 = quad_add(Dot8<T>::dot(go, r00)), e01 = quad_add(Dot8<T>::dot(go, r01));
+        const float e10 = quad_add(Dot8<T>::dot(go, r10)), e11 = quad_add(Dot8<T>::dot(go, r11));
+#pragma unroll
+        for (int jj = 0; jj < NS; ++jj)
+          if (mine && jj == jm) { d00[jj] = e00; d01[jj] = e01; d10[jj] = e10; d11[jj] = e11; }
+        if (mine) mm &= mm - 1u;
       }
     }
     // ---- per-sample gradients of this lane's samples ----
@@ -800,7 +1081,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
 #pragma unroll
   for (int l = 1; l < L; ++l)
     if (lev == l) { H = a.h[l]; W = a.w[l]; lstart = a.start[l]; }
-  for (int i = threadIdx.x; i < npix * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0;
+  int* slab_c = slab + a.g_guard * MSDA_SLAB_PITCH;      // pixel 0 of the block's range; [-guard, npix + guard) is allocated and zeroed
+  for (int i = threadIdx.x; i < (npix + 2 * a.g_guard) * MSDA_SLAB_PITCH; i += blockDim.x) slab[i] = 0;
   const T* gbase = (const T*)a.dout + (long long)b * a.Lq * (a.M * 32) + m * 32;
   float mx = (probe & 1) ? 4.f : 0.f;
   if (a.gmax_n > 0) {        // left by the gradient kernel that has just read all of dout (the scan below costs 12 us of a 60 us kernel)
@@ -854,12 +1136,15 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
         w4.z = (vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix) ? aw * ly * (1.f - lx) : 0.f;
         w4.w = (vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix) ? aw * ly * lx : 0.f;
       }
+      // a sample with a corner in the range has f00 in [-(W + 1), npix): its four cells stay inside the guarded slab, so they are all
+      // added without a test (weight 0 adds 0).  Samples with nothing in the range are marked and skipped with ONE test.
+      const bool hit_any = w4.x != 0.f || w4.y != 0.f || w4.z != 0.f || w4.w != 0.f;
+      if (!hit_any) f00 = (int)0x80000000;
       // a wave whose 2 x QB queries put no sample of this level inside the block's pixel range has nothing to add: skip the
       // dout loads and the sample loop (wave-uniform branch).  Queries are stored row-major per level and sample near their
       // own reference point, so for a level cut into several ranges most waves of a block skip most of their iterations
       // (Lv = 5376: level 0 in 4 ranges, every block walked all 5376 queries' samples to keep a quarter of them).
-      const bool hit = w4.x != 0.f || w4.y != 0.f || w4.z != 0.f || w4.w != 0.f;
-      if (__ballot(hit) == 0ull && !(probe & 64)) continue;
+      if (__ballot(hit_any) == 0ull && !(probe & 64)) continue;
       rec_w[ch] = w4;
       rec_f[ch] = f00;
     }
@@ -872,13 +1157,16 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int src = qq * P + p;
-        const float4 w4 = rec_w[src];          // same address in all 32 lanes: broadcast
-        const int f00 = rec_f[src];
-        int* cell = slab + f00 * MSDA_SLAB_PITCH + ch;
-        if (w4.x != 0.f) atomicAdd(cell, __float2int_rn(gq[qq] * w4.x));
-        if (w4.y != 0.f) atomicAdd(cell + MSDA_SLAB_PITCH, __float2int_rn(gq[qq] * w4.y));
-        if (w4.z != 0.f) atomicAdd(cell + W * MSDA_SLAB_PITCH, __float2int_rn(gq[qq] * w4.z));
-        if (w4.w != 0.f) atomicAdd(cell + (W + 1) * MSDA_SLAB_PITCH, __float2int_rn(gq[qq] * w4.w));
+        const int f00 = rec_f[src];            // same address in all 32 lanes: broadcast
+        if (f00 != (int)0x80000000) {
+          const float4 w4 = rec_w[src];
+          int* cell = slab_c + f00 * MSDA_SLAB_PITCH + ch;
+          const float g = gq[qq];
+          atomicAdd(cell, __float2int_rn(g * w4.x));
+          atomicAdd(cell + MSDA_SLAB_PITCH, __float2int_rn(g * w4.y));
+          atomicAdd(cell + W * MSDA_SLAB_PITCH, __float2int_rn(g * w4.z));
+          atomicAdd(cell + (W + 1) * MSDA_SLAB_PITCH, __float2int_rn(g * w4.w));
+        }
       }
     }
   }
@@ -886,16 +1174,23 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
   T* outp = (T*)a.dvalue_t + ((long long)b * a.Lv + pix0) * (a.M * 32) + m * 32;
   for (int i = threadIdx.x; i < npix * 32; i += blockDim.x) {
     const int pix = i >> 5, c = i & 31;
-    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>((float)slab[pix * MSDA_SLAB_PITCH + c] * inv_scale);
+    outp[(long long)pix * (a.M * 32) + c] = from_f32<T>((float)slab_c[pix * MSDA_SLAB_PITCH + c] * inv_scale);
   }
 }
 
-static const int MSDA_MAX_NPIX = 1024;   // 1024 * 33 * 4 B = 135 168 B slab + 20 480 B of sample records of the 160 KiB LDS
+// pixels of a scatter range: (npix + 2 guard) * 33 * 4 B of slab + 20 480 B of sample records must fit the 160 KiB LDS
+static int msda_max_npix(int guard) { return ((160 * 1024 - 20480) / (MSDA_SLAB_PITCH * 4) - 2 * guard) & ~3; }
 
 // Slab ranges: every level is cut into equal runs of whole rows, at least enough that a run fits in LDS, and more when
-// the grid would otherwise leave CUs idle (a block's work is Lq * P sample steps whatever its range size, so the largest
-// level is the one worth cutting further).  Returns the number of ranges (<= 8) or -1.
+// the grid would otherwise leave CUs idle (the largest level is the one worth cutting further).  Returns the number of ranges
+// (<= 8 unless the developer knob forces more) or -1.
+// Measured (round 3, tools/bench_msda.py): a block's time is ~25 instructions per sample of every wave that has ANY sample in its range
+// (not memory latency, not LDS bandwidth), and the samples of a small level spread over all of its rows: cutting the 16 x 16 / 8 x 8 levels
+// into row ranges multiplies the work instead of dividing it (batch 8, 256x256: 4 ranges 87 us, 9 ranges 124 us for the whole backward call).
+#define MSDA_MAX_RANGES 16
 static int msda_ranges(MsdaArgs& a, int L, int bm) {
+  const int MSDA_MAX_NPIX = msda_max_npix(a.g_guard);
+  if (MSDA_MAX_NPIX < 64) return -1;
   int cuts[4];
   int total = 0;
   for (int l = 0; l < L; ++l) {
@@ -914,7 +1209,15 @@ static int msda_ranges(MsdaArgs& a, int L, int bm) {
     ++cuts[best];
     ++total;
   }
-  if (total > 8) return -1;
+  if (g_tune.msda_scatter_cuts > 0) {                    // developer knob: the same number of cuts for every level
+    total = 0;
+    for (int l = 0; l < L; ++l) {
+      const int need = (a.h[l] * a.w[l] + MSDA_MAX_NPIX - 1) / MSDA_MAX_NPIX;
+      cuts[l] = g_tune.msda_scatter_cuts < need ? need : (g_tune.msda_scatter_cuts > a.h[l] ? a.h[l] : g_tune.msda_scatter_cuts);
+      total += cuts[l];
+    }
+  }
+  if (total > MSDA_MAX_RANGES) return -1;
   int g = 0;
   for (int l = 0; l < L; ++l) {
     const int rows_per = (a.h[l] + cuts[l] - 1) / cuts[l];
@@ -997,6 +1300,48 @@ static int msda_launch_fwd_lds(const MsdaArgs& a, int L, int P, int chunks, int 
 }
 
 template <class T>
+static int msda_launch_fwd_band(const MsdaArgs& a, int L, int P, int NB, int halo, int guard, size_t slab, hipStream_t st) {
+#define MSDA_FWD_BAND_CASE(LL, PP)                                                                                        \
+  if (L == LL && P == PP) {                                                                                             \
+    static bool attr = false;                                                                                           \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_fwd_band_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_fwd_band_kernel<T, LL, PP>), dim3(a.B * a.M * NB), dim3(1024), slab, st, a, NB, halo, guard); \
+    return check_launch("emrt_msda_fwd(band)");                                                                         \
+  }
+  MSDA_FWD_BAND_CASE(3, 6)
+  MSDA_FWD_BAND_CASE(4, 4)
+  MSDA_FWD_BAND_CASE(3, 4)
+#undef MSDA_FWD_BAND_CASE
+  return fail("emrt_msda_fwd", "unsupported (levels, points) for the band kernel");
+}
+
+// Band plan for a pyramid whose whole slab does not fit: the number of bands NB (every level's height divisible by it) and the halo
+// (rows staged beyond a band on both sides, the same for every level) with the largest halo <= 7 whose slab fits 159 KB; NB as small as
+// gives about one block per CU.  Returns false when no plan fits (the global-gather kernels take the call).
+static bool msda_band_plan(const MsdaArgs& a, int L, int bm, int guard, int& NB_out, int& halo_out, size_t& slab_out) {
+  for (int NB = 2; NB <= 64; NB *= 2) {
+    bool div = true;
+    for (int l = 0; l < L; ++l) div = div && a.h[l] % NB == 0;
+    if (!div) break;
+    if ((long long)NB * bm < 192 && NB * 2 <= 64) {        // too few blocks: try more bands first (if the heights allow)
+      bool div2 = true;
+      for (int l = 0; l < L; ++l) div2 = div2 && a.h[l] % (NB * 2) == 0;
+      if (div2) continue;
+    }
+    for (int halo = g_tune.msda_band_halo > 0 ? g_tune.msda_band_halo : 7; halo >= 3; --halo) {
+      int npx = guard;
+      for (int l = 0; l < L; ++l) {
+        const int rows = a.h[l] / NB + 2 * halo < a.h[l] ? a.h[l] / NB + 2 * halo : a.h[l];
+        npx = ((npx + 15) & ~15) + rows * a.w[l];
+      }
+      const size_t slab = (size_t)(((npx + guard + 15) >> 4) << 4) * MSDA_FWD_PITCH;
+      if (slab <= 159 * 1024) { NB_out = NB; halo_out = halo; slab_out = slab; return true; }
+    }
+  }
+  return false;
+}
+
+template <class T>
 static int msda_launch_bwd_grad_lds(const MsdaArgs& a, int L, int P, int chunks, int qpb, int guard, size_t slab, hipStream_t st) {
 #define MSDA_BWD_GLDS_CASE(LL, PP)                                                                                        \
   if (L == LL && P == PP) {                                                                                             \
@@ -1011,6 +1356,22 @@ static int msda_launch_bwd_grad_lds(const MsdaArgs& a, int L, int P, int chunks,
   MSDA_BWD_GLDS_CASE(1, 4)
 #undef MSDA_BWD_GLDS_CASE
   return fail("emrt_msda_bwd", "unsupported (levels, points)");
+}
+
+template <class T>
+static int msda_launch_bwd_grad_band(const MsdaArgs& a, int L, int P, int NB, int halo, int guard, size_t slab, hipStream_t st) {
+#define MSDA_BWD_BAND_CASE(LL, PP)                                                                                        \
+  if (L == LL && P == PP) {                                                                                             \
+    static bool attr = false;                                                                                           \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_lds_kernel<T, LL, PP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_bwd_lds_kernel<T, LL, PP, true>), dim3(a.B * a.M * NB), dim3(1024), slab, st, a, NB, halo, guard); \
+    return check_launch("emrt_msda_bwd(band gradients)");                                                               \
+  }
+  MSDA_BWD_BAND_CASE(3, 6)
+  MSDA_BWD_BAND_CASE(4, 4)
+  MSDA_BWD_BAND_CASE(3, 4)
+#undef MSDA_BWD_BAND_CASE
+  return fail("emrt_msda_bwd", "unsupported (levels, points) for the band kernel");
 }
 
 template <class T>
@@ -1075,6 +1436,14 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
     chunks = (Lq + qpb - 1) / qpb;
     return dtype == EMRT_BF16 ? msda_launch_fwd_lds<bf16_t>(a, L, P, chunks, qpb, guard, slab, st) : msda_launch_fwd_lds<f16_t>(a, L, P, chunks, qpb, guard, slab, st);
   }
+  if (dtype != EMRT_F32 && slab > 159 * 1024 && Lq == Lv && L >= 2 && (long long)B * M * Lq >= g_tune.msda_lds_min_pairs &&
+      !g_tune.msda_fwd_global) {
+    // self-attention over a pyramid too large for one slab: row bands (msda_fwd_band_kernel)
+    int NB = 0, halo = 0;
+    size_t bslab = 0;
+    if (msda_band_plan(a, L, B * M, guard, NB, halo, bslab))
+      return dtype == EMRT_BF16 ? msda_launch_fwd_band<bf16_t>(a, L, P, NB, halo, guard, bslab, st) : msda_launch_fwd_band<f16_t>(a, L, P, NB, halo, guard, bslab, st);
+  }
   if (dtype == EMRT_F16) return msda_launch_fwd<f16_t>(a, L, P, st);
   return dtype == EMRT_F32 ? msda_launch_fwd<float>(a, L, P, st) : msda_launch_fwd<bf16_t>(a, L, P, st);
 }
@@ -1103,15 +1472,17 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     EMRT_REQUIRE(workspace, "LDS scatter path needs the probability workspace");
     a.probs = (float*)workspace;
     a.dvalue_t = dvalue;
+    int wmax = 1;
+    for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
+    const int guard = wmax + 2;
+    a.g_guard = guard;
     const int ng = msda_ranges(a, L, B * M);
     EMRT_REQUIRE(ng > 0, "value map rows too long for the LDS slab");
     int npix_max = 0;
     for (int g = 0; g < ng; ++g) npix_max = a.g_npix[g] > npix_max ? a.g_npix[g] : npix_max;
     // offset / logit gradients: from the LDS-staged slab when it fits (same conditions and launch shape as the forward)
-    int wmax = 1;
-    for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
-    const int guard = wmax + 2;
     const size_t slab = (size_t)(Lv + 2 * guard) * MSDA_FWD_PITCH;
+    size_t bslab = 0;
     int rc;
     if (dtype == EMRT_BF16 && (!dref || g_tune.msda_bwd_dref_lds) && slab <= 159 * 1024 && (long long)B * M * Lq >= g_tune.msda_lds_min_pairs && !g_tune.msda_bwd_global) {
       int chunks = (256 + B * M / 2) / (B * M);
@@ -1122,6 +1493,12 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
       a.gmax = (float*)workspace + (size_t)B * Lq * M * L * P;
       a.gmax_n = chunks;
       rc = msda_launch_bwd_grad_lds<bf16_t>(a, L, P, chunks, qpb, guard, slab, st);
+    } else if (int NB = 0, halo = 0; dtype == EMRT_BF16 && !dref && slab > 159 * 1024 && Lq == Lv && L >= 2 && !g_tune.msda_bwd_global &&
+               (long long)B * M * Lq >= g_tune.msda_lds_min_pairs && msda_band_plan(a, L, B * M, guard, NB, halo, bslab)) {
+      // self-attention over a pyramid too large for one slab: row bands (msda_bwd_lds_kernel<BAND>), leaves max |dout| per block too
+      a.gmax = (float*)workspace + (size_t)B * Lq * M * L * P;
+      a.gmax_n = NB;
+      rc = msda_launch_bwd_grad_band<bf16_t>(a, L, P, NB, halo, guard, bslab, st);
     } else {
       rc = dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 2, st) : msda_launch<bf16_t>(a, L, P, 2, st);
       if (!rc && Lq >= 1024 && M <= 8 && 256 % (M * 4) == 0) {      // long scans only: the extra launch costs ~3 us
@@ -1132,7 +1509,7 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
       }
     }
     if (rc) return rc;
-    a.g_npix_max = (npix_max + 3) & ~3;          // keeps the records 16-byte aligned
+    a.g_npix_max = (npix_max + 2 * guard + 3) & ~3;          // slab + both guard bands; keeps the records 16-byte aligned
     const size_t lds = (size_t)a.g_npix_max * MSDA_SLAB_PITCH * sizeof(int) + 32 * 32 * (sizeof(float4) + sizeof(int));
     return dtype == EMRT_F32 ? msda_launch_lds<float>(a, L, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, L, P, ng, lds, st);
   }

@@ -32,7 +32,12 @@ MSDA_BENCH = [
     dict(name="cfg2-encoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=None, lds=True),
     dict(name="cfg2-decoder", B=8, shapes=[(32, 32), (16, 16), (8, 8)], Lq=110, lds=True),     # B*M*Lq = 7040 >= 2048: LDS kernel too (forward)
     dict(name="tiny-decoder", B=1, shapes=[(32, 32), (16, 16), (8, 8)], Lq=110, lds=False),    # B*M*Lq = 880: global kernel
-    dict(name="cfg3-encoder", B=4, shapes=[(64, 64), (32, 32), (16, 16)], Lq=None, lds=False),   # slab 430 KB: global kernel
+    # slab 344 KB > LDS: the ROW-BAND kernel (msda_fwd_band_kernel: 8 bands x (22 of 64 + 18 of 32 + 16 of 16 rows) staged per block)
+    dict(name="cfg3-encoder", B=4, shapes=[(64, 64), (32, 32), (16, 16)], Lq=None, lds=False, band=True),
+    # the same with offsets far beyond the staged halo (sigma 12 px): most level-0 / level-1 samples miss the band -> global fallback
+    dict(name="cfg3-encoder-wild", B=4, shapes=[(64, 64), (32, 32), (16, 16)], Lq=None, lds=False, band=True, sigma=12.0),
+    # non-square pyramid (16 bands; widths that are not multiples of the 16-pixel DMA piece)
+    dict(name="band-nonsquare", B=2, shapes=[(64, 80), (32, 40), (16, 20)], Lq=None, lds=False, band=True),
 ]
 
 
@@ -46,7 +51,7 @@ def _msda_inputs(cfg, seed):
     tp = M * L * Pn
     value = rnd(torch.randn(B, Lv, M * 32, generator=g))
     # offsets of a few pixels (the trained regime: |off| <~ 6 px in the level's own units) and O(1) logits
-    offw = torch.cat([torch.randn(B, Lq, 2 * tp, generator=g) * 2.5, torch.randn(B, Lq, tp, generator=g)], -1)
+    offw = torch.cat([torch.randn(B, Lq, 2 * tp, generator=g) * cfg.get("sigma", 2.5), torch.randn(B, Lq, tp, generator=g)], -1)
     if cfg["Lq"] is None:      # encoder: pixel-centre reference points, shared by the batch, one per level (identical)
         from emrt_amd.src.models.emrt import encoder_reference_points
         ref = encoder_reference_points(shapes)
@@ -84,7 +89,15 @@ def test_msda_bench_shape_bf16_vs_oracle(cfg):
         y_glob = Fn.msda(vd, od, rd, shapes, M, Pn)
     finally:
         L_.set_tuning("msda_fwd_global", old)
-    assert torch.equal(y_glob, y), "LDS-staged and global MSDA forward differ: max |diff| %.3g" % (y_glob.float() - y.float()).abs().max().item()
+    if cfg.get("band"):
+        # the band kernel adds the samples that missed its staged rows LAST (from global memory): same terms, other order for those
+        # pairs only -- a last-bit fp32 difference can flip the bf16 rounding of an output (1 ulp = 2^-8 relative)
+        diff = (y_glob.float() - y.float()).abs()
+        frac = (diff > 0).float().mean().item()
+        print("msda %s: band vs global kernel: %.4f %% of the outputs differ, max |diff| %.3g" % (cfg["name"], 100 * frac, diff.max().item()))
+        assert frac < (0.2 if cfg.get("sigma") else 0.01) and diff.max().item() <= 2.0 ** -6 * max(1.0, y.float().abs().max().item())
+    else:
+        assert torch.equal(y_glob, y), "LDS-staged and global MSDA forward differ: max |diff| %.3g" % (y_glob.float() - y.float()).abs().max().item()
     dv, do = run_bwd(tape, [(y, dev(dy))], [vd, od])
     gv, go = vr.grad, orq.grad
     rel_v = ((host(dv) - gv).norm() / gv.norm()).item()

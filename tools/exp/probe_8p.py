@@ -24,7 +24,9 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for (N, H, W, C, OC, k) in [(8, 128, 128, 256, 256, 3), (8, 128, 128, 512, 256, 3), (8, 64, 64, 256, 256, 3), (8, 32, 32, 1536, 1536, 1)]:
+SHAPES = [(8, 128, 128, 256, 256, 3), (8, 128, 128, 512, 256, 3), (8, 64, 64, 256, 256, 3), (8, 32, 32, 1536, 1536, 1),
+          (8, 128, 128, 64, 256, 1), (8, 128, 128, 128, 256, 1), (8, 64, 64, 64, 256, 1)]      # last three: 1-2 k-tiles = the kernel's fixed cost
+for (N, H, W, C, OC, k) in SHAPES:
     pad = k // 2
     x = torch.randn(N, H, W, C, device=dev).bfloat16()
     wf = (torch.randn(OC, k, k, C, device=dev) / (k * k * C) ** 0.5).bfloat16()
@@ -35,7 +37,7 @@ for (N, H, W, C, OC, k) in [(8, 128, 128, 256, 256, 3), (8, 128, 128, 512, 256, 
                            k, k, 1, pad, 0, 0, 0, None, None, 0, 0, 1, None, 1, stream)
     L.set_tuning("conv_tile", 7)
     line = "N%d %dx%dx%d->%d k%d (%d k-tiles, %d blocks):" % (N, H, W, C, OC, k, k * k * C // 64, (N * H * W // 256) * ((OC + 255) // 256))
-    for pr in (0, 1, 2, 4, 3, 6, 7):
+    for pr in (0, 1, 4, 8, 16):
         L.set_tuning("igemm8p_probe", pr)
         line += "  probe %d %.1f us" % (pr, timed(fn=fwd))
     L.set_tuning("igemm8p_probe", 0)
