@@ -49,6 +49,7 @@ struct Tuning {
   int msda_bwd_dref_lds; // 1 (default): the LDS-staged gradient kernel also serves calls that want the reference-point gradient (the
                         // decoder): fp32 atomics into the caller-ZEROED dref; 0 = those calls take the global-gather kernel
   int msda_band_halo;   // band MSDA kernels (pyramids too large for one LDS slab): rows staged beyond a band (0 = 7, fewer if LDS is short)
+  int msda_scatter_qsplit; // value-gradient scatter: -1 = never split a range's queries over several blocks, 0 = automatic, n > 0 = force n
   int msda_scatter_cuts; // value-gradient scatter: row ranges per level (0 = automatic: about two blocks per CU)
   int msda_fwd_chunks;  // LDS-staged MSDA forward: query chunks per (batch, head) slab (0 = automatic)
   int msda_fwd_threads; // ... threads per block (1024)

@@ -9,7 +9,7 @@ using namespace emrt;
 thread_local char emrt::g_err[512] = {0};
 
 extern "C" const char* emrt_last_error(void) { return emrt::g_err; }
-extern "C" int emrt_abi_version(void) { return 3; }
+extern "C" int emrt_abi_version(void) { return 4; }
 
 // ---- tuning knobs: one table, environment read once at load time --------------------------------------------------
 namespace {
@@ -26,7 +26,7 @@ const TuneEntry kTune[] = {
     {"msda_lds_min_pairs", &emrt::Tuning::msda_lds_min_pairs, 2048}, {"msda_bwd_dref_lds", &emrt::Tuning::msda_bwd_dref_lds, 1},
     {"gn_group_blocks", &emrt::Tuning::gn_group_blocks, 0}, {"gn_stat_rows", &emrt::Tuning::gn_stat_rows, 32},
     {"gn_bwd_stat_rows", &emrt::Tuning::gn_bwd_stat_rows, 32}, {"gn_apply_rows", &emrt::Tuning::gn_apply_rows, 8},
-    {"msda_scatter_cuts", &emrt::Tuning::msda_scatter_cuts, 0}, {"msda_band_halo", &emrt::Tuning::msda_band_halo, 0},
+    {"msda_scatter_cuts", &emrt::Tuning::msda_scatter_cuts, 0}, {"msda_scatter_qsplit", &emrt::Tuning::msda_scatter_qsplit, 0}, {"msda_band_halo", &emrt::Tuning::msda_band_halo, 0},
     {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160},
 };
 emrt::Tuning tuning_from_env() {

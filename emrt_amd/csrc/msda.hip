@@ -42,6 +42,11 @@ struct MsdaArgs {
   int Lv;
   int g_level[16], g_pix0[16], g_npix[16];   // scatter blocks: (level, first flat pixel, pixel count) of each LDS slab range
   int g_npix_max;                         // largest g_npix (+ the two guard bands): the per-half-wave sample records sit behind a slab of that size
+  int g_qs[16], g_nqs[16];                // query split of a scatter block: it walks the query groups qs, qs + nqs, ... (nqs = 1: all of them)
+  int g_part[16];                         // nqs > 1: offset (ints) of the block's partial slab inside its (batch, head) stretch of `part`
+  int* part;                              // int32 partial slabs of the query-split blocks, [B * M][part_stride]
+  long long part_stride;
+  int f_n, f_pix0[8], f_npix[8], f_nqs[8], f_part[8];      // the ranges that were split: summed and written by msda_bwd_value_finalize_kernel
   int g_guard;                            // zero guard pixels on both sides of a scatter slab (widest level + 2): corners whose weight is 0 are
                                           // still ADDED (branch-free inner loop) and may fall up to W + 1 pixels outside the block's range
   float* gmax;        // [B*M][gmax_n] per-block max |dout| of a (batch, head) slice, left by the LDS gradient kernel for the scatter
@@ -1113,7 +1118,8 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
   // this replaces three cross-lane shuffles plus the per-lane floor / weight / validity arithmetic of every step
   float4* rec_w = reinterpret_cast<float4*>(slab + a.g_npix_max * MSDA_SLAB_PITCH) + half * 32;
   int* rec_f = reinterpret_cast<int*>(reinterpret_cast<float4*>(slab + a.g_npix_max * MSDA_SLAB_PITCH) + nhalf * 32) + half * 32;
-  for (int q0 = half * QB; q0 < ((probe & 2) ? 0 : a.Lq); q0 += nhalf * QB) {
+  const int qs = a.g_qs[blockIdx.y], nqs = a.g_nqs[blockIdx.y];
+  for (int q0 = (qs * nhalf + half) * QB; q0 < ((probe & 2) ? 0 : a.Lq); q0 += nqs * nhalf * QB) {
     {
       float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
       int f00 = 0;
@@ -1171,10 +1177,50 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
     }
   }
   __syncthreads();
+  if (nqs > 1) {      // one of several blocks that share this range: leave the integer sums, the finalize kernel adds them up
+    int* outi = a.part + (long long)blockIdx.x * a.part_stride + a.g_part[blockIdx.y];
+    for (int i = threadIdx.x; i < npix * 32; i += blockDim.x) outi[i] = slab_c[(i >> 5) * MSDA_SLAB_PITCH + (i & 31)];
+    return;
+  }
   T* outp = (T*)a.dvalue_t + ((long long)b * a.Lv + pix0) * (a.M * 32) + m * 32;
   for (int i = threadIdx.x; i < npix * 32; i += blockDim.x) {
     const int pix = i >> 5, c = i & 31;
     outp[(long long)pix * (a.M * 32) + c] = from_f32<T>((float)slab_c[pix * MSDA_SLAB_PITCH + c] * inv_scale);
+  }
+}
+
+// Ranges whose queries were split over several scatter blocks (the small levels of a large pyramid: every query hits them, so one
+// block per range is the kernel's critical path): sum the blocks' integer slabs, undo the fixed-point scale, write the compute dtype.
+// Same scale as the scatter blocks used: it only depends on max |dout| of the (batch, head) slice.
+template <class T>
+__global__ __launch_bounds__(256) void msda_bwd_value_finalize_kernel(MsdaArgs a) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
+  const int r = blockIdx.y;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < a.gmax_n; i += blockDim.x) mx = fmaxf(mx, a.gmax[(long long)blockIdx.x * a.gmax_n + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const bool usable = mx > 0.f && mx < 3.0e38f;
+  const float inv_scale = usable ? ((float)a.Lq * mx) * (1.f / 1073741824.f) : 0.f;
+  const int npix = a.f_npix[r], nq = a.f_nqs[r];
+  const int* src = a.part + (long long)blockIdx.x * a.part_stride + a.f_part[r];
+  T* outp = (T*)a.dvalue_t + ((long long)b * a.Lv + a.f_pix0[r]) * (a.M * 32) + m * 32;
+  // blockIdx.z cuts the range's cells into chunks (a lone block per range ran 43 us on dependent loads); a thread sums 4 consecutive
+  // channels of a pixel over the nq <= 8 slabs with 16-byte loads, all slabs' loads issued before the first add
+  const int ncell4 = npix * 8;
+  for (int i = blockIdx.z * blockDim.x + threadIdx.x; i < ncell4; i += gridDim.z * blockDim.x) {
+    int4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < nq ? *reinterpret_cast<const int4*>(src + (long long)k * npix * 32 + i * 4) : make_int4(0, 0, 0, 0);
+    int4 acc = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }      // (integer: exact, order-independent)
+    const float o[4] = {(float)acc.x * inv_scale, (float)acc.y * inv_scale, (float)acc.z * inv_scale, (float)acc.w * inv_scale};
+    Vec4<T>::store(outp + (long long)(i >> 3) * (a.M * 32) + (i & 7) * 4, o);
   }
 }
 
@@ -1188,7 +1234,7 @@ static int msda_max_npix(int guard) { return ((160 * 1024 - 20480) / (MSDA_SLAB_
 // (not memory latency, not LDS bandwidth), and the samples of a small level spread over all of its rows: cutting the 16 x 16 / 8 x 8 levels
 // into row ranges multiplies the work instead of dividing it (batch 8, 256x256: 4 ranges 87 us, 9 ranges 124 us for the whole backward call).
 #define MSDA_MAX_RANGES 16
-static int msda_ranges(MsdaArgs& a, int L, int bm) {
+static int msda_ranges(MsdaArgs& a, int L, int bm, bool allow_split) {
   const int MSDA_MAX_NPIX = msda_max_npix(a.g_guard);
   if (MSDA_MAX_NPIX < 64) return -1;
   int cuts[4];
@@ -1218,15 +1264,58 @@ static int msda_ranges(MsdaArgs& a, int L, int bm) {
     }
   }
   if (total > MSDA_MAX_RANGES) return -1;
+  // Query split.  A block's time is the number of LDS atomics it issues (7 cycles per wave instruction, measured), i.e. the number of
+  // samples that land in its range; every level receives the same number of samples, so a range of a level with c cuts carries 1 / c of
+  // a level's samples: at Lv = 5376 the block that owns the whole 16 x 16 level carries 5x what a level-0 block does and IS the kernel
+  // (216 of 216 us).  Ranges are therefore also split by QUERIES (nqs blocks, each walking every nqs-th group of queries into its own
+  // slab; msda_bwd_value_finalize_kernel adds the slabs) until every block carries about what the finest-cut level's blocks do -- if
+  // the estimate (rounds of 256 blocks x heaviest block) improves by 20 % or more; needs the per-(batch, head) max |dout| partials.
+  int nqs[4];
+  for (int l = 0; l < L; ++l) nqs[l] = 1;
+  a.f_n = 0;
+  a.part_stride = 0;
+  if (allow_split && g_tune.msda_scatter_qsplit >= 0) {
+    int cmax = 1;
+    for (int l = 0; l < L; ++l) cmax = cuts[l] > cmax ? cuts[l] : cmax;
+    int entries = 0, cand[4];
+    double heavy = 0.0;
+    for (int l = 0; l < L; ++l) {
+      cand[l] = (cmax + cuts[l] - 1) / cuts[l];
+      if (cand[l] > 8) cand[l] = 8;
+      if (g_tune.msda_scatter_qsplit > 0) cand[l] = cuts[l] < cmax ? g_tune.msda_scatter_qsplit : 1;
+      entries += cuts[l] * cand[l];
+      const double w = 1.0 / (cuts[l] * cand[l]);
+      heavy = w > heavy ? w : heavy;
+    }
+    const double rounds_new = (double)(((long long)entries * bm + 255) / 256), rounds_old = (double)(((long long)total * bm + 255) / 256);
+    int cmin = cuts[0];
+    for (int l = 1; l < L; ++l) cmin = cuts[l] < cmin ? cuts[l] : cmin;
+    if (entries <= MSDA_MAX_RANGES && (rounds_new * heavy < 0.8 * rounds_old / cmin || g_tune.msda_scatter_qsplit > 0))
+      for (int l = 0; l < L; ++l) nqs[l] = cand[l];
+  }
   int g = 0;
   for (int l = 0; l < L; ++l) {
     const int rows_per = (a.h[l] + cuts[l] - 1) / cuts[l];
     for (int r0 = 0; r0 < a.h[l]; r0 += rows_per) {
       const int rows = a.h[l] - r0 < rows_per ? a.h[l] - r0 : rows_per;
-      a.g_level[g] = l;
-      a.g_pix0[g] = a.start[l] + r0 * a.w[l];
-      a.g_npix[g] = rows * a.w[l];
-      ++g;
+      if (nqs[l] > 1) {
+        if (a.f_n >= 8) return -1;
+        a.f_pix0[a.f_n] = a.start[l] + r0 * a.w[l];
+        a.f_npix[a.f_n] = rows * a.w[l];
+        a.f_nqs[a.f_n] = nqs[l];
+        a.f_part[a.f_n] = (int)a.part_stride;
+        ++a.f_n;
+      }
+      for (int k = 0; k < nqs[l]; ++k) {
+        a.g_level[g] = l;
+        a.g_pix0[g] = a.start[l] + r0 * a.w[l];
+        a.g_npix[g] = rows * a.w[l];
+        a.g_qs[g] = k;
+        a.g_nqs[g] = nqs[l];
+        a.g_part[g] = (int)a.part_stride;
+        if (nqs[l] > 1) a.part_stride += (long long)rows * a.w[l] * 32;
+        ++g;
+      }
     }
   }
   return g;
@@ -1237,10 +1326,35 @@ extern "C" int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L) {
   return (L >= 1 && L <= 4) ? 1 : 0;     // pixel-range slabs fit for every map size
 }
 
-extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P) {
+static int msda_fill(MsdaArgs& a, const int* shapes_hw, int L, int Lv);
+// Whether the query-split scatter may be planned for a call: it needs the max |dout| partials some gradient kernel leaves (every
+// path with Lq >= 1024 or the LDS / band gradient kernels does) -- decided from the same quantities in both functions below.
+static bool msda_split_allowed(int B, int Lq, int M, int dtype_is_2byte) {
+  (void)B;
+  return dtype_is_2byte && Lq >= 1024 && M <= 8 && 256 % (M * 4) == 0;
+}
+
+static size_t msda_part_offset_floats(int B, int Lq, int M, int L, int P) {      // where the partial slabs start inside the workspace
+  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M + (size_t)B * M * ((Lq + 63) / 64) + 3) & ~(size_t)3;      // 16-byte aligned
+}
+
+extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P, const int* shapes_hw, int dtype) {
   // softmax probabilities + per-block max |dout| partials (the LDS gradient kernel leaves at most 256 / (B M) + 1 per (batch, head), the
-  // separate scan Lq / 64)
-  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M + (size_t)B * M * ((Lq + 63) / 64)) * sizeof(float);
+  // separate scan Lq / 64) + the integer partial slabs of a query-split scatter (the plan emrt_msda_bwd will make for these shapes)
+  size_t n = msda_part_offset_floats(B, Lq, M, L, P);
+  if (shapes_hw && L >= 1 && L <= 4) {
+    MsdaArgs a;
+    memset(&a, 0, sizeof(a));
+    int Lv = 0;
+    for (int l = 0; l < L; ++l) Lv += shapes_hw[2 * l] * shapes_hw[2 * l + 1];
+    if (msda_fill(a, shapes_hw, L, Lv) == 0) {
+      int wmax = 1;
+      for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
+      a.g_guard = wmax + 2;
+      if (msda_ranges(a, L, B * M, msda_split_allowed(B, Lq, M, dtype != EMRT_F32)) > 0) n += (size_t)B * M * (size_t)a.part_stride;
+    }
+  }
+  return n * sizeof(float);
 }
 
 template <class T>
@@ -1476,8 +1590,9 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     for (int l = 0; l < L; ++l) wmax = a.w[l] > wmax ? a.w[l] : wmax;
     const int guard = wmax + 2;
     a.g_guard = guard;
-    const int ng = msda_ranges(a, L, B * M);
+    const int ng = msda_ranges(a, L, B * M, msda_split_allowed(B, Lq, M, dtype != EMRT_F32));
     EMRT_REQUIRE(ng > 0, "value map rows too long for the LDS slab");
+    a.part = (int*)((float*)workspace + msda_part_offset_floats(B, Lq, M, L, P));
     int npix_max = 0;
     for (int g = 0; g < ng; ++g) npix_max = a.g_npix[g] > npix_max ? a.g_npix[g] : npix_max;
     // offset / logit gradients: from the LDS-staged slab when it fits (same conditions and launch shape as the forward)
@@ -1511,7 +1626,11 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     if (rc) return rc;
     a.g_npix_max = (npix_max + 2 * guard + 3) & ~3;          // slab + both guard bands; keeps the records 16-byte aligned
     const size_t lds = (size_t)a.g_npix_max * MSDA_SLAB_PITCH * sizeof(int) + 32 * 32 * (sizeof(float4) + sizeof(int));
-    return dtype == EMRT_F32 ? msda_launch_lds<float>(a, L, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, L, P, ng, lds, st);
+    EMRT_REQUIRE(a.f_n == 0 || a.gmax_n > 0, "internal: query-split scatter planned without the max |dout| partials");
+    rc = dtype == EMRT_F32 ? msda_launch_lds<float>(a, L, P, ng, lds, st) : msda_launch_lds<bf16_t>(a, L, P, ng, lds, st);
+    if (rc || a.f_n == 0) return rc;
+    hipLaunchKernelGGL((msda_bwd_value_finalize_kernel<bf16_t>), dim3(B * M, a.f_n, 8), dim3(256), 0, st, a);
+    return check_launch("emrt_msda_bwd(scatter finalize)");
   }
   a.dvalue = (float*)dvalue;
   return dtype == EMRT_F32 ? msda_launch<float>(a, L, P, 1, st) : msda_launch<bf16_t>(a, L, P, 1, st);

@@ -844,7 +844,7 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
             dref = c.zeros((B, Lq, ref_L, 2), torch.float32) if need_dref else None      # zeroed: the LDS gradient kernel accumulates into it
             if use_lds:
                 dvalue = c.empty((B, Lv, CC))          # compute dtype, fully overwritten by the LDS scatter
-                ws = c.empty((_L().query("emrt_msda_bwd_workspace_bytes", B, Lq, M, L, Pn) // 4,), torch.float32)
+                ws = c.empty((_L().query("emrt_msda_bwd_workspace_bytes", B, Lq, M, L, Pn, ctypes.cast(arr, ctypes.c_void_p), c.dtype) // 4,), torch.float32)
             else:
                 dvalue = c.zeros((B, Lv, CC), torch.float32)
                 ws = None

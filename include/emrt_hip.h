@@ -126,9 +126,12 @@ int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw,
  * LDS-staged gradient kernel adds the heads' contributions with atomics; the global-gather kernel overwrites it).  dvalue: when
  * emrt_msda_bwd_uses_lds(shapes_hw, L) == 1 (every level group's fp32 slab fits in LDS) it is [B][Lv][M*D] in the
  * compute dtype, fully overwritten by an LDS-privatised scatter (needs `workspace` of emrt_msda_bwd_workspace_bytes);
- * otherwise it is fp32, must be zeroed by the caller and is accumulated with global atomics. */
+ * otherwise it is fp32, must be zeroed by the caller and is accumulated with global atomics.
+ * emrt_msda_bwd_workspace_bytes (ABI 4: takes the level shapes and the dtype of the call it sizes): softmax probabilities, the
+ * per-block max |dout| partials and -- for large pyramids, where the small levels' scatter blocks are split by queries -- the
+ * integer partial slabs; it makes the same plan emrt_msda_bwd will make for these arguments. */
 int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L);
-size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P);
+size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P, const int* shapes_hw, int dtype);
 int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream);
 
 /* ---- fused softmax(QK^T/sqrt(d)) V with dropout on the weights: EMRT_utils/layers.py:283-303 (L <= 128, D = 32) */

@@ -49,9 +49,21 @@ def test_loader_binds_all_entry_points(built):
     from emrt_amd import _lib
     _lib._LIB = None
     L = _lib.lib()
-    assert L.query("emrt_abi_version") == 3
+    assert L.query("emrt_abi_version") == 4
     assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
-    assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6) == (2 * 10 * 8 * 18 + 512 + 2 * 2 * 8 + 2 * 8 * 1) * 4     # probabilities + per-block max |dout| partials
+    import ctypes
+    small = (ctypes.c_int * 6)(2, 2, 2, 2, 1, 2)                   # Lv = 10
+    base = lambda B, Lq, M: ((B * Lq * M * 18 + 512 + 2 * B * M + B * M * ((Lq + 63) // 64) + 3) // 4 * 4) * 4     # probabilities + max |dout| partials
+    assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6, ctypes.cast(small, ctypes.c_void_p), 1) == base(2, 10, 8)
+    # batch 8 at 256x256 (Lv = 1344): no range of the value-gradient scatter is split by queries -> no partial slabs
+    cfg2 = (ctypes.c_int * 6)(32, 32, 16, 16, 8, 8)
+    assert L.query("emrt_msda_bwd_workspace_bytes", 8, 1344, 8, 3, 6, ctypes.cast(cfg2, ctypes.c_void_p), 1) == base(8, 1344, 8)
+    # batch 4 at 512x512 (Lv = 5376), bf16: level 1 (2 ranges x 3 query splits) and level 2 (5 splits) leave int32 partial slabs;
+    # the fp32 path never splits
+    cfg3 = (ctypes.c_int * 6)(64, 64, 32, 32, 16, 16)
+    part = 4 * 8 * (2 * 3 * 512 * 32 + 5 * 256 * 32) * 4
+    assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 3, 6, ctypes.cast(cfg3, ctypes.c_void_p), 1) == base(4, 5376, 8) + part
+    assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 3, 6, ctypes.cast(cfg3, ctypes.c_void_p), 0) == base(4, 5376, 8)
     assert L.last_error() == "" or isinstance(L.last_error(), str)
 
 
