@@ -86,6 +86,15 @@ def msda_bytes(a, esz):
     return B * (Lv * M * D * esz + Lq * tp * 2 * 4 + Lq * tp * 4 + Lq * M * D * esz) + Lq * 2 * 4
 
 
+def msda_bwd_bytes(a, esz):
+    """Compulsory HBM bytes of one emrt_msda_bwd call (same accounting as SURVEY.md 8(d) uses for the forward): read value, the fp32
+    offsets | logits rows and dout; write dvalue and the offset / logit gradients (compute dtype when the projection's GEMM reads that)."""
+    B, Lq, Lv, M, D, L, P = a[13:20]
+    tp = M * L * P
+    doffw_esz = esz if a[11] else 4
+    return B * (Lv * M * D * esz + Lq * tp * 3 * 4 + Lq * M * D * esz + Lv * M * D * esz + Lq * tp * 3 * doffw_esz)
+
+
 def vals_of(a):
     return [x.value if hasattr(x, "value") else x for x in a]
 
@@ -174,6 +183,18 @@ def rooflines(calls, dtype_name, cfg_key, train):
                          "ideal_us_at_peak": round(ideal_us, 2),
                          "note": "a launch that moves nothing already reads event_timed_trivial_launch_us (roofline) on this clock: at %.1f MB the HBM "
                                  "time is %.1f us, so frac is bounded well below 1 by the launch itself; see DESIGN.md 5 for the per-shape table" % (by / 1e6, ideal_us)}
+        encb = [(vals_of(a), ms) for name, a, ms in calls if name == "emrt_msda_bwd"]
+        encb = [(vb, ms) for vb, ms in encb if vb[14] == vb[15]]     # Lq == Lv: encoder self-attention calls
+        if encb:
+            vb = encb[0][0]
+            byb = msda_bwd_bytes(vb, esz)
+            avg_b = sum(ms for _, ms in encb) / len(encb)
+            roofline_msda["backward"] = {
+                "kernel": "emrt_msda_bwd: gradient kernel + value-gradient scatter (+ finalize), encoder call", "bound": "hbm",
+                "achieved": round(byb / avg_b / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(byb / avg_b / 1e6 / PEAK_HBM_GBPS, 4),
+                "traffic": None, "algorithmic_mbytes_per_call": round(byb / 1e6, 2), "avg_call_us": round(1e3 * avg_b, 2),
+                "note": "two or three launches per call, each event-timed (event_timed_trivial_launch_us each); the scatter is bound by LDS atomics "
+                        "(7 cycles per wave instruction), not by HBM: DESIGN.md 5"}
         if pmc is not None and "msda_fwd_kernel_encoder" in pmc:
             m = pmc["msda_fwd_kernel_encoder"]
             roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)

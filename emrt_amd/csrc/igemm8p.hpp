@@ -48,7 +48,8 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned vo
 }
 
 // PROBE (timing experiments only, -DEMRT_8P_PROBES builds; results are WRONG): 1 = no DMA issue in the loop, 2 = no fragment reads,
-// 4 = no MFMAs, 8 = no global stores / loads in the epilogue, 16 = no epilogue at all.  The production instantiation is PROBE = 0.
+// 4 = no MFMAs, 8 = no global stores / loads in the epilogue, 16 = no epilogue at all (kills most MFMAs too: only valid for the 1-k-tile
+// shapes), 32 = non-temporal output stores.  The production instantiation is PROBE = 0.
 // Measured and not kept (round 3, tools/bench_conv.py big): a second schedule that keeps the b0 fragments in registers through phase 4
 // (20 instead of 24 fragment reads per k-tile), re-stages every unit TWO phases after its last read (ph1: UB1(t+1), ph2: UA1(t+1),
 // ph3: UA0(t+2), ph4: UB0(t+2), vmcnt(4)) and retires the reads AFTER the first barrier: within 1 % of this one on every shape
@@ -80,6 +81,26 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   // linearly (lane l -> row l >> 3, position l & 7 of its piece), so the permutation is applied to the SOURCE chunk.
   const int lrow = lane >> 3;
   const unsigned chunk_b = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);   // byte offset inside the k-tile row
+  // the weight operand first: its addresses need no division, so its first k-tile is in flight while the pixel decomposition below runs
+  unsigned b_off[4];                                   // q = 2 j + u: unit UBu, piece j
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = bn * BN + (wave >> 2) * 64 + (wave & 3) * 8 + 128 * (q >> 1) + 32 * (q & 1) + lrow;
+    b_off[q] = n < p.OC ? (unsigned)((long long)n * K * 2) : BUF_OOB;
+  }
+  int bkt = 0;
+  auto stage_b = [&](int u, int par) {                 // unit UBu of k-tile bkt -> buffer par
+    if constexpr ((PROBE & 1) != 0) { if (bkt >= 2) return; }
+    const unsigned kbad = bkt < nkt ? 0u : BUF_OOB;
+    const unsigned kb = (unsigned)bkt * 128u + chunk_b;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row0 = (wave >> 2) * 64 + (wave & 3) * 8 + 128 * j + 32 * u;
+      lds_dma16(rs_w, (b_off[2 * j + u] | kbad) + kb, (unsigned)par * BUFB + AB + (unsigned)row0 * 128u, smem);
+    }
+  };
+
+  stage_b(0, 0); stage_b(1, 0);                        // prologue, part 1 (k-tile 0 of the weights)
   int a_h[4], a_w[4];
   unsigned a_base[4];
   bool a_ok[4];
@@ -112,18 +133,11 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
     const unsigned off = a_base[i] + (unsigned)((hi * p.W + wi) * p.ldin) * 2u;
     return ok ? off : BUF_OOB;
   };
-  unsigned b_off[4];                                   // q = 2 j + u: unit UBu, piece j
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n = bn * BN + (wave >> 2) * 64 + (wave & 3) * 8 + 128 * (q >> 1) + 32 * (q & 1) + lrow;
-    b_off[q] = n < p.OC ? (unsigned)((long long)n * K * 2) : BUF_OOB;
-  }
   // cursors of the NEXT k-tile to stage, one for the A units and one for the B units (they advance at different phases)
   int akt = 0, a_c0 = 0, a_kh = 0, a_kw = 0;
   unsigned a_cur[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) a_cur[i] = a_pixel(i, 0, 0);
-  int bkt = 0;
   const bool one_tap = p.KH * p.KW == 1;
   auto advance_a = [&]() {
     ++akt;
@@ -148,17 +162,6 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
       lds_dma16(rs_in, (a_cur[i] | kbad) + cb, (unsigned)par * BUFB + (unsigned)(64 * i + 8 * wave) * 128u, smem);
     }
   };
-  auto stage_b = [&](int u, int par) {                 // unit UBu of k-tile bkt -> buffer par
-    if constexpr ((PROBE & 1) != 0) { if (bkt >= 2) return; }
-    const unsigned kbad = bkt < nkt ? 0u : BUF_OOB;
-    const unsigned kb = (unsigned)bkt * 128u + chunk_b;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row0 = (wave >> 2) * 64 + (wave & 3) * 8 + 128 * j + 32 * u;
-      lds_dma16(rs_w, (b_off[2 * j + u] | kbad) + kb, (unsigned)par * BUFB + AB + (unsigned)row0 * 128u, smem);
-    }
-  };
-
   f32x16_t acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   };
 
   // ---- prologue: k-tile 0 whole, then the units of k-tile 1 that the last phases of "tile -1" would have issued ----------------
-  stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+  stage_a(0, 0); stage_a(1, 0);                        // (the weights' half of k-tile 0 was issued above)
   advance_a(); ++bkt;
   stage_a(0, 1); stage_b(1, 1); stage_a(1, 1);        // UB0(1) follows in phase 1 of tile 0 (bkt advances there)
   advance_a();
@@ -252,13 +255,17 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
     if (acc[0][0][0] == 123.456f) ((float*)p.out)[tid] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];      // keeps the accumulators alive
     return;
   }
-  // ---- epilogue: four passes of 64 rows (pass i = M-tile i of both wave rows) through a row-major fp32 LDS tile ----------------
-  // Same arithmetic, order and statistics as igemm_body's row-vectorised epilogue (the host only sends problems that satisfy its
-  // vector conditions): accumulate * scale + bias -> + residual -> ReLU -> mask -> store -> statistics of the stored value.
-  constexpr int CP = BN + 8;
-  float* tile = reinterpret_cast<float*>(smem);
-  const int cg = tid & 31, rr = tid >> 5;              // 8-channel group, row lane (16 rows per step)
-  const int n0 = bn * BN + cg * 8;
+  // ---- epilogue: every wave on its own, through a PRIVATE 32 x 64 fp32 LDS tile, one M-tile (32 rows) at a time ---------------------
+  // The C/D layout of the 32x32 MFMA gives a lane one output COLUMN; rows of 8 consecutive channels per lane (16-byte stores, 128-byte
+  // runs per row) need a transposition, and doing it per wave needs no block barrier: LDS accesses of one wave execute in order, so the
+  // eight waves drift apart and their LDS / store phases overlap (the first version ran four block-wide passes of 64 rows with two
+  // __syncthreads() each: ~7 of the kernel's ~16 us of fixed cost).  Same arithmetic and order per element as igemm_body's row-vectorised
+  // epilogue (the host only sends problems that satisfy its vector conditions): accumulate * scale + bias -> + residual -> ReLU -> mask ->
+  // store -> statistics of the stored value.
+  constexpr int WP = 68;                               // floats per row of the wave tile: 16-byte aligned rows, write side conflict-free
+  float* tile = reinterpret_cast<float*>(smem) + wave * (32 * WP);
+  const int cg = lane & 7, rl = lane >> 3;             // 8-channel group of the wave's 64 columns, row lane (8 rows per step)
+  const int n0 = bn * BN + wc * 64 + cg * 8;
   const bool col_ok = n0 < p.OC;
   float bv[8], sv[8], ss[8], sq[8];
 #pragma unroll
@@ -267,25 +274,27 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   const T* ymask = (const T*)p.mask_y;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (i) __syncthreads();                            // the previous pass's rows are consumed
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        tile[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * CP + wc * 64 + j * 32 + frow] = acc[i][j][r];
-    __syncthreads();
+        tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * WP + j * 32 + frow] = acc[i][j][r];
+    // same wave: the LDS queue executes the reads below behind these writes; the wave barrier (no instruction) only keeps the COMPILER
+    // from moving a lane's reads above other lanes' writes, which it cannot see as a dependence
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
-    for (int tr = rr; tr < 64; tr += 16) {
-      const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)((tr >> 5) * 128 + i * 32 + (tr & 31));
+    for (int st = 0; st < 4; ++st) {
+      const int tr = st * 8 + rl;
+      const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)(wr * 128 + i * 32 + tr);
+      float v[8];
+      {
+        const float4 a = *reinterpret_cast<const float4*>(tile + tr * WP + cg * 8);
+        const float4 b = *reinterpret_cast<const float4*>(tile + tr * WP + cg * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
       if ((long long)m >= M || !col_ok) continue;
       const int e_nb = (int)(m / (unsigned)OHW);
       const int e_pix = (int)(m - (unsigned)e_nb * (unsigned)OHW);
-      float v[8];
-      {
-        const float4 a = *reinterpret_cast<const float4*>(tile + tr * CP + cg * 8);
-        const float4 b = *reinterpret_cast<const float4*>(tile + tr * CP + cg * 8 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sv[e], bv[e]);
       if (resp && !(PROBE & 8)) {
@@ -310,6 +319,12 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
         if (v[0] == 123.456f) Vec8<T>::store((T*)p.out + obase, v);
       } else if (p.out_f32) {
         Vec8<float>::store((float*)p.out + obase, v);
+      } else if constexpr ((PROBE & 32) != 0 && std::is_same<T, bf16_t>::value) {      // experiment: non-temporal output stores
+        typedef __attribute__((ext_vector_type(4))) unsigned int nt_u32x4;
+        nt_u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        __builtin_nontemporal_store(pk, reinterpret_cast<nt_u32x4*>((T*)p.out + obase));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = to_f32(from_f32<T>(v[e]));
       } else {
         Vec8<T>::store((T*)p.out + obase, v);
 #pragma unroll
@@ -321,21 +336,28 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
         sq[e] = fmaf(v[e], ymask ? second[e] : v[e], sq[e]);
       }
     }
+    __builtin_amdgcn_wave_barrier();                   // the next M-tile's writes stay behind this tile's reads
   }
-  if (p.stats) {                                       // column sums: [16 row lanes][256] partials per statistic, one atomic per column
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
+  if (p.stats) {
+    // column sums: the 8 row lanes of a column group by shuffles, the two wave rows (wr) through LDS, ONE atomic per column and statistic
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      red[rr * BN + cg * 8 + e] = ss[e];
-      red[(16 + rr) * BN + cg * 8 + e] = sq[e];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { ss[e] += __shfl_xor(ss[e], o, 64); sq[e] += __shfl_xor(sq[e], o, 64); }
+    }
+    __syncthreads();                                   // every wave is done with its private tile
+    float* red = reinterpret_cast<float*>(smem);      // [2 wr][2 statistics][256 columns]
+    if (rl == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wr * 2 + 0) * BN + wc * 64 + cg * 8 + e] = ss[e];
+        red[(wr * 2 + 1) * BN + wc * 64 + cg * 8 + e] = sq[e];
+      }
     }
     __syncthreads();
     const int which = tid >> 8, col = tid & 255;
     const int n = bn * BN + col;
-    float a = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a += red[(which * 16 + q) * BN + col];
+    const float a = red[which * BN + col] + red[(2 + which) * BN + col];
     if (n < p.OC) atomicAdd(p.stats + (long long)(bm & 7) * 2 * p.OC + (long long)which * p.OC + n, (double)a);
   }
 }
@@ -369,6 +391,7 @@ static int launch_igemm8p(const ConvArgs& a, hipStream_t st) {
       case 7: return launch_igemm8p<T, MODE, 7>(a, st);
       case 8: return launch_igemm8p<T, MODE, 8>(a, st);
       case 16: return launch_igemm8p<T, MODE, 16>(a, st);
+      case 32: return launch_igemm8p<T, MODE, 32>(a, st);
       default: break;
     }
   }

@@ -37,7 +37,7 @@ for (N, H, W, C, OC, k) in SHAPES:
                            k, k, 1, pad, 0, 0, 0, None, None, 0, 0, 1, None, 1, stream)
     L.set_tuning("conv_tile", 7)
     line = "N%d %dx%dx%d->%d k%d (%d k-tiles, %d blocks):" % (N, H, W, C, OC, k, k * k * C // 64, (N * H * W // 256) * ((OC + 255) // 256))
-    for pr in (0, 1, 4, 8, 16):
+    for pr in (0, 32, 0, 32, 8):
         L.set_tuning("igemm8p_probe", pr)
         line += "  probe %d %.1f us" % (pr, timed(fn=fwd))
     L.set_tuning("igemm8p_probe", 0)
