@@ -49,7 +49,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned vo
 
 // PROBE (timing experiments only, -DEMRT_8P_PROBES builds; results are WRONG): 1 = no DMA issue in the loop, 2 = no fragment reads,
 // 4 = no MFMAs, 8 = no global stores / loads in the epilogue, 16 = no epilogue at all (kills most MFMAs too: only valid for the 1-k-tile
-// shapes), 32 = non-temporal output stores.  The production instantiation is PROBE = 0.
+// shapes).  The production instantiation is PROBE = 0.
 // Measured and not kept (round 3, tools/bench_conv.py big): a second schedule that keeps the b0 fragments in registers through phase 4
 // (20 instead of 24 fragment reads per k-tile), re-stages every unit TWO phases after its last read (ph1: UB1(t+1), ph2: UA1(t+1),
 // ph3: UA0(t+2), ph4: UB0(t+2), vmcnt(4)) and retires the reads AFTER the first barrier: within 1 % of this one on every shape
@@ -319,14 +319,14 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
         if (v[0] == 123.456f) Vec8<T>::store((T*)p.out + obase, v);
       } else if (p.out_f32) {
         Vec8<float>::store((float*)p.out + obase, v);
-      } else if constexpr ((PROBE & 32) != 0 && std::is_same<T, bf16_t>::value) {      // experiment: non-temporal output stores
-        typedef __attribute__((ext_vector_type(4))) unsigned int nt_u32x4;
-        nt_u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        __builtin_nontemporal_store(pk, reinterpret_cast<nt_u32x4*>((T*)p.out + obase));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = to_f32(from_f32<T>(v[e]));
       } else {
-        Vec8<T>::store((T*)p.out + obase, v);
+        // NON-TEMPORAL: this kernel only runs on outputs of tens of MB (>= 160 blocks x 128 KiB) that every block writes at the same moment;
+        // streaming them past L2 measured -4 % on UpHead conv_2 and -15 % on the kernel's fixed cost (profiles/r3_conv_8phase_probes.txt)
+        typedef __attribute__((ext_vector_type(4))) unsigned int nt_u32x4;
+        nt_u32x4 pk;
+        if constexpr (std::is_same<T, bf16_t>::value) pk = nt_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        else pk = nt_u32x4{pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7])};
+        __builtin_nontemporal_store(pk, reinterpret_cast<nt_u32x4*>((T*)p.out + obase));
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = to_f32(from_f32<T>(v[e]));       // statistics of what the next kernel will read
       }
@@ -391,7 +391,6 @@ static int launch_igemm8p(const ConvArgs& a, hipStream_t st) {
       case 7: return launch_igemm8p<T, MODE, 7>(a, st);
       case 8: return launch_igemm8p<T, MODE, 8>(a, st);
       case 16: return launch_igemm8p<T, MODE, 16>(a, st);
-      case 32: return launch_igemm8p<T, MODE, 32>(a, st);
       default: break;
     }
   }

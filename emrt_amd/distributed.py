@@ -90,14 +90,32 @@ def bucket_slices(n, bucket_elems, start=0):
 
 class FlatGradReducer:
     """Averages the flat gradient buffer over ranks.  `launch()` enqueues async all-reduces (one per bucket) and
-    `wait()` blocks the compute stream on them; with bucket_elems >= n it is a single collective."""
+    `wait()` blocks the compute stream on them; with bucket_elems >= n it is a single collective.
 
-    def __init__(self, flat_grad, n, world_size, bucket_elems=32 * 1024 * 1024, always=False):
+    exchange_dtype="bf16": the slices travel as bf16 (108 MB instead of 216 MB per step over xGMI: BASELINE.md section 2) -- each
+    slice is cast into a bf16 staging buffer by emrt_cast on the training stream, all-reduced (AVG) there, and cast back into the
+    fp32 gradient buffer in wait().  The fp32 master weights, momentum and the clip still see fp32 gradients; what is rounded is each
+    rank's contribution (2^-9 relative) and the ring's partial sums.  Off by default: the reference exchanges fp32
+    (paddle.DataParallel, train.py:116-123); tests/test_distributed_cpu.py and tests/test_gpu_dp2.py bound the difference."""
+
+    def __init__(self, flat_grad, n, world_size, bucket_elems=32 * 1024 * 1024, always=False, exchange_dtype="fp32"):
         self.flat, self.n, self.world = flat_grad, n, world_size
         self.bucket = bucket_elems
         self.slices = bucket_slices(n, bucket_elems)
         self.handles = []
         self.always = always        # issue the collectives even in a 1-rank group (single-GPU test of the N > 1 path)
+        assert exchange_dtype in ("fp32", "bf16")
+        self.exchange_dtype = exchange_dtype
+        self.half = torch.empty(n, dtype=torch.bfloat16, device=flat_grad.device) if exchange_dtype == "bf16" else None
+
+    def _cast(self, src, dst, to_bf16):
+        """fp32 <-> bf16 on the current stream: the HIP cast kernel on a GPU (no torch arithmetic on the product path), torch on CPU tests."""
+        if src.is_cuda:
+            from . import _lib
+            from .runtime import BF16, ctx
+            _lib.lib().call("emrt_cast", src.data_ptr(), dst.data_ptr(), src.numel(), 0 if to_bf16 else 1, BF16, ctx().stream)
+        else:
+            dst.copy_(src)
 
     def launch(self, ranges=None):
         """ranges=None: the whole buffer.  Otherwise a list of [start, end) element ranges (each bucketed); handles
@@ -108,16 +126,23 @@ class FlatGradReducer:
         slices = self.slices if ranges is None else [b for a, e in ranges for b in bucket_slices(e, self.bucket, a)]
         for s, e in slices:
             t = self.flat[s:e]
+            back = None
+            if self.half is not None:
+                back = t
+                t = self.half[s:e]
+                self._cast(back, t, True)
             if use_avg:
-                self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True), None))
+                self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True), None, t, back))
             else:   # gloo has no AVG: sum then scale (CPU tests, single-GPU multi-rank test)
-                self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t))
+                self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t, t, back))
 
     def wait(self):
-        for h, t in self.handles:
+        for h, scale_t, t, back in self.handles:
             h.wait()
-            if t is not None:
-                t.div_(self.world)
+            if scale_t is not None:
+                scale_t.div_(self.world)
+            if back is not None:
+                self._cast(t, back, False)
         self.handles = []
 
     def allreduce(self):

@@ -88,7 +88,7 @@ class GraphSequence:
 
 class TrainEngine:
     def __init__(self, model, optimizer, loss_fn, world_size=1, use_graph=True, warmup_eager=2, bucket_elems=32 * 1024 * 1024,
-                 overlap=False, two_phase=None, early_exchange=True):
+                 overlap=False, two_phase=None, early_exchange=True, exchange_dtype=None):
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.world = world_size
         self.use_graph = use_graph
@@ -105,8 +105,11 @@ class TrainEngine:
         # statistics inside the capture) in a 1-rank process group: the single-GPU test of the multi-GPU path
         self.two_phase = (world_size > 1) if two_phase is None else bool(two_phase)
         c.sync_always = self.two_phase and world_size == 1      # 1-rank group: still issue the SyncBatchNorm collectives
+        import os
+        # gradient exchange precision: fp32 as the reference (paddle.DataParallel), or bf16 = half the bytes over xGMI (EMRT_GRAD_EXCHANGE=bf16)
+        exchange_dtype = exchange_dtype or os.environ.get("EMRT_GRAD_EXCHANGE", "fp32")
         self.reducer = FlatGradReducer(model.store.grad, model.store.n_train, world_size, bucket_elems,
-                                       always=self.two_phase) if self.two_phase else None
+                                       always=self.two_phase, exchange_dtype=exchange_dtype) if self.two_phase else None
         # early exchange: backward runs in segments between the model's marks (ResNet.forward: before layer3 and before
         # layer4); the gradients a segment completes are all-reduced on RCCL's stream while the next segments still run:
         #   segment 1 (heads, transformer, layer4: ~84 % of the elements) -> exchanged under layer3 .. conv1's backward

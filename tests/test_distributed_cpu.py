@@ -47,6 +47,20 @@ def _worker(rank, world, port, q):
         m = sum(range(1, world + 1)) / world
         assert torch.allclose(flat[:300], torch.full((300,), m)) and torch.allclose(flat[300:700], torch.full((400,), 100 * m))
         assert torch.allclose(flat[700:n], torch.full((300,), 10 * m)) and not flat[n:].any() and not red.handles
+        # 1c. bf16 exchange (half the bytes over the links): the averaged gradient is the fp32 one to bf16 rounding, ranges and tail intact
+        g = torch.Generator().manual_seed(7 + rank)
+        flat = torch.randn(n + 24, generator=g)
+        keep = flat.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        red = FlatGradReducer(flat, n, world, bucket_elems=256, exchange_dtype="bf16")
+        red.launch([(0, 300)])
+        red.launch([(300, n)])
+        red.wait()
+        want = sum(gathered) / world
+        assert torch.equal(flat[n:], keep[n:])
+        err = (flat[:n] - want[:n]).abs().max().item()
+        assert 0 < err < 2.0 ** -7 * want[:n].abs().max().item(), err          # rounded (not fp32-exact), within bf16 resolution
         # 2. DP identity on a BN-free piece of the oracle (decoder layer): mean of per-rank grads == full-batch grads
         from oracle.emrt_torch import TransformerDecoderLayer
         torch.manual_seed(0)

@@ -68,11 +68,13 @@ def _worker(rank, world, port, q):
 
         # 2. step structures: eager + one exchange (reference behaviour) vs eager + early exchange vs the multi-graph step
         traces, sums = {}, {}
-        for mode in ("eager_plain", "eager_early", "graph_early"):
+        for mode in ("eager_plain", "eager_early", "graph_early", "graph_early_bf16"):
             model, opt = build()
-            eng = TrainEngine(model, opt, get_loss_function(cfg), world, use_graph=(mode == "graph_early"), warmup_eager=1,
-                              early_exchange=(mode != "eager_plain"), bucket_elems=4 * 1024 * 1024)
+            eng = TrainEngine(model, opt, get_loss_function(cfg), world, use_graph=mode.startswith("graph_early"), warmup_eager=1,
+                              early_exchange=(mode != "eager_plain"), bucket_elems=4 * 1024 * 1024,
+                              exchange_dtype="bf16" if mode.endswith("bf16") else "fp32")
             assert eng.two_phase and (eng.early_ranges is not None) == (mode != "eager_plain")
+            assert (eng.reducer.half is not None) == mode.endswith("bf16")
             traces[mode] = [eng.step(x, labels).item() for _ in range(5)]
             torch.cuda.synchronize()
             chk = model.store.master[:n].double().sum().reshape(1)
@@ -93,6 +95,13 @@ def _worker(rank, world, port, q):
         assert abs(sums["eager_plain"] - sums["graph_early"]) <= 5e-6 * abs(sums["eager_plain"]), sums
         assert eng.graph_a.n_graphs > 1, "the forward + first backward segment must have been cut at the SyncBatchNorm all-reduces"
         assert traces["graph_early"][-1] < traces["graph_early"][0]
+        # bf16 gradient exchange (half the bytes over xGMI): every rank's contribution is rounded to 8 significant bits before the sum, the
+        # update itself stays fp32: over 5 steps the loss trace stays within 2e-3 of the fp32 exchange's and the weights within 1e-4
+        # relative (a wrong range / a missing cast-back would be 1e-1), and the ranks stay bit-identical (asserted in the loop above)
+        for a, b in zip(traces["eager_plain"], traces["graph_early_bf16"]):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (traces["eager_plain"], traces["graph_early_bf16"])
+        assert abs(sums["eager_plain"] - sums["graph_early_bf16"]) <= 1e-4 * abs(sums["eager_plain"]), sums
+        assert traces["graph_early_bf16"][-1] < traces["graph_early_bf16"][0]
         q.put((rank, "ok", traces["graph_early"]))
     finally:
         dist.destroy_process_group()
