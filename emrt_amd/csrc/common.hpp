@@ -62,6 +62,8 @@ struct Tuning {
   int gn_bwd_stat_rows; // ... of the backward sums launch (32; each block also adds 2 C parameter-gradient atomics)
   int gn_apply_rows;    // ... of the apply / dx launches (8)
   int igemm8p_probe;    // -DEMRT_8P_PROBES builds only: which parts of the 256x256 kernel's loop are switched off (timing experiments)
+  int igemm8p_cmajor;   // 256x256 kernel, stride-1 problems: 1 = channel-block-major k order (A/B knob; 1.11x instead of 2.6x the algorithmic HBM-side
+                        // traffic, 4-18 % slower: igemm8p.hpp)
   int igemm8p_min_blocks; // smallest 256x256 grid that takes the LDS-DMA 8-phase kernel (160); 0 = never
 };
 extern Tuning g_tune;

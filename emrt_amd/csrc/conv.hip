@@ -42,6 +42,7 @@ struct ConvArgs {
   int KH, KW, stride, pad;
   int dil;         // dilation of the kernel taps (resnet50c's dilated stages, backbones/resnet.py:65-66); 1 everywhere else
   int relu, out_f32;
+  int cmajor;      // igemm8p only: channel-block-major k order (developer A/B knob igemm8p_cmajor), 0 everywhere else
   double* stats;   // optional [8][2*OC]: per-channel sum / sum of squares of the STORED outputs (BatchNorm statistics);
                    // fp64 atomics spread over 8 replicas (by M-tile index) so that blocks do not pile onto one address
   // optional ReLU mask: outputs are zeroed where mask_y <= 0 (same geometry as the output, own strides), and with it the
@@ -985,7 +986,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
   a.ldres = ldres; a.res_bs = res_bs;
-  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu; a.out_f32 = out_f32; a.stats = bn_stats;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu; a.out_f32 = out_f32; a.cmajor = g_tune.igemm8p_cmajor; a.stats = bn_stats;
   a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
@@ -1389,7 +1390,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(lddx >= C && dx_bs >= 0, "bad dx strides");
   EMRT_REQUIRE(!(accumulate && addend), "accumulate adds into dx itself; addend is a different tensor");
   EMRT_REQUIRE(!stat_x || mask_y, "stat_x replaces the mask tensor in the second statistic: it needs mask_y");
-  d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dilation; d.relu = 0; d.out_f32 = 0; d.stats = bn_stats;
+  d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dilation; d.relu = 0; d.out_f32 = 0; d.cmajor = g_tune.igemm8p_cmajor; d.stats = bn_stats;
   d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale; d.stat_x = stat_x; d.ldsx = ldsx; d.sx_bs = sx_bs;
   WgradArgs w;
   w.x = x; w.dy = dy; w.dw = dw;
@@ -1457,7 +1458,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldin = d.ldin; a.in_bs = d.in_bs;
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
   a.ldres = d.ldres; a.res_bs = d.res_bs;
-  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = 0; a.stats = d.bn_stats;
+  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = 0; a.cmajor = 0; a.stats = d.bn_stats;
   a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
 }
 
@@ -1524,7 +1525,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     d.N = b.N; d.H = b.OH; d.W = b.OW; d.C = b.OC; d.ldin = b.lddy; d.in_bs = b.dy_bs;
     d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
-    d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.stats = nullptr;
+    d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.cmajor = 0; d.stats = nullptr;
     d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
     WgradArgs& w = g.w[i];
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;

@@ -27,7 +27,7 @@ const TuneEntry kTune[] = {
     {"gn_group_blocks", &emrt::Tuning::gn_group_blocks, 0}, {"gn_stat_rows", &emrt::Tuning::gn_stat_rows, 32},
     {"gn_bwd_stat_rows", &emrt::Tuning::gn_bwd_stat_rows, 32}, {"gn_apply_rows", &emrt::Tuning::gn_apply_rows, 8},
     {"msda_scatter_cuts", &emrt::Tuning::msda_scatter_cuts, 0}, {"msda_scatter_qsplit", &emrt::Tuning::msda_scatter_qsplit, 0}, {"msda_band_halo", &emrt::Tuning::msda_band_halo, 0},
-    {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160},
+    {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160}, {"igemm8p_cmajor", &emrt::Tuning::igemm8p_cmajor, 0},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;

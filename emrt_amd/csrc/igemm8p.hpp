@@ -88,11 +88,27 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
     const int n = bn * BN + (wave >> 2) * 64 + (wave & 3) * 8 + 128 * (q >> 1) + 32 * (q & 1) + lrow;
     b_off[q] = n < p.OC ? (unsigned)((long long)n * K * 2) : BUF_OOB;
   }
-  int bkt = 0;
+  // K order.  Default: tap-major (all channels of tap 0, then tap 1, ...: consecutive k-tiles read consecutive 128-byte pieces of the same
+  // pixel rows and weight rows).  A/B knob igemm8p_cmajor (stride-1 problems): CHANNEL-BLOCK major, k-tile t = (64-channel block t / ntap,
+  // tap t % ntap), so the KH*KW taps of one channel block are consecutive k-tiles and their re-reads of the same pixels hit L2.  Measured on
+  // UpHead conv_2 (profiles/r3_pmc_conv_8phase.txt): FETCH_SIZE 146 -> 43 MB, i.e. 2 x FETCH + WRITE = 358 -> 151 MB = 2.6x -> 1.11x the
+  // 135 MB of algorithmic bytes -- and 141 -> 147 us; with C = 1536 (cls_psp.0) 231 -> 272 us.  The tap-major order's extra fetches are
+  // re-reads of a 67 MB tensor that sits in the 256 MB Infinity Cache (FETCH_SIZE counts fabric requests, MALL hits included), and its
+  // sequential streams cost less than the strided ones that buy the L2 hits: the faster order stays the default.
+  const int ntap = p.KH * p.KW;
+  const bool cmajor = p.cmajor != 0 && p.stride == 1 && ntap <= 32;
+  int bkt = 0, b_tap = 0, b_c0 = 0;
+  auto advance_b = [&]() {
+    ++bkt;
+    if (cmajor) {
+      ++b_tap;
+      if (b_tap == ntap) { b_tap = 0; b_c0 += 64; }
+    }
+  };
   auto stage_b = [&](int u, int par) {                 // unit UBu of k-tile bkt -> buffer par
     if constexpr ((PROBE & 1) != 0) { if (bkt >= 2) return; }
     const unsigned kbad = bkt < nkt ? 0u : BUF_OOB;
-    const unsigned kb = (unsigned)bkt * 128u + chunk_b;
+    const unsigned kb = (cmajor ? (unsigned)(b_tap * p.C + b_c0) * 2u : (unsigned)bkt * 128u) + chunk_b;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row0 = (wave >> 2) * 64 + (wave & 3) * 8 + 128 * j + 32 * u;
@@ -138,9 +154,37 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   unsigned a_cur[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) a_cur[i] = a_pixel(i, 0, 0);
-  const bool one_tap = p.KH * p.KW == 1;
+  const bool one_tap = ntap == 1;
+  // channel-block-major order: the tap changes with every k-tile, so a row's tap offsets must be cheap: offset = rowbase + tapd (tapd is the
+  // same for every row: scalar) where the tap is inside the map, a bit of vmask says where that is
+  unsigned rowbase[4], vmask[4];
+  if (cmajor) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rowbase[i] = a_base[i] + (unsigned)((a_h[i] * p.W + a_w[i]) * p.ldin) * 2u;      // (wraps for border rows: only used where vmask says valid)
+      unsigned vh = 0u, vw = 0u;
+      for (int kh = 0; kh < p.KH; ++kh) vh |= ((unsigned)(MODE == 0 ? a_h[i] + kh * p.dil : a_h[i] - kh * p.dil) < (unsigned)p.H ? 1u : 0u) << kh;
+      for (int kw = 0; kw < p.KW; ++kw) vw |= ((unsigned)(MODE == 0 ? a_w[i] + kw * p.dil : a_w[i] - kw * p.dil) < (unsigned)p.W ? 1u : 0u) << kw;
+      unsigned vm = 0u;
+      for (int kh = 0; kh < p.KH; ++kh) vm |= ((vh >> kh) & 1u) ? vw << (kh * p.KW) : 0u;
+      vmask[i] = a_ok[i] ? vm : 0u;
+    }
+  }
+  int a_tap = 0;
   auto advance_a = [&]() {
     ++akt;
+    if (cmajor) {
+      ++a_tap; ++a_kw;
+      if (a_kw == p.KW) { a_kw = 0; ++a_kh; }
+      if (a_tap == ntap) { a_tap = 0; a_kh = 0; a_kw = 0; a_c0 += 64; }
+      if (!one_tap) {
+        const int d = (a_kh * p.dil * p.W + a_kw * p.dil) * p.ldin * 2;
+        const unsigned tapd = (unsigned)(MODE == 0 ? d : -d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_cur[i] = ((vmask[i] >> a_tap) & 1u) ? rowbase[i] + tapd : BUF_OOB;
+      }
+      return;
+    }
     a_c0 += 64;
     if (a_c0 >= p.C) {
       a_c0 = 0;
@@ -185,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
 
   // ---- prologue: k-tile 0 whole, then the units of k-tile 1 that the last phases of "tile -1" would have issued ----------------
   stage_a(0, 0); stage_a(1, 0);                        // (the weights' half of k-tile 0 was issued above)
-  advance_a(); ++bkt;
+  advance_a(); advance_b();
   stage_a(0, 1); stage_b(1, 1); stage_a(1, 1);        // UB0(1) follows in phase 1 of tile 0 (bkt advances there)
   advance_a();
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // k-tile 0 has landed (this wave's pieces; the barrier covers the others)
@@ -204,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) fa[i][s] = lds16(buf + a_tile0 + (unsigned)i * 4096u + fpos[s]);
       stage_b(0, PAR ^ 1);                              // UB0 of the NEXT k-tile (its slot's last reader: phase 4 of the tile before)
-      ++bkt;
+      advance_b();
     } else if constexpr (Q == 2) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) fb1[s] = lds16(buf + b_tile0 + 4096u + fpos[s]);

@@ -198,9 +198,11 @@ class FCNHead(hnn.HipLayer):
         self.conv_seg = hnn.Conv2D(channels, num_classes, 1)
         self.salt = _salt()
 
-    def forward(self, x):
+    def forward(self, x, features=None):
+        """features: the output of convs[0] (conv -> SyncBN -> ReLU) when the caller already ran it inside a statistics group
+        (EMRT.forward at N > 1: one all-reduce for the pyramid-pooling branches and this head)."""
         N, H, W, _ = x.shape
-        o = Fn.conv_bn(self.convs[0][0], self.convs[0][1], x, relu=True)
+        o = features if features is not None else Fn.conv_bn(self.convs[0][0], self.convs[0][1], x, relu=True)
         o = Fn.dropout(o, self.p, self.salt, mode=1, hw=H * W)
         o = self.conv_seg(o)
         return Fn.resize_bilinear(o, H * self.up_ratio, W * self.up_ratio, False, out_nchw_f32=True)
@@ -550,14 +552,21 @@ class PyramidPoolingModule(hnn.HipLayer):  # :50-78
             hnn.Sequential(None, hnn.Conv2D(in_channels, channels, 1, bias=False), hnn.BatchNorm2D(channels, sync=True), None)
             for _ in pool_scales])
 
-    def forward(self, x):
+    def forward(self, x, extra=None):
+        """extra = (conv, SyncBatchNorm, input) of ANOTHER conv -> SyncBN -> ReLU stage (the auxiliary head's, fcn_head.py:47-56) that joins
+        the group: its statistics travel in the same all-reduce as the four pooling branches'.  Returns tokens, or (tokens, extra output)."""
         tokens = Fn.adaptive_avgpool_tokens(x, self.pool_scales)       # all four pools in one launch -> [B, 110, C]
         slices, s0 = [], 0
         for k in self.pool_scales:
             slices.append(Fn.narrow(tokens, 1, s0, k * k))
             s0 += k * k
-        # the four SyncBatchNorm branches share one statistics all-reduce per direction (Fn.conv_bn_group)
-        parts = Fn.conv_bn_group([br[1] for br in self.pool_branches], [br[2] for br in self.pool_branches], slices, relu=True)
+        convs, bns = [br[1] for br in self.pool_branches], [br[2] for br in self.pool_branches]
+        if extra is not None:
+            convs, bns, slices = convs + [extra[0]], bns + [extra[1]], slices + [extra[2]]
+        # the SyncBatchNorm branches share one statistics all-reduce per direction (Fn.conv_bn_group)
+        parts = Fn.conv_bn_group(convs, bns, slices, relu=True)
+        if extra is not None:
+            return Fn.concat_tokens(parts[:-1]), parts[-1]
         return Fn.concat_tokens(parts)
 
 
@@ -757,7 +766,16 @@ class EMRT(hnn.HipLayer):  # :184-304
         SH, SW = H // 8, W // 8                 # x_context.shape[2:] (:283-288); tiles need not be square
         psp_cat = c.empty((B, SH, SW, 256 * (2 + len(self.psp_scale))))
         x_context = self.spatial_branch(x, out=Fn.narrow(psp_cat, 3, 0, 256))
-        x_psp = self.psp_module(x_context)
+        # data-parallel training: the five SyncBatchNorm layers (paddle_EMRT.py:64, fcn_head.py:53) all-reduce their statistics, and inside a
+        # captured step every such collective is a cut between two hipGraphs.  The auxiliary head's conv -> SyncBN only needs c3, so it joins
+        # the pyramid-pooling group here: ONE collective per direction for all five layers (2 cuts per step instead of 4).  With one rank
+        # (no collective, nothing to merge) the reference's order is kept.
+        aux_feat = None
+        head0 = self.auxlayer.convs[0]
+        if self.training and Fn._sync_active(head0[1].state):
+            x_psp, aux_feat = self.psp_module(x_context, extra=(head0[0], head0[1], c3))
+        else:
+            x_psp = self.psp_module(x_context)
         hs, memory, shapes, spans = self.model([c2, c3, c4], x_psp)
         maps = [Fn.tokens_as_map(Fn.narrow(memory, 1, a, n), h, w) for (h, w), (a, n) in zip(shapes, spans)]
         nps = len(self.psp_scale)
@@ -768,7 +786,7 @@ class EMRT(hnn.HipLayer):  # :184-304
         o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW)
         logits = self.uphead(o)
         if self.training or self.compute_aux_in_eval:
-            aux = self.auxlayer(c3)      # x16 bilinear; the reference's final align_corners=True resize is the identity here
+            aux = self.auxlayer(c3, features=aux_feat)      # x16 bilinear; the reference's final align_corners=True resize is the identity here
             assert aux.shape[2] == H and aux.shape[3] == W
         else:
             aux = None

@@ -197,17 +197,20 @@ CONV_8P = [
 ]
 
 
+@pytest.mark.parametrize("cmajor", [0, 1])        # tap-major (default) and channel-block-major k order
 @pytest.mark.parametrize("case", CONV_8P, ids=[c[0] for c in CONV_8P])
-def test_conv_8phase_kernel_bf16_vs_torch(case):
+def test_conv_8phase_kernel_bf16_vs_torch(case, cmajor):
     from emrt_amd import _lib
     L_ = _lib.lib()
     old = L_.set_tuning("conv_tile", 7)
     oldp = L_.set_tuning("pair_max", 0)          # the data gradient goes out as its own launch: through the forced tile
+    oldc = L_.set_tuning("igemm8p_cmajor", cmajor)
     try:
         _conv_case_vs_torch(case, dilation=case[10] or 1)
     finally:
         L_.set_tuning("conv_tile", old)
         L_.set_tuning("pair_max", oldp)
+        L_.set_tuning("igemm8p_cmajor", oldc)
 
 
 def _conv_case_vs_torch(case, dilation=1):
