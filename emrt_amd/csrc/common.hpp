@@ -65,8 +65,16 @@ struct Tuning {
   int igemm8p_cmajor;   // 256x256 kernel, stride-1 problems: 1 = channel-block-major k order (A/B knob; 1.11x instead of 2.6x the algorithmic HBM-side
                         // traffic, 4-18 % slower: igemm8p.hpp)
   int igemm8p_min_blocks; // smallest 256x256 grid that takes the LDS-DMA 8-phase kernel (160); 0 = never
+  int wgrad8p_min_steps;  // 256x256 weight-gradient kernel: fewest 64-pixel steps per block worth its prologue / 256 KiB epilogue (8); 0 = never
+  int wgrad8p_slab;       // 1 (default): partial tiles through the registered scratch + a reduce launch; 0: fp32 atomics into dW
+  int wgrad8p_xcd;        // 1 (default): slices of the pixel reduction pinned to XCDs (shared L2); 0: launch order (A/B knob)
+  int wgrad8p_force;      // tests: 1 = take the 256x256 kernel whenever the shape allows, whatever the grid size
 };
 extern Tuning g_tune;
+
+// scratch for partial sums, registered once per process by emrt_set_scratch (kernels of ONE stream use it one after the other)
+struct Scratch { void* ptr; size_t bytes; };
+extern Scratch g_scratch;
 
 // ---- element types ---------------------------------------------------------------------------
 struct bf16_t {

@@ -1033,10 +1033,16 @@ static void wgrad_plan(WgradArgs& a, int& tx, int& ty, int& S_out) {
   S_out = (int)((mt_total + a.tiles_per_split - 1) / a.tiles_per_split);
 }
 
+#include "wgrad8p.hpp"
+
 template <class T>
 static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   using Cfg = WgradCfg<T>;
   WgradArgs a = a0;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    int tk, toc, S8, per;
+    if (wgrad8p_plan<T>(a, tk, toc, S8, per)) return launch_wgrad8p(a, tk, toc, S8, per, st);
+  }
   const bool vec = wgrad_is_vec<T>(a);
   int tx, ty, S;
   wgrad_plan<T>(a, tx, ty, S);

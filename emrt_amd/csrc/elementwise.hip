@@ -28,6 +28,7 @@ const TuneEntry kTune[] = {
     {"gn_bwd_stat_rows", &emrt::Tuning::gn_bwd_stat_rows, 32}, {"gn_apply_rows", &emrt::Tuning::gn_apply_rows, 8},
     {"msda_scatter_cuts", &emrt::Tuning::msda_scatter_cuts, 0}, {"msda_scatter_qsplit", &emrt::Tuning::msda_scatter_qsplit, 0}, {"msda_band_halo", &emrt::Tuning::msda_band_halo, 0},
     {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160}, {"igemm8p_cmajor", &emrt::Tuning::igemm8p_cmajor, 0},
+    {"wgrad8p_min_steps", &emrt::Tuning::wgrad8p_min_steps, 8}, {"wgrad8p_slab", &emrt::Tuning::wgrad8p_slab, 1}, {"wgrad8p_force", &emrt::Tuning::wgrad8p_force, 0}, {"wgrad8p_xcd", &emrt::Tuning::wgrad8p_xcd, 1},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;
@@ -45,6 +46,14 @@ emrt::Tuning tuning_from_env() {
 }
 }  // namespace
 emrt::Tuning emrt::g_tune = tuning_from_env();
+emrt::Scratch emrt::g_scratch = {nullptr, 0};
+
+extern "C" int emrt_set_scratch(void* ptr, size_t bytes) {
+  EMRT_REQUIRE((ptr != nullptr) == (bytes > 0) && ((uintptr_t)ptr) % 256 == 0, "scratch must be 256-byte aligned device memory (or nullptr, 0)");
+  emrt::g_scratch.ptr = ptr;
+  emrt::g_scratch.bytes = bytes;
+  return 0;
+}
 
 extern "C" int emrt_set_tuning(const char* name, int value) {
   EMRT_REQUIRE(name, "null name");

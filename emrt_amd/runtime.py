@@ -261,6 +261,11 @@ class Context:
         torch.cuda.set_stream(self._main)
         self.dtype = dtype
         self._ws = torch.empty(8 << 20, dtype=torch.uint8, device=self.device)
+        # partial-sum scratch of the 256 x 256 weight-gradient kernel (one 256 KiB fp32 tile per CU), registered once: its address is baked
+        # into captured graphs, so it is never reallocated
+        if getattr(self, "_scratch", None) is None or self._scratch.device != self.device:
+            self._scratch = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+            _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()))
         self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._arena, self._arena_off, self._arena_live = None, 0, False

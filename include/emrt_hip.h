@@ -41,6 +41,11 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * Not thread-safe against concurrent launches; production code never calls these. */
 int emrt_set_tuning(const char* name, int value);
 int emrt_get_tuning(const char* name, int* value);
+/* Registers DEVICE memory (256-byte aligned; nullptr, 0 to unregister) that kernels may use for partial sums between two of their own
+ * launches on the caller's stream: today the 256x256 weight-gradient kernel's per-block partial tiles (<= 64 MiB: one 256 KiB tile per CU)
+ * for train.py:142-149's loss.backward() of the large layers.  Without it that kernel adds its tiles into dW with fp32 atomics.  The
+ * memory must stay valid (and the pointer unchanged across hipGraph replays) until it is unregistered; one stream at a time. */
+int emrt_set_scratch(void* ptr, size_t bytes);
 
 /* ---- convolution / linear as implicit GEMM (MFMA 32x32) ---------------------------------------------------
  * replaces nn.Conv2D: backbones/paddle_vision_resnet.py:108-123,192-198,226-233; paddle_EMRT.py:16-23,63,85-91,

@@ -213,6 +213,75 @@ def test_conv_8phase_kernel_bf16_vs_torch(case, cmajor):
         L_.set_tuning("igemm8p_cmajor", oldc)
 
 
+# the 256 x 256 weight-gradient kernel (csrc/wgrad8p.hpp), forced through its knob: one-step blocks (an odd step count multiplies an all-zero
+# step), stride 2 (stride holes of the x operand), one tap, dilation, OW = 128 / 8 (both carries of the pixel cursor), two oc tiles with two
+# channel blocks, x as a channel slice of a wider buffer is covered by the model tests; partial tiles through the scratch slabs AND fp32
+# atomics, forced slice counts with a ragged last slice, and the three layers it is built for at the benchmark's size
+WGRAD_8P = [
+    ("w8p-uphead-128", 8, 128, 128, 256, 256, 3, 1, 1, True, None),
+    ("w8p-uphead-64", 8, 64, 64, 256, 256, 3, 1, 1, True, None),
+    ("w8p-cls_psp-0", 8, 32, 32, 1536, 512, 3, 1, 1, False, None),
+    ("w8p-one-step", 2, 16, 16, 256, 256, 3, 1, 1, True, None),
+    ("w8p-stride2", 2, 32, 32, 256, 512, 3, 2, 1, True, None),
+    ("w8p-1x1", 5, 8, 8, 512, 256, 1, 1, 0, True, None),
+    ("w8p-dilated", 2, 16, 16, 256, 256, 3, 1, 2, False, 2),
+    ("w8p-wide-rows", 1, 8, 128, 256, 256, 3, 1, 1, True, None),
+]
+
+
+@pytest.mark.parametrize("slab,split", [(1, 0), (0, 0), (1, 3), (1, 1)], ids=["slab", "atomics", "slab-3-slices", "one-slice"])
+@pytest.mark.parametrize("case", WGRAD_8P, ids=[c[0] for c in WGRAD_8P])
+def test_wgrad_8phase_kernel_bf16_vs_torch(case, slab, split):
+    from emrt_amd import _lib
+    L_ = _lib.lib()
+    if split and case[1] * case[2] * case[3] > 100000:
+        pytest.skip("forced slice counts are exercised on the small cases")
+    old = [(k, L_.set_tuning(k, v)) for k, v in (("wgrad8p_force", 1), ("pair_max", 0), ("wgrad8p_slab", slab), ("wgrad_split", split))]
+    try:
+        _conv_case_vs_torch(case, dilation=case[10] or 1)
+    finally:
+        for k, v in old:
+            L_.set_tuning(k, v)
+
+
+def test_wgrad_8phase_slab_path_is_bit_reproducible_and_matches_the_128_tile():
+    """Partial tiles through the scratch slabs are summed in a fixed order: two launches give identical bits (the fp32-atomic paths do
+    not); and the 256 x 256 kernel agrees with the 128 x 128 register-staged one to fp32 summation-order noise."""
+    from emrt_amd import _lib
+    L_ = _lib.lib()
+    c = init(BF16)
+    g = torch.Generator().manual_seed(47)
+    N, H, W, Cin, Cout = 8, 64, 64, 256, 256
+    conv = hnn.Conv2D(Cin, Cout, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(Cout, Cin, 3, 3, generator=g) / 48))
+    Holder(conv=conv).place()
+    xd = dev_map(rnd(torch.randn(N, Cin, H, W, generator=g)))
+    dyd = dev_map(rnd(torch.randn(N, Cout, H, W, generator=g)))
+
+    def grad():
+        conv.weight.grad.zero_()
+        tape = Tape()
+        c.tape = tape
+        y = conv(xd)
+        c.tape = None
+        tape.add_grad(y, dyd)
+        tape.backward()
+        torch.cuda.synchronize()
+        return conv.weight.grad.clone()
+
+    a, b = grad(), grad()
+    assert torch.equal(a, b)
+    old = L_.set_tuning("wgrad8p_min_steps", 0)      # 0 = never: the 128 x 128 kernel
+    try:
+        ref = grad()
+    finally:
+        L_.set_tuning("wgrad8p_min_steps", old)
+    rel = ((a - ref).norm() / ref.norm()).item()
+    print("wgrad 256x256 vs 128x128: rel %.2e" % rel)
+    assert 0 < rel < 2e-6, rel
+
+
 def _conv_case_vs_torch(case, dilation=1):
     name, N, H, W, Cin, Cout, k, stride, pad, bias = case[:10]
     c = init(BF16)

@@ -120,8 +120,47 @@ def big():
         print(line, flush=True)
 
 
+def wbig():
+    """Weight gradient of the big layers: 128 x 128 register-staged tile with fp32 atomics against the 256 x 256 LDS-DMA 8-phase kernel
+    (partial tiles through the scratch slabs + reduce launch, or fp32 atomics), and the 8-phase kernel's slice count."""
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()))
+    for (name, N, H, W, C, OC, k) in BIG + [("cfg2 layer3 3x3", 8, 16, 16, 256, 256, 3), ("cfg2 layer4 3x3", 8, 8, 8, 512, 512, 3), ("cfg3 layer3 3x3", 4, 32, 32, 256, 256, 3)]:
+        pad = k // 2
+        x = torch.randn(N, H, W, C, device=dev).bfloat16()
+        dy = torch.randn(N, H, W, OC, device=dev).bfloat16()
+        dw = torch.zeros(OC, k, k, C, device=dev, dtype=torch.float32)
+        db = torch.zeros(OC, device=dev, dtype=torch.float32)
+        gf = 2.0 * N * H * W * OC * k * k * C / 1e9
+
+        def wgrad():
+            L._raw_emrt_conv2d_wgrad(P(x), P(dy), P(dw), N, H, W, C, C, H * W * C, H, W, OC, OC, H * W * OC, k, k, 1, pad, P(db), 1, 1, stream)
+
+        def one(**knobs):
+            old = [(kk, L.set_tuning(kk, v)) for kk, v in knobs.items()]
+            dw.zero_()
+            wgrad()
+            out = dw.clone()
+            t = min(timed(wgrad, 20), timed(wgrad, 20))
+            for kk, v in old:
+                L.set_tuning(kk, v)
+            return t, out
+        t0, ref = one(wgrad8p_min_steps=0)
+        line = "%-20s N%d %dx%dx%d->%d k%d %7.2f GF | 128x128 %.1f us (%.0f TF/s) |" % (name, N, H, W, C, OC, k, gf, t0, gf / t0 * 1e3)
+        ta, oa = one()
+        line += " auto %.1f us (%.0f TF/s) |" % (ta, gf / ta * 1e3)
+        for label, knobs in (("8p slab", dict(wgrad8p_force=1)), ("8p launch-order", dict(wgrad8p_force=1, wgrad8p_xcd=0)), ("8p atomics", dict(wgrad8p_force=1, wgrad8p_slab=0)),
+                             ("8p slab S/2", dict(wgrad8p_force=1, wgrad_split=max(1, 128 // (k * k * (C // 256) * (OC // 256))))),
+                             ("8p 1 slice", dict(wgrad8p_force=1, wgrad_split=1))):
+            t, o = one(**knobs)
+            line += " %s %.1f us (%.0f TF/s) rel %.1e |" % (label, t, gf / t * 1e3, ((o - ref).norm() / ref.norm()).item())
+        print(line, flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "wbig":
+        return wbig()
     if which == "thin":
         return thin()
     if which == "big":
