@@ -58,6 +58,10 @@ class _Lib:
             raise EmrtHipError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU/PyTorch fallback for the EMRT hot path)" % LIB_PATH)
+        # torch first: the library must bind to the HIP runtime torch has loaded (torch's streams and device memory are handed to it).
+        # Loaded before torch it pulls in /opt/rocm's copy, torch then brings its bundled one, and launches fail with "no ROCm-capable
+        # device is detected" (seen when build() and smoke() ran in one process).
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self._rec = None
         self.protos = parse_header()
