@@ -48,7 +48,7 @@ PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
 GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: per-level encoder convs)",
                  "emrt_conv2d_bwd_group": "bwd_group_kernel (emrt_conv2d_bwd_group)",
                  "emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
-                 "emrt_conv2d_bwd": "igemm_kernel + wgrad_kernel (emrt_conv2d_bwd: data + weight gradients, paired launch for small layers)",
+                 "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel + wgrad_kernel / wgrad8p_kernel (emrt_conv2d_bwd: data + weight gradients; paired launch for small layers, 256x256 LDS-DMA kernels for the large ones)",
                  "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)"}
 
 
