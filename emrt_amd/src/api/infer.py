@@ -1,8 +1,8 @@
 """Sliding-window / single-scale inference (reference: src/api/infer.py:22-80 slide_inference, :82-157 ss_inference).
 
 Windows of one image are gathered into ONE batch per model call (the reference issues one call per window position);
-logit accumulation / count normalisation / argmax follow the reference exactly and run as HIP kernels.  The only torch op
-left is the bilinear resize of the logits when the network output size differs from `ori_shape` (never the case for
+logit accumulation / count normalisation / argmax follow the reference exactly and run as HIP kernels, and so does the
+bilinear resize of the logits when the network output size differs from `ori_shape` (infer.py:146-150; never the case for
 the EMRT configs, whose tiles are evaluated at their own size).
 """
 import torch
@@ -76,7 +76,7 @@ def ss_inference(model, img, ori_shape, is_slide, base_size, stride_size, crop_s
     for logit, shape in zip(logit_list, ori_shape):
         shape = tuple(int(s) for s in shape)
         if tuple(logit.shape[-2:]) != shape:
-            logit = torch.nn.functional.interpolate(logit, shape, mode="bilinear", align_corners=False)
+            logit = _resize_nchw_f32(logit, shape[0], shape[1])      # F.interpolate(mode='bilinear'): infer.py:146-150
         # softmax is monotonic: argmax(softmax(x)) == argmax(x)  (infer.py:152-153)
         logit = logit.contiguous()
         n, ncls, hh, ww = logit.shape

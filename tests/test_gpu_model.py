@@ -508,6 +508,26 @@ def test_sliding_window_inference_and_metrics(ih, iw):
         assert u.cpu().tolist() == v.tolist()
 
 
+def test_ss_inference_resizes_logits_to_ori_shape_on_the_hip_path():
+    """infer.py:146-150: when the network output size differs from ori_shape the logits are resized (bilinear, align_corners False)
+    before the argmax; the HIP resize kernel against torch's F.interpolate on the same logits, up- and down-scaling, odd sizes."""
+    from emrt_amd.src.api import infer
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    ref, model = build_pair("resnet18", x)
+    model.eval()
+    img = torch.randn(3, 64, 64, generator=g)
+    logits = model(img.unsqueeze(0).cuda())[0]
+    for shape in ((97, 75), (40, 52), (64, 64)):
+        got = infer._resize_nchw_f32(logits, *shape).cpu()
+        want = torch.nn.functional.interpolate(logits.cpu(), shape, mode="bilinear", align_corners=False)
+        assert (got - want).abs().max().item() < 1e-5, shape
+        pred = infer.ss_inference(model, [img.cuda()], [shape], False, 64, (32, 32), (64, 64), 6)[0]
+        assert pred.dtype == torch.int32 and tuple(pred.shape) == (1, 1) + shape
+        agree = (pred.cpu()[0, 0] == want.argmax(1)[0].to(torch.int32)).float().mean().item()
+        assert agree > 0.999, (shape, agree)      # (a 1e-5 logit difference can flip an exact tie)
+
+
 def test_large_tile_train_step_512_bf16():
     """BASELINE configs[2]: LoveDA 512x512, 7 classes, batch 4 -- the large-tile attention path (Lv = 5376: the MSDA
     scatter cuts level 0 into four LDS ranges, the forward takes the global-gather kernel).  bf16 fwd + bwd + SGD steps
