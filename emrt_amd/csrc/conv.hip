@@ -850,10 +850,24 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x
     }
 }
 
+// One-dimensional grid of 8 * ceil(tx * ty * S / 8) blocks.  Consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each) and the
+// tx * ty output tiles of ONE pixel slice stream the same dy / x rows: the work items (slice-major) are cut into 8 contiguous ranges, XCD
+// id % 8 takes range id % 8 (wgrad8p.hpp has the measurement: 7x less fabric traffic on UpHead conv_2).  xcd = 0: launch order (A/B knob).
 template <class T, bool VEC, int G, int NSTW = 2>
-__global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p) {   // 2 waves per SIMD (<= 256 registers)
+__global__ __launch_bounds__(256 * G, 2) void wgrad_kernel(WgradArgs p, int tx, int ty, int S, int xcd) {   // 2 waves per SIMD (<= 256 registers)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-  wgrad_body<T, VEC, G, NSTW>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem_all);
+  const int nb = tx * ty * S;
+  int w = (int)blockIdx.x;
+  if (xcd) {
+    const int k = w & 7, idx = w >> 3;
+    const int w0 = (int)(((long long)k * nb) >> 3), w1 = (int)(((long long)(k + 1) * nb) >> 3);
+    w = w0 + idx;
+    if (w >= w1) return;
+  } else if (w >= nb) return;
+  // (integer divisions run on the vector ALU: the wave-uniform results go back to scalar registers)
+  const int bz = __builtin_amdgcn_readfirstlane(w / (tx * ty)), t = __builtin_amdgcn_readfirstlane(w - bz * (tx * ty));
+  const int by = __builtin_amdgcn_readfirstlane(t / tx);
+  wgrad_body<T, VEC, G, NSTW>(p, __builtin_amdgcn_readfirstlane(t - by * tx), by, bz, smem_all);
 }
 
 // Backward pair: ONE launch runs the data-gradient tiles (blocks [0, n_dgrad)) and the weight-gradient tiles (the rest)
@@ -1060,12 +1074,14 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
       return fail("emrt_conv2d_wgrad", "cannot raise the dynamic LDS limit");
     attr_done = true;
   }
+  const int xcd = g_tune.wgrad8p_xcd;
+  const unsigned grid1 = 8u * (unsigned)(((long long)tx * ty * S + 7) / 8);
   if (vec && g_tune.wgrad_nst == 3) {       // A/B knob: the spilling three-stage ring
     static bool attr3 = false;
     if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, true, G, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)G * 4 * Cfg::BKM * Cfg::PITCH)); attr3 = true; }
-    hipLaunchKernelGGL((wgrad_kernel<T, true, G, 3>), dim3(tx, ty, (unsigned)S), dim3(256 * G), lds, st, a);
-  } else if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true, G>), dim3(tx, ty, (unsigned)S), dim3(256 * G), lds, st, a);
-  else hipLaunchKernelGGL((wgrad_kernel<T, false, 1>), dim3(tx, ty, (unsigned)S), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<T, true, G, 3>), dim3(grid1), dim3(256 * G), lds, st, a, tx, ty, S, xcd);
+  } else if (vec) hipLaunchKernelGGL((wgrad_kernel<T, true, G>), dim3(grid1), dim3(256 * G), lds, st, a, tx, ty, S, xcd);
+  else hipLaunchKernelGGL((wgrad_kernel<T, false, 1>), dim3(grid1), dim3(256), lds, st, a, tx, ty, S, xcd);
   return check_launch("emrt_conv2d_wgrad");
 }
 

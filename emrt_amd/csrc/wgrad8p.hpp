@@ -9,15 +9,16 @@
 //     blocks that stream the SAME pixels (same slice, the KH*KW taps x channel blocks x oc tiles) must share one: the work items
 //     w = (slice, oc tile, channel block, tap) in that order are cut into 8 contiguous ranges, XCD k = id % 8 takes range k.  Without it the
 //     taps of a slice sat on 8 different XCDs and every block pulled its 64 KiB per step from the fabric: 1.2 GB per launch on UpHead's
-//     conv_2 instead of the 134 MB of x + dy (measured: tools/bench_conv.py wbig, profiles/r3_wgrad_8phase.txt);
+//     conv_2 instead of the 134 MB of x + dy (measured: tools/bench_conv.py wbig, profiles/r3_wgrad_8phase_vs_128.txt, r3_pmc_wgrad_8phase.txt);
 //   * both operands are PIXEL-major in memory (64 pixels x 512 bytes per step and operand), the MFMA wants 8 consecutive pixels per lane:
 //     fragments come out of LDS through the transposing read ds_read_b64_tr_b16 (two per 32x16 fragment), as in wgrad_body;
 //   * the DMA source address is per lane, so the LDS image need not look like memory: every step's tile is stored as COLUMN SLICES, one per
 //     (wave row / column, half) -- dy as 4 sub-images [64 pixels][64 oc] (128-byte rows), x as 8 sub-images [64 pixels][32 c] (64-byte rows)
 //     -- which is what makes the four 16 KiB units of a step (a0 / a1 halves of dy, b0 / b1 halves of x) separately re-stageable;
 //     the 128-byte-row images XOR the 64-byte half of a row with bit 1 of the row (conflict-free transposed reads), permutation on the source;
-//   * a thread stages ONE dy pixel row and ONE x pixel row per step (four 16-byte pieces of each): the mixed-radix pixel cursor
-//     (image, row, column) advances by 64 pixels per step with two carries, no division;
+//   * a thread stages ONE dy pixel row and ONE x pixel row per step (four 16-byte pieces of each); OH * OW % 64 == 0 (host), so a step lies
+//     inside one image: the image and the step's first pixel are wave-uniform and live in scalar registers (the buffer instruction's
+//     soffset), a lane keeps one constant byte offset (dy) or its (oh, ow) pair advanced with one carry (x); no division in the loop;
 //   * the 256 x 256 fp32 tile is a PARTIAL sum over the block's pixel slice: written to a scratch slab (emrt_set_scratch) and added
 //     into dW by wgrad8p_reduce_kernel, or -- without scratch -- added with fp32 atomics (two 128-byte segments per wave instruction);
 //   * the bias gradient (sum_m dy[m][oc]) is taken from the dy FRAGMENTS by the wave column 0 of the blocks of the k-tile whose turn it
