@@ -13,6 +13,7 @@
 // fetch one contiguous 64/128-byte head slice.  HBM-compulsory bytes are tiny; the kernel is
 // bound by L2/TA gather throughput, which is why value stays L2-resident across the B*M slabs.
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 using namespace emrt;
@@ -112,6 +113,18 @@ struct MsdaPrep {
   // here (the branch-free LDS loop then adds nothing for it) and the block gathers it from global memory afterwards
   unsigned miss;
   float smx, sinv;                                 // softmax max / 1 / denominator of the pair (to re-derive a missed sample)
+  // forward kernels, 16-bit value types: the weights of a sample's two corner ROWS, rounded to the value type and packed --
+  // wp0 = (w00 | w01 << 16), wp1 = (w10 | w11 << 16): operand B of a 2-way dot product whose operand A is (corner x0, corner x0 + 1) of one
+  // channel (msda_dot_row).  After pack16() the fp32 weights are dead in the forward kernels (3 values per sample to broadcast, not 5).
+  unsigned wp0[NS], wp1[NS];
+  template <class T>
+  __device__ __forceinline__ void pack16() {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) { wp0[j] = pack_f16x2(w00[j], w01[j]); wp1[j] = pack_f16x2(w10[j], w11[j]); }
+      else { wp0[j] = pack_bf16x2(w00[j], w01[j]); wp1[j] = pack_bf16x2(w10[j], w11[j]); }
+    }
+  }
 
   // row: the pair's fp32 [M*LP*2 offsets | M*LP logits] row; refp: its reference point(s); live: false for tail lanes
   // BAND: lo / hi = first / one-past-last staged row of every level (msda_fwd_band_kernel); samples outside get idx = lo * W
@@ -231,21 +244,64 @@ __device__ __forceinline__ void axpy8(float (&acc)[8], float w, const float (&v)
   for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, v[e], acc[e]);
 }
 
+// 16-bit value types: acc[e] += r0[e] * w.lo + r1[e] * w.hi over the lane's 8 channels, r0 / r1 = the raw 16 bytes of the corners x0 and
+// x0 + 1 of one row, w = their two weights in the value type.  Per pair of channels: two byte permutes bring (r0[c], r1[c]) and
+// (r0[c+1], r1[c+1]) together, two v_dot2_f32_{bf16,f16} accumulate in fp32: ONE instruction per multiply-add where unpack + fma needs two
+// (the gather is bound by VALU issue: 72 corners x 8 channels per lane and pair).  The price is the weights' rounding to the value type --
+// 2^-9 relative for bf16, the rounding every stored activation already carries; the products and the sums stay fp32.
+typedef __attribute__((ext_vector_type(2))) __bf16 msda_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 msda_f16x2_t;
+template <class T>
+__device__ __forceinline__ void msda_dot_row(float (&acc)[8], const uint4& r0, const uint4& r1, unsigned w) {
+  const unsigned a0[4] = {r0.x, r0.y, r0.z, r0.w}, a1[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lo = __builtin_amdgcn_perm(a1[i], a0[i], 0x05040100u);      // (r0 channel 2i, r1 channel 2i)
+    const unsigned hi = __builtin_amdgcn_perm(a1[i], a0[i], 0x07060302u);      // (r0 channel 2i + 1, r1 channel 2i + 1)
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      acc[2 * i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(msda_bf16x2_t, lo), __builtin_bit_cast(msda_bf16x2_t, w), acc[2 * i], false);
+      acc[2 * i + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(msda_bf16x2_t, hi), __builtin_bit_cast(msda_bf16x2_t, w), acc[2 * i + 1], false);
+    } else {
+      acc[2 * i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(msda_f16x2_t, lo), __builtin_bit_cast(msda_f16x2_t, w), acc[2 * i], false);
+      acc[2 * i + 1] = __builtin_amdgcn_fdot2(__builtin_bit_cast(msda_f16x2_t, hi), __builtin_bit_cast(msda_f16x2_t, w), acc[2 * i + 1], false);
+    }
+  }
+}
+#define MSDA_BCAST3(PP, SMP, W0, W1, ID)                                                                 \
+  do {                                                                                                   \
+    constexpr int K_ = (SMP) & 3, J_ = (SMP) >> 2;                                                       \
+    W0 = (unsigned)quad_bcast<K_>((int)(PP).wp0[J_]); W1 = (unsigned)quad_bcast<K_>((int)(PP).wp1[J_]); ID = quad_bcast<K_>((PP).idx[J_]); \
+  } while (0)
+
 #define MSDA_FWD_PITCH 64        /* bytes per LDS row of the staged forward slab (unpadded: see msda_fwd_lds_kernel) */
 template <class T, int L, int P, int SMP>
 __device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const T* vb, float (&acc)[8]) {
   if constexpr (SMP < L * P) {
     constexpr int l = SMP / P;
-    float c00, c01, c10, c11;
-    int id;
-    MSDA_BCAST5(pp, SMP, c00, c01, c10, c11, id);
     const int W = a.w[l];
-    const T* p00 = vb + ((long long)a.start[l] + id) * a.ldv;
-    float v[8];
-    if (c00 != 0.f) { load8<T>(p00, v); axpy8<T>(acc, c00, v); }
-    if (c01 != 0.f) { load8<T>(p00 + a.ldv, v); axpy8<T>(acc, c01, v); }
-    if (c10 != 0.f) { load8<T>(p00 + (long long)W * a.ldv, v); axpy8<T>(acc, c10, v); }
-    if (c11 != 0.f) { load8<T>(p00 + (long long)(W + 1) * a.ldv, v); axpy8<T>(acc, c11, v); }
+    if constexpr (sizeof(T) == 2) {                  // same arithmetic, same order as msda_gather_lds: bit-identical results
+      unsigned w0, w1;
+      int id;
+      MSDA_BCAST3(pp, SMP, w0, w1, id);
+      const T* p00 = vb + ((long long)a.start[l] + id) * a.ldv;
+      const uint4 z = make_uint4(0, 0, 0, 0);        // a corner of weight 0 is not read (it may lie outside the tensor) and contributes 0 * 0
+      const uint4 r00 = (w0 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00) : z;
+      const uint4 r01 = (w0 >> 16) ? *reinterpret_cast<const uint4*>(p00 + a.ldv) : z;
+      const uint4 r10 = (w1 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00 + (long long)W * a.ldv) : z;
+      const uint4 r11 = (w1 >> 16) ? *reinterpret_cast<const uint4*>(p00 + (long long)(W + 1) * a.ldv) : z;
+      msda_dot_row<T>(acc, r00, r01, w0);
+      msda_dot_row<T>(acc, r10, r11, w1);
+    } else {
+      float c00, c01, c10, c11;
+      int id;
+      MSDA_BCAST5(pp, SMP, c00, c01, c10, c11, id);
+      const T* p00 = vb + ((long long)a.start[l] + id) * a.ldv;
+      float v[8];
+      if (c00 != 0.f) { load8<T>(p00, v); axpy8<T>(acc, c00, v); }
+      if (c01 != 0.f) { load8<T>(p00 + a.ldv, v); axpy8<T>(acc, c01, v); }
+      if (c10 != 0.f) { load8<T>(p00 + (long long)W * a.ldv, v); axpy8<T>(acc, c10, v); }
+      if (c11 != 0.f) { load8<T>(p00 + (long long)(W + 1) * a.ldv, v); axpy8<T>(acc, c11, v); }
+    }
     msda_gather_global<T, L, P, SMP + 1>(a, pp, vb, acc);
   }
 }
@@ -270,13 +326,13 @@ __device__ __forceinline__ void msda_gather_lds(const MsdaArgs& a, MsdaPrep<L, P
 #pragma unroll
         for (int t = 1; t < L; ++t)
           if (l == t) { start = a.start[t]; W = a.w[t]; }
-        float c00, c01, c10, c11;
+        unsigned w0, w1;
         int id;
         switch (k) {
-          case 0: MSDA_BCAST5(pp, 0, c00, c01, c10, c11, id); break;
-          case 1: MSDA_BCAST5(pp, 1, c00, c01, c10, c11, id); break;
-          case 2: MSDA_BCAST5(pp, 2, c00, c01, c10, c11, id); break;
-          default: MSDA_BCAST5(pp, 3, c00, c01, c10, c11, id); break;
+          case 0: MSDA_BCAST3(pp, 0, w0, w1, id); break;
+          case 1: MSDA_BCAST3(pp, 1, w0, w1, id); break;
+          case 2: MSDA_BCAST3(pp, 2, w0, w1, id); break;
+          default: MSDA_BCAST3(pp, 3, w0, w1, id); break;
         }
         const unsigned char* p00 = vslab_sub + (start + id) * MSDA_FWD_PITCH;
         const unsigned char* p10 = p00 + W * MSDA_FWD_PITCH;
@@ -284,16 +340,13 @@ __device__ __forceinline__ void msda_gather_lds(const MsdaArgs& a, MsdaPrep<L, P
         const uint4 r01 = *reinterpret_cast<const uint4*>(p00 + MSDA_FWD_PITCH);
         const uint4 r10 = *reinterpret_cast<const uint4*>(p10);
         const uint4 r11 = *reinterpret_cast<const uint4*>(p10 + MSDA_FWD_PITCH);
-        float v[8];
-        Vec8<T>::unpack(r00, v); axpy8<T>(acc, c00, v);
-        Vec8<T>::unpack(r01, v); axpy8<T>(acc, c01, v);
-        Vec8<T>::unpack(r10, v); axpy8<T>(acc, c10, v);
-        Vec8<T>::unpack(r11, v); axpy8<T>(acc, c11, v);
+        msda_dot_row<T>(acc, r00, r01, w0);
+        msda_dot_row<T>(acc, r10, r11, w1);
       }
     }
 #pragma unroll
     for (int i = 0; i + 1 < NS; ++i) {                // next slot becomes slot 0
-      pp.w00[i] = pp.w00[i + 1]; pp.w01[i] = pp.w01[i + 1]; pp.w10[i] = pp.w10[i + 1]; pp.w11[i] = pp.w11[i + 1]; pp.idx[i] = pp.idx[i + 1];
+      pp.wp0[i] = pp.wp0[i + 1]; pp.wp1[i] = pp.wp1[i + 1]; pp.idx[i] = pp.idx[i + 1];
     }
   }
 }
@@ -314,6 +367,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
   const int q = (int)(bq - (long long)b * a.Lq);
   MsdaPrep<L, P> pp;
   pp.run(a, a.offw + bq * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2, m, sub, live);
+  if constexpr (sizeof(T) == 2) pp.template pack16<T>();
   const T* vb = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8;
   float acc[8];
 #pragma unroll
@@ -374,11 +428,12 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
     const int q = qw + (lane >> 2);
     const bool live = q < q_end;
     const int qq = live ? q : q_end - 1;          // tail lanes shadow the last query: the quad shuffles stay defined
-    if (!(probe & 4)) pp.run(a, a.offw + ((long long)b * a.Lq + qq) * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2, m, sub, live);
+    if (!(probe & 4)) { pp.run(a, a.offw + ((long long)b * a.Lq + qq) * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2, m, sub, live); pp.template pack16<T>(); }
   };
   if (probe & 4) {
 #pragma unroll
     for (int j = 0; j < MsdaPrep<L, P>::NS; ++j) { pp.w00[j] = 0.25f; pp.w01[j] = 0.25f; pp.w10[j] = 0.25f; pp.w11[j] = 0.25f; pp.idx[j] = (lane * 37 + j * 101) & 63; }
+    pp.template pack16<T>();
   }
   if (qw < q_end) prepare();
   __syncthreads();                                // (drains the LDS-DMA: vmcnt(0) in front of the barrier)
@@ -476,6 +531,7 @@ __global__ __launch_bounds__(1024) void msda_fwd_band_kernel(MsdaArgs a, int NB,
       const float* row = a.offw + ((long long)b * a.Lq + qq) * a.ldo;
       const float* refp = a.ref + (long long)b * a.ref_bs + (long long)qq * a.ref_L * 2;
       pp.template run<true>(a, row, refp, m, sub, live, lo, hi);
+      pp.template pack16<T>();
       unsigned mm = pp.miss;                        // (the gather below shifts the slots down: read the mask first)
       if (!staged) { __syncthreads(); staged = true; }        // drains the LDS-DMA (vmcnt(0) in front of the barrier)
       float acc[8];
@@ -505,11 +561,17 @@ __global__ __launch_bounds__(1024) void msda_fwd_band_kernel(MsdaArgs a, int NB,
           for (int t = 1; t < L; ++t)
             if (lev == t) { W = a.w[t]; st0 = a.start[t]; }
           const T* p00 = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8 + ((long long)st0 + id) * a.ldv;
-          float v[8];
-          if (c00 != 0.f) { load8<T>(p00, v); axpy8<T>(acc, c00, v); }
-          if (c01 != 0.f) { load8<T>(p00 + a.ldv, v); axpy8<T>(acc, c01, v); }
-          if (c10 != 0.f) { load8<T>(p00 + (long long)W * a.ldv, v); axpy8<T>(acc, c10, v); }
-          if (c11 != 0.f) { load8<T>(p00 + (long long)(W + 1) * a.ldv, v); axpy8<T>(acc, c11, v); }
+          // same rounded weights and dot products as the staged samples (a sample's contribution does not depend on where it was read)
+          unsigned w0, w1;
+          if constexpr (std::is_same<T, bf16_t>::value) { w0 = pack_bf16x2(c00, c01); w1 = pack_bf16x2(c10, c11); }
+          else { w0 = pack_f16x2(c00, c01); w1 = pack_f16x2(c10, c11); }
+          const uint4 z = make_uint4(0, 0, 0, 0);
+          const uint4 r00 = (w0 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00) : z;
+          const uint4 r01 = (w0 >> 16) ? *reinterpret_cast<const uint4*>(p00 + a.ldv) : z;
+          const uint4 r10 = (w1 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00 + (long long)W * a.ldv) : z;
+          const uint4 r11 = (w1 >> 16) ? *reinterpret_cast<const uint4*>(p00 + (long long)(W + 1) * a.ldv) : z;
+          msda_dot_row<T>(acc, r00, r01, w0);
+          msda_dot_row<T>(acc, r10, r11, w1);
         }
       }
       if (live) Vec8<T>::store((T*)a.out + ((long long)b * a.Lq + q) * (a.M * 32) + m * 32 + sub * 8, acc);
