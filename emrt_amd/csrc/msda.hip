@@ -121,7 +121,13 @@ struct MsdaPrep {
   __device__ __forceinline__ void pack16() {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) { wp0[j] = pack_f16x2(w00[j], w01[j]); wp1[j] = pack_f16x2(w10[j], w11[j]); }
+      if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) {
+        // v_cvt_pk_f16_f32 (round to nearest even) spelled out: through pack_f16x2's vector convert the slot arrays stayed in scratch memory
+        // (+3 us on the fp16 encoder call), and scalar converts let hipcc fuse the weights' last multiply into v_fma_mix in one kernel and
+        // not in the other (single against double rounding: the LDS and the global kernel then differed in 1 output of 15 000 by one ulp)
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(wp0[j]) : "v"(w00[j]), "v"(w01[j]));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(wp1[j]) : "v"(w10[j]), "v"(w11[j]));
+      }
       else { wp0[j] = pack_bf16x2(w00[j], w01[j]); wp1[j] = pack_bf16x2(w10[j], w11[j]); }
     }
   }
@@ -252,20 +258,23 @@ __device__ __forceinline__ void axpy8(float (&acc)[8], float w, const float (&v)
 typedef __attribute__((ext_vector_type(2))) __bf16 msda_bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 msda_f16x2_t;
 template <class T>
-__device__ __forceinline__ void msda_dot_row(float (&acc)[8], const uint4& r0, const uint4& r1, unsigned w) {
-  const unsigned a0[4] = {r0.x, r0.y, r0.z, r0.w}, a1[4] = {r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned lo = __builtin_amdgcn_perm(a1[i], a0[i], 0x05040100u);      // (r0 channel 2i, r1 channel 2i)
-    const unsigned hi = __builtin_amdgcn_perm(a1[i], a0[i], 0x07060302u);      // (r0 channel 2i + 1, r1 channel 2i + 1)
-    if constexpr (std::is_same<T, bf16_t>::value) {
-      acc[2 * i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(msda_bf16x2_t, lo), __builtin_bit_cast(msda_bf16x2_t, w), acc[2 * i], false);
-      acc[2 * i + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(msda_bf16x2_t, hi), __builtin_bit_cast(msda_bf16x2_t, w), acc[2 * i + 1], false);
-    } else {
-      acc[2 * i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(msda_f16x2_t, lo), __builtin_bit_cast(msda_f16x2_t, w), acc[2 * i], false);
-      acc[2 * i + 1] = __builtin_amdgcn_fdot2(__builtin_bit_cast(msda_f16x2_t, hi), __builtin_bit_cast(msda_f16x2_t, w), acc[2 * i + 1], false);
-    }
+__device__ __forceinline__ void msda_dot_pair(float& acc_even, float& acc_odd, unsigned x0, unsigned x1, unsigned w) {
+  const unsigned lo = __builtin_amdgcn_perm(x1, x0, 0x05040100u);      // (r0 even channel, r1 even channel)
+  const unsigned hi = __builtin_amdgcn_perm(x1, x0, 0x07060302u);      // (r0 odd channel, r1 odd channel)
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    acc_even = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(msda_bf16x2_t, lo), __builtin_bit_cast(msda_bf16x2_t, w), acc_even, false);
+    acc_odd = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(msda_bf16x2_t, hi), __builtin_bit_cast(msda_bf16x2_t, w), acc_odd, false);
+  } else {
+    acc_even = __builtin_amdgcn_fdot2(__builtin_bit_cast(msda_f16x2_t, lo), __builtin_bit_cast(msda_f16x2_t, w), acc_even, false);
+    acc_odd = __builtin_amdgcn_fdot2(__builtin_bit_cast(msda_f16x2_t, hi), __builtin_bit_cast(msda_f16x2_t, w), acc_odd, false);
   }
+}
+template <class T>
+__device__ __forceinline__ void msda_dot_row(float (&acc)[8], const uint4& r0, const uint4& r1, unsigned w) {
+  msda_dot_pair<T>(acc[0], acc[1], r0.x, r1.x, w);      // (components by name: a local array of them ended up in scratch memory)
+  msda_dot_pair<T>(acc[2], acc[3], r0.y, r1.y, w);
+  msda_dot_pair<T>(acc[4], acc[5], r0.z, r1.z, w);
+  msda_dot_pair<T>(acc[6], acc[7], r0.w, r1.w, w);
 }
 #define MSDA_BCAST3(PP, SMP, W0, W1, ID)                                                                 \
   do {                                                                                                   \
@@ -273,9 +282,19 @@ __device__ __forceinline__ void msda_dot_row(float (&acc)[8], const uint4& r0, c
     W0 = (unsigned)quad_bcast<K_>((int)(PP).wp0[J_]); W1 = (unsigned)quad_bcast<K_>((int)(PP).wp1[J_]); ID = quad_bcast<K_>((PP).idx[J_]); \
   } while (0)
 
+// 16 bytes through a buffer descriptor: an offset with bit 31 set is out of the descriptor's range and returns zeros -- a corner of weight
+// 0 (it may lie outside the tensor) costs neither a branch nor a select of addresses (which hipcc lowered to flat loads from a stack slot)
+typedef __attribute__((ext_vector_type(4))) unsigned int msda_u32x4_t;
+__device__ __forceinline__ uint4 msda_buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const msda_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+constexpr unsigned MSDA_OOB = 0x80000000u;
+
 #define MSDA_FWD_PITCH 64        /* bytes per LDS row of the staged forward slab (unpadded: see msda_fwd_lds_kernel) */
+// vb: the lane's pointer to (batch, pixel 0, head slice); rs / vb_bytes: the whole value tensor as a buffer + the lane's byte offset of the same
 template <class T, int L, int P, int SMP>
-__device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const T* vb, float (&acc)[8]) {
+__device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const MsdaPrep<L, P>& pp, const T* vb, __amdgpu_buffer_rsrc_t rs, unsigned vb_bytes, float (&acc)[8]) {
   if constexpr (SMP < L * P) {
     constexpr int l = SMP / P;
     const int W = a.w[l];
@@ -283,12 +302,13 @@ __device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const Msda
       unsigned w0, w1;
       int id;
       MSDA_BCAST3(pp, SMP, w0, w1, id);
-      const T* p00 = vb + ((long long)a.start[l] + id) * a.ldv;
-      const uint4 z = make_uint4(0, 0, 0, 0);        // a corner of weight 0 is not read (it may lie outside the tensor) and contributes 0 * 0
-      const uint4 r00 = (w0 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00) : z;
-      const uint4 r01 = (w0 >> 16) ? *reinterpret_cast<const uint4*>(p00 + a.ldv) : z;
-      const uint4 r10 = (w1 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00 + (long long)W * a.ldv) : z;
-      const uint4 r11 = (w1 >> 16) ? *reinterpret_cast<const uint4*>(p00 + (long long)(W + 1) * a.ldv) : z;
+      // a corner of weight 0 is not read (it may lie outside the tensor): its offset is out of range, the load returns 0, it contributes 0 * 0
+      const unsigned ld_b = (unsigned)a.ldv * 2u;
+      const unsigned o00 = vb_bytes + (unsigned)(a.start[l] + id) * ld_b;      // (garbage when no corner is valid: never used in range then)
+      const uint4 r00 = msda_buf_load16(rs, (w0 & 0xffffu) ? o00 : MSDA_OOB);
+      const uint4 r01 = msda_buf_load16(rs, (w0 >> 16) ? o00 + ld_b : MSDA_OOB);
+      const uint4 r10 = msda_buf_load16(rs, (w1 & 0xffffu) ? o00 + (unsigned)W * ld_b : MSDA_OOB);
+      const uint4 r11 = msda_buf_load16(rs, (w1 >> 16) ? o00 + (unsigned)(W + 1) * ld_b : MSDA_OOB);
       msda_dot_row<T>(acc, r00, r01, w0);
       msda_dot_row<T>(acc, r10, r11, w1);
     } else {
@@ -302,7 +322,7 @@ __device__ __forceinline__ void msda_gather_global(const MsdaArgs& a, const Msda
       if (c10 != 0.f) { load8<T>(p00 + (long long)W * a.ldv, v); axpy8<T>(acc, c10, v); }
       if (c11 != 0.f) { load8<T>(p00 + (long long)(W + 1) * a.ldv, v); axpy8<T>(acc, c11, v); }
     }
-    msda_gather_global<T, L, P, SMP + 1>(a, pp, vb, acc);
+    msda_gather_global<T, L, P, SMP + 1>(a, pp, vb, rs, vb_bytes, acc);
   }
 }
 
@@ -372,7 +392,10 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  msda_gather_global<T, L, P, 0>(a, pp, vb, acc);
+  // (16-bit value types: the host guarantees the tensor spans less than 2 GiB, so byte offsets fit the descriptor's 32 bits with bit 31 free)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.value, 0, (int)0x80000000u, 0x00020000);
+  const unsigned vb_bytes = (unsigned)(((long long)b * a.v_bs + m * 32 + sub * 8) * (long long)sizeof(T));
+  msda_gather_global<T, L, P, 0>(a, pp, vb, rs, vb_bytes, acc);
   if (live) Vec8<T>::store((T*)a.out + bq * (a.M * 32) + m * 32 + sub * 8, acc);
 }
 
@@ -506,6 +529,7 @@ __global__ __launch_bounds__(1024) void msda_fwd_band_kernel(MsdaArgs a, int NB,
   }
   MsdaPrep<L, P> pp;
   const unsigned char* vslab_sub = vslab_raw + sub * 16;
+  const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void*)a.value, 0, (int)0x80000000u, 0x00020000);      // (misses: see msda_buf_load16)
   bool staged = false;
   // the block's queries: its rows of every level, walked as ONE index space (a wave's 16 queries may straddle two levels)
   int seg_n[L], seg_q0[L];
@@ -560,16 +584,19 @@ __global__ __launch_bounds__(1024) void msda_fwd_band_kernel(MsdaArgs a, int NB,
 #pragma unroll
           for (int t = 1; t < L; ++t)
             if (lev == t) { W = a.w[t]; st0 = a.start[t]; }
-          const T* p00 = (const T*)a.value + (long long)b * a.v_bs + m * 32 + sub * 8 + ((long long)st0 + id) * a.ldv;
           // same rounded weights and dot products as the staged samples (a sample's contribution does not depend on where it was read)
           unsigned w0, w1;
           if constexpr (std::is_same<T, bf16_t>::value) { w0 = pack_bf16x2(c00, c01); w1 = pack_bf16x2(c10, c11); }
-          else { w0 = pack_f16x2(c00, c01); w1 = pack_f16x2(c10, c11); }
-          const uint4 z = make_uint4(0, 0, 0, 0);
-          const uint4 r00 = (w0 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00) : z;
-          const uint4 r01 = (w0 >> 16) ? *reinterpret_cast<const uint4*>(p00 + a.ldv) : z;
-          const uint4 r10 = (w1 & 0xffffu) ? *reinterpret_cast<const uint4*>(p00 + (long long)W * a.ldv) : z;
-          const uint4 r11 = (w1 >> 16) ? *reinterpret_cast<const uint4*>(p00 + (long long)(W + 1) * a.ldv) : z;
+          else {      // (the same instruction as MsdaPrep::pack16)
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w0) : "v"(c00), "v"(c01));
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w1) : "v"(c10), "v"(c11));
+          }
+          const unsigned ld_b = (unsigned)a.ldv * 2u;
+          const unsigned o00 = (unsigned)(((long long)b * a.v_bs + m * 32 + sub * 8) * 2) + (unsigned)(st0 + id) * ld_b;
+          const uint4 r00 = msda_buf_load16(rs_val, (w0 & 0xffffu) ? o00 : MSDA_OOB);
+          const uint4 r01 = msda_buf_load16(rs_val, (w0 >> 16) ? o00 + ld_b : MSDA_OOB);
+          const uint4 r10 = msda_buf_load16(rs_val, (w1 & 0xffffu) ? o00 + (unsigned)W * ld_b : MSDA_OOB);
+          const uint4 r11 = msda_buf_load16(rs_val, (w1 >> 16) ? o00 + (unsigned)(W + 1) * ld_b : MSDA_OOB);
           msda_dot_row<T>(acc, r00, r01, w0);
           msda_dot_row<T>(acc, r10, r11, w1);
         }
@@ -1591,6 +1618,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
   EMRT_REQUIRE(M >= 1 && L >= 1 && L <= 4 && P >= 1, "bad M/L/P");
   EMRT_REQUIRE(ldv % 8 == 0 && v_bs % 8 == 0 && ldo % 2 == 0, "value strides must be multiples of 8 elements");
   EMRT_REQUIRE(ldo >= M * L * P * 3, "offw row too short");
+  EMRT_REQUIRE(dtype == EMRT_F32 || ((long long)(B - 1) * v_bs + (long long)Lv * ldv) * 2 < (1ll << 31), "value tensor spans 2 GiB or more (32-bit buffer offsets)");
   MsdaArgs a;
   memset(&a, 0, sizeof(a));
   a.value = value; a.ldv = ldv; a.v_bs = v_bs; a.offw = offw; a.ldo = ldo; a.ref = ref; a.ref_bs = ref_bs; a.ref_L = ref_L; a.out = out;
