@@ -393,7 +393,11 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
               tile[((wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * CP + (wc * TN + j) * 32 + frow] = acc[i][j][r];
       }
       __syncthreads();
-      const int t = (int)threadIdx.x;
+      int t = (int)threadIdx.x;
+      // the thread id "again", opaque to the compiler: it otherwise keeps the prologue's 64-bit row index alive across the whole k loop for this
+      // epilogue -- at the 128-register cap of the 64x64 tile that was the one value spilled to scratch memory (a kernel that touches scratch
+      // pays for its set-up in every wave launch), and re-deriving it costs three instructions
+      asm volatile("" : "+v"(t));
       const int cg = t % CGR, rr = t / CGR;
       const int n0 = bn * BN + cg * 8;
       const bool col_ok = n0 < p.OC;                 // OC % 8 == 0: a group is all in or all out
