@@ -251,6 +251,41 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t salt, uint64_
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
+// Flat index -> coordinates for the grid-stride elementwise kernels.  idx = ((i3 * D2 + i2) * D1 + i1) * D0 + i0.
+// A 64-bit division is ~100 VALU instructions on gfx950 (no 64-bit divider, quarter-rate 32x32 multiplies): three of them per 16-byte vector
+// made these "memory-bound" kernels VALU-bound.  Every EMRT tensor has fewer than 2^32 elements, so the 32-bit form runs (a 32-bit division is
+// ~25 instructions); `small` is wave-uniform (idx < 2^32 for the whole grid), the 64-bit form stays for anything larger.
+__device__ __forceinline__ void unravel2(long long idx, int D0, bool small, int& i0, long long& i1) {
+  if (small) {
+    const unsigned r = (unsigned)idx, q = r / (unsigned)D0;
+    i0 = (int)(r - q * (unsigned)D0); i1 = (long long)q;
+  } else {
+    i1 = idx / D0; i0 = (int)(idx - i1 * D0);
+  }
+}
+__device__ __forceinline__ void unravel3(long long idx, int D0, int D1, bool small, int& i0, int& i1, long long& i2) {
+  if (small) {
+    unsigned r = (unsigned)idx, q = r / (unsigned)D0;
+    i0 = (int)(r - q * (unsigned)D0); r = q; q = r / (unsigned)D1;
+    i1 = (int)(r - q * (unsigned)D1); i2 = (long long)q;
+  } else {
+    long long r = idx / D0; i0 = (int)(idx - r * D0);
+    i2 = r / D1; i1 = (int)(r - i2 * D1);
+  }
+}
+__device__ __forceinline__ void unravel4(long long idx, int D0, int D1, int D2, bool small, int& i0, int& i1, int& i2, int& i3) {
+  if (small) {
+    unsigned r = (unsigned)idx, q = r / (unsigned)D0;
+    i0 = (int)(r - q * (unsigned)D0); r = q; q = r / (unsigned)D1;
+    i1 = (int)(r - q * (unsigned)D1); r = q; q = r / (unsigned)D2;
+    i2 = (int)(r - q * (unsigned)D2); i3 = (int)q;
+  } else {
+    long long r = idx / D0; i0 = (int)(idx - r * D0);
+    long long q = r / D1; i1 = (int)(r - q * D1); r = q;
+    q = r / D2; i2 = (int)(r - q * D2); i3 = (int)q;
+  }
+}
+
 // entry points with a backward / training-only meaning accept f32 and bf16; fp16 (dtype 2) is inference-only
 #define EMRT_REQUIRE_TRAIN_DTYPE(dtype) EMRT_REQUIRE((dtype) == EMRT_F32 || (dtype) == EMRT_BF16, "dtype must be 0 (f32) or 1 (bf16): fp16 (2) is inference-only")
 #define EMRT_REQUIRE_FWD_DTYPE(dtype) EMRT_REQUIRE((dtype) == EMRT_F32 || (dtype) == EMRT_BF16 || (dtype) == EMRT_F16, "dtype must be 0 (f32), 1 (bf16) or 2 (f16)")

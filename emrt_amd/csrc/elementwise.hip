@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float x[4], y[4];
     Vec4<T>::load(a + i * 4, x);
-    Vec4<T>::load(b + (i % period4) * 4, y);
+    Vec4<T>::load(b + ((n4 | period4) <= 0xffffffffll ? (long long)((unsigned)i % (unsigned)period4) : i % period4) * 4, y);      // (32-bit division: common.hpp, unravel)
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] += y[e];
     Vec4<T>::store(out + i * 4, x);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void add_f32row_kernel(const T* __restrict__ a
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float x[4];
     Vec4<T>::load(a + i * 4, x);
-    const float4 y = reinterpret_cast<const float4*>(b)[i % period4];
+    const float4 y = reinterpret_cast<const float4*>(b)[(n4 | period4) <= 0xffffffffll ? (long long)((unsigned)i % (unsigned)period4) : i % period4];
     x[0] += y.x; x[1] += y.y; x[2] += y.z; x[3] += y.w;
     Vec4<T>::store(out + i * 4, x);
   }
@@ -109,9 +109,10 @@ __global__ __launch_bounds__(256) void acc3d_kernel(T* __restrict__ dst, long lo
                                                     long long src_bs, long long src_rs, long long B, long long rows, long long cols4) {
   const long long total = B * rows * cols4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long c = (i % cols4) * 4;
-    const long long br = i / cols4;
-    const long long r = br % rows, b = br / rows;
+    int c4, ri;
+    long long b;
+    unravel3(i, (int)cols4, (int)rows, total <= 0xffffffffll, c4, ri, b);      // (rows, cols < 2^31: host-checked)
+    const long long c = (long long)c4 * 4, r = ri;
     float x[4], y[4];
     Vec4<T>::load(dst + b * dst_bs + r * dst_rs + c, x);
     Vec4<T>::load(src + b * src_bs + r * src_rs + c, y);
@@ -128,9 +129,10 @@ __global__ __launch_bounds__(256) void add3d_kernel(const T* __restrict__ a, lon
                                                     long long B, long long rows, long long cols4) {
   const long long total = B * rows * cols4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long c = (i % cols4) * 4;
-    const long long br = i / cols4;
-    const long long r = br % rows, b = br / rows;
+    int c4, ri;
+    long long b;
+    unravel3(i, (int)cols4, (int)rows, total <= 0xffffffffll, c4, ri, b);      // (rows, cols < 2^31: host-checked)
+    const long long c = (long long)c4 * 4, r = ri;
     float x[4], y[4];
     Vec4<T>::load(a + b * a_bs + r * a_rs + c, x);
     Vec4<T>::load(b2 + b * b_bs + r * b_rs + c, y);
@@ -227,6 +229,7 @@ extern "C" int emrt_add3d(const void* a, long long a_bs, long long a_rs, const v
   EMRT_REQUIRE(a && b && out, "null pointer");
   EMRT_REQUIRE(cols % 4 == 0 && a_rs % 4 == 0 && b_rs % 4 == 0 && out_rs % 4 == 0 && a_bs % 4 == 0 && b_bs % 4 == 0 && out_bs % 4 == 0,
                "cols and strides must be multiples of 4");
+  EMRT_REQUIRE(B > 0 && rows > 0 && cols > 0 && rows < (1ll << 31) && cols < (1ll << 31), "rows / cols must be in [1, 2^31)");
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid(B * rows * (cols / 4));
   if (dtype == EMRT_F32) hipLaunchKernelGGL((add3d_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, a_bs, a_rs, (const float*)b, b_bs, b_rs, (float*)out, out_bs, out_rs, B, rows, cols / 4);
@@ -247,9 +250,10 @@ template <class T, int SPLIT>
 __global__ __launch_bounds__(256) void concat_tokens_kernel(ConcatArgs a, T* __restrict__ whole) {
   const long long count = (long long)a.B * a.total * a.C4;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += (long long)gridDim.x * blockDim.x) {
-    const int q = (int)(idx % a.C4);
-    long long r = idx / a.C4;
-    const int row = (int)(r % a.total), b = (int)(r / a.total);
+    int q, row;
+    long long bb;
+    unravel3(idx, a.C4, a.total, count <= 0xffffffffll, q, row, bb);
+    const int b = (int)bb;
     int p = 0;
 #pragma unroll
     for (int k = 1; k < EMRT_MAX_PARTS; ++k)
@@ -287,6 +291,7 @@ extern "C" int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const v
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(dst && src, "null pointer");
   EMRT_REQUIRE(cols % 4 == 0 && dst_rs % 4 == 0 && src_rs % 4 == 0 && dst_bs % 4 == 0 && src_bs % 4 == 0, "cols and strides must be multiples of 4");
+  EMRT_REQUIRE(B > 0 && rows > 0 && cols > 0 && rows < (1ll << 31) && cols < (1ll << 31), "rows / cols must be in [1, 2^31)");
   hipStream_t st = (hipStream_t)stream;
   const int grid = ew_grid(B * rows * (cols / 4));
   if (dtype == EMRT_F32) hipLaunchKernelGGL((acc3d_kernel<float>), dim3(grid), dim3(256), 0, st, (float*)dst, dst_bs, dst_rs, (const float*)src, src_bs, src_rs, B, rows, cols / 4);

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long lab = labels[idx];
     if (lab == ignore_index) continue;
-    const long long n = idx / HW, p = idx - n * HW;
+    const long long n = total <= 0xffffffffll ? (long long)((unsigned)idx / (unsigned)HW) : idx / HW, p = idx - n * HW;      // (32-bit division when it can be)
     const float* lp = logits + n * C * HW + p;
     float mx = -3.0e38f;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[c * HW]);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   const float g = weight * (upstream ? upstream[0] : 1.f) / fmaxf(result[1], 1.f);      // (all-ignored batch: zero gradient)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long lab = labels[idx];
-    const long long n = idx / HW, p = idx - n * HW;
+    const long long n = total <= 0xffffffffll ? (long long)((unsigned)idx / (unsigned)HW) : idx / HW, p = idx - n * HW;      // (32-bit division when it can be)
     const float* lp = logits + n * C * HW + p;
     float* dp = dlogits + n * C * HW + p;
     if (lab == ignore_index) {

@@ -381,9 +381,11 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
   const bool live = pair_raw < total;
   const long long pair = live ? pair_raw : total - 1;   // tail lanes shadow a live pair: the quad shuffles stay defined
   const int sub = lane & 3;
-  const int m = (int)(pair % a.M);
-  const long long bq = pair / a.M;
-  const int b = (int)(bq / a.Lq);
+  // (32-bit divisions when the pair count allows: a 64-bit one is ~100 instructions, common.hpp unravel)
+  const bool small = total <= 0xffffffffll;
+  const long long bq = small ? (long long)((unsigned)pair / (unsigned)a.M) : pair / a.M;
+  const int m = (int)(pair - bq * a.M);
+  const int b = small ? (int)((unsigned)bq / (unsigned)a.Lq) : (int)(bq / a.Lq);
   const int q = (int)(bq - (long long)b * a.Lq);
   MsdaPrep<L, P> pp;
   pp.run(a, a.offw + bq * a.ldo, a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2, m, sub, live);
@@ -655,9 +657,11 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(MsdaArgs a) {
   const bool live = pair_raw < total;
   const long long pair = live ? pair_raw : total - 1;   // dead lanes shadow a live pair so shuffles stay full-wave
   const int sub = lane & 3;
-  const int m = (int)(pair % a.M);
-  const long long bq = pair / a.M;
-  const int b = (int)(bq / a.Lq);
+  // (32-bit divisions when the pair count allows: a 64-bit one is ~100 instructions, common.hpp unravel)
+  const bool small = total <= 0xffffffffll;
+  const long long bq = small ? (long long)((unsigned)pair / (unsigned)a.M) : pair / a.M;
+  const int m = (int)(pair - bq * a.M);
+  const int b = small ? (int)((unsigned)bq / (unsigned)a.Lq) : (int)(bq / a.Lq);
   const int q = (int)(bq - (long long)b * a.Lq);
 
   const float* row = a.offw + bq * a.ldo;

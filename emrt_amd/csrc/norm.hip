@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
         }
         r += 3 * rs;
       } else {
-        const long long bb = r / rpb;   // batch-strided rows: row r = (batch bb, row r - bb*rpb)
+        const long long bb = (M | rpb) <= 0xffffffffll ? (long long)((unsigned)r / (unsigned)rpb) : r / rpb;   // batch-strided rows: row r = (batch bb, row r - bb*rpb); 32-bit division when it can be
         Vec4<T>::load(x + bb * bs + (r - bb * rpb) * ldx + c, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s0[e] += v[e];

@@ -59,11 +59,9 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs a) {
   const int cv = a.C / VEC;
   const long long total = (long long)a.N * a.OH * a.OW * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cv) * VEC;
-    long long r = idx / cv;
-    const int ow = (int)(r % a.OW); r /= a.OW;
-    const int oh = (int)(r % a.OH);
-    const int n = (int)(r / a.OH);
+    int c, ow, oh, n;
+    unravel4(idx, cv, a.OW, a.OH, total <= 0xffffffffll, c, ow, oh, n);
+    c *= VEC;
     int y0, y1, x0, x1;
     float wy0, wy1, wx0, wx1;
     axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
@@ -102,11 +100,8 @@ template <class T>
 __global__ __launch_bounds__(256) void resize_fwd_nchw_kernel(ResizeArgs a) {
   const long long total = (long long)a.N * a.C * a.OH * a.OW;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int ow = (int)(idx % a.OW);
-    long long r = idx / a.OW;
-    const int oh = (int)(r % a.OH); r /= a.OH;
-    const int c = (int)(r % a.C);
-    const int n = (int)(r / a.C);
+    int ow, oh, c, n;
+    unravel4(idx, a.OW, a.OH, a.C, total <= 0xffffffffll, ow, oh, c, n);
     int y0, y1, x0, x1;
     float wy0, wy1, wx0, wx1;
     axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
@@ -154,11 +149,9 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
   const int cv = a.C / VEC;
   const long long total = (long long)a.N * a.IH * a.IW * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cv) * VEC;
-    long long r = idx / cv;
-    const int iw = (int)(r % a.IW); r /= a.IW;
-    const int ih = (int)(r % a.IH);
-    const int n = (int)(r / a.IH);
+    int c, iw, ih, n;
+    unravel4(idx, cv, a.IW, a.IH, total <= 0xffffffffll, c, iw, ih, n);
+    c *= VEC;
     int ylo, yhi, xlo, xhi;
     axis_range(a.ay, ih, a.OH, ylo, yhi);
     axis_range(a.ax, iw, a.OW, xlo, xhi);
@@ -255,8 +248,9 @@ __global__ __launch_bounds__(256) void resize_bwd_nchw_w_kernel(ResizeBwdArgs a,
   const long long total = (long long)a.N * a.C * a.OH * a.IW;
   const float* __restrict__ g = (const float*)a.dout;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int iw = (int)(idx % a.IW);
-    const long long row = idx / a.IW;            // (n, c, oh)
+    int iw;
+    long long row;                               // (n, c, oh)
+    unravel2(idx, a.IW, total <= 0xffffffffll, iw, row);
     int xlo, xhi;
     axis_range(a.ax, iw, a.OW, xlo, xhi);
     const float* gr = g + row * a.OW;
@@ -270,11 +264,8 @@ template <class T>
 __global__ __launch_bounds__(256) void resize_bwd_nchw_h_kernel(ResizeBwdArgs a, const float* __restrict__ tmp) {
   const long long total = (long long)a.N * a.C * a.IH * a.IW;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int iw = (int)(idx % a.IW);
-    long long r = idx / a.IW;
-    const int ih = (int)(r % a.IH); r /= a.IH;
-    const int c = (int)(r % a.C);
-    const int n = (int)(r / a.C);
+    int iw, ih, c, n;
+    unravel4(idx, a.IW, a.IH, a.C, total <= 0xffffffffll, iw, ih, c, n);
     int ylo, yhi;
     axis_range(a.ay, ih, a.OH, ylo, yhi);
     const float* tp = tmp + ((long long)n * a.C + c) * a.OH * a.IW + iw;
@@ -378,11 +369,8 @@ template <class T>
 __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(PoolArgs a) {
   const long long total = (long long)a.N * a.H * a.W * a.C;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % a.C);
-    long long r = idx / a.C;
-    const int w = (int)(r % a.W); r /= a.W;
-    const int h = (int)(r % a.H);
-    const int n = (int)(r / a.H);
+    int c, w, h, n;
+    unravel4(idx, a.C, a.W, a.H, total <= 0xffffffffll, c, w, h, n);
     const T* gp = (const T*)a.out + (long long)n * a.out_bs + c;   // tokens gradient
     float acc = 0.f;
     for (int s = 0; s < a.nscales; ++s) {
@@ -411,11 +399,9 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_vec_kernel(PoolArgs a) 
   const int cq = a.C / 4;
   const long long total = (long long)a.N * a.H * a.W * cq;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cq) * 4;
-    long long r = idx / cq;
-    const int w = (int)(r % a.W); r /= a.W;
-    const int h = (int)(r % a.H);
-    const int n = (int)(r / a.H);
+    int c, w, h, n;
+    unravel4(idx, cq, a.W, a.H, total <= 0xffffffffll, c, w, h, n);
+    c *= 4;
     const T* gp = (const T*)a.out + (long long)n * a.out_bs + c;   // tokens gradient
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < a.nscales; ++s) {
@@ -453,11 +439,8 @@ template <class T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxPoolArgs a) {
   const long long total = (long long)a.N * a.OH * a.OW * a.C;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % a.C);
-    long long r = idx / a.C;
-    const int ow = (int)(r % a.OW); r /= a.OW;
-    const int oh = (int)(r % a.OH);
-    const int n = (int)(r / a.OH);
+    int c, ow, oh, n;
+    unravel4(idx, a.C, a.OW, a.OH, total <= 0xffffffffll, c, ow, oh, n);
     float best = -INFINITY;
     int slot = 255;
     for (int kh = 0; kh < a.k; ++kh) {
@@ -482,11 +465,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec8_kernel(MaxPoolArgs a) {
   const int cv = a.C / 8;
   const long long total = (long long)a.N * a.OH * a.OW * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cv) * 8;
-    long long r = idx / cv;
-    const int ow = (int)(r % a.OW); r /= a.OW;
-    const int oh = (int)(r % a.OH);
-    const int n = (int)(r / a.OH);
+    int c, ow, oh, n;
+    unravel4(idx, cv, a.OW, a.OH, total <= 0xffffffffll, c, ow, oh, n);
+    c *= 8;
     float best[8];
     int slot[8];
 #pragma unroll
@@ -521,11 +502,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
   const int cv = a.C / VEC;
   const long long total = (long long)a.N * a.H * a.W * cv;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cv) * VEC;
-    long long r = idx / cv;
-    const int w = (int)(r % a.W); r /= a.W;
-    const int h = (int)(r % a.H);
-    const int n = (int)(r / a.H);
+    int c, w, h, n;
+    unravel4(idx, cv, a.W, a.H, total <= 0xffffffffll, c, w, h, n);
+    c *= VEC;
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
@@ -571,11 +550,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   // weight gradients) on the 16-byte vector path of the GEMM kernels
   const long long total = (long long)N * H * W * CO;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % CO);
-    long long r = idx / CO;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
+    int c, w, h, n;
+    unravel4(idx, CO, W, H, total <= 0xffffffffll, c, w, h, n);
     out[idx] = from_f32<T>(c < C ? in[(((long long)n * C + c) * H + h) * W + w] : 0.f);
   }
 }
@@ -586,7 +562,9 @@ template <class T, int CO>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pix_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, long long HW) {
   const long long total = (long long)N * HW;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const long long n = idx / HW, p = idx - n * HW;
+    long long n, p;
+    if (total <= 0xffffffffll) { const unsigned q = (unsigned)idx / (unsigned)HW; n = q; p = (unsigned)idx - q * (unsigned)HW; }      // (32-bit division: common.hpp, unravel)
+    else { n = idx / HW; p = idx - n * HW; }
     float v[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) v[c] = c < C ? in[(n * C + c) * HW + p] : 0.f;
@@ -830,11 +808,8 @@ struct WindowArgs {
 __global__ __launch_bounds__(256) void crop_windows_kernel(const float* __restrict__ img, float* __restrict__ batch, WindowArgs a) {
   const long long total = (long long)a.n * a.C * a.ch * a.cw;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(idx % a.cw);
-    long long r = idx / a.cw;
-    const int y = (int)(r % a.ch); r /= a.ch;
-    const int c = (int)(r % a.C);
-    const int j = (int)(r / a.C);
+    int x, y, c, j;
+    unravel4(idx, a.cw, a.ch, a.C, total <= 0xffffffffll, x, y, c, j);
     batch[idx] = img[((long long)c * a.H + a.y0[j] + y) * a.W + a.x0[j] + x];
   }
 }
@@ -844,10 +819,10 @@ __global__ __launch_bounds__(256) void window_accumulate_kernel(const float* __r
                                                                 float* __restrict__ count, WindowArgs a) {
   const long long total = (long long)a.C * a.H * a.W;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(idx % a.W);
-    long long r = idx / a.W;
-    const int y = (int)(r % a.H);
-    const int c = (int)(r / a.H);
+    int x, y;
+    long long cc;
+    unravel3(idx, a.W, a.H, total <= 0xffffffffll, x, y, cc);
+    const int c = (int)cc;
     float s = 0.f, k = 0.f;
     for (int j = 0; j < a.n; ++j) {
       const int yy = y - a.y0[j], xx = x - a.x0[j];
@@ -868,10 +843,11 @@ __global__ __launch_bounds__(256) void window_accumulate_vec4_kernel(const float
   const int W4 = a.W / 4;
   const long long total = (long long)a.C * a.H * W4;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(idx % W4) * 4;
-    long long r = idx / W4;
-    const int y = (int)(r % a.H);
-    const int c = (int)(r / a.H);
+    int x, y;
+    long long cc;
+    unravel3(idx, W4, a.H, total <= 0xffffffffll, x, y, cc);
+    x *= 4;
+    const int c = (int)cc;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float k = 0.f;
     for (int j = 0; j < a.n; ++j) {
