@@ -342,7 +342,9 @@ static bool wgrad8p_plan(const WgradArgs& a, int& tiles_k, int& tiles_oc, int& S
   if (S < 1) return false;                             // too few pixels per block: prologue / epilogue dominated
   steps_per = (steps + S - 1) / S;
   S = (steps + steps_per - 1) / steps_per;
-  return g_tune.wgrad8p_force || (long long)tiles * S >= 160;
+  // >= 8 output tiles: with fewer (the FFN linears at 512x512: 4 tiles x 42 slices) the slab traffic per FLOP is too high and the 128 x 128
+  // kernel wins (tools/bench_conv.py wbig: 35.0 vs 38.8 us)
+  return g_tune.wgrad8p_force || ((long long)tiles * S >= 160 && tiles >= 8);
 }
 
 static int launch_wgrad8p(const WgradArgs& a, int tiles_k, int tiles_oc, int S, int steps_per, hipStream_t st) {
