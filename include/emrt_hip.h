@@ -124,7 +124,10 @@ int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gam
 /* ---- multi-scale deformable attention core (fused softmax + sampling locations + bilinear gather + weighted sum)
  * replaces transformer_encoder_decoder.py:89-104 and EMRT_utils/utils.py:64-97 (deformable_attention_core_func).
  * value [B][Lv][M*D] (D = 32); offw fp32 [B*Lq][ldo] = M*L*P*2 offsets then M*L*P logits per row;
- * ref fp32 [B or 1][Lq][ref_L][2] (ref_bs = 0 broadcasts over batch; ref_L = L, or 1 to share one point across levels); shapes_hw: HOST int [L][2] = (H_l, W_l); out [B][Lq][M*D]. */
+ * ref fp32 [B or 1][Lq][ref_L][2] (ref_bs = 0 broadcasts over batch; ref_L = L, or 1 to share one point across levels); shapes_hw: HOST int [L][2] = (H_l, W_l); out [B][Lq][M*D].
+ * Arithmetic: softmax, coordinates and corner weights in fp32; with a 16-bit value type the corner weights are then rounded to that type and the
+ * weighted sum is a chain of 2-way dot products with fp32 accumulation (forward relative L2 error 2.3e-3 in bf16 = output rounding + weight rounding;
+ * fp32 maps keep fp32 weights); 16-bit value tensors must span less than 2 GiB (32-bit buffer offsets). */
 int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, void* out, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, int dtype, void* stream);
 /* Backward.  doffw [B*Lq][ldo] (fp32, or the compute dtype when doffw_compute_dtype != 0 and dtype is a 2-byte type: what the
  * offsets|logits projection's backward GEMM reads) is overwritten; dref [B][Lq][ref_L][2] (nullable) must be ZEROED by the caller (the
