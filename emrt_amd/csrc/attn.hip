@@ -286,8 +286,9 @@ extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, cons
   hipStream_t st = (hipStream_t)stream;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)mha_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    hipFuncSetAttribute((const void*)mha_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (hipFuncSetAttribute((const void*)mha_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mha_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
+      return fail("emrt_mha_bwd", "cannot raise the dynamic LDS limit");
     attr_done = true;
   }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_bwd_kernel<float>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);

@@ -147,8 +147,6 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   const long long M = (long long)p.N * OHW;
   const int chunk = tid & 7, row0 = tid >> 3;
 
-  const T* __restrict__ inp = (const T*)p.in;
-  const T* __restrict__ wp = (const T*)p.w;
   const int K = p.KH * p.KW * p.C;
   const int nkt = ((K + BK - 1) / BK + G - 1) / G;       // k-tiles walked by each group (tiles past K are all-zero)
 

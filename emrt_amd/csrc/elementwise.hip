@@ -401,6 +401,5 @@ extern "C" int emrt_event_elapsed_ms(void* start, void* stop, float* ms) {
   return 0;
 }
 extern "C" int emrt_event_destroy(void* ev) {
-  hipEventDestroy((hipEvent_t)ev);
-  return 0;
+  return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? 0 : emrt::fail("emrt_event_destroy", "hipEventDestroy failed");
 }

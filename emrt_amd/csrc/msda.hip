@@ -374,7 +374,6 @@ __device__ __forceinline__ void msda_gather_lds(const MsdaArgs& a, MsdaPrep<L, P
 // Gather straight from global memory (L2): fp32 maps, slabs that do not fit in LDS (512x512 tiles), small launches.
 template <class T, int L, int P>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaArgs a) {
-  constexpr int LP = L * P;
   const int lane = threadIdx.x & 63;
   const long long pair_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
   const long long total = (long long)a.B * a.Lq * a.M;
@@ -488,7 +487,6 @@ __global__ __launch_bounds__(1024) void msda_fwd_lds_kernel(MsdaArgs a, int q_pe
 template <class T, int L, int P>
 __global__ __launch_bounds__(1024) void msda_fwd_band_kernel(MsdaArgs a, int NB, int halo, int guard) {
   static_assert(sizeof(T) == 2, "the staged slab is sized for 2-byte elements");
-  constexpr int LP = L * P;
   extern __shared__ __attribute__((aligned(16))) unsigned char vslab_raw[];
   int bid = blockIdx.x;
   const int nblk = gridDim.x;

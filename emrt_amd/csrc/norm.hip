@@ -1191,13 +1191,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
     if ((dtype) == EMRT_F32) { EXPR_F32; } else if ((dtype) == EMRT_BF16) { EXPR_BF16; } else { EXPR_F16; } \
   } while (0)
 
-static inline int ew_grid(long long total) {
-  long long g = (total + 255) / 256;
-  if (g > 4096) g = 4096;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-
 extern "C" size_t emrt_colreduce_workspace_bytes(long long M, int C) {
   int tx, gx, gy;
   col_reduce_geometry(M, C, tx, gx, gy);
