@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from .runtime import ctx, dtype_of, F32, BF16, F16
+from .runtime import ctx, dtype_of, F32
 
 
 def _L():

@@ -9,14 +9,13 @@ range, and keeps the packed compute-dtype copies of all GEMM weights (forward la
 transposed dgrad layout [C][KH][KW][OC]) that emrt_pack_weights refreshes once per optimizer step.
 Conv weights keep the reference's logical shape [OC, C, KH, KW] in the state dict but live in memory as OHWI.
 """
-import ctypes
 
 import torch
 import torch.nn as tnn
 
 from . import _lib
 from . import functional as Fn
-from .runtime import ctx, F32, BF16, _TORCH_DTYPE
+from .runtime import ctx, F32, _TORCH_DTYPE
 
 
 # element alignment of weight matrices in the flat buffers / of their transposed copies (measured 8 ... 2048: 729 -> 744 tiles/s;

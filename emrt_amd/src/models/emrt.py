@@ -23,7 +23,7 @@ import torch.nn as tnn
 
 from ... import functional as Fn
 from ... import nn as hnn
-from ...runtime import ctx, Tape, F32, BF16
+from ...runtime import ctx, Tape, F32
 
 NOGRAD_PARAMS = ("backbone.fc.weight", "backbone.fc.bias", "model.tgt_embed.weight")
 # parameters whose gradient is only final after the ops recorded before the tape's split mark (ResNet.forward) have run
