@@ -49,7 +49,8 @@ GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: pe
                  "emrt_conv2d_bwd_group": "bwd_group_kernel (emrt_conv2d_bwd_group)",
                  "emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
                  "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel + wgrad_kernel / wgrad8p_kernel (emrt_conv2d_bwd: data + weight gradients; paired launch for small layers, 256x256 LDS-DMA kernels for the large ones)",
-                 "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)"}
+                 "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)",
+                 "emrt_conv2d_wgrad_group": "wgrad_group_kernel / wgrad8p_kernel (emrt_conv2d_wgrad_group: the weight gradients of up to 24 layers per launch)"}
 
 
 def log(*a):
@@ -65,14 +66,15 @@ def conv_flops(name, a):
         if mode == 0:
             return 2.0 * N * OH * OW * OC * KH * KW * C
         return 2.0 * N * H * W * C * KH * KW * OC          # dgrad: useful MACs = those of the forward conv
-    if name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group"):      # a[0]: ctypes array of descriptors, a[1]: how many
-        f = 2.0 if name == "emrt_conv2d_group" else 4.0
-        return sum(f * d.N * d.OH * d.OW * d.OC * d.KH * d.KW * d.C for d in list(a[0])[:a[1]])
-    if name == "emrt_conv2d_bwd":           # data gradient + weight gradient of one layer
+    if name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad_group"):      # a[0]: ctypes array of descriptors, a[1]: how many
+        ds = list(a[0])[:a[1]]
+        f = 4.0 if (name == "emrt_conv2d_bwd_group" and ds[0].dw) else 2.0       # (a backward group without dw: the data gradients only)
+        return sum(f * d.N * d.OH * d.OW * d.OC * d.KH * d.KW * d.C for d in ds)
+    if name == "emrt_conv2d_bwd":           # data gradient (+ weight gradient unless dw == NULL: batched elsewhere) of one layer
         N, H, W, C = a[9:13]
         OH, OW, OC = a[15:18]
         KH, KW = a[20:22]
-        return 4.0 * N * OH * OW * OC * KH * KW * C
+        return (4.0 if a[7] else 2.0) * N * OH * OW * OC * KH * KW * C
     N, H, W, C = a[3:7]
     OH, OW, OC = a[9:12]
     KH, KW = a[14:16]
@@ -120,7 +122,7 @@ def dump_calls(path, calls):
                 extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
             elif name == "emrt_conv2d_wgrad":
                 extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
-            elif name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group"):
+            elif name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad_group"):
                 extra = "n=%d " % vals[1] + " ".join("%dx%dx%d->%d k%d" % (d.H, d.W, d.C, d.OC, d.KH) for d in list(vals[0])[:vals[1]]) + " gflop %.2f" % (conv_flops(name, vals) / 1e9)
             else:       # integer arguments only: enough to recognise the layer
                 extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))

@@ -1356,6 +1356,7 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   const long long nd = ((Md + 63) / 64) * ((d.OC + 63) / 64);                 // 64x64 dgrad tiles
   const int nkt = (d.KH * d.KW * d.C + BK - 1) / BK;
   const bool big_tile = d.OC > 64 && nkt >= 16 && ((Md + 127) / 128) * ((d.OC + 127) / 128) >= 256;   // conv_pick_tile would take 128x128
+  if (!w0.dw) return conv_dispatch<T, 1>(d, st);      // data gradient only: the caller batches the weight gradient (emrt_conv2d_wgrad_group)
   if (thin_bwd_ok<T>(d, w0) && !g_tune.no_thin_bwd) return thin_bwd_launch<T>(d, w0, st);
   int tx = 0, ty = 0, S = 0;
   if (vec_w) wgrad_plan<T>(w, tx, ty, S);
@@ -1390,7 +1391,8 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
                                int KH, int KW, int stride, int pad, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
                                float mask_scale, const void* stat_x, int ldsx, long long sx_bs, const void* addend, int ldadd, long long add_bs,
                                int dilation, int dtype, void* stream) {
-  EMRT_REQUIRE(x && dy && w_bwd_packed && dx && dw, "null pointer");
+  EMRT_REQUIRE(x && dy && w_bwd_packed && dx, "null pointer");
+  EMRT_REQUIRE(dw || !dbias, "dw == NULL asks for the data gradient only: the bias gradient travels with the deferred weight gradient");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
   EMRT_REQUIRE(OH == (H + 2 * pad - dilation * (KH - 1) - 1) / stride + 1 && OW == (W + 2 * pad - dilation * (KW - 1) - 1) / stride + 1, "output size mismatch");
@@ -1451,13 +1453,13 @@ struct BwdGroupArgs {
   int nd[EMRT_MAX_GROUP], wtx[EMRT_MAX_GROUP], wty[EMRT_MAX_GROUP];
 };
 
-template <class T>
+template <class T, int MODE = 0>
 __global__ __launch_bounds__(256, 4) void igemm_group_kernel(ConvGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   int i = 0;
 #pragma unroll
   for (int k = 1; k < EMRT_MAX_GROUP; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
-  igemm_body<T, 1, 1, 2, 2, 0, true, 3, 1>(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], smem_all);
+  igemm_body<T, 1, 1, 2, 2, MODE, true, 3, 1>(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], smem_all);
 }
 
 template <class T>
@@ -1536,9 +1538,44 @@ extern "C" int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, vo
   return dtype == EMRT_F32 ? conv_group_dispatch<float>(descs, n, st) : conv_group_dispatch<bf16_t>(descs, n, st);
 }
 
+// dw == NULL in every descriptor: the data gradients only, as one grouped launch of 64x64 dgrad tiles (the weight gradients are
+// batched by the caller: emrt_conv2d_wgrad_group)
+template <class T>
+static int conv_dgrad_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStream_t st) {
+  ConvGroupArgs g;
+  bool groupable = true;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const EmrtConvBwdDesc& b = descs[i];
+    ConvArgs& d = g.p[i];
+    d.in = b.dy; d.w = b.w_bwd_packed; d.out = b.dx; d.bias = nullptr; d.scale = nullptr; d.res = b.accumulate ? b.dx : nullptr;
+    d.N = b.N; d.H = b.OH; d.W = b.OW; d.C = b.OC; d.ldin = b.lddy; d.in_bs = b.dy_bs;
+    d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
+    d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
+    d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.cmajor = 0; d.stats = nullptr;
+    d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
+    const long long Md = (long long)d.N * d.OH * d.OW;
+    g.first[i] = (int)total;
+    total += ((Md + 63) / 64) * ((d.OC + 63) / 64);
+    groupable = groupable && conv_desc_is_vec<T>(d) && d.OC > 32;
+  }
+  for (int i = n; i <= EMRT_MAX_GROUP; ++i) g.first[i] = (int)total;
+  for (int i = n; i < EMRT_MAX_GROUP; ++i) g.p[i] = g.p[0];
+  if (!groupable || total > 4096) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = conv_dispatch<T, 1>(g.p[i], st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL((igemm_group_kernel<T, 1>), dim3((unsigned)total), dim3(256), (size_t)2 * 128 * 144, st, g);
+  return check_launch("emrt_conv2d_bwd_group");
+}
+
 template <class T>
 static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStream_t st) {
   using Cfg = WgradCfg<T>;
+  if (!descs[0].dw) return conv_dgrad_group_dispatch<T>(descs, n, st);
   BwdGroupArgs g;
   bool groupable = true;
   long long total = 0;
@@ -1593,7 +1630,8 @@ extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dt
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   for (int i = 0; i < n; ++i) {
     const EmrtConvBwdDesc& b = descs[i];
-    EMRT_REQUIRE(b.x && b.dy && b.w_bwd_packed && b.dx && b.dw, "null pointer");
+    EMRT_REQUIRE(b.x && b.dy && b.w_bwd_packed && b.dx, "null pointer");
+    EMRT_REQUIRE((b.dw == nullptr) == (descs[0].dw == nullptr) && (b.dw || !b.dbias), "dw == NULL (data gradients only) must hold for every problem of the group, without dbias");
     EMRT_REQUIRE(b.N > 0 && b.H > 0 && b.W > 0 && b.C > 0 && b.OC > 0 && b.KH > 0 && b.KW > 0 && b.stride > 0 && b.pad >= 0, "bad dims");
     EMRT_REQUIRE(b.OH == (b.H + 2 * b.pad - b.KH) / b.stride + 1 && b.OW == (b.W + 2 * b.pad - b.KW) / b.stride + 1, "output size mismatch");
     EMRT_REQUIRE((long long)b.N * b.OH * b.OW + 512 < (1ll << 31) && (long long)b.N * b.H * b.W + 512 < (1ll << 31), "more than 2^31 pixels");
@@ -1606,4 +1644,156 @@ extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dt
   }
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? conv_bwd_group_dispatch<float>(descs, n, st) : conv_bwd_group_dispatch<bf16_t>(descs, n, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched weight gradients.  dW(L) needs only x(L) and dy(L): nothing in backward waits for it, so the caller (functional.py) runs each
+// small layer's DATA gradient as its own launch (emrt_conv2d_bwd with dw == NULL: 64x64 tiles at 4 blocks per CU instead of the pair
+// kernel's 2) and hands the weight gradients of many layers to ONE launch here.  A lone small weight gradient has to cut its pixel
+// reduction into 8-64 slices to fill 256 CUs and then pays S * |dW| of fp32 atomics (measured: 14 of the 35 us of a 32x32x256->256 3x3
+// layer); a batch of 8-24 layers fills the machine with 1-4 slices each.
+// ------------------------------------------------------------------------------------------------
+#define EMRT_MAX_WGROUP 24
+struct EmrtWgradDesc {
+  const void* x; const void* dy; float* dw; float* dbias;
+  int N, H, W, C, ldx; long long x_bs;
+  int OH, OW, OC, lddy; long long dy_bs;
+  int KH, KW, stride, pad, dilation;
+};
+struct WgradGroupArgs {
+  WgradArgs w[EMRT_MAX_WGROUP];
+  int first[EMRT_MAX_WGROUP + 1];      // work items of problem i: [first[i], first[i+1]), slice-major (slice, oc tile, k tile)
+  short wtx[EMRT_MAX_WGROUP], wty[EMRT_MAX_WGROUP];
+  int n, xcd;
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int nb = g.first[g.n];
+  int w = (int)blockIdx.x;
+  if (g.xcd) {      // as wgrad_kernel: the work items are cut into 8 contiguous ranges, one per XCD (the tiles of a slice stream the same rows)
+    const int k = w & 7, idx = w >> 3;
+    const int w0 = (int)(((long long)k * nb) >> 3), w1 = (int)(((long long)(k + 1) * nb) >> 3);
+    w = w0 + idx;
+    if (w >= w1) return;
+  } else if (w >= nb) return;
+  int i = 0;
+  for (int k = 1; k < g.n; ++k) i += w >= g.first[k] ? 1 : 0;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int local = w - g.first[i];
+  const int tx = g.wtx[i], ty = g.wty[i];
+  const int bz = __builtin_amdgcn_readfirstlane(local / (tx * ty)), t = __builtin_amdgcn_readfirstlane(local - bz * (tx * ty));
+  const int by = __builtin_amdgcn_readfirstlane(t / tx);
+  wgrad_body<T, true, 1>(g.w[i], __builtin_amdgcn_readfirstlane(t - by * tx), by, bz, smem_all);
+}
+
+static void wgrad_args_from_desc(WgradArgs& a, const EmrtWgradDesc& d) {
+  a.x = d.x; a.dy = d.dy; a.dw = d.dw;
+  a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldx = d.ldx; a.x_bs = d.x_bs;
+  a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.lddy = d.lddy; a.dy_bs = d.dy_bs;
+  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = d.dilation; a.tiles_per_split = 0; a.dbias = d.dbias;
+}
+
+template <class T>
+static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t st) {
+  using Cfg = WgradCfg<T>;
+  WgradArgs pend[EMRT_MAX_WGROUP];
+  int npend = 0;
+  auto flush = [&]() -> int {
+    if (npend == 0) return 0;
+    if (npend == 1) { const int rc = wgrad_dispatch<T>(pend[0], st); npend = 0; return rc; }
+    // one target for the block length (pixel tiles per block) of the whole batch: about wgroup_blocks blocks in all, never fewer than
+    // wgroup_min_steps tiles per block, and never MORE slices for a problem than it would take alone
+    int tx[EMRT_MAX_WGROUP], ty[EMRT_MAX_WGROUP], S1[EMRT_MAX_WGROUP];
+    long long mt[EMRT_MAX_WGROUP], work = 0;
+    for (int i = 0; i < npend; ++i) {
+      WgradArgs tmp = pend[i];
+      wgrad_plan<T>(tmp, tx[i], ty[i], S1[i]);
+      mt[i] = ((long long)pend[i].N * pend[i].OH * pend[i].OW + Cfg::BKM - 1) / Cfg::BKM;
+      work += (long long)tx[i] * ty[i] * mt[i];
+    }
+    const long long want = g_tune.wgroup_blocks > 0 ? g_tune.wgroup_blocks : 1024;
+    long long Tt = (work + want - 1) / want;
+    if (Tt < g_tune.wgroup_min_steps) Tt = g_tune.wgroup_min_steps;
+    if (Tt < 1) Tt = 1;
+    // longest blocks first (the tail of the launch is then made of short ones)
+    int order[EMRT_MAX_WGROUP];
+    long long tps[EMRT_MAX_WGROUP];
+    for (int i = 0; i < npend; ++i) {
+      long long S = (mt[i] + Tt - 1) / Tt;
+      if (S > S1[i]) S = S1[i];
+      if (S < 1) S = 1;
+      tps[i] = (mt[i] + S - 1) / S;
+      order[i] = i;
+    }
+    for (int i = 1; i < npend; ++i)
+      for (int j = i; j > 0 && tps[order[j]] > tps[order[j - 1]]; --j) { const int t_ = order[j]; order[j] = order[j - 1]; order[j - 1] = t_; }
+    WgradGroupArgs g;
+    long long total = 0;
+    for (int q = 0; q < npend; ++q) {
+      const int i = order[q];
+      g.w[q] = pend[i];
+      g.w[q].tiles_per_split = (int)tps[i];
+      const long long S = (mt[i] + tps[i] - 1) / tps[i];
+      g.first[q] = (int)total;
+      g.wtx[q] = (short)tx[i]; g.wty[q] = (short)ty[i];
+      total += (long long)tx[i] * ty[i] * S;
+    }
+    for (int q = npend; q <= EMRT_MAX_WGROUP; ++q) g.first[q] = (int)total;
+    for (int q = npend; q < EMRT_MAX_WGROUP; ++q) { g.w[q] = g.w[0]; g.wtx[q] = 1; g.wty[q] = 1; }
+    g.n = npend; g.xcd = g_tune.wgrad8p_xcd;
+    npend = 0;
+    if (total >= (1ll << 30)) return fail("emrt_conv2d_wgrad_group", "too many blocks");
+    auto kern = wgrad_group_kernel<T>;
+    const size_t lds = (size_t)4 * Cfg::BKM * Cfg::PITCH;
+    static bool attr_done = false;      // one flag per element type
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail("emrt_conv2d_wgrad_group", "cannot raise the dynamic LDS limit");
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(8u * (unsigned)((total + 7) / 8)), dim3(256), lds, st, g);
+    return check_launch("emrt_conv2d_wgrad_group");
+  };
+  for (int i = 0; i < n; ++i) {
+    WgradArgs a;
+    wgrad_args_from_desc(a, descs[i]);
+    bool alone = !wgrad_is_vec<T>(a) || a.KH * a.KW * a.C >= 32768 * 128 || a.OC >= 32768 * 128;     // (tile counts are shorts)
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      int tk, toc, S8, per;
+      if (wgrad8p_plan<T>(a, tk, toc, S8, per)) alone = true;      // a large layer: the 256x256 LDS-DMA kernel, its own launch
+    }
+    if (alone) {
+      const int rc = wgrad_dispatch<T>(a, st);
+      if (rc) return rc;
+      continue;
+    }
+    pend[npend++] = a;
+    if (npend == EMRT_MAX_WGROUP || (g_tune.wgroup_max > 0 && npend >= g_tune.wgroup_max)) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
+extern "C" int emrt_conv2d_wgrad_group(const EmrtWgradDesc* descs, int n, int dtype, void* stream) {
+  EMRT_REQUIRE(descs && n >= 1, "no problems");
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  for (int i = 0; i < n; ++i) {
+    const EmrtWgradDesc& d = descs[i];
+    EMRT_REQUIRE(d.x && d.dy && d.dw, "null pointer");
+    EMRT_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.OH > 0 && d.OW > 0 && d.OC > 0 && d.dilation >= 1, "bad dims");
+    EMRT_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad >= 0, "bad kernel geometry");
+    EMRT_REQUIRE(d.OH == (d.H + 2 * d.pad - d.dilation * (d.KH - 1) - 1) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.dilation * (d.KW - 1) - 1) / d.stride + 1, "output size mismatch");
+    EMRT_REQUIRE((long long)d.N * d.OH * d.OW + 512 < (1ll << 31) && (long long)d.N * d.H * d.W + 512 < (1ll << 31), "more than 2^31 pixels (32-bit pixel arithmetic)");
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long x_ext = ((long long)(d.N - 1) * d.x_bs + ((long long)d.H * d.W - 1) * d.ldx + d.C) * esz;
+    const long long dy_ext = ((long long)(d.N - 1) * d.dy_bs + ((long long)d.OH * d.OW - 1) * d.lddy + d.OC) * esz;
+    EMRT_REQUIRE(d.x_bs >= 0 && d.dy_bs >= 0 && x_ext < (1ll << 31) && dy_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
+    EMRT_REQUIRE((long long)d.H * d.W < (1 << 24) && (long long)d.ldx * esz < (1 << 24) && d.stride < (1 << 12), "map too large for the 24-bit address arithmetic");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? wgrad_group_dispatch<float>(descs, n, st) : wgrad_group_dispatch<bf16_t>(descs, n, st);
 }

@@ -284,6 +284,38 @@ class GemmWeight:
         self.need_bwd = True
 
 
+class _WgradDesc(ctypes.Structure):       # EmrtWgradDesc (include/emrt_hip.h)
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("ldx", ctypes.c_int),
+                ("x_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int), ("lddy", ctypes.c_int),
+                ("dy_bs", ctypes.c_longlong), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+                ("dilation", ctypes.c_int)]
+
+
+def wgrad_deferred(w):
+    """True when this layer's weight gradient is batched with other layers' (Context.wgrad_batch).  The 1x1 classifiers (OC <= 8) keep
+    their one-pass streaming backward (data + weight gradient in one launch, csrc/conv.hip: thin_bwd_kernel)."""
+    c = ctx()
+    return c.wgrad_batch > 0 and not c.overlap and w.OC > 8 and c._in_backward
+
+
+def defer_wgrad(tape, x, dy, w, geom, stride, pad, dil):
+    """Queue dW += wgrad(x, dy) (+ dbias) of one layer; x and dy stay alive until the batch is launched (Tape.flush_wgrads)."""
+    N, H, Wd, C, ldx, x_bs, OH, OW, lddy, dy_bs = geom
+    tape.wgrads.append(((x.data_ptr(), dy.data_ptr(), w.grad.data_ptr(), w.bias_grad.data_ptr() if w.bias is not None else None,
+                         N, H, Wd, C, ldx, x_bs, OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, dil), (x, dy)))
+    if len(tape.wgrads) >= ctx().wgrad_batch:
+        tape.flush_wgrads()
+
+
+def launch_wgrads(pending):
+    c = ctx()
+    arr = (_WgradDesc * len(pending))()
+    for d, (f, _keep) in zip(arr, pending):
+        (d.x, d.dy, d.dw, d.dbias, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, d.KH, d.KW, d.stride, d.pad, d.dilation) = f
+    _L().call("emrt_conv2d_wgrad_group", arr, len(pending), c.dtype, c.stream)
+
+
 def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1,
            out_scale=None, out_shift=None):
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice).
@@ -324,9 +356,13 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 dy = dm
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             dbias = P(w.bias_grad) if w.bias is not None else None
+            deferred = wgrad_deferred(w)
+            if deferred:
+                defer_wgrad(tape, x, dy, w, (N, H, W, C, ldin, in_bs, OH, OW, lddy, dy_bs), stride, pad, dil)
             if not need_dx:
-                _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
-                          w.KH, w.KW, stride, pad, dbias, dil, c.dtype, c.stream)
+                if not deferred:
+                    _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), N, H, W, C, ldin, in_bs, OH, OW, w.OC, lddy, dy_bs,
+                              w.KH, w.KW, stride, pad, dbias, dil, c.dtype, c.stream)
             else:
                 slot = tape.grad_slot(x)          # accumulate straight into an existing gradient / a slice of the base buffer
                 # contributions other consumers made so far that are not ours to write into: the kernel reads them as an
@@ -355,8 +391,8 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 side = c.fork(x, dy)
                 if side is None:
                     # one call for both gradients: small layers run their dgrad and wgrad tiles in ONE launch
-                    _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), lddx, dx_bs, int(slot is not None), P(w.grad), dbias,
-                              N, H, W, C, ldin, in_bs,
+                    _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), lddx, dx_bs, int(slot is not None),
+                              None if deferred else P(w.grad), None if deferred else dbias, N, H, W, C, ldin, in_bs,
                               OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, P(ysums), P(ymask), ldin if ymask is not None else 0,
                               in_bs if ymask is not None else 0, float(mscale), P(stat), ldsx, sx_bs, P(addend), ldadd, add_bs,
                               dil, c.dtype, c.stream)
@@ -686,11 +722,15 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             dx = slot if slot is not None else c.empty((B, Lv, C))
             assert dx.is_contiguous()
             bd = (_ConvBwdDesc * L)()
+            deferred = all(wgrad_deferred(w) for w in convs)
             for l, (w, (h, wd), (s0, n)) in enumerate(zip(convs, spatial_shapes, level_spans)):
                 d = bd[l]
                 off = s0 * C * esz
                 d.x, d.dy, d.w_bwd_packed, d.dx = src.data_ptr() + off, dy.data_ptr() + off, w.bwd_ptr, dx.data_ptr() + off
-                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = C, Lv * C, int(slot is not None), w.grad.data_ptr(), None
+                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = C, Lv * C, int(slot is not None), None if deferred else w.grad.data_ptr(), None
+                if deferred:
+                    xs, dys = src.narrow(1, s0, n), dy.narrow(1, s0, n)
+                    defer_wgrad(tape, xs, dys, w, (B, h, wd, C, C, Lv * C, h, wd, C, Lv * C), 1, 1, 1)
                 d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, h, wd, C, C, Lv * C
                 d.OH, d.OW, d.OC, d.lddy, d.dy_bs = h, wd, C, C, Lv * C
                 d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
@@ -754,12 +794,17 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
             slots = [tape.grad_slot(f) for f in feats]
             dxs = [s_ if s_ is not None else c.empty(tuple(f.shape)) for s_, f in zip(slots, feats)]
             bd = (_ConvBwdDesc * L)()
+            deferred = all(wgrad_deferred(w) for w in convs)
             for l, (w, f, (a, n), dx) in enumerate(zip(convs, feats, spans, dxs)):
                 _, h, wd, Cl = f.shape
                 _, _, _, _, lddx, dx_bs = _check_map(dx)
                 d = bd[l]
                 d.x, d.dy, d.w_bwd_packed, d.dx = f.data_ptr(), dy.data_ptr() + a * OC * esz, w.bwd_ptr, dx.data_ptr()
-                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = lddx, dx_bs, int(slots[l] is not None), w.grad.data_ptr(), _dp(w.bias_grad) if w.bias is not None else None
+                d.lddx, d.dx_bs, d.accumulate = lddx, dx_bs, int(slots[l] is not None)
+                d.dw = None if deferred else w.grad.data_ptr()
+                d.dbias = None if deferred else (_dp(w.bias_grad) if w.bias is not None else None)
+                if deferred:
+                    defer_wgrad(tape, f, dy.narrow(1, a, n), w, (B, h, wd, Cl, Cl, h * wd * Cl, h, wd, OC, Lv * OC), 1, 0, 1)
                 d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, h, wd, Cl, Cl, h * wd * Cl
                 d.OH, d.OW, d.OC, d.lddy, d.dy_bs = h, wd, OC, OC, Lv * OC
                 d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0

@@ -35,6 +35,7 @@ class Tape:
         self.results = {}
         self.splits = []    # len(ops) at the model's gradient-exchange marks, in forward order (engine.py: backward runs in
                             # segments between them, newest first, and exchanges the gradients each segment completes)
+        self.wgrads = []    # weight-gradient problems whose launch is deferred (functional.defer_wgrad): (descriptor fields, tensors kept alive)
 
     @property
     def split(self):
@@ -163,6 +164,13 @@ class Tape:
         else:
             e[0], e[1] = Fn.add_maps(e[0], g), True
 
+    def flush_wgrads(self):
+        """Launch the deferred weight gradients (one emrt_conv2d_wgrad_group call: grouped launches of up to 24 layers)."""
+        if self.wgrads:
+            from . import functional as Fn
+            pending, self.wgrads = self.wgrads, []
+            Fn.launch_wgrads(pending)
+
     def backward(self, stop_at=0):
         """Run the recorded closures newest-first.  stop_at > 0 stops once only the first `stop_at` ops are left (the
         engine's early gradient exchange: everything recorded after `self.split` first, the rest in a second call)."""
@@ -171,6 +179,8 @@ class Tape:
         try:
             while len(self.ops) > stop_at:
                 self.ops.pop()()
+            # the weight gradients this segment deferred: the caller (optimizer, or the gradient exchange of this segment's ranges) needs them now
+            self.flush_wgrads()
         finally:
             _CTX._in_backward = False
         if stop_at > 0:
@@ -206,6 +216,10 @@ class Context:
         self.fold_live = False    # True inside an eval forward whose ParamStore.fold_bn() has just run (the folds are fresh)
         self.capture = None       # engine.GraphSequence while a step is being captured: collective() then breaks the graph
         self.sync_always = False  # issue the SyncBatchNorm collectives even in a 1-rank group (single-GPU test of the N > 1 path)
+        # Weight gradients are not on backward's dependency chain: each conv / linear launches its data gradient alone and the weight
+        # gradients of up to `wgrad_batch` layers go out as ONE grouped launch (emrt_conv2d_wgrad_group).  0 = every layer on its own.
+        import os
+        self.wgrad_batch = int(os.environ.get("EMRT_WGRAD_BATCH", "24"))
 
     def collective(self, fn):
         """Run a host-issued collective (fn enqueues it on the current stream's timeline) at this point of the step.  Eager:

@@ -35,7 +35,7 @@ int emrt_abi_version(void);
 int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len);
 /* Developer / test knobs of the dispatchers (forced tile shapes, kernel variants).  The table is filled ONCE from the
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
- * conv_tile, wgrad_split, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
+ * conv_tile, wgrad_split, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
  * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
  * gn_bwd_stat_rows, gn_apply_rows.
  * Not thread-safe against concurrent launches; production code never calls these. */
@@ -76,9 +76,24 @@ typedef struct EmrtConvBwdDesc {         /* the arguments of emrt_conv2d_bwd wit
   int N, H, W, C, ldx; long long x_bs; int OH, OW, OC, lddy; long long dy_bs; int KH, KW, stride, pad;
 } EmrtConvBwdDesc;
 int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream);
+/* dw == NULL in EVERY descriptor (then dbias must be NULL too): the data gradients only, one grouped launch of dgrad tiles */
 int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream);
+/* ---- batched weight gradients (ABI 5): dW(L) needs only x(L) and dy(L), nothing in loss.backward() (train.py:142-149) waits for it.  A
+ * caller may therefore run each layer's DATA gradient alone (emrt_conv2d_bwd / emrt_conv2d_bwd_group with dw == NULL), keep x and dy
+ * alive, and hand the weight gradients of many layers (any n >= 1; HOST array) to one call here: small vector-path problems run as grouped
+ * launches of up to 24 problems whose pixel reductions are cut into far fewer slices than each would need alone to fill the GPU (less fp32
+ * atomic traffic into dW); large layers take the 256x256 LDS-DMA kernel and odd shapes the element-wise path, one launch each.  Same
+ * arithmetic as emrt_conv2d_wgrad: dw [OC][KH][KW][C] += , dbias (nullable) += . */
+typedef struct EmrtWgradDesc {
+  const void* x; const void* dy; float* dw; float* dbias;
+  int N, H, W, C, ldx; long long x_bs;
+  int OH, OW, OC, lddy; long long dy_bs;
+  int KH, KW, stride, pad, dilation;
+} EmrtWgradDesc;
+int emrt_conv2d_wgrad_group(const EmrtWgradDesc* descs, int n, int dtype, void* stream);
 
-/* backward of one conv / linear layer in one call (dx NHWC with strides lddx / dx_bs, overwritten or accumulated into; dW += ; dbias += when given; optional fused
+/* backward of one conv / linear layer in one call (dx NHWC with strides lddx / dx_bs, overwritten or accumulated into; dW += ; dbias += when given;
+ * dw == NULL (then dbias == NULL): the data gradient only, see emrt_conv2d_wgrad_group; optional fused
  * BatchNorm-backward sums as in emrt_conv2d): small layers are ONE launch that runs the dgrad and wgrad tiles side by side.
  * With mask_y, dx = mask_y > 0 ? mask_scale * dgrad : 0: mask_scale = 1 for a ReLU, 1/(1-p) when mask_y is the output of
  * dropout(relu(.)) -- the FFN's dropout and ReLU backward cost no pass of their own.  addend (same geometry as dx, own strides):

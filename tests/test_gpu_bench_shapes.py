@@ -179,7 +179,14 @@ def test_conv_bench_shape_bf16_vs_torch(case):
     fwd_big, dgrad_big, pair = _expected_paths(N, H, W, Cin, Cout, k, stride, pad)
     assert {"128x128": fwd_big and dgrad_big and not pair, "pair": pair, "ksplit": not fwd_big}[path], \
         "the case no longer reaches the kernel it was written for: %s" % ((fwd_big, dgrad_big, pair),)
-    _conv_case_vs_torch(case)
+    _conv_case_vs_torch(case)          # default: the data gradient alone, the weight gradient through emrt_conv2d_wgrad_group
+    if pair:                           # the layer-by-layer backward (Context.wgrad_batch = 0): dgrad + wgrad tiles in one launch
+        from emrt_amd.runtime import ctx
+        ctx().wgrad_batch = 0
+        try:
+            _conv_case_vs_torch(case)
+        finally:
+            ctx().wgrad_batch = 24
 
 
 # the 256 x 256 LDS-DMA kernel (csrc/igemm8p.hpp), forced through the dispatcher knob so that every edge it has is exercised

@@ -79,12 +79,15 @@ def test_conv_random_geometry_forced_tiles(case, tile):
 
 @pytest.mark.parametrize("case", BIG[:6], ids=[c[0] for c in BIG[:6]])
 def test_conv_random_geometry_pair_kernel(case):
+    from emrt_amd.runtime import ctx
     L_ = _lib.lib()
     old = L_.set_tuning("pair_max", 1 << 30)          # dgrad + wgrad tiles in ONE launch whatever the grid size
+    ctx().wgrad_batch = 0                             # (layer-by-layer backward: with batching on, the data gradient goes out alone)
     try:
         _conv_case_vs_torch(case, dilation=case[10])
     finally:
         L_.set_tuning("pair_max", old)
+        ctx().wgrad_batch = 24
 
 
 @pytest.mark.parametrize("slab", [1, 0], ids=["slab", "atomics"])

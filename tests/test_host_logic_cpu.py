@@ -63,8 +63,18 @@ def test_train_step_launch_sequence(fake, backbone):
     assert n_fwd > n_eval                                              # training adds dropout / statistics launches
     n_grouped = sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_bwd_group")     # problems inside grouped backward launches
     assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15       # (4 encoder layers + input_proj) x 3 levels
-    assert cnt["emrt_conv2d_wgrad"] + cnt["emrt_conv2d_bwd"] + n_grouped == len(st.gemms)     # every GEMM weight gets exactly one weight gradient
-    assert cnt["emrt_conv2d_wgrad"] <= 4                               # alone only where no data gradient is needed (image-fed convs)
+    # every GEMM weight gets exactly one weight gradient: immediately (the 1x1 classifiers' one-pass backward) or in a batched
+    # emrt_conv2d_wgrad_group call made while backward runs; a layer whose weight gradient is batched passes dw = NULL to its data gradient
+    batched = [a[0][i] for n, a in fake.calls if n == "emrt_conv2d_wgrad_group" for i in range(a[1])]
+    immediate = [a for n, a in fake.calls if n == "emrt_conv2d_bwd" and a[7] is not None]
+    assert cnt["emrt_conv2d_wgrad"] == 0 and len(batched) + len(immediate) == len(st.gemms)
+    assert len(immediate) == 3 and all(a[17] <= 8 for a in immediate)      # the two classifiers (OC = num_classes) and reference_points (OC = 2)
+    assert all(a[8] is None for n, a in fake.calls if n == "emrt_conv2d_bwd" and a[7] is None)      # dbias travels with the batched dW
+    assert all(a[0][i].dw is None and a[0][i].dbias is None for n, a in fake.calls if n == "emrt_conv2d_bwd_group" for i in range(a[1]))
+    assert 4 <= cnt["emrt_conv2d_wgrad_group"] <= 12 and max(a[1] for n, a in fake.calls if n == "emrt_conv2d_wgrad_group") <= 24
+    last_bwd = max(i for i, (n, a) in enumerate(fake.calls) if n in ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group"))
+    first_opt = min(i for i, (n, a) in enumerate(fake.calls) if n == "emrt_grad_clip_scale")
+    assert last_bwd < max(i for i, (n, a) in enumerate(fake.calls) if n == "emrt_conv2d_wgrad_group") < first_opt      # flushed before the optimizer
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
     assert cnt["emrt_bn_apply"] == cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
@@ -103,9 +113,9 @@ def test_train_step_launch_sequence(fake, backbone):
     assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
     # wgrad destinations are distinct slices inside the trainable gradient range
     g0 = st.grad.data_ptr()
-    dws = [a[2].value - g0 for n, a in fake.calls if n == "emrt_conv2d_wgrad"] + [a[7].value - g0 for n, a in fake.calls if n == "emrt_conv2d_bwd"]
-    dws += [a[0][i].dw - g0 for n, a in fake.calls if n == "emrt_conv2d_bwd_group" for i in range(a[1])]
-    assert len(set(dws)) == len(dws) and all(0 <= d < 4 * st.n_train for d in dws)
+    dws = [a[7].value - g0 for a in immediate] + [d.dw - g0 for d in batched]
+    assert len(set(dws)) == len(dws) == len(st.gemms) and all(0 <= d < 4 * st.n_train for d in dws)
+    assert sum(1 for d in batched if d.dbias) + sum(1 for a in immediate if a[8] is not None) == sum(1 for g_ in st.gemms if g_.bias is not None)
     # every device pointer handed to a conv is 2-byte aligned at least and non-null
     for n, a in fake.calls:
         if n == "emrt_conv2d":
