@@ -45,12 +45,17 @@ CONFIGS = {
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
+PEAK_LDS_GBPS = 128 * 256 * 2.4   # LDS gather: 128 B/clk/CU (MI355X_MICROARCH.md, LDS: ds_read_b32 rate; random 64-B pixel reads get no more) x 256 CUs x 2.4 GHz
 GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: per-level encoder convs)",
-                 "emrt_conv2d_bwd_group": "bwd_group_kernel (emrt_conv2d_bwd_group)",
-                 "emrt_conv2d": "igemm_kernel (emrt_conv2d: forward convs / linears)",
-                 "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel + wgrad_kernel / wgrad8p_kernel (emrt_conv2d_bwd: data + weight gradients; paired launch for small layers, 256x256 LDS-DMA kernels for the large ones)",
+                 "emrt_conv2d_bwd_group": "igemm_group_kernel<mode 1> (emrt_conv2d_bwd_group: data gradients of the per-level convs)",
+                 "emrt_conv2d": "igemm_kernel / igemm8p_kernel (emrt_conv2d: forward convs / linears)",
+                 "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel mode 1 (emrt_conv2d_bwd: data gradients; thin_bwd_kernel for the classifiers)",
                  "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)",
                  "emrt_conv2d_wgrad_group": "wgrad_group_kernel / wgrad8p_kernel (emrt_conv2d_wgrad_group: the weight gradients of up to 24 layers per launch)"}
+# the roofline's kernel family: every launch that computes a convolution / linear layer's BACKWARD (data gradient + weight gradient) --
+# the same population of work whether a layer's two gradients share a launch (round 3's pair kernel) or not (round 4: batched dW)
+CONV_BWD = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group")
+CONV_FWD = ("emrt_conv2d", "emrt_conv2d_group")
 
 
 def log(*a):
@@ -79,6 +84,46 @@ def conv_flops(name, a):
     OH, OW, OC = a[9:12]
     KH, KW = a[14:16]
     return 2.0 * N * OH * OW * OC * KH * KW * C
+
+
+def conv_bytes(name, a, esz):
+    """Algorithmic (compulsory) HBM bytes of one conv C-ABI call: every operand read once, every result written once (dW: fp32
+    read-modify-write; masks / residuals / BatchNorm inputs read by a fused epilogue count too)."""
+    def one(N, H, W, C, OH, OW, OC, KH, KW, fwd, dgrad, wgrad, extra_in=0, extra_out=0):
+        x, y, w = N * H * W * C * esz, N * OH * OW * OC * esz, OC * KH * KW * C
+        b = 0
+        if fwd:
+            b += x + w * esz + y + extra_in * y
+        if dgrad:
+            b += y + w * esz + x + extra_out * x
+        if wgrad:
+            b += x + y + 2 * 4 * w
+        return b
+    if name == "emrt_conv2d":
+        N, H, W, C = a[5:9]
+        OH, OW, OC = a[11:14]
+        KH, KW, stride, pad, mode = a[18:23]
+        extra = (1 if a[4] else 0) + (1 if a[26] else 0)          # residual, mask
+        if mode == 0:
+            return one(N, H, W, C, OH, OW, OC, KH, KW, True, False, False, extra_in=extra)
+        return N * H * W * C * esz + C * KH * KW * OC * esz + N * OH * OW * OC * esz * (1 + extra)      # dgrad call: `in` is dY, `out` is dX
+    if name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad_group"):
+        ds = list(a[0])[:a[1]]
+        if name == "emrt_conv2d_group":
+            return sum(one(d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.KH, d.KW, True, False, False, extra_in=1 if d.residual else 0) for d in ds)
+        if name == "emrt_conv2d_wgrad_group":
+            return sum(one(d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.KH, d.KW, False, False, True) for d in ds)
+        return sum(one(d.N, d.H, d.W, d.C, d.OH, d.OW, d.OC, d.KH, d.KW, False, True, bool(d.dw), extra_out=1 if d.accumulate else 0) for d in ds)
+    if name == "emrt_conv2d_bwd":
+        N, H, W, C = a[9:13]
+        OH, OW, OC = a[15:18]
+        KH, KW = a[20:22]
+        extra = (1 if a[6] else 0) + (1 if a[25] else 0) + (1 if a[29] else 0) + (1 if a[32] else 0)     # accumulate, mask, stat_x, addend
+        return one(N, H, W, C, OH, OW, OC, KH, KW, False, True, bool(a[7]), extra_out=extra)
+    N, H, W, C = a[3:7]
+    OH, OW, OC = a[9:12]
+    KH, KW = a[14:16]
+    return one(N, H, W, C, OH, OW, OC, KH, KW, False, False, True)
 
 
 def msda_bytes(a, esz):
@@ -132,25 +177,35 @@ def dump_calls(path, calls):
 def rooflines(calls, dtype_name, cfg_key, train):
     """-> (roofline of the dominant GEMM family, roofline of the MSDA encoder call, per-family log lines)."""
     fam = family_table(calls)
+    esz = 4 if dtype_name == "fp32" else 2
     total_ms = sum(v[1] for v in fam.values())
     lines = ["[bench] per-launch HIP-event time of one replayed %s: %.2f ms over %d launches" % ("step" if train else "image", total_ms, len(calls))]
     for name, (cnt, ms, fl) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:12]:
         lines.append("    %-28s %5d calls %9.3f ms %5.1f%%%s" % (name, cnt, ms, 100 * ms / total_ms, "  %.1f TFLOP/s" % (fl / ms / 1e9) if fl else ""))
     peak = PEAK_TFLOPS[dtype_name]
-    dom = max(GEMM_FAMILIES, key=lambda k: fam.get(k, [0, 0.0, 0.0])[1])
-    cnt, ms, fl = fam[dom]
+    # training: the convolution / linear BACKWARD (data + weight gradients) is the dominant family; inference: the forward convolutions
+    names = CONV_BWD if train else CONV_FWD
+    cnt = sum(fam.get(k, [0, 0.0, 0.0])[0] for k in names)
+    ms = sum(fam.get(k, [0, 0.0, 0.0])[1] for k in names)
+    fl = sum(fam.get(k, [0, 0.0, 0.0])[2] for k in names)
+    by = sum(conv_bytes(n_, vals_of(a_), esz) for n_, a_, _ in calls if n_ in names)
     ach = fl / ms / 1e9
     all_ms = sum(fam.get(k, [0, 0.0, 0.0])[1] for k in GEMM_FAMILIES)
     all_fl = sum(fam.get(k, [0, 0.0, 0.0])[2] for k in GEMM_FAMILIES)
     # what a HIP-event pair costs around a launch that does nothing: the per-launch figures above all contain it
-    trivial = [ms for name, a, ms in calls if name in ("emrt_counter_add", "emrt_scalar_axpby")]
-    roofline = {"kernel": GEMM_FAMILIES[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+    trivial = [ms_ for name, a, ms_ in calls if name in ("emrt_counter_add", "emrt_scalar_axpby")]
+    triv_ms = min(trivial) if trivial else 0.0
+    net_ms = max(ms - cnt * triv_ms, 1e-6)
+    roofline = {"kernel": "; ".join(GEMM_FAMILIES[k] for k in names if k in fam), "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
-                "algorithmic_gflop_per_step": round(fl / 1e9, 1), "share_of_step_kernel_time": round(ms / total_ms, 3),
+                "algorithmic_gflop_per_step": round(fl / 1e9, 1), "algorithmic_bytes_per_launch": int(by / cnt),
+                "achieved_net_of_event_cost": round(fl / net_ms / 1e9, 2), "frac_net_of_event_cost": round(fl / net_ms / 1e9 / peak, 4),
+                "share_of_step_kernel_time": round(ms / total_ms, 3),
                 "all_gemm_tflops": round(all_fl / all_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_ms / total_ms, 3),
-                "event_timed_trivial_launch_us": round(1e3 * min(trivial), 2) if trivial else None,
-                "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch "
-                          "(event_timed_trivial_launch_us = what the same pair reads around a one-thread kernel: included in every figure)"}
+                "event_timed_trivial_launch_us": round(1e3 * triv_ms, 2) if trivial else None,
+                "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch; "
+                          "achieved = algorithmic FLOPs / sum of those times (event_timed_trivial_launch_us = what the same pair reads around a one-thread "
+                          "kernel: included in every launch's figure; *_net_of_event_cost subtracts it per launch)"}
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this config (bench.py cannot profile itself): newest round
     pmc = None
     import glob
@@ -161,13 +216,12 @@ def rooflines(calls, dtype_name, cfg_key, train):
             pmc = json.load(f)
         pmc_src = os.path.relpath(cands[-1], ROOT)
     if pmc is not None:
-        key = {"emrt_conv2d": "igemm_kernel", "emrt_conv2d_bwd": "bwd_pair_kernel", "emrt_conv2d_wgrad": "wgrad_kernel"}.get(dom, "igemm_kernel")
-        if key not in pmc:
-            key = "igemm_kernel"
+        key = "conv_backward_family" if train else "conv_forward_family"
         if key in pmc:
             roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
-            roofline["traffic_kernel"] = key
-            roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, average over the step's launches)"
+            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] * pmc[key]["dispatches_per_step"] / by, 3)
+            roofline["traffic_kernels"] = pmc[key].get("kernels")
+            roofline["traffic_unit"] = "bytes per kernel dispatch (2*FETCH_SIZE + WRITE_SIZE, average over the family's dispatches of a step)"
             roofline["traffic_source"] = pmc_src + ": " + pmc.get("method", "")
     esz = 4 if dtype_name == "fp32" else 2
     enc = [(vals_of(a), ms) for name, a, ms in calls if name == "emrt_msda_fwd"]
@@ -176,6 +230,7 @@ def rooflines(calls, dtype_name, cfg_key, train):
     if enc:
         v = enc[0][0]
         by = msda_bytes(v, esz)
+        lds_by = v[9] * v[10] * v[12] * v[14] * v[15] * 4 * v[13] * esz       # B * Lq * M * L * P * 4 corners * D channels
         avg_ms = sum(ms for _, ms in enc) / len(enc)
         ideal_us = by / PEAK_HBM_GBPS / 1e3
         roofline_msda = {"kernel": "msda_fwd_lds_kernel / msda_fwd_kernel (encoder call, B=%d Lq=Lv=%d, %s)" % (v[9], v[10], dtype_name), "bound": "hbm",
@@ -183,8 +238,15 @@ def rooflines(calls, dtype_name, cfg_key, train):
                          "frac": round(by / avg_ms / 1e6 / PEAK_HBM_GBPS, 4), "traffic": None,
                          "algorithmic_mbytes_per_launch": round(by / 1e6, 2), "avg_launch_us": round(1e3 * avg_ms, 2),
                          "ideal_us_at_peak": round(ideal_us, 2),
+                         # the gather itself: every (query, head, level, point) reads 4 corners x 32 channels from the LDS-staged slab
+                         # (SURVEY.md 8d "secondary figure"); the LDS serves 128 B/clk/CU for this access width on 256 CUs
+                         "lds_bytes": int(lds_by), "lds_peak": PEAK_LDS_GBPS, "lds_achieved": round(lds_by / avg_ms / 1e6, 1),
+                         "lds_frac": round(lds_by / avg_ms / 1e6 / PEAK_LDS_GBPS, 4), "lds_ideal_us_at_peak": round(lds_by / PEAK_LDS_GBPS / 1e3, 2),
+                         "binding_roof": "lds" if lds_by / PEAK_LDS_GBPS > by / PEAK_HBM_GBPS else "hbm",
                          "note": "a launch that moves nothing already reads event_timed_trivial_launch_us (roofline) on this clock: at %.1f MB the HBM "
-                                 "time is %.1f us, so frac is bounded well below 1 by the launch itself; see DESIGN.md 5 for the per-shape table" % (by / 1e6, ideal_us)}
+                                 "time is %.1f us and the LDS gather floor %.1f us, so the HBM fraction is bounded below %.2f by the gather alone and lower "
+                                 "still by the launch; see DESIGN.md 5 for the per-shape table (bench.py --config cfg5 --batch 64 / 128 gives the large-batch rows)"
+                                 % (by / 1e6, ideal_us, lds_by / PEAK_LDS_GBPS / 1e3, min(1.0, ideal_us / (lds_by / PEAK_LDS_GBPS / 1e3)))}
         encb = [(vals_of(a), ms) for name, a, ms in calls if name == "emrt_msda_bwd"]
         encb = [(vb, ms) for vb, ms in encb if vb[14] == vb[15]]     # Lq == Lv: encoder self-attention calls
         if encb:
@@ -247,9 +309,11 @@ def spawn_ranks(n, argv):
 
 
 def check_world(args):
-    """Under a launcher WORLD_SIZE must be the --gpus the caller asked for: a silently smaller job would be a wrong number.
-    Checked before the rendezvous and before any GPU call."""
+    """Under a launcher WORLD_SIZE must be the --gpus the caller asked for: a silently smaller job would be a wrong number.  --gpus left out:
+    the launcher's size is taken (as emrt_amd.train does).  Checked before the rendezvous and before any GPU call."""
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus is None:
+        args.gpus = world
     if world != args.gpus:
         raise SystemExit("[bench] WORLD_SIZE=%d but --gpus %d: start %d ranks (python bench.py --gpus %d starts them itself)"
                          % (world, args.gpus, args.gpus, args.gpus))
@@ -270,17 +334,37 @@ def describe_group(rank, world, dev):
         (backend, ver, torch.distributed.get_world_size(), dev, "share GPU 0 (test aid)" if os.environ.get("EMRT_ALL_RANKS_ON_GPU0") else "one GPU each"))
 
 
+def collective_probe(dev, world, n_elems, reps=5):
+    """N > 1, rank 0's view: a bare all-reduce of the step's gradient payload (fp32, n_elems elements) timed on its own, so that a poor
+    scaling number can be attributed (link time vs everything else) without a second run."""
+    buf = torch.zeros(n_elems, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        torch.distributed.all_reduce(buf)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch.distributed.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nbytes = n_elems * 4
+    return {"payload_mbytes": round(nbytes / 1e6, 1), "reps": reps, "ms": round(1e3 * dt, 3), "algbw_GBps": round(nbytes / dt / 1e9, 1),
+            "busbw_GBps": round(nbytes / dt / 1e9 * 2 * (world - 1) / world, 1),
+            "note": "bare torch.distributed.all_reduce (RCCL) of the whole flat gradient, nothing overlapping it; busbw = algbw * 2(N-1)/N"}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (default: WORLD_SIZE under a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json config: cfg2 = configs[1] (headline), cfg3 = configs[2], cfg5 = configs[4]")
-    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (default: the config's)")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU (default: the config's); cfg5: windows per image (the image becomes rows x cols crops)")
     ap.add_argument("--size", type=int, default=0)
     ap.add_argument("--dtype", default="", choices=["", "bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="the default command also measures cfg3 and cfg5 (short runs) into other_configs; this skips them")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--overlap", default="", choices=["", "pair", "deferred"], help="wgrad on a second stream (A/B experiment)")
     ap.add_argument("--two-phase", action="store_true", help="run the N>1 step structure (graphs around RCCL all-reduce) in a 1-rank group")
@@ -288,33 +372,56 @@ def main():
     ap.add_argument("--two-phase-no-syncbn", action="store_true", help="--two-phase without the SyncBatchNorm collectives (A/B: what the graph cuts cost)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+    if (args.gpus or 1) > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     check_world(args)
+    from emrt_amd.distributed import init_process_group
+    if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = init_process_group()
+    dev = torch.device("cuda", local_rank)
+    describe_group(rank, world, dev)
+    env = dict(rank=rank, world=world, dev=dev)
+
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["batch"] = args.batch
     if args.size:
         cfg["size"] = args.size
     dtype_name = args.dtype or cfg["dtype"]
-    if cfg["mode"] == "infer":
-        return main_infer(args, cfg, dtype_name)
+    run = run_infer if cfg["mode"] == "infer" else run_train
+    result = run(args, args.config, cfg, dtype_name, env, args.steps, args.warmup, cpu=not args.no_cpu_baseline, dump=args.dump_calls)
+    # The driver only ever runs the default command: the other two single-GPU configurations of BASELINE.json ride along as short runs
+    # (metric / config / value above stay configs[1]'s).  Not at N > 1, not for experiments that changed the workload.
+    default_workload = (args.config == "cfg2" and not args.batch and not args.size and not args.dtype and not args.no_graph and not args.overlap
+                        and not args.two_phase)
+    if world == 1 and default_workload and not args.no_other_configs:
+        others = {}
+        for key, steps, warm in (("cfg3", 12, 4), ("cfg5", 20, 5)):
+            c2 = dict(CONFIGS[key])
+            r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=1)
+            others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "end_to_end_tflops", "roofline",
+                                               "roofline_msda", "cpu_baseline") if k in r2}
+        result["other_configs"] = others
+    if world > 1:
+        torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump=None, cpu_steps=None):
+    """One training configuration: W warm-up + K timed steps (barrier + synchronize on both sides, max over ranks) -> rank 0's result dict."""
     if dtype_name == "fp16":
         raise SystemExit("fp16 is inference-only (include/emrt_hip.h); training configs run in bf16 or fp32")
-
-    from emrt_amd.distributed import init_process_group
     from emrt_amd.engine import TrainEngine
     from emrt_amd.runtime import BF16, F32
     from emrt_amd.src.models.emrt import EMRT
     from emrt_amd.src.models.losses import MixSoftmaxCrossEntropyLoss
     from emrt_amd.src.models.solver import Momentum, PolynomialDecay
-
-    if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
-        os.environ["LOCAL_RANK"] = "0"
-    rank, local_rank, world = init_process_group()
+    rank, world, dev = env["rank"], env["world"], env["dev"]
     dtype = BF16 if dtype_name == "bf16" else F32
-    dev = torch.device("cuda", local_rank)
-    describe_group(rank, world, dev)
     torch.manual_seed(1234)
     B, S, ncls = cfg["batch"], cfg["size"], cfg["ncls"]
     model = EMRT(num_classes=ncls, backbone="resnet50")
@@ -340,7 +447,7 @@ def main():
     for _ in range(eng.warmup_eager + 1):
         eng.step(images, labels)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.step(images, labels)
 
     def barrier():
@@ -349,7 +456,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss_t = eng.step(images, labels)
     torch.cuda.synchronize()
     barrier()
@@ -359,7 +466,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss_t.item())
-    tiles_per_s = world * B * args.steps / elapsed
+    tiles_per_s = world * B * steps / elapsed
+    probe = None
+    if world > 1 and torch.distributed.get_backend() == "nccl":      # every rank takes part; rank 0 reports
+        probe = collective_probe(dev, world, model.store.n_train)
 
     result = None
     if rank == 0:
@@ -367,62 +477,65 @@ def main():
         eng_prof = TrainEngine(model, opt, loss_fn, 1, use_graph=False, overlap=False)   # serialised: per-kernel durations
         eng_prof.reducer = None
         calls = timed_replay(lambda: eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels))
-        if args.dump_calls:
-            dump_calls(args.dump_calls, calls)
-        roofline, roofline_msda, lines = rooflines(calls, dtype_name, args.config if (B, S) == (CONFIGS[args.config]["batch"], CONFIGS[args.config]["size"]) else "custom", True)
+        if dump:
+            dump_calls(dump, calls)
+        roofline, roofline_msda, lines = rooflines(calls, dtype_name, cfg_key if (B, S) == (CONFIGS[cfg_key]["batch"], CONFIGS[cfg_key]["size"]) else "custom", True)
         for ln in lines:
             log(ln)
         cpu_baseline = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = run_cpu_baseline_train(B, S, ncls, args.cpu_threads, timed_steps=3 if args.config == "cfg2" else 2)
-        flop_tile = 3.0 * cfg["fwd_gflop"] * 1e9 * (S * S) / (CONFIGS[args.config]["size"] ** 2)
+        if world == 1 and cpu:
+            cpu_baseline = run_cpu_baseline_train(B, S, ncls, args.cpu_threads, timed_steps=cpu_steps or (3 if cfg_key == "cfg2" else 2))
+        flop_tile = 3.0 * cfg["fwd_gflop"] * 1e9 * (S * S) / (CONFIGS[cfg_key]["size"] ** 2)
         result = {
             "metric": "training tiles/sec at %dx%d" % (S, S), "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": cfg["name"].replace("batch %d" % CONFIGS[args.config]["batch"], "batch %d" % B) + ", " + dtype_name,
+            "config": {"workload": cfg["name"].replace("batch %d" % CONFIGS[cfg_key]["batch"], "batch %d" % B) + ", " + dtype_name,
                        "global_batch": world * B, "tile": [S, S, 3], "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
             "end_to_end_tflops": round(tiles_per_s * flop_tile / 1e12, 2), "final_loss": round(loss_val, 4),
             "roofline": roofline, "roofline_msda": roofline_msda, "cpu_baseline": cpu_baseline,
         }
-    if world > 1:
-        torch.distributed.barrier()
-    if torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+        if probe is not None:
+            # what the exchange would cost if nothing hid it, next to what the step really paid over the 1-rank step structure
+            result["collective"] = probe
+    del eng
+    return result
 
 
-def main_infer(args, cfg, dtype_name):
+def _window_grid(n):
+    """rows x cols = n windows, as square as possible."""
+    r = int(n ** 0.5)
+    while n % r:
+        r -= 1
+    return r, n // r
+
+
+def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump=None, cpu_steps=None):
     """cfg5: sliding-window inference of 1024x1024 images (replicas only: --gpus N runs N independent replicas, no collective)."""
-    from emrt_amd.distributed import init_process_group
     from emrt_amd.runtime import BF16, F16, F32
     from emrt_amd.src.api.infer import SlidingWindowEngine, slide_inference
     from emrt_amd.src.models.emrt import EMRT
-
-    if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):
-        os.environ["LOCAL_RANK"] = "0"
-    rank, local_rank, world = init_process_group()
-    dev = torch.device("cuda", local_rank)
-    describe_group(rank, world, dev)
+    rank, world, dev = env["rank"], env["world"], env["dev"]
     torch.manual_seed(1234)
-    ncls, crop, img_size = cfg["ncls"], cfg["size"], cfg["image"]
+    ncls, crop = cfg["ncls"], cfg["size"]
+    rows, cols = (cfg["image"] // crop,) * 2 if cfg["batch"] == CONFIGS[cfg_key]["batch"] else _window_grid(cfg["batch"])
+    img_h, img_w = rows * crop, cols * crop
     model = EMRT(num_classes=ncls, backbone="resnet50")
     model.to_hip(str(dev), {"bf16": BF16, "fp16": F16, "fp32": F32}[dtype_name], seed=1234 + rank)
     model.eval()
     model.compute_aux_in_eval = False        # every inference caller discards the auxiliary logits (infer.py:66)
     g = torch.Generator().manual_seed(1234 + rank)
-    img = torch.randn(3, img_size, img_size, generator=g).to(dev)
+    img = torch.randn(3, img_h, img_w, generator=g).to(dev)
     # BatchNorm running statistics from one pass in train-mode arithmetic would need fp16 backward entry points; the
     # throughput does not depend on their values: they stay at their initial (0, 1)
-    eng = SlidingWindowEngine(model, (3, img_size, img_size), (crop, crop), (crop, crop), ncls, warmup=0 if args.no_graph else 1)
+    eng = SlidingWindowEngine(model, (3, img_h, img_w), (crop, crop), (crop, crop), ncls, warmup=0 if args.no_graph else 1)
     if args.no_graph:
         eng.warmup = 1 << 30
-    nwin = (img_size // crop) ** 2
+    nwin = rows * cols
     for _ in range(3):
         eng(img)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng(img)
 
     def barrier():
@@ -431,7 +544,7 @@ def main_infer(args, cfg, dtype_name):
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         pred = eng(img)
     torch.cuda.synchronize()
     barrier()
@@ -440,35 +553,32 @@ def main_infer(args, cfg, dtype_name):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    tiles_per_s = world * nwin * args.steps / elapsed
+    tiles_per_s = world * nwin * steps / elapsed
     result = None
     if rank == 0:
-        assert tuple(pred.shape) == (1, 1, img_size, img_size) and pred.dtype == torch.int32
+        assert tuple(pred.shape) == (1, 1, img_h, img_w) and pred.dtype == torch.int32
         calls = timed_replay(lambda: slide_inference(model, [img], (crop, crop), (crop, crop), ncls))
-        if args.dump_calls:
-            dump_calls(args.dump_calls, calls)
-        roofline, roofline_msda, lines = rooflines(calls, dtype_name, args.config, False)
+        if dump:
+            dump_calls(dump, calls)
+        roofline, roofline_msda, lines = rooflines(calls, dtype_name, cfg_key if nwin == CONFIGS[cfg_key]["batch"] else "custom", False)
         for ln in lines:
             log(ln)
         cpu_baseline = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = run_cpu_baseline_infer(ncls, crop, nwin, args.cpu_threads)
+        if world == 1 and cpu:
+            cpu_baseline = run_cpu_baseline_infer(ncls, crop, nwin, args.cpu_threads, timed=cpu_steps or 3)
         result = {
-            "metric": "inference tiles/sec at %dx%d (sliding window over %dx%d images)" % (crop, crop, img_size, img_size),
-            "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "inference tiles/sec at %dx%d (sliding window over %dx%d images)" % (crop, crop, img_h, img_w),
+            "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": cfg["name"] + ", " + dtype_name, "windows_per_step": nwin, "image": [img_size, img_size, 3], "tile": [crop, crop, 3],
+            "config": {"workload": cfg["name"].replace("1024x1024", "%dx%d" % (img_h, img_w)).replace("16 windows", "%d windows" % nwin) + ", " + dtype_name,
+                       "windows_per_step": nwin, "image": [img_h, img_w, 3], "tile": [crop, crop, 3],
                        "parallelism": "replicas%d" % world, "hipgraph": not args.no_graph},
             "end_to_end_tflops": round(tiles_per_s * cfg["fwd_gflop"] * 1e9 / 1e12, 2),
             "roofline": roofline, "roofline_msda": roofline_msda, "cpu_baseline": cpu_baseline,
         }
-    if world > 1:
-        torch.distributed.barrier()
-    if torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    del eng
+    return result
 
 
 def run_cpu_baseline_train(B, S, ncls, threads, timed_steps=3):
@@ -484,7 +594,7 @@ def run_cpu_baseline_train(B, S, ncls, threads, timed_steps=3):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, 3, S, S, generator=g)
     lab = torch.randint(0, ncls, (B, S, S), generator=g)
-    train_ref.train_step(ref, opt, x, lab, 0)
+    train_ref.train_step(ref, opt, x[:2, :, :64, :64].contiguous(), lab[:2, :64, :64].contiguous(), 0)      # warm-up (thread pool, allocator, oneDNN primitives): 2 tiles of 64x64
     times = []
     for i in range(timed_steps):
         t0 = time.perf_counter()
@@ -492,12 +602,14 @@ def run_cpu_baseline_train(B, S, ncls, threads, timed_steps=3):
         times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {"value": round(B / med, 3), "unit": "tiles/s", "cores": n, "kind": "port",
-            "sample": "median of %d full train steps (fwd+bwd+clip+SGD) of the torch-CPU fp32 oracle at batch %d, %dx%d, after 1 warm-up step; "
-                      "step times %s s" % (timed_steps, B, S, S, ["%.2f" % t for t in times])}
+            "sample": "median of %d full train step(s) (fwd+bwd+clip+SGD) of the torch-CPU fp32 oracle at batch %d, %dx%d, after a small warm-up step "
+                      "(2 tiles of 64x64); step times %s s" % (timed_steps, B, S, S, ["%.2f" % t for t in times])}
 
 
-def run_cpu_baseline_infer(ncls, crop, nwin, threads):
-    """The oracle's eval forward over the 16 windows of one image (fp32, the reference's precision), median of 3 after 1 warm-up."""
+def run_cpu_baseline_infer(ncls, crop, nwin, threads, timed=3):
+    """The oracle's eval forward over the windows of one image (fp32, the reference's precision), median of `timed` after 1 warm-up; a BOUNDED
+    sample: at most 32 windows are evaluated (the rate per window does not depend on how many more there are)."""
+    nwin = min(nwin, 32)
     from oracle.emrt_torch import EMRT as OracleEMRT
     n = threads or min(os.cpu_count() or 1, 64)
     torch.set_num_threads(n)
@@ -506,15 +618,15 @@ def run_cpu_baseline_infer(ncls, crop, nwin, threads):
     x = torch.randn(nwin, 3, crop, crop, generator=torch.Generator().manual_seed(1234))
     times = []
     with torch.no_grad():
-        ref(x)
-        for _ in range(3):
+        ref(x[:2])                  # warm-up: thread pool, allocator, oneDNN primitives
+        for _ in range(timed):
             t0 = time.perf_counter()
             ref(x)
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {"value": round(nwin / med, 3), "unit": "tiles/s", "cores": n, "kind": "port",
-            "sample": "median of 3 eval forwards of the torch-CPU fp32 oracle over the %d windows of one image (one batch of %d), after 1 warm-up; "
-                      "times %s s" % (nwin, nwin, ["%.2f" % t for t in times])}
+            "sample": "median of %d eval forward(s) of the torch-CPU fp32 oracle over %d windows (one batch of %d), after a 2-window warm-up; "
+                      "times %s s" % (timed, nwin, nwin, ["%.2f" % t for t in times])}
 
 
 if __name__ == "__main__":

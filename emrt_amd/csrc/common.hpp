@@ -76,7 +76,7 @@ struct Tuning {
 extern Tuning g_tune;
 
 // scratch for partial sums, registered once per process by emrt_set_scratch (kernels of ONE stream use it one after the other)
-struct Scratch { void* ptr; size_t bytes; };
+struct Scratch { void* ptr; size_t bytes; void* stream; };      // stream: the ONE stream whose launches may use it (partial tiles + reduce are not atomic across streams)
 extern Scratch g_scratch;
 
 // ---- element types ---------------------------------------------------------------------------

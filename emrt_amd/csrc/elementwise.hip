@@ -47,12 +47,13 @@ emrt::Tuning tuning_from_env() {
 }
 }  // namespace
 emrt::Tuning emrt::g_tune = tuning_from_env();
-emrt::Scratch emrt::g_scratch = {nullptr, 0};
+emrt::Scratch emrt::g_scratch = {nullptr, 0, nullptr};
 
-extern "C" int emrt_set_scratch(void* ptr, size_t bytes) {
+extern "C" int emrt_set_scratch(void* ptr, size_t bytes, void* stream) {
   EMRT_REQUIRE((ptr != nullptr) == (bytes > 0) && ((uintptr_t)ptr) % 256 == 0, "scratch must be 256-byte aligned device memory (or nullptr, 0)");
   emrt::g_scratch.ptr = ptr;
   emrt::g_scratch.bytes = bytes;
+  emrt::g_scratch.stream = stream;
   return 0;
 }
 

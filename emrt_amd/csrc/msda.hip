@@ -1426,14 +1426,21 @@ static bool msda_split_allowed(int B, int Lq, int M, int dtype_is_2byte) {
 }
 
 static size_t msda_part_offset_floats(int B, int Lq, int M, int L, int P) {      // where the partial slabs start inside the workspace
-  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M + (size_t)B * M * ((Lq + 63) / 64) + 3) & ~(size_t)3;      // 16-byte aligned
+  // max |dout| partials per (batch, head): Lq / 64 from the separate scan, <= Lq / 128 chunks from the LDS gradient kernel, up to 64 row
+  // bands from the band kernel whatever Lq is (narrow maps: ADVICE r3)
+  const size_t gparts = (size_t)((Lq + 63) / 64 > 64 ? (Lq + 63) / 64 : 64);
+  return ((size_t)B * Lq * M * L * P + 512 + 2 * (size_t)B * M + (size_t)B * M * gparts + 3) & ~(size_t)3;      // 16-byte aligned
 }
 
 extern "C" size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P, const int* shapes_hw, int dtype) {
   // softmax probabilities + per-block max |dout| partials (the LDS gradient kernel leaves at most 256 / (B M) + 1 per (batch, head), the
   // separate scan Lq / 64) + the integer partial slabs of a query-split scatter (the plan emrt_msda_bwd will make for these shapes)
+  if (!shapes_hw || L < 1 || L > 4 || B < 1 || Lq < 1 || M < 1 || P < 1) {      // (a size that left the partial slabs out would be written past)
+    fail("emrt_msda_bwd_workspace_bytes", "needs the level shapes (L = 1..4) and positive sizes; returns 0");
+    return 0;
+  }
   size_t n = msda_part_offset_floats(B, Lq, M, L, P);
-  if (shapes_hw && L >= 1 && L <= 4) {
+  {
     MsdaArgs a;
     memset(&a, 0, sizeof(a));
     int Lv = 0;
@@ -1658,7 +1665,7 @@ extern "C" int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const f
 // of emrt_msda_bwd_workspace_bytes required); otherwise fp32, pre-zeroed by the caller, accumulated with global atomics.
 extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref,
                              long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref,
-                             int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream) {
+                             int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, size_t workspace_bytes, int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(ref_L == 1 || ref_L == L, "ref_L must be 1 or L");
   EMRT_REQUIRE(value && offw && ref && dout && dvalue && doffw && shapes_hw, "null pointer");
@@ -1676,6 +1683,7 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
   const bool lds_ok = (L == 3 && P == 6) || (L == 4 && P == 4) || (L == 3 && P == 4) || (L == 1 && P == 4);
   if (lds_ok) {
     EMRT_REQUIRE(workspace, "LDS scatter path needs the probability workspace");
+    EMRT_REQUIRE(workspace_bytes >= emrt_msda_bwd_workspace_bytes(B, Lq, M, L, P, shapes_hw, dtype), "workspace smaller than emrt_msda_bwd_workspace_bytes() for these arguments");
     a.probs = (float*)workspace;
     a.dvalue_t = dvalue;
     int wmax = 1;

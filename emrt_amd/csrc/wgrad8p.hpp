@@ -355,7 +355,9 @@ static int launch_wgrad8p(const WgradArgs& a, int tiles_k, int tiles_oc, int S, 
   w.KH = a.KH; w.KW = a.KW; w.stride = a.stride; w.pad = a.pad; w.dil = a.dil;
   w.steps_per_split = steps_per; w.steps_total = (int)((long long)a.N * a.OH * a.OW / 64);
   const size_t need = (size_t)S * tiles_k * tiles_oc * 65536 * sizeof(float);
-  w.slab = (g_tune.wgrad8p_slab && S > 1 && g_scratch.ptr && g_scratch.bytes >= need) ? (float*)g_scratch.ptr : nullptr;
+  // the slab / reduce pair is only safe on the stream the scratch was registered for: a launch on any other stream (a second-stream
+  // weight-gradient experiment, Context.overlap) takes the atomic epilogue instead of sharing the slab with a kernel it is not ordered against
+  w.slab = (g_tune.wgrad8p_slab && S > 1 && g_scratch.ptr && g_scratch.bytes >= need && g_scratch.stream == (void*)st) ? (float*)g_scratch.ptr : nullptr;
   auto kern = wgrad8p_kernel;
   static bool attr_done = false;
   if (!attr_done) {

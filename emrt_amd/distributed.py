@@ -30,12 +30,40 @@ def init_process_group(backend=None):
     return rank, local_rank, world
 
 
+def visible_gpu_count():
+    """GPUs this process may use, counted WITHOUT a HIP call (torch.cuda.device_count() may initialise the runtime on ROCm builds that
+    lack amdsmi): the kernel driver's topology nodes with SIMDs (CPUs have simd_count 0), cut down by HIP_/ROCR_/CUDA_VISIBLE_DEVICES."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        n = 0
+    if n == 0:      # no readable topology (containers without /sys/class/kfd): torch's count (on this image it does not initialise HIP either)
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            n = min(n, listed) if n else listed
+    return n
+
+
 def spawn_ranks(n, cmd, capture_rank0=False, log=None):
     """Launcher-less multi-GPU start: run `cmd` (an argv list) as n child processes, one rank each, with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set -- what paddle.distributed.launch gives the reference
-    (train.py:116-123 reads the ranks from it).  The CALLER must not have touched the GPU: a process that has initialised the
-    GPU runtime is never forked or replaced; the children are fresh interpreters.  A rank that dies takes the job down at once
-    (the others would otherwise wait in the rendezvous or a collective until a timeout).
+    (train.py:116-123 reads the ranks from it).  The ranks are always FRESH interpreters (subprocess.Popen): this process is never
+    forked with a live GPU runtime nor replaced by exec, and it makes no GPU call itself (the device count below comes from the
+    kernel driver's sysfs nodes, not from HIP).  A rank that dies takes the job down at once (the others would otherwise wait in
+    the rendezvous or a collective until a timeout), and so does anything that ends this function early (KeyboardInterrupt, SIGTERM,
+    an exception in the log / reader path): no rank outlives its parent holding a GPU.
     Returns (exit codes, rank 0's stdout as str or None)."""
     import socket
     import subprocess
@@ -44,7 +72,7 @@ def spawn_ranks(n, cmd, capture_rank0=False, log=None):
     import time
     log = log or (lambda *a: print(*a, file=sys.stderr, flush=True))
     if not os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):
-        have = torch.cuda.device_count()            # counts devices without initialising the GPU runtime
+        have = visible_gpu_count()
         if have < n:
             log("[launch] %d ranks requested but this node exposes %d GPU(s)" % (n, have))
             return [2] * n, None
@@ -52,25 +80,41 @@ def spawn_ranks(n, cmd, capture_rank0=False, log=None):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
-        out = (subprocess.PIPE if capture_rank0 else None) if r == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen(list(cmd), env=env, stdout=out))
     chunks = []
     reader = None
-    if capture_rank0:
-        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-        reader.start()
-    while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()                                  # exactly the processes started above
-            break
-        time.sleep(0.2)
-    codes = [p.wait() for p in procs]
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                      # exactly the processes started here
+        for p in procs:
+            p.wait()
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+    import signal
+    old_term = None
+    if threading.current_thread() is threading.main_thread():
+        old_term = signal.signal(signal.SIGTERM, on_term)     # a plain SIGTERM would end this process without running `finally`
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+            out = (subprocess.PIPE if capture_rank0 else None) if r == 0 else subprocess.DEVNULL
+            procs.append(subprocess.Popen(list(cmd), env=env, stdout=out))
+        if capture_rank0:
+            reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+            reader.start()
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break
+            time.sleep(0.2)
+    finally:
+        kill_all()                                            # normal end: everything has exited already; early end: nothing survives
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
+    codes = [p.returncode for p in procs]
     if reader is not None:
         reader.join(timeout=10)
     if any(codes):

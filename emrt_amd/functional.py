@@ -894,7 +894,8 @@ def msda(value, offw, ref, shapes, n_heads, n_points, need_dref=False):
                 dvalue = c.zeros((B, Lv, CC), torch.float32)
                 ws = None
             _L().call("emrt_msda_bwd", P(value), value.stride(1), value.stride(0), P(offw), ldo, P(ref), ref_bs, ref_L, P(dy), P(dvalue), P(doffw),
-                      int(c.dtype != F32), P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), P(ws), c.dtype, c.stream)
+                      int(c.dtype != F32), P(dref), B, Lq, Lv, M, 32, L, Pn, ctypes.cast(arr, ctypes.c_void_p), P(ws), ws.numel() * 4 if ws is not None else 0,
+                      c.dtype, c.stream)
             tape.add_grad(value, dvalue if use_lds else cast_from_f32(dvalue), owned=True)
             tape.add_grad(offw, doffw, owned=True)
             if need_dref:

@@ -275,11 +275,9 @@ class Context:
         torch.cuda.set_stream(self._main)
         self.dtype = dtype
         self._ws = torch.empty(8 << 20, dtype=torch.uint8, device=self.device)
-        # partial-sum scratch of the 256 x 256 weight-gradient kernel (one 256 KiB fp32 tile per CU), registered once: its address is baked
-        # into captured graphs, so it is never reallocated
-        if getattr(self, "_scratch", None) is None or self._scratch.device != self.device:
-            self._scratch = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
-            _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()))
+        # (the partial-sum scratch of the 256 x 256 weight-gradient kernel is allocated by the first TRAINING step in bf16: begin_step)
+        if getattr(self, "_scratch", None) is not None and self._scratch.device != self.device:
+            self._scratch = None
         self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._arena, self._arena_off, self._arena_live = None, 0, False
@@ -334,6 +332,17 @@ class Context:
         _lib.lib().call("emrt_memset", ctypes.c_void_p(self._arena.data_ptr()), 0, self._arena.numel() * 8, self.stream)
         self._arena_off = 0
         self._arena_live = True
+        self.ensure_scratch()
+
+    def ensure_scratch(self):
+        """Partial-sum scratch of the 256 x 256 weight-gradient kernel (one 256 KiB fp32 tile per CU = 64 MiB), registered for THIS
+        context's stream by the first bf16 training step -- the only kernel that uses it is bf16-only and backward-only, so inference,
+        validation and fp32 contexts never pay for it.  Its address is baked into captured graphs: allocated once, outside any capture
+        (the eager warm-up steps come first), never reallocated."""
+        if self.dtype != BF16 or getattr(self, "_scratch", None) is not None or torch.cuda.is_current_stream_capturing():
+            return
+        self._scratch = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+        _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()), self.stream)
 
     def end_step(self):
         """Outside a training step (eval forward) the arena is not re-zeroed: zeros_f64() must hand out fresh zeroed buffers."""

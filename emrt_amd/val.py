@@ -83,14 +83,15 @@ def evaluate(model, images, labels, config, rank=0, nranks=1, multi_scales=False
     t0 = time.time()
     images, labels = _OnDevice(images, dev), _OnDevice(labels, dev)
     for i in range(rank, len(images), nranks):
+        img, lab = images[i], labels[i]          # ONE host-to-device copy each per evaluation (indexing _OnDevice copies)
         if multi_scales:            # val.py:168-181: VAL.SCALE_RATIOS + horizontal flip
-            pred = infer.ms_inference(model, [images[i]], labels[i].shape[-2:], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
+            pred = infer.ms_inference(model, [img], lab.shape[-2:], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
                                       config.VAL.CROP_SIZE, ncls, scales=list(config.VAL.SCALE_RATIOS), flip_horizontal=True,
                                       flip_vertical=False, rescale_from_ori=config.VAL.RESCALE_FROM_ORI)
         else:
-            pred = infer.ss_inference(model, [images[i]], [labels[i].shape[-2:]], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
+            pred = infer.ss_inference(model, [img], [lab.shape[-2:]], True, config.VAL.IMAGE_BASE_SIZE, config.VAL.STRIDE_SIZE,
                                       config.VAL.CROP_SIZE, ncls, config.VAL.RESCALE_FROM_ORI)[0]
-        inter, pa, la = metrics.calculate_area(pred, labels[i], ncls, config.TRAIN.IGNORE_INDEX)
+        inter, pa, la = metrics.calculate_area(pred, lab, ncls, config.TRAIN.IGNORE_INDEX)
         tot[0] += inter
         tot[1] += pa
         tot[2] += la

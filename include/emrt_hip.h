@@ -44,8 +44,10 @@ int emrt_get_tuning(const char* name, int* value);
 /* Registers DEVICE memory (256-byte aligned; nullptr, 0 to unregister) that kernels may use for partial sums between two of their own
  * launches on the caller's stream: today the 256x256 weight-gradient kernel's per-block partial tiles (<= 64 MiB: one 256 KiB tile per CU)
  * for train.py:142-149's loss.backward() of the large layers.  Without it that kernel adds its tiles into dW with fp32 atomics.  The
- * memory must stay valid (and the pointer unchanged across hipGraph replays) until it is unregistered; one stream at a time. */
-int emrt_set_scratch(void* ptr, size_t bytes);
+ * memory must stay valid (and the pointer unchanged across hipGraph replays) until it is unregistered.  `stream` (ABI 5) is the ONE stream
+ * whose launches may use it: a call on any other stream falls back to the atomic epilogue (partial tiles + reduce launch are only ordered
+ * within a stream). */
+int emrt_set_scratch(void* ptr, size_t bytes, void* stream);
 
 /* ---- convolution / linear as implicit GEMM (MFMA 32x32) ---------------------------------------------------
  * replaces nn.Conv2D: backbones/paddle_vision_resnet.py:108-123,192-198,226-233; paddle_EMRT.py:16-23,63,85-91,
@@ -152,10 +154,12 @@ int emrt_msda_fwd(const void* value, int ldv, long long v_bs, const float* offw,
  * otherwise it is fp32, must be zeroed by the caller and is accumulated with global atomics.
  * emrt_msda_bwd_workspace_bytes (ABI 4: takes the level shapes and the dtype of the call it sizes): softmax probabilities, the
  * per-block max |dout| partials and -- for large pyramids, where the small levels' scatter blocks are split by queries -- the
- * integer partial slabs; it makes the same plan emrt_msda_bwd will make for these arguments. */
+ * integer partial slabs; it makes the same plan emrt_msda_bwd will make for these arguments.  ABI 5: shapes_hw == NULL (or L outside
+ * 1..4) is an error (returns 0, emrt_last_error() says why), and emrt_msda_bwd takes the size of the workspace it was given and
+ * refuses one that is smaller than this function's answer. */
 int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L);
 size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P, const int* shapes_hw, int dtype);
-int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, int dtype, void* stream);
+int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
 /* ---- fused softmax(QK^T/sqrt(d)) V with dropout on the weights: EMRT_utils/layers.py:283-303 (L <= 128, D = 32) */
 int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);

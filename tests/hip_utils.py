@@ -11,6 +11,7 @@ TOL = {F32: dict(atol=2e-4, rtol=2e-4), BF16: dict(atol=6e-2, rtol=6e-2)}
 def init(dtype, seed=0):
     c = ctx()
     c.init_device("cuda:0", dtype, seed)
+    c.ensure_scratch()          # (a training context: the model's train-mode forward does this; bf16 only)
     c.training = True
     c.tape = None
     c.world_size = 1

@@ -53,7 +53,7 @@ def test_loader_binds_all_entry_points(built):
     assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
     import ctypes
     small = (ctypes.c_int * 6)(2, 2, 2, 2, 1, 2)                   # Lv = 10
-    base = lambda B, Lq, M: ((B * Lq * M * 18 + 512 + 2 * B * M + B * M * ((Lq + 63) // 64) + 3) // 4 * 4) * 4     # probabilities + max |dout| partials
+    base = lambda B, Lq, M: ((B * Lq * M * 18 + 512 + 2 * B * M + B * M * max((Lq + 63) // 64, 64) + 3) // 4 * 4) * 4     # probabilities + max |dout| partials (>= 64 per (batch, head): row bands)
     assert L.query("emrt_msda_bwd_workspace_bytes", 2, 10, 8, 3, 6, ctypes.cast(small, ctypes.c_void_p), 1) == base(2, 10, 8)
     # batch 8 at 256x256 (Lv = 1344): no range of the value-gradient scatter is split by queries -> no partial slabs
     cfg2 = (ctypes.c_int * 6)(32, 32, 16, 16, 8, 8)
@@ -64,7 +64,9 @@ def test_loader_binds_all_entry_points(built):
     part = 4 * 8 * (2 * 3 * 512 * 32 + 5 * 256 * 32) * 4
     assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 3, 6, ctypes.cast(cfg3, ctypes.c_void_p), 1) == base(4, 5376, 8) + part
     assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 3, 6, ctypes.cast(cfg3, ctypes.c_void_p), 0) == base(4, 5376, 8)
-    assert L.last_error() == "" or isinstance(L.last_error(), str)
+    # without the level shapes the size would leave the partial slabs out -> an error, not a too-small answer
+    assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 3, 6, None, 1) == 0 and "level shapes" in L.last_error()
+    assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 5, 6, ctypes.cast(cfg3, ctypes.c_void_p), 1) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -51,3 +51,62 @@ def test_bench_world_size_must_match_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr and r.stdout.strip() == ""
     r = _run([sys.executable, "-m", "emrt_amd.train", "--gpus", "4"], WORLD_SIZE="2", RANK="0")
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+
+
+def test_spawn_ranks_kills_its_ranks_when_the_parent_is_terminated(tmp_path):
+    """a parent that ends early (SIGTERM, KeyboardInterrupt, an exception) must not leave ranks behind holding GPUs."""
+    import signal
+    import time
+    pidfile = tmp_path / "pids"
+    child = tmp_path / "child.py"
+    child.write_text("import os, time\nopen(%r + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(300)\n" % str(pidfile))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from emrt_amd.distributed import spawn_ranks\n"
+            "spawn_ranks(2, [sys.executable, %r])\n" % (ROOT, str(child)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e["EMRT_ALL_RANKS_ON_GPU0"] = "1"
+    parent = subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, env=e)
+    try:
+        t0 = time.time()
+        while not all(os.path.exists(str(pidfile) + r) and open(str(pidfile) + r).read() for r in "01"):
+            assert time.time() - t0 < 120 and parent.poll() is None
+            time.sleep(0.2)
+        pids = [int(open(str(pidfile) + r).read()) for r in "01"]
+        parent.send_signal(signal.SIGTERM)
+        parent.wait(timeout=60)
+        t0 = time.time()
+        alive = pids
+        while alive and time.time() - t0 < 30:
+            alive = [p for p in alive if os.path.exists("/proc/%d" % p) and open("/proc/%d/stat" % p).read().split()[2] != "Z"]
+            time.sleep(0.2)
+        assert not alive, "ranks %s survived their parent" % alive
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+
+
+def test_bench_without_gpus_flag_takes_the_launchers_world_size():
+    """`torchrun ... bench.py` (no --gpus) runs with WORLD_SIZE, as emrt_amd.train does; only an explicit mismatch is an error."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = os.environ.get("WORLD_SIZE")
+    try:
+        os.environ["WORLD_SIZE"] = "4"
+        a = argparse.Namespace(gpus=None)
+        mod.check_world(a)
+        assert a.gpus == 4
+        import pytest
+        with pytest.raises(SystemExit):
+            mod.check_world(argparse.Namespace(gpus=2))
+        del os.environ["WORLD_SIZE"]
+        a = argparse.Namespace(gpus=None)
+        mod.check_world(a)
+        assert a.gpus == 1
+    finally:
+        if old is None:
+            os.environ.pop("WORLD_SIZE", None)
+        else:
+            os.environ["WORLD_SIZE"] = old

@@ -124,7 +124,7 @@ def wbig():
     """Weight gradient of the big layers: 128 x 128 register-staged tile with fp32 atomics against the 256 x 256 LDS-DMA 8-phase kernel
     (partial tiles through the scratch slabs + reduce launch, or fp32 atomics), and the 8-phase kernel's slice count."""
     scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()))
+    L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()), stream)
     extra = [("cfg2 layer3 3x3", 8, 16, 16, 256, 256, 3), ("cfg2 layer4 3x3", 8, 8, 8, 512, 512, 3), ("cfg3 layer3 3x3", 4, 32, 32, 256, 256, 3),
              ("cfg2 ffn linear1", 8, 1, 1344, 256, 1024, 1), ("cfg2 ffn linear2", 8, 1, 1344, 1024, 256, 1), ("cfg2 attn proj", 8, 1, 1344, 256, 256, 1),
              ("cfg3 ffn linear1", 4, 1, 5376, 256, 1024, 1), ("cfg3 ffn linear2", 4, 1, 5376, 1024, 256, 1), ("cfg3 attn proj", 4, 1, 5376, 256, 256, 1)]
