@@ -380,19 +380,20 @@ BF16_GRAD_COSINE = 0.985        # cosine between the whole bf16 gradient vector 
 BF16_GRAD_NORM_RATIO = 0.02     # | ||g_bf16|| / ||g_ref|| - 1 |
 
 
-def test_full_size_bf16_model_vs_fp32_oracle():
-    """BASELINE configs[1] (ResNet-50, batch 8, 256x256, 6 classes) in bf16 storage / fp32 accumulation against the fp32
-    CPU oracle (the reference is fp32 throughout, train.py:141-159): eval-mode logits and argmax masks, then one
+@pytest.mark.parametrize("B,S,ncls", [(8, 256, 6), (4, 512, 7)], ids=["cfg2-8x256", "cfg3-4x512"])
+def test_full_size_bf16_model_vs_fp32_oracle(B, S, ncls):
+    """BASELINE configs[1] (ResNet-50, batch 8, 256x256, 6 classes) and configs[2] (LoveDA geometry: batch 4, 512x512, 7 classes,
+    Lv = 5376 -- the row-band MSDA kernels, the query-split scatter) in THEIR OWN dtype and batch: bf16 storage / fp32 accumulation
+    against the fp32 CPU oracle (the reference is fp32 throughout, train.py:141-159): eval-mode logits and argmax masks, then one
     train-mode forward + loss + backward (dropout off: the oracle cannot share the device's mask stream)."""
     from tests.test_gpu_model import build_pair, make_config
     from emrt_amd.src.models.losses import get_loss_function
     from oracle import train_ref
     g = torch.Generator().manual_seed(17)
-    B, S = 8, 256
     x = torch.randn(B, 3, S, S, generator=g)
-    labels = torch.randint(0, 6, (B, S, S), generator=g)
+    labels = torch.randint(0, ncls, (B, S, S), generator=g)
     labels[torch.rand(B, S, S, generator=g) < 0.02] = 255
-    ref, model = build_pair("resnet50", x, dtype=BF16, perturb=True, condition=0.1)
+    ref, model = build_pair("resnet50", x, dtype=BF16, perturb=True, condition=0.1, ncls=ncls)
     # ---- eval-mode logits (running statistics calibrated on this batch) ---------------------------------------------
     ref.eval()
     model.eval()
@@ -410,9 +411,9 @@ def test_full_size_bf16_model_vs_fp32_oracle():
         margin = top2[:, 0] - top2[:, 1]
         decisive = margin > 0.1 * (b.max() - b.min())
         agree_dec = (a.argmax(1) == b.argmax(1))[decisive].float().mean().item()
-        print("bf16 eval %s logits: rel L2 %.4f (torch CPU autocast: %.4f), max |diff| %.4f (|ref| max %.3f), argmax agreement %.5f (autocast %.5f), "
-              "among %d decisive pixels %.6f" % (name, rel, rel_y, (a - b).abs().max().item(), b.abs().max().item(), agree, agree_y,
-                                                   int(decisive.sum()), agree_dec))
+        print("bf16 eval %dx%dx%d %s logits: rel L2 %.4f (torch CPU autocast: %.4f), max |diff| %.4f (|ref| max %.3f), argmax agreement %.5f (autocast %.5f) "
+              "= %d of %d pixels differ, among %d decisive pixels %.6f" % (B, S, S, name, rel, rel_y, (a - b).abs().max().item(), b.abs().max().item(), agree, agree_y,
+                                                   int((a.argmax(1) != b.argmax(1)).sum()), a.argmax(1).numel(), int(decisive.sum()), agree_dec))
         assert rel < BF16_LOGIT_REL_L2, (name, rel)
         assert rel <= BF16_VS_AUTOCAST * rel_y + 0.005, (name, rel, rel_y)
         assert agree >= BF16_ARGMAX_AGREE and agree >= agree_y - 0.01, (name, agree, agree_y)
@@ -425,7 +426,7 @@ def test_full_size_bf16_model_vs_fp32_oracle():
     model.train()
     model.clear_gradients()
     out = model(x.cuda())
-    loss = get_loss_function(make_config("resnet50"))(out, labels.cuda())
+    loss = get_loss_function(make_config("resnet50", ncls=ncls))(out, labels.cuda())
     loss.backward()
     torch.cuda.synchronize()
     rel_main = ((out[0].cpu() - out_r[0].detach()).norm() / out_r[0].detach().norm()).item()
