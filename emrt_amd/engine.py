@@ -184,9 +184,10 @@ class TrainEngine:
         self.labels = labels.clone()
         c.workspace(64 << 20)
         torch.cuda.synchronize()
-        # with a process group alive, ProcessGroupNCCL's watchdog thread polls events while we capture: the default
-        # "global" capture mode turns such a foreign-thread call into a capture error (seen as a watchdog abort)
-        mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
+        # other threads make HIP calls while this one captures: ProcessGroupNCCL's watchdog polls events, the TileLoader's reader threads
+        # page-lock their batches (train.py --data dataset).  The default "global" capture mode turns any such foreign-thread call into a
+        # capture error (seen as a watchdog abort, and as hipErrorStreamCaptureInvalidated at the first captured step of a real-data run)
+        mode = {"capture_error_mode": "thread_local"}
         # every stretch is a GraphSequence: one hipGraph, or several around the SyncBatchNorm statistics all-reduces
         self.graph_a = GraphSequence(mode=mode)
         if self.seg_ranges is not None:

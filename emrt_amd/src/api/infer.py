@@ -182,7 +182,7 @@ class SlidingWindowEngine:
             self.image = img.contiguous().clone()
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):      # (reader threads of a validation loader may make HIP calls meanwhile)
                 self.logits, self.pred = self._run(self.image)
         if img.data_ptr() != self.image.data_ptr():
             self.image.copy_(img, non_blocking=True)
