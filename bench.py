@@ -157,7 +157,7 @@ def family_table(calls):
     return fam
 
 
-def dump_calls(path, calls):
+def dump_calls(path, calls, esz=2):
     with open(path, "w") as f:
         for name, a, ms in calls:
             vals = vals_of(a)
@@ -171,6 +171,8 @@ def dump_calls(path, calls):
                 extra = "n=%d " % vals[1] + " ".join("%dx%dx%d->%d k%d" % (d.H, d.W, d.C, d.OC, d.KH) for d in list(vals[0])[:vals[1]]) + " gflop %.2f" % (conv_flops(name, vals) / 1e9)
             else:       # integer arguments only: enough to recognise the layer
                 extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))
+            if name in GEMM_FAMILIES:
+                extra += " bytes %d" % conv_bytes(name, vals, esz)
             f.write("%-26s %9.4f ms  %s\n" % (name, ms, extra))
 
 
@@ -478,7 +480,7 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         eng_prof.reducer = None
         calls = timed_replay(lambda: eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels))
         if dump:
-            dump_calls(dump, calls)
+            dump_calls(dump, calls, 4 if dtype_name == "fp32" else 2)
         roofline, roofline_msda, lines = rooflines(calls, dtype_name, cfg_key if (B, S) == (CONFIGS[cfg_key]["batch"], CONFIGS[cfg_key]["size"]) else "custom", True)
         for ln in lines:
             log(ln)
@@ -559,7 +561,7 @@ def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         assert tuple(pred.shape) == (1, 1, img_h, img_w) and pred.dtype == torch.int32
         calls = timed_replay(lambda: slide_inference(model, [img], (crop, crop), (crop, crop), ncls))
         if dump:
-            dump_calls(dump, calls)
+            dump_calls(dump, calls, 4 if dtype_name == "fp32" else 2)
         roofline, roofline_msda, lines = rooflines(calls, dtype_name, cfg_key if nwin == CONFIGS[cfg_key]["batch"] else "custom", False)
         for ln in lines:
             log(ln)

@@ -328,7 +328,9 @@ def test_fifty_step_training_trajectory_tracks_the_oracle():
     for step in range(50):
         x, lab = xs[step % 2], labs[step % 2]
         loss_ref, lr_ref = train_ref.train_step(ref, ropt, x, lab, step, 0.01, 0.0, 100, 0.9)
+        lr_host = opt.get_lr()
         loss_t = eng.step(x.cuda(), lab.cuda())
+        assert abs(lr_host - lr_ref) < 1e-12 and abs(float(opt.lr_dev.item()) - lr_ref) < 1e-8
         dl = abs(loss_t.item() - loss_ref) / max(1.0, abs(loss_ref))
         dg = abs(opt.grad_norm() - ropt.last_grad_norm) / ropt.last_grad_norm
         num = den = 0.0
@@ -340,7 +342,6 @@ def test_fifty_step_training_trajectory_tracks_the_oracle():
         dw = (num / den) ** 0.5
         rows.append((step, loss_t.item(), loss_ref, dl, dg, dw))
         worst = [max(worst[0], dl), max(worst[1], dg), max(worst[2], dw)]
-        assert abs(opt.get_lr() - lr_ref) < 1e-12 or step == 49
     for r in rows[::5] + [rows[-1]]:
         print("step %2d: loss %.5f (oracle %.5f, rel %.1e)  grad-norm rel %.1e  weights rel L2 %.1e" % r)
     print("TRAJECTORY 50 steps: worst loss rel %.2e, worst grad-norm rel %.2e, final weight distance %.2e" % (worst[0], worst[1], rows[-1][5]))

@@ -161,8 +161,64 @@ def wbig():
         print(line, flush=True)
 
 
+class _WD(ctypes.Structure):       # EmrtWgradDesc
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("ldx", ctypes.c_int),
+                ("x_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int), ("lddy", ctypes.c_int),
+                ("dy_bs", ctypes.c_longlong), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+                ("dilation", ctypes.c_int)]
+
+
+def wgroup():
+    """Batched weight gradients (emrt_conv2d_wgrad_group) in the throughput regime: n copies of one layer shape in one call, against n single
+    launches; and the step's real mixes (a ResNet stage, an encoder layer).  What the 128x128 weight-gradient body delivers when the machine is full."""
+    def problems(shapes):
+        keep, arr = [], (_WD * len(shapes))()
+        gf = 0.0
+        for d, (N, H, W, C, OC, k, s, pad) in zip(arr, shapes):
+            OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+            x = torch.randn(N, H, W, C, device=dev).bfloat16()
+            dy = torch.randn(N, OH, OW, OC, device=dev).bfloat16()
+            dw = torch.zeros(OC, k, k, C, device=dev, dtype=torch.float32)
+            keep += [x, dy, dw]
+            d.x, d.dy, d.dw, d.dbias = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None
+            d.N, d.H, d.W, d.C, d.ldx, d.x_bs = N, H, W, C, C, H * W * C
+            d.OH, d.OW, d.OC, d.lddy, d.dy_bs = OH, OW, OC, OC, OH * OW * OC
+            d.KH, d.KW, d.stride, d.pad, d.dilation = k, k, s, pad, 1
+            gf += 2.0 * N * OH * OW * OC * k * k * C / 1e9
+        return arr, keep, gf
+
+    def run(arr, n):
+        return lambda: L._raw_emrt_conv2d_wgrad_group(arr, n, 1, stream)
+    one = [(8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1), (8, 16, 16, 1024, 256, 1, 1, 0), (8, 16, 16, 256, 1024, 1, 1, 0), (8, 8, 8, 512, 512, 3, 1, 1),
+           (8, 1, 1344, 256, 1024, 1, 1, 0), (8, 1, 1344, 1024, 256, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0), (8, 64, 64, 64, 256, 1, 1, 0), (8, 64, 64, 256, 64, 1, 1, 0),
+           (8, 64, 64, 64, 64, 3, 1, 1), (8, 32, 32, 128, 128, 3, 1, 1), (8, 32, 32, 512, 128, 1, 1, 0)]
+    for shp in one:
+        line = "N%d %dx%dx%d->%d k%d |" % shp[:6]
+        for n in (1, 4, 12, 24):
+            arr, keep, gf = problems([shp] * n)
+            t = min(timed(run(arr, n), 20), timed(run(arr, n), 20))
+            line += " x%-2d %7.1f us = %5.1f us each, %4.0f TF/s |" % (n, t, t / n, gf / t * 1e3)
+        print(line, flush=True)
+    layer3 = [(8, 16, 16, 1024, 256, 1, 1, 0), (8, 16, 16, 256, 256, 3, 1, 1), (8, 16, 16, 256, 1024, 1, 1, 0)] * 6
+    layer1 = [(8, 64, 64, 256, 64, 1, 1, 0), (8, 64, 64, 64, 64, 3, 1, 1), (8, 64, 64, 64, 256, 1, 1, 0)] * 3
+    enc = [(8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 432, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 1024, 1, 1, 0), (8, 1, 1344, 1024, 256, 1, 1, 0),
+           (8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1), (8, 8, 8, 256, 256, 3, 1, 1)] * 3
+    for name, mix in (("resnet layer3 x18", layer3), ("resnet layer1 x9", layer1), ("encoder layers x24", enc)):
+        arr, keep, gf = problems(mix)
+        line = "%-20s %6.1f GF |" % (name, gf)
+        for blocks in (512, 1024, 2048):
+            old = L.set_tuning("wgroup_blocks", blocks)
+            t = min(timed(run(arr, len(mix)), 20), timed(run(arr, len(mix)), 20))
+            L.set_tuning("wgroup_blocks", old)
+            line += " blocks %4d: %7.1f us %4.0f TF/s |" % (blocks, t, gf / t * 1e3)
+        print(line, flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "wgroup":
+        return wgroup()
     if which == "wbig":
         return wbig()
     if which == "thin":

@@ -1,63 +1,157 @@
-"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB per dispatch) per kernel into profiles/.
+"""Summarise the rocprofv3 passes of one eager bench run per config into profiles/ (tools/profile_round.sh):
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 0 --no-graph --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 0 --no-graph --no-cpu-baseline
-    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r1d_pmc_traffic
+    python tools/pmc_summary.py <fetch dir> <write dir> <dst prefix> [<sq dir> <trace dir> <calls.txt>]
 
-gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-B read requests as 64 B, i.e. reports half
-of the bytes of wide coalesced reads; WRITE_SIZE is exact for streaming stores and float atomics.  Both raw and
-corrected (2 x FETCH + WRITE) figures are written.
-"""
+  <dst>.csv   per kernel: dispatches, FETCH_SIZE / WRITE_SIZE KB per dispatch, corrected traffic
+  <dst>.json  per kernel FAMILY: bytes per dispatch and dispatches per step -- what bench.py attaches to `roofline.traffic`
+              (conv_backward_family: every kernel that computes a conv / linear data or weight gradient; conv_forward_family)
+  <dst>_layers.csv (with the three optional inputs) the small-launch table: ONE ROW PER C-ABI CONV CALL of a step, in step order --
+              layer shape, rocprof duration, GFLOP, TFLOP/s, algorithmic bytes, PMC bytes, MFMA-busy fraction.
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-B read requests as 64 B, i.e. reports half of the bytes of wide
+coalesced reads; WRITE_SIZE is exact for streaming stores and float atomics.  Raw and corrected (2 x FETCH + WRITE) figures are written.
+The passes are separate runs of the same deterministic launch sequence, so dispatch i of one pass is dispatch i of the others."""
 import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
-def load(d):
-    out = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        out[name].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
-    return out
+def rows_of(d, pattern):
+    f = glob.glob(d + "/*/*" + pattern) or glob.glob(d + "/*" + pattern)
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def last_step(names):
+    """Index range of the last complete step: between the last two optimizer kernels (a training run), else the whole list."""
+    idx = [i for i, n in enumerate(names) if "sgd_momentum" in n]
+    if len(idx) >= 2:
+        return idx[-2] + 1, idx[-1] + 1
+    return 0, len(names)
+
+
+def per_dispatch(d, counter=None):
+    """-> [(kernel, value, grid)] in dispatch order for one counter of a --pmc pass (rows carry Dispatch_Id)."""
+    rows = rows_of(d, "counter_collection.csv")
+    out = {}
+    for n, r in enumerate(rows):
+        if counter and r["Counter_Name"] != counter:
+            continue
+        key = int(r["Dispatch_Id"]) if r.get("Dispatch_Id") else n
+        prev = out.get(key)
+        val = float(r["Counter_Value"]) + (prev[1] if prev else 0.0)       # (a counter reported per XCD / per dimension: summed)
+        out[key] = (short(r["Kernel_Name"]), val, int(r["Grid_Size"]))
+    return [out[k] for k in sorted(out)]
+
+
+CONV_BWD = lambda k: ("igemm_kernel" in k and re.search(r"igemm_kernel<[^,]+, \d+, \d+, \d+, \d+, 1,", k)) or ("igemm8p_kernel" in k and re.search(r"igemm8p_kernel<[^,]+, 1,", k)) \
+    or "wgrad" in k or "bwd_pair" in k or "bwd_group" in k or "thin_bwd" in k or re.search(r"igemm_group_kernel<[^,]+, 1>", k)
+CONV_FWD = lambda k: ("igemm" in k) and not CONV_BWD(k)
 
 
 def main():
-    fetch, write, dst = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    fetch_d, write_d, dst = sys.argv[1:4]
+    fetch, write = per_dispatch(fetch_d), per_dispatch(write_d)
+    names = [k for k, _, _ in fetch]
+    assert len(fetch) == len(write) and names == [k for k, _, _ in write], "the two passes launched different sequences"
+    by = collections.defaultdict(list)
+    for (k, f, g), (_, w, _) in zip(fetch, write):
+        by[k].append((f, w, g))
     rows = []
-    for name in sorted(fetch, key=lambda k: -sum(x[0] for x in fetch[k])):
-        f, w = fetch[name], write.get(name, [])
-        if not w or "emrt" not in name and "kernel" not in name:
-            continue
-        n = len(f)
-        fk, wk = sum(x[0] for x in f) / n, sum(x[0] for x in w) / max(1, len(w))
-        rows.append((name, n, fk, wk, 2 * fk + wk))
+    for k in sorted(by, key=lambda k: -sum(2 * f + w for f, w, _ in by[k])):
+        v = by[k]
+        n = len(v)
+        rows.append((k, n, sum(x[0] for x in v) / n, sum(x[1] for x in v) / n, sum(2 * x[0] + x[1] for x in v) / n))
     with open(dst + ".csv", "w") as fo:
         fo.write("kernel,dispatches,FETCH_SIZE_KB_per_dispatch_raw,WRITE_SIZE_KB_per_dispatch,traffic_KB_per_dispatch_corrected(2*FETCH+WRITE)\n")
         for r in rows:
             fo.write('"%s",%d,%.2f,%.2f,%.2f\n' % r)
+    a, b = last_step(names)
+    step = [(k, f, w, g) for (k, f, g), (_, w, _) in zip(fetch[a:b], write[a:b])]
 
     def family(pred, grid=None):
-        fs = [x[0] for k, v in fetch.items() if pred(k) for x in v if grid is None or x[1] == grid]
-        ws = [x[0] for k, v in write.items() if pred(k) for x in v if grid is None or x[1] == grid]
-        if not fs or not ws:
+        sel = [(f, w) for k, f, w, g in step if pred(k) and (grid is None or g == grid)]
+        if not sel:
             return None
-        return {"dispatches": len(fs), "fetch_mb_raw": round(sum(fs) / len(fs) / 1e3, 3), "write_mb": round(sum(ws) / len(ws) / 1e3, 3),
-                "traffic_mb_corrected": round((2 * sum(fs) / len(fs) + sum(ws) / len(ws)) / 1e3, 3)}
-
-    enc_name = max((k for k in fetch if "msda_fwd" in k), key=lambda k: max(x[1] for x in fetch[k]))    # the encoder call: largest grid
-    enc_grid = max(x[1] for x in fetch[enc_name])
-    js = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 0 --no-graph`; "
-                    "per-dispatch averages; corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B reads as 64 B)",
-          "igemm_kernel": family(lambda k: "igemm_kernel" in k),
-          "wgrad_kernel": family(lambda k: "wgrad_kernel" in k),
-          "msda_fwd_kernel_encoder": family(lambda k: k == enc_name, enc_grid),
-          "bwd_pair_kernel": family(lambda k: "bwd_pair_kernel" in k)}
-    js = {k: v for k, v in js.items() if v is not None}        # (inference profiles have no backward kernels)
-    js["msda_fwd_kernel_encoder"]["kernel"] = enc_name
+        n = len(sel)
+        return {"dispatches_per_step": n, "fetch_mb_raw": round(sum(f for f, _ in sel) / n / 1e3, 3), "write_mb": round(sum(w for _, w in sel) / n / 1e3, 3),
+                "traffic_mb_corrected": round(sum(2 * f + w for f, w in sel) / n / 1e3, 3), "kernels": sorted({k.split("<")[0] for k, f, w, g in step if pred(k)})}
+    enc = [(k, g) for k, f, w, g in step if "msda_fwd" in k]
+    js = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 2 --warmup 0 --no-graph`; the dispatches of the "
+                    "last complete step; per-dispatch averages; corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B reads as 64 B)",
+          "conv_backward_family": family(CONV_BWD), "conv_forward_family": family(CONV_FWD)}
+    if enc:
+        enc_grid = max(g for _, g in enc)
+        enc_name = [k for k, g in enc if g == enc_grid][0]
+        js["msda_fwd_kernel_encoder"] = family(lambda k: k == enc_name, enc_grid)
+        js["msda_fwd_kernel_encoder"]["kernel"] = enc_name
+    js = {k: v for k, v in js.items() if v is not None}
     json.dump(js, open(dst + ".json", "w"), indent=1)
     print(json.dumps(js, indent=1))
+    if len(sys.argv) >= 7:
+        layer_table(dst, step, a, b, names, sys.argv[4], sys.argv[5], sys.argv[6])
+
+
+def layer_table(dst, step, a, b, names, sq_d, trace_d, calls_path):
+    mfma = per_dispatch(sq_d, "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui = per_dispatch(sq_d, "GRBM_GUI_ACTIVE")
+    tr = rows_of(trace_d, "kernel_trace.csv")
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    tnames = [short(r["Kernel_Name"]) for r in tr]
+    ta, tb = last_step(tnames)
+    dur = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in tr[ta:tb]]
+    ok_sq = len(mfma) == len(names) and [k for k, _, _ in mfma] == names
+    ok_tr = [k for k, _ in dur] == [k for k, _, _, _ in step]
+    if not ok_tr:
+        print("[layers] kernel-trace pass launched a different sequence (%d vs %d dispatches): durations left out" % (len(dur), len(step)))
+    calls = []
+    for ln in open(calls_path):
+        m = re.match(r"(\S+)\s+([\d.]+) ms\s+(.*)", ln)
+        if m:
+            calls.append((m.group(1), float(m.group(2)) * 1e3, m.group(3)))
+    conv_names = ("emrt_conv2d", "emrt_conv2d_bwd", "emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group")
+    is_conv_kernel = lambda k: "igemm" in k or "wgrad" in k or "thin_bwd" in k or "bwd_pair" in k or "bwd_group" in k
+    wg_kernels = lambda k: "wgrad" in k
+    i = 0
+    out = []
+    for cname, ev_us, extra in calls:
+        if cname not in conv_names:
+            continue
+        while i < len(step) and not is_conv_kernel(step[i][0]):
+            i += 1
+        if i >= len(step):
+            break
+        j = i + 1
+        if cname == "emrt_conv2d_wgrad_group" or (cname == "emrt_conv2d_bwd" and wg_kernels(step[i][0])):     # several dispatches: every weight-gradient kernel in a row
+            while j < len(step) and wg_kernels(step[j][0]):
+                j += 1
+            if cname == "emrt_conv2d_bwd":      # wgrad dispatch(es) then the data gradient
+                j += 1
+        ks = step[i:j]
+        us = sum(d for _, d in dur[i:j]) if ok_tr else float("nan")
+        traffic = sum(2 * f + w for _, f, w, _ in ks) * 1e3
+        busy = float("nan")
+        if ok_sq:
+            mb = sum(v for _, v, _ in mfma[a + i:a + j])
+            cyc = sum(v for _, v, _ in gui[a + i:a + j]) / 8.0
+            busy = mb / (1024.0 * cyc) if cyc > 0 else float("nan")
+        gf = float(re.search(r"gflop ([\d.]+)", extra).group(1)) if "gflop" in extra else 0.0
+        ab = int(re.search(r"bytes (\d+)", extra).group(1)) if "bytes" in extra else 0
+        shape = re.sub(r"\s*gflop.*", "", extra)[:110]
+        out.append((cname, shape, len(ks), ks[0][0].split("<")[0], us, gf, gf / us * 1e3 if us == us and us > 0 else 0.0, ab, traffic, traffic / ab if ab else 0.0, busy, ev_us))
+        i = j
+    with open(dst + "_layers.csv", "w") as fo:
+        fo.write("call,layer,dispatches,first_kernel,rocprof_us,gflop,tflops,algorithmic_bytes,pmc_bytes(2*FETCH+WRITE),pmc_over_algorithmic,mfma_busy_frac,event_clock_us\n")
+        for r in out:
+            fo.write('%s,"%s",%d,%s,%.2f,%.3f,%.1f,%d,%d,%.2f,%.3f,%.2f\n' % r)
+    tot_us = sum(r[4] for r in out if r[4] == r[4])
+    print("[layers] %d conv calls, %.3f ms of kernel time, %.1f GFLOP -> %.1f TFLOP/s; table in %s_layers.csv" % (len(out), tot_us / 1e3, sum(r[5] for r in out), sum(r[5] for r in out) / tot_us * 1e3 if tot_us else 0, dst))
 
 
 if __name__ == "__main__":
