@@ -410,6 +410,14 @@ def main():
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if rank == 0:
+        # the JSON line goes out LAST: RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise
+        # be flushed after this line, at exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
         print(json.dumps(result), flush=True)
 
 

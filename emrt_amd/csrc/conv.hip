@@ -1703,8 +1703,6 @@ static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t s
   auto flush = [&]() -> int {
     if (npend == 0) return 0;
     if (npend == 1) { const int rc = wgrad_dispatch<T>(pend[0], st); npend = 0; return rc; }
-    // one target for the block length (pixel tiles per block) of the whole batch: about wgroup_blocks blocks in all, never fewer than
-    // wgroup_min_steps tiles per block, and never MORE slices for a problem than it would take alone
     int tx[EMRT_MAX_WGROUP], ty[EMRT_MAX_WGROUP], S1[EMRT_MAX_WGROUP];
     long long mt[EMRT_MAX_WGROUP], work = 0;
     for (int i = 0; i < npend; ++i) {
@@ -1713,18 +1711,27 @@ static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t s
       mt[i] = ((long long)pend[i].N * pend[i].OH * pend[i].OW + Cfg::BKM - 1) / Cfg::BKM;
       work += (long long)tx[i] * ty[i] * mt[i];
     }
-    const long long want = g_tune.wgroup_blocks > 0 ? g_tune.wgroup_blocks : 1024;
-    long long Tt = (work + want - 1) / want;
-    if (Tt < g_tune.wgroup_min_steps) Tt = g_tune.wgroup_min_steps;
-    if (Tt < 1) Tt = 1;
-    // longest blocks first (the tail of the launch is then made of short ones)
     int order[EMRT_MAX_WGROUP];
-    long long tps[EMRT_MAX_WGROUP];
+    long long tps[EMRT_MAX_WGROUP], Sl[EMRT_MAX_WGROUP];
+    {
+      // ONE block length T (pixel tiles per block) for the whole batch; problem i is cut into ceil(mt_i / T) slices, never more than it would
+      // take alone.  T = max(work / wgroup_blocks, wgroup_min_steps) = max(work / 1024, 32), from sweeps of the step's own mixes on MI355X
+      // (tools/bench_conv.py wgroup mixes, profiles/r4_wgroup_plan.txt): large batches (an encoder layer's 24 weight gradients, 87 GFLOP)
+      // want ~1000 blocks (158 us; 217 us with 128 long blocks), but cutting blocks shorter than ~32 tiles only buys fp32 atomic traffic --
+      // every slice re-adds its problem's whole dW at 1.3 TB/s: ResNet layer3 x18 (28 MB of dW) 59 us with one slice each, 86 us with two to
+      // three; the decoder's twelve small linears 26 vs 48 us.  (A fitted cost model -- block time c0 + c1 T, 512 resident blocks, atomics at
+      // 1.3 TB/s -- was tried in its place: it cannot see how much of the atomic tail the next wave of blocks hides, and chose worse.)
+      long long Tt = (work + g_tune.wgroup_blocks - 1) / (g_tune.wgroup_blocks > 0 ? g_tune.wgroup_blocks : 1024);
+      if (Tt < g_tune.wgroup_min_steps) Tt = g_tune.wgroup_min_steps;
+      if (Tt < 1) Tt = 1;
+      for (int i = 0; i < npend; ++i) {
+        long long S = (mt[i] + Tt - 1) / Tt;
+        Sl[i] = S > S1[i] ? S1[i] : (S < 1 ? 1 : S);
+      }
+    }
+    // longest blocks first (the tail of the launch is then made of short ones)
     for (int i = 0; i < npend; ++i) {
-      long long S = (mt[i] + Tt - 1) / Tt;
-      if (S > S1[i]) S = S1[i];
-      if (S < 1) S = 1;
-      tps[i] = (mt[i] + S - 1) / S;
+      tps[i] = (mt[i] + Sl[i] - 1) / Sl[i];
       order[i] = i;
     }
     for (int i = 1; i < npend; ++i)

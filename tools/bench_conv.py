@@ -193,7 +193,7 @@ def wgroup():
     one = [(8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1), (8, 16, 16, 1024, 256, 1, 1, 0), (8, 16, 16, 256, 1024, 1, 1, 0), (8, 8, 8, 512, 512, 3, 1, 1),
            (8, 1, 1344, 256, 1024, 1, 1, 0), (8, 1, 1344, 1024, 256, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0), (8, 64, 64, 64, 256, 1, 1, 0), (8, 64, 64, 256, 64, 1, 1, 0),
            (8, 64, 64, 64, 64, 3, 1, 1), (8, 32, 32, 128, 128, 3, 1, 1), (8, 32, 32, 512, 128, 1, 1, 0)]
-    for shp in one:
+    for shp in ([] if len(sys.argv) > 2 and sys.argv[2] == "mixes" else one):
         line = "N%d %dx%dx%d->%d k%d |" % shp[:6]
         for n in (1, 4, 12, 24):
             arr, keep, gf = problems([shp] * n)
@@ -204,14 +204,18 @@ def wgroup():
     layer1 = [(8, 64, 64, 256, 64, 1, 1, 0), (8, 64, 64, 64, 64, 3, 1, 1), (8, 64, 64, 64, 256, 1, 1, 0)] * 3
     enc = [(8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 432, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 1024, 1, 1, 0), (8, 1, 1344, 1024, 256, 1, 1, 0),
            (8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1), (8, 8, 8, 256, 256, 3, 1, 1)] * 3
-    for name, mix in (("resnet layer3 x18", layer3), ("resnet layer1 x9", layer1), ("encoder layers x24", enc)):
+    layer4 = [(8, 8, 8, 2048, 512, 1, 1, 0), (8, 8, 8, 512, 512, 3, 1, 1), (8, 8, 8, 512, 2048, 1, 1, 0)] * 3
+    layer2 = [(8, 32, 32, 512, 128, 1, 1, 0), (8, 32, 32, 128, 128, 3, 1, 1), (8, 32, 32, 128, 512, 1, 1, 0)] * 4
+    dec = [(8, 1, 110, 256, 256, 1, 1, 0), (8, 1, 110, 256, 512, 1, 1, 0), (8, 1, 110, 256, 1024, 1, 1, 0), (8, 1, 110, 1024, 256, 1, 1, 0), (8, 1, 110, 256, 432, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0)] * 2
+    for name, mix in (("resnet layer3 x18", layer3), ("resnet layer4 x9", layer4), ("resnet layer2 x12", layer2), ("resnet layer1 x9", layer1), ("encoder layers x24", enc), ("decoder x12", dec)):
         arr, keep, gf = problems(mix)
-        line = "%-20s %6.1f GF |" % (name, gf)
-        for blocks in (512, 1024, 2048):
-            old = L.set_tuning("wgroup_blocks", blocks)
+        t = min(timed(run(arr, len(mix)), 20), timed(run(arr, len(mix)), 20))
+        line = "%-20s %6.1f GF | default plan %6.1f us | forced block counts:" % (name, gf, t)
+        for blocks in (128, 256, 384, 512, 768, 1024, 2048):
+            old, oldm = L.set_tuning("wgroup_blocks", blocks), L.set_tuning("wgroup_min_steps", 1)
             t = min(timed(run(arr, len(mix)), 20), timed(run(arr, len(mix)), 20))
-            L.set_tuning("wgroup_blocks", old)
-            line += " blocks %4d: %7.1f us %4.0f TF/s |" % (blocks, t, gf / t * 1e3)
+            L.set_tuning("wgroup_blocks", old), L.set_tuning("wgroup_min_steps", oldm)
+            line += " %4d: %6.1f us |" % (blocks, t)
         print(line, flush=True)
 
 
