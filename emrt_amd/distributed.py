@@ -166,6 +166,8 @@ class FlatGradReducer:
         accumulate until wait(), so an early launch(early_ranges) can overlap the rest of backward."""
         if self.world <= 1 and not self.always:
             return
+        if self.world <= 1 and os.environ.get("EMRT_EXCHANGE_NOOP"):      # measurement aid (1-rank group only): the step structure without the collective
+            return
         use_avg = dist.get_backend() == "nccl"
         slices = self.slices if ranges is None else [b for a, e in ranges for b in bucket_slices(e, self.bucket, a)]
         for s, e in slices:

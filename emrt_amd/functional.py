@@ -313,7 +313,8 @@ def launch_wgrads(pending):
     arr = (_WgradDesc * len(pending))()
     for d, (f, _keep) in zip(arr, pending):
         (d.x, d.dy, d.dw, d.dbias, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, d.KH, d.KW, d.stride, d.pad, d.dilation) = f
-    _L().call("emrt_conv2d_wgrad_group", arr, len(pending), c.dtype, c.stream)
+    stream = c.wgrad_fork([t for _f, keep in pending for t in keep]) if c.wgrad_side else c.stream
+    _L().call("emrt_conv2d_wgrad_group", arr, len(pending), c.dtype, stream)
 
 
 def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1,

@@ -181,6 +181,7 @@ class Tape:
                 self.ops.pop()()
             # the weight gradients this segment deferred: the caller (optimizer, or the gradient exchange of this segment's ranges) needs them now
             self.flush_wgrads()
+            _CTX.wgrad_join()
         finally:
             _CTX._in_backward = False
         if stop_at > 0:
@@ -220,6 +221,11 @@ class Context:
         # gradients of up to `wgrad_batch` layers go out as ONE grouped launch (emrt_conv2d_wgrad_group).  0 = every layer on its own.
         import os
         self.wgrad_batch = int(os.environ.get("EMRT_WGRAD_BATCH", "24"))
+        # EMRT_WGRAD_SIDE=1 (A/B experiment): the batched weight-gradient launches go to a second stream, next to the latency-bound
+        # data-gradient / BatchNorm chain of the main stream; joined at the end of each backward segment
+        self.wgrad_side = bool(int(os.environ.get("EMRT_WGRAD_SIDE", "0")))
+        self._wside = None
+        self._wside_keep = []
 
     def collective(self, fn):
         """Run a host-issued collective (fn enqueues it on the current stream's timeline) at this point of the step.  Eager:
@@ -256,6 +262,21 @@ class Context:
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_keep = []
+        self.wgrad_join()
+
+    def wgrad_fork(self, keep):
+        """Side stream for a batch of weight gradients, ordered after everything issued so far on the current stream; `keep`: the tensors its
+        kernels read (they must not go back to the allocator before the join)."""
+        if self._wside is None:
+            self._wside = torch.cuda.Stream(device=self.device)
+        self._wside.wait_stream(torch.cuda.current_stream())
+        self._wside_keep.extend(keep)
+        return ctypes.c_void_p(self._wside.cuda_stream)
+
+    def wgrad_join(self):
+        if self._wside is not None and self._wside_keep:
+            torch.cuda.current_stream().wait_stream(self._wside)
+            self._wside_keep = []
 
     # ---- device / dtype -------------------------------------------------------------------------
     def init_device(self, device="cuda:0", dtype=F32, seed=1234):
@@ -342,7 +363,12 @@ class Context:
         if self.dtype != BF16 or getattr(self, "_scratch", None) is not None or torch.cuda.is_current_stream_capturing():
             return
         self._scratch = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
-        _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()), self.stream)
+        st = self.stream
+        if self.wgrad_side:          # (every weight gradient, the large layers' included, is then launched from the side stream)
+            if self._wside is None:
+                self._wside = torch.cuda.Stream(device=self.device)
+            st = ctypes.c_void_p(self._wside.cuda_stream)
+        _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()), st)
 
     def end_step(self):
         """Outside a training step (eval forward) the arena is not re-zeroed: zeros_f64() must hand out fresh zeroed buffers."""
