@@ -123,8 +123,16 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // Occupancy: the 64x64 tile without K split is what every many-block, short-K layer runs (token linears, 1x1 convs);
 // those are prologue / epilogue dominated, so it is held to 128 registers = 4 blocks per CU (measured: 180 registers, i.e.
 // 2 blocks per CU, cost 25-35 % on those shapes).
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G>
+// S2 (data gradient of a stride-2 convolution, dilation 1, even output size, C % BK == 0; 64x64 tile): an output pixel of parity class
+// (oh & 1, ow & 1) only receives the taps with kh = (oh + pad) mod 2, kw = (ow + pad) mod 2 -- a quarter of a 3x3 kernel's taps on average
+// and, for a 1x1 kernel, ONE class in four receives anything at all -- while the generic loop walks every tap and multiplies zeros
+// (out-of-range loads) for the others.  Here the rows of the implicit GEMM are enumerated class by class (m' = class * M/4 + the pixel's
+// index on the half-resolution grid), so that a 64-row tile is parity-pure (host: M/4 % 64 == 0) and its k loop visits its own taps only;
+// a class without taps skips the loop and runs the epilogue (addend / mask / statistics) on zeros.  Same result, bit for bit, as the
+// generic kernel: the skipped k-tiles contributed exact zeros.
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false>
 __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id, const int block_count, unsigned char* smem_all) {
+  static_assert(!S2 || (MODE == 1 && VEC && G == 1 && TM == 1 && TN == 1), "S2 is the 64x64 vector-path data gradient");
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
@@ -148,7 +156,12 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   const int chunk = tid & 7, row0 = tid >> 3;
 
   const int K = p.KH * p.KW * p.C;
-  const int nkt = ((K + BK - 1) / BK + G - 1) / G;       // k-tiles walked by each group (tiles past K are all-zero)
+  // S2: this tile's parity class and its tap lattice kh = s2_kh0 + 2 i, kw = s2_kw0 + 2 j
+  const unsigned s2_mq = S2 ? (unsigned)(M >> 2) : 1u;                       // rows per class
+  const int s2_cls = S2 ? (int)(((unsigned)bm * (unsigned)BM) / s2_mq) : 0;  // (oh & 1) * 2 + (ow & 1) of every row of the tile
+  const int s2_kh0 = S2 ? (((s2_cls >> 1) + p.pad) & 1) : 0, s2_kw0 = S2 ? (((s2_cls & 1) + p.pad) & 1) : 0;
+  const int s2_nh = S2 ? (p.KH - s2_kh0 + 1) / 2 : 0, s2_nw = S2 ? (p.KW - s2_kw0 + 1) / 2 : 0;
+  const int nkt = S2 ? s2_nh * s2_nw * (p.C / BK) : ((K + BK - 1) / BK + G - 1) / G;       // k-tiles walked by each group (tiles past K are all-zero)
 
   // Operands are read through raw buffer descriptors: an out-of-range byte offset returns zeros, which is how padding
   // taps, stride holes, rows beyond M / OC and the k tail are zero-filled without a branch or a select on the data.
@@ -165,9 +178,20 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)(row0 + 32 * i);
     a_ok[i] = (long long)m < M;
     const unsigned mm = a_ok[i] ? m : 0u;
-    const int nb = (int)(mm / (unsigned)OHW);
-    const int r = (int)(mm - (unsigned)nb * (unsigned)OHW);
-    const int oh = (int)((unsigned)r / (unsigned)p.OW), ow = r - oh * p.OW;
+    int nb, oh, ow;
+    if constexpr (S2) {      // class-major row order: index on the half-resolution grid, then the class's parity offsets
+      const unsigned q = mm - (unsigned)s2_cls * s2_mq, hw2 = (unsigned)(OHW >> 2), ow2 = (unsigned)(p.OW >> 1);
+      nb = (int)(q / hw2);
+      const unsigned r2 = q - (unsigned)nb * hw2;
+      const int oh2 = (int)(r2 / ow2);
+      oh = 2 * oh2 + (s2_cls >> 1);
+      ow = 2 * (int)(r2 - (unsigned)oh2 * ow2) + (s2_cls & 1);
+    } else {
+      nb = (int)(mm / (unsigned)OHW);
+      const int r = (int)(mm - (unsigned)nb * (unsigned)OHW);
+      oh = (int)((unsigned)r / (unsigned)p.OW);
+      ow = r - oh * p.OW;
+    }
     a_base[i] = (unsigned)((long long)nb * p.in_bs * (long long)sizeof(T));
     if (MODE == 0) { a_h[i] = oh * p.stride - p.pad; a_w[i] = ow * p.stride - p.pad; }
     else { a_h[i] = oh + p.pad; a_w[i] = ow + p.pad; }
@@ -207,7 +231,12 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   // advancing past K (the ring prefetches beyond the last tile): those chunks are all-zero.
   constexpr int KSTEP = BK * G;        // a group's consecutive tiles are G tiles apart
   int ld_kc = grp * BK + chunk * EPC, ld_kh, ld_kw, ld_c0;
-  {
+  if constexpr (S2) {
+    ld_c0 = chunk * EPC;
+    ld_kh = (s2_nh > 0 && s2_nw > 0) ? s2_kh0 : p.KH;      // a class without taps: every prefetch of the ring is out of range (zeros, no access)
+    ld_kw = s2_kw0 < p.KW ? s2_kw0 : 0;
+    ld_kc = ld_kh < p.KH ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;
+  } else {
     const int tap = ld_kc / p.C;
     ld_c0 = ld_kc - tap * p.C;
     ld_kh = tap / p.KW;
@@ -220,7 +249,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   }
   auto load_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
     if constexpr (VEC) {
-      const unsigned kbad = ld_kc < K ? 0u : BUF_OOB;      // OR-ing BUF_OOB into an offset < BUF_OOB puts it out of range
+      const unsigned kbad = (S2 ? ld_kh < p.KH : ld_kc < K) ? 0u : BUF_OOB;      // OR-ing BUF_OOB into an offset < BUF_OOB puts it out of range
       const unsigned cbytes = (unsigned)ld_c0 * (unsigned)sizeof(T), kbytes = (unsigned)ld_kc * (unsigned)sizeof(T);
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra_[i] = buf_load16(rs_in, (a_cur[i] | kbad) + cbytes);
@@ -228,7 +257,18 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       for (int j = 0; j < BR; ++j) rb_[j] = buf_load16(rs_w, (b_off[j] | kbad) + kbytes);
       ld_kc += KSTEP;
       bool new_tap;
-      if (c_ge_bk) {          // at most one tap boundary per step: plain selects
+      if constexpr (S2) {     // next 64 channels of this tap, else the next tap of the class's lattice (two columns / rows further)
+        ld_c0 += BK;
+        new_tap = ld_c0 >= p.C;
+        if (new_tap) {
+          ld_c0 -= p.C;
+          ld_kw += 2;
+          const bool wrap2 = ld_kw >= p.KW;
+          ld_kw = wrap2 ? s2_kw0 : ld_kw;
+          ld_kh += wrap2 ? 2 : 0;
+          ld_kc = ld_kh < p.KH ? (ld_kh * p.KW + ld_kw) * p.C + ld_c0 : 0;      // (past the last tap: ld_kh >= KH marks the tile all-zero)
+        }
+      } else if (c_ge_bk) {          // at most one tap boundary per step: plain selects
         ld_c0 += KSTEP;
         new_tap = ld_c0 >= p.C;
         ld_c0 -= new_tap ? p.C : 0;
@@ -408,8 +448,17 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       for (int row = rr; row < BM; row += RP) {
         const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)row;
         if ((long long)m >= M || !col_ok) continue;
-        const int e_nb = (int)(m / (unsigned)OHW);
-        const int e_pix = (int)(m - (unsigned)e_nb * (unsigned)OHW);
+        int e_nb, e_pix;
+        if constexpr (S2) {
+          const unsigned q = m - (unsigned)s2_cls * s2_mq, hw2 = (unsigned)(OHW >> 2), ow2 = (unsigned)(p.OW >> 1);
+          e_nb = (int)(q / hw2);
+          const unsigned r2 = q - (unsigned)e_nb * hw2;
+          const unsigned oh2 = r2 / ow2;
+          e_pix = (int)((2u * oh2 + (unsigned)(s2_cls >> 1)) * (unsigned)p.OW + 2u * (r2 - oh2 * ow2) + (unsigned)(s2_cls & 1));
+        } else {
+          e_nb = (int)(m / (unsigned)OHW);
+          e_pix = (int)(m - (unsigned)e_nb * (unsigned)OHW);
+        }
         float v[8];
         {
           const float4 a = *reinterpret_cast<const float4*>(tile + row * CP + cg * 8);
@@ -544,6 +593,12 @@ template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, 
 __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   igemm_body<T, TM, TN, WR, WC, MODE, VEC, NST, G>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
+}
+
+template <class T>
+__global__ __launch_bounds__(256, 4) void igemm_s2_kernel(ConvArgs p) {      // data gradient of a stride-2 convolution: see igemm_body, S2
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  igemm_body<T, 1, 1, 2, 2, 1, true, 3, 1, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
 }
 
 #include "igemm8p.hpp"
@@ -924,10 +979,34 @@ static int launch_igemm(const ConvArgs& a, hipStream_t st) {
   return launch_igemm_nst<T, TM, TN, WR, WC, MODE, VEC, G, NST>(a, st);
 }
 
+// stride-2 data gradient through the parity-class kernel: whole classes per 64-row tile, 64-channel k-tiles, the row-vectorised epilogue
+template <class T>
+static bool igemm_s2_ok(const ConvArgs& a) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  if (a.KH * a.KW == 1 && g_tune.no_s2_dgrad != -1) return false;      // 1x1: three classes in four skip their loop, but the launch lasts as long as the
+                                                                       // fourth class's blocks (measured: 20.0 vs 19.8 us, 23.5 vs 22.3); -1 = tests take it anyway
+  if (g_tune.no_s2_dgrad == 1 || a.stride != 2 || a.dil != 1 || a.C % BK != 0 || (a.OH & 1) || (a.OW & 1) || (M % 4) || ((M / 4) % 64) || a.OC <= 32 || a.OC % 8) return false;
+  if (a.out_f32 || a.bias || a.scale) return false;
+  auto al = [](const void* q) { return ((uintptr_t)q) % 16 == 0; };
+  if (!al(a.out) || (a.res && !al(a.res)) || (a.mask_y && !al(a.mask_y)) || (a.stat_x && !al(a.stat_x))) return false;
+  if (a.ldout % EPC || a.out_bs % EPC || (a.res && (a.ldres % EPC || a.res_bs % EPC)) || (a.mask_y && (a.ldy % EPC || a.y_bs % EPC)) ||
+      (a.stat_x && (a.ldsx % EPC || a.sx_bs % EPC))) return false;
+  return true;
+}
+
 template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
   const long long M = (long long)a.N * a.OH * a.OW;
   auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
+  if constexpr (MODE == 1 && VEC) {
+    if (!g_tune.conv_tile && igemm_s2_ok<T>(a)) {
+      // measured (tools/bench_conv.py s2): the three 3x3 stride-2 data gradients of the ResNet-50 step 25.3 / 24.3 / 27.3 -> 13.8 / 13.0 / 14.5 us
+      hipLaunchKernelGGL((igemm_s2_kernel<T>), dim3((unsigned)blocks(64, 64)), dim3(256), (size_t)2 * 128 * 144, st, a);
+      return check_launch("emrt_conv2d");
+    }
+  }
   if (g_tune.conv_tile) {                               // developer knob for tools/bench_conv.py; 0 in production
     switch (g_tune.conv_tile) {
       case 1: return launch_igemm<T, 1, 1, 2, 2, MODE, VEC>(a, st);

@@ -100,3 +100,61 @@ def test_wgrad_8phase_random_geometry(case, slab):
     finally:
         for k, v in old:
             L_.set_tuning(k, v)
+
+
+# stride-2 data gradients through the parity-class kernel (csrc/conv.hip: igemm_body S2): 1x1 / 3x3 / 5x5 taps, pad 0 / k//2, non-square
+# maps, several 64-channel k-tiles, two N tiles -- against torch, and bit for bit against the generic kernel (the skipped k-tiles are exact zeros)
+S2_CASES = [("s2-ds-1x1", 8, 32, 32, 512, 1024, 1, 2, 0, False, 1), ("s2-3x3", 2, 16, 16, 64, 64, 3, 2, 1, False, 1),
+            ("s2-3x3-nonsquare", 1, 32, 16, 128, 192, 3, 2, 1, False, 1), ("s2-1x1-small", 4, 8, 8, 256, 64, 1, 2, 0, False, 1),
+            ("s2-5x5", 2, 16, 32, 64, 128, 5, 2, 2, False, 1), ("s2-2x2-nopad", 2, 16, 16, 64, 128, 2, 2, 0, False, 1),
+            ("s2-layer2-conv2", 8, 64, 64, 128, 128, 3, 2, 1, False, 1)]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=[c[0] for c in S2_CASES])
+def test_stride2_data_gradient_parity_class_kernel(case):
+    import math
+    import torch.nn.functional as F
+    from emrt_amd import nn as hnn
+    from emrt_amd.runtime import BF16, Tape
+    from tests.hip_utils import Holder, dev_map, host_map, init, rnd
+    name, N, H, W, Cin, Cout, k, stride, pad = case[:9]
+    L_ = _lib.lib()
+    c = init(BF16)
+    g = torch.Generator().manual_seed(3)
+    x = rnd(torch.randn(N, Cin, H, W, generator=g))
+    conv = hnn.Conv2D(Cin, Cout, k, stride, pad, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)))
+    wref = conv.weight.detach().clone()
+    Holder(conv=conv).place()
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wref, None, stride=stride, padding=pad)
+    dy = rnd(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    got = []
+    for knob in (-1, 1):
+        # knob -1: the parity-class kernel for every eligible shape (the dispatcher leaves 1x1 kernels on the generic path: no gain there);
+        # knob 1: the generic 64x64 tile without k split (conv_tile = 1) -- the same k order per accumulator as the parity-class kernel, which
+        # only leaves out k-tiles that are exact zeros; the dispatcher's own choice for a shape may be a k-split variant (another fp32 order)
+        old = L_.set_tuning("no_s2_dgrad", knob)
+        oldt = L_.set_tuning("conv_tile", 1 if knob == 1 else 0)
+        try:
+            xd = dev_map(x)
+            tape = Tape()
+            c.tape = tape
+            y = conv(xd)
+            c.tape = None
+            tape.watch(xd)
+            tape.add_grad(y, dev_map(dy))
+            L_.start_record()
+            tape.backward()
+            rec = L_.stop_record()
+            torch.cuda.synchronize()
+            got.append(host_map(tape.result(xd)))
+        finally:
+            L_.set_tuning("no_s2_dgrad", old)
+            L_.set_tuning("conv_tile", oldt)
+    rel = ((got[0] - xr.grad).norm() / xr.grad.norm()).item()
+    print("%s: dx vs torch rel %.2e; parity-class kernel == generic kernel: %s" % (name, rel, torch.equal(got[0], got[1])))
+    assert rel < 4e-3, rel
+    assert torch.equal(got[0], got[1]), (got[0] - got[1]).abs().max().item()

@@ -219,8 +219,35 @@ def wgroup():
         print(line, flush=True)
 
 
+def s2():
+    """The stride-2 data gradients of the ResNet-50 step: generic kernels (no_s2_dgrad = 1) against the parity-class kernel."""
+    shapes = [(8, 64, 64, 256, 512, 1, 2, 0), (8, 64, 64, 128, 128, 3, 2, 1), (8, 32, 32, 512, 1024, 1, 2, 0), (8, 32, 32, 256, 256, 3, 2, 1),
+              (8, 16, 16, 1024, 2048, 1, 2, 0), (8, 16, 16, 512, 512, 3, 2, 1)]
+    tot = [0.0, 0.0]
+    for (N, H, W, C, OC, k, s, pad) in shapes:
+        OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        wb = (torch.randn(C, k, k, OC, device=dev) * 0.05).bfloat16()
+        dy = torch.randn(N, OH, OW, OC, device=dev).bfloat16()
+        dx = torch.empty(N, H, W, C, device=dev, dtype=torch.bfloat16)
+
+        def dgrad():
+            L._raw_emrt_conv2d(P(dy), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0,
+                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, None, 1, stream)
+        res = []
+        for knob in (1, 0):
+            old = L.set_tuning("no_s2_dgrad", knob)
+            res.append(min(timed(dgrad), timed(dgrad)))
+            L.set_tuning("no_s2_dgrad", old)
+        tot[0] += res[0]
+        tot[1] += res[1]
+        print("N%d %dx%dx%d<-%d k%d s2 dgrad: generic %.1f us  parity-class %.1f us" % (N, H, W, C, OC, k, res[0], res[1]), flush=True)
+    print("sum: generic %.1f us  parity-class %.1f us" % tuple(tot))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "s2":
+        return s2()
     if which == "wgroup":
         return wgroup()
     if which == "wbig":
