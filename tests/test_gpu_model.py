@@ -316,6 +316,8 @@ def test_fifty_step_training_trajectory_tracks_the_oracle():
     loss and the weights -- which only see the clipped update -- stay together), so it is bounded on the first ten steps and by its median after."""
     g = torch.Generator().manual_seed(23)
     B, S = 2, 64
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 8))          # (the oracle's tensors are tiny here: 64 threads spend their time handing work round)
     xs = [torch.randn(B, 3, S, S, generator=g) for _ in range(2)]
     labs = [torch.randint(0, 6, (B, S, S), generator=g) for _ in range(2)]
     ref, model = build_pair("resnet18", xs[0])
@@ -336,17 +338,20 @@ def test_fifty_step_training_trajectory_tracks_the_oracle():
         assert abs(lr_host - lr_ref) < 1e-12 and abs(float(opt.lr_dev.item()) - lr_ref) < 1e-8
         dl = abs(loss_t.item() - loss_ref) / max(1.0, abs(loss_ref))
         dg = abs(opt.grad_norm() - ropt.last_grad_norm) / ropt.last_grad_norm
-        num = den = 0.0
-        hp = dict(model.named_parameters())
-        for n in names:
-            a, b = hp[n].detach().cpu().double(), refp[n].detach().double()
-            num += float((a - b).pow(2).sum())
-            den += float(b.pow(2).sum())
-        dw = (num / den) ** 0.5
+        dw = rows[-1][5] if rows else 0.0
+        if step % 5 == 4 or step == 0:          # (every parameter to the host: not at every step)
+            num = den = 0.0
+            hp = dict(model.named_parameters())
+            for n in names:
+                a, b = hp[n].detach().cpu().double(), refp[n].detach().double()
+                num += float((a - b).pow(2).sum())
+                den += float(b.pow(2).sum())
+            dw = (num / den) ** 0.5
         rows.append((step, loss_t.item(), loss_ref, dl, dg, dw))
         worst = [max(worst[0], dl), max(worst[1], dg), max(worst[2], dw)]
     for r in rows[::5] + [rows[-1]]:
         print("step %2d: loss %.5f (oracle %.5f, rel %.1e)  grad-norm rel %.1e  weights rel L2 %.1e" % r)
+    torch.set_num_threads(threads)
     print("TRAJECTORY 50 steps: worst loss rel %.2e, worst grad-norm rel %.2e, final weight distance %.2e" % (worst[0], worst[1], rows[-1][5]))
     assert rows[-1][1] < rows[0][1], "the loss did not go down"
     med_g = sorted(r[4] for r in rows)[len(rows) // 2]
