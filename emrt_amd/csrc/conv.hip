@@ -373,22 +373,29 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   for (int d = 0; d < NST - 1; ++d)
     if (d < rem) k_tile(ra[d], rb[d], (kt + d) & 1, false);
 
+  // (group / thread indices re-derived from an opaque copy of the thread id: the compiler otherwise keeps the prologue's copies alive across the
+  // k loop for the code below, and at the 128-register cap of the 1024-thread block that cost the K-split variants two spilled registers)
+  int grp_e = grp;
   if constexpr (G > 1) {
+    int tl = (int)threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    grp_e = tl >> 8;
+    const int tid_e = tl & 255;
     // sum the groups' accumulators: groups 1..G-1 park theirs in LDS ([group-1][register][thread], conflict-free),
     // group 0 adds them and alone runs the epilogue
     __syncthreads();
     float* park = reinterpret_cast<float*>(smem_all);
     constexpr int NACC = TM * TN * 16;
-    if (grp > 0) {
+    if (grp_e > 0) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) park[((grp - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) park[((grp_e - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid_e] = acc[i][j][r];
     }
     __syncthreads();
-    if (grp == 0) {
+    if (grp_e == 0) {
 #pragma unroll
       for (int g = 1; g < G; ++g)
 #pragma unroll
@@ -396,7 +403,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += park[((g - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += park[((g - 1) * NACC + (i * TN + j) * 16 + r) * 256 + tid_e];
     }
   }
 
@@ -421,7 +428,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     if (vec_ok) {
       float* tile = reinterpret_cast<float*>(smem_all);
       __syncthreads();                               // every wave is done with the k-tile buffers / the parked accumulators
-      if (grp == 0) {
+      if (grp_e == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -519,7 +526,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       return;
     }
   }
-  if (grp > 0) return;
+  if (grp_e > 0) return;
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Rows are visited in
   // increasing order, so (image, pixel) is carried along instead of divided out per row.
