@@ -282,6 +282,7 @@ struct PoolArgs {
   int N, C, nscales;
   int k[4], tok0[4];
   int ntok;
+  int parts[4], item0[4], nitem;      // split pooling: blocks per bin of scale s, first work item of scale s, work items per image
 };
 
 __device__ __forceinline__ void bin_of(int i, int k, int S, int& b0, int& b1) {
@@ -692,15 +693,123 @@ static int fill_pool(PoolArgs& a, const int* scales, int nscales) {
   return 0;
 }
 
+// Large bins cut over several blocks.  One block per (image, bin) makes the 1x1 scale's bin -- the whole map: 32x32 pixels x 512 bytes at
+// 256x256 tiles, 64x64 at 512x512 -- ONE block's serial read through one CU (36 us / 102 us of the step for 4 / 16 MB).  Here block (bin, part)
+// sums every S-th run of the bin's pixels and adds its partial, already divided by the bin's size, into a ZEROED fp32 workspace [N][tokens][C]
+// (fp32 atomics: a few hundred KB); adaptive_pool_final_kernel rounds the sums to the output type.
+template <class T>
+__global__ __launch_bounds__(POOL_THREADS) void adaptive_pool_part_kernel(PoolArgs a, float* __restrict__ ws, int S) {
+  __shared__ float red[POOL_THREADS * 4];
+  // work item -> (scale, bin, part): the grid holds only as many blocks per bin as its scale's largest bin needs at 128 pixels each
+  const int item = blockIdx.x % a.nitem, n = blockIdx.x / a.nitem;
+  int s = 0;
+  while (s + 1 < a.nscales && item >= a.item0[s + 1]) ++s;
+  (void)S;
+  const int k = a.k[s], P_ = a.parts[s];
+  const int t = (item - a.item0[s]) / P_, part = (item - a.item0[s]) - t * P_;
+  const int tok = a.tok0[s] + t;
+  const int oi = t / k, oj = t - oi * k;
+  int h0, h1, w0, w1;
+  bin_of(oi, k, a.H, h0, h1);
+  bin_of(oj, k, a.W, w0, w1);
+  const int bw = w1 - w0, npix = (h1 - h0) * bw;
+  const int per = (npix + P_ - 1) / P_;
+  const int p0 = part * per, p1 = p0 + per < npix ? p0 + per : npix;
+  if (p0 >= npix) return;
+  const int cq = a.C / 4, phases = POOL_THREADS / cq;          // host: C % 4 == 0, C / 4 <= 256 and a power of two
+  const int q = (int)threadIdx.x % cq, ph = (int)threadIdx.x / cq;
+  const T* ip = (const T*)a.in + (long long)n * a.in_bs + q * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;          // a part is <= 128 pixels (host): with C = 256 all of its loads are in flight at once
+  for (int px0 = p0 + ph; px0 < p1; px0 += phases * U) {
+    float v[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pxi = px0 + u * phases;
+      const int pc = pxi < p1 ? pxi : p0;
+      const int hh = h0 + pc / bw, ww = w0 + pc % bw;
+      Vec4<T>::load(ip + ((long long)hh * a.W + ww) * a.in_ld, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = px0 + u * phases < p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += ok ? v[u][e] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = acc[e];
+  __syncthreads();
+  if (ph == 0) {
+    for (int o = 1; o < phases; ++o)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += red[(threadIdx.x + o * cq) * 4 + e];
+    const float inv = 1.f / (float)npix;
+    float* wp = ws + ((long long)n * a.ntok + tok) * a.C + q * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(wp + e, acc[e] * inv);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void adaptive_pool_final_kernel(PoolArgs a, const float* __restrict__ ws) {
+  const long long total = (long long)a.N * a.ntok * (a.C / 4);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int cq = a.C / 4;
+    const int q = (int)(idx % cq);
+    const long long nt = idx / cq;
+    const int tok = (int)(nt % a.ntok), n = (int)(nt / a.ntok);
+    const float4 v = *reinterpret_cast<const float4*>(ws + nt * a.C + q * 4);
+    float o[4] = {v.x, v.y, v.z, v.w};
+    Vec4<T>::store((T*)a.out + (long long)n * a.out_bs + (long long)tok * a.out_ld + q * 4, o);
+  }
+}
+
 // out tokens [N][sum k^2][C] (row stride out_ld, batch stride out_bs)
 extern "C" int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs,
-                                         int out_ld, int N, int C, const int* scales /*host*/, int nscales, int dtype, void* stream) {
+                                         int out_ld, int N, int C, const int* scales /*host*/, int nscales, float* zeroed_workspace, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out && scales, "null pointer");
   PoolArgs a;
   a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.N = N; a.C = C;
   EMRT_REQUIRE(fill_pool(a, scales, nscales) == 0, "1..4 scales supported");
   hipStream_t st = (hipStream_t)stream;
+  {
+    int kmin = scales[0];
+    for (int i = 1; i < nscales; ++i) kmin = scales[i] < kmin ? scales[i] : kmin;
+    const long long big = (long long)((H + kmin - 1) / kmin + 1) * ((W + kmin - 1) / kmin + 1);      // pixels of the largest bin (upper bound)
+    const int esz = dtype == EMRT_F32 ? 4 : 2;
+    const int cq = C / 4;
+    const bool vec = (C % 4 == 0) && cq <= 256 && (cq & (cq - 1)) == 0 && (in_ld % 4 == 0) && (in_bs % 4 == 0) && (out_ld % 4 == 0) && (out_bs % 4 == 0) &&
+                     (((uintptr_t)in) % (4 * esz) == 0) && (((uintptr_t)out) % (4 * esz) == 0);
+    if (zeroed_workspace && vec && big >= 512) {
+      int S = 1;
+      a.nitem = 0;
+      for (int i = 0; i < 4; ++i) { a.parts[i] = 1; a.item0[i] = 0; }
+      for (int i = 0; i < nscales; ++i) {
+        const long long mx = (long long)((H + scales[i] - 1) / scales[i] + 1) * ((W + scales[i] - 1) / scales[i] + 1);      // largest bin of this scale (upper bound)
+        long long pp = (mx + 127) / 128;
+        if (pp > 256) pp = 256;
+        a.parts[i] = (int)pp;
+        a.item0[i] = a.nitem;
+        a.nitem += scales[i] * scales[i] * (int)pp;
+        S = (int)pp > S ? (int)pp : S;
+      }
+      const dim3 grid((unsigned)(N * a.nitem));
+      const int fg = ew_grid((long long)N * a.ntok * cq);
+      if (dtype == EMRT_F32) {
+        hipLaunchKernelGGL((adaptive_pool_part_kernel<float>), grid, dim3(POOL_THREADS), 0, st, a, zeroed_workspace, S);
+        hipLaunchKernelGGL((adaptive_pool_final_kernel<float>), dim3(fg), dim3(256), 0, st, a, (const float*)zeroed_workspace);
+      } else if (dtype == EMRT_BF16) {
+        hipLaunchKernelGGL((adaptive_pool_part_kernel<bf16_t>), grid, dim3(POOL_THREADS), 0, st, a, zeroed_workspace, S);
+        hipLaunchKernelGGL((adaptive_pool_final_kernel<bf16_t>), dim3(fg), dim3(256), 0, st, a, (const float*)zeroed_workspace);
+      } else {
+        hipLaunchKernelGGL((adaptive_pool_part_kernel<f16_t>), grid, dim3(POOL_THREADS), 0, st, a, zeroed_workspace, S);
+        hipLaunchKernelGGL((adaptive_pool_final_kernel<f16_t>), dim3(fg), dim3(256), 0, st, a, (const float*)zeroed_workspace);
+      }
+      return check_launch("emrt_adaptive_avgpool_fwd");
+    }
+  }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((adaptive_pool_fwd_kernel<float>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
   else if (dtype == EMRT_BF16) hipLaunchKernelGGL((adaptive_pool_fwd_kernel<bf16_t>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);
   else hipLaunchKernelGGL((adaptive_pool_fwd_kernel<f16_t>), dim3(N * a.ntok), dim3(POOL_THREADS), 0, st, a);

@@ -1038,8 +1038,10 @@ def adaptive_avgpool_tokens(x, scales):
     ntok = sum(k * k for k in scales)
     out = c.empty((N, ntok, C))
     arr = (ctypes.c_int * len(scales))(*scales)
+    # zeroed fp32 partial-sum buffer: large maps are pooled by several blocks per bin (csrc/spatial.hip: adaptive_pool_part_kernel)
+    ws = c.zeros((N, ntok, C), torch.float32) if H * W >= 512 else None
     _L().call("emrt_adaptive_avgpool_fwd", P(x), in_bs, in_ld, H, W, P(out), ntok * C, C, N, C, ctypes.cast(arr, ctypes.c_void_p), len(scales),
-              c.dtype, c.stream)
+              P(ws), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():

@@ -171,8 +171,10 @@ int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH,
 size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, int dout_nchw_f32);
 int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs, int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, void* workspace, int dtype, void* stream);
 /* nn.AdaptiveAvgPool2D(k), k in scales (host int[nscales], <= 4), all scales in one launch -> tokens [N][sum k^2][C]:
- * paddle_EMRT.py:62,70-78 */
-int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs, int out_ld, int N, int C, const int* scales, int nscales, int dtype, void* stream);
+ * paddle_EMRT.py:62,70-78.  zeroed_workspace (ABI 5, nullable): fp32 [N][sum k^2][C], ZEROED by the caller; with it, maps whose largest bin
+ * has >= 512 pixels are pooled by several blocks per bin (partial sums added there, a second launch rounds them into `out`) instead of one
+ * block per bin reading the whole map of the 1x1 scale through one CU */
+int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs, int out_ld, int N, int C, const int* scales, int nscales, float* zeroed_workspace, int dtype, void* stream);
 int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void* din, long long di_bs, int di_ld, int H, int W, int N, int C, const int* scales, int nscales, int dtype, void* stream);
 /* nn.MaxPool2D(3, 2, 1): paddle_vision_resnet.py:201; paddle_EMRT.py:84 (dense NHWC) */
 int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);

@@ -1011,3 +1011,20 @@ def test_msda_golden_vectors(dtype):
         close("msda golden", host(y), want, dtype, atol=2e-5, rtol=1e-4)
     else:
         close("msda golden", host(y), torch.from_numpy(z["out"]), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,C,Ctot", [(16, 16, 256, 256), (64, 64, 256, 1536), (48, 80, 128, 128), (21, 30, 64, 64)],
+                         ids=["small-map-one-block-per-bin", "512-tile-map-slice-of-concat", "non-square", "odd-size"])
+def test_adaptive_pool_split_bins(dtype, H, W, C, Ctot):
+    """AdaptiveAvgPool2D pyramid (paddle_EMRT.py:62,70-78) on maps below and above the size at which a bin is pooled by several blocks
+    (csrc/spatial.hip: adaptive_pool_part_kernel), on a channel slice of a wider buffer as in the model, non-square and odd sizes."""
+    c = init(dtype)
+    g = torch.Generator().manual_seed(5)
+    N = 3
+    scales = [1, 3, 6, 8]
+    x = rnd(torch.randn(N, Ctot, H, W, generator=g))
+    toks = torch.cat([F.adaptive_avg_pool2d(x[:, :C], k).reshape(N, C, -1) for k in scales], -1).transpose(1, 2)
+    xd = dev_map(x)[..., :C]
+    y = Fn.adaptive_avgpool_tokens(xd, scales)
+    close("pool fwd %dx%d" % (H, W), host(y), toks, dtype)
