@@ -395,6 +395,66 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(PoolArgs a) {
 
 // the same with 4 channels per thread: the bin geometry (integer divisions) is worked out once per pixel quad instead of
 // once per element, token gradients come in 8/16-byte loads (the scalar version spent 65 us on a 4 MB map in divisions)
+// The same gather with the bin membership of every row and column worked out ONCE per block: a pixel lies in at most two bins per axis and
+// scale (neighbouring adaptive bins overlap by at most one pixel), and finding them costs ~14 integer divisions per scale -- the kernel above
+// does that per thread (and tries 3 x 3 candidate bins), which is what its 25 us for a 4 MB map were.  Table: [scale][H + W] entries of
+// (first bin, second bin or -1, 1 / extent of each) in LDS, built by the first (H + W) * nscales threads' worth of work; the pixel loop is then
+// <= 2 x 2 loads per scale with one multiply each.  Host: H + W <= 512.
+struct PoolAxisEntry { short i0, i1; float inv0, inv1; };
+template <class T>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_tab_kernel(PoolArgs a) {
+  __shared__ PoolAxisEntry tab[4 * 512];
+  const int HW_ = a.H + a.W;
+  for (int e = threadIdx.x; e < HW_ * a.nscales; e += blockDim.x) {
+    const int s = e / HW_, r = e - s * HW_;
+    const bool is_row = r < a.H;
+    const int x = is_row ? r : r - a.H, S = is_row ? a.H : a.W, k = a.k[s];
+    const int hi = (x * k) / S;
+    PoolAxisEntry en;
+    en.i0 = en.i1 = -1;
+    en.inv0 = en.inv1 = 0.f;
+    for (int i = hi > 0 ? hi - 1 : 0; i <= hi + 1 && i < k; ++i) {
+      int b0, b1;
+      bin_of(i, k, S, b0, b1);
+      if (x < b0 || x >= b1) continue;
+      if (en.i0 < 0) { en.i0 = (short)i; en.inv0 = 1.f / (float)(b1 - b0); }
+      else { en.i1 = (short)i; en.inv1 = 1.f / (float)(b1 - b0); }
+    }
+    tab[s * 512 + r] = en;
+  }
+  __syncthreads();
+  const int cq = a.C / 4;
+  const long long total = (long long)a.N * a.H * a.W * cq;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int c, w, h, n;
+    unravel4(idx, cq, a.W, a.H, total <= 0xffffffffll, c, w, h, n);
+    c *= 4;
+    const T* gp = (const T*)a.out + (long long)n * a.out_bs + c;   // tokens gradient
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.nscales; ++s) {
+      const int k = a.k[s];
+      const PoolAxisEntry er = tab[s * 512 + h], ec = tab[s * 512 + a.H + w];
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri) {
+        const int oi = ri ? er.i1 : er.i0;
+        if (oi < 0) continue;
+        const float wr = ri ? er.inv1 : er.inv0;
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci) {
+          const int oj = ci ? ec.i1 : ec.i0;
+          if (oj < 0) continue;
+          const float wt = wr * (ci ? ec.inv1 : ec.inv0);
+          float g[4];
+          Vec4<T>::load(gp + (long long)(a.tok0[s] + oi * k + oj) * a.out_ld, g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], wt, acc[e]);
+        }
+      }
+    }
+    Vec4<T>::store((T*)const_cast<void*>(a.in) + (long long)n * a.in_bs + ((long long)h * a.W + w) * a.in_ld + c, acc);
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void adaptive_pool_bwd_vec_kernel(PoolArgs a) {
   const int cq = a.C / 4;
@@ -828,7 +888,10 @@ extern "C" int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int 
   const int esz = dtype == EMRT_F32 ? 4 : 2;
   const bool vec = C % 4 == 0 && do_ld % 4 == 0 && do_bs % 4 == 0 && di_ld % 4 == 0 && di_bs % 4 == 0 &&
                    ((uintptr_t)dout % (4 * esz) == 0) && ((uintptr_t)din % (4 * esz) == 0);
-  if (vec) {
+  if (vec && H + W <= 512) {
+    const int grid = ew_grid((long long)N * H * W * (C / 4));
+    DT2(dtype, adaptive_pool_bwd_tab_kernel, grid, a);
+  } else if (vec) {
     const int grid = ew_grid((long long)N * H * W * (C / 4));
     DT2(dtype, adaptive_pool_bwd_vec_kernel, grid, a);
   } else {

@@ -1024,7 +1024,16 @@ def test_adaptive_pool_split_bins(dtype, H, W, C, Ctot):
     N = 3
     scales = [1, 3, 6, 8]
     x = rnd(torch.randn(N, Ctot, H, W, generator=g))
-    toks = torch.cat([F.adaptive_avg_pool2d(x[:, :C], k).reshape(N, C, -1) for k in scales], -1).transpose(1, 2)
+    xr = x[:, :C].clone().requires_grad_(True)
+    toks = torch.cat([F.adaptive_avg_pool2d(xr, k).reshape(N, C, -1) for k in scales], -1).transpose(1, 2)
+    dy = rnd(torch.randn(toks.shape, generator=g))
+    toks.backward(dy)
     xd = dev_map(x)[..., :C]
+    tape = Tape()
+    c.tape = tape
     y = Fn.adaptive_avgpool_tokens(xd, scales)
-    close("pool fwd %dx%d" % (H, W), host(y), toks, dtype)
+    c.tape = None
+    tape.watch(xd)
+    close("pool fwd %dx%d" % (H, W), host(y), toks.detach(), dtype)
+    dx, = run_bwd(tape, [(y, dev(dy))], [xd])          # (the bin-membership table kernel: rows / columns that lie in two overlapping bins)
+    close("pool dx %dx%d" % (H, W), host_map(dx), xr.grad, dtype)
