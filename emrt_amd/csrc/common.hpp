@@ -69,6 +69,7 @@ struct Tuning {
   int wgrad8p_slab;       // 1 (default): partial tiles through the registered scratch + a reduce launch; 0: fp32 atomics into dW
   int wgrad8p_xcd;        // 1 (default): slices of the pixel reduction pinned to XCDs (shared L2); 0: launch order (A/B knob)
   int wgrad8p_force;      // tests: 1 = take the 256x256 kernel whenever the shape allows, whatever the grid size
+  int wgrad_no_overwrite; // 1 = weight gradients always accumulate with atomics, even into a dW the caller declared zero (A/B knob)
   int no_s2_dgrad;        // 1 = stride-2 data gradients through the generic kernels (A/B knob; tests compare the two bit for bit); -1 = the parity-class kernel for 1x1 kernels too
   int wgroup_blocks;      // batched weight gradients (emrt_conv2d_wgrad_group): blocks a launch aims for (1024 = 4 per CU)
   int wgroup_min_steps;   // ... fewest 64-pixel tiles per block (32: shorter blocks only buy fp32 atomic traffic)

@@ -628,6 +628,8 @@ struct WgradArgs {
   int dil;              // dilation of the kernel taps
   int tiles_per_split;  // number of BKm pixel tiles each z-slice processes
   float* dbias;         // optional [OC]: += sum_m dy[m][oc] (bias gradient), accumulated by the k-tile-0 blocks from the dy tiles they stream
+  int overwrite;        // 1: the caller vouches that dw is all zero AND this launch has ONE pixel slice: the tile is stored, not added with atomics
+                        // (fp32 atomics run at 1.3 TB/s against ~6 TB/s for stores: layer3 / layer4's large dW with few pixels is all epilogue)
 };
 
 template <class T>
@@ -909,7 +911,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int block_x
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = k0 + wc * 64 + j * 32 + frow;
-        if (k < K) atomicAdd(p.dw + (long long)oc * K + k, acc[i][j][r]);
+        if (k < K) {
+          if (p.overwrite) p.dw[(long long)oc * K + k] = acc[i][j][r];
+          else atomicAdd(p.dw + (long long)oc * K + k, acc[i][j][r]);
+        }
       }
     }
 }
@@ -1148,6 +1153,7 @@ static int wgrad_dispatch(const WgradArgs& a0, hipStream_t st) {
   const bool vec = wgrad_is_vec<T>(a);
   int tx, ty, S;
   wgrad_plan<T>(a, tx, ty, S);
+  if (S > 1 || !vec || g_tune.wgrad_no_overwrite) a.overwrite = 0;      // (the scalar-path kernel and multi-slice launches always accumulate)
   // wave groups per block on the vector path (wgrad_kernel).  G = 2 measured SLOWER than two independent G = 1 blocks per
   // CU on every EMRT shape but one (coupled barriers, 160 KB of LDS per block), so 1 it is.
   constexpr int G = 1;
@@ -1193,7 +1199,7 @@ extern "C" int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw,
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.H = H; a.W = W; a.C = C; a.ldx = ldx; a.x_bs = x_bs;
   a.OH = OH; a.OW = OW; a.OC = OC; a.lddy = lddy; a.dy_bs = dy_bs;
-  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.tiles_per_split = 0; a.dbias = dbias;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.tiles_per_split = 0; a.dbias = dbias; a.overwrite = 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? wgrad_dispatch<float>(a, st) : wgrad_dispatch<bf16_t>(a, st);
 }
@@ -1508,7 +1514,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   w.x = x; w.dy = dy; w.dw = dw;
   w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
   w.OH = OH; w.OW = OW; w.OC = OC; w.lddy = lddy; w.dy_bs = dy_bs;
-  w.KH = KH; w.KW = KW; w.stride = stride; w.pad = pad; w.dil = dilation; w.tiles_per_split = 0; w.dbias = dbias;
+  w.KH = KH; w.KW = KW; w.stride = stride; w.pad = pad; w.dil = dilation; w.tiles_per_split = 0; w.dbias = dbias; w.overwrite = 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EMRT_F32 ? conv_bwd_dispatch<float>(d, w, st) : conv_bwd_dispatch<bf16_t>(d, w, st);
 }
@@ -1678,7 +1684,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;
     w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;
     w.OH = b.OH; w.OW = b.OW; w.OC = b.OC; w.lddy = b.lddy; w.dy_bs = b.dy_bs;
-    w.KH = b.KH; w.KW = b.KW; w.stride = b.stride; w.pad = b.pad; w.dil = 1; w.tiles_per_split = 0; w.dbias = b.dbias;
+    w.KH = b.KH; w.KW = b.KW; w.stride = b.stride; w.pad = b.pad; w.dil = 1; w.tiles_per_split = 0; w.dbias = b.dbias; w.overwrite = 0;
     const bool vec = conv_desc_is_vec<T>(d) && wgrad_is_vec<T>(w) && d.OC > 32;
     groupable = groupable && vec;
     int tx = 1, ty = 1, S = 1;
@@ -1745,6 +1751,7 @@ struct EmrtWgradDesc {
   int N, H, W, C, ldx; long long x_bs;
   int OH, OW, OC, lddy; long long dy_bs;
   int KH, KW, stride, pad, dilation;
+  int dw_is_zero;
 };
 struct WgradGroupArgs {
   WgradArgs w[EMRT_MAX_WGROUP];
@@ -1779,6 +1786,7 @@ static void wgrad_args_from_desc(WgradArgs& a, const EmrtWgradDesc& d) {
   a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldx = d.ldx; a.x_bs = d.x_bs;
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.lddy = d.lddy; a.dy_bs = d.dy_bs;
   a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = d.dilation; a.tiles_per_split = 0; a.dbias = d.dbias;
+  a.overwrite = d.dw_is_zero ? 1 : 0;      // (cleared below for every problem that ends up with more than one slice)
 }
 
 template <class T>
@@ -1829,6 +1837,7 @@ static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t s
       g.w[q] = pend[i];
       g.w[q].tiles_per_split = (int)tps[i];
       const long long S = (mt[i] + tps[i] - 1) / tps[i];
+      if (S > 1 || g_tune.wgrad_no_overwrite) g.w[q].overwrite = 0;
       g.first[q] = (int)total;
       g.wtx[q] = (short)tx[i]; g.wty[q] = (short)ty[i];
       total += (long long)tx[i] * ty[i] * S;

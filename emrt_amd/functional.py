@@ -289,7 +289,7 @@ class _WgradDesc(ctypes.Structure):       # EmrtWgradDesc (include/emrt_hip.h)
                 ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("ldx", ctypes.c_int),
                 ("x_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int), ("lddy", ctypes.c_int),
                 ("dy_bs", ctypes.c_longlong), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
-                ("dilation", ctypes.c_int)]
+                ("dilation", ctypes.c_int), ("dw_is_zero", ctypes.c_int)]
 
 
 def wgrad_deferred(w):
@@ -302,8 +302,11 @@ def wgrad_deferred(w):
 def defer_wgrad(tape, x, dy, w, geom, stride, pad, dil):
     """Queue dW += wgrad(x, dy) (+ dbias) of one layer; x and dy stay alive until the batch is launched (Tape.flush_wgrads)."""
     N, H, Wd, C, ldx, x_bs, OH, OW, lddy, dy_bs = geom
+    # first contribution to this weight's gradient since ParamStore.zero_grad(): dW is still all zero, a one-slice launch may store its tiles
+    fresh = int(getattr(w, "grad_is_zero", False))
+    w.grad_is_zero = False
     tape.wgrads.append(((x.data_ptr(), dy.data_ptr(), w.grad.data_ptr(), w.bias_grad.data_ptr() if w.bias is not None else None,
-                         N, H, Wd, C, ldx, x_bs, OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, dil), (x, dy)))
+                         N, H, Wd, C, ldx, x_bs, OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, dil, fresh), (x, dy)))
     if len(tape.wgrads) >= ctx().wgrad_batch:
         tape.flush_wgrads()
 
@@ -312,7 +315,7 @@ def launch_wgrads(pending):
     c = ctx()
     arr = (_WgradDesc * len(pending))()
     for d, (f, _keep) in zip(arr, pending):
-        (d.x, d.dy, d.dw, d.dbias, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, d.KH, d.KW, d.stride, d.pad, d.dilation) = f
+        (d.x, d.dy, d.dw, d.dbias, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, d.KH, d.KW, d.stride, d.pad, d.dilation, d.dw_is_zero) = f
     stream = c.wgrad_fork([t for _f, keep in pending for t in keep]) if c.wgrad_side else c.stream
     _L().call("emrt_conv2d_wgrad_group", arr, len(pending), c.dtype, stream)
 
@@ -358,6 +361,8 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
             _, _, _, _, lddy, dy_bs = _check_map(dy)
             dbias = P(w.bias_grad) if w.bias is not None else None
             deferred = wgrad_deferred(w)
+            if not deferred:
+                w.grad_is_zero = False           # (an immediate weight gradient accumulates into dW: it is not zero afterwards)
             if deferred:
                 defer_wgrad(tape, x, dy, w, (N, H, W, C, ldin, in_bs, OH, OW, lddy, dy_bs), stride, pad, dil)
             if not need_dx:
@@ -724,6 +729,9 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             assert dx.is_contiguous()
             bd = (_ConvBwdDesc * L)()
             deferred = all(wgrad_deferred(w) for w in convs)
+            if not deferred:
+                for w in convs:
+                    w.grad_is_zero = False
             for l, (w, (h, wd), (s0, n)) in enumerate(zip(convs, spatial_shapes, level_spans)):
                 d = bd[l]
                 off = s0 * C * esz
@@ -796,6 +804,9 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
             dxs = [s_ if s_ is not None else c.empty(tuple(f.shape)) for s_, f in zip(slots, feats)]
             bd = (_ConvBwdDesc * L)()
             deferred = all(wgrad_deferred(w) for w in convs)
+            if not deferred:
+                for w in convs:
+                    w.grad_is_zero = False
             for l, (w, f, (a, n), dx) in enumerate(zip(convs, feats, spans, dxs)):
                 _, h, wd, Cl = f.shape
                 _, _, _, _, lddx, dx_bs = _check_map(dx)

@@ -234,6 +234,8 @@ class ParamStore:
 
     def zero_grad(self):
         _lib.lib().call("emrt_memset", Fn.P(self.grad), 0, self.n_train * 4, ctx().stream)
+        for g in self.gemms:          # the next weight gradient of each GEMM weight is its first contribution: it may store instead of add
+            g.grad_is_zero = True
 
 
 # ---------------------------------------------------------------------------------------------------

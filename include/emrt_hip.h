@@ -35,7 +35,7 @@ int emrt_abi_version(void);
 int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len);
 /* Developer / test knobs of the dispatchers (forced tile shapes, kernel variants).  The table is filled ONCE from the
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
- * conv_tile, wgrad_split, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
+ * conv_tile, wgrad_split, wgrad_no_overwrite, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
  * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
  * gn_bwd_stat_rows, gn_apply_rows.
  * Not thread-safe against concurrent launches; production code never calls these. */
@@ -91,6 +91,8 @@ typedef struct EmrtWgradDesc {
   int N, H, W, C, ldx; long long x_bs;
   int OH, OW, OC, lddy; long long dy_bs;
   int KH, KW, stride, pad, dilation;
+  int dw_is_zero;      /* 1: the caller vouches that dw (and nothing else) is all zero when this call executes (first contribution after the
+                          per-step clear): a problem that runs as ONE pixel slice then stores its tiles instead of adding them with atomics */
 } EmrtWgradDesc;
 int emrt_conv2d_wgrad_group(const EmrtWgradDesc* descs, int n, int dtype, void* stream);
 

@@ -37,8 +37,10 @@ def _geoms(seed, n, odd=False):
     return out
 
 
-def _run(geoms, dtype, batch, seed):
-    """-> per layer (dW, dbias, dx) on the host; all layers' backward on one tape."""
+def _run(geoms, dtype, batch, seed, cleared=False, passes=1):
+    """-> per layer (dW, dbias, dx) on the host; all layers' backward on one tape.  cleared: the gradients are cleared through
+    ParamStore.zero_grad() first, which also marks every weight gradient 'known zero' (one-slice problems then STORE their tiles);
+    passes > 1 replays the same backward into the same gradients without clearing."""
     c = init(dtype)
     c.wgrad_batch = batch
     g = torch.Generator().manual_seed(seed)
@@ -57,20 +59,24 @@ def _run(geoms, dtype, batch, seed):
         xs.append(x)
         dys.append(dy)
         refs.append((wr.grad, br.grad if bias else None, xr.grad))
-    Holder(**layers).place()
-    tape = Tape()
-    c.tape = tape
-    xd = [dev_map(x) for x in xs]
-    ys = [layers["l%d" % i](xd[i]) for i in range(len(geoms))]
-    c.tape = None
-    for x_ in xd:
-        tape.watch(x_)
-    for y, dy in zip(ys, dys):
-        tape.add_grad(y, dev_map(dy))
+    holder = Holder(**layers).place()
+    if cleared:
+        holder.store.grad.fill_(7.0)         # (whatever was there is cleared by zero_grad, not by the kernels)
+        holder.store.zero_grad()
     L_ = _lib.lib()
-    L_.start_record()
-    tape.backward()
-    rec = L_.stop_record()
+    for _ in range(passes):
+        tape = Tape()
+        c.tape = tape
+        xd = [dev_map(x) for x in xs]
+        ys = [layers["l%d" % i](xd[i]) for i in range(len(geoms))]
+        c.tape = None
+        for x_ in xd:
+            tape.watch(x_)
+        for y, dy in zip(ys, dys):
+            tape.add_grad(y, dev_map(dy))
+        L_.start_record()
+        tape.backward()
+        rec = L_.stop_record()
     torch.cuda.synchronize()
     got = []
     for i in range(len(geoms)):
@@ -131,3 +137,26 @@ def test_batched_weight_gradients_under_extreme_plans(knobs):
             L_.set_tuning(k, v)
     for i, ((dw, db, dx), (rw, rb, rx)) in enumerate(zip(got, refs)):
         assert ((dw - rw).norm() / rw.norm()).item() < 1e-3, (i, geoms[i])
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "fp32"])
+def test_first_contribution_is_stored_and_later_ones_are_added(dtype):
+    """EmrtWgradDesc.dw_is_zero: after ParamStore.zero_grad() the first weight gradient of a layer that runs as ONE pixel slice is stored
+    instead of added with atomics.  Same bits as the accumulating path (0 + v == v), and a second backward without clearing must ADD."""
+    geoms = _geoms(41, 12) + [(1, 6, 6, 512, 512, 3, 1, 1, 1, True), (1, 8, 8, 256, 1024, 1, 1, 0, 1, False)]     # + few pixels, large dW
+    L_ = _lib.lib()
+    old = L_.set_tuning("wgrad_no_overwrite", 1)
+    try:
+        base, refs, _ = _run(geoms, dtype, 24, 13, cleared=True)
+    finally:
+        L_.set_tuning("wgrad_no_overwrite", old)
+    got, _, _ = _run(geoms, dtype, 24, 13, cleared=True)
+    twice, _, _ = _run(geoms, dtype, 24, 13, cleared=True, passes=2)
+    tol = 1e-3 if dtype == BF16 else 2e-5
+    for i, ((dw, db, _), (bw, bb, _), (tw, tb, _), (rw, rb, _)) in enumerate(zip(got, base, twice, refs)):
+        assert ((dw - rw).norm() / rw.norm()).item() < tol, (i, geoms[i])
+        # one-slice problems are bit-identical to the accumulating path; multi-slice ones are atomics in both (order-dependent last bits)
+        assert ((dw - bw).norm() / bw.norm()).item() < 5e-6, (i, geoms[i])
+        assert ((tw - 2 * rw).norm() / rw.norm()).item() < 2 * tol, (i, geoms[i])
+        if db is not None:
+            assert ((tb - 2 * rb).norm() / rb.norm()).item() < 2 * tol
