@@ -56,6 +56,7 @@ struct Tuning {
   int msda_fwd_probe;   // timing experiments only (results are WRONG): forward 1 = no gather, 2 = no staging, 4 = no preparation;
                         // value-gradient scatter 16 = no |g| scan, 32 = no sample loop (tools/exp/probe_msda_*.sh)
   int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
+  int bn_operand_blocks; // kernels that apply BatchNorm to their input operand (bn_operand.hpp): most blocks per launch (0 = 2048)
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
   int gn_group_blocks;  // 1 = multi-level GroupNorm with one block per (image, group) instead of the row-major stats + apply pair
   int gn_stat_rows;     // row-major GroupNorm: token rows per block of the forward statistics launch (32)

@@ -7,6 +7,7 @@
 // nn.GroupNorm(32,256)+nn.GELU (transformer_encoder_decoder.py:125-144,378), nn.LayerNorm(256)
 // (transformer_encoder_decoder.py:116,123,251,256,264).
 #include "common.hpp"
+#include "bn_operand.hpp"
 #include <stdlib.h>
 
 using namespace emrt;
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
                                                          const T* __restrict__ y, int ldy, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, long long M, int C, int tx_n,
                                                          float* __restrict__ partial, long long rpb, long long bs,
-                                                         double* __restrict__ dsums, float* __restrict__ facc) {
+                                                         double* __restrict__ dsums, float* __restrict__ facc,
+                                                         const float* __restrict__ mgamma = nullptr, const float* __restrict__ mbeta = nullptr) {
   __shared__ float red[256 * 8];
   const int ty_n = 256 / tx_n;
   const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -32,9 +34,14 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
   float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   if (c < C) {
     float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+    float msc[4] = {0, 0, 0, 0}, msh[4] = {0, 0, 0, 0};      // MODE 1 with mbeta: the ReLU mask re-derived from x (bn_operand.hpp)
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+      if (mbeta) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bn_scale_shift(mu[e], is[e], mgamma[c + e], mbeta[c + e], msc[e], msh[e]);
+      }
     }
     for (long long r = (long long)blockIdx.x * ty_n + ty; r < M; r += (long long)gridDim.x * ty_n) {
       float v[4];
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
           for (int e = 0; e < 4; ++e) {
             float g = ok ? gg[u][e] : 0.f;
             if (y) g = oo[u][e] > 0.f ? g : 0.f;
+            else if (mbeta) g = fmaf(vv[u][e], msc[e], msh[e]) > 0.f ? g : 0.f;
             s0[e] += g;
             s1[e] = fmaf(g, (vv[u][e] - mu[e]) * is[e], s1[e]);
           }
@@ -161,33 +169,6 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, fl
   if (dgamma) dgamma[c] += sums[C + c];
 }
 
-// BatchNorm sums are accumulated into 8 replicas [8][2C] (fewer adders per address); consumers add them up.
-#define BN_REPLICAS 8
-__device__ __forceinline__ double rep_sum(const double* __restrict__ sums, int C, int idx) {
-  double t = 0.0;
-#pragma unroll
-  for (int r = 0; r < BN_REPLICAS; ++r) t += sums[(long long)r * 2 * C + idx];
-  return t;
-}
-
-// Per-channel constants of one BatchNorm layer, from fp64 sums (training) or the running statistics (eval).
-struct BnChan { float mean, invstd; };
-__device__ __forceinline__ BnChan bn_chan(const double* __restrict__ sums, const float* __restrict__ run_mean,
-                                          const float* __restrict__ run_var, int C, int c, double inv_count, float eps) {
-  BnChan o;
-  if (sums) {
-    const double mu = rep_sum(sums, C, c) * inv_count;
-    double var = rep_sum(sums, C, C + c) * inv_count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    o.mean = (float)mu;
-    o.invstd = (float)(1.0 / sqrt(var + (double)eps));
-  } else {
-    o.mean = run_mean[c];
-    o.invstd = rsqrtf(run_var[c] + eps);
-  }
-  return o;
-}
-
 // y = [relu]((x - mean) * invstd * gamma + beta [+ res]).  Training (sums != null): mean/invstd come from the fp64
 // sums; block 0 also saves them for backward and updates the running statistics (Paddle convention: momentum 0.9 =>
 // running = 0.9*running + 0.1*batch, biased variance).  Threads own a fixed channel quad, so the per-channel constants
@@ -215,9 +196,10 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
   extern __shared__ float bn_lds[];          // [2][C]
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const BnChan k = bn_chan(sums, run_mean, run_var, C, ch, inv_count, eps);
-    const float scale = k.invstd * gamma[ch];
+    float scale, shift;
+    bn_scale_shift(k.mean, k.invstd, gamma[ch], beta[ch], scale, shift);
     bn_lds[ch] = scale;
-    bn_lds[C + ch] = beta[ch] - k.mean * scale;
+    bn_lds[C + ch] = shift;
     if (sums && blockIdx.x == 0) {
       mean_out[ch] = k.mean;
       invstd_out[ch] = k.invstd;
@@ -267,7 +249,8 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const double* __restrict__ sums, const double* __restrict__ lsums,
                                                         double inv_count, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                        long long M, int C, int rows_per_pass, const float* __restrict__ beta_y, int sums_vs_x) {
+                                                        long long M, int C, int rows_per_pass, const float* __restrict__ beta_y, int sums_vs_x,
+                                                        const float* __restrict__ mbeta) {
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
@@ -297,7 +280,7 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     }
   }
   __syncthreads();
-  float mu[4], is[4], k0[4], k1[4], gi[4];
+  float mu[4], is[4], k0[4], k1[4], gi[4], msc[4], msh[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     mu[e] = mean[c + e];
@@ -305,6 +288,8 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     gi[e] = gamma[c + e] * is[e];
     k0[e] = bn_lds[c + e];
     k1[e] = bn_lds[C + c + e];
+    msc[e] = msh[e] = 0.f;
+    if (mbeta) bn_scale_shift(mu[e], is[e], gamma[c + e], mbeta[c + e], msc[e], msh[e]);      // ReLU mask re-derived from x (bn_operand.hpp)
   }
   while (r < M) {
     const long long rn = r + rstep;
@@ -317,6 +302,9 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     if (y) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+    } else if (mbeta) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = fmaf(v[e], msc[e], msh[e]) > 0.f ? g[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = gi[e] * (g[e] - k0[e] - (v[e] - mu[e]) * is[e] * k1[e]);
@@ -1278,17 +1266,21 @@ extern "C" int emrt_bn_fold(const float* params, const float* buffers, const lon
 }
 
 // BN backward step 1: sums[2C] (fp64, PRE-ZEROED) += (sum dy', sum dy'*xhat); y (post-ReLU output) may be null when no ReLU was fused.
+// mask_gamma / mask_beta (both or neither; y must then be null): the layer's ReLU output was never written (its consumer applied
+// BatchNorm + ReLU on load, emrt_bn_resize_bilinear_fwd / emrt_bn_maxpool_fwd): the mask is re-derived from x.
 extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean,
-                                  const float* invstd, long long M, int C, double* sums, int dtype, void* stream) {
+                                  const float* invstd, long long M, int C, double* sums, const float* mask_gamma, const float* mask_beta,
+                                  int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && mean && invstd && sums, "null pointer");
+  EMRT_REQUIRE((mask_gamma != nullptr) == (mask_beta != nullptr) && !(mask_beta && y), "mask_gamma and mask_beta come together and replace y");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && (!y || ldy % 4 == 0), "C and ld must be multiples of 4");
   int tx, gx, gy;
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr));
+            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr, mask_gamma, mask_beta),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr, mask_gamma, mask_beta));
   return check_launch("emrt_bn_bwd_reduce");
 }
 
@@ -1300,16 +1292,17 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
 extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx,
                               void* dres, int lddres, const float* mean, const float* invstd, const float* gamma,
                               const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M,
-                              int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream) {
+                              int C, const float* beta_y_moments, int sums_vs_x, const float* mask_beta, int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(x && dy && dx && mean && invstd && gamma && sums, "null pointer");
+  EMRT_REQUIRE(!(mask_beta && (y || beta_y_moments || sums_vs_x)), "mask_beta (ReLU mask re-derived from x) excludes y and the fused-sum forms");
   EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C and ld must be multiples of 4");
   int threads, rpp, grid;
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x),
-            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x));
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x, mask_beta),
+            hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x, mask_beta));
   return check_launch("emrt_bn_bwd_dx");
 }
 

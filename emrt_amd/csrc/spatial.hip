@@ -7,6 +7,7 @@
 // (paddle_vision_resnet.py:201, paddle_EMRT.py:84), paddle.concat (paddle_EMRT.py:290-293 -- replaced by writing
 // each producer straight into its channel slice of the [B,S,S,1536] buffer).
 #include "common.hpp"
+#include "bn_operand.hpp"
 
 using namespace emrt;
 
@@ -91,6 +92,64 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs a) {
       T* op = (T*)a.out + (long long)n * a.out_bs + ((long long)oh * a.OW + ow) * a.out_ld + c;
       VecIO<T, VEC>::store(op, o);
     }
+  }
+}
+
+// out = resize(relu(BN(in))): `in` is the raw pre-BatchNorm map of the producing conv, normalised tap by tap as it is loaded
+// (bn_operand.hpp).  The ReLU comes BEFORE the interpolation, so each of the four taps is transformed on its own.
+template <class T, int VEC>
+struct ResizeTaps {
+  float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+  float wy0, wy1, wx0, wx1;
+  long long out_off;
+};
+template <class T, int VEC>
+__device__ __forceinline__ void resize_taps_load(const ResizeArgs& a, long long idx, int cv, bool small, ResizeTaps<T, VEC>& t) {
+  int c, ow, oh, n;
+  unravel4(idx, cv, a.OW, a.OH, small, c, ow, oh, n);
+  c *= VEC;
+  int y0, y1, x0, x1;
+  axis_src(a.ay, oh, a.IH, y0, y1, t.wy0, t.wy1);
+  axis_src(a.ax, ow, a.IW, x0, x1, t.wx0, t.wx1);
+  const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
+  VecIO<T, VEC>::load(ip + ((long long)y0 * a.IW + x0) * a.in_ld, t.v00);
+  VecIO<T, VEC>::load(ip + ((long long)y0 * a.IW + x1) * a.in_ld, t.v01);
+  VecIO<T, VEC>::load(ip + ((long long)y1 * a.IW + x0) * a.in_ld, t.v10);
+  VecIO<T, VEC>::load(ip + ((long long)y1 * a.IW + x1) * a.in_ld, t.v11);
+  t.out_off = (long long)n * a.out_bs + ((long long)oh * a.OW + ow) * a.out_ld + c;
+}
+// host: 256 % (C / VEC) == 0, so a thread keeps ONE channel group over its grid-stride loop: its scale / shift live in registers.  The
+// first element's four taps are requested before the per-channel preamble and every later element one iteration ahead (a block is a
+// latency chain: gather -> blend -> store).
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void resize_fwd_bn_kernel(ResizeArgs a, BnOperand bn) {
+  extern __shared__ float bn_lds[];          // [2][C]: scale, shift
+  const int cv = a.C / VEC;
+  const long long total = (long long)a.N * a.OH * a.OW * cv;
+  const bool small = total <= 0xffffffffll;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  ResizeTaps<T, VEC> cur, nxt;
+  if (idx < total) resize_taps_load<T, VEC>(a, idx, cv, small, cur);
+  bn_operand_preamble(bn, a.C, bn_lds, blockIdx.x == 0);
+  const float lo = bn.relu ? 0.f : -INFINITY;
+  const int c = ((int)threadIdx.x % cv) * VEC;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sc[e] = bn_lds[c + e]; sh[e] = bn_lds[a.C + c + e]; }
+  while (idx < total) {
+    const long long nidx = idx + step;
+    if (nidx < total) resize_taps_load<T, VEC>(a, nidx, cv, small, nxt);
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float t00 = fmaxf(fmaf(cur.v00[e], sc[e], sh[e]), lo), t01 = fmaxf(fmaf(cur.v01[e], sc[e], sh[e]), lo);
+      const float t10 = fmaxf(fmaf(cur.v10[e], sc[e], sh[e]), lo), t11 = fmaxf(fmaf(cur.v11[e], sc[e], sh[e]), lo);
+      o[e] = cur.wy0 * (cur.wx0 * t00 + cur.wx1 * t01) + cur.wy1 * (cur.wx0 * t10 + cur.wx1 * t11);
+    }
+    VecIO<T, VEC>::store((T*)a.out + cur.out_off, o);
+    cur = nxt;
+    idx = nidx;
   }
 }
 
@@ -557,6 +616,49 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec8_kernel(MaxPoolArgs a) {
   }
 }
 
+// out = maxpool(relu(BN(in))) on the raw pre-BatchNorm map (bn_operand.hpp): every window tap is normalised as it is loaded (gamma may be
+// negative, so the transform is not monotone and cannot be applied to the window's maximum instead).
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_bn_kernel(MaxPoolArgs a, BnOperand bn) {
+  extern __shared__ float bn_lds[];          // [2][C]: scale, shift
+  bn_operand_preamble(bn, a.C, bn_lds, blockIdx.x == 0);
+  const float lo = bn.relu ? 0.f : -INFINITY;
+  const int cv = a.C / 8;
+  const long long total = (long long)a.N * a.OH * a.OW * cv;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int c, ow, oh, n;
+    unravel4(idx, cv, a.OW, a.OH, total <= 0xffffffffll, c, ow, oh, n);
+    c *= 8;
+    float best[8], sc[8], sh[8];
+    int slot[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; slot[e] = 255; sc[e] = bn_lds[c + e]; sh[e] = bn_lds[a.C + c + e]; }
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int h = oh * a.stride - a.pad + kh;
+      if ((unsigned)h >= (unsigned)a.H) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int w = ow * a.stride - a.pad + kw;
+        if ((unsigned)w >= (unsigned)a.W) continue;
+        float v[8];
+        Vec8<T>::load((const T*)a.in + (((long long)n * a.H + h) * a.W + w) * a.C + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = fmaxf(fmaf(v[e], sc[e], sh[e]), lo);
+          if (t > best[e] || t != t || slot[e] == 255) { best[e] = t; slot[e] = kh * a.k + kw; }
+        }
+      }
+    }
+    const long long o = (((long long)n * a.OH + oh) * a.OW + ow) * a.C + c;
+    Vec8<T>::store((T*)a.out + o, best);
+    if (a.arg) {
+      uint2 pk;
+      pk.x = (unsigned)slot[0] | ((unsigned)slot[1] << 8) | ((unsigned)slot[2] << 16) | ((unsigned)slot[3] << 24);
+      pk.y = (unsigned)slot[4] | ((unsigned)slot[5] << 8) | ((unsigned)slot[6] << 16) | ((unsigned)slot[7] << 24);
+      *reinterpret_cast<uint2*>(a.arg + o) = pk;
+    }
+  }
+}
+
 // VEC = 4: four channels per thread (one 4-byte load of argmax slots, one 8/16-byte load of dout per window)
 template <class T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolArgs a) {
@@ -694,6 +796,54 @@ extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_
   return check_launch("emrt_resize_bilinear_fwd");
 }
 
+// every block of a BatchNorm-operand kernel first derives the per-channel constants (C x 16 fp64 loads from L2 + fp64 math, ~2 us): few,
+// long-lived blocks (4 per CU), the element loop is grid-strided
+static inline int bn_operand_grid(long long total) {
+  const int g = ew_grid(total);
+  const int cap = g_tune.bn_operand_blocks > 0 ? g_tune.bn_operand_blocks : 2048;
+  return g > cap ? cap : g;
+}
+
+static int fill_bn_operand(BnOperand& b, const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
+                           float* run_mean, float* run_var, const float* gamma, const float* beta, int relu) {
+  if (!sums || !mean || !invstd || !gamma || !beta || !(count > 0.0) || (run_mean != nullptr) != (run_var != nullptr)) return -1;
+  b.sums = sums; b.inv_count = 1.0 / count; b.eps = eps; b.momentum = momentum; b.mean = mean; b.invstd = invstd;
+  b.run_mean = run_mean; b.run_var = run_var; b.gamma = gamma; b.beta = beta; b.relu = relu;
+  return 0;
+}
+
+// out = bilinear_resize([relu](BatchNorm_train(in))) in ONE pass over the raw map: emrt_bn_apply + emrt_resize_bilinear_fwd without the
+// normalised intermediate (bn_operand.hpp).  `sums` are the complete fp64 batch sums [8][2C] (emrt_conv2d's bn_stats / emrt_bn_stats,
+// all-reduced over ranks by the caller for SyncBatchNorm, `count` then the global row count); mean / invstd are saved for backward and the
+// running statistics updated exactly as emrt_bn_apply does.  Vector path only (C % 4 == 0, 16-byte aligned, C <= 4096): anything else is
+// an error, the caller then keeps the two separate launches.
+extern "C" int emrt_bn_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs,
+                                           int out_ld, int OH, int OW, int N, int C, int align_corners, const double* sums, double count,
+                                           float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+                                           const float* gamma, const float* beta, int relu, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(in && out, "null pointer");
+  EMRT_REQUIRE(N > 0 && C > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "bad dims");
+  ResizeArgs a;
+  a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.IH = IH; a.IW = IW;
+  a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.OH = OH; a.OW = OW;
+  a.add = nullptr; a.add_bs = 0; a.add_ld = 0; a.N = N; a.C = C;
+  a.ay = make_axis(IH, OH, align_corners); a.ax = make_axis(IW, OW, align_corners); a.out_nchw_f32 = 0;
+  BnOperand b;
+  EMRT_REQUIRE(fill_bn_operand(b, sums, count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, relu) == 0,
+               "BatchNorm operand: sums, mean, invstd, gamma, beta and a positive count are required");
+  const bool v4 = C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && in_bs % 4 == 0 && out_bs % 4 == 0 &&
+                  ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  EMRT_REQUIRE(v4, "vector path only: C / 4 a divisor of 256, 16-byte aligned rows");
+  const bool v8 = dtype != EMRT_F32 && C % 8 == 0 && 256 % (C / 8) == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && in_bs % 8 == 0 && out_bs % 8 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  if (v8) hipLaunchKernelGGL((resize_fwd_bn_kernel<bf16_t, 8>), dim3(bn_operand_grid((long long)N * OH * OW * (C / 8))), dim3(256), lds, st, a, b);
+  else if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_bn_kernel<float, 4>), dim3(bn_operand_grid((long long)N * OH * OW * (C / 4))), dim3(256), lds, st, a, b);
+  else hipLaunchKernelGGL((resize_fwd_bn_kernel<bf16_t, 4>), dim3(bn_operand_grid((long long)N * OH * OW * (C / 4))), dim3(256), lds, st, a, b);
+  return check_launch("emrt_bn_resize_bilinear_fwd");
+}
+
 extern "C" size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, int dout_nchw_f32) {
   return dout_nchw_f32 ? (size_t)N * C * OH * IW * sizeof(float) : 0;
 }
@@ -754,28 +904,26 @@ static int fill_pool(PoolArgs& a, const int* scales, int nscales) {
 }
 
 // Large bins cut over several blocks.  One block per (image, bin) makes the 1x1 scale's bin -- the whole map: 32x32 pixels x 512 bytes at
-// 256x256 tiles, 64x64 at 512x512 -- ONE block's serial read through one CU (36 us / 102 us of the step for 4 / 16 MB).  Here block (bin, part)
-// sums every S-th run of the bin's pixels and adds its partial, already divided by the bin's size, into a ZEROED fp32 workspace [N][tokens][C]
-// (fp32 atomics: a few hundred KB); adaptive_pool_final_kernel rounds the sums to the output type.
+// 256x256 tiles, 64x64 at 512x512 -- ONE block's serial read through one CU (36 us / 102 us of the step for 4 / 16 MB).  Here block
+// (bin, part) sums every pixel of its part of the bin and WRITES the partial, already divided by the bin's size, to its own slot of an fp32
+// workspace [N][items][C]; adaptive_pool_final_kernel adds a bin's parts in part order and rounds to the output type.  No atomics: the
+// result does not depend on the order the blocks ran in (two evaluations of the same tile give the same bits).
 template <class T>
-__global__ __launch_bounds__(POOL_THREADS) void adaptive_pool_part_kernel(PoolArgs a, float* __restrict__ ws, int S) {
+__global__ __launch_bounds__(POOL_THREADS) void adaptive_pool_part_kernel(PoolArgs a, float* __restrict__ ws) {
   __shared__ float red[POOL_THREADS * 4];
   // work item -> (scale, bin, part): the grid holds only as many blocks per bin as its scale's largest bin needs at 128 pixels each
   const int item = blockIdx.x % a.nitem, n = blockIdx.x / a.nitem;
   int s = 0;
   while (s + 1 < a.nscales && item >= a.item0[s + 1]) ++s;
-  (void)S;
   const int k = a.k[s], P_ = a.parts[s];
   const int t = (item - a.item0[s]) / P_, part = (item - a.item0[s]) - t * P_;
-  const int tok = a.tok0[s] + t;
   const int oi = t / k, oj = t - oi * k;
   int h0, h1, w0, w1;
   bin_of(oi, k, a.H, h0, h1);
   bin_of(oj, k, a.W, w0, w1);
   const int bw = w1 - w0, npix = (h1 - h0) * bw;
   const int per = (npix + P_ - 1) / P_;
-  const int p0 = part * per, p1 = p0 + per < npix ? p0 + per : npix;
-  if (p0 >= npix) return;
+  const int p0 = part * per, p1 = p0 + per < npix ? p0 + per : npix;      // (p0 >= npix: a small bin of this scale has fewer parts: a zero slot)
   const int cq = a.C / 4, phases = POOL_THREADS / cq;          // host: C % 4 == 0, C / 4 <= 256 and a power of two
   const int q = (int)threadIdx.x % cq, ph = (int)threadIdx.x / cq;
   const T* ip = (const T*)a.in + (long long)n * a.in_bs + q * 4;
@@ -805,9 +953,9 @@ __global__ __launch_bounds__(POOL_THREADS) void adaptive_pool_part_kernel(PoolAr
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] += red[(threadIdx.x + o * cq) * 4 + e];
     const float inv = 1.f / (float)npix;
-    float* wp = ws + ((long long)n * a.ntok + tok) * a.C + q * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(wp + e, acc[e] * inv);
+    float4 o4;
+    o4.x = acc[0] * inv; o4.y = acc[1] * inv; o4.z = acc[2] * inv; o4.w = acc[3] * inv;
+    *reinterpret_cast<float4*>(ws + ((long long)n * a.nitem + item) * a.C + q * 4) = o4;
   }
 }
 
@@ -819,53 +967,76 @@ __global__ __launch_bounds__(256) void adaptive_pool_final_kernel(PoolArgs a, co
     const int q = (int)(idx % cq);
     const long long nt = idx / cq;
     const int tok = (int)(nt % a.ntok), n = (int)(nt / a.ntok);
-    const float4 v = *reinterpret_cast<const float4*>(ws + nt * a.C + q * 4);
-    float o[4] = {v.x, v.y, v.z, v.w};
+    int s = 0;
+    while (s + 1 < a.nscales && tok >= a.tok0[s + 1]) ++s;
+    const int P_ = a.parts[s];
+    const float* wp = ws + ((long long)n * a.nitem + a.item0[s] + (long long)(tok - a.tok0[s]) * P_) * a.C + q * 4;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P_; ++p) {          // fixed order
+      const float4 v = *reinterpret_cast<const float4*>(wp + (long long)p * a.C);
+      o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+    }
     Vec4<T>::store((T*)a.out + (long long)n * a.out_bs + (long long)tok * a.out_ld + q * 4, o);
   }
 }
 
+// The split plan of emrt_adaptive_avgpool_fwd: parts per bin of each scale (128 pixels per part), items = sum k^2 * parts; false when the
+// map is small (largest bin < 512 pixels) or the channel count is off the vector path: one block per bin then.
+static bool pool_split_plan(PoolArgs& a, int H, int W, int C, const int* scales, int nscales) {
+  int kmin = scales[0];
+  for (int i = 1; i < nscales; ++i) kmin = scales[i] < kmin ? scales[i] : kmin;
+  const long long big = (long long)((H + kmin - 1) / kmin + 1) * ((W + kmin - 1) / kmin + 1);      // pixels of the largest bin (upper bound)
+  const int cq = C / 4;
+  if (!((C % 4 == 0) && cq <= 256 && (cq & (cq - 1)) == 0 && big >= 512)) return false;
+  a.nitem = 0;
+  for (int i = 0; i < 4; ++i) { a.parts[i] = 1; a.item0[i] = 0; }
+  for (int i = 0; i < nscales; ++i) {
+    const long long mx = (long long)((H + scales[i] - 1) / scales[i] + 1) * ((W + scales[i] - 1) / scales[i] + 1);      // largest bin of this scale (upper bound)
+    long long pp = (mx + 127) / 128;
+    if (pp > 256) pp = 256;
+    a.parts[i] = (int)pp;
+    a.item0[i] = a.nitem;
+    a.nitem += scales[i] * scales[i] * (int)pp;
+  }
+  return true;
+}
+
+// bytes of the fp32 partial-sum workspace emrt_adaptive_avgpool_fwd can use for this call (0: the map is pooled by one block per bin and
+// no workspace is needed).  The workspace need not be cleared.
+extern "C" size_t emrt_adaptive_avgpool_workspace_bytes(int H, int W, int N, int C, const int* scales /*host*/, int nscales) {
+  PoolArgs a;
+  if (!scales || N <= 0 || H <= 0 || W <= 0 || C <= 0 || fill_pool(a, scales, nscales) != 0) return 0;
+  if (!pool_split_plan(a, H, W, C, scales, nscales)) return 0;
+  return (size_t)N * a.nitem * C * sizeof(float);
+}
+
 // out tokens [N][sum k^2][C] (row stride out_ld, batch stride out_bs)
 extern "C" int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs,
-                                         int out_ld, int N, int C, const int* scales /*host*/, int nscales, float* zeroed_workspace, int dtype, void* stream) {
+                                         int out_ld, int N, int C, const int* scales /*host*/, int nscales, float* workspace, size_t workspace_bytes,
+                                         int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(in && out && scales, "null pointer");
   PoolArgs a;
   a.in = in; a.in_bs = in_bs; a.in_ld = in_ld; a.H = H; a.W = W; a.out = out; a.out_bs = out_bs; a.out_ld = out_ld; a.N = N; a.C = C;
   EMRT_REQUIRE(fill_pool(a, scales, nscales) == 0, "1..4 scales supported");
   hipStream_t st = (hipStream_t)stream;
-  {
-    int kmin = scales[0];
-    for (int i = 1; i < nscales; ++i) kmin = scales[i] < kmin ? scales[i] : kmin;
-    const long long big = (long long)((H + kmin - 1) / kmin + 1) * ((W + kmin - 1) / kmin + 1);      // pixels of the largest bin (upper bound)
+  if (workspace) {
     const int esz = dtype == EMRT_F32 ? 4 : 2;
-    const int cq = C / 4;
-    const bool vec = (C % 4 == 0) && cq <= 256 && (cq & (cq - 1)) == 0 && (in_ld % 4 == 0) && (in_bs % 4 == 0) && (out_ld % 4 == 0) && (out_bs % 4 == 0) &&
-                     (((uintptr_t)in) % (4 * esz) == 0) && (((uintptr_t)out) % (4 * esz) == 0);
-    if (zeroed_workspace && vec && big >= 512) {
-      int S = 1;
-      a.nitem = 0;
-      for (int i = 0; i < 4; ++i) { a.parts[i] = 1; a.item0[i] = 0; }
-      for (int i = 0; i < nscales; ++i) {
-        const long long mx = (long long)((H + scales[i] - 1) / scales[i] + 1) * ((W + scales[i] - 1) / scales[i] + 1);      // largest bin of this scale (upper bound)
-        long long pp = (mx + 127) / 128;
-        if (pp > 256) pp = 256;
-        a.parts[i] = (int)pp;
-        a.item0[i] = a.nitem;
-        a.nitem += scales[i] * scales[i] * (int)pp;
-        S = (int)pp > S ? (int)pp : S;
-      }
+    const bool vec = (in_ld % 4 == 0) && (in_bs % 4 == 0) && (out_ld % 4 == 0) && (out_bs % 4 == 0) && (((uintptr_t)in) % (4 * esz) == 0) &&
+                     (((uintptr_t)out) % (4 * esz) == 0) && (((uintptr_t)workspace) % 16 == 0);
+    if (vec && pool_split_plan(a, H, W, C, scales, nscales)) {
+      EMRT_REQUIRE(workspace_bytes >= (size_t)N * a.nitem * C * sizeof(float), "workspace smaller than emrt_adaptive_avgpool_workspace_bytes()");
       const dim3 grid((unsigned)(N * a.nitem));
-      const int fg = ew_grid((long long)N * a.ntok * cq);
+      const int fg = ew_grid((long long)N * a.ntok * (C / 4));
       if (dtype == EMRT_F32) {
-        hipLaunchKernelGGL((adaptive_pool_part_kernel<float>), grid, dim3(POOL_THREADS), 0, st, a, zeroed_workspace, S);
-        hipLaunchKernelGGL((adaptive_pool_final_kernel<float>), dim3(fg), dim3(256), 0, st, a, (const float*)zeroed_workspace);
+        hipLaunchKernelGGL((adaptive_pool_part_kernel<float>), grid, dim3(POOL_THREADS), 0, st, a, workspace);
+        hipLaunchKernelGGL((adaptive_pool_final_kernel<float>), dim3(fg), dim3(256), 0, st, a, (const float*)workspace);
       } else if (dtype == EMRT_BF16) {
-        hipLaunchKernelGGL((adaptive_pool_part_kernel<bf16_t>), grid, dim3(POOL_THREADS), 0, st, a, zeroed_workspace, S);
-        hipLaunchKernelGGL((adaptive_pool_final_kernel<bf16_t>), dim3(fg), dim3(256), 0, st, a, (const float*)zeroed_workspace);
+        hipLaunchKernelGGL((adaptive_pool_part_kernel<bf16_t>), grid, dim3(POOL_THREADS), 0, st, a, workspace);
+        hipLaunchKernelGGL((adaptive_pool_final_kernel<bf16_t>), dim3(fg), dim3(256), 0, st, a, (const float*)workspace);
       } else {
-        hipLaunchKernelGGL((adaptive_pool_part_kernel<f16_t>), grid, dim3(POOL_THREADS), 0, st, a, zeroed_workspace, S);
-        hipLaunchKernelGGL((adaptive_pool_final_kernel<f16_t>), dim3(fg), dim3(256), 0, st, a, (const float*)zeroed_workspace);
+        hipLaunchKernelGGL((adaptive_pool_part_kernel<f16_t>), grid, dim3(POOL_THREADS), 0, st, a, workspace);
+        hipLaunchKernelGGL((adaptive_pool_final_kernel<f16_t>), dim3(fg), dim3(256), 0, st, a, (const float*)workspace);
       }
       return check_launch("emrt_adaptive_avgpool_fwd");
     }
@@ -920,6 +1091,31 @@ extern "C" int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax
   const int grid = ew_grid((long long)N * a.OH * a.OW * C);
   DT3(dtype, maxpool_fwd_kernel, grid, a);
   return check_launch("emrt_maxpool_fwd");
+}
+
+// out = maxpool([relu](BatchNorm_train(in))) in one pass over the raw map (see emrt_bn_resize_bilinear_fwd).  C % 8 == 0, C <= 4096.
+extern "C" int emrt_bn_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad,
+                                   const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
+                                   float* run_mean, float* run_var, const float* gamma, const float* beta, int relu, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(in && out, "null pointer");
+  EMRT_REQUIRE(k > 0 && k <= 15 && stride > 0 && pad >= 0 && pad < k, "bad window");
+  MaxPoolArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.out = out; a.arg = argmax; a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.stride = stride; a.pad = pad;
+  a.OH = (H + 2 * pad - k) / stride + 1; a.OW = (W + 2 * pad - k) / stride + 1;
+  BnOperand b;
+  EMRT_REQUIRE(fill_bn_operand(b, sums, count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, relu) == 0,
+               "BatchNorm operand: sums, mean, invstd, gamma, beta and a positive count are required");
+  const int esz = dtype == EMRT_F32 ? 4 : 2;
+  EMRT_REQUIRE(C % 8 == 0 && C <= 4096 && ((uintptr_t)in % (8 * esz) == 0) && ((uintptr_t)out % (8 * esz) == 0) && (!argmax || (uintptr_t)argmax % 8 == 0),
+               "vector path only: C % 8 == 0, C <= 4096, aligned maps");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = bn_operand_grid((long long)N * a.OH * a.OW * (C / 8));
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((maxpool_fwd_bn_kernel<float>), dim3(grid), dim3(256), lds, st, a, b);
+  else hipLaunchKernelGGL((maxpool_fwd_bn_kernel<bf16_t>), dim3(grid), dim3(256), lds, st, a, b);
+  return check_launch("emrt_bn_maxpool_fwd");
 }
 
 extern "C" int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, int N, int H, int W, int C, int k, int stride,

@@ -530,7 +530,7 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
                 yv = None                 # dy is already masked
             else:
                 sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
-                _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), c.dtype, c.stream)
+                _L().call("emrt_bn_bwd_reduce", P(x), ldx, P(dy), lddy, P(yv), ldy, P(mean), P(invstd), M, C, P(sums2), None, None, c.dtype, c.stream)
             # dgamma/dbeta use the LOCAL sums (the gradient all-reduce combines ranks); dx needs the GLOBAL sums
             local = None
             if sync:
@@ -541,7 +541,7 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
             dres = c.empty(tuple(x.shape)) if (residual is not None and relu and not fused) else None
             _L().call("emrt_bn_bwd_dx", P(x), ldx, P(dy), lddy, P(yv), ldy, P(dx), C, P(dres), C, P(mean), P(invstd), P(bn.gamma),
                       P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C,
-                      P(bn.beta) if (fused and residual is None) else None, int(fused and residual is not None), c.dtype, c.stream)
+                      P(bn.beta) if (fused and residual is None) else None, int(fused and residual is not None), None, c.dtype, c.stream)
             tape.add_grad(x, dx, owned=True)
             if residual is not None:
                 tape.add_grad(residual, dres if dres is not None else dy, owned=dres is not None)
@@ -549,9 +549,52 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
     return out
 
 
-def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
+class PendingBN:
+    """relu(BatchNorm_train(raw)) that has NOT been applied: the raw conv output plus its complete fp64 batch sums.  A streaming consumer
+    (resize_bilinear, maxpool) applies the affine map + ReLU to every element it loads (csrc/bn_operand.hpp), so the normalised map is
+    never written and the emrt_bn_apply launch disappears; the consumer's backward then runs this layer's BatchNorm backward with the
+    ReLU mask re-derived from `raw`.  Only conv_bn(..., defer=True) makes one, and only resize_bilinear / maxpool accept one."""
+
+    def __init__(self, raw, bn, sums, count, relu):
+        c = ctx()
+        self.raw, self.bn, self.sums, self.count, self.relu = raw, bn, sums, count, relu
+        self.shape = raw.shape
+        N, H, W, C, ldx, x_bs = _check_map(raw)
+        assert x_bs == H * W * ldx and ldx == C, "a deferred BatchNorm needs a dense NHWC map"
+        self.M, self.C = N * H * W, C
+        self.mean = c.empty((C,), torch.float32)
+        self.invstd = c.empty((C,), torch.float32)
+
+    def operand(self):
+        """the BatchNorm arguments of emrt_bn_resize_bilinear_fwd / emrt_bn_maxpool_fwd"""
+        bn = self.bn
+        return (P(self.sums), float(self.count), bn.eps, bn.momentum, P(self.mean), P(self.invstd), P(bn.run_mean), P(bn.run_var), P(bn.gamma),
+                P(bn.beta), int(self.relu))
+
+    def backward(self, tape, dy):
+        """dy: gradient of relu(BN(raw)) (dense, unmasked) -> BatchNorm backward (emrt_bn_bwd_reduce + emrt_bn_bwd_dx, mask from raw)"""
+        c = ctx()
+        bn, M, C = self.bn, self.M, self.C
+        _, _, _, _, lddy, dy_bs = _check_map(dy)
+        assert dy_bs == (M // self.raw.shape[0]) * lddy
+        mg, mb = (P(bn.gamma), P(bn.beta)) if self.relu else (None, None)
+        sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
+        _L().call("emrt_bn_bwd_reduce", P(self.raw), C, P(dy), lddy, None, 0, P(self.mean), P(self.invstd), M, C, P(sums2), mg, mb, c.dtype, c.stream)
+        local = None
+        if _sync_active(bn):
+            local = c.empty((BN_REPLICAS * 2 * C,), torch.float64)
+            _L().call("emrt_cast", P(sums2), P(local), BN_REPLICAS * 4 * C, 0, F32, c.stream)     # raw 8-byte copy as 2 x f32
+            _allreduce_sums(sums2, M)
+        dx = c.empty(tuple(self.raw.shape))
+        _L().call("emrt_bn_bwd_dx", P(self.raw), C, P(dy), lddy, None, 0, P(dx), C, None, C, P(self.mean), P(self.invstd), P(bn.gamma),
+                  P(sums2), P(local), float(self.count), P(bn.dgamma), P(bn.dbeta), M, C, None, 0, mb, c.dtype, c.stream)
+        tape.add_grad(self.raw, dx, owned=True)
+
+
+def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
     """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training).  Inference: the BatchNorm is
-    an affine map of running statistics and is folded into the conv's epilogue -- no BatchNorm launch, no intermediate tensor."""
+    an affine map of running statistics and is folded into the conv's epilogue -- no BatchNorm launch, no intermediate tensor.
+    defer=True (training, when the only consumer is resize_bilinear or maxpool): returns a PendingBN instead of launching emrt_bn_apply."""
     c = ctx()
     if c.fold_live and not c.training and c.tape is None and (conv.gw.bias is None or bn.state.fold_conv is conv):
         scale, shift = bn.state.fold_scale, bn.state.fold_shift      # ParamStore.fold_bn(): refreshed at the top of every eval forward
@@ -559,6 +602,11 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
                       dilation=getattr(conv, "dilation", 1), out_scale=scale, out_shift=shift)
     sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
     y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums, dilation=getattr(conv, "dilation", 1))
+    if defer and c.training and c.bn_defer and residual is None and out is None and bn.C % 8 == 0 and 256 % (bn.C // 8) == 0:
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        if _sync_active(bn.state):
+            count = _allreduce_sums(sums, count)
+        return PendingBN(y, bn.state, sums, count, relu)
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 
 
@@ -608,7 +656,7 @@ def conv_bn_group(convs, bns, xs, relu=True):
                 C, ldx = geo[i]
                 lddy = _check_map(dys[i])[4]
                 _L().call("emrt_bn_bwd_reduce", P(ys[i]), ldx, P(dys[i]), lddy, P(outs[i]) if relu else None, C, P(saved[i][0]), P(saved[i][1]), Ms[i], C,
-                          P(sums2[offs[i]:offs[i] + sizes[i]]), c.dtype, c.stream)
+                          P(sums2[offs[i]:offs[i] + sizes[i]]), None, None, c.dtype, c.stream)
             # dgamma / dbeta from this rank's own sums (the gradient all-reduce combines ranks), dx from the rank-summed ones
             local = c.empty((sum(sizes),), torch.float64)
             _L().call("emrt_cast", P(sums2), P(local), 2 * sum(sizes), 0, F32, c.stream)       # raw 8-byte copy as 2 x f32
@@ -620,7 +668,7 @@ def conv_bn_group(convs, bns, xs, relu=True):
                 dx = c.empty(tuple(ys[i].shape))
                 _L().call("emrt_bn_bwd_dx", P(ys[i]), ldx, P(dys[i]), lddy, P(outs[i]) if relu else None, C, P(dx), C, None, C, P(saved[i][0]), P(saved[i][1]),
                           P(st.gamma), P(sums2[offs[i]:offs[i] + sizes[i]]), P(local[offs[i]:offs[i] + sizes[i]]), float(Ms[i] * world), P(st.dgamma),
-                          P(st.dbeta), Ms[i], C, None, 0, c.dtype, c.stream)
+                          P(st.dbeta), Ms[i], C, None, 0, None, c.dtype, c.stream)
                 tape.add_grad(ys[i], dx, owned=True)
         tape.record(bwd)
     return outs
@@ -969,6 +1017,28 @@ def nchw_to_nhwc(img, c_out=None):
 def resize_bilinear(x, OH, OW, align_corners, add_t=None, out=None, out_nchw_f32=False):
     """x [N,IH,IW,C] view -> [N,OH,OW,C] (or fp32 [N,C,OH,OW] when out_nchw_f32), optional fused '+ add_t'."""
     c = ctx()
+    if isinstance(x, PendingBN):
+        assert add_t is None and not out_nchw_f32
+        pend, x = x, x.raw
+        N, IH, IW, C, in_ld, in_bs = _check_map(x)
+        if out is None:
+            out = c.empty((N, OH, OW, C))
+        _, _, _, _, out_ld, out_bs = _check_map(out)
+        _L().call("emrt_bn_resize_bilinear_fwd", P(x), in_bs, in_ld, IH, IW, P(out), out_bs, out_ld, OH, OW, N, C, int(align_corners),
+                  *pend.operand(), c.dtype, c.stream)
+        tape = c.tape
+        if tape is not None:
+            def bwd_pending():
+                dy = tape.pop_grad(out)
+                if dy is None:
+                    return
+                da = c.empty((N, IH, IW, C))
+                _, _, _, _, do_ld, do_bs = _check_map(dy)
+                _L().call("emrt_resize_bilinear_bwd", P(dy), do_bs, do_ld, OH, OW, P(da), IH * IW * C, C, IH, IW, N, C, int(align_corners), 0,
+                          None, c.dtype, c.stream)
+                pend.backward(tape, da)
+            tape.record(bwd_pending)
+        return out
     N, IH, IW, C, in_ld, in_bs = _check_map(x)
     if out_nchw_f32:
         assert out is None and add_t is None
@@ -1049,10 +1119,11 @@ def adaptive_avgpool_tokens(x, scales):
     ntok = sum(k * k for k in scales)
     out = c.empty((N, ntok, C))
     arr = (ctypes.c_int * len(scales))(*scales)
-    # zeroed fp32 partial-sum buffer: large maps are pooled by several blocks per bin (csrc/spatial.hip: adaptive_pool_part_kernel)
-    ws = c.zeros((N, ntok, C), torch.float32) if H * W >= 512 else None
+    # fp32 partial-sum slots: large maps are pooled by several blocks per bin (csrc/spatial.hip: adaptive_pool_part_kernel)
+    nws = _L().query("emrt_adaptive_avgpool_workspace_bytes", H, W, N, C, ctypes.cast(arr, ctypes.c_void_p), len(scales))
+    ws = c.empty((nws // 4,), torch.float32) if nws else None
     _L().call("emrt_adaptive_avgpool_fwd", P(x), in_bs, in_ld, H, W, P(out), ntok * C, C, N, C, ctypes.cast(arr, ctypes.c_void_p), len(scales),
-              P(ws), c.dtype, c.stream)
+              P(ws), nws, c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
@@ -1070,6 +1141,9 @@ def adaptive_avgpool_tokens(x, scales):
 
 def maxpool(x, k=3, stride=2, pad=1, need_dx=True):
     c = ctx()
+    pend = None
+    if isinstance(x, PendingBN):
+        pend, x = x, x.raw
     assert x.is_contiguous()
     N, H, W, C = x.shape
     OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -1077,7 +1151,10 @@ def maxpool(x, k=3, stride=2, pad=1, need_dx=True):
     tape = c.tape
     keep = tape is not None and need_dx
     arg = c.empty((N, OH, OW, C), torch.uint8) if keep else None      # winning window slot per output, for the backward
-    _L().call("emrt_maxpool_fwd", P(x), P(out), P(arg), N, H, W, C, k, stride, pad, c.dtype, c.stream)
+    if pend is not None:
+        _L().call("emrt_bn_maxpool_fwd", P(x), P(out), P(arg), N, H, W, C, k, stride, pad, *pend.operand(), c.dtype, c.stream)
+    else:
+        _L().call("emrt_maxpool_fwd", P(x), P(out), P(arg), N, H, W, C, k, stride, pad, c.dtype, c.stream)
     if keep:
         def bwd():
             dy = tape.pop_grad(out)
@@ -1086,7 +1163,10 @@ def maxpool(x, k=3, stride=2, pad=1, need_dx=True):
             assert dy.is_contiguous()
             dx = c.empty((N, H, W, C))
             _L().call("emrt_maxpool_bwd", P(arg), P(dy), P(dx), N, H, W, C, k, stride, pad, c.dtype, c.stream)
-            tape.add_grad(x, dx, owned=True)
+            if pend is not None:
+                pend.backward(tape, dx)
+            else:
+                tape.add_grad(x, dx, owned=True)
         tape.record(bwd)
     return out
 

@@ -111,7 +111,7 @@ class ResNet(hnn.HipLayer):  # :152-257
         return hnn.Sequential(*mods)
 
     def forward(self, x):
-        x = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
+        x = Fn.conv_bn(self.conv1, self.bn1, x, relu=True, defer=True)      # BatchNorm + ReLU applied by the max-pool's loads
         x = Fn.maxpool(x, 3, 2, 1)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -174,7 +174,7 @@ class ResNetV1c(hnn.HipLayer):  # backbones/resnet.py:102-221 with deep_stem=Tru
     def forward(self, x):  # :209-221
         x = Fn.conv_bn(self.conv1[0], self.conv1[1], x, relu=True)
         x = Fn.conv_bn(self.conv1[3], self.conv1[4], x, relu=True)
-        x = Fn.conv_bn(self.conv1[6], self.bn1, x, relu=True)
+        x = Fn.conv_bn(self.conv1[6], self.bn1, x, relu=True, defer=True)
         x = Fn.maxpool(x, 3, 2, 1)
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -581,7 +581,8 @@ class branch_block(hnn.HipLayer):  # :80-97
     def forward(self, x, out=None):
         x = Fn.maxpool(x, 3, 2, 1, need_dx=not self.first)
         x = Fn.conv_bn(self.encode[0], self.encode[1], x, relu=True)
-        return Fn.conv_bn(self.encode[3], self.encode[4], x, relu=True, out=out)
+        # (without `out` the only consumer is the next block's max-pool: its loads apply this BatchNorm + ReLU)
+        return Fn.conv_bn(self.encode[3], self.encode[4], x, relu=True, out=out, defer=out is None)
 
 
 class spatial_branch(hnn.HipLayer):  # :99-113
@@ -604,9 +605,9 @@ class UpHead(hnn.HipLayer):  # :115-181 (num_conv == 3)
                                                                 hnn.BatchNorm2D(256, after=self.conv_2))
 
     def forward(self, x):  # :164-180
-        x = Fn.conv_bn(self.conv_0, self.syncbn_fc_0, x, relu=True)
+        x = Fn.conv_bn(self.conv_0, self.syncbn_fc_0, x, relu=True, defer=True)      # BatchNorm + ReLU applied by the resize's loads
         x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
-        x = Fn.conv_bn(self.conv_1, self.syncbn_fc_1, x, relu=True)
+        x = Fn.conv_bn(self.conv_1, self.syncbn_fc_1, x, relu=True, defer=True)
         x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
         x = Fn.conv_bn(self.conv_2, self.syncbn_fc_2, x, relu=True)
         x = self.conv_3(x)

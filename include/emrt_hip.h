@@ -35,7 +35,7 @@ int emrt_abi_version(void);
 int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len);
 /* Developer / test knobs of the dispatchers (forced tile shapes, kernel variants).  The table is filled ONCE from the
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
- * conv_tile, wgrad_split, wgrad_no_overwrite, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
+ * conv_tile, wgrad_split, wgrad_no_overwrite, bn_operand_blocks, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
  * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
  * gn_bwd_stat_rows, gn_apply_rows.
  * Not thread-safe against concurrent launches; production code never calls these. */
@@ -119,8 +119,11 @@ int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, i
  * the convolution feeding this BatchNorm or -1; writes out[o..o+C) = s = gamma / sqrt(var + eps) and
  * out[o+C..o+2C) = beta + (conv_bias - mean) * s: emrt_conv2d's out_scale / bias. */
 int emrt_bn_fold(const float* params, const float* buffers, const long long* desc, int n, float eps, float* out, void* stream);
-int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, int dtype, void* stream);
-int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int sums_vs_x, int dtype, void* stream);
+/* ABI 6: mask_gamma / mask_beta of emrt_bn_bwd_reduce and mask_beta of emrt_bn_bwd_dx (nullable; y must then be NULL): the layer's ReLU
+ * output was never written because its consumer applied BatchNorm + ReLU on load (emrt_bn_resize_bilinear_fwd, emrt_bn_maxpool_fwd); the
+ * mask is re-derived from x with the forward's own expression, relu'(x * invstd * gamma + (beta - mean * invstd * gamma)). */
+int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, const float* mask_gamma, const float* mask_beta, int dtype, void* stream);
+int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int sums_vs_x, const float* mask_beta, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
 
@@ -170,16 +173,27 @@ int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, 
 /* ---- bilinear F.interpolate (align_corners True/False), optional fused "+ add", strided (concat-slice) output,
  * optional fp32 NCHW output for the returned logits: paddle_EMRT.py:40,44,169,174,180,288-289,301; fcn_head.py:80 */
 int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs, int out_ld, int OH, int OW, const void* add, long long add_bs, int add_ld, int N, int C, int align_corners, int out_nchw_f32, int dtype, void* stream);
+/* ABI 6: out = resize([relu](BatchNorm_train(in))) in one pass over the RAW map of the producing conv -- emrt_bn_apply +
+ * emrt_resize_bilinear_fwd without the normalised intermediate (nn.SyncBatchNorm -> ReLU -> F.interpolate, paddle_EMRT.py:164-175).
+ * sums / count / eps / momentum / mean / invstd / run_* / gamma / beta / relu exactly as emrt_bn_apply takes them (sums complete, and
+ * all-reduced by the caller for SyncBatchNorm).  Vector path only (C / 4 a divisor of 256, 16-byte aligned rows), an error otherwise.
+ * Backward: emrt_resize_bilinear_bwd, then emrt_bn_bwd_reduce / emrt_bn_bwd_dx with the mask_* arguments. */
+int emrt_bn_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs, int out_ld, int OH, int OW, int N, int C, int align_corners, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int relu, int dtype, void* stream);
 size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, int dout_nchw_f32);
 int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs, int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, void* workspace, int dtype, void* stream);
 /* nn.AdaptiveAvgPool2D(k), k in scales (host int[nscales], <= 4), all scales in one launch -> tokens [N][sum k^2][C]:
- * paddle_EMRT.py:62,70-78.  zeroed_workspace (ABI 5, nullable): fp32 [N][sum k^2][C], ZEROED by the caller; with it, maps whose largest bin
- * has >= 512 pixels are pooled by several blocks per bin (partial sums added there, a second launch rounds them into `out`) instead of one
- * block per bin reading the whole map of the 1x1 scale through one CU */
-int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs, int out_ld, int N, int C, const int* scales, int nscales, float* zeroed_workspace, int dtype, void* stream);
+ * paddle_EMRT.py:62,70-78.  workspace (nullable; ABI 6: sized by emrt_adaptive_avgpool_workspace_bytes for the same H, W, N, C, scales, NOT
+ * cleared by the caller): with it, maps whose largest bin has >= 512 pixels are pooled by several blocks per bin, each writing its partial
+ * sum to its own slot, and a second launch adds a bin's parts in a fixed order -- no atomics, the same bits on every run -- instead of one
+ * block per bin reading the whole map of the 1x1 scale through one CU.  The query returns 0 when the call would not use a workspace. */
+size_t emrt_adaptive_avgpool_workspace_bytes(int H, int W, int N, int C, const int* scales, int nscales);
+int emrt_adaptive_avgpool_fwd(const void* in, long long in_bs, int in_ld, int H, int W, void* out, long long out_bs, int out_ld, int N, int C, const int* scales, int nscales, float* workspace, size_t workspace_bytes, int dtype, void* stream);
 int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int do_ld, void* din, long long di_bs, int di_ld, int H, int W, int N, int C, const int* scales, int nscales, int dtype, void* stream);
 /* nn.MaxPool2D(3, 2, 1): paddle_vision_resnet.py:201; paddle_EMRT.py:84 (dense NHWC) */
 int emrt_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
+/* ABI 6: out = maxpool([relu](BatchNorm_train(in))) on the raw map (BatchNorm2D -> ReLU -> MaxPool2D: paddle_vision_resnet.py:199-201,
+ * paddle_EMRT.py:84-91); BatchNorm arguments as emrt_bn_resize_bilinear_fwd.  C % 8 == 0, C <= 4096. */
+int emrt_bn_maxpool_fwd(const void* in, void* out, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int relu, int dtype, void* stream);
 int emrt_maxpool_bwd(const unsigned char* argmax, const void* dout, void* din, int N, int H, int W, int C, int k, int stride, int pad, int dtype, void* stream);
 /* model input: fp32 NCHW images (paddle_EMRT.py:252) -> NHWC compute dtype with c_out >= C channels (the extra ones zero: the
  * 3-channel image as an 8-channel map keeps the first convolutions on the GEMM kernels' 16-byte operand path) */

@@ -49,7 +49,7 @@ def test_loader_binds_all_entry_points(built):
     from emrt_amd import _lib
     _lib._LIB = None
     L = _lib.lib()
-    assert L.query("emrt_abi_version") == 5
+    assert L.query("emrt_abi_version") == 6
     assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
     import ctypes
     small = (ctypes.c_int * 6)(2, 2, 2, 2, 1, 2)                   # Lv = 10
@@ -67,6 +67,13 @@ def test_loader_binds_all_entry_points(built):
     # without the level shapes the size would leave the partial slabs out -> an error, not a too-small answer
     assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 3, 6, None, 1) == 0 and "level shapes" in L.last_error()
     assert L.query("emrt_msda_bwd_workspace_bytes", 4, 5376, 8, 5, 6, ctypes.cast(cfg3, ctypes.c_void_p), 1) == 0
+    # adaptive pooling: no workspace for small maps / odd channel counts; 256x256 tiles (32x32 map, scales 1 2 3 6): 8 + 4*2 + 9 + 36 slots
+    sc = (ctypes.c_int * 4)(1, 2, 3, 6)
+    scp = ctypes.cast(sc, ctypes.c_void_p)
+    assert L.query("emrt_adaptive_avgpool_workspace_bytes", 16, 16, 8, 256, scp, 4) == 0
+    assert L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 250, scp, 4) == 0
+    assert L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 256, scp, 4) == 8 * (9 + 4 * 3 + 9 * 2 + 36) * 256 * 4
+    assert L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 256, None, 4) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

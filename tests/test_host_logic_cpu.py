@@ -76,7 +76,14 @@ def test_train_step_launch_sequence(fake, backbone):
     first_opt = min(i for i, (n, a) in enumerate(fake.calls) if n == "emrt_grad_clip_scale")
     assert last_bwd < max(i for i, (n, a) in enumerate(fake.calls) if n == "emrt_conv2d_wgrad_group") < first_opt      # flushed before the optimizer
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
-    assert cnt["emrt_bn_apply"] == cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
+    # five BatchNorm + ReLU layers are applied by their streaming consumer's loads (functional.PendingBN): the stem's and the spatial
+    # branch's two into a max-pool, UpHead's first two into a x2 resize; their backward re-derives the ReLU mask from the raw map
+    n_defer = cnt["emrt_bn_maxpool_fwd"] + cnt["emrt_bn_resize_bilinear_fwd"]
+    assert cnt["emrt_bn_maxpool_fwd"] == 3 and cnt["emrt_bn_resize_bilinear_fwd"] == 2 and cnt["emrt_maxpool_fwd"] == 1
+    masked_x = [a for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[22] is not None]
+    assert len(masked_x) == n_defer and all(a[4] is None and a[20] is None and a[21] == 0 for a in masked_x)
+    assert sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_reduce" and a[12] is not None and a[4] is None) == n_defer
+    assert cnt["emrt_bn_apply"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
     assert not any(n == "emrt_conv2d" and a[22] == 1 for n, a in fake.calls)      # data gradients go through emrt_conv2d_bwd
     dgrads = [a for n, a in fake.calls if n == "emrt_conv2d_bwd"]
