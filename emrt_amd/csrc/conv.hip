@@ -16,6 +16,7 @@
 //   MODE 1 (dgrad): pix = ((oh + pad - kh)/stride, (ow + pad - kw)/stride) when divisible
 // wgrad: dW[oc][tap*C + c] += sum_m dy[m][oc] * x[pix(m,tap)][c]   (fp32 atomics, split over m)
 #include "common.hpp"
+#include "bn_operand.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1217,6 +1218,7 @@ struct ThinBwdArgs {
   int HW, C, OC, ldx, lddy, lddx, ldy, accumulate, pix_per_block, cg_shift;
   float mask_scale;
   long long x_bs, dy_bs, dx_bs, y_bs, M;
+  const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;      // BNX: x is the RAW map, the layer's input is relu(BN(x))
 };
 
 // MASK: 0 no ReLU mask, 1 the mask source is x itself (y = relu(bn(.)) feeds this conv), 2 a separate tensor.  ACC: dx +=.
@@ -1228,7 +1230,9 @@ struct VecN<T, 4> : Vec4<T> {};
 template <class T>
 struct VecN<T, 8> : Vec8<T> {};
 
-template <class T, int CH, int MASK, bool ACC>
+// BNX (with MASK == 1): x is the raw pre-BatchNorm map and the conv's input a = relu(x * scale + shift) is re-derived per element as it is
+// loaded (bn_operand.hpp; the forward was emrt_bn_pointwise_fwd, the normalised map was never written): a feeds dW, the mask and the sums.
+template <class T, int CH, int MASK, bool ACC, bool BNX = false>
 __global__ __launch_bounds__(256, CH == 4 ? 4 : 2) void thin_bwd_kernel(ThinBwdArgs p) {
   constexpr int U = 2;              // pixels in flight per thread
   using V = VecN<T, CH>;
@@ -1260,6 +1264,11 @@ __global__ __launch_bounds__(256, CH == 4 ? 4 : 2) void thin_bwd_kernel(ThinBwdA
   }
 #pragma unroll
   for (int j = 0; j < CH; ++j) { ss[j] = 0.f; sq[j] = 0.f; }
+  float bsc[BNX ? CH : 1], bsh[BNX ? CH : 1];
+  if (BNX) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) bn_scale_shift(p.bn_mean[c0 + j], p.bn_invstd[c0 + j], p.bn_gamma[c0 + j], p.bn_beta[c0 + j], bsc[j], bsh[j]);
+  }
   // 32-bit element offsets throughout (thin_bwd_ok checks that every operand stays below 2^31 elements)
   const int xbs = (int)p.x_bs, dybs = (int)p.dy_bs, dxbs = (int)p.dx_bs, ybs = (int)p.y_bs, M = (int)p.M;
   const int m0 = (int)blockIdx.x * p.pix_per_block;
@@ -1289,6 +1298,10 @@ __global__ __launch_bounds__(256, CH == 4 ? 4 : 2) void thin_bwd_kernel(ThinBwdA
 #pragma unroll
       for (int o = 0; o < 8; ++o) dyv[o] = __shfl(mydy[u], gbase + o, 64);     // executed by every lane (0 for the dead tail)
       if (!ok[u]) continue;
+      if (BNX) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) xv[u][j] = fmaxf(fmaf(xv[u][j], bsc[j], bsh[j]), 0.f);
+      }
       float v[CH];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
@@ -1378,7 +1391,7 @@ static bool thin_bwd_ok(const ConvArgs& d, const WgradArgs& w) {
 }
 
 template <class T, int CH>
-static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t st) {
+static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t st, const float* const* xbn = nullptr) {
   ThinBwdArgs a;
   a.x = w.x; a.dy = w.dy; a.wd = d.w; a.dx = d.out; a.dw = w.dw; a.dbias = w.dbias; a.stats = d.stats; a.mask_y = d.mask_y;
   a.HW = w.H * w.W; a.C = w.C; a.OC = w.OC; a.ldx = w.ldx; a.lddy = w.lddy; a.lddx = d.ldout; a.ldy = d.ldy;
@@ -1408,6 +1421,13 @@ static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t
   const bool same = d.mask_y && d.mask_y == w.x && d.ldy == w.ldx && d.y_bs == w.x_bs;
   const int mask = !d.mask_y ? 0 : (same ? 1 : 2);
   const dim3 grid((unsigned)blocks, (unsigned)cchunks), block(256);
+  a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
+  if (xbn) {
+    if (mask != 1 || a.accumulate) return fail("emrt_bn_pointwise_bwd", "internal: the BatchNorm-operand form is the mask-from-input, overwrite form");
+    a.bn_mean = xbn[0]; a.bn_invstd = xbn[1]; a.bn_gamma = xbn[2]; a.bn_beta = xbn[3];
+    hipLaunchKernelGGL((thin_bwd_kernel<T, CH, 1, false, true>), grid, block, 0, st, a);
+    return check_launch("emrt_bn_pointwise_bwd");
+  }
   if (a.accumulate) {      // (the C-ABI excludes accumulate together with a mask)
     hipLaunchKernelGGL((thin_bwd_kernel<T, CH, 0, true>), grid, block, 0, st, a);
   } else if (mask == 0) {
@@ -1421,13 +1441,133 @@ static int thin_bwd_launch_ch(const ConvArgs& d, const WgradArgs& w, hipStream_t
 }
 
 template <class T>
-static int thin_bwd_launch(const ConvArgs& d, const WgradArgs& w, hipStream_t st) {
+static int thin_bwd_launch(const ConvArgs& d, const WgradArgs& w, hipStream_t st, const float* const* xbn = nullptr) {
   const int want = g_tune.thin_ch;            // developer knob (default 8)
   constexpr int EPC = 16 / (int)sizeof(T);
   const bool can8 = w.C >= 64 && w.ldx % 8 == 0 && w.x_bs % 8 == 0 && d.ldout % 8 == 0 && d.out_bs % 8 == 0 &&
                     (!d.mask_y || (d.ldy % 8 == 0 && d.y_bs % 8 == 0)) && EPC <= 8;
-  if (want == 8 && can8) return thin_bwd_launch_ch<T, 8>(d, w, st);
-  return thin_bwd_launch_ch<T, 4>(d, w, st);
+  if (want == 8 && can8) return thin_bwd_launch_ch<T, 8>(d, w, st, xbn);
+  return thin_bwd_launch_ch<T, 4>(d, w, st, xbn);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thin forward with a BatchNorm operand: out[p][o] = bias[o] + sum_c relu(BN(x[p][c])) * w[o][c], OC <= 8 (the classifier behind
+// conv -> SyncBatchNorm -> ReLU, paddle_EMRT.py:176-179).  x is the RAW conv output (67 MB at batch 8 / 256x256 tiles); the separate
+// path reads it, writes the normalised map, and reads that again through a 256x32-tile GEMM (35 + 20 us): here it is read once.
+// VALU kernel (0.4 GFLOP): a pixel is spread over CG = C / 8 lanes (8 channels = one 16-byte load each), a thread works on U = 4 pixels
+// at a time, and the 4 x 8 partial dot products are summed across the CG lanes by a reduce-scatter butterfly (each step hands half of the
+// values to the partner lane: 16 + 8 + 4 + 2 + 1 exchanges instead of 32 x 5), after which lane i of the group owns value i.
+// ------------------------------------------------------------------------------------------------
+struct ThinFwdArgs {
+  const void* x; const void* w; const float* bias; void* out;
+  int HW, C, OC, ldx, ldo;
+  long long x_bs, o_bs, M;
+};
+
+// eight elements as they come from memory (16 B of bf16 / 32 B of fp32), unpacked where they are used: the prefetched pixels stay packed
+template <class T>
+struct Raw8;
+template <>
+struct Raw8<bf16_t> {
+  uint4 q;
+  __device__ __forceinline__ void load(const bf16_t* p) { q = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float (&o)[8]) const { Vec8<bf16_t>::unpack(q, o); }
+};
+template <>
+struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void unpack(float (&o)[8]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
+template <class T, int CGS>
+__global__ __launch_bounds__(256, 2) void thin_fwd_bn_kernel(ThinFwdArgs p, BnOperand bn) {
+  constexpr int CH = 8, U = 4;
+  extern __shared__ float bn_lds[];          // [2][C]: scale, shift
+  const T* x = (const T*)p.x;
+  const T* wp = (const T*)p.w;
+  T* out = (T*)p.out;
+  const int tid = threadIdx.x;
+  constexpr int CG = 1 << CGS, ppb = 256 >> CGS;          // 8 <= CG <= 32: a lane group lies inside one wave
+  const int cg = tid & (CG - 1), pl = tid >> CGS;
+  const int c0 = cg * CH;
+  // 32-bit element offsets throughout (the host checks that every operand stays below 2^31 elements)
+  const int M = (int)p.M, HW = p.HW, xbs = (int)p.x_bs, obs = (int)p.o_bs;
+  const int step = (int)gridDim.x * ppb * U;
+  int mb = (int)blockIdx.x * ppb * U + pl;
+  auto xoff = [&](int m) {
+    const int mc = m < M ? m : 0;          // (a dead tail pixel reads pixel 0 and is zeroed below)
+    const int nb = mc / HW;
+    return nb * xbs + (mc - nb * HW) * p.ldx + c0;
+  };
+  // first group's loads before the per-channel preamble
+  Raw8<T> xv[U], xn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) xv[u].load(x + xoff(mb + u * ppb));
+  bn_operand_preamble(bn, p.C, bn_lds, blockIdx.x == 0);
+  float sc[CH], sh[CH], w[8][CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { sc[j] = bn_lds[c0 + j]; sh[j] = bn_lds[p.C + c0 + j]; }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float wv[CH];
+    Vec8<T>::load(wp + ((o < p.OC ? o : 0) * p.C + c0), wv);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) w[o][j] = o < p.OC ? wv[j] : 0.f;
+  }
+  const float lo = bn.relu ? 0.f : -INFINITY;
+  while (mb - pl < M) {          // (uniform per block: every lane takes part in the exchanges)
+    const int mnext = mb + step;
+#pragma unroll
+    for (int u = 0; u < U; ++u) xn[u].load(x + xoff(mnext + u * ppb));
+    float part[U * 8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = mb + u * ppb < M;
+      float a[CH];
+      xv[u].unpack(a);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] = ok ? fmaxf(fmaf(a[j], sc[j], sh[j]), lo) : 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) t = fmaf(a[j], w[o][j], t);
+        part[u * 8 + o] = t;
+      }
+    }
+    // reduce-scatter over the CG lanes of the group: at the step with distance d a lane keeps the half of its values selected by its
+    // bit d and adds the partner's copy of that half; n values -> n / 2.  CG = 32: 32 -> 16 -> 8 -> 4 -> 2 -> 1.
+#pragma unroll
+    for (int k = 0; k < CGS; ++k) {
+      const int n = (U * 8 / 2) >> k, d = (CG / 2) >> k;      // compile-time after unrolling
+      const bool hi = (cg & d) != 0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        // (the empty asm keeps the two elements values: without it the optimizer folds the selects into ONE element read with a
+        // lane-dependent index, i.e. a 32-way compare / select chain per value -- 1920 of them, 147 us instead of 20)
+        float lo_v = part[i], hi_v = part[n + i];
+        asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+        const float keep = hi ? hi_v : lo_v;
+        const float send = hi ? lo_v : hi_v;
+        part[i] = keep + __shfl_xor(send, d, 64);
+      }
+    }
+    // bit d of cg selected the upper half (offset + n) at the step with distance d, so the lane now owns indices [cg * nleft, + nleft)
+    constexpr int nleft = (U * 8) / CG;          // 1, 2 or 4 values per lane
+#pragma unroll
+    for (int i = 0; i < nleft; ++i) {
+      const int idx = cg * nleft + i, u = idx >> 3, o = idx & 7;
+      const int m = mb + u * ppb;
+      if (o < p.OC && m < M) {
+        const int nb = m / HW;
+        out[nb * obs + (m - nb * HW) * p.ldo + o] = from_f32<T>(part[i] + (p.bias ? p.bias[o] : 0.f));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = xn[u];
+    mb = mnext;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1476,6 +1616,80 @@ static int conv_bwd_dispatch(const ConvArgs& d, const WgradArgs& w0, hipStream_t
   if (rc) return rc;
   return conv_dispatch<T, 1>(d, st);
 }
+
+// ---- the classifier behind conv -> SyncBatchNorm -> ReLU with the BatchNorm applied by its loads (ABI 6) --------------------------
+// forward: out[N][HW][OC] = bias + relu(BN_train(x)) . w^T, x the RAW map [N][HW][C] of the producing conv, w the forward-packed [OC][C]
+// weight (a 1x1 conv / linear), OC <= 8, C in {64, 128, 256} (C / 8 lanes per pixel inside one wave).  BatchNorm arguments as
+// emrt_bn_apply (sums complete; mean / invstd saved; running statistics updated).
+extern "C" int emrt_bn_pointwise_fwd(const void* x, int ldx, long long x_bs, const void* w_packed, const float* bias, void* out, int ldo,
+                                     long long o_bs, int N, int HW, int C, int OC, const double* sums, double count, float eps,
+                                     float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                                     const float* beta, int relu, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(x && w_packed && out && sums && mean && invstd && gamma && beta, "null pointer");
+  EMRT_REQUIRE(N > 0 && HW > 0 && OC >= 1 && OC <= 8 && (C == 64 || C == 128 || C == 256), "OC <= 8 and C in {64, 128, 256}");
+  EMRT_REQUIRE(count > 0.0 && (run_mean != nullptr) == (run_var != nullptr), "bad BatchNorm operand");
+  {
+    const long long LIM = 1ll << 31, px = (long long)HW - 1;
+    EMRT_REQUIRE((long long)N * HW + 8192ll * 128 < LIM && (N - 1) * x_bs + px * ldx + C < LIM && (N - 1) * o_bs + px * ldo + OC < LIM,
+                 "operand spans 2^31 elements or more (32-bit offsets)");
+  }
+  const int esz = dtype == EMRT_F32 ? 4 : 2;
+  EMRT_REQUIRE(ldx % 8 == 0 && x_bs % 8 == 0 && ((uintptr_t)x % (8 * esz) == 0) && ((uintptr_t)w_packed % (8 * esz) == 0), "x rows and the weight must be 8-element aligned");
+  ThinFwdArgs a;
+  a.x = x; a.w = w_packed; a.bias = bias; a.out = out; a.HW = HW; a.C = C; a.OC = OC; a.ldx = ldx; a.ldo = ldo; a.x_bs = x_bs; a.o_bs = o_bs;
+  a.M = (long long)N * HW;
+  BnOperand b;
+  b.sums = sums; b.inv_count = 1.0 / count; b.eps = eps; b.momentum = momentum; b.mean = mean; b.invstd = invstd; b.run_mean = run_mean;
+  b.run_var = run_var; b.gamma = gamma; b.beta = beta; b.relu = relu;
+  const int cgs = C == 256 ? 5 : (C == 128 ? 4 : 3);
+  const long long per_iter = (long long)(256 >> cgs) * 4;          // pixels one block covers per iteration
+  long long blocks = (a.M + per_iter - 1) / per_iter;
+  const long long cap = g_tune.bn_operand_blocks > 0 ? g_tune.bn_operand_blocks : 1024;
+  if (blocks > cap) blocks = cap;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+#define EMRT_THIN_FWD(TT)                                                                                                     \
+  do {                                                                                                                        \
+    if (cgs == 5) hipLaunchKernelGGL((thin_fwd_bn_kernel<TT, 5>), dim3((unsigned)blocks), dim3(256), lds, st, a, b);           \
+    else if (cgs == 4) hipLaunchKernelGGL((thin_fwd_bn_kernel<TT, 4>), dim3((unsigned)blocks), dim3(256), lds, st, a, b);      \
+    else hipLaunchKernelGGL((thin_fwd_bn_kernel<TT, 3>), dim3((unsigned)blocks), dim3(256), lds, st, a, b);                    \
+  } while (0)
+  if (dtype == EMRT_F32) EMRT_THIN_FWD(float);
+  else EMRT_THIN_FWD(bf16_t);
+#undef EMRT_THIN_FWD
+  return check_launch("emrt_bn_pointwise_fwd");
+}
+
+// backward of the same layer in one pass: da = dy . w masked by a = relu(BN(x)) > 0 (a re-derived from the raw x per element),
+// dW += dy^T . a, dbias += sum dy, and the BatchNorm's backward sums (sum da, sum da * a) into the ZEROED fp64 `stats` [8][2C] -- the form
+// emrt_bn_bwd_dx takes with beta_y_moments.  w_bwd_packed: the [C][OC] weight.  da: dense [N][HW][C].
+extern "C" int emrt_bn_pointwise_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, const void* w_bwd_packed,
+                                     void* da, int ldda, long long da_bs, float* dw, float* dbias, double* stats, int N, int HW, int C, int OC,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(x && dy && w_bwd_packed && da && dw && mean && invstd && gamma && beta, "null pointer");
+  EMRT_REQUIRE(N > 0 && HW > 0 && OC >= 1 && OC <= 8, "OC <= 8");
+  ConvArgs d;
+  memset(&d, 0, sizeof(d));
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  // the data-gradient view: "input" dy [N][HW][OC], "output" da [N][HW][C]
+  d.in = dy; d.w = w_bwd_packed; d.out = da; d.N = N; d.H = 1; d.W = HW; d.C = OC; d.ldin = lddy; d.in_bs = dy_bs;
+  d.OH = 1; d.OW = HW; d.OC = C; d.ldout = ldda; d.out_bs = da_bs; d.KH = d.KW = 1; d.stride = 1; d.pad = 0; d.dil = 1;
+  d.mask_y = x; d.ldy = ldx; d.y_bs = x_bs; d.mask_scale = 1.f; d.stats = stats;
+  w.x = x; w.dy = dy; w.dw = dw; w.dbias = dbias; w.N = N; w.H = 1; w.W = HW; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
+  w.OH = 1; w.OW = HW; w.OC = OC; w.lddy = lddy; w.dy_bs = dy_bs; w.KH = w.KW = 1; w.stride = 1; w.pad = 0; w.dil = 1; w.overwrite = 0;
+  const float* xbn[4] = {mean, invstd, gamma, beta};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) {
+    EMRT_REQUIRE(thin_bwd_ok<float>(d, w), "shape outside the thin kernel (C a power of two in 32..1024, 16-byte aligned rows)");
+    return thin_bwd_launch<float>(d, w, st, xbn);
+  }
+  EMRT_REQUIRE(thin_bwd_ok<bf16_t>(d, w), "shape outside the thin kernel (C a power of two in 32..1024, 16-byte aligned rows)");
+  return thin_bwd_launch<bf16_t>(d, w, st, xbn);
+}
+
 
 extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, void* dx, int lddx, long long dx_bs,
                                int accumulate, float* dw, float* dbias,

@@ -325,6 +325,9 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice).
     out_scale / out_shift (fp32 [OC], inference only): out = conv * out_scale + out_shift -- an eval-mode BatchNorm folded in."""
     c = ctx()
+    if isinstance(x, PendingBN):
+        assert stride == 1 and pad == 0 and not relu and residual is None and out is None and not out_f32 and bn_stats is None and out_scale is None
+        return _pointwise_on_pending(x, w)
     N, H, W, C, ldin, in_bs = _check_map(x)
     assert C == w.C, (C, w.C)
     dil = int(dilation)
@@ -571,13 +574,14 @@ class PendingBN:
         return (P(self.sums), float(self.count), bn.eps, bn.momentum, P(self.mean), P(self.invstd), P(bn.run_mean), P(bn.run_var), P(bn.gamma),
                 P(bn.beta), int(self.relu))
 
-    def backward(self, tape, dy):
-        """dy: gradient of relu(BN(raw)) (dense, unmasked) -> BatchNorm backward (emrt_bn_bwd_reduce + emrt_bn_bwd_dx, mask from raw)"""
+    def backward(self, tape, dy, masked=False):
+        """dy: gradient of relu(BN(raw)), dense; unmasked unless `masked` -> BatchNorm backward (emrt_bn_bwd_reduce + emrt_bn_bwd_dx,
+        the ReLU mask re-derived from raw)"""
         c = ctx()
         bn, M, C = self.bn, self.M, self.C
         _, _, _, _, lddy, dy_bs = _check_map(dy)
         assert dy_bs == (M // self.raw.shape[0]) * lddy
-        mg, mb = (P(bn.gamma), P(bn.beta)) if self.relu else (None, None)
+        mg, mb = (P(bn.gamma), P(bn.beta)) if (self.relu and not masked) else (None, None)
         sums2 = c.zeros_f64(BN_REPLICAS * 2 * C)
         _L().call("emrt_bn_bwd_reduce", P(self.raw), C, P(dy), lddy, None, 0, P(self.mean), P(self.invstd), M, C, P(sums2), mg, mb, c.dtype, c.stream)
         local = None
@@ -589,6 +593,49 @@ class PendingBN:
         _L().call("emrt_bn_bwd_dx", P(self.raw), C, P(dy), lddy, None, 0, P(dx), C, None, C, P(self.mean), P(self.invstd), P(bn.gamma),
                   P(sums2), P(local), float(self.count), P(bn.dgamma), P(bn.dbeta), M, C, None, 0, mb, c.dtype, c.stream)
         tape.add_grad(self.raw, dx, owned=True)
+
+
+def pointwise_takes_pending(w, C):
+    """the thin classifier kernels (emrt_bn_pointwise_fwd / _bwd): a 1x1 conv to at most 8 channels from 64 / 128 / 256"""
+    return w.KH == 1 and w.KW == 1 and w.OC <= 8 and C in (64, 128, 256)
+
+
+def _pointwise_on_pending(pend, w):
+    """out = conv1x1(relu(BN(raw))) with the BatchNorm + ReLU applied by the classifier's own loads (paddle_EMRT.py:176-179: conv_2 ->
+    SyncBatchNorm -> ReLU -> conv_3); backward: one pass gives the masked input gradient, dW, dbias and the BatchNorm's backward sums."""
+    c = ctx()
+    x = pend.raw
+    N, H, W, C, ldin, in_bs = _check_map(x)
+    assert C == w.C and pointwise_takes_pending(w, C) and pend.relu
+    out = c.empty((N, H, W, w.OC))
+    _L().call("emrt_bn_pointwise_fwd", P(x), ldin, in_bs, ctypes.c_void_p(w.fwd_ptr), P(w.bias), P(out), w.OC, H * W * w.OC, N, H * W, C, w.OC,
+              *pend.operand(), c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dy = tape.pop_grad(out)
+            if dy is None:
+                return
+            if dy.dtype != x.dtype:
+                dy = cast_from_f32(dy)
+            _, _, _, _, lddy, dy_bs = _check_map(dy)
+            bn = pend.bn
+            da = c.empty((N, H, W, C))
+            sync = _sync_active(bn)
+            sums2 = None if sync else c.zeros_f64(BN_REPLICAS * 2 * C)
+            w.grad_is_zero = False
+            _L().call("emrt_bn_pointwise_bwd", P(x), ldin, in_bs, P(dy), lddy, dy_bs, ctypes.c_void_p(w.bwd_ptr), P(da), C, H * W * C, P(w.grad),
+                      P(w.bias_grad) if w.bias is not None else None, P(sums2), N, H * W, C, w.OC, P(pend.mean), P(pend.invstd), P(bn.gamma),
+                      P(bn.beta), c.dtype, c.stream)
+            if sync:
+                pend.backward(tape, da, masked=True)      # SyncBatchNorm over ranks: the sums go through the reduce -> all-reduce path
+                return
+            dx = c.empty((N, H, W, C))
+            _L().call("emrt_bn_bwd_dx", P(x), C, P(da), C, None, 0, P(dx), C, None, C, P(pend.mean), P(pend.invstd), P(bn.gamma), P(sums2), None,
+                      float(pend.count), P(bn.dgamma), P(bn.dbeta), pend.M, C, P(bn.beta), 0, None, c.dtype, c.stream)
+            tape.add_grad(x, dx, owned=True)
+        tape.record(bwd)
+    return out
 
 
 def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):

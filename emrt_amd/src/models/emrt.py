@@ -609,7 +609,8 @@ class UpHead(hnn.HipLayer):  # :115-181 (num_conv == 3)
         x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
         x = Fn.conv_bn(self.conv_1, self.syncbn_fc_1, x, relu=True, defer=True)
         x = Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False)
-        x = Fn.conv_bn(self.conv_2, self.syncbn_fc_2, x, relu=True)
+        # (the classifier's loads apply the last BatchNorm + ReLU when it is one of the thin shapes: <= 8 classes)
+        x = Fn.conv_bn(self.conv_2, self.syncbn_fc_2, x, relu=True, defer=Fn.pointwise_takes_pending(self.conv_3.gw, 256))
         x = self.conv_3(x)
         return Fn.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], False, out_nchw_f32=True)
 

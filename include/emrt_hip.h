@@ -124,6 +124,13 @@ int emrt_bn_fold(const float* params, const float* buffers, const long long* des
  * mask is re-derived from x with the forward's own expression, relu'(x * invstd * gamma + (beta - mean * invstd * gamma)). */
 int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, const float* mean, const float* invstd, long long M, int C, double* sums, const float* mask_gamma, const float* mask_beta, int dtype, void* stream);
 int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, const void* y, int ldy, void* dx, int lddx, void* dres, int lddres, const float* mean, const float* invstd, const float* gamma, const double* sums, const double* local_sums, double count, float* dgamma, float* dbeta, long long M, int C, const float* beta_y_moments, int sums_vs_x, const float* mask_beta, int dtype, void* stream);
+/* ABI 6: the classifier behind conv -> SyncBatchNorm -> ReLU (paddle_EMRT.py:176-179) with the BatchNorm + ReLU applied by its own loads.
+ * fwd: out[N][HW][OC] = bias + relu(BatchNorm_train(x)) . w^T; x the RAW map of the producing conv (row stride ldx, image stride x_bs),
+ * w_packed the forward-packed [OC][C] weight of a 1x1 conv / linear, OC <= 8, C in {64, 128, 256}; BatchNorm arguments as emrt_bn_apply.
+ * bwd (one pass): da = (dy . w) masked by relu(BN(x)) > 0 (dense [N][HW][C]), dW += dy^T . relu(BN(x)), dbias += sum dy (nullable), and
+ * `stats` (nullable, ZEROED fp64 [8][2C]) += (sum da, sum da * relu(BN(x))): the sums emrt_bn_bwd_dx takes with beta_y_moments. */
+int emrt_bn_pointwise_fwd(const void* x, int ldx, long long x_bs, const void* w_packed, const float* bias, void* out, int ldo, long long o_bs, int N, int HW, int C, int OC, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int relu, int dtype, void* stream);
+int emrt_bn_pointwise_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, const void* w_bwd_packed, void* da, int ldda, long long da_bs, float* dw, float* dbias, double* stats, int N, int HW, int C, int OC, const float* mean, const float* invstd, const float* gamma, const float* beta, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
 

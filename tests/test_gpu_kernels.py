@@ -1138,3 +1138,74 @@ def test_batchnorm_relu_applied_by_the_consumers_loads(dtype, consumer, case):
     var = y.detach().var(dim=(0, 2, 3), unbiased=False)
     close("deferred run_mean", rm, 0.1 * mean, F32, atol=2e-3 if dtype == BF16 else 1e-4)
     close("deferred run_var", rv, 0.9 + 0.1 * var, F32, atol=5e-3 if dtype == BF16 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 6, True), (3, 9, 13, 32, 128, 8, False), (1, 20, 20, 32, 64, 3, True), (2, 33, 17, 64, 256, 2, True)])
+def test_batchnorm_relu_applied_by_the_classifiers_loads(dtype, case):
+    """conv3x3 -> BatchNorm(train) -> ReLU -> conv1x1 to <= 8 channels (paddle_EMRT.py:176-179) with the BatchNorm deferred into the
+    classifier (emrt_bn_pointwise_fwd / _bwd): no emrt_bn_apply, no normalised map, logits and every gradient against torch and against
+    the separate path."""
+    from emrt_amd import _lib
+    N, H, W, Cin, C, OC, bias = case
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    wt = torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    w2 = torch.randn(OC, C, 1, 1, generator=g) / math.sqrt(C)
+    b2 = torch.randn(OC, generator=g) * 0.1
+    gam = torch.rand(C, generator=g) + 0.5
+    gam[::4] *= -1.0
+    bet = torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(N, OC, H, W, generator=g)
+
+    def run(defer):
+        c = init(dtype)
+        c.bn_defer = defer
+        conv, bn, cls = hnn.Conv2D(Cin, C, 3, 1, 1, bias=False), hnn.BatchNorm2D(C), hnn.Conv2D(C, OC, 1, bias=bias)
+        with torch.no_grad():
+            conv.weight.copy_(rnd(wt))
+            bn.weight.copy_(gam)
+            bn.bias.copy_(bet)
+            cls.weight.copy_(rnd(w2))
+            if bias:
+                cls.bias.copy_(b2)
+        Holder(conv=conv, bn=bn, cls=cls).place()
+        xd = dev_map(rnd(x))
+        tape = Tape()
+        c.tape = tape
+        L = _lib.lib()
+        L.start_record()
+        a = Fn.conv_bn(conv, bn, xd, relu=True, defer=Fn.pointwise_takes_pending(cls.gw, C))
+        out = cls(a)
+        c.tape = None
+        tape.watch(xd)
+        dx, = run_bwd(tape, [(out, dev_map(rnd(dy)))], [xd])
+        names = [n for n, _ in L.stop_record()]
+        torch.cuda.synchronize()
+        c.bn_defer = True
+        return (names, host_map(out), host_map(dx), host(conv.weight.grad), host(bn.weight.grad), host(bn.bias.grad), host(cls.weight.grad),
+                host(cls.bias.grad) if bias else None, host(bn._buffers["_mean"]), host(bn._buffers["_variance"]))
+
+    names, out, dx, dw, dgam, dbet, dw2, db2, rm, rv = run(True)
+    names0, out0, dx0, dw0, dgam0, dbet0, dw20, db20, rm0, rv0 = run(False)
+    assert "emrt_bn_apply" not in names and "emrt_bn_pointwise_fwd" in names and "emrt_bn_pointwise_bwd" in names
+    assert "emrt_bn_bwd_reduce" not in names and names0.count("emrt_bn_apply") == 1
+    xr, wr, w2r = rnd(x).clone().requires_grad_(True), rnd(wt).clone().requires_grad_(True), rnd(w2).clone().requires_grad_(True)
+    b2r = b2.clone().requires_grad_(True)
+    gr, br_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, padding=1)
+    o = F.conv2d(F.relu(F.batch_norm(y, None, None, gr, br_, True, 0.1, 1e-5)), w2r, b2r if bias else None)
+    o.backward(rnd(dy))
+    close("classifier fwd", out, o.detach(), dtype)
+    assert torch.equal(rm, rm0) and torch.equal(rv, rv0)
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+    errs = {"dx": rel(dx, xr.grad), "dw": rel(dw, wr.grad), "dgamma": rel(dgam, gr.grad), "dbeta": rel(dbet, br_.grad), "dw2": rel(dw2, w2r.grad),
+            "out/sep": rel(out, out0), "dx/sep": rel(dx, dx0), "dw/sep": rel(dw, dw0), "dgamma/sep": rel(dgam, dgam0), "dbeta/sep": rel(dbet, dbet0),
+            "dw2/sep": rel(dw2, dw20)}
+    if bias:
+        errs["db2"] = rel(db2, b2r.grad)
+    print("deferred classifier relative errors:", {k: "%.2e" % v for k, v in errs.items()})
+    tol = 2e-5 if dtype == F32 else 3e-2
+    assert all(v < tol for v in errs.values()), errs
