@@ -56,7 +56,7 @@ struct Tuning {
   int msda_fwd_probe;   // timing experiments only (results are WRONG): forward 1 = no gather, 2 = no staging, 4 = no preparation;
                         // value-gradient scatter 16 = no |g| scan, 32 = no sample loop (tools/exp/probe_msda_*.sh)
   int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
-  int bn_operand_blocks; // kernels that apply BatchNorm to their input operand (bn_operand.hpp): most blocks per launch (0 = 2048)
+  int bn_operand_blocks; // kernels that apply BatchNorm to their input operand (bn_operand.hpp): most blocks per launch (0 = 1024; the classifier kernel 512)
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
   int gn_group_blocks;  // 1 = multi-level GroupNorm with one block per (image, group) instead of the row-major stats + apply pair
   int gn_stat_rows;     // row-major GroupNorm: token rows per block of the forward statistics launch (32)
@@ -70,6 +70,7 @@ struct Tuning {
   int wgrad8p_slab;       // 1 (default): partial tiles through the registered scratch + a reduce launch; 0: fp32 atomics into dW
   int wgrad8p_xcd;        // 1 (default): slices of the pixel reduction pinned to XCDs (shared L2); 0: launch order (A/B knob)
   int wgrad8p_force;      // tests: 1 = take the 256x256 kernel whenever the shape allows, whatever the grid size
+  int no_ksplit128;     // 1 = never the 128x128 tile with two wave groups splitting K (A/B knob)
   int wgrad_no_overwrite; // 1 = weight gradients always accumulate with atomics, even into a dW the caller declared zero (A/B knob)
   int no_s2_dgrad;        // 1 = stride-2 data gradients through the generic kernels (A/B knob; tests compare the two bit for bit); -1 = the parity-class kernel for 1x1 kernels too
   int wgroup_blocks;      // batched weight gradients (emrt_conv2d_wgrad_group): blocks a launch aims for (1024 = 4 per CU)

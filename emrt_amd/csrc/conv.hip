@@ -1029,6 +1029,7 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
       case 5: if constexpr (VEC) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 2>(a, st); break;
       case 6: if constexpr (VEC) return launch_igemm<T, 1, 1, 2, 2, MODE, VEC, 4>(a, st); break;
       case 7: if constexpr (VEC && sizeof(T) == 2) { if (igemm8p_ok<T>(a)) return launch_igemm8p<T, MODE>(a, st); } break;
+      case 8: if constexpr (VEC && sizeof(T) == 2) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC, 2>(a, st); break;      // 128x128, K split over two wave groups
       default: break;
     }
   }
@@ -1046,6 +1047,12 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
   // prologue / epilogue (>= 16 k-tiles) and there is at least one block per CU; everything else is fastest on 64x64
   constexpr int BK = 8 * (16 / (int)sizeof(T));
   const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
+  if constexpr (VEC && sizeof(T) == 2) {
+    // exactly one 128x128 block per CU and a long k loop: a second wave group walking the other half of the k-tiles (147 KB of LDS) keeps
+    // the MFMA pipe fed where 4 waves per CU cannot (measured: the decoder's 32x32x1536 -> 512 3x3 forward 158 -> 138 us, 32x32x512 -> 256 data
+    // gradient 35.8 -> 32.2; with two rounds of blocks -- 512 at 64x64x256 -> 256 -- the plain tile wins 51 vs 63)
+    if (a.OC > 64 && nkt >= 32 && blocks(128, 128) == 256 && !g_tune.no_ksplit128) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC, 2>(a, st);
+  }
   if (a.OC > 64 && nkt >= 16 && blocks(128, 128) >= 256) return launch_igemm<T, 2, 2, 2, 2, MODE, VEC>(a, st);
   if constexpr (VEC) {
     // at most one 64x64 block per CU and a long k loop: split K inside the block (see igemm_kernel; thresholds measured)
@@ -1645,7 +1652,9 @@ extern "C" int emrt_bn_pointwise_fwd(const void* x, int ldx, long long x_bs, con
   const int cgs = C == 256 ? 5 : (C == 128 ? 4 : 3);
   const long long per_iter = (long long)(256 >> cgs) * 4;          // pixels one block covers per iteration
   long long blocks = (a.M + per_iter - 1) / per_iter;
-  const long long cap = g_tune.bn_operand_blocks > 0 ? g_tune.bn_operand_blocks : 1024;
+  // 256 registers: two blocks per CU are resident, so 512 blocks are one round and every block pays the per-channel preamble once
+  // (measured on 8 x 128 x 128 x 256 -> 6: 512 blocks 28 us, 1024 31 us, 4096 41 us)
+  const long long cap = g_tune.bn_operand_blocks > 0 ? g_tune.bn_operand_blocks : 512;
   if (blocks > cap) blocks = cap;
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)2 * C * sizeof(float);

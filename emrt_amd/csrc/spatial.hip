@@ -800,7 +800,7 @@ extern "C" int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_
 // long-lived blocks (4 per CU), the element loop is grid-strided
 static inline int bn_operand_grid(long long total) {
   const int g = ew_grid(total);
-  const int cap = g_tune.bn_operand_blocks > 0 ? g_tune.bn_operand_blocks : 2048;
+  const int cap = g_tune.bn_operand_blocks > 0 ? g_tune.bn_operand_blocks : 1024;      // (measured: 1024 <= 2048 < 4096 on the step's five maps)
   return g > cap ? cap : g;
 }
 

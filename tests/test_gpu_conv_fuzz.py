@@ -62,8 +62,9 @@ def test_conv_random_geometry_default_dispatch(case):
     _conv_case_vs_torch(case, dilation=case[10])
 
 
-# conv_tile: 1 = 64x64, 3 = 128x128, 4 = 128x32 (thin OC), 5 / 6 = in-block K split by 2 / 4, 7 = 256x256 LDS-DMA 8-phase (C % 64 == 0)
-@pytest.mark.parametrize("tile", [1, 3, 4, 5, 6, 7])
+# conv_tile: 1 = 64x64, 3 = 128x128, 4 = 128x32 (thin OC), 5 / 6 = in-block K split by 2 / 4, 7 = 256x256 LDS-DMA 8-phase (C % 64 == 0),
+# 8 = 128x128 with K split over two wave groups
+@pytest.mark.parametrize("tile", [1, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("case", BIG, ids=[c[0] for c in BIG])
 def test_conv_random_geometry_forced_tiles(case, tile):
     L_ = _lib.lib()

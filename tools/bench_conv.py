@@ -39,6 +39,9 @@ SHAPES = [  # N, H, W, C, OC, k, stride, pad
     (8, 128, 128, 64, 64, 3, 1, 1),
     (8, 128, 128, 256, 256, 3, 1, 1),
     (8, 32, 32, 1536, 512, 3, 1, 1),
+    (8, 32, 32, 512, 256, 3, 1, 1),
+    (8, 16, 16, 1024, 256, 3, 1, 1),
+    (8, 16, 16, 512, 512, 3, 1, 1),
 ]
 
 
@@ -296,11 +299,11 @@ def main():
         if which in ("all", "conv"):
             for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
                 res = []
-                for tile in (0, 1, 5, 6, 3):
+                for tile in (0, 1, 5, 6, 3, 8):
                     L.set_tuning("conv_tile", tile)
                     res.append(timed(fn))
                 L.set_tuning("conv_tile", 0)
-                line += " %s auto %.1f 64x64 %.1f ksplit2 %.1f ksplit4 %.1f 128x128 %.1f |" % (name, *res)
+                line += " %s auto %.1f 64x64 %.1f ksplit2 %.1f ksplit4 %.1f 128x128 %.1f 128x128-ksplit2 %.1f |" % (name, *res)
         if which in ("all", "wgrad"):
             res = []
             for sp in (0, 1, 2, 4, 8, 16, 32):
