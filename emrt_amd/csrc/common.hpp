@@ -57,6 +57,8 @@ struct Tuning {
                         // value-gradient scatter 16 = no |g| scan, 32 = no sample loop (tools/exp/probe_msda_*.sh)
   int bn_block_kb;      // BatchNorm streaming kernels: KB of input per block (8)
   int bn_operand_blocks; // kernels that apply BatchNorm to their input operand (bn_operand.hpp): most blocks per launch (0 = 1024; the classifier kernel 512)
+  int ln_bwd_rows;      // LayerNorm backward: rows per block (0 = 32) and most blocks (0 = 512): every block ends with 2C fp32 atomics
+  int ln_bwd_max_blocks;
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
   int gn_group_blocks;  // 1 = multi-level GroupNorm with one block per (image, group) instead of the row-major stats + apply pair
   int gn_stat_rows;     // row-major GroupNorm: token rows per block of the forward statistics launch (32)

@@ -1437,8 +1437,10 @@ extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post
 
 // blocks of the LayerNorm backward: ~32 rows (8 per wave) each, at most 512 partial-sum rows for the finalize
 static inline long long ln_bwd_blocks(long long rows) {
-  long long blocks = (rows + 31) / 32;
-  if (blocks > 512) blocks = 512;
+  const int per = g_tune.ln_bwd_rows > 0 ? g_tune.ln_bwd_rows : 32;
+  const int cap = g_tune.ln_bwd_max_blocks > 0 ? g_tune.ln_bwd_max_blocks : 512;
+  long long blocks = (rows + per - 1) / per;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return blocks;
 }
