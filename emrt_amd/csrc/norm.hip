@@ -179,7 +179,11 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
                                                        float eps, float momentum, float* __restrict__ mean_out,
                                                        float* __restrict__ invstd_out, float* __restrict__ run_mean,
                                                        float* __restrict__ run_var, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, long long M, int C, int relu, int rows_per_pass) {
+                                                       const float* __restrict__ beta, long long M, int C, int relu, int rows_per_pass,
+                                                       BnOperand rbn) {
+  // rbn.sums != null: `res` is the RAW output of the shortcut's conv and its own training-mode BatchNorm (no ReLU) is applied as it is
+  // loaded -- out = relu(BN(x) + BN_shortcut(res)), the first block of a ResNet stage (paddle_vision_resnet.py:132-147, 226-233) -- instead
+  // of a separate launch that writes the normalised shortcut for this one to read back
   const int quads = C / 4;
   const int c = (threadIdx.x % quads) * 4;
   const int lane_row = threadIdx.x / quads;
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
     if (res) Vec4<T>::load(res + r * ldres + c, w);
   }
   // per-channel scale/shift computed cooperatively (one channel per thread) and shared through LDS
-  extern __shared__ float bn_lds[];          // [2][C]
+  extern __shared__ float bn_lds[];          // [2][C] (+ [2][C] for the shortcut's BatchNorm)
+  if (rbn.sums) bn_operand_preamble(rbn, C, bn_lds + 2 * C, blockIdx.x == 0);      // (its barrier is harmless here)
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const BnChan k = bn_chan(sums, run_mean, run_var, C, ch, inv_count, eps);
     float scale, shift;
@@ -213,9 +218,13 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  float sc[4], sh[4];
+  float sc[4], sh[4], rsc[4], rsh[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e]; }
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e];
+    rsc[e] = rbn.sums ? bn_lds[2 * C + c + e] : 1.f;
+    rsh[e] = rbn.sums ? bn_lds[3 * C + c + e] : 0.f;
+  }
   while (r < M) {
     const long long rn = r + rstep;
     float vn[4], wn[4], o[4];
@@ -226,8 +235,14 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], sc[e], sh[e]);
     if (res) {
+      if (rbn.sums) {
+        // the separate path stores the normalised shortcut in T before adding it: round the same way so both paths give the same bits
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += w[e];
+        for (int e = 0; e < 4; ++e) o[e] += to_f32(from_f32<T>(fmaf(w[e], rsc[e], rsh[e])));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += w[e];
+      }
     }
     if (relu) {
 #pragma unroll
@@ -1231,11 +1246,41 @@ extern "C" int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres,
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
   const double inv_count = sums ? 1.0 / count : 0.0;
+  BnOperand none;
+  memset(&none, 0, sizeof(none));
   DT_SWITCH3(dtype,
-            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
-            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp),
-            hipLaunchKernelGGL((bn_apply_kernel<f16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const f16_t*)x, ldx, (const f16_t*)res, ldres, (f16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp));
+            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)res, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, none),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, none),
+            hipLaunchKernelGGL((bn_apply_kernel<f16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const f16_t*)x, ldx, (const f16_t*)res, ldres, (f16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, none));
   return check_launch("emrt_bn_apply");
+}
+
+// out = [relu](BN_train(x) + BN_train(res_raw)): the join at the end of the FIRST block of a ResNet stage, where the shortcut is
+// conv1x1 -> BatchNorm (no ReLU; paddle_vision_resnet.py:132-147, 226-233), with the shortcut's BatchNorm applied as its raw conv output is
+// loaded.  Both BatchNorms take their arguments as emrt_bn_apply does (r_*: the shortcut's); both save mean / invstd and update their
+// running statistics.  The normalised shortcut is rounded to the storage type before the add, so the result equals the two-launch path's.
+extern "C" int emrt_bn_apply_join(const void* x, int ldx, const void* res_raw, int ldres, void* y, int ldy, const double* sums, double count,
+                                  float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                                  const float* beta, const double* r_sums, double r_count, float r_eps, float r_momentum, float* r_mean,
+                                  float* r_invstd, float* r_run_mean, float* r_run_var, const float* r_gamma, const float* r_beta, long long M,
+                                  int C, int relu, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(x && res_raw && y && gamma && beta && sums && mean && invstd, "null pointer");
+  EMRT_REQUIRE(r_sums && r_mean && r_invstd && r_gamma && r_beta && r_count > 0.0 && count > 0.0 && (r_run_mean != nullptr) == (r_run_var != nullptr),
+               "the shortcut's BatchNorm needs sums, mean, invstd, gamma, beta and a positive count");
+  EMRT_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldres % 4 == 0, "C and ld must be multiples of 4");
+  int threads, rpp, grid;
+  EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
+  BnOperand r;
+  r.sums = r_sums; r.inv_count = 1.0 / r_count; r.eps = r_eps; r.momentum = r_momentum; r.mean = r_mean; r.invstd = r_invstd;
+  r.run_mean = r_run_mean; r.run_var = r_run_var; r.gamma = r_gamma; r.beta = r_beta; r.relu = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const double inv_count = 1.0 / count;
+  const size_t lds = (size_t)4 * C * sizeof(float);
+  DT_SWITCH(dtype,
+            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), lds, st, (const float*)x, ldx, (const float*)res_raw, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, r),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), lds, st, (const bf16_t*)x, ldx, (const bf16_t*)res_raw, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, r));
+  return check_launch("emrt_bn_apply_join");
 }
 
 // Eval-mode BatchNorm as a per-channel affine map, for every BatchNorm of a model in one launch: block i handles row i of

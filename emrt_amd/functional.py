@@ -486,6 +486,11 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
     _, _, _, _, ldy, y_bs = _check_map(out)
     assert y_bs == H * W * ldy
     ldres = 0
+    res_pend = None
+    if isinstance(residual, PendingBN):
+        # the shortcut's conv -> BatchNorm (no ReLU), not applied yet: this join applies it as it loads the raw map (emrt_bn_apply_join)
+        res_pend, residual = residual, residual.raw
+        assert c.training and not res_pend.relu and res_pend.C == C and res_pend.M == M
     if residual is not None:
         _, _, _, _, ldres, r_bs = _check_map(residual)
         assert r_bs == H * W * ldres
@@ -499,8 +504,14 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
             _L().call("emrt_bn_stats", P(x), ldx, M, C, P(sums), c.dtype, c.stream)
         if _sync_active(bn):
             count = _allreduce_sums(sums, M)
-        _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd),
-                  P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
+        if res_pend is not None:
+            rb = res_pend.bn
+            _L().call("emrt_bn_apply_join", P(x), ldx, P(residual), ldres, P(out), ldy, P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd),
+                      P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), P(res_pend.sums), float(res_pend.count), rb.eps, rb.momentum,
+                      P(res_pend.mean), P(res_pend.invstd), P(rb.run_mean), P(rb.run_var), P(rb.gamma), P(rb.beta), M, C, int(relu), c.dtype, c.stream)
+        else:
+            _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, P(sums), float(count), bn.eps, bn.momentum, P(mean), P(invstd),
+                      P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
     else:
         _L().call("emrt_bn_apply", P(x), ldx, P(residual), ldres, P(out), ldy, None, 1.0, bn.eps, bn.momentum, None, None,
                   P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), M, C, int(relu), c.dtype, c.stream)
@@ -546,7 +557,10 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
                       P(sums2), P(local), float(count), P(bn.dgamma), P(bn.dbeta), M, C,
                       P(bn.beta) if (fused and residual is None) else None, int(fused and residual is not None), None, c.dtype, c.stream)
             tape.add_grad(x, dx, owned=True)
-            if residual is not None:
+            if res_pend is not None:
+                # the shortcut's BatchNorm backward on (its raw map, this join's masked gradient); no ReLU of its own
+                res_pend.backward(tape, dres if dres is not None else dy, masked=True)
+            elif residual is not None:
                 tape.add_grad(residual, dres if dres is not None else dy, owned=dres is not None)
         tape.record(bwd)
     return out
@@ -649,7 +663,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
                       dilation=getattr(conv, "dilation", 1), out_scale=scale, out_shift=shift)
     sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
     y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums, dilation=getattr(conv, "dilation", 1))
-    if defer and c.training and c.bn_defer and residual is None and out is None and bn.C % 8 == 0 and 256 % (bn.C // 8) == 0:
+    if defer and c.training and c.bn_defer and residual is None and out is None and ((bn.C % 8 == 0 and 256 % (bn.C // 8) == 0) or defer == "join"):
         count = y.shape[0] * y.shape[1] * y.shape[2]
         if _sync_active(bn.state):
             count = _allreduce_sums(sums, count)

@@ -58,7 +58,8 @@ class BasicBlock(hnn.HipLayer):  # :43-88
 
     def forward(self, x):
         out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
-        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x)
+        # (the shortcut's BatchNorm is applied by the join's loads: Fn.batch_norm with a PendingBN residual)
+        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x, defer="join")
         return Fn.conv_bn(self.conv2, self.bn2, out, relu=True, residual=identity)
 
 
@@ -78,7 +79,7 @@ class BottleneckBlock(hnn.HipLayer):  # :91-149
     def forward(self, x):
         out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
         out = Fn.conv_bn(self.conv2, self.bn2, out, relu=True)
-        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x)
+        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x, defer="join")
         return Fn.conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 

@@ -114,6 +114,12 @@ int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_packed, voi
 size_t emrt_colreduce_workspace_bytes(long long M, int C);
 int emrt_bn_stats(const void* x, int ldx, long long M, int C, double* sums, int dtype, void* stream);
 int emrt_bn_apply(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, long long M, int C, int relu, int dtype, void* stream);
+/* ABI 6: out = [relu](BN_train(x) + BN_train(res_raw)) -- the join that ends the first block of a ResNet stage, whose shortcut is
+ * conv1x1 -> BatchNorm without ReLU (paddle_vision_resnet.py:132-147, 226-233) -- with the shortcut's BatchNorm applied as its raw conv
+ * output is loaded (no separate emrt_bn_apply for it, no normalised shortcut map).  r_*: the shortcut's BatchNorm, same meaning as the
+ * main one's arguments; both save mean / invstd and update their running statistics.  Backward: the main BatchNorm as after
+ * emrt_bn_apply with a residual; the shortcut's through emrt_bn_bwd_reduce / _dx on (res_raw, masked dy). */
+int emrt_bn_apply_join(const void* x, int ldx, const void* res_raw, int ldres, void* y, int ldy, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, const double* r_sums, double r_count, float r_eps, float r_momentum, float* r_mean, float* r_invstd, float* r_run_mean, float* r_run_var, const float* r_gamma, const float* r_beta, long long M, int C, int relu, int dtype, void* stream);
 /* eval: every BatchNorm of a model as an affine map, one launch.  desc: device int64 [n][7] = (gamma offset, beta offset) into
  * `params`, (running mean offset, running variance offset) into `buffers`, C, offset into `out`, offset in `params` of the bias of
  * the convolution feeding this BatchNorm or -1; writes out[o..o+C) = s = gamma / sqrt(var + eps) and

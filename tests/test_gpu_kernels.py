@@ -1209,3 +1209,64 @@ def test_batchnorm_relu_applied_by_the_classifiers_loads(dtype, case):
     print("deferred classifier relative errors:", {k: "%.2e" % v for k, v in errs.items()})
     tol = 2e-5 if dtype == F32 else 3e-2
     assert all(v < tol for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 1), (2, 12, 12, 128, 512, 2), (3, 9, 9, 64, 64, 1)])
+def test_shortcut_batchnorm_applied_by_the_join(dtype, case):
+    """The first block of a ResNet stage: out = relu(BN3(conv3(a)) + BN_d(conv_d(x))) (paddle_vision_resnet.py:132-147, 226-233) with the
+    shortcut's BatchNorm applied by the join's loads (emrt_bn_apply_join).  Same bits as the two-launch path, forward and backward (the
+    normalised shortcut is rounded to the storage type before the add exactly as the separate launch stores it), and against torch."""
+    from emrt_amd import _lib
+    N, H, W, Cin, C, stride = case
+    g = torch.Generator().manual_seed(57)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    a = torch.randn(N, Cin, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=g)
+    w3 = torch.randn(C, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    wd = torch.randn(C, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    g3, b3 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    gd, bd = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(N, C, a.shape[2], a.shape[3], generator=g)
+
+    def run(defer):
+        c = init(dtype)
+        c.bn_defer = defer
+        conv3, bn3 = hnn.Conv2D(Cin, C, 1, bias=False), hnn.BatchNorm2D(C)
+        convd, bnd = hnn.Conv2D(Cin, C, 1, stride, 0, bias=False), hnn.BatchNorm2D(C)
+        with torch.no_grad():
+            conv3.weight.copy_(rnd(w3)); convd.weight.copy_(rnd(wd))
+            bn3.weight.copy_(g3); bn3.bias.copy_(b3); bnd.weight.copy_(gd); bnd.bias.copy_(bd)
+        Holder(conv3=conv3, bn3=bn3, convd=convd, bnd=bnd).place()
+        xd, ad = dev_map(rnd(x)), dev_map(rnd(a))
+        tape = Tape()
+        c.tape = tape
+        L = _lib.lib()
+        L.start_record()
+        identity = Fn.conv_bn(convd, bnd, xd, defer="join")
+        out = Fn.conv_bn(conv3, bn3, ad, relu=True, residual=identity)
+        c.tape = None
+        tape.watch(xd)
+        tape.watch(ad)
+        dx, da = run_bwd(tape, [(out, dev_map(rnd(dy)))], [xd, ad])
+        names = [n for n, _ in L.stop_record()]
+        torch.cuda.synchronize()
+        c.bn_defer = True
+        return (names, [host_map(out), host_map(dx), host_map(da), host(conv3.weight.grad), host(convd.weight.grad), host(bn3.weight.grad),
+                        host(bn3.bias.grad), host(bnd.weight.grad), host(bnd.bias.grad), host(bnd._buffers["_mean"]), host(bnd._buffers["_variance"])])
+
+    names, got = run(True)
+    names0, sep = run(False)
+    assert names.count("emrt_bn_apply_join") == 1 and names.count("emrt_bn_apply") == 0 and names0.count("emrt_bn_apply") == 2
+    labels = ["out", "dx", "da", "dw3", "dwd", "dgamma3", "dbeta3", "dgammad", "dbetad", "run_mean_d", "run_var_d"]
+    for lab, u, v in zip(labels, got, sep):
+        if lab in ("dw3", "dwd"):          # (weight gradients ride fp32 atomics: last-bit order effects)
+            assert ((u - v).norm() / v.norm()).item() < 1e-5, lab
+        else:
+            assert torch.equal(u, v), (lab, (u - v).abs().max())
+    xr, ar = rnd(x).clone().requires_grad_(True), rnd(a).clone().requires_grad_(True)
+    o = F.relu(F.batch_norm(F.conv2d(ar, rnd(w3)), None, None, g3, b3, True, 0.1, 1e-5) +
+               F.batch_norm(F.conv2d(xr, rnd(wd), stride=stride), None, None, gd, bd, True, 0.1, 1e-5))
+    o.backward(rnd(dy))
+    tol = 2e-5 if dtype == F32 else 3e-2
+    for lab, u, v in (("out", got[0], o.detach()), ("dx", got[1], xr.grad), ("da", got[2], ar.grad)):
+        assert ((u - v).norm() / v.norm()).item() < tol, (lab, ((u - v).norm() / v.norm()).item())

@@ -67,8 +67,10 @@ def test_train_step_launch_sequence(fake, backbone):
     # emrt_conv2d_wgrad_group call made while backward runs; a layer whose weight gradient is batched passes dw = NULL to its data gradient
     batched = [a[0][i] for n, a in fake.calls if n == "emrt_conv2d_wgrad_group" for i in range(a[1])]
     immediate = [a for n, a in fake.calls if n == "emrt_conv2d_bwd" and a[7] is not None]
-    assert cnt["emrt_conv2d_wgrad"] == 0 and len(batched) + len(immediate) == len(st.gemms)
-    assert len(immediate) == 3 and all(a[17] <= 8 for a in immediate)      # the two classifiers (OC = num_classes) and reference_points (OC = 2)
+    # (UpHead's classifier: forward and backward with its BatchNorm operand, emrt_bn_pointwise_fwd / _bwd, dW inside the one-pass backward)
+    assert cnt["emrt_bn_pointwise_fwd"] == cnt["emrt_bn_pointwise_bwd"] == 1
+    assert cnt["emrt_conv2d_wgrad"] == 0 and len(batched) + len(immediate) + 1 == len(st.gemms)
+    assert len(immediate) == 2 and all(a[17] <= 8 for a in immediate)      # the auxiliary head's classifier (OC = num_classes) and reference_points (OC = 2)
     assert all(a[8] is None for n, a in fake.calls if n == "emrt_conv2d_bwd" and a[7] is None)      # dbias travels with the batched dW
     assert all(a[0][i].dw is None and a[0][i].dbias is None for n, a in fake.calls if n == "emrt_conv2d_bwd_group" for i in range(a[1]))
     assert 4 <= cnt["emrt_conv2d_wgrad_group"] <= 12 and max(a[1] for n, a in fake.calls if n == "emrt_conv2d_wgrad_group") <= 24
@@ -78,12 +80,16 @@ def test_train_step_launch_sequence(fake, backbone):
     n_bn = sum(1 for mod in m.modules() if type(mod).__name__ == "BatchNorm2D")
     # five BatchNorm + ReLU layers are applied by their streaming consumer's loads (functional.PendingBN): the stem's and the spatial
     # branch's two into a max-pool, UpHead's first two into a x2 resize; their backward re-derives the ReLU mask from the raw map
-    n_defer = cnt["emrt_bn_maxpool_fwd"] + cnt["emrt_bn_resize_bilinear_fwd"]
+    n_stream = cnt["emrt_bn_maxpool_fwd"] + cnt["emrt_bn_resize_bilinear_fwd"]
     assert cnt["emrt_bn_maxpool_fwd"] == 3 and cnt["emrt_bn_resize_bilinear_fwd"] == 2 and cnt["emrt_maxpool_fwd"] == 1
     masked_x = [a for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[22] is not None]
-    assert len(masked_x) == n_defer and all(a[4] is None and a[20] is None and a[21] == 0 for a in masked_x)
-    assert sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_reduce" and a[12] is not None and a[4] is None) == n_defer
-    assert cnt["emrt_bn_apply"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
+    assert len(masked_x) == n_stream and all(a[4] is None and a[20] is None and a[21] == 0 for a in masked_x)
+    assert sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_reduce" and a[12] is not None and a[4] is None) == n_stream
+    # ... and the shortcut BatchNorm of every stage's first block by the join that adds it (emrt_bn_apply_join)
+    n_join_defer = cnt["emrt_bn_apply_join"]
+    assert n_join_defer == sum(1 for mod in m.modules() if getattr(mod, "downsample", None) is not None) > 0
+    n_defer = n_stream + 1 + n_join_defer
+    assert cnt["emrt_bn_apply"] + cnt["emrt_bn_apply_join"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
     assert not any(n == "emrt_conv2d" and a[22] == 1 for n, a in fake.calls)      # data gradients go through emrt_conv2d_bwd
     dgrads = [a for n, a in fake.calls if n == "emrt_conv2d_bwd"]
@@ -109,8 +115,9 @@ def test_train_step_launch_sequence(fake, backbone):
     fused_x = sum(1 for n, a in fake.calls if n == "emrt_bn_bwd_dx" and a[21] == 1)
     assert not any(a[20] is not None and a[21] == 1 for n, a in fake.calls if n == "emrt_bn_bwd_dx")
     assert all(a[4] is None for n, a in fake.calls if n == "emrt_bn_bwd_dx" and (a[20] is not None or a[21] == 1))     # fused: dy arrives masked
-    assert fused_y + fused_x + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_y + fused_x <= n_fused
-    n_join_bn = sum(1 for n, a in fake.calls if n == "emrt_bn_apply" and a[2] is not None and a[18] == 1)
+    # (the classifier's one-pass backward hands its BatchNorm the (sum, sum * y) form too, without being an emrt_conv2d_bwd call)
+    assert fused_y + fused_x + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_y + fused_x <= n_fused + 1
+    n_join_bn = sum(1 for n, a in fake.calls if n == "emrt_bn_apply" and a[2] is not None and a[18] == 1) + cnt["emrt_bn_apply_join"]
     assert 0 < fused_x <= n_join_bn and fused_x >= n_join_bn - 4, (fused_x, n_join_bn)     # every join inside the backbone stages
     assert fused_y >= n_bn // 3, (fused_y, n_bn)
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
@@ -120,9 +127,11 @@ def test_train_step_launch_sequence(fake, backbone):
     assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
     # wgrad destinations are distinct slices inside the trainable gradient range
     g0 = st.grad.data_ptr()
-    dws = [a[7].value - g0 for a in immediate] + [d.dw - g0 for d in batched]
+    dws = ([a[7].value - g0 for a in immediate] + [d.dw - g0 for d in batched] +
+           [a[10].value - g0 for n, a in fake.calls if n == "emrt_bn_pointwise_bwd"])
     assert len(set(dws)) == len(dws) == len(st.gemms) and all(0 <= d < 4 * st.n_train for d in dws)
-    assert sum(1 for d in batched if d.dbias) + sum(1 for a in immediate if a[8] is not None) == sum(1 for g_ in st.gemms if g_.bias is not None)
+    assert (sum(1 for d in batched if d.dbias) + sum(1 for a in immediate if a[8] is not None) +
+            sum(1 for n, a in fake.calls if n == "emrt_bn_pointwise_bwd" and a[11] is not None)) == sum(1 for g_ in st.gemms if g_.bias is not None)
     # every device pointer handed to a conv is 2-byte aligned at least and non-null
     for n, a in fake.calls:
         if n == "emrt_conv2d":
