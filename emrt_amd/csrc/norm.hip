@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
   float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   if (c < C) {
     float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
-    float msc[4] = {0, 0, 0, 0}, msh[4] = {0, 0, 0, 0};      // MODE 1 with mbeta: the ReLU mask re-derived from x (bn_operand.hpp)
-    if (MODE == 1) {
+    float msc[MODE == 3 ? 4 : 1], msh[MODE == 3 ? 4 : 1];      // MODE 3 = MODE 1 with the ReLU mask re-derived from x (bn_operand.hpp)
+    if (MODE == 1 || MODE == 3) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
-      if (mbeta) {
+      if constexpr (MODE == 3) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bn_scale_shift(mu[e], is[e], mgamma[c + e], mbeta[c + e], msc[e], msh[e]);
       }
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
         Vec4<T>::load(x + r * ldx + c, v);   // BN statistics: always dense rows
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s0[e] += v[e]; s1[e] = fmaf(v[e], v[e], s1[e]); }
-      } else if (MODE == 1) {
+      } else if (MODE == 1 || MODE == 3) {
         // four rows per iteration, all their loads issued before the first use: one row per trip left 4-6 KB in flight per
         // block and the kernel at the latency of its load chain (13 us for 33 MB)
         const long long rs = (long long)gridDim.x * ty_n;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ x
           for (int e = 0; e < 4; ++e) {
             float g = ok ? gg[u][e] : 0.f;
             if (y) g = oo[u][e] > 0.f ? g : 0.f;
-            else if (mbeta) g = fmaf(vv[u][e], msc[e], msh[e]) > 0.f ? g : 0.f;
+            if constexpr (MODE == 3) g = fmaf(vv[u][e], msc[e], msh[e]) > 0.f ? g : 0.f;
             s0[e] += g;
             s1[e] = fmaf(g, (vv[u][e] - mu[e]) * is[e], s1[e]);
           }
@@ -173,7 +173,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, fl
 // sums; block 0 also saves them for backward and updates the running statistics (Paddle convention: momentum 0.9 =>
 // running = 0.9*running + 0.1*batch, biased variance).  Threads own a fixed channel quad, so the per-channel constants
 // are computed once per thread and the row loop is a pure streaming fma.
-template <class T>
+template <class T, bool JOIN = false>
 __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ res, int ldres,
                                                        T* __restrict__ y, int ldy, const double* __restrict__ sums, double inv_count,
                                                        float eps, float momentum, float* __restrict__ mean_out,
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
   }
   // per-channel scale/shift computed cooperatively (one channel per thread) and shared through LDS
   extern __shared__ float bn_lds[];          // [2][C] (+ [2][C] for the shortcut's BatchNorm)
-  if (rbn.sums) bn_operand_preamble(rbn, C, bn_lds + 2 * C, blockIdx.x == 0);      // (its barrier is harmless here)
+  if constexpr (JOIN) bn_operand_preamble(rbn, C, bn_lds + 2 * C, blockIdx.x == 0);      // (its barrier is harmless here)
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const BnChan k = bn_chan(sums, run_mean, run_var, C, ch, inv_count, eps);
     float scale, shift;
@@ -218,12 +218,11 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  float sc[4], sh[4], rsc[4], rsh[4];
+  float sc[4], sh[4], rsc[JOIN ? 4 : 1], rsh[JOIN ? 4 : 1];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e];
-    rsc[e] = rbn.sums ? bn_lds[2 * C + c + e] : 1.f;
-    rsh[e] = rbn.sums ? bn_lds[3 * C + c + e] : 0.f;
+    if constexpr (JOIN) { rsc[e] = bn_lds[2 * C + c + e]; rsh[e] = bn_lds[3 * C + c + e]; }
   }
   while (r < M) {
     const long long rn = r + rstep;
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], sc[e], sh[e]);
     if (res) {
-      if (rbn.sums) {
+      if constexpr (JOIN) {
         // the separate path stores the normalised shortcut in T before adding it: round the same way so both paths give the same bits
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += to_f32(from_f32<T>(fmaf(w[e], rsc[e], rsh[e])));
@@ -257,7 +256,9 @@ __global__ __launch_bounds__(512) void bn_apply_kernel(const T* __restrict__ x, 
 
 // dx = gamma*invstd*(dy' - sum_dy/count - xhat*sum_dyxhat/count); optional dres = dy' (gradient of the fused residual);
 // block 0 accumulates dgamma += sum dy'*xhat, dbeta += sum dy' (from this rank's `lsums` when given: SyncBN).
-template <class T>
+// MX: the ReLU mask is re-derived from x (mbeta; bn_operand.hpp) -- a separate instantiation: with the mask parameters in the common
+// kernel it went from 64 to 68 registers (8 -> 7 waves per SIMD) and from 8.3 to 9.8 us per launch x 75 launches
+template <class T, bool MX = false>
 __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                         const T* __restrict__ y, int ldy, T* __restrict__ dx, int lddx,
                                                         T* __restrict__ dres, int lddres, const float* __restrict__ mean,
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     }
   }
   __syncthreads();
-  float mu[4], is[4], k0[4], k1[4], gi[4], msc[4], msh[4];
+  float mu[4], is[4], k0[4], k1[4], gi[4], msc[MX ? 4 : 1], msh[MX ? 4 : 1];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     mu[e] = mean[c + e];
@@ -303,8 +304,7 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     gi[e] = gamma[c + e] * is[e];
     k0[e] = bn_lds[c + e];
     k1[e] = bn_lds[C + c + e];
-    msc[e] = msh[e] = 0.f;
-    if (mbeta) bn_scale_shift(mu[e], is[e], gamma[c + e], mbeta[c + e], msc[e], msh[e]);      // ReLU mask re-derived from x (bn_operand.hpp)
+    if constexpr (MX) bn_scale_shift(mu[e], is[e], gamma[c + e], mbeta[c + e], msc[e], msh[e]);      // ReLU mask re-derived from x (bn_operand.hpp)
   }
   while (r < M) {
     const long long rn = r + rstep;
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(512) void bn_bwd_dx_kernel(const T* __restrict__ x,
     if (y) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
-    } else if (mbeta) {
+    }
+    if constexpr (MX) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = fmaf(v[e], msc[e], msh[e]) > 0.f ? g[e] : 0.f;
     }
@@ -1278,8 +1279,8 @@ extern "C" int emrt_bn_apply_join(const void* x, int ldx, const void* res_raw, i
   const double inv_count = 1.0 / count;
   const size_t lds = (size_t)4 * C * sizeof(float);
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(threads), lds, st, (const float*)x, ldx, (const float*)res_raw, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, r),
-            hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(threads), lds, st, (const bf16_t*)x, ldx, (const bf16_t*)res_raw, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, r));
+            hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(grid), dim3(threads), lds, st, (const float*)x, ldx, (const float*)res_raw, ldres, (float*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, r),
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), dim3(grid), dim3(threads), lds, st, (const bf16_t*)x, ldx, (const bf16_t*)res_raw, ldres, (bf16_t*)y, ldy, sums, inv_count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, M, C, relu, rpp, r));
   return check_launch("emrt_bn_apply_join");
 }
 
@@ -1323,9 +1324,15 @@ extern "C" int emrt_bn_bwd_reduce(const void* x, int ldx, const void* dy, int ld
   int tx, gx, gy;
   col_reduce_geometry(M, C, tx, gx, gy);
   hipStream_t st = (hipStream_t)stream;
+  if (mask_beta) {
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((col_reduce_kernel<float, 3>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)nullptr, 0, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr, mask_gamma, mask_beta),
+              hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 3>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)nullptr, 0, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr, mask_gamma, mask_beta));
+    return check_launch("emrt_bn_bwd_reduce");
+  }
   DT_SWITCH(dtype,
-            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr, mask_gamma, mask_beta),
-            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr, mask_gamma, mask_beta));
+            hipLaunchKernelGGL((col_reduce_kernel<float, 1>), dim3(gx, gy), dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr),
+            hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, mean, invstd, M, C, tx, nullptr, M, 0LL, sums, nullptr));
   return check_launch("emrt_bn_bwd_reduce");
 }
 
@@ -1345,6 +1352,12 @@ extern "C" int emrt_bn_bwd_dx(const void* x, int ldx, const void* dy, int lddy, 
   int threads, rpp, grid;
   EMRT_REQUIRE(bn_rowgeom(M, C, threads, rpp, grid), "unsupported channel count (C/4 must divide 256, or C <= 2048)");
   hipStream_t st = (hipStream_t)stream;
+  if (mask_beta) {
+    DT_SWITCH(dtype,
+              hipLaunchKernelGGL((bn_bwd_dx_kernel<float, true>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)nullptr, 0, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, nullptr, 0, mask_beta),
+              hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t, true>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)nullptr, 0, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, nullptr, 0, mask_beta));
+    return check_launch("emrt_bn_bwd_dx");
+  }
   DT_SWITCH(dtype,
             hipLaunchKernelGGL((bn_bwd_dx_kernel<float>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const float*)x, ldx, (const float*)dy, lddy, (const float*)y, ldy, (float*)dx, lddx, (float*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x, mask_beta),
             hipLaunchKernelGGL((bn_bwd_dx_kernel<bf16_t>), dim3(grid), dim3(threads), (size_t)2 * C * sizeof(float), st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (const bf16_t*)y, ldy, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, mean, invstd, gamma, sums, local_sums, 1.0 / count, dgamma, dbeta, M, C, rpp, beta_y_moments, sums_vs_x, mask_beta));
