@@ -1,5 +1,6 @@
 """CPU: the C-ABI shared library loads and exports exactly what include/emrt_hip.h declares; the header's prototypes are
 the definitions' prototypes (no compute calls -- there is no GPU here)."""
+import ctypes
 import glob
 import os
 import re
@@ -74,6 +75,44 @@ def test_loader_binds_all_entry_points(built):
     assert L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 250, scp, 4) == 0
     assert L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 256, scp, 4) == 8 * (9 + 4 * 3 + 9 * 2 + 36) * 256 * 4
     assert L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 256, None, 4) == 0
+
+
+def test_abi6_entry_points_refuse_bad_arguments_before_any_launch(built):
+    """Argument checks of the round-4 entry points run on the host before anything touches a device: a bad call returns non-zero with a
+    message (no GPU here; the pointers are never dereferenced)."""
+    from emrt_amd import _lib
+    _lib._LIB = None
+    L = _lib.lib()
+    p = ctypes.c_void_p(0x10000)          # "a device pointer": aligned, never read
+    bn = (p, 64.0, 1e-5, 0.9, p, p, p, p, p, p, 1)      # sums, count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, relu
+
+    def refused(name, *args, match):
+        with pytest.raises(_lib.EmrtHipError, match=match):
+            L.call(name, *args)
+
+    # classifier: C outside {64, 128, 256}; more than 8 outputs
+    refused("emrt_bn_pointwise_fwd", p, 96, 96 * 64, p, None, p, 6, 6 * 64, 1, 64, 96, 6, *bn, 1, None, match="C in")
+    refused("emrt_bn_pointwise_fwd", p, 256, 256 * 64, p, None, p, 9, 9 * 64, 1, 64, 256, 9, *bn, 1, None, match="OC <= 8")
+    refused("emrt_bn_pointwise_bwd", p, 256, 256 * 64, p, 9, 9 * 64, p, p, 256, 256 * 64, p, None, None, 1, 64, 256, 9, p, p, p, p, 1, None, match="OC <= 8")
+    # resize / max-pool with a BatchNorm operand: off the vector path, missing sums, non-positive count
+    refused("emrt_bn_resize_bilinear_fwd", p, 6 * 16, 6, 4, 4, p, 6 * 64, 6, 8, 8, 1, 6, 0, *bn, 1, None, match="vector path")
+    nosums = (None,) + bn[1:]
+    refused("emrt_bn_resize_bilinear_fwd", p, 64 * 16, 64, 4, 4, p, 64 * 64, 64, 8, 8, 1, 64, 0, *nosums, 1, None, match="BatchNorm operand")
+    zerocount = (p, 0.0) + bn[2:]
+    refused("emrt_bn_maxpool_fwd", p, p, p, 1, 8, 8, 64, 3, 2, 1, *zerocount, 1, None, match="BatchNorm operand")
+    refused("emrt_bn_maxpool_fwd", p, p, p, 1, 8, 8, 60, 3, 2, 1, *bn, 1, None, match="vector path")
+    # the join: the shortcut's BatchNorm is not optional
+    refused("emrt_bn_apply_join", p, 64, p, 64, p, 64, p, 64.0, 1e-5, 0.9, p, p, p, p, p, p, None, 64.0, 1e-5, 0.9, p, p, p, p, p, p, 64, 64, 1, 1, None,
+            match="shortcut")
+    # mask arguments come as a pair and replace y
+    refused("emrt_bn_bwd_reduce", p, 64, p, 64, None, 0, p, p, 64, 64, p, p, None, 1, None, match="come together")
+    refused("emrt_bn_bwd_reduce", p, 64, p, 64, p, 64, p, p, 64, 64, p, p, p, 1, None, match="replace y")
+    refused("emrt_bn_bwd_dx", p, 64, p, 64, p, 64, p, 64, None, 64, p, p, p, p, None, 64.0, None, None, 64, 64, None, 0, p, 1, None, match="mask_beta")
+    # pooling workspace smaller than the query's answer
+    sc = (ctypes.c_int * 4)(1, 2, 3, 6)
+    scp = ctypes.cast(sc, ctypes.c_void_p)
+    need = L.query("emrt_adaptive_avgpool_workspace_bytes", 32, 32, 8, 256, scp, 4)
+    refused("emrt_adaptive_avgpool_fwd", p, 32 * 32 * 256, 256, 32, 32, p, 50 * 256, 256, 8, 256, scp, 4, p, need - 4, 1, None, match="workspace smaller")
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
