@@ -263,19 +263,18 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeBwdArgs a) {
 // destination window, reduced through LDS.
 constexpr int RBW_THREADS = 1024;
 template <class T>
-__global__ __launch_bounds__(RBW_THREADS) void resize_bwd_wide_kernel(ResizeBwdArgs a) {
-  __shared__ float red[RBW_THREADS * 4];
-  const int iw = blockIdx.x % a.IW, ih = (blockIdx.x / a.IW) % a.IH, n = blockIdx.x / (a.IW * a.IH);
+__device__ __forceinline__ void resize_bwd_wide_body(const ResizeBwdArgs& a, const int pixel_block, const int chunk, const int nchunks, float* red) {
+  const int iw = pixel_block % a.IW, ih = (pixel_block / a.IW) % a.IH, n = pixel_block / (a.IW * a.IH);
   int ylo, yhi, xlo, xhi;
   axis_range(a.ay, ih, a.OH, ylo, yhi);
   axis_range(a.ax, iw, a.OW, xlo, xhi);
   const int bw = xhi - xlo + 1, npix = (yhi - ylo + 1) * bw;
-  // blockIdx.y: channel chunk (a 1x1 or 3x3 source map has only 8 / 72 pixels in the batch: splitting the channels over
-  // gridDim.y blocks gives each block fewer quads, hence more phases over the 1024-pixel window and more blocks in flight)
-  const int cq = a.C / 4 / (int)gridDim.y;         // host guarantees C % 4 == 0, gridDim.y | C/4 and cq <= RBW_THREADS
+  // chunk: channel chunk (a 1x1 or 3x3 source map has only 8 / 72 pixels in the batch: splitting the channels over
+  // nchunks blocks gives each block fewer quads, hence more phases over the 1024-pixel window and more blocks in flight)
+  const int cq = a.C / 4 / nchunks;         // host guarantees C % 4 == 0, nchunks | C/4 and cq <= RBW_THREADS
   const int phases = RBW_THREADS / cq;
   const int q = (int)threadIdx.x % cq, ph = (int)threadIdx.x / cq;
-  const int qg = (int)blockIdx.y * cq + q;         // global channel quad
+  const int qg = chunk * cq + q;         // global channel quad
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (ph < phases) {
     const T* gimg = (const T*)a.dout + (long long)n * a.do_bs + qg * 4;
@@ -298,6 +297,58 @@ __global__ __launch_bounds__(RBW_THREADS) void resize_bwd_wide_kernel(ResizeBwdA
       for (int e = 0; e < 4; ++e) acc[e] += red[(threadIdx.x + o * cq) * 4 + e];
     Vec4<T>::store((T*)a.din + (long long)n * a.di_bs + ((long long)ih * a.IW + iw) * a.di_ld + qg * 4, acc);
   }
+}
+
+template <class T>
+__global__ __launch_bounds__(RBW_THREADS) void resize_bwd_wide_kernel(ResizeBwdArgs a) {
+  __shared__ float red[RBW_THREADS * 4];
+  resize_bwd_wide_body<T>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, red);
+}
+
+// The pyramid maps (paddle_EMRT.py:281-291: 1x1 / 3x3 / 6x6 / 8x8 token maps blown up to the feature map): all scales in one launch, forward
+// and backward -- each alone is 8 ... 512 blocks, at the floor of a launch.
+constexpr int PYR_MAX = 4;
+struct PyramidResize {
+  ResizeArgs f[PYR_MAX];
+  ResizeBwdArgs b[PYR_MAX];
+  long long first[PYR_MAX + 1];      // forward: first thread item of a scale; backward: first block
+  int chunks[PYR_MAX];               // backward: channel chunks per source pixel of a scale (the rule of the one-scale launch)
+  int n;
+};
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void resize_fwd_pyramid_kernel(PyramidResize m) {
+  const long long total = m.first[m.n];
+  for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += (long long)gridDim.x * blockDim.x) {
+    int s = 0;
+    while (s + 1 < m.n && gidx >= m.first[s + 1]) ++s;
+    const ResizeArgs& a = m.f[s];
+    const long long idx = gidx - m.first[s];
+    const int cv = a.C / VEC;
+    int c, ow, oh, n;
+    unravel4(idx, cv, a.OW, a.OH, true, c, ow, oh, n);
+    c *= VEC;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    axis_src(a.ay, oh, a.IH, y0, y1, wy0, wy1);
+    axis_src(a.ax, ow, a.IW, x0, x1, wx0, wx1);
+    const T* ip = (const T*)a.in + (long long)n * a.in_bs + c;
+    float v00[VEC], v01[VEC], v10[VEC], v11[VEC], o[VEC];
+    VecIO<T, VEC>::load(ip + ((long long)y0 * a.IW + x0) * a.in_ld, v00);
+    VecIO<T, VEC>::load(ip + ((long long)y0 * a.IW + x1) * a.in_ld, v01);
+    VecIO<T, VEC>::load(ip + ((long long)y1 * a.IW + x0) * a.in_ld, v10);
+    VecIO<T, VEC>::load(ip + ((long long)y1 * a.IW + x1) * a.in_ld, v11);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = wy0 * (wx0 * v00[e] + wx1 * v01[e]) + wy1 * (wx0 * v10[e] + wx1 * v11[e]);
+    VecIO<T, VEC>::store((T*)a.out + (long long)n * a.out_bs + ((long long)oh * a.OW + ow) * a.out_ld + c, o);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(RBW_THREADS) void resize_bwd_pyramid_kernel(PyramidResize m) {
+  __shared__ float red[RBW_THREADS * 4];
+  int s = 0;
+  while (s + 1 < m.n && (long long)blockIdx.x >= m.first[s + 1]) ++s;
+  const int local = (int)((long long)blockIdx.x - m.first[s]), nch = m.chunks[s];
+  resize_bwd_wide_body<T>(m.b[s], local / nch, local % nch, nch, red);
 }
 
 // fp32 NCHW gradient (the logits): separable two-pass gather.  Pass W folds the columns, tmp[n][c][oh][iw] =
@@ -891,6 +942,86 @@ extern "C" int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int d
     else hipLaunchKernelGGL((resize_bwd_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, a);
   }
   return check_launch("emrt_resize_bilinear_bwd");
+}
+
+// ABI 6: the decoder's pyramid maps in ONE launch per direction.  tokens [N][sum k^2][C] dense (the k x k map of scale i starts at token
+// sum_{j<i} k_j^2); outs[i] / douts[i]: NHWC maps [N][OH][OW][C] with row stride ld[i] and image stride bs[i] (channel slices of the concat
+// buffer).  scales, outs, ld, bs: HOST arrays of nscales <= 4 entries.  C % 4 == 0, 16-byte aligned rows (the model's shapes: anything else
+// is an error -- call emrt_resize_bilinear_fwd / _bwd per scale).  Backward: every map is >= x4 smaller than OH x OW per axis.
+static int pyramid_fill(PyramidResize& m, const void* tokens, const int* scales, int nscales, void* const* maps, const int* ld, const long long* bs,
+                        int OH, int OW, int N, int C, int align_corners, int esz) {
+  if (!tokens || !scales || !maps || !ld || !bs || nscales < 1 || nscales > PYR_MAX || N <= 0 || C <= 0 || OH <= 0 || OW <= 0) return -1;
+  if (C % 4 || ((uintptr_t)tokens % 16)) return -2;
+  int ntok = 0;
+  for (int i = 0; i < nscales; ++i) ntok += scales[i] * scales[i];
+  int start = 0;
+  m.n = nscales;
+  for (int i = 0; i < nscales; ++i) {
+    const int k = scales[i];
+    if (k <= 0 || !maps[i] || ld[i] % 4 || bs[i] % 4 || ((uintptr_t)maps[i] % 16)) return -2;
+    const char* tk = (const char*)tokens + (size_t)start * C * esz;
+    ResizeArgs& f = m.f[i];
+    f.in = tk; f.in_bs = (long long)ntok * C; f.in_ld = C; f.IH = k; f.IW = k;
+    f.out = maps[i]; f.out_bs = bs[i]; f.out_ld = ld[i]; f.OH = OH; f.OW = OW;
+    f.add = nullptr; f.add_bs = 0; f.add_ld = 0; f.N = N; f.C = C;
+    f.ay = make_axis(k, OH, align_corners); f.ax = make_axis(k, OW, align_corners); f.out_nchw_f32 = 0;
+    ResizeBwdArgs& b = m.b[i];
+    b.dout = maps[i]; b.do_bs = bs[i]; b.do_ld = ld[i]; b.OH = OH; b.OW = OW;
+    b.din = const_cast<char*>(tk); b.di_bs = (long long)ntok * C; b.di_ld = C; b.IH = k; b.IW = k; b.N = N; b.C = C;
+    b.ay = f.ay; b.ax = f.ax; b.dout_nchw_f32 = 0;
+    start += k * k;
+  }
+  return 0;
+}
+
+extern "C" int emrt_pyramid_resize_fwd(const void* tokens, const int* scales, int nscales, void* const* outs, const int* out_ld,
+                                       const long long* out_bs, int OH, int OW, int N, int C, int align_corners, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
+  PyramidResize m;
+  const int rc = pyramid_fill(m, tokens, scales, nscales, outs, out_ld, out_bs, OH, OW, N, C, align_corners, dtype == EMRT_F32 ? 4 : 2);
+  EMRT_REQUIRE(rc != -1, "null pointer or bad dims (1..4 scales)");
+  EMRT_REQUIRE(rc == 0, "vector path only: C % 4 == 0, 16-byte aligned rows");
+  const bool v8 = dtype != EMRT_F32 && C % 8 == 0;
+  bool all8 = v8;
+  for (int i = 0; i < nscales; ++i) all8 = all8 && out_ld[i] % 8 == 0 && out_bs[i] % 8 == 0;
+  const int vec = all8 ? 8 : 4;
+  m.first[0] = 0;
+  for (int i = 0; i < nscales; ++i) m.first[i + 1] = m.first[i] + (long long)N * OH * OW * (C / vec);
+  EMRT_REQUIRE(m.first[nscales] <= 0xffffffffll, "too many elements");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(m.first[nscales]);
+  if (vec == 8) {
+    if (dtype == EMRT_BF16) hipLaunchKernelGGL((resize_fwd_pyramid_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, m);
+    else hipLaunchKernelGGL((resize_fwd_pyramid_kernel<f16_t, 8>), dim3(grid), dim3(256), 0, st, m);
+  } else if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_fwd_pyramid_kernel<float, 4>), dim3(grid), dim3(256), 0, st, m);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((resize_fwd_pyramid_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL((resize_fwd_pyramid_kernel<f16_t, 4>), dim3(grid), dim3(256), 0, st, m);
+  return check_launch("emrt_pyramid_resize_fwd");
+}
+
+extern "C" int emrt_pyramid_resize_bwd(const void* const* douts, const int* do_ld, const long long* do_bs, int OH, int OW, void* dtokens,
+                                       const int* scales, int nscales, int N, int C, int align_corners, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  PyramidResize m;
+  const int rc = pyramid_fill(m, dtokens, scales, nscales, const_cast<void* const*>(douts), do_ld, do_bs, OH, OW, N, C, align_corners, dtype == EMRT_F32 ? 4 : 2);
+  EMRT_REQUIRE(rc != -1, "null pointer or bad dims (1..4 scales)");
+  EMRT_REQUIRE(rc == 0, "vector path only: C % 4 == 0, 16-byte aligned rows");
+  EMRT_REQUIRE(C / 4 <= RBW_THREADS, "C too large");
+  m.first[0] = 0;
+  for (int i = 0; i < nscales; ++i) {
+    EMRT_REQUIRE((long long)OH * OW >= 16ll * scales[i] * scales[i], "every pyramid map must be at least x4 smaller than the output per axis");
+    // a 1x1 map has N source pixels, each collecting from the WHOLE output: its channels are split over up to 8 blocks (as the one-scale
+    // launch does: same chunks, same summation order, same bits); the launch lasts as long as its slowest block
+    int chunks = 1;
+    while (chunks < 8 && (long long)N * scales[i] * scales[i] * chunks < 256 && (C / 4) % (chunks * 2) == 0 && (C / 4) / (chunks * 2) >= 8) chunks *= 2;
+    m.chunks[i] = chunks;
+    m.first[i + 1] = m.first[i] + (long long)N * scales[i] * scales[i] * chunks;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)m.first[nscales]);
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((resize_bwd_pyramid_kernel<float>), grid, dim3(RBW_THREADS), 0, st, m);
+  else hipLaunchKernelGGL((resize_bwd_pyramid_kernel<bf16_t>), grid, dim3(RBW_THREADS), 0, st, m);
+  return check_launch("emrt_pyramid_resize_bwd");
 }
 
 static int fill_pool(PoolArgs& a, const int* scales, int nscales) {

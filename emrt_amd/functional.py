@@ -1147,20 +1147,41 @@ def pyramid_tokens_to_maps(tokens, scales, OH, OW, outs):
     B, ntok, C = tokens.shape
     assert tokens.is_contiguous() and ntok == sum(k * k for k in scales) and len(outs) == len(scales)
     esz = tokens.element_size()
-    geo, start = [], 0
+    L = len(scales)
+    sc_arr = (ctypes.c_int * L)(*scales)
+    geo, start, lds, bss = [], 0, [], []
     for k, out in zip(scales, outs):
         _, oh_, ow_, oc_, out_ld, out_bs = _check_map(out)
         assert (oh_, ow_, oc_) == (OH, OW, C)
-        _L().call("emrt_resize_bilinear_fwd", ctypes.c_void_p(tokens.data_ptr() + start * C * esz), ntok * C, C, k, k, P(out), out_bs, out_ld, OH, OW,
-                  None, 0, 0, B, C, 1, 0, c.dtype, c.stream)
         geo.append((k, start, out))
+        lds.append(out_ld)
+        bss.append(out_bs)
         start += k * k
+    # one launch for all scales when the shapes are on the vector path (each scale alone is a launch of a few blocks)
+    grouped = (c.pyramid_group and L <= 4 and C % 4 == 0 and tokens.data_ptr() % 16 == 0 and
+               all(o.data_ptr() % 16 == 0 and ld % 4 == 0 and bs % 4 == 0 for o, ld, bs in zip(outs, lds, bss)))
+    if grouped:
+        _L().call("emrt_pyramid_resize_fwd", P(tokens), ctypes.cast(sc_arr, ctypes.c_void_p), L, (ctypes.c_void_p * L)(*[o.data_ptr() for o in outs]),
+                  (ctypes.c_int * L)(*lds), (ctypes.c_longlong * L)(*bss), OH, OW, B, C, 1, c.dtype, c.stream)
+    else:
+        for (k, s0, out), out_ld, out_bs in zip(geo, lds, bss):
+            _L().call("emrt_resize_bilinear_fwd", ctypes.c_void_p(tokens.data_ptr() + s0 * C * esz), ntok * C, C, k, k, P(out), out_bs, out_ld, OH, OW,
+                      None, 0, 0, B, C, 1, 0, c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
             dys = [tape.pop_grad(out) for _, _, out in geo]
             if all(d is None for d in dys):
                 return
+            if grouped and all(d is not None for d in dys) and all(OH * OW >= 16 * k * k for k in scales):
+                dgeo = [_check_map(d)[4:6] for d in dys]
+                if all(d.data_ptr() % 16 == 0 and ld % 4 == 0 and bs % 4 == 0 for d, (ld, bs) in zip(dys, dgeo)):
+                    dtok = c.empty((B, ntok, C))
+                    _L().call("emrt_pyramid_resize_bwd", (ctypes.c_void_p * L)(*[d.data_ptr() for d in dys]), (ctypes.c_int * L)(*[g_[0] for g_ in dgeo]),
+                              (ctypes.c_longlong * L)(*[g_[1] for g_ in dgeo]), OH, OW, P(dtok), ctypes.cast(sc_arr, ctypes.c_void_p), L, B, C, 1,
+                              c.dtype, c.stream)
+                    tape.add_grad(tokens, dtok, owned=True)
+                    return
             dtok = c.empty((B, ntok, C)) if all(d is not None for d in dys) else c.zeros((B, ntok, C))
             for (k, s0, _), dy in zip(geo, dys):
                 if dy is None:

@@ -224,6 +224,8 @@ class Context:
         # training: a BatchNorm + ReLU whose only consumer streams the map once (x2 resize, 3x3 max-pool) is applied by that consumer's
         # loads instead of its own emrt_bn_apply launch (functional.PendingBN).  0 = always the separate launch (A/B knob).
         self.bn_defer = bool(int(os.environ.get("EMRT_BN_DEFER", "1")))
+        # the decoder's pyramid maps resized by ONE launch per direction (emrt_pyramid_resize_fwd / _bwd); 0 = one launch per scale (A/B knob)
+        self.pyramid_group = bool(int(os.environ.get("EMRT_PYRAMID_GROUP", "1")))
         # EMRT_WGRAD_SIDE=1 (A/B experiment): the batched weight-gradient launches go to a second stream, next to the latency-bound
         # data-gradient / BatchNorm chain of the main stream; joined at the end of each backward segment
         self.wgrad_side = bool(int(os.environ.get("EMRT_WGRAD_SIDE", "0")))

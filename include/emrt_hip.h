@@ -194,6 +194,13 @@ int emrt_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH,
 int emrt_bn_resize_bilinear_fwd(const void* in, long long in_bs, int in_ld, int IH, int IW, void* out, long long out_bs, int out_ld, int OH, int OW, int N, int C, int align_corners, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int relu, int dtype, void* stream);
 size_t emrt_resize_bwd_workspace_bytes(int N, int C, int OH, int IW, int dout_nchw_f32);
 int emrt_resize_bilinear_bwd(const void* dout, long long do_bs, int do_ld, int OH, int OW, void* din, long long di_bs, int di_ld, int IH, int IW, int N, int C, int align_corners, int dout_nchw_f32, void* workspace, int dtype, void* stream);
+/* ABI 6: the decoder's pyramid token maps (k x k per scale, paddle_EMRT.py:281-291) resized to OH x OW, ALL scales in one launch per
+ * direction.  tokens / dtokens: dense [N][sum k^2][C], the map of scale i starting at token sum_{j<i} k_j^2; outs[i] / douts[i]: NHWC maps with
+ * row stride ld[i] and image stride bs[i] (channel slices of a concat buffer).  scales, outs, ld, bs: HOST arrays, nscales <= 4.  Vector path
+ * only (C % 4 == 0, 16-byte aligned rows); backward additionally needs every map >= x4 smaller than the output per axis and writes every
+ * token of dtokens (no zeroing needed).  Per scale these are emrt_resize_bilinear_fwd / _bwd launches of 8 ... 512 blocks. */
+int emrt_pyramid_resize_fwd(const void* tokens, const int* scales, int nscales, void* const* outs, const int* out_ld, const long long* out_bs, int OH, int OW, int N, int C, int align_corners, int dtype, void* stream);
+int emrt_pyramid_resize_bwd(const void* const* douts, const int* do_ld, const long long* do_bs, int OH, int OW, void* dtokens, const int* scales, int nscales, int N, int C, int align_corners, int dtype, void* stream);
 /* nn.AdaptiveAvgPool2D(k), k in scales (host int[nscales], <= 4), all scales in one launch -> tokens [N][sum k^2][C]:
  * paddle_EMRT.py:62,70-78.  workspace (nullable; ABI 6: sized by emrt_adaptive_avgpool_workspace_bytes for the same H, W, N, C, scales, NOT
  * cleared by the caller): with it, maps whose largest bin has >= 512 pixels are pooled by several blocks per bin, each writing its partial

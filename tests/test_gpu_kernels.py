@@ -1270,3 +1270,60 @@ def test_shortcut_batchnorm_applied_by_the_join(dtype, case):
     tol = 2e-5 if dtype == F32 else 3e-2
     for lab, u, v in (("out", got[0], o.detach()), ("dx", got[1], xr.grad), ("da", got[2], ar.grad)):
         assert ((u - v).norm() / v.norm()).item() < tol, (lab, ((u - v).norm() / v.norm()).item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("OH,OW,C", [(32, 32, 256), (24, 40, 64), (64, 64, 128)])
+def test_pyramid_maps_resized_in_one_launch(dtype, OH, OW, C):
+    """The decoder's pyramid token maps (1x1 / 3x3 / 6x6 / 8x8 -> OH x OW, align_corners=True, written into channel slices of the concat
+    buffer: paddle_EMRT.py:281-291) by ONE launch per direction (emrt_pyramid_resize_fwd / _bwd) against one launch per scale: same bits,
+    forward and backward; and against torch."""
+    from emrt_amd import _lib
+    scales, B = [1, 3, 6, 8], 3
+    ntok = sum(k * k for k in scales)
+    g = torch.Generator().manual_seed(3)
+    tok = rnd(torch.randn(B, ntok, C, generator=g))
+    dcat = rnd(torch.randn(B, OH, OW, C * 5, generator=g))
+
+    def run(grouped):
+        c = init(dtype)
+        c.pyramid_group = grouped
+        td = dev(tok)
+        cat = c.zeros((B, OH, OW, C * 5))
+        outs = [Fn.narrow(cat, 3, C * (1 + i), C) for i in range(4)]
+        tape = Tape()
+        c.tape = tape
+        L = _lib.lib()
+        L.start_record()
+        Fn.pyramid_tokens_to_maps(td, scales, OH, OW, outs)
+        c.tape = None
+        tape.watch(td)
+        dd = dev(dcat)
+        dtok, = run_bwd(tape, [(o, Fn.narrow(dd, 3, C * (1 + i), C)) for i, o in enumerate(outs)], [td])
+        names = [n for n, _ in L.stop_record()]
+        torch.cuda.synchronize()
+        c.pyramid_group = True
+        return names, host(cat), host(dtok)
+
+    names, cat, dtok = run(True)
+    names0, cat0, dtok0 = run(False)
+    wide = OH * OW >= 16 * 64          # (the grouped backward is the block-per-source-pixel form: every map >= x4 smaller per axis)
+    assert names.count("emrt_pyramid_resize_fwd") == 1 and "emrt_resize_bilinear_fwd" not in names
+    assert names.count("emrt_pyramid_resize_bwd") == (1 if wide else 0) and names.count("emrt_resize_bilinear_bwd") == (0 if wide else 4)
+    assert names0.count("emrt_resize_bilinear_fwd") == 4 and names0.count("emrt_resize_bilinear_bwd") == 4
+    # same arithmetic, separately compiled kernels: the blend's multiply-adds may be contracted differently (an ulp in fp32; a bf16 output
+    # then rounds the other way once in a while); the backward sums in the same order in both (same channel chunks per scale)
+    ulp = 1e-6 if dtype == F32 else 2.0 ** -7
+    for name_, u, v in (("maps", cat, cat0), ("dtokens", dtok, dtok0)):
+        assert (u - v).abs().max().item() <= ulp * v.abs().max().item(), (name_, (u - v).abs().max().item())
+        assert dtype == F32 or (u != v).float().mean().item() < 2e-3, name_
+    tr = tok.clone().requires_grad_(True)
+    s0, ref = 0, []
+    for k in scales:
+        m = tr[:, s0:s0 + k * k].reshape(B, k, k, C).permute(0, 3, 1, 2)
+        ref.append(F.interpolate(m, size=(OH, OW), mode="bilinear", align_corners=True).permute(0, 2, 3, 1))
+        s0 += k * k
+    full = torch.cat(ref, 3)
+    full.backward(dcat[..., C:])
+    close("pyramid fwd", cat[..., C:], full.detach(), dtype)
+    close("pyramid dtokens", dtok, tr.grad, dtype, math.sqrt(OH * OW))
