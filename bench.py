@@ -51,11 +51,13 @@ GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: pe
                  "emrt_conv2d": "igemm_kernel / igemm8p_kernel (emrt_conv2d: forward convs / linears)",
                  "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel mode 1 (emrt_conv2d_bwd: data gradients; thin_bwd_kernel for the classifiers)",
                  "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)",
+                 "emrt_bn_pointwise_fwd": "thin_fwd_bn_kernel (emrt_bn_pointwise_fwd: the classifier with its BatchNorm operand)",
+                 "emrt_bn_pointwise_bwd": "thin_bwd_kernel (emrt_bn_pointwise_bwd: the classifier's data + weight gradient in one pass)",
                  "emrt_conv2d_wgrad_group": "wgrad_group_kernel / wgrad8p_kernel (emrt_conv2d_wgrad_group: the weight gradients of up to 24 layers per launch)"}
 # the roofline's kernel family: every launch that computes a convolution / linear layer's BACKWARD (data gradient + weight gradient) --
 # the same population of work whether a layer's two gradients share a launch (round 3's pair kernel) or not (round 4: batched dW)
-CONV_BWD = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group")
-CONV_FWD = ("emrt_conv2d", "emrt_conv2d_group")
+CONV_BWD = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group", "emrt_bn_pointwise_bwd")
+CONV_FWD = ("emrt_conv2d", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
 
 
 def log(*a):
@@ -64,6 +66,10 @@ def log(*a):
 
 def conv_flops(name, a):
     """Algorithmic FLOPs of one emrt_conv2d / emrt_conv2d_wgrad call from its C-ABI arguments."""
+    if name == "emrt_bn_pointwise_fwd":        # the classifier with its BatchNorm operand: N, HW, C, OC = a[8:12]
+        return 2.0 * a[8] * a[9] * a[10] * a[11]
+    if name == "emrt_bn_pointwise_bwd":        # data + weight gradient in one pass: N, HW, C, OC = a[13:17]
+        return 4.0 * a[13] * a[14] * a[15] * a[16]
     if name == "emrt_conv2d":
         N, H, W, C = a[5:9]
         OH, OW, OC = a[11:14]
@@ -99,6 +105,12 @@ def conv_bytes(name, a, esz):
         if wgrad:
             b += x + y + 2 * 4 * w
         return b
+    if name == "emrt_bn_pointwise_fwd":        # raw map read once, weight, logits written
+        N, HW, C, OC = a[8:12]
+        return N * HW * C * esz + OC * C * esz + N * HW * OC * esz
+    if name == "emrt_bn_pointwise_bwd":        # raw map + dy read, masked input gradient written, dW read-modify-write
+        N, HW, C, OC = a[13:17]
+        return 2 * N * HW * C * esz + N * HW * OC * esz + OC * C * esz + 2 * 4 * OC * C
     if name == "emrt_conv2d":
         N, H, W, C = a[5:9]
         OH, OW, OC = a[11:14]
@@ -169,6 +181,10 @@ def dump_calls(path, calls, esz=2):
                 extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[3], vals[4], vals[5], vals[6], vals[9], vals[10], vals[11], vals[14], vals[16], conv_flops(name, vals) / 1e9)
             elif name in ("emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad_group"):
                 extra = "n=%d " % vals[1] + " ".join("%dx%dx%d->%d k%d" % (d.H, d.W, d.C, d.OC, d.KH) for d in list(vals[0])[:vals[1]]) + " gflop %.2f" % (conv_flops(name, vals) / 1e9)
+            elif name == "emrt_bn_pointwise_fwd":
+                extra = "classifier+BN N%d px%d %d->%d gflop %.2f" % (vals[8], vals[9], vals[10], vals[11], conv_flops(name, vals) / 1e9)
+            elif name == "emrt_bn_pointwise_bwd":
+                extra = "classifier+BN N%d px%d %d->%d gflop %.2f" % (vals[13], vals[14], vals[15], vals[16], conv_flops(name, vals) / 1e9)
             else:       # integer arguments only: enough to recognise the layer
                 extra = " ".join(str(v) for v in vals if isinstance(v, int) and not isinstance(v, bool) and abs(v) < (1 << 31))
             if name in GEMM_FAMILIES:
