@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/bench_under_trace.json 2> $OUT/trace.err
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 tools/r4/trace_summary.py $f $OUT/${TAG}_timeline.txt > $OUT/${TAG}_timeline_summary.txt
 find $OUT/trace -name "*.csv" -delete
