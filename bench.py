@@ -236,11 +236,20 @@ def rooflines(calls, dtype_name, cfg_key, train):
     if pmc is not None:
         key = "conv_backward_family" if train else "conv_forward_family"
         if key in pmc:
-            roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
-            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] * pmc[key]["dispatches_per_step"] / by, 3)
-            roofline["traffic_kernels"] = pmc[key].get("kernels")
-            roofline["traffic_unit"] = "bytes per kernel dispatch (2*FETCH_SIZE + WRITE_SIZE, average over the family's dispatches of a step)"
-            roofline["traffic_source"] = pmc_src + ": " + pmc.get("method", "")
+            # the committed profile is only this run's traffic if it was taken on the same launch list: the profile records how many C-ABI
+            # calls of the family its step made (tools/pmc_summary.py --calls), this run knows its own count
+            prof_calls = pmc[key].get("calls_per_step")
+            if prof_calls is not None and prof_calls != cnt:
+                roofline["traffic_note"] = ("%s was taken on a different launch list (%d %s calls per step there, %d in this run): traffic left out -- "
+                                            "re-run tools/r5/profile_round.sh" % (pmc_src, prof_calls, key, cnt))
+                pmc = None
+            else:
+                roofline["traffic"] = int(pmc[key]["traffic_mb_corrected"] * 1e6)
+                roofline["traffic_over_algorithmic"] = round(roofline["traffic"] * pmc[key]["dispatches_per_step"] / by, 3)
+                roofline["traffic_kernels"] = pmc[key].get("kernels")
+                roofline["traffic_unit"] = "bytes per kernel dispatch (2*FETCH_SIZE + WRITE_SIZE, average over the family's dispatches of a step)"
+                roofline["traffic_source"] = pmc_src + ": " + pmc.get("method", "")
+                roofline["traffic_calls_checked"] = prof_calls is not None
     esz = 4 if dtype_name == "fp32" else 2
     enc = [(vals_of(a), ms) for name, a, ms in calls if name == "emrt_msda_fwd"]
     enc = [(v, ms) for v, ms in enc if v[10] == v[11]]     # Lq == Lv: encoder self-attention calls
@@ -260,6 +269,8 @@ def rooflines(calls, dtype_name, cfg_key, train):
                          # (SURVEY.md 8d "secondary figure"); the LDS serves 128 B/clk/CU for this access width on 256 CUs
                          "lds_bytes": int(lds_by), "lds_peak": PEAK_LDS_GBPS, "lds_achieved": round(lds_by / avg_ms / 1e6, 1),
                          "lds_frac": round(lds_by / avg_ms / 1e6 / PEAK_LDS_GBPS, 4), "lds_ideal_us_at_peak": round(lds_by / PEAK_LDS_GBPS / 1e3, 2),
+                         # the same bytes against the conflict-free ds_read_b128 rate (256 B/clk/CU): what a layout whose 16-lane groups never collide would allow
+                         "lds_peak_b128": 2 * PEAK_LDS_GBPS, "lds_frac_b128": round(lds_by / avg_ms / 1e6 / (2 * PEAK_LDS_GBPS), 4),
                          "binding_roof": "lds" if lds_by / PEAK_LDS_GBPS > by / PEAK_HBM_GBPS else "hbm",
                          "note": "a launch that moves nothing already reads event_timed_trivial_launch_us (roofline) on this clock: at %.1f MB the HBM "
                                  "time is %.1f us and the LDS gather floor %.1f us, so the HBM fraction is bounded below %.2f by the gather alone and lower "
@@ -337,6 +348,77 @@ def check_world(args):
                          % (world, args.gpus, args.gpus, args.gpus))
 
 
+def dry_run(args):
+    """`bench.py --gpus N --dry-run` (also under a launcher): every rank checks its environment, joins a gloo group on the CPU, builds the
+    model's parameter layout on the host and derives what the N > 1 step would exchange -- flat-gradient ranges of the three backward
+    segments, bucket slices, the SyncBatchNorm statistics group, its share of a tile set -- and the ranks compare their plans.  No GPU, no
+    libemrt_hip.so: usable on a login node before the job is submitted.  Reference: train.py:116-123, dataloader.py:38-41."""
+    import hashlib
+    import torch.distributed as dist
+    from emrt_amd import nn as hnn
+    from emrt_amd.distributed import DistributedTileSampler, bucket_slices, env_rank_world
+    from emrt_amd.runtime import BF16
+    from emrt_amd.src.models import emrt as M
+    rank, local_rank, world = env_rank_world()
+    problems = []
+    if world != args.gpus:
+        problems.append("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not (0 <= rank < world) or not (0 <= local_rank < world):
+        problems.append("RANK=%d LOCAL_RANK=%d outside [0, %d)" % (rank, local_rank, world))
+    if world > 1:
+        for k in ("MASTER_ADDR", "MASTER_PORT"):
+            if not os.environ.get(k):
+                problems.append("%s is not set" % k)
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") != "0":
+            problems.append("HSA_ENABLE_IPC_MODE_LEGACY must be 0 (dmabuf IPC) for RCCL across processes on this driver")
+    if world > 1 and not problems:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = CONFIGS[args.config]
+    torch.manual_seed(1234)
+    model = M.EMRT(num_classes=cfg["ncls"], backbone="resnet50")
+    store = hnn.ParamStore(model, torch.device("cpu"), BF16, nograd_names=M.NOGRAD_PARAMS, fused_groups=model.fused_groups(),
+                           lr_mult_names=model.lr_mult_names(), lr_mult=0.1)
+    segs = store.segment_ranges(M.GRAD_SEGMENT_PREFIXES)
+    covered = sorted(r for seg in segs for r in seg)
+    if covered[0][0] != 0 or covered[-1][1] != store.n_train or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+        problems.append("the backward segments' ranges do not tile [0, n_train)")
+    bucket = 32 * 1024 * 1024
+    slices = [[b for a, e in seg for b in bucket_slices(e, bucket, a)] for seg in segs]
+    sync = [n for n, m in model.named_modules() if isinstance(m, hnn.BatchNorm2D) and m.state.sync]
+    n_tiles = 3456
+    smp = DistributedTileSampler(n_tiles, cfg["batch"], rank, world, shuffle=True, drop_last=True, seed=1234)
+    mine = [i for b in smp for i in b]
+    plan = {"n_train": store.n_train, "segments": segs, "slices": slices, "sync_bn": sync, "batches_per_rank": len(smp)}
+    digest = hashlib.sha256(json.dumps(plan, sort_keys=True).encode()).hexdigest()
+    if world > 1 and dist.is_initialized():
+        every = [None] * world
+        dist.all_gather_object(every, (rank, digest, mine))
+        if len({d for _, d, _ in every}) != 1:
+            problems.append("ranks derived different exchange plans: %r" % [(r, d[:8]) for r, d, _ in every])
+        flat = [i for _, _, m in every for i in m]
+        if len(flat) != len(set(flat)) or len({len(m) for _, _, m in every}) != 1:
+            problems.append("tile shards overlap or differ in size")
+        if sorted(r for r, _, _ in every) != list(range(world)):
+            problems.append("rank set %r" % sorted(r for r, _, _ in every))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {"dry_run": True, "n_gpus": world, "config": args.config, "ok": not problems, "problems": problems,
+               "gradient_elements": store.n_train, "gradient_mbytes_fp32": round(4e-6 * store.n_train, 1),
+               "exchange_ranges": [{"segment": name, "elements": sum(e - a for a, e in seg), "mbytes_fp32": round(4e-6 * sum(e - a for a, e in seg), 2),
+                                    "ranges": len(seg), "all_reduce_launches": len(sl)}
+                                   for name, seg, sl in zip(("heads + transformer + layer4", "layer3", "conv1 + layer1 + layer2"), segs, slices)],
+               "sync_batchnorm_layers": sync, "sync_batchnorm_collectives_per_step": {"forward": 1, "backward": 1,
+                    "note": "the five layers share one statistics all-reduce per direction (Fn.conv_bn_group + the auxiliary head joining the group)"},
+               "tiles_per_rank_per_step": cfg["batch"], "global_batch": world * cfg["batch"],
+               "sampler": {"tiles": n_tiles, "batches_per_rank_per_epoch": len(smp)}, "plan_sha256": digest}
+        print(json.dumps(out), flush=True)
+    if problems:
+        log("[bench] dry run, rank %d: %s" % (rank, "; ".join(problems)))
+        return 1
+    return 0
+
+
 def describe_group(rank, world, dev):
     """Rank 0: what the process group really is (a SCALE run is then self-evidencing)."""
     if rank != 0 or not torch.distributed.is_initialized():
@@ -389,10 +471,17 @@ def main():
     ap.add_argument("--no-early-exchange", action="store_true", help="N>1: one all-reduce after the whole backward (A/B experiment)")
     ap.add_argument("--two-phase-no-syncbn", action="store_true", help="--two-phase without the SyncBatchNorm collectives (A/B: what the graph cuts cost)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
+    ap.add_argument("--exchange-noop", action="store_true", help="A/B: the N > 1 step structure with the gradient all-reduce switched off (NOT a valid throughput)")
+    ap.add_argument("--dry-run", action="store_true", help="--gpus N without a GPU: start the N ranks, rendezvous over gloo, and check rank environment, "
+                    "gradient-exchange ranges, SyncBatchNorm group membership and tile sharding; prints a JSON plan, launches no kernel")
     args = ap.parse_args()
     if (args.gpus or 1) > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        if args.dry_run:
+            os.environ["EMRT_ALL_RANKS_ON_GPU0"] = "1"      # (the parent's "enough GPUs?" check does not apply: a dry run opens none)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     check_world(args)
+    if args.dry_run:
+        sys.exit(dry_run(args))
     from emrt_amd.distributed import init_process_group
     if os.environ.get("EMRT_ALL_RANKS_ON_GPU0"):      # test aid (with EMRT_DIST_BACKEND=gloo): every rank on device 0
         os.environ["LOCAL_RANK"] = "0"
@@ -415,11 +504,12 @@ def main():
                         and not args.two_phase)
     if world == 1 and default_workload and not args.no_other_configs:
         others = {}
-        for key, steps, warm in (("cfg3", 12, 4), ("cfg5", 20, 5)):
+        # (30 timed steps after 8 warm-up steps each: round 4's 12-step mean moved 18 % on ONE stalled step in the driver's run)
+        for key, steps, warm in (("cfg3", 30, 8), ("cfg5", 30, 8)):
             c2 = dict(CONFIGS[key])
             r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=1)
-            others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "end_to_end_tflops", "roofline",
-                                               "roofline_msda", "cpu_baseline") if k in r2}
+            others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "value_at_median",
+                                               "dtype", "config", "end_to_end_tflops", "loss_check", "roofline", "roofline_msda", "cpu_baseline") if k in r2}
         result["other_configs"] = others
     if world > 1:
         torch.distributed.barrier()
@@ -463,6 +553,8 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
     if args.two_phase_no_syncbn:
         from emrt_amd.runtime import ctx as _ctx
         _ctx().sync_always = False
+    if args.exchange_noop and eng.reducer is not None:
+        eng.reducer.noop = True
     g = torch.Generator().manual_seed(1234 + rank)
     images = torch.randn(B, 3, S, S, generator=g).to(dev)
     labels = torch.randint(0, ncls, (B, S, S), generator=g)
@@ -470,8 +562,11 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
     labels = labels.to(dev)
 
     # setup (untimed, not part of the W warm-up steps): eager steps + hipGraph capture
+    first_loss = None
     for _ in range(eng.warmup_eager + 1):
-        eng.step(images, labels)
+        lt = eng.step(images, labels)
+        if first_loss is None:
+            first_loss = float(lt.item())
     torch.cuda.synchronize()
     for _ in range(warmup):
         eng.step(images, labels)
@@ -481,9 +576,14 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
             torch.distributed.barrier()
     torch.cuda.synchronize()
     barrier()
+    # a device timestamp after every step (an event record on the step's stream: no host wait, nothing added to the timed region but the
+    # records themselves): the mean below is the contract's number, median and max make a single stalled step visible next to it
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         loss_t = eng.step(images, labels)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -491,9 +591,44 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     loss_val = float(loss_t.item())
     tiles_per_s = world * B * steps / elapsed
-    probe = None
+    # the timed steps did real work on real weights: the loss of a repeated batch must be finite, positive, below the first step's, and inside
+    # the band recorded for this workload (bf16, synthetic tiles, seed 1234: 2.95 at step 1, 2.87 after 16 steps, 2.72 after 43; ln(ncls) * 1.4
+    # is the untrained value of CE + 0.4 aux CE).  A NaN, a frozen model or a diverging one fails the run instead of printing a number.
+    import math
+    untrained = 1.4 * math.log(ncls)
+    band = (0.3 * untrained, 1.35 * untrained)
+    loss_ok = (loss_val == loss_val and first_loss == first_loss and band[0] < loss_val < band[1] and loss_val < first_loss * (1.0 + 1e-3))
+    loss_check = {"first_step": round(first_loss, 4), "final": round(loss_val, 4), "band": [round(band[0], 3), round(band[1], 3)],
+                  "steps_taken": eng.calls, "ok": bool(loss_ok)}
+    if not loss_ok:
+        raise SystemExit("[bench] loss check failed: %r" % (loss_check,))
+    probe = exposed = None
+    if world > 1 and eng.reducer is not None and not args.exchange_noop:
+        # what the gradient exchange costs the step: the same structure (graphs, SyncBatchNorm cuts, optimizer graph) with the all-reduce
+        # switched off, 3 extra steps after the timed region (the ranks' weights drift apart meanwhile: nothing is measured after this)
+        eng.reducer.noop = True
+        eng.step(images, labels)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.step(images, labels)
+        torch.cuda.synchronize()
+        barrier()
+        noop_ms = 1e3 * (time.perf_counter() - t1) / 3
+        eng.reducer.noop = False
+        t = torch.tensor([noop_ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        noop_ms = float(t.item())
+        ranges = eng.seg_ranges if eng.seg_ranges is not None else [[(0, model.store.n_train)]]
+        exposed = {"ms_per_step_without_exchange": round(noop_ms, 3), "exchange_exposed_ms": round(1e3 * elapsed / steps - noop_ms, 3),
+                   "range_payload_mbytes": [round(4e-6 * sum(e - a for a, e in seg), 2) for seg in ranges],
+                   "exchange_dtype": eng.reducer.exchange_dtype,
+                   "note": "3 extra steps with the all-reduce launches skipped (FlatGradReducer.noop, set here only); ranges in launch order: "
+                           "heads + transformer + layer4 | layer3 | conv1 + layer1 + layer2 (the last one is the only exposed collective)"}
     if world > 1 and torch.distributed.get_backend() == "nccl":      # every rank takes part; rank 0 reports
         probe = collective_probe(dev, world, model.store.n_train)
 
@@ -514,16 +649,22 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         flop_tile = 3.0 * cfg["fwd_gflop"] * 1e9 * (S * S) / (CONFIGS[cfg_key]["size"] ** 2)
         result = {
             "metric": "training tiles/sec at %dx%d" % (S, S), "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world,
-            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "ms_per_step_median": round(statistics.median(per_step_ms), 3), "ms_per_step_max": round(max(per_step_ms), 3),
+            "value_at_median": round(world * B * 1e3 / statistics.median(per_step_ms), 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": cfg["name"].replace("batch %d" % CONFIGS[cfg_key]["batch"], "batch %d" % B) + ", " + dtype_name,
                        "global_batch": world * B, "tile": [S, S, 3], "parallelism": "dp%d" % world, "hipgraph": not args.no_graph},
-            "end_to_end_tflops": round(tiles_per_s * flop_tile / 1e12, 2), "final_loss": round(loss_val, 4),
+            "end_to_end_tflops": round(tiles_per_s * flop_tile / 1e12, 2), "final_loss": round(loss_val, 4), "loss_check": loss_check,
             "roofline": roofline, "roofline_msda": roofline_msda, "cpu_baseline": cpu_baseline,
         }
         if probe is not None:
             # what the exchange would cost if nothing hid it, next to what the step really paid over the 1-rank step structure
             result["collective"] = probe
+        if exposed is not None:
+            result["exchange"] = exposed
+        if args.exchange_noop:
+            result["invalid"] = "--exchange-noop: gradient all-reduce switched off (A/B of the step structure, not a throughput)"
     del eng
     return result
 
@@ -569,12 +710,16 @@ def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
             torch.distributed.barrier()
     torch.cuda.synchronize()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # device timestamps per image: see run_train
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         pred = eng(img)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -595,7 +740,9 @@ def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         result = {
             "metric": "inference tiles/sec at %dx%d (sliding window over %dx%d images)" % (crop, crop, img_h, img_w),
             "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_step_median": round(statistics.median(per_step_ms), 3),
+            "ms_per_step_max": round(max(per_step_ms), 3), "value_at_median": round(world * nwin * 1e3 / statistics.median(per_step_ms), 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": cfg["name"].replace("1024x1024", "%dx%d" % (img_h, img_w)).replace("16 windows", "%d windows" % nwin) + ", " + dtype_name,
                        "windows_per_step": nwin, "image": [img_h, img_w, 3], "tile": [crop, crop, 3],

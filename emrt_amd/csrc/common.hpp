@@ -78,11 +78,19 @@ struct Tuning {
   int wgroup_blocks;      // batched weight gradients (emrt_conv2d_wgrad_group): blocks a launch aims for (1024 = 4 per CU)
   int wgroup_min_steps;   // ... fewest 64-pixel tiles per block (32: shorter blocks only buy fp32 atomic traffic)
   int wgroup_max;         // ... most problems per launch (0 = the kernel's limit, 24)
+  int xk;                 // cross-block K split of few-tile, long-K convolutions: 0 = the dispatcher's choice, -1 = never, n >= 2 = n copies whenever the shape allows
 };
 extern Tuning g_tune;
 
 // scratch for partial sums, registered once per process by emrt_set_scratch (kernels of ONE stream use it one after the other)
-struct Scratch { void* ptr; size_t bytes; void* stream; };      // stream: the ONE stream whose launches may use it (partial tiles + reduce are not atomic across streams)
+struct Scratch {
+  void* ptr; size_t bytes; void* stream;      // stream: the ONE stream whose launches may use it (partial tiles + reduce are not atomic across streams)
+  unsigned* tick;                              // arrival counters of the cross-block K split (conv.hip: igemm_body XK), SCRATCH_TICKS words kept ZERO
+                                               // between launches (the last block to arrive resets its tile's counter); nullptr when the registered
+                                               // region was too small to carve them out
+};
+constexpr size_t SCRATCH_TICK_BYTES = 65536;   // the tail of the registered region: 16384 counters
+constexpr int SCRATCH_TICKS = (int)(SCRATCH_TICK_BYTES / 4);
 extern Scratch g_scratch;
 
 // ---- element types ---------------------------------------------------------------------------

@@ -58,6 +58,12 @@ struct ConvArgs {
   long long sx_bs;
   int ldy;
   long long y_bs;
+  // cross-block K split (igemm_body<..., XK>): the grid is xk_S copies of the tile grid, copy s walks the k-tiles [s * per, (s + 1) * per);
+  // partial fp32 tiles go to xk_part [tile][s][BM][BN], arrivals are counted in xk_tick[tile], and the LAST block to arrive sums the
+  // partials (in s order: bit-reproducible) and runs the epilogue.  0 / nullptr everywhere else.
+  int xk_S;
+  float* xk_part;
+  unsigned* xk_tick;
 };
 
 template <class T>
@@ -131,9 +137,17 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // index on the half-resolution grid), so that a 64-row tile is parity-pure (host: M/4 % 64 == 0) and its k loop visits its own taps only;
 // a class without taps skips the loop and runs the epilogue (addend / mask / statistics) on zeros.  Same result, bit for bit, as the
 // generic kernel: the skipped k-tiles contributed exact zeros.
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false>
+// XK (cross-block K split, 64x64 vector-path tile): few-tile, long-K layers (layer4's 8x8 maps, the auxiliary head's 16x16x1024 3x3, layer3's
+// 3x3 convs: 64-128 tiles of 64x64) leave most CUs idle, and a CU streams its operands at ~50-70 GB/s whatever runs on it (G = 1 / 2 /
+// 4 wave groups per block give 27 / 24 / 21 us on 8x8x512 -> 512 3x3 -- the L1 fill rate of the FEW CUs that have a block is the bound).  Here the
+// k range is cut over S blocks per tile, so S times as many CUs pull the same bytes; each block leaves its fp32 partial tile in the registered
+// scratch with write-through (sc1) stores, every storing wave drains its stores, one lane takes a ticket (agent-scope atomic add), and the
+// block whose ticket is the last one acquires (agent scope), sums the S partials in s order and runs the usual epilogue (bias / residual / mask
+// / BatchNorm sums / store) -- no finishing launch.  MI355X_MICROARCH.md "splitk-seam"; cdna_hip_programming.md Guideline 16, R1.
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false, bool XK = false>
 __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id, const int block_count, unsigned char* smem_all) {
   static_assert(!S2 || (MODE == 1 && VEC && G == 1 && TM == 1 && TN == 1), "S2 is the 64x64 vector-path data gradient");
+  static_assert(!XK || (VEC && G == 1 && !S2), "XK is a vector-path tile without the in-block K split");
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
@@ -151,6 +165,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   int bid = block_id;
   const int nblk = block_count;
   if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  int xk_s = 0, xk_tile = 0;
+  if constexpr (XK) {      // copy-major: the blocks of one k range are neighbours (they share the weight rows of that range)
+    const int ntile = nblk / p.xk_S;
+    xk_s = bid / ntile;
+    xk_tile = bid - xk_s * ntile;
+    bid = xk_tile;
+  }
   const int bm = bid / tiles_n, bn = bid % tiles_n;
   const int OHW = p.OH * p.OW;
   const long long M = (long long)p.N * OHW;
@@ -162,7 +183,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   const int s2_cls = S2 ? (int)(((unsigned)bm * (unsigned)BM) / s2_mq) : 0;  // (oh & 1) * 2 + (ow & 1) of every row of the tile
   const int s2_kh0 = S2 ? (((s2_cls >> 1) + p.pad) & 1) : 0, s2_kw0 = S2 ? (((s2_cls & 1) + p.pad) & 1) : 0;
   const int s2_nh = S2 ? (p.KH - s2_kh0 + 1) / 2 : 0, s2_nw = S2 ? (p.KW - s2_kw0 + 1) / 2 : 0;
-  const int nkt = S2 ? s2_nh * s2_nw * (p.C / BK) : ((K + BK - 1) / BK + G - 1) / G;       // k-tiles walked by each group (tiles past K are all-zero)
+  int nkt = S2 ? s2_nh * s2_nw * (p.C / BK) : ((K + BK - 1) / BK + G - 1) / G;       // k-tiles walked by each group (tiles past K are all-zero)
+  int xk_kt0 = 0;
+  if constexpr (XK) {
+    const int per = (nkt + p.xk_S - 1) / p.xk_S;
+    xk_kt0 = xk_s * per;
+    nkt = nkt - xk_kt0 < per ? nkt - xk_kt0 : per;      // (<= 0 for a trailing copy without k-tiles: it still arrives, with zeros)
+  }
 
   // Operands are read through raw buffer descriptors: an out-of-range byte offset returns zeros, which is how padding
   // taps, stride holes, rows beyond M / OC and the k tail are zero-filled without a branch or a select on the data.
@@ -231,7 +258,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   // loader cursor: k index / tap / channel of this thread's 16-byte chunk in the NEXT k-tile to fetch.  It keeps
   // advancing past K (the ring prefetches beyond the last tile): those chunks are all-zero.
   constexpr int KSTEP = BK * G;        // a group's consecutive tiles are G tiles apart
-  int ld_kc = grp * BK + chunk * EPC, ld_kh, ld_kw, ld_c0;
+  int ld_kc = (grp + xk_kt0) * BK + chunk * EPC, ld_kh, ld_kw, ld_c0;
   if constexpr (S2) {
     ld_c0 = chunk * EPC;
     ld_kh = (s2_nh > 0 && s2_nw > 0) ? s2_kh0 : p.KH;      // a class without taps: every prefetch of the ring is out of range (zeros, no access)
@@ -447,6 +474,33 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       const int cg = t % CGR, rr = t / CGR;
       const int n0 = bn * BN + cg * 8;
       const bool col_ok = n0 < p.OC;                 // OC % 8 == 0: a group is all in or all out
+      __amdgpu_buffer_rsrc_t rs_part;
+      if constexpr (XK) {
+        // publish this block's partial tile ([BM][BN] fp32, row-major) write-through, take a ticket, and leave unless it is the last one
+        const int S = p.xk_S;
+        float* part = p.xk_part + (size_t)xk_tile * (size_t)S * (size_t)(BM * BN);
+        rs_part = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (int)((unsigned)S * (unsigned)(BM * BN) * 4u), 0x00020000);
+#pragma unroll 2
+        for (int row = rr; row < BM; row += RP) {
+          const u32x4_t a = *reinterpret_cast<const u32x4_t*>(tile + row * CP + cg * 8);
+          const u32x4_t b = *reinterpret_cast<const u32x4_t*>(tile + row * CP + cg * 8 + 4);
+          const int off = ((xk_s * BM + row) * BN + cg * 8) * 4;
+          __builtin_amdgcn_raw_buffer_store_b128(a, rs_part, off, 0, 16);            // aux 16 = sc1: write-through, nothing left dirty in this XCD's L2
+          __builtin_amdgcn_raw_buffer_store_b128(b, rs_part, off + 16, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its stores before the block's ticket is taken
+        __syncthreads();
+        volatile unsigned* arrived = reinterpret_cast<volatile unsigned*>(smem_all + BM * CP * 4);      // (past the fp32 tile)
+        if (t == 0) *arrived = __hip_atomic_fetch_add(p.xk_tick + xk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*arrived != (unsigned)(S - 1)) return;
+        if (t == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 may hold lines of the scratch from an earlier tile / launch
+          __hip_atomic_store(p.xk_tick + xk_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every copy has arrived: ready for the next launch
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       float bv[8], sv[8], ss[8], sq[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && col_ok) ? p.bias[n0 + e] : 0.f; sv[e] = (p.scale && col_ok) ? p.scale[n0 + e] : 1.f; ss[e] = 0.f; sq[e] = 0.f; }
@@ -468,7 +522,17 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
           e_pix = (int)(m - (unsigned)e_nb * (unsigned)OHW);
         }
         float v[8];
-        {
+        if constexpr (XK) {      // the S partials in s order, this block's own included (read back: the sum does not depend on who came last)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          for (int q = 0; q < p.xk_S; ++q) {
+            const int off = ((q * BM + row) * BN + cg * 8) * 4;
+            const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs_part, off, 0, 16);
+            const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs_part, off + 16, 0, 16);
+            v[0] += __uint_as_float(a.x); v[1] += __uint_as_float(a.y); v[2] += __uint_as_float(a.z); v[3] += __uint_as_float(a.w);
+            v[4] += __uint_as_float(b.x); v[5] += __uint_as_float(b.y); v[6] += __uint_as_float(b.z); v[7] += __uint_as_float(b.w);
+          }
+        } else {
           const float4 a = *reinterpret_cast<const float4*>(tile + row * CP + cg * 8);
           const float4 b = *reinterpret_cast<const float4*>(tile + row * CP + cg * 8 + 4);
           v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -528,6 +592,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     }
   }
   if (grp_e > 0) return;
+  if constexpr (XK) return;      // (the host only takes XK when the row-vectorised epilogue applies: igemm_xk_ok)
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Rows are visited in
   // increasing order, so (image, pixel) is carried along instead of divided out per row.
@@ -601,6 +666,12 @@ template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, 
 __global__ __launch_bounds__(256 * G, (TM * TN == 1 && G == 1) ? 4 : 1) void igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   igemm_body<T, TM, TN, WR, WC, MODE, VEC, NST, G>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
+}
+
+template <class T, int MODE>
+__global__ __launch_bounds__(256, 4) void igemm_xk_kernel(ConvArgs p) {      // 64x64 tile, K cut over xk_S blocks per tile: see igemm_body, XK
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  igemm_body<T, 1, 1, 2, 2, MODE, true, 3, 1, false, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
 }
 
 template <class T>
@@ -1009,6 +1080,45 @@ static bool igemm_s2_ok(const ConvArgs& a) {
   return true;
 }
 
+// Cross-block K split (igemm_body XK): S copies of the 64x64 tile grid.  Needs the registered scratch on THIS stream (partials + counters), the
+// row-vectorised epilogue (16-byte aligned rows of every epilogue operand) and a 2-byte element type.  Returns S (0 = not applicable).
+template <class T>
+static int igemm_xk_copies(const ConvArgs& a, hipStream_t st, int want) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  if (sizeof(T) != 2 || g_tune.xk < 0 || !g_scratch.ptr || !g_scratch.tick || g_scratch.stream != (void*)st) return 0;
+  if (a.OC <= 32 || a.OC % 8 || a.out_f32) return 0;
+  auto al = [](const void* q) { return ((uintptr_t)q) % 16 == 0; };
+  if (!al(a.out) || (a.res && !al(a.res)) || (a.mask_y && !al(a.mask_y)) || (a.stat_x && !al(a.stat_x))) return 0;
+  if (a.ldout % EPC || a.out_bs % EPC || (a.res && (a.ldres % EPC || a.res_bs % EPC)) || (a.mask_y && (a.ldy % EPC || a.y_bs % EPC)) ||
+      (a.stat_x && (a.ldsx % EPC || a.sx_bs % EPC))) return 0;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const long long nb = ((M + 63) / 64) * ((a.OC + 63) / 64);
+  const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
+  int S = want;
+  if (S <= 0) {
+    // (thresholds from tools/bench_conv.py xk on MI355X: the seam -- drain, ticket, acquire, S partial reads -- costs ~4-5 us, so it pays
+    // where the serial k loop of a block is long AND the grid leaves CUs idle; ~512 blocks = two per CU, never fewer than 8 k-tiles per block)
+    if (nb > 160 || nkt < 32) return 0;
+    S = (int)(512 / nb);
+    if (S > 8) S = 8;
+    while (S > 1 && nkt / S < 8) --S;
+  }
+  if (S > nkt) S = nkt;
+  if (S < 2 || nb > SCRATCH_TICKS || (size_t)nb * (size_t)S * 64 * 64 * 4 > g_scratch.bytes) return 0;
+  return S;
+}
+
+template <class T, int MODE>
+static int launch_igemm_xk(const ConvArgs& a0, hipStream_t st, int S) {
+  ConvArgs a = a0;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const long long nb = ((M + 63) / 64) * ((a.OC + 63) / 64);
+  a.xk_S = S; a.xk_part = (float*)g_scratch.ptr; a.xk_tick = g_scratch.tick;
+  hipLaunchKernelGGL((igemm_xk_kernel<T, MODE>), dim3((unsigned)(nb * S)), dim3(256), (size_t)2 * 128 * 144, st, a);
+  return check_launch("emrt_conv2d");
+}
+
 template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
   const long long M = (long long)a.N * a.OH * a.OW;
@@ -1034,6 +1144,12 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
     }
   }
   if (a.OC <= 32) return launch_igemm<T, 2, 1, 4, 1, MODE, VEC>(a, st);
+  if constexpr (VEC && sizeof(T) == 2) {
+    if (!g_tune.conv_tile) {
+      const int S = igemm_xk_copies<T>(a, st, g_tune.xk > 0 ? g_tune.xk : 0);
+      if (S >= 2) return launch_igemm_xk<T, MODE>(a, st, S);
+    }
+  }
   if constexpr (VEC && sizeof(T) == 2) {
     // the 256 x 256 LDS-DMA kernel (igemm8p.hpp) wins once its grid covers most of the 256 CUs (one 128 KiB block per CU), or about half
     // of them with a long k loop; measured with tools/bench_conv.py big: UpHead conv_2 214 -> 149 us, cls_psp.0 dgrad 154 -> 110 us at
@@ -1103,6 +1219,7 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.ldres = ldres; a.res_bs = res_bs;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu; a.out_f32 = out_f32; a.cmajor = g_tune.igemm8p_cmajor; a.stats = bn_stats;
   a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
+  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr;
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
@@ -1733,6 +1850,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(!stat_x || mask_y, "stat_x replaces the mask tensor in the second statistic: it needs mask_y");
   d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dilation; d.relu = 0; d.out_f32 = 0; d.cmajor = g_tune.igemm8p_cmajor; d.stats = bn_stats;
   d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale; d.stat_x = stat_x; d.ldsx = ldsx; d.sx_bs = sx_bs;
+  d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr;
   WgradArgs w;
   w.x = x; w.dy = dy; w.dw = dw;
   w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
@@ -1801,6 +1919,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.ldres = d.ldres; a.res_bs = d.res_bs;
   a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = 0; a.cmajor = 0; a.stats = d.bn_stats;
   a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
+  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr;
 }
 
 template <class T>
@@ -1869,6 +1988,7 @@ static int conv_dgrad_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStr
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
     d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.cmajor = 0; d.stats = nullptr;
     d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
+    d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr;
     const long long Md = (long long)d.N * d.OH * d.OW;
     g.first[i] = (int)total;
     total += ((Md + 63) / 64) * ((d.OC + 63) / 64);
@@ -1903,6 +2023,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
     d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.cmajor = 0; d.stats = nullptr;
     d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
+    d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr;
     WgradArgs& w = g.w[i];
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;
     w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;
@@ -2084,6 +2205,11 @@ static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t s
   for (int i = 0; i < n; ++i) {
     WgradArgs a;
     wgrad_args_from_desc(a, descs[i]);
+    // a weight used more than once in the step (a shared layer) appears as several problems with the same dw: a stored tile of one would
+    // race with the atomic adds of the other (same launch), or land after them ('alone' problems are launched before the pended batch):
+    // every problem whose dw another problem of this call also writes accumulates
+    for (int j = 0; j < n && a.overwrite; ++j)
+      if (j != i && descs[j].dw == descs[i].dw) a.overwrite = 0;
     bool alone = !wgrad_is_vec<T>(a) || a.KH * a.KW * a.C >= 32768 * 128 || a.OC >= 32768 * 128;     // (tile counts are shorts)
     if constexpr (std::is_same<T, bf16_t>::value) {
       int tk, toc, S8, per;

@@ -30,6 +30,7 @@ const TuneEntry kTune[] = {
     {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160}, {"igemm8p_cmajor", &emrt::Tuning::igemm8p_cmajor, 0},
     {"wgrad8p_min_steps", &emrt::Tuning::wgrad8p_min_steps, 8}, {"wgrad8p_slab", &emrt::Tuning::wgrad8p_slab, 1}, {"wgrad8p_force", &emrt::Tuning::wgrad8p_force, 0}, {"wgrad8p_xcd", &emrt::Tuning::wgrad8p_xcd, 1},
     {"wgrad_no_overwrite", &emrt::Tuning::wgrad_no_overwrite, 0}, {"no_ksplit128", &emrt::Tuning::no_ksplit128, 0}, {"ln_bwd_rows", &emrt::Tuning::ln_bwd_rows, 0}, {"ln_bwd_max_blocks", &emrt::Tuning::ln_bwd_max_blocks, 0}, {"bn_operand_blocks", &emrt::Tuning::bn_operand_blocks, 0}, {"no_s2_dgrad", &emrt::Tuning::no_s2_dgrad, 0}, {"wgroup_blocks", &emrt::Tuning::wgroup_blocks, 1024}, {"wgroup_min_steps", &emrt::Tuning::wgroup_min_steps, 32}, {"wgroup_max", &emrt::Tuning::wgroup_max, 0},
+    {"xk", &emrt::Tuning::xk, 0},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;
@@ -47,13 +48,24 @@ emrt::Tuning tuning_from_env() {
 }
 }  // namespace
 emrt::Tuning emrt::g_tune = tuning_from_env();
-emrt::Scratch emrt::g_scratch = {nullptr, 0, nullptr};
+emrt::Scratch emrt::g_scratch = {nullptr, 0, nullptr, nullptr};
 
 extern "C" int emrt_set_scratch(void* ptr, size_t bytes, void* stream) {
   EMRT_REQUIRE((ptr != nullptr) == (bytes > 0) && ((uintptr_t)ptr) % 256 == 0, "scratch must be 256-byte aligned device memory (or nullptr, 0)");
   emrt::g_scratch.ptr = ptr;
   emrt::g_scratch.bytes = bytes;
   emrt::g_scratch.stream = stream;
+  emrt::g_scratch.tick = nullptr;
+  // a region of more than 1 MiB gives its last 64 KiB to the arrival counters of the cross-block K split; they are zeroed HERE, once, on the
+  // registered stream (an enqueued memset, no synchronisation) and every launch leaves them zero again
+  if (ptr && bytes >= (1u << 20) + emrt::SCRATCH_TICK_BYTES && bytes % 256 == 0) {
+    emrt::g_scratch.bytes = bytes - emrt::SCRATCH_TICK_BYTES;
+    emrt::g_scratch.tick = reinterpret_cast<unsigned*>(static_cast<char*>(ptr) + emrt::g_scratch.bytes);
+    if (hipMemsetAsync(emrt::g_scratch.tick, 0, emrt::SCRATCH_TICK_BYTES, (hipStream_t)stream) != hipSuccess) {
+      emrt::g_scratch.tick = nullptr;
+      return emrt::fail("emrt_set_scratch", "cannot zero the arrival counters");
+    }
+  }
   return 0;
 }
 

@@ -1190,7 +1190,11 @@ extern "C" int emrt_adaptive_avgpool_bwd(const void* dout, long long do_bs, int 
   const int esz = dtype == EMRT_F32 ? 4 : 2;
   const bool vec = C % 4 == 0 && do_ld % 4 == 0 && do_bs % 4 == 0 && di_ld % 4 == 0 && di_bs % 4 == 0 &&
                    ((uintptr_t)dout % (4 * esz) == 0) && ((uintptr_t)din % (4 * esz) == 0);
-  if (vec && H + W <= 512) {
+  // the table kernel keeps at most TWO bins per row / column and scale, which holds while every scale k <= min(H, W) (bins then overlap by at
+  // most one pixel); a pooled map smaller than a scale (k > S: a pixel can belong to 3 or more bins) takes the general gather kernels
+  bool two_bins = true;
+  for (int i = 0; i < nscales; ++i) two_bins = two_bins && scales[i] <= (H < W ? H : W);
+  if (vec && H + W <= 512 && two_bins) {
     const int grid = ew_grid((long long)N * H * W * (C / 4));
     DT2(dtype, adaptive_pool_bwd_tab_kernel, grid, a);
   } else if (vec) {

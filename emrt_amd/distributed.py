@@ -48,6 +48,15 @@ def visible_gpu_count():
         n = 0
     if n == 0:      # no readable topology (containers without /sys/class/kfd): torch's count (on this image it does not initialise HIP either)
         return torch.cuda.device_count()
+    # containers may list every node of the host but expose fewer render devices: a GPU without an accessible /dev/dri/renderD* node cannot be
+    # opened, so it is not counted (no render nodes visible at all = nothing to cross-check against)
+    try:
+        rd = [d for d in os.listdir("/dev/dri") if d.startswith("renderD")]
+        usable = sum(os.access(os.path.join("/dev/dri", d), os.R_OK | os.W_OK) for d in rd)
+        if rd and usable:
+            n = min(n, usable)
+    except OSError:
+        pass
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -93,9 +102,10 @@ def spawn_ranks(n, cmd, capture_rank0=False, log=None):
     def on_term(signum, frame):
         raise KeyboardInterrupt("signal %d" % signum)
     import signal
-    old_term = None
+    old_term, hooked = None, False
     if threading.current_thread() is threading.main_thread():
         old_term = signal.signal(signal.SIGTERM, on_term)     # a plain SIGTERM would end this process without running `finally`
+        hooked = True
     try:
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -112,8 +122,8 @@ def spawn_ranks(n, cmd, capture_rank0=False, log=None):
             time.sleep(0.2)
     finally:
         kill_all()                                            # normal end: everything has exited already; early end: nothing survives
-        if old_term is not None:
-            signal.signal(signal.SIGTERM, old_term)
+        if hooked:      # (signal.signal returns None for a disposition that was not installed from Python: that restores to the default)
+            signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
     codes = [p.returncode for p in procs]
     if reader is not None:
         reader.join(timeout=10)
@@ -148,6 +158,7 @@ class FlatGradReducer:
         self.slices = bucket_slices(n, bucket_elems)
         self.handles = []
         self.always = always        # issue the collectives even in a 1-rank group (single-GPU test of the N > 1 path)
+        self.noop = False           # never set by the product: launch() then returns without a collective (what the exchange costs = with - without)
         assert exchange_dtype in ("fp32", "bf16")
         self.exchange_dtype = exchange_dtype
         self.half = torch.empty(n, dtype=torch.bfloat16, device=flat_grad.device) if exchange_dtype == "bf16" else None
@@ -166,7 +177,7 @@ class FlatGradReducer:
         accumulate until wait(), so an early launch(early_ranges) can overlap the rest of backward."""
         if self.world <= 1 and not self.always:
             return
-        if self.world <= 1 and os.environ.get("EMRT_EXCHANGE_NOOP"):      # measurement aid (1-rank group only): the step structure without the collective
+        if self.noop:      # set by a measurement harness only (bench.py: exchange_exposed_ms, --exchange-noop): the step structure without the collective
             return
         use_avg = dist.get_backend() == "nccl"
         slices = self.slices if ranges is None else [b for a, e in ranges for b in bucket_slices(e, self.bucket, a)]

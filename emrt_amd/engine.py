@@ -183,6 +183,10 @@ class TrainEngine:
         self.images = images.clone()
         self.labels = labels.clone()
         c.workspace(64 << 20)
+        # the weight-gradient scratch is registered by the first bf16 training step, but never from inside a capture: when the captured
+        # step IS the first one (warmup_eager=0, a re-capture after init_device) it has to exist before the capture begins, or the graph
+        # is baked with the slab path of the 256 x 256 weight-gradient kernel switched off for good
+        c.ensure_scratch()
         torch.cuda.synchronize()
         # other threads make HIP calls while this one captures: ProcessGroupNCCL's watchdog polls events, the TileLoader's reader threads
         # page-lock their batches (train.py --data dataset).  The default "global" capture mode turns any such foreign-thread call into a

@@ -305,6 +305,11 @@ def defer_wgrad(tape, x, dy, w, geom, stride, pad, dil):
     # first contribution to this weight's gradient since ParamStore.zero_grad(): dW is still all zero, a one-slice launch may store its tiles
     fresh = int(getattr(w, "grad_is_zero", False))
     w.grad_is_zero = False
+    # a weight used twice in one step (a shared layer): its earlier contribution may be queued as "dW is zero: store the tile"; that
+    # launch must be on the stream before this one's adds are (emrt_conv2d_wgrad_group also drops the store for aliased problems)
+    dwp = w.grad.data_ptr()
+    if any(f[2] == dwp for f, _keep in tape.wgrads):
+        tape.flush_wgrads()
     tape.wgrads.append(((x.data_ptr(), dy.data_ptr(), w.grad.data_ptr(), w.bias_grad.data_ptr() if w.bias is not None else None,
                          N, H, Wd, C, ldx, x_bs, OH, OW, w.OC, lddy, dy_bs, w.KH, w.KW, stride, pad, dil, fresh), (x, dy)))
     if len(tape.wgrads) >= ctx().wgrad_batch:
@@ -663,7 +668,11 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
                       dilation=getattr(conv, "dilation", 1), out_scale=scale, out_shift=shift)
     sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
     y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums, dilation=getattr(conv, "dilation", 1))
-    if defer and c.training and c.bn_defer and residual is None and out is None and ((bn.C % 8 == 0 and 256 % (bn.C // 8) == 0) or defer == "join"):
+    # what the consumers' fused entry points accept (emrt_bn_resize_bilinear_fwd, emrt_bn_maxpool_fwd: C <= 1024 and C / (elements per 16 bytes)
+    # a divisor of 256 -- C / 4 in fp32); a PendingBN has no fallback once created, so anything else takes the separate emrt_bn_apply here
+    per16 = 4 if c.dtype == F32 else 8
+    fits = bn.C % per16 == 0 and bn.C <= 1024 and 256 % (bn.C // per16) == 0
+    if defer and c.training and c.bn_defer and residual is None and out is None and (fits or defer == "join"):
         count = y.shape[0] * y.shape[1] * y.shape[2]
         if _sync_active(bn.state):
             count = _allreduce_sums(sums, count)

@@ -303,6 +303,8 @@ class Context:
         self._ws = torch.empty(8 << 20, dtype=torch.uint8, device=self.device)
         # (the partial-sum scratch of the 256 x 256 weight-gradient kernel is allocated by the first TRAINING step in bf16: begin_step)
         if getattr(self, "_scratch", None) is not None and self._scratch.device != self.device:
+            # the library keeps the registered pointer: withdraw it before the tensor (and its memory) goes away
+            _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(0), ctypes.c_size_t(0), ctypes.c_void_p(0))
             self._scratch = None
         self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -361,13 +363,15 @@ class Context:
         self.ensure_scratch()
 
     def ensure_scratch(self):
-        """Partial-sum scratch of the 256 x 256 weight-gradient kernel (one 256 KiB fp32 tile per CU = 64 MiB), registered for THIS
-        context's stream by the first bf16 training step -- the only kernel that uses it is bf16-only and backward-only, so inference,
-        validation and fp32 contexts never pay for it.  Its address is baked into captured graphs: allocated once, outside any capture
-        (the eager warm-up steps come first), never reallocated."""
-        if self.dtype != BF16 or getattr(self, "_scratch", None) is not None or torch.cuda.is_current_stream_capturing():
+        """Partial-sum scratch of the 256 x 256 weight-gradient kernel (one 256 KiB fp32 tile per CU = 64 MiB) and of the convolutions'
+        cross-block K split, registered for THIS context's stream by the first bf16 / fp16 forward -- fp32 contexts (the parity mode) never
+        pay for it and never take those kernels.  Its address is baked into captured graphs: allocated once, outside any capture (the eager
+        warm-up steps come first; TrainEngine._capture and SlidingWindowEngine make sure of it), never reallocated."""
+        if self.dtype == F32 or getattr(self, "_scratch", None) is not None or torch.cuda.is_current_stream_capturing():
             return
-        self._scratch = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+        # + 64 KiB: the arrival counters of the convolutions' cross-block K split (csrc/conv.hip, igemm_body XK), carved off the tail and zeroed by
+        # emrt_set_scratch; the split's partial tiles (<= 8 MiB) share the slab with the weight-gradient kernel -- same stream, one after the other
+        self._scratch = torch.empty((64 << 20) + 65536, dtype=torch.uint8, device=self.device)
         st = self.stream
         if self.wgrad_side:          # (every weight gradient, the large layers' included, is then launched from the side stream)
             if self._wside is None:
@@ -378,6 +382,7 @@ class Context:
     def end_step(self):
         """Outside a training step (eval forward) the arena is not re-zeroed: zeros_f64() must hand out fresh zeroed buffers."""
         self._arena_live = False
+        self.ensure_scratch()          # (fp16 / bf16 inference: the few-tile layers' cross-block K split needs its partial-tile scratch too)
 
     def zeros_f64(self, n):
         """Zeroed fp64 [n] buffer (BatchNorm sums).  Inside a step it is a slice of the pre-zeroed arena."""

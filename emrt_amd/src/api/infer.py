@@ -180,6 +180,7 @@ class SlidingWindowEngine:
             return self.pred
         if self.graph is None:
             self.image = img.contiguous().clone()
+            ctx().ensure_scratch()      # (registered outside the capture: the captured kernels bake its address in)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):      # (reader threads of a validation loader may make HIP calls meanwhile)

@@ -1,4 +1,5 @@
-"""CPU: the data-parallel plumbing over gloo with world_size 2 (the RCCL path is the same code with backend "nccl"):
+"""CPU: the data-parallel plumbing over gloo with world_size 2, 4 and 8 -- BASELINE configs[3]'s rank count and the driver's other
+scaling points -- (the RCCL path is the same code with backend "nccl"):
 flat-gradient averaging in buckets, rank-strided tile sharding, and the DP identity the reducer must deliver --
 rank-averaged gradients == gradients of the concatenated batch."""
 import os
@@ -21,6 +22,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from emrt_amd.distributed import FlatGradReducer, DistributedTileSampler, init_process_group
+    torch.set_num_threads(max(1, 8 // world))          # (the ranks share this machine's cores)
     r, lr, w = init_process_group("gloo")
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
     try:
@@ -87,15 +89,25 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(gathered, mine_idx)
         allidx = [i for l in gathered for i in l]
         assert len(mine_idx) == len(s) * 4 and len(set(allidx)) >= 32 and set(allidx) <= set(range(37))
+        # drop_last: every rank the same number of whole batches, no index handed to two ranks (src/utils/dataloader.py:38-41)
+        assert len(allidx) == world * len(s) * 4 == len(set(allidx)) and len({len(l) for l in gathered}) == 1
         s.set_epoch(3)
         assert [i for b in s for i in b] != mine_idx
+        # the reference's recipe at configs[3]'s size: 8 tiles per rank (config.py:10), every sample seen at most once per epoch
+        big = DistributedTileSampler(3456, 8, rank, world, shuffle=True, drop_last=True, seed=1234)
+        big.set_epoch(0)
+        mine_big = [i for b in big for i in b]
+        dist.all_gather_object(gathered, mine_big)
+        flat_big = [i for l in gathered for i in l]
+        assert len(flat_big) == len(set(flat_big)) == (3456 // (8 * world)) * 8 * world and all(len(b) == 8 for b in big)
         q.put((rank, "ok"))
     finally:
         dist.destroy_process_group()
 
 
-def test_gloo_world_size_2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gloo_world_size(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -103,9 +115,12 @@ def test_gloo_world_size_2():
         p.start()
     for p in procs:
         p.join(240)
+    for p in procs:
+        if p.is_alive():
+            p.kill()          # (exactly the processes started here)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = sorted(q.get(timeout=5) for _ in range(world))
-    assert got == [(0, "ok"), (1, "ok")]
+    assert got == [(r, "ok") for r in range(world)]
 
 
 def test_bucket_slices():

@@ -159,3 +159,78 @@ def test_stride2_data_gradient_parity_class_kernel(case):
     print("%s: dx vs torch rel %.2e; parity-class kernel == generic kernel: %s" % (name, rel, torch.equal(got[0], got[1])))
     assert rel < 4e-3, rel
     assert torch.equal(got[0], got[1]), (got[0] - got[1]).abs().max().item()
+
+
+# cross-block K split (csrc/conv.hip: igemm_body XK): S copies of the 64x64 tile grid, partial tiles through the registered scratch, the last
+# block to arrive sums them and runs the epilogue.  Forced on every fuzz geometry (ragged M / OC / K tails, stride, dilation, bias), forward
+# and data gradient (pair_max 0, batched weight gradients: the data gradient is its own launch), S = 2 / 3 / 8 (3: copies with unequal k ranges;
+# 8 on the short-K cases: trailing copies with NO k-tile, which still have to arrive)
+@pytest.mark.parametrize("copies", [2, 3, 8])
+@pytest.mark.parametrize("case", BIG, ids=[c[0] for c in BIG])
+def test_conv_random_geometry_cross_block_k_split(case, copies):
+    L_ = _lib.lib()
+    old = [(k, L_.set_tuning(k, v)) for k, v in (("xk", copies), ("pair_max", 0))]
+    try:
+        from tests.hip_utils import init
+        from emrt_amd.runtime import BF16
+        init(BF16)
+        L_.start_record()
+        _conv_case_vs_torch(case, dilation=case[10])
+        names = [n for n, _ in L_.stop_record()]
+        assert "emrt_conv2d" in names
+    finally:
+        for k, v in old:
+            L_.set_tuning(k, v)
+
+
+def test_cross_block_k_split_is_bit_reproducible_under_uneven_load():
+    """The hand-off (sc1 partial stores -> every wave drains -> ticket -> the last arriver's agent-scope acquire -> partial loads) must not
+    depend on dispatch order, timing or placement: the same layer is launched 300 times while OTHER kernels of varying size run before it
+    (the consuming CUs' L1 then holds lines of the scratch from the previous launch: a missing acquire reads stale partials), with the
+    BatchNorm-statistics epilogue on; every launch's output must be bit-identical to the first (its fp64 sums equal to 1e-12), and equal the unsplit kernel's
+    result to fp32 summation-order noise.  Layer4's 3x3 (8 x 8 x 8 x 512 -> 512: 64 tiles, 72 k-tiles) and the auxiliary head's 16 x 16 x 1024 3x3."""
+    import ctypes
+    from tests.hip_utils import init
+    from emrt_amd.runtime import BF16
+    c = init(BF16)
+    L_ = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    g = torch.Generator().manual_seed(5)
+    for (N, H, W, C, OC, k, S) in ((8, 8, 8, 512, 512, 3, 8), (8, 16, 16, 1024, 256, 3, 4), (3, 7, 9, 256, 320, 3, 5)):
+        x = torch.randn(N, H, W, C, generator=g).cuda().bfloat16()
+        w = (torch.randn(OC, k, k, C, generator=g) / (k * k * C) ** 0.5).cuda().bfloat16()
+        y = torch.empty(N, H, W, OC, device="cuda", dtype=torch.bfloat16)
+        stats = torch.zeros(8 * 2 * OC, device="cuda", dtype=torch.float64)
+        junk = [torch.randn(n, device="cuda") for n in (1 << 12, 1 << 18, 1 << 22, 1 << 24)]
+
+        def run():
+            stats.zero_()
+            L_.call("emrt_conv2d", P(x), P(w), P(y), None, None, N, H, W, C, C, H * W * C, H, W, OC, OC, H * W * OC, 0, 0,
+                    k, k, 1, k // 2, 0, 1, 0, P(stats), None, 0, 0, 1, None, BF16, c.stream)
+        old = L_.set_tuning("xk", -1)
+        run()
+        torch.cuda.synchronize()
+        ref, ref_stats = y.float().clone(), stats.clone()
+        L_.set_tuning("xk", S)
+        try:
+            L_.start_record()
+            run()
+            assert [n for n, _ in L_.stop_record()] == ["emrt_conv2d"]
+            torch.cuda.synchronize()
+            first, first_stats = y.clone(), stats.clone()
+            rel = ((first.float() - ref).norm() / ref.norm()).item()
+            assert rel < 2e-3, rel           # bf16 outputs of two fp32 summation orders: the occasional last-bit flip
+            assert ((first_stats - ref_stats).abs().max() / ref_stats.abs().max()).item() < 1e-3
+            bad = 0
+            for i in range(300):
+                junk[i % 4].mul_(1.0001)                       # another kernel of a different size in front: uneven load, warm L1s
+                if i % 3 == 0:
+                    junk[(i + 1) % 4].add_(1e-6)
+                run()
+                if i % 10 == 9 or i < 20:
+                    torch.cuda.synchronize()
+                    # (the statistics are fp64 atomics of several tiles' column sums into 8 replicas: their ORDER is free, as in every conv kernel)
+                    bad += int(not torch.equal(y, first)) + int(not torch.allclose(stats, first_stats, rtol=1e-12, atol=1e-9))
+            assert bad == 0, "%d of the checked launches differed from the first (N%d %dx%dx%d->%d, S=%d)" % (bad, N, H, W, C, OC, S)
+        finally:
+            L_.set_tuning("xk", old)

@@ -160,3 +160,62 @@ def test_first_contribution_is_stored_and_later_ones_are_added(dtype):
         assert ((tw - 2 * rw).norm() / rw.norm()).item() < 2 * tol, (i, geoms[i])
         if db is not None:
             assert ((tb - 2 * rb).norm() / rb.norm()).item() < 2 * tol
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "fp32"])
+def test_a_weight_used_twice_in_one_step_sums_both_contributions(dtype):
+    """A shared layer: the same conv applied to two inputs on one tape.  Its first weight gradient is queued as 'dW is zero:
+    store the tile', the second as an add; stored tiles must never race with (or land after) the other use's atomic adds.  Few pixels and a
+    large dW, i.e. the one-slice case where the store path is taken; the sum must equal torch's, and the same through the C-ABI with both
+    problems in ONE call (the library drops the store for problems whose dw aliases another problem's)."""
+    import ctypes
+    from emrt_amd import functional as Fn
+    c = init(dtype)
+    c.wgrad_batch = 24
+    g = torch.Generator().manual_seed(77)
+    N, H, W, Cin, Cout = 1, 6, 6, 512, 512
+    conv = hnn.Conv2D(Cin, Cout, 3, 1, 1, bias=True)
+    other = hnn.Conv2D(Cin, 256, 1, 1, 0, bias=False)          # an unrelated layer between the two uses
+    with torch.no_grad():
+        conv.weight.copy_(rnd(torch.randn(Cout, Cin, 3, 3, generator=g) / 68))
+        other.weight.copy_(rnd(torch.randn(256, Cin, 1, 1, generator=g) / 23))
+    wr = conv.weight.detach().clone().requires_grad_(True)          # (host copy: place() moves the parameter into the device store)
+    holder = Holder(conv=conv, other=other).place()
+    xs = [rnd(torch.randn(N, Cin, H, W, generator=g)) for _ in range(3)]
+    dys = [rnd(torch.randn(N, Cout, H, W, generator=g)) for _ in range(2)] + [rnd(torch.randn(N, 256, H, W, generator=g))]
+    br = torch.zeros(Cout, requires_grad=True)
+    for x, dy in zip(xs[:2], dys[:2]):
+        F.conv2d(x, wr, br, padding=1).backward(dy)
+    tol = 1e-3 if dtype == BF16 else 2e-5
+    for trial in range(3):          # (a race would not show every time)
+        holder.store.grad.fill_(3.0)
+        holder.store.zero_grad()
+        tape = Tape()
+        c.tape = tape
+        xd = [dev_map(x) for x in xs]
+        ys = [conv(xd[0]), other(xd[2]), conv(xd[1])]
+        c.tape = None
+        for y, dy in zip(ys, [dys[0], dys[2], dys[1]]):
+            tape.add_grad(y, dev_map(dy))
+        tape.backward()
+        torch.cuda.synchronize()
+        rel = ((host(conv.weight.grad) - wr.grad).norm() / wr.grad.norm()).item()
+        relb = ((host(conv.bias.grad) - br.grad).norm() / br.grad.norm()).item()
+        assert rel < tol and relb < tol, (trial, rel, relb)
+    # the C-ABI alone: two descriptors with the same dw, both claiming "dw is zero", in one call
+    xd = [dev_map(x) for x in xs[:2]]
+    dyd = [dev_map(dy) for dy in dys[:2]]
+    for trial in range(3):
+        conv.weight.grad.zero_()
+        conv.bias.grad.zero_()
+        arr = (Fn._WgradDesc * 2)()
+        for d, x_, dy_ in zip(arr, xd, dyd):
+            _, _, _, _, ldx, x_bs = Fn._check_map(x_)
+            _, _, _, _, lddy, dy_bs = Fn._check_map(dy_)
+            (d.x, d.dy, d.dw, d.dbias, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, d.KH, d.KW, d.stride, d.pad,
+             d.dilation, d.dw_is_zero) = (x_.data_ptr(), dy_.data_ptr(), conv.weight.grad.data_ptr(), conv.bias.grad.data_ptr(), N, H, W, Cin,
+                                          ldx, x_bs, H, W, Cout, lddy, dy_bs, 3, 3, 1, 1, 1, 1)
+        _lib.lib().call("emrt_conv2d_wgrad_group", arr, 2, c.dtype, c.stream)
+        torch.cuda.synchronize()
+        rel = ((host(conv.weight.grad) - wr.grad).norm() / wr.grad.norm()).item()
+        assert rel < tol, (trial, rel)

@@ -110,3 +110,38 @@ def test_bench_without_gpus_flag_takes_the_launchers_world_size():
             os.environ.pop("WORLD_SIZE", None)
         else:
             os.environ["WORLD_SIZE"] = old
+
+
+def test_spawn_ranks_at_eight_ranks():
+    """BASELINE configs[3]: 8 ranks, one per GPU of the node -- the rank environment every child gets."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from emrt_amd.distributed import spawn_ranks\n"
+            "child = 'import os; open(os.environ[\"OUT\"] + os.environ[\"RANK\"], \"w\").write(\" \".join(os.environ[k] for k in "
+            "(\"RANK\", \"LOCAL_RANK\", \"WORLD_SIZE\", \"LOCAL_WORLD_SIZE\", \"MASTER_ADDR\", \"HSA_ENABLE_IPC_MODE_LEGACY\")))'\n"
+            "codes, _ = spawn_ranks(8, [sys.executable, '-c', child])\n"
+            "print(codes)\n" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        r = _run([sys.executable, "-c", code], EMRT_ALL_RANKS_ON_GPU0="1", OUT=os.path.join(d, "rank"))
+        assert r.returncode == 0 and r.stdout.strip() == str([0] * 8), (r.stdout, r.stderr)
+        got = [open(os.path.join(d, "rank%d" % i)).read() for i in range(8)]
+    assert got == ["%d %d 8 8 127.0.0.1 0" % (i, i) for i in range(8)], got
+
+
+def test_bench_dry_run_validates_the_eight_rank_plan_without_a_gpu():
+    """`bench.py --gpus 8 --dry-run`: eight rank processes, a gloo rendezvous, and the N > 1 step's plan compared across ranks -- the three
+    gradient-exchange ranges tile the trainable part of the flat buffer, the five SyncBatchNorm layers (paddle_EMRT.py:64, fcn_head.py:53)
+    form the statistics group, every rank gets the same number of distinct tiles.  No GPU and no libemrt_hip.so involved."""
+    import json
+    r = _run([sys.executable, "bench.py", "--gpus", "8", "--dry-run"], EMRT_HIP_LIB="/nonexistent/libemrt_hip.so")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] and d["ok"] and d["n_gpus"] == 8 and d["global_batch"] == 64 and not d["problems"]
+    assert sum(x["elements"] for x in d["exchange_ranges"]) == d["gradient_elements"] and len(d["exchange_ranges"]) == 3
+    assert 0.80 < d["exchange_ranges"][0]["elements"] / d["gradient_elements"] < 0.88          # heads + transformer + layer4 go first
+    assert d["exchange_ranges"][2]["mbytes_fp32"] < 8                                          # the one exposed collective is small
+    assert len(d["sync_batchnorm_layers"]) == 5 and d["sync_batchnorm_layers"][-1].startswith("auxlayer")
+    # under a launcher whose size disagrees with --gpus the dry run fails before any rendezvous
+    r = _run([sys.executable, "bench.py", "--gpus", "8", "--dry-run"], WORLD_SIZE="4", RANK="0")
+    assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 8" in r.stderr

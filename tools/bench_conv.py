@@ -247,8 +247,60 @@ def s2():
     print("sum: generic %.1f us  parity-class %.1f us" % tuple(tot))
 
 
+def xk():
+    """Cross-block K split (igemm_body XK) on the step's few-tile, long-K layers: the old choice (xk = -1: in-block wave-group split) against S = 2 / 4 / 8
+    copies of the tile grid, forward and data gradient; agreement with the old kernel and bit-reproducibility of the split over 20 launches."""
+    scratch = torch.empty((64 << 20) + 65536, dtype=torch.uint8, device=dev)
+    L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()), stream)
+    shapes = [(8, 16, 16, 256, 256, 3, 1, 1), (8, 8, 8, 512, 512, 3, 1, 1), (8, 8, 8, 2048, 512, 1, 1, 0), (8, 8, 8, 512, 2048, 1, 1, 0),
+              (8, 16, 16, 1024, 256, 3, 1, 1), (8, 16, 16, 1024, 256, 1, 1, 0), (8, 16, 16, 256, 1024, 1, 1, 0), (8, 16, 16, 512, 512, 3, 2, 1),
+              (8, 8, 8, 256, 256, 3, 1, 1), (8, 32, 32, 256, 256, 3, 1, 1), (8, 32, 32, 512, 128, 1, 1, 0), (8, 1, 110, 1024, 256, 1, 1, 0),
+              (16, 8, 8, 512, 512, 3, 1, 1), (16, 16, 16, 256, 256, 3, 1, 1), (4, 16, 16, 512, 512, 3, 1, 1), (4, 32, 32, 256, 256, 3, 1, 1)]
+    for (N, H, W, C, OC, k, s, pad) in shapes:
+        OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        x = torch.randn(N, H, W, C, device=dev).bfloat16()
+        wf = (torch.randn(OC, k, k, C, device=dev) / (k * k * C) ** 0.5).bfloat16()
+        wb = (torch.randn(C, k, k, OC, device=dev) / (k * k * OC) ** 0.5).bfloat16()
+        dy = torch.randn(N, OH, OW, OC, device=dev).bfloat16()
+        y = torch.empty(N, OH, OW, OC, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty_like(x)
+        stats = torch.zeros(8 * 2 * max(C, OC), device=dev, dtype=torch.float64)
+        gf = 2.0 * N * OH * OW * OC * k * k * C / 1e9
+
+        def fwd():
+            L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC, 0, 0,
+                               k, k, s, pad, 0, 0, 0, P(stats), None, 0, 0, 1, None, 1, stream)
+
+        def dgrad():
+            L._raw_emrt_conv2d(P(dy), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0,
+                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, None, 1, stream)
+        tiles = ((N * OH * OW + 63) // 64) * ((OC + 63) // 64)
+        line = "N%d %dx%dx%d->%d k%d s%d %6.2f GF, %4d fwd tiles, %3d k-tiles |" % (N, H, W, C, OC, k, s, gf, tiles, k * k * C // 64)
+        for nm, fn, out in (("fwd", fwd, y), ("dgrad", dgrad, dx)):
+            res, outs = [], []
+            for knob in (-1, 0, 2, 4, 8):
+                old = L.set_tuning("xk", knob)
+                fn()
+                torch.cuda.synchronize()
+                outs.append(out.float().clone())
+                res.append(min(timed(fn, 20), timed(fn, 20)))
+                same = True
+                if knob > 0:
+                    for _ in range(20):
+                        fn()
+                        same = same and torch.equal(out.float(), outs[-1])
+                L.set_tuning("xk", old)
+                res[-1] = (res[-1], same)
+            rel = max(((o - outs[0]).norm() / outs[0].norm()).item() for o in outs[1:])
+            line += " %s old %.1f auto %.1f S2 %.1f S4 %.1f S8 %.1f us  rel %.1e %s |" % (nm, res[0][0], res[1][0], res[2][0], res[3][0], res[4][0], rel,
+                                                                                          "reproducible" if all(r[1] for r in res) else "NOT REPRODUCIBLE")
+        print(line, flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "xk":
+        return xk()
     if which == "s2":
         return s2()
     if which == "wgroup":

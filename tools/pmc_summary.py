@@ -1,6 +1,7 @@
 """Summarise the rocprofv3 passes of one eager bench run per config into profiles/ (tools/profile_round.sh):
 
     python tools/pmc_summary.py <fetch dir> <write dir> <dst prefix> [<sq dir> <trace dir> <calls.txt>]
+    python tools/pmc_summary.py <fetch dir> <write dir> <dst prefix> --calls <calls.txt>        (no per-layer table: the call counts only)
 
   <dst>.csv   per kernel: dispatches, FETCH_SIZE / WRITE_SIZE KB per dispatch, corrected traffic
   <dst>.json  per kernel FAMILY: bytes per dispatch and dispatches per step -- what bench.py attaches to `roofline.traffic`
@@ -29,10 +30,16 @@ def short(name):
 
 
 def last_step(names):
-    """Index range of the last complete step: between the last two optimizer kernels (a training run), else the whole list."""
+    """Index range of the last complete step: between the last two optimizer kernels (a training run); an inference run has none and is
+    cut at the kernel that ingests an image (the NCHW -> NHWC layout change of the window batch, once per image): the dispatches of ONE
+    image, from the last-but-one ingest to the last one.  (Round 4 took the whole list there -- all 8 images of the eager run as one
+    "step" -- and bench.py multiplied the per-dispatch traffic by 8 x 117 dispatches: traffic_over_algorithmic 12.3 instead of ~1.5.)"""
     idx = [i for i, n in enumerate(names) if "sgd_momentum" in n]
     if len(idx) >= 2:
         return idx[-2] + 1, idx[-1] + 1
+    idx = [i for i, n in enumerate(names) if "nchw_to_nhwc" in n]
+    if len(idx) >= 2:
+        return idx[-2], idx[-1]
     return 0, len(names)
 
 
@@ -55,7 +62,27 @@ CONV_BWD = lambda k: ("igemm_kernel" in k and re.search(r"igemm_kernel<[^,]+, \d
 CONV_FWD = lambda k: ("igemm" in k or "thin_fwd" in k) and not CONV_BWD(k)
 
 
+CONV_BWD_CALLS = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group", "emrt_bn_pointwise_bwd")
+CONV_FWD_CALLS = ("emrt_conv2d", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
+
+
+def call_counts(calls_path):
+    """C-ABI calls per family in bench.py's --dump-calls file of the SAME command (one replayed step / image): what bench.py compares
+    with its own launch list before it attaches this profile's traffic to a line."""
+    names = [ln.split()[0] for ln in open(calls_path) if ln.strip()]
+    # (a dgrad is an emrt_conv2d call with mode 1 only on the two-stream experiment path: not in the default command)
+    return {"conv_backward_family": sum(n in CONV_BWD_CALLS for n in names), "conv_forward_family": sum(n in CONV_FWD_CALLS for n in names),
+            "all": len(names)}
+
+
 def main():
+    argv = sys.argv[:]
+    calls_only = None
+    if "--calls" in argv:
+        i = argv.index("--calls")
+        calls_only = argv[i + 1]
+        del argv[i:i + 2]
+    sys.argv = argv
     fetch_d, write_d, dst = sys.argv[1:4]
     fetch, write = per_dispatch(fetch_d), per_dispatch(write_d)
     names = [k for k, _, _ in fetch]
@@ -92,6 +119,14 @@ def main():
         js["msda_fwd_kernel_encoder"] = family(lambda k: k == enc_name, enc_grid)
         js["msda_fwd_kernel_encoder"]["kernel"] = enc_name
     js = {k: v for k, v in js.items() if v is not None}
+    js["dispatches_in_step"] = b - a
+    calls_path = calls_only or (sys.argv[6] if len(sys.argv) >= 7 else None)
+    if calls_path:
+        cc = call_counts(calls_path)
+        for fam in ("conv_backward_family", "conv_forward_family"):
+            if fam in js:
+                js[fam]["calls_per_step"] = cc[fam]
+        js["calls_in_step"] = cc["all"]
     json.dump(js, open(dst + ".json", "w"), indent=1)
     print(json.dumps(js, indent=1))
     if len(sys.argv) >= 7:
