@@ -244,6 +244,306 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(MhaArgs a) {
   Vec8<T>::store((T*)a.dv + (r0 + i) * a.lddv + co, dv);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// MFMA path (bf16 / fp16 storage): v_mfma_f32_16x16x32 -- the head dim IS the instruction's K = 32, so a 16 x 16 score tile is ONE MFMA.
+// One block per (batch, head); wave w owns tile w of the (padded) sequence: 16 query rows in the forward, and in the backward the same 16
+// rows as QUERIES (dq) and as KEYS (dk, dv).  Everything is computed TRANSPOSED so that no operand ever needs a lane transpose:
+//     S^T[j][i] = sum_d K[j][d] Q[i][d]          A = rows of K (16 B per lane, straight from global), B = rows of Q
+//   the C/D layout then gives lane (i = lane & 15, g = lane >> 4) the scores of ITS query i against keys j = 16 t + 4 g + r of tile t: the
+//   softmax over j is a reduction over the lane's own registers plus two cross-lane steps (xor 16, 32), and for the second product
+//     O^T[d][i] = sum_j V[j][d] Pd[i][j]         B = the probabilities AS THEY STAND in the accumulator registers (packed pairwise),
+//   with k order permuted: k-step s takes element jj of lane group g from key j = 32 s + 16 (jj >> 2) + 4 g + (jj & 3); the A operand (V^T,
+//   read from a transposed LDS image, two 8-byte reads) uses the same map, and a contraction does not care in which order k is walked
+//   (cdna_hip_programming.md 3, "An accumulator tile as the next MFMA's operand").
+// Saved for backward: (row max, 1 / row sum) per query -- 2 L floats per (batch, head) in the `probs` buffer -- instead of L x L
+// probabilities; the backward recomputes P from them and uses rowdot_i = sum_j dP_ij P_ij from its own row pass.
+// Dropout on the weights (layers.py:297): one 64-bit hash per (query, 4 consecutive keys) = four 16-bit uniforms; forward and backward
+// call the same function, so they agree by construction (the fp32 VALU kernels above keep the per-element hash).
+// 0.07 GMAC per tile: the point is not MFMA throughput but that a (batch, head) is ~100 matrix instructions per wave instead of ~3000
+// dependent VALU instructions per lane: 17 -> ~6 us forward, 38 -> ~8 us backward at B = 8 (64 blocks).
+// ------------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 mha_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 mha_f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float mha_f32x4_t;
+
+template <class T>
+__device__ __forceinline__ mha_f32x4_t mha_mma(const uint4& a, const uint4& b, mha_f32x4_t c);
+template <>
+__device__ __forceinline__ mha_f32x4_t mha_mma<bf16_t>(const uint4& a, const uint4& b, mha_f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mha_bf16x8_t, a), __builtin_bit_cast(mha_bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ mha_f32x4_t mha_mma<f16_t>(const uint4& a, const uint4& b, mha_f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mha_f16x8_t, a), __builtin_bit_cast(mha_f16x8_t, b), c, 0, 0, 0);
+}
+template <class T>
+__device__ __forceinline__ uint32_t mha_pack2(float lo, float hi);
+template <>
+__device__ __forceinline__ uint32_t mha_pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <>
+__device__ __forceinline__ uint32_t mha_pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+
+#define MHA_TP 136      /* pitch (elements) of the transposed [32][128] LDS images: 272-byte rows, 8-byte aligned quads */
+#define MHA_TILES 8     /* 16-row tiles of the padded sequence (L <= 128) */
+
+// 16 bytes of row `r` of a [B * L][ld] operand at head column `col`, zero for rows beyond this (batch, head)'s L
+template <class T>
+__device__ __forceinline__ uint4 mha_row16(const void* base, long long r0, int r, int L, int ld, int col) {
+  if (r >= L) return make_uint4(0u, 0u, 0u, 0u);
+  return *reinterpret_cast<const uint4*>((const T*)base + (r0 + r) * ld + col);
+}
+// the whole block writes the transposed image sXt[d][j] = X[j][d] (j < L, zero up to 128) of one [L][32] operand
+template <class T>
+__device__ __forceinline__ void mha_stage_t(const void* base, long long r0, int L, int ld, int col0, T* sXt) {
+  for (int t = threadIdx.x; t < 128 * 4; t += blockDim.x) {
+    const int j = t >> 2, c = t & 3;
+    const uint4 v = mha_row16<T>(base, r0, j, L, ld, col0 + 8 * c);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sXt[(8 * c + e) * MHA_TP + j].v = (unsigned short)((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+  }
+}
+// A fragment of k-step s for output rows d = 16 dt + (lane & 15): element jj <- column 32 s + 16 (jj >> 2) + 4 g + (jj & 3) of the image
+template <class T>
+__device__ __forceinline__ uint4 mha_frag_t(const T* sXt, int dt, int s, int lane) {
+  const T* row = sXt + (16 * dt + (lane & 15)) * MHA_TP + 32 * s + 4 * (lane >> 4);
+  const uint2 lo = *reinterpret_cast<const uint2*>(row), hi = *reinterpret_cast<const uint2*>(row + 16);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+// four 16-bit uniforms for (row, quad of 4 consecutive columns); keep iff u16 >= thr
+__device__ __forceinline__ void mha_drop4(unsigned long long seed, unsigned salt, unsigned group, uint32_t (&h)[2]) {
+  h[0] = mix32(group ^ (uint32_t)seed);
+  h[1] = mix32(h[0] ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+}
+__device__ __forceinline__ bool mha_keep4(const uint32_t (&h)[2], int e, uint32_t thr) { return ((h[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
+
+template <class T>
+__global__ __launch_bounds__(64 * MHA_TILES) void mha_fwd_mfma_kernel(MhaArgs a) {
+  __shared__ __attribute__((aligned(16))) T sVt[32 * MHA_TP];
+  const int L = a.L, bm = blockIdx.x, b = bm / a.M, m = bm % a.M;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = (L + 15) >> 4;
+  const int il = lane & 15, g = lane >> 4;
+  const long long r0 = (long long)b * L;
+  const int col = m * MHA_D;
+  mha_stage_t<T>(a.v, r0, L, a.ldv, col, sVt);
+  const int i = 16 * w + il;                                      // this lane's query
+  const uint4 qf = mha_row16<T>(a.q, r0, i, L, a.ldq, col + 8 * g);
+  mha_f32x4_t st[MHA_TILES];
+#pragma unroll
+  for (int t = 0; t < MHA_TILES; ++t) {
+    st[t] = (mha_f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (t < nt) st[t] = mha_mma<T>(mha_row16<T>(a.k, r0, 16 * t + il, L, a.ldk, col + 8 * g), qf, st[t]);
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < MHA_TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * t + 4 * g + r;
+      st[t][r] = j < L ? st[t][r] * a.scale : -3.0e38f;
+      mx = fmaxf(mx, st[t][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < MHA_TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      st[t][r] = (16 * t + 4 * g + r) < L ? __expf(st[t][r] - mx) : 0.f;
+      den += st[t][r];
+    }
+  den += __shfl_xor(den, 16, 64);
+  den += __shfl_xor(den, 32, 64);
+  const float inv = 1.f / den;
+  if (g == 0 && i < L) {                                          // what the backward recomputes the probabilities from
+    float* stats = a.probs + (long long)bm * L * L;
+    stats[i] = mx;
+    stats[L + i] = inv;
+  }
+  const unsigned long long seed = a.pdrop > 0.f ? *a.seed : 0ull;
+  const uint32_t thr = (uint32_t)(a.pdrop * 65536.f);
+  const float ks = a.pdrop > 0.f ? inv / (1.f - a.pdrop) : inv;
+  uint32_t pk[MHA_TILES][2];
+#pragma unroll
+  for (int t = 0; t < MHA_TILES; ++t) {
+    float pv[4];
+    uint32_t h[2];
+    if (a.pdrop > 0.f) mha_drop4(seed, a.salt, ((unsigned)bm * (unsigned)L + (unsigned)i) * 32u + (unsigned)(4 * t + g), h);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pv[r] = (a.pdrop > 0.f && !mha_keep4(h, r, thr)) ? 0.f : st[t][r] * ks;
+    pk[t][0] = mha_pack2<T>(pv[0], pv[1]);
+    pk[t][1] = mha_pack2<T>(pv[2], pv[3]);
+  }
+  __syncthreads();                                                // the V^T image is complete
+  if (w >= nt) return;
+  mha_f32x4_t o[2] = {(mha_f32x4_t){0.f, 0.f, 0.f, 0.f}, (mha_f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int s = 0; s < MHA_TILES / 2; ++s) {
+    if (2 * s >= nt) break;
+    const uint4 pf = make_uint4(pk[2 * s][0], pk[2 * s][1], pk[2 * s + 1][0], pk[2 * s + 1][1]);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) o[dt] = mha_mma<T>(mha_frag_t<T>(sVt, dt, s, lane), pf, o[dt]);
+  }
+  if (i < L) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      uint2 v;
+      v.x = mha_pack2<T>(o[dt][0], o[dt][1]);
+      v.y = mha_pack2<T>(o[dt][2], o[dt][3]);
+      *reinterpret_cast<uint2*>((T*)a.o + (r0 + i) * a.ldo + col + 16 * dt + 4 * g) = v;
+    }
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a) {
+  __shared__ __attribute__((aligned(16))) T sKt[32 * MHA_TP];
+  __shared__ __attribute__((aligned(16))) T sQt[32 * MHA_TP];
+  __shared__ __attribute__((aligned(16))) T sGt[32 * MHA_TP];
+  __shared__ float sMx[128], sInv[128], sDot[128];
+  const int L = a.L, bm = blockIdx.x, b = bm / a.M, m = bm % a.M;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = (L + 15) >> 4;
+  const int il = lane & 15, g = lane >> 4;
+  const long long r0 = (long long)b * L;
+  const int col = m * MHA_D;
+  mha_stage_t<T>(a.k, r0, L, a.ldk, col, sKt);
+  mha_stage_t<T>(a.q, r0, L, a.ldq, col, sQt);
+  mha_stage_t<T>(a.dout, r0, L, a.lddo, col, sGt);
+  const float* stats = a.probs + (long long)bm * L * L;
+  for (int t = threadIdx.x; t < 128; t += blockDim.x) {
+    sMx[t] = t < L ? stats[t] : 0.f;
+    sInv[t] = t < L ? stats[L + t] : 0.f;
+  }
+  const unsigned long long seed = a.pdrop > 0.f ? *a.seed : 0ull;
+  const uint32_t thr = (uint32_t)(a.pdrop * 65536.f);
+  const float kd = a.pdrop > 0.f ? 1.f / (1.f - a.pdrop) : 1.f;
+  const int x = 16 * w + il;            // this lane's query (pass 1) / key (pass 2)
+  // ---- pass 1: the row strip of query tile w: P, dP, rowdot, dS -> dq ------------------------------------------------------------
+  {
+    const uint4 qf = mha_row16<T>(a.q, r0, x, L, a.ldq, col + 8 * g), gf = mha_row16<T>(a.dout, r0, x, L, a.lddo, col + 8 * g);
+    const float mx = x < L ? stats[x] : 0.f, inv = x < L ? stats[L + x] : 0.f;
+    mha_f32x4_t st[MHA_TILES], dp[MHA_TILES];
+#pragma unroll
+    for (int t = 0; t < MHA_TILES; ++t) {
+      st[t] = (mha_f32x4_t){0.f, 0.f, 0.f, 0.f};
+      dp[t] = (mha_f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+        st[t] = mha_mma<T>(mha_row16<T>(a.k, r0, 16 * t + il, L, a.ldk, col + 8 * g), qf, st[t]);
+        dp[t] = mha_mma<T>(mha_row16<T>(a.v, r0, 16 * t + il, L, a.ldv, col + 8 * g), gf, dp[t]);
+      }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < MHA_TILES; ++t) {
+      uint32_t h[2];
+      if (a.pdrop > 0.f) mha_drop4(seed, a.salt, ((unsigned)bm * (unsigned)L + (unsigned)x) * 32u + (unsigned)(4 * t + g), h);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool in = (16 * t + 4 * g + r) < L && x < L;
+        const float p = in ? __expf(st[t][r] * a.scale - mx) * inv : 0.f;
+        const bool keep = !(a.pdrop > 0.f) || mha_keep4(h, r, thr);
+        const float d = keep ? dp[t][r] * kd : 0.f;        // dP_ij (gradient of the UNdropped probability)
+        st[t][r] = p;
+        dp[t][r] = d;
+        dot = fmaf(d, p, dot);
+      }
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (g == 0) sDot[x] = dot;
+    uint32_t pk[MHA_TILES][2];
+#pragma unroll
+    for (int t = 0; t < MHA_TILES; ++t) {
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[r] = st[t][r] * (dp[t][r] - dot) * a.scale;
+      pk[t][0] = mha_pack2<T>(ds[0], ds[1]);
+      pk[t][1] = mha_pack2<T>(ds[2], ds[3]);
+    }
+    __syncthreads();                                              // transposed images, statistics and every row's rowdot are in LDS
+    if (w < nt) {
+      mha_f32x4_t dq[2] = {(mha_f32x4_t){0.f, 0.f, 0.f, 0.f}, (mha_f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s = 0; s < MHA_TILES / 2; ++s) {
+        if (2 * s >= nt) break;
+        const uint4 pf = make_uint4(pk[2 * s][0], pk[2 * s][1], pk[2 * s + 1][0], pk[2 * s + 1][1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = mha_mma<T>(mha_frag_t<T>(sKt, dt, s, lane), pf, dq[dt]);
+      }
+      if (x < L) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          uint2 v;
+          v.x = mha_pack2<T>(dq[dt][0], dq[dt][1]);
+          v.y = mha_pack2<T>(dq[dt][2], dq[dt][3]);
+          *reinterpret_cast<uint2*>((T*)a.dq + (r0 + x) * a.lddq + col + 16 * dt + 4 * g) = v;
+        }
+      }
+    }
+  }
+  if (w >= nt) return;
+  // ---- pass 2: the column strip of key tile w: S[i][j], dPd[i][j] with the lane's key j = x fixed and the queries i in the registers ----
+  {
+    const uint4 kf = mha_row16<T>(a.k, r0, x, L, a.ldk, col + 8 * g), vf = mha_row16<T>(a.v, r0, x, L, a.ldv, col + 8 * g);
+    mha_f32x4_t st[MHA_TILES], dp[MHA_TILES];
+#pragma unroll
+    for (int t = 0; t < MHA_TILES; ++t) {
+      st[t] = (mha_f32x4_t){0.f, 0.f, 0.f, 0.f};
+      dp[t] = (mha_f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+        st[t] = mha_mma<T>(mha_row16<T>(a.q, r0, 16 * t + il, L, a.ldq, col + 8 * g), kf, st[t]);
+        dp[t] = mha_mma<T>(mha_row16<T>(a.dout, r0, 16 * t + il, L, a.lddo, col + 8 * g), vf, dp[t]);
+      }
+    }
+    uint32_t pks[MHA_TILES][2], pkp[MHA_TILES][2];
+#pragma unroll
+    for (int t = 0; t < MHA_TILES; ++t) {
+      float ds[4], pd[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * t + 4 * g + r;
+        const bool in = i < L && x < L;
+        const float p = in ? __expf(st[t][r] * a.scale - sMx[i]) * sInv[i] : 0.f;
+        bool keep = true;
+        if (a.pdrop > 0.f) {      // the forward's group is (query i, the quad of keys x belongs to): one hash per register here
+          uint32_t h[2];
+          mha_drop4(seed, a.salt, ((unsigned)bm * (unsigned)L + (unsigned)i) * 32u + (unsigned)(x >> 2), h);
+          keep = mha_keep4(h, x & 3, thr);
+        }
+        const float d = keep ? dp[t][r] * kd : 0.f;
+        ds[r] = p * (d - sDot[i]) * a.scale;
+        pd[r] = keep ? p * kd : 0.f;
+      }
+      pks[t][0] = mha_pack2<T>(ds[0], ds[1]); pks[t][1] = mha_pack2<T>(ds[2], ds[3]);
+      pkp[t][0] = mha_pack2<T>(pd[0], pd[1]); pkp[t][1] = mha_pack2<T>(pd[2], pd[3]);
+    }
+    mha_f32x4_t dk[2] = {(mha_f32x4_t){0.f, 0.f, 0.f, 0.f}, (mha_f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    mha_f32x4_t dv[2] = {(mha_f32x4_t){0.f, 0.f, 0.f, 0.f}, (mha_f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < MHA_TILES / 2; ++s) {
+      if (2 * s >= nt) break;
+      const uint4 sf = make_uint4(pks[2 * s][0], pks[2 * s][1], pks[2 * s + 1][0], pks[2 * s + 1][1]);
+      const uint4 pf = make_uint4(pkp[2 * s][0], pkp[2 * s][1], pkp[2 * s + 1][0], pkp[2 * s + 1][1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dk[dt] = mha_mma<T>(mha_frag_t<T>(sQt, dt, s, lane), sf, dk[dt]);
+        dv[dt] = mha_mma<T>(mha_frag_t<T>(sGt, dt, s, lane), pf, dv[dt]);
+      }
+    }
+    if (x < L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        uint2 v;
+        v.x = mha_pack2<T>(dk[dt][0], dk[dt][1]); v.y = mha_pack2<T>(dk[dt][2], dk[dt][3]);
+        *reinterpret_cast<uint2*>((T*)a.dk + (r0 + x) * a.lddk + col + 16 * dt + 4 * g) = v;
+        v.x = mha_pack2<T>(dv[dt][0], dv[dt][1]); v.y = mha_pack2<T>(dv[dt][2], dv[dt][3]);
+        *reinterpret_cast<uint2*>((T*)a.dv + (r0 + x) * a.lddv + col + 16 * dt + 4 * g) = v;
+      }
+    }
+  }
+}
+
 extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs,
                             int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt,
                             int dtype, void* stream) {
@@ -260,6 +560,16 @@ extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, cons
   const size_t lds = (size_t)(2 * L * MHA_P + MHA_FWD_ROWS * MHA_P + MHA_FWD_ROWS * (L + 1)) * sizeof(float);      // <= 58 KB at L = 128
   const int nchunk = (L + MHA_FWD_ROWS - 1) / MHA_FWD_ROWS;
   hipStream_t st = (hipStream_t)stream;
+  // bf16 / fp16: the MFMA kernels (one block per (batch, head), a wave per 16 rows); `probs` then holds (row max, 1 / row sum) in the first 2 L
+  // floats of each (batch, head) slab -- the backward of the SAME dtype reads them back.  mha_valu = 1: the VALU kernels for every dtype (A/B).
+  const bool mfma = dtype != EMRT_F32 && !g_tune.mha_valu && L >= 2 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0) && ((uintptr_t)o % 8 == 0);
+  if (mfma) {
+    const int threads = 64 * ((L + 15) / 16);
+    if (dtype == EMRT_BF16) hipLaunchKernelGGL((mha_fwd_mfma_kernel<bf16_t>), dim3(B * M), dim3(threads), 0, st, a);
+    else hipLaunchKernelGGL((mha_fwd_mfma_kernel<f16_t>), dim3(B * M), dim3(threads), 0, st, a);
+    return check_launch("emrt_mha_fwd");
+  }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_fwd_kernel<float>), dim3(B * M * nchunk), dim3(4 * MHA_FWD_ROWS), lds, st, a, nchunk);
   else if (dtype == EMRT_BF16) hipLaunchKernelGGL((mha_fwd_kernel<bf16_t>), dim3(B * M * nchunk), dim3(4 * MHA_FWD_ROWS), lds, st, a, nchunk);
   else hipLaunchKernelGGL((mha_fwd_kernel<f16_t>), dim3(B * M * nchunk), dim3(4 * MHA_FWD_ROWS), lds, st, a, nchunk);
@@ -290,6 +600,14 @@ extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, cons
         hipFuncSetAttribute((const void*)mha_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess)
       return fail("emrt_mha_bwd", "cannot raise the dynamic LDS limit");
     attr_done = true;
+  }
+  // (the same condition as the forward's: the two must agree on what `probs` holds)
+  const bool mfma = dtype != EMRT_F32 && !g_tune.mha_valu && L >= 2 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) % 16 == 0) &&
+                    lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 == 0);
+  if (mfma) {
+    hipLaunchKernelGGL((mha_bwd_mfma_kernel<bf16_t>), dim3(B * M), dim3(64 * ((L + 15) / 16)), 0, st, a);
+    return check_launch("emrt_mha_bwd");
   }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_bwd_kernel<float>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);
   else hipLaunchKernelGGL((mha_bwd_kernel<bf16_t>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);

@@ -78,6 +78,8 @@ struct Tuning {
   int wgroup_blocks;      // batched weight gradients (emrt_conv2d_wgrad_group): blocks a launch aims for (1024 = 4 per CU)
   int wgroup_min_steps;   // ... fewest 64-pixel tiles per block (32: shorter blocks only buy fp32 atomic traffic)
   int wgroup_max;         // ... most problems per launch (0 = the kernel's limit, 24)
+  int msda_scatter_merge; // 1 = the value-gradient scatter adds consecutive points of a query with the same 2 x 2 footprint in registers first (A/B knob)
+  int mha_valu;           // 1 = the decoder's softmax attention on the VALU kernels for every dtype (A/B knob; bf16 / fp16 default to the MFMA kernels)
   int xk;                 // cross-block K split of few-tile, long-K convolutions: 0 = the dispatcher's choice, -1 = never, n >= 2 = n copies whenever the shape allows
 };
 extern Tuning g_tune;
@@ -267,6 +269,29 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t salt, uint64_
   uint32_t h = mix32(a ^ (b + 0x9E3779B9U + (a << 6) + (a >> 2)));
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
+
+// Element-mode dropout (nn.Dropout on token tensors: the stand-alone kernels and the LayerNorm kernels that apply a branch's dropout themselves):
+// the kernels move 4 consecutive elements per lane, so ONE 64-bit draw per aligned quad of the flat index gives their four 16-bit uniforms --
+// 2 hash rounds per 4 elements where uniform01() needs 12 (the hash was most of the VALU work of the LayerNorm kernels: 14 + 14 launches a step).
+// keep iff u16 >= p * 65536.  Every kernel that must agree on a mask calls these two functions with the same (seed, salt, quad index).
+__device__ __forceinline__ void drop_quad(uint64_t seed, uint32_t salt, uint64_t quad, uint32_t (&h)[2]) {
+  h[0] = mix32((uint32_t)quad ^ (uint32_t)seed);
+  h[1] = mix32(h[0] ^ (uint32_t)(quad >> 32) ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+}
+__device__ __forceinline__ bool drop_quad_keep(const uint32_t (&h)[2], int e, uint32_t thr) { return ((h[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.f); }
+
+// Dropout inside a GEMM epilogue (conv.hip: linear1 -> ReLU -> Dropout of the FFN): the per-element hash above costs ~45 VALU instructions
+// per element, which on a GEMM's critical path cost more than the separate dropout launch it replaced.  Here ONE group of
+// 8 consecutive channels of a row draws four 32-bit words = eight 16-bit uniforms (~4 instructions per element); keep iff u16 >= p * 65536.
+// The backward never re-derives this mask: the consumer's data gradient masks with (stored output > 0) (functional.conv2d: drop_rec).
+__device__ __forceinline__ void drop_words8(uint64_t seed, uint32_t salt, uint32_t group, uint32_t (&h)[4]) {
+  h[0] = mix32(group ^ (uint32_t)seed);
+  h[1] = mix32(h[0] ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+  h[2] = mix32(h[1] + 0x9E3779B9U + (h[0] << 6));
+  h[3] = mix32(h[2] ^ 0x85EBCA6BU ^ (h[1] >> 2));
+}
+__device__ __forceinline__ bool drop_keep8(const uint32_t (&h)[4], int e, uint32_t thr) { return ((h[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
 
 // Flat index -> coordinates for the grid-stride elementwise kernels.  idx = ((i3 * D2 + i2) * D1 + i1) * D0 + i0.
 // A 64-bit division is ~100 VALU instructions on gfx950 (no 64-bit divider, quarter-rate 32x32 multiplies): three of them per 16-byte vector

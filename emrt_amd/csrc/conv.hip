@@ -64,6 +64,11 @@ struct ConvArgs {
   int xk_S;
   float* xk_part;
   unsigned* xk_tick;
+  // optional inverted dropout of the stored outputs, after the ReLU (emrt_conv2d_drop: linear1 -> ReLU -> Dropout of the FFN, t_e_d.py:157-161):
+  // kept values are multiplied by 1 / (1 - p); the mask comes from drop_words8(seed, salt, (row * OC + col) / 8)
+  const unsigned long long* drop_seed;
+  unsigned drop_salt;
+  float drop_p;
 };
 
 template <class T>
@@ -144,7 +149,7 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // scratch with write-through (sc1) stores, every storing wave drains its stores, one lane takes a ticket (agent-scope atomic add), and the
 // block whose ticket is the last one acquires (agent scope), sums the S partials in s order and runs the usual epilogue (bias / residual / mask
 // / BatchNorm sums / store) -- no finishing launch.  MI355X_MICROARCH.md "splitk-seam"; cdna_hip_programming.md Guideline 16, R1.
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false, bool XK = false>
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false, bool XK = false, bool DROP = false>
 __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id, const int block_count, unsigned char* smem_all) {
   static_assert(!S2 || (MODE == 1 && VEC && G == 1 && TM == 1 && TN == 1), "S2 is the 64x64 vector-path data gradient");
   static_assert(!XK || (VEC && G == 1 && !S2), "XK is a vector-path tile without the in-block K split");
@@ -506,6 +511,10 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
       for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && col_ok) ? p.bias[n0 + e] : 0.f; sv[e] = (p.scale && col_ok) ? p.scale[n0 + e] : 1.f; ss[e] = 0.f; sq[e] = 0.f; }
       const T* resp = (const T*)p.res;
       const T* ymask = (const T*)p.mask_y;
+      // (read ONCE, before the row loop: left inside it the seed was a dependent global load per row -- the pointer may alias the stores)
+      const unsigned long long drop_sd = DROP ? p.drop_seed[0] : 0ull;
+      const uint32_t drop_thr = DROP ? (uint32_t)(p.drop_p * 65536.f) : 0u;
+      const float drop_ks = DROP ? 1.f / (1.f - p.drop_p) : 1.f;
 #pragma unroll 2
       for (int row = rr; row < BM; row += RP) {
         const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)row;
@@ -548,6 +557,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (DROP) {      // (its own instantiation -- igemm_drop_kernel: at the 128-register cap of this tile the extra epilogue code cost the
+                                   // K-split and XK variants their last free registers: 8-12 bytes of scratch per lane)
+          uint32_t hw[4];
+          drop_words8(drop_sd, p.drop_salt, (m * (unsigned)p.OC + (unsigned)n0) >> 3, hw);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = drop_keep8(hw, e, drop_thr) ? v[e] * drop_ks : 0.f;
         }
         float second[8];
         if (ymask) {
@@ -630,6 +646,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
         float v = fmaf(acc[i][j][r], scale_v[j], bias_v[j]);
         if (resp) v += to_f32(resp[rbase + n]);
         if (p.relu) v = fmaxf(v, 0.f);
+
         float second = 0.f;              // what the second statistic multiplies v with
         if (ymask) {
           second = to_f32(ymask[ybase + n]);
@@ -672,6 +689,12 @@ template <class T, int MODE>
 __global__ __launch_bounds__(256, 4) void igemm_xk_kernel(ConvArgs p) {      // 64x64 tile, K cut over xk_S blocks per tile: see igemm_body, XK
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   igemm_body<T, 1, 1, 2, 2, MODE, true, 3, 1, false, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
+}
+
+template <class T>
+__global__ __launch_bounds__(256, 4) void igemm_drop_kernel(ConvArgs p) {      // forward 64x64 tile whose epilogue draws the dropout mask: see ConvArgs::drop_seed
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  igemm_body<T, 1, 1, 2, 2, 0, true, 3, 1, false, false, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
 }
 
 template <class T>
@@ -1097,12 +1120,16 @@ static int igemm_xk_copies(const ConvArgs& a, hipStream_t st, int want) {
   const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
   int S = want;
   if (S <= 0) {
-    // (thresholds from tools/bench_conv.py xk on MI355X: the seam -- drain, ticket, acquire, S partial reads -- costs ~4-5 us, so it pays
-    // where the serial k loop of a block is long AND the grid leaves CUs idle; ~512 blocks = two per CU, never fewer than 8 k-tiles per block)
-    if (nb > 160 || nkt < 32) return 0;
-    S = (int)(512 / nb);
-    if (S > 8) S = 8;
-    while (S > 1 && nkt / S < 8) --S;
+    // Measured on MI355X (tools/bench_conv.py xk, profiles/r5_xk_sweep.txt; us, old choice -> S = 2 / 4 / 8): the seam -- write-through drain, ticket,
+    // acquire, S partial reads -- costs ~7 us, more than priced, so the split only pays where a block's operand stream is LONG (a CU pulls
+    // ~55 GB/s whatever runs on it) and the grid leaves most CUs idle:
+    //   8x8x512 -> 512 3x3 (64 tiles, 72 k-tiles)      22.4 -> 20.3 / 17.3 / 20.3     16x16x512 -> 512 3x3 s2 (64, 72)     22.7 -> 20.4 / 17.3 / 20.5
+    //   16x16x1024 -> 256 3x3 (128 tiles, 144 k-tiles)  38.0 -> 33.7 / 28.5 / 35.9     8x8x256 -> 256 3x3 (32, 36)          15.4 -> 13.9 / 12.8 / 15.0
+    //   16x16x256 -> 256 3x3 (128 tiles, 36 k-tiles)    16.3 -> 16.5 / 19.1 / 28.6     8x8x2048 -> 512 1x1 (64, 32)         12.9 -> 13.6 / 13.6 / 18.7
+    //   batch 16: 8x8x512 3x3 (128 tiles, 72)           23.4 -> 22.3 / 22.0 / 28.9     16x16x256 3x3 (256 tiles, 36)        16.3 -> 20.5 / 26.2 / 53.7
+    // i.e. four copies, for <= 64 tiles with >= 36 k-tiles or <= 128 tiles with >= 128 k-tiles; everything else keeps the in-block split.
+    if (!((nb <= 64 && nkt >= 36) || (nb <= 128 && nkt >= 128))) return 0;
+    S = 4;
   }
   if (S > nkt) S = nkt;
   if (S < 2 || nb > SCRATCH_TICKS || (size_t)nb * (size_t)S * 64 * 64 * 4 > g_scratch.bytes) return 0;
@@ -1123,6 +1150,17 @@ template <class T, int MODE, bool VEC>
 static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
   const long long M = (long long)a.N * a.OH * a.OW;
   auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
+  if (a.drop_seed) {      // emrt_conv2d_drop: the 64x64 tile with the dropout epilogue (the FFN's first linear: short K, thousands of tiles)
+    if constexpr (MODE == 0 && VEC && sizeof(T) != 0) {
+      constexpr int EPC = 16 / (int)sizeof(T);
+      const bool vec_out = ((uintptr_t)a.out) % 16 == 0 && a.ldout % EPC == 0 && a.out_bs % EPC == 0 && a.OC % 8 == 0 && !a.out_f32 && !a.res && !a.mask_y;
+      if (vec_out) {
+        hipLaunchKernelGGL((igemm_drop_kernel<T>), dim3((unsigned)blocks(64, 64)), dim3(256), (size_t)2 * 128 * 144, st, a);
+        return check_launch("emrt_conv2d_drop");
+      }
+    }
+    return fail("emrt_conv2d_drop", "needs 16-byte aligned rows of C, OC multiples of 8 elements (the vector path)");
+  }
   if constexpr (MODE == 1 && VEC) {
     if (!g_tune.conv_tile && igemm_s2_ok<T>(a)) {
       // measured (tools/bench_conv.py s2): the three 3x3 stride-2 data gradients of the ResNet-50 step 25.3 / 24.3 / 27.3 -> 13.8 / 13.0 / 14.5 us
@@ -1187,13 +1225,13 @@ static int conv_dispatch(const ConvArgs& a, hipStream_t st) {
   return vec ? conv_pick_tile<T, MODE, true>(a, st) : conv_pick_tile<T, MODE, false>(a, st);
 }
 
-extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual,
-                           int N, int H, int W, int C, int ldin, long long in_bs,
-                           int OH, int OW, int OC, int ldout, long long out_bs,
-                           int ldres, long long res_bs,
-                           int KH, int KW, int stride, int pad,
-                           int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
-                           int dilation, const float* out_scale, int dtype, void* stream) {
+static int conv2d_impl(const void* in, const void* w_packed, void* out, const float* bias, const void* residual,
+                       int N, int H, int W, int C, int ldin, long long in_bs,
+                       int OH, int OW, int OC, int ldout, long long out_bs,
+                       int ldres, long long res_bs,
+                       int KH, int KW, int stride, int pad,
+                       int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
+                       int dilation, const float* out_scale, float drop_p, const unsigned long long* drop_seed, unsigned drop_salt, int dtype, void* stream) {
   EMRT_REQUIRE(in && w_packed && out, "null pointer");
   EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0, "bad dims");
   EMRT_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && dilation >= 1, "bad kernel geometry");
@@ -1219,12 +1257,38 @@ extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, cons
   a.ldres = ldres; a.res_bs = res_bs;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu; a.out_f32 = out_f32; a.cmajor = g_tune.igemm8p_cmajor; a.stats = bn_stats;
   a.mask_y = mask_y; a.ldy = ldy; a.y_bs = y_bs; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
-  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr;
+  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr; a.drop_seed = nullptr; a.drop_salt = 0; a.drop_p = 0.f;
+  if (drop_p > 0.f) { a.drop_seed = drop_seed; a.drop_salt = drop_salt; a.drop_p = drop_p; }
   EMRT_REQUIRE(!mask_y || !out_f32, "the ReLU mask needs an output in the compute dtype");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) return mode == 0 ? conv_dispatch<float, 0>(a, st) : conv_dispatch<float, 1>(a, st);
   if (dtype == EMRT_F16) return conv_dispatch<f16_t, 0>(a, st);
   return mode == 0 ? conv_dispatch<bf16_t, 0>(a, st) : conv_dispatch<bf16_t, 1>(a, st);
+}
+
+extern "C" int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual,
+                           int N, int H, int W, int C, int ldin, long long in_bs,
+                           int OH, int OW, int OC, int ldout, long long out_bs,
+                           int ldres, long long res_bs,
+                           int KH, int KW, int stride, int pad,
+                           int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs,
+                           int dilation, const float* out_scale, int dtype, void* stream) {
+  return conv2d_impl(in, w_packed, out, bias, residual, N, H, W, C, ldin, in_bs, OH, OW, OC, ldout, out_bs, ldres, res_bs, KH, KW, stride, pad,
+                     mode, relu, out_f32, bn_stats, mask_y, ldy, y_bs, dilation, out_scale, 0.f, nullptr, 0u, dtype, stream);
+}
+
+// out = dropout_p(relu(linear(in) + bias)): the first half of the transformer FFN (linear1 -> ReLU -> Dropout, transformer_encoder_decoder.py:
+// 118-121,157-161,259-262) in ONE launch -- the mask is drawn in the GEMM epilogue, the dropped activation is the only tensor written (the
+// separate path wrote relu(linear1), read it back and wrote the dropped copy: a 10 us launch and 44 MB per encoder layer at batch 8).
+// 1x1 / stride 1 / no residual; 0 < p < 1; OC % 8 == 0; training dtypes.  The backward needs no mask tensor and no seed: the consumer's data
+// gradient masks with (out > 0) and scales by 1 / (1 - p) (emrt_conv2d_bwd: mask_y = out, mask_scale).
+extern "C" int emrt_conv2d_drop(const void* in, const void* w_packed, void* out, const float* bias, int M, int C, int ldin, int OC, int ldout,
+                                float p, const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(seed && p > 0.f && p < 1.f, "needs a device seed and 0 < p < 1");
+  EMRT_REQUIRE(M > 0 && C > 0 && OC > 0 && OC % 8 == 0 && (long long)M * OC < (1ll << 32), "bad dims (OC a multiple of 8, fewer than 2^32 outputs)");
+  return conv2d_impl(in, w_packed, out, bias, nullptr, 1, 1, M, C, ldin, (long long)M * ldin, 1, M, OC, ldout, (long long)M * ldout, 0, 0, 1, 1, 1, 0,
+                     0, 1, 0, nullptr, nullptr, 0, 0, 1, nullptr, p, seed, salt, dtype, stream);
 }
 
 // vector path eligibility of a weight-gradient problem
@@ -1850,7 +1914,7 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
   EMRT_REQUIRE(!stat_x || mask_y, "stat_x replaces the mask tensor in the second statistic: it needs mask_y");
   d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad; d.dil = dilation; d.relu = 0; d.out_f32 = 0; d.cmajor = g_tune.igemm8p_cmajor; d.stats = bn_stats;
   d.mask_y = mask_y; d.ldy = ldy; d.y_bs = y_bs; d.mask_scale = mask_scale; d.stat_x = stat_x; d.ldsx = ldsx; d.sx_bs = sx_bs;
-  d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr;
+  d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr; d.drop_seed = nullptr; d.drop_salt = 0; d.drop_p = 0.f;
   WgradArgs w;
   w.x = x; w.dy = dy; w.dw = dw;
   w.N = N; w.H = H; w.W = W; w.C = C; w.ldx = ldx; w.x_bs = x_bs;
@@ -1919,7 +1983,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.ldres = d.ldres; a.res_bs = d.res_bs;
   a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = 0; a.cmajor = 0; a.stats = d.bn_stats;
   a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
-  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr;
+  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr; a.drop_seed = nullptr; a.drop_salt = 0; a.drop_p = 0.f;
 }
 
 template <class T>
@@ -1988,7 +2052,7 @@ static int conv_dgrad_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStr
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
     d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.cmajor = 0; d.stats = nullptr;
     d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
-    d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr;
+    d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr; d.drop_seed = nullptr; d.drop_salt = 0; d.drop_p = 0.f;
     const long long Md = (long long)d.N * d.OH * d.OW;
     g.first[i] = (int)total;
     total += ((Md + 63) / 64) * ((d.OC + 63) / 64);
@@ -2023,7 +2087,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
     d.ldres = b.accumulate ? b.lddx : 0; d.res_bs = b.accumulate ? b.dx_bs : 0;
     d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = 1; d.relu = 0; d.out_f32 = 0; d.cmajor = 0; d.stats = nullptr;
     d.mask_y = nullptr; d.ldy = 0; d.y_bs = 0; d.mask_scale = 1.f; d.stat_x = nullptr; d.ldsx = 0; d.sx_bs = 0;
-    d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr;
+    d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr; d.drop_seed = nullptr; d.drop_salt = 0; d.drop_p = 0.f;
     WgradArgs& w = g.w[i];
     w.x = b.x; w.dy = b.dy; w.dw = b.dw;
     w.N = b.N; w.H = b.H; w.W = b.W; w.C = b.C; w.ldx = b.ldx; w.x_bs = b.x_bs;

@@ -9,7 +9,7 @@ using namespace emrt;
 thread_local char emrt::g_err[512] = {0};
 
 extern "C" const char* emrt_last_error(void) { return emrt::g_err; }
-extern "C" int emrt_abi_version(void) { return 6; }
+extern "C" int emrt_abi_version(void) { return 7; }
 
 // ---- tuning knobs: one table, environment read once at load time --------------------------------------------------
 namespace {
@@ -30,7 +30,7 @@ const TuneEntry kTune[] = {
     {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160}, {"igemm8p_cmajor", &emrt::Tuning::igemm8p_cmajor, 0},
     {"wgrad8p_min_steps", &emrt::Tuning::wgrad8p_min_steps, 8}, {"wgrad8p_slab", &emrt::Tuning::wgrad8p_slab, 1}, {"wgrad8p_force", &emrt::Tuning::wgrad8p_force, 0}, {"wgrad8p_xcd", &emrt::Tuning::wgrad8p_xcd, 1},
     {"wgrad_no_overwrite", &emrt::Tuning::wgrad_no_overwrite, 0}, {"no_ksplit128", &emrt::Tuning::no_ksplit128, 0}, {"ln_bwd_rows", &emrt::Tuning::ln_bwd_rows, 0}, {"ln_bwd_max_blocks", &emrt::Tuning::ln_bwd_max_blocks, 0}, {"bn_operand_blocks", &emrt::Tuning::bn_operand_blocks, 0}, {"no_s2_dgrad", &emrt::Tuning::no_s2_dgrad, 0}, {"wgroup_blocks", &emrt::Tuning::wgroup_blocks, 1024}, {"wgroup_min_steps", &emrt::Tuning::wgroup_min_steps, 32}, {"wgroup_max", &emrt::Tuning::wgroup_max, 0},
-    {"xk", &emrt::Tuning::xk, 0},
+    {"xk", &emrt::Tuning::xk, 0}, {"mha_valu", &emrt::Tuning::mha_valu, 0}, {"msda_scatter_merge", &emrt::Tuning::msda_scatter_merge, 0},
 };
 emrt::Tuning tuning_from_env() {
   emrt::Tuning t;
@@ -52,6 +52,13 @@ emrt::Scratch emrt::g_scratch = {nullptr, 0, nullptr, nullptr};
 
 extern "C" int emrt_set_scratch(void* ptr, size_t bytes, void* stream) {
   EMRT_REQUIRE((ptr != nullptr) == (bytes > 0) && ((uintptr_t)ptr) % 256 == 0, "scratch must be 256-byte aligned device memory (or nullptr, 0)");
+  // the SAME region again: only the stream it belongs to changes (host state, legal during a stream capture: the caller moves the region to the
+  // capture stream for the duration of a capture and back -- a graph's kernels are ordered among themselves like one stream's).  No memset:
+  // the counters are zero between launches by construction.
+  if (ptr && ptr == emrt::g_scratch.ptr && emrt::g_scratch.tick && bytes == emrt::g_scratch.bytes + emrt::SCRATCH_TICK_BYTES) {
+    emrt::g_scratch.stream = stream;
+    return 0;
+  }
   emrt::g_scratch.ptr = ptr;
   emrt::g_scratch.bytes = bytes;
   emrt::g_scratch.stream = stream;
@@ -166,11 +173,18 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ 
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float v[4];
     Vec4<T>::load(x + i * 4, v);
+    if (mode == 0) {      // one draw per quad of elements (common.hpp: drop_quad)
+      uint32_t h[2];
+      drop_quad(sd, salt, (unsigned long long)i, h);
+      const uint32_t thr = drop_thr16(p);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long idx = i * 4 + e;
-      const unsigned long long key = mode == 0 ? (unsigned long long)idx : (unsigned long long)((idx / C / hw) * C + idx % C);
-      v[e] = uniform01(sd, salt, key) >= p ? v[e] * ks : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = drop_quad_keep(h, e, thr) ? v[e] * ks : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long idx = i * 4 + e;
+        v[e] = uniform01(sd, salt, (unsigned long long)((idx / C / hw) * C + idx % C)) >= p ? v[e] * ks : 0.f;
+      }
     }
     Vec4<T>::store(y + i * 4, v);
   }
@@ -181,18 +195,26 @@ template <class T>
 __global__ __launch_bounds__(256) void mask_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ relu_out, T* __restrict__ dx,
                                                        long long n4, float p, const unsigned long long* __restrict__ seed,
                                                        unsigned salt, int mode, long long hw, int C) {
-  const unsigned long long sd = p > 0.f ? seed[0] : 0ull;
+  const unsigned long long sd = (p > 0.f && seed) ? seed[0] : 0ull;
   const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float g[4];
     Vec4<T>::load(dy + i * 4, g);
-    if (p > 0.f) {
+    if (p > 0.f && seed && mode == 0) {
+      uint32_t h[2];
+      drop_quad(sd, salt, (unsigned long long)i, h);
+      const uint32_t thr = drop_thr16(p);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = drop_quad_keep(h, e, thr) ? g[e] * ks : 0.f;
+    } else if (p > 0.f && seed) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const long long idx = i * 4 + e;
-        const unsigned long long key = mode == 0 ? (unsigned long long)idx : (unsigned long long)((idx / C / hw) * C + idx % C);
-        g[e] = uniform01(sd, salt, key) >= p ? g[e] * ks : 0.f;
+        g[e] = uniform01(sd, salt, (unsigned long long)((idx / C / hw) * C + idx % C)) >= p ? g[e] * ks : 0.f;
       }
+    } else if (p > 0.f) {      // seed == NULL: relu_out is dropout(relu(.)) as emrt_conv2d_drop stored it -- (relu_out > 0) below is BOTH masks, this the scale
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= ks;
     }
     if (relu_out) {
       float r[4];
@@ -342,7 +364,7 @@ extern "C" int emrt_mask_bwd(const void* dy, const void* relu_out, void* dx, lon
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(dy && dx, "null pointer");
   EMRT_REQUIRE(n % 4 == 0 && p >= 0.f && p < 1.f, "n must be a multiple of 4, 0 <= p < 1");
-  EMRT_REQUIRE(p == 0.f || seed, "dropout needs a device seed");
+  EMRT_REQUIRE(p == 0.f || seed || relu_out, "dropout needs a device seed (or, seed == NULL, the stored output of emrt_conv2d_drop as relu_out)");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMRT_F32) hipLaunchKernelGGL((mask_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dy, (const float*)relu_out, (float*)dx, n / 4, p, seed, salt, mode, hw, C);
   else hipLaunchKernelGGL((mask_bwd_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)relu_out, (bf16_t*)dx, n / 4, p, seed, salt, mode, hw, C);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
 // host side: can this problem take the 256 x 256 kernel?  (vector operand path, whole k-tiles per tap, vector epilogue)
 template <class T>
 static bool igemm8p_ok(const ConvArgs& a) {
-  if (sizeof(T) != 2) return false;
+  if (sizeof(T) != 2 || a.drop_seed) return false;      // (the dropout epilogue lives in igemm_body only)
   if (a.C % 64 != 0 || a.OC % 8 != 0) return false;
   if (a.ldin % 8 || a.in_bs % 8 || ((uintptr_t)a.in) % 16 || ((uintptr_t)a.w) % 16) return false;
   const int eo = a.out_f32 ? 4 : 8;

@@ -91,11 +91,93 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
+// ---- the two heads of MixSoftmaxCrossEntropyLoss in one pass (mix_softmax_cross_entropy_loss.py:29-35,44-51: CE(main) + 0.4 CE(aux) on the SAME
+// labels): forward = one streaming launch over both logit tensors (labels read once) + one finalize launch that also forms the weighted total
+// (was: 2 x (stream + finalize) + a scalar axpby = 5 launches, each at the ~4.6 us floor of a dependent kernel in the step's graph); backward = one
+// launch writing both gradients.  Per-pixel arithmetic and the fp64 finalize are those of the single-head kernels: bit-identical results.
+__device__ __forceinline__ float ce_pixel(const float* lp, int C, long long HW, long long lab) {
+  float mx = -3.0e38f;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[c * HW]);
+  float den = 0.f;
+  for (int c = 0; c < C; ++c) den += __expf(lp[c * HW] - mx);
+  const float picked = (lab >= 0 && lab < C) ? lp[lab * HW] : 0.f;
+  return logf(den) + mx - picked;
+}
+__global__ __launch_bounds__(256) void ce_pair_fwd_kernel(const float* __restrict__ la, const float* __restrict__ lb, const long long* __restrict__ labels,
+                                                          int N, int C, long long HW, int ignore_index, float* __restrict__ partial) {
+  __shared__ float red[3 * 4];
+  const long long total = (long long)N * HW;
+  float sa = 0.f, sb = 0.f, cnt = 0.f;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long lab = labels[idx];
+    if (lab == ignore_index) continue;
+    const long long n = total <= 0xffffffffll ? (long long)((unsigned)idx / (unsigned)HW) : idx / HW, p = idx - n * HW;
+    sa += ce_pixel(la + n * C * HW + p, C, HW, lab);
+    sb += ce_pixel(lb + n * C * HW + p, C, HW, lab);
+    cnt += 1.f;
+  }
+  sa = wave_sum(sa); sb = wave_sum(sb); cnt = wave_sum(cnt);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[wv * 3] = sa; red[wv * 3 + 1] = sb; red[wv * 3 + 2] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int w = 0; w < 4; ++w) { a += red[w * 3]; b += red[w * 3 + 1]; c += red[w * 3 + 2]; }
+    partial[blockIdx.x * 3] = a; partial[blockIdx.x * 3 + 1] = b; partial[blockIdx.x * 3 + 2] = c;
+  }
+}
+__global__ __launch_bounds__(256) void ce_pair_finalize_kernel(const float* __restrict__ partial, int nblk, float wa, float wb, float* __restrict__ res_a,
+                                                               float* __restrict__ res_b, float* __restrict__ total) {
+  __shared__ double ra[256], rb[256], rc[256];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
+  ra[threadIdx.x] = a; rb[threadIdx.x] = b; rc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ra[threadIdx.x] += ra[threadIdx.x + o]; rb[threadIdx.x] += rb[threadIdx.x + o]; rc[threadIdx.x] += rc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double den = rc[0] > 0.0 ? rc[0] : 1.0;
+    res_a[0] = (float)(ra[0] / den); res_a[1] = (float)rc[0];
+    res_b[0] = (float)(rb[0] / den); res_b[1] = (float)rc[0];
+    total[0] = wa * res_a[0] + wb * res_b[0];
+  }
+}
+__global__ __launch_bounds__(256) void ce_pair_bwd_kernel(const float* __restrict__ la, const float* __restrict__ lb, const long long* __restrict__ labels,
+                                                          const float* __restrict__ res_a, const float* __restrict__ up_a, const float* __restrict__ up_b,
+                                                          float wa, float wb, int N, int C, long long HW, int ignore_index, float* __restrict__ da,
+                                                          float* __restrict__ db) {
+  const long long total = (long long)N * HW;
+  const float inv_cnt = 1.f / fmaxf(res_a[1], 1.f);
+  const float ga = wa * (up_a ? up_a[0] : 1.f) * inv_cnt, gb = wb * (up_b ? up_b[0] : 1.f) * inv_cnt;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long lab = labels[idx];
+    const long long n = total <= 0xffffffffll ? (long long)((unsigned)idx / (unsigned)HW) : idx / HW, p = idx - n * HW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* lp = (h ? lb : la) + n * C * HW + p;
+      float* dp = (h ? db : da) + n * C * HW + p;
+      const float g = h ? gb : ga;
+      if (lab == ignore_index) {
+        for (int c = 0; c < C; ++c) dp[c * HW] = 0.f;
+        continue;
+      }
+      float mx = -3.0e38f;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[c * HW]);
+      float den = 0.f;
+      for (int c = 0; c < C; ++c) den += __expf(lp[c * HW] - mx);
+      const float inv = 1.f / den;
+      for (int c = 0; c < C; ++c) dp[c * HW] = g * (__expf(lp[c * HW] - mx) * inv - (c == lab ? 1.f : 0.f));
+    }
+  }
+}
+
 __global__ void axpby_scalar_kernel(float* out, const float* a, float wa, const float* b, float wb) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = wa * a[0] + (b ? wb * b[0] : 0.f);
 }
 
-extern "C" size_t emrt_ce_workspace_bytes(void) { return 1024 * 2 * sizeof(float); }
+extern "C" size_t emrt_ce_workspace_bytes(void) { return 1024 * 3 * sizeof(float); }
 
 // result[2] (device): {mean loss, non-ignored count}
 extern "C" int emrt_softmax_ce_fwd(const float* logits, const long long* labels, int N, int C, int H, int W, int ignore_index,
@@ -109,6 +191,35 @@ extern "C" int emrt_softmax_ce_fwd(const float* logits, const long long* labels,
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, N, C, (long long)H * W, ignore_index, (float*)workspace);
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, result);
   return check_launch("emrt_softmax_ce_fwd");
+}
+
+// both heads at once: res_a / res_b (device float[2] each: {mean loss, non-ignored count}), total[0] = wa * loss_a + wb * loss_b.
+// workspace: emrt_ce_workspace_bytes().
+extern "C" int emrt_softmax_ce_pair_fwd(const float* logits_a, const float* logits_b, const long long* labels, int N, int C, int H, int W,
+                                        int ignore_index, float wa, float wb, float* res_a, float* res_b, float* total, void* workspace, void* stream) {
+  EMRT_REQUIRE(logits_a && logits_b && labels && res_a && res_b && total && workspace, "null pointer");
+  const long long npix = (long long)N * H * W;
+  int grid = (int)((npix + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_pair_fwd_kernel, dim3(grid), dim3(256), 0, st, logits_a, logits_b, labels, N, C, (long long)H * W, ignore_index, (float*)workspace);
+  hipLaunchKernelGGL(ce_pair_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, wa, wb, res_a, res_b, total);
+  return check_launch("emrt_softmax_ce_pair_fwd");
+}
+
+// d logits_a = wa * up_a * (softmax - onehot) / count, d logits_b likewise (up_*: device scalars or NULL == 1); res_a from the forward.
+extern "C" int emrt_softmax_ce_pair_bwd(const float* logits_a, const float* logits_b, const long long* labels, const float* res_a, const float* up_a,
+                                        const float* up_b, float wa, float wb, int N, int C, int H, int W, int ignore_index, float* dlogits_a,
+                                        float* dlogits_b, void* stream) {
+  EMRT_REQUIRE(logits_a && logits_b && labels && res_a && dlogits_a && dlogits_b, "null pointer");
+  const long long npix = (long long)N * H * W;
+  int grid = (int)((npix + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(ce_pair_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_a, logits_b, labels, res_a, up_a, up_b, wa, wb, N, C,
+                     (long long)H * W, ignore_index, dlogits_a, dlogits_b);
+  return check_launch("emrt_softmax_ce_pair_bwd");
 }
 
 extern "C" int emrt_softmax_ce_bwd(const float* logits, const long long* labels, const float* result, const float* upstream,

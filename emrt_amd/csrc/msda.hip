@@ -1237,6 +1237,26 @@ __global__ __launch_bounds__(1024) void msda_bwd_value_lds_kernel(MsdaArgs a, in
       // added without a test (weight 0 adds 0).  Samples with nothing in the range are marked and skipped with ONE test.
       const bool hit_any = w4.x != 0.f || w4.y != 0.f || w4.z != 0.f || w4.w != 0.f;
       if (!hit_any) f00 = (int)0x80000000;
+      if (probe & 128) {
+        // knob msda_scatter_merge: consecutive points of one query whose bilinear footprint is the SAME 2 x 2 cells are added in registers
+        // before they touch the LDS -- point p hands its four weights to point p + 1 and drops out (one test in the step loop skips it), so a run
+        // of k such points costs 4 LDS atomics instead of 4 k.  Lanes are ordered (query, point): the neighbour is one lane up (wave_shl /
+        // wave_shr DPP moves: VALU, not the LDS crossbar).  On the untrained compass offsets of _reset_parameters the coarser levels see runs
+        // (steps of 1 px at level 0 are steps of 1/2 and 1/4 px there); once offsets have spread by >= 2 px hardly any
+        // (profiles/r4_msda_scatter_merge_analysis.txt), which is why this is a knob and its measurement decides.
+        const int f_next = __builtin_amdgcn_update_dpp(0, f00, 0x130, 0xf, 0xf, false);      // wave_shl:1: lane + 1's f00
+        const bool gives = my_p + 1 < P && my_qq < QB && f00 != (int)0x80000000 && f_next == f00;
+#pragma unroll
+        for (int t = 1; t < P; ++t) {      // weights flow up a run, one point per step (point t takes what point t - 1 has gathered so far)
+          const float ax = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w4.x), 0x138, 0xf, 0xf, false));      // wave_shr:1: lane - 1
+          const float ay = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w4.y), 0x138, 0xf, 0xf, false));
+          const float az = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w4.z), 0x138, 0xf, 0xf, false));
+          const float aw4 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w4.w), 0x138, 0xf, 0xf, false));
+          const bool prev_gives = __builtin_amdgcn_update_dpp(0, (int)gives, 0x138, 0xf, 0xf, false) != 0;
+          if (my_p == t && prev_gives) { w4.x += ax; w4.y += ay; w4.z += az; w4.w += aw4; }
+        }
+        if (gives) f00 = (int)0x80000000;
+      }
       // a wave whose 2 x QB queries put no sample of this level inside the block's pixel range has nothing to add: skip the
       // dout loads and the sample loop (wave-uniform branch).  Queries are stored row-major per level and sample near their
       // own reference point, so for a level cut into several ranges most waves of a block skip most of their iterations
@@ -1592,7 +1612,7 @@ static int msda_launch_lds(const MsdaArgs& a, int L, int P, int ngroups, size_t 
   if (L == LL && P == PP) {                                                                                   \
     static bool attr = false;                                                                                 \
     if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_value_lds_kernel<T, LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
-    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, LL, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a, g_tune.msda_fwd_probe >> 4); \
+    hipLaunchKernelGGL((msda_bwd_value_lds_kernel<T, LL, PP>), dim3(a.B * a.M, ngroups), dim3(1024), lds, st, a, ((g_tune.msda_fwd_probe >> 4) & 127) | (g_tune.msda_scatter_merge ? 128 : 0)); \
     return check_launch("emrt_msda_bwd(lds scatter)");                                                        \
   }
   MSDA_LDS_CASE(3, 6)

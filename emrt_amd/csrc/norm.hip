@@ -1018,10 +1018,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
         float w[4];
         Vec4<T>::load(b + row * C + c, w);
         if (pdrop > 0.f) {
+          uint32_t hq[2];
+          drop_quad(sd, salt, (unsigned long long)(row * C + c) >> 2, hq);      // (C % 4 == 0: an aligned quad of the flat index)
+          const uint32_t thr = drop_thr16(pdrop);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // the dropped value is rounded through T exactly as a separate dropout kernel would store it
-            const float d = uniform01(sd, salt, (unsigned long long)(row * C + c + e)) >= pdrop ? w[e] * ks : 0.f;
+            const float d = drop_quad_keep(hq, e, thr) ? w[e] * ks : 0.f;
             w[e] = to_f32(from_f32<T>(d));
           }
         }
@@ -1148,9 +1151,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
           Vec4<T>::store(dz + row[k] * C + c, o);
           if (dzb) {
             if (pdrop > 0.f) {
+              uint32_t hq[2];
+              drop_quad(sd, salt, (unsigned long long)(row[k] * C + c) >> 2, hq);
+              const uint32_t thr = drop_thr16(pdrop);
 #pragma unroll
               for (int e = 0; e < 4; ++e)   // the mask is applied to the STORED dz (rounded through T), as a separate mask kernel would read it
-                o[e] = uniform01(sd, salt, (unsigned long long)(row[k] * C + c + e)) >= pdrop ? to_f32(from_f32<T>(o[e])) * ks : 0.f;
+                o[e] = drop_quad_keep(hq, e, thr) ? to_f32(from_f32<T>(o[e])) * ks : 0.f;
             }
             Vec4<T>::store(dzb + row[k] * C + c, o);
           }

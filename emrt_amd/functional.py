@@ -326,10 +326,14 @@ def launch_wgrads(pending):
 
 
 def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1,
-           out_scale=None, out_shift=None):
+           out_scale=None, out_shift=None, drop=None):
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice).
-    out_scale / out_shift (fp32 [OC], inference only): out = conv * out_scale + out_shift -- an eval-mode BatchNorm folded in."""
+    out_scale / out_shift (fp32 [OC], inference only): out = conv * out_scale + out_shift -- an eval-mode BatchNorm folded in.
+    drop=(p, salt) with relu=True (training, 1x1): out = dropout_p(relu(linear(x))) with the mask drawn in the GEMM epilogue
+    (emrt_conv2d_drop); the caller promises that the result feeds exactly one conv2d / linear, whose data gradient applies both masks."""
     c = ctx()
+    if drop is not None and not (c.training and drop[0] > 0.0):
+        drop = None
     if isinstance(x, PendingBN):
         assert stride == 1 and pad == 0 and not relu and residual is None and out is None and not out_f32 and bn_stats is None and out_scale is None
         return _pointwise_on_pending(x, w)
@@ -347,10 +351,24 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     if residual is not None:
         _, _, _, _, ldres, res_bs = _check_map(residual)
     assert out_scale is None or c.tape is None, "BatchNorm folding is inference only"     # (out_shift already holds w.bias * scale)
-    _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(out_shift) if out_scale is not None else P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
-              OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), None, 0, 0,
-              dil, P(out_scale), c.dtype, c.stream)
+    fused_drop = (drop is not None and relu and w.KH * w.KW == 1 and stride == 1 and pad == 0 and residual is None and not out_f32 and bn_stats is None
+                  and out_scale is None and w.OC % 8 == 0 and in_bs == H * W * ldin and out_bs == OH * OW * ldout and c.fuse_ffn_dropout
+                  and C % 8 == 0 and ldin % 8 == 0 and ldout % 8 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
+    if fused_drop:
+        _L().call("emrt_conv2d_drop", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), N * H * W, C, ldin, w.OC, ldout, float(drop[0]), c.seed_ptr,
+                  int(drop[1]), c.dtype, c.stream)
+    else:
+        _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(out_shift) if out_scale is not None else P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
+                  OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), None, 0, 0,
+                  dil, P(out_scale), c.dtype, c.stream)
+    if drop is not None and not fused_drop:      # (a geometry the fused entry point does not take: the separate dropout launch)
+        return dropout(out, drop[0], drop[1], sole_consumer_is_linear=True)
     tape = c.tape
+    own_drop = None
+    if fused_drop and tape is not None:
+        # as Fn.dropout(sole_consumer_is_linear=True): the consumer's data gradient multiplies by (out > 0) / (1 - p) and leaves its dx here
+        own_drop = {"scale": 1.0 / (1.0 - float(drop[0])), "dx": None}
+        out._drop_rec = own_drop
     bn_rec = getattr(x, "_bn_rec", None)      # x = relu(BatchNorm(.)) fresh from batch_norm(): see the dgrad call below
     drop_rec = getattr(x, "_drop_rec", None)  # x = dropout(relu(linear(.))) with this layer as its only consumer
     res_rec = getattr(x, "_bnres_rec", None)  # x = relu(BatchNorm(.) + residual): a residual join, several consumers
@@ -361,7 +379,15 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                 return
             if out_f32 and dy.dtype == torch.float32:      # (a producer may hand the gradient over in the compute dtype already: Fn.msda)
                 dy = cast_from_f32(dy)
-            if relu and getattr(out, "_premasked", None) is not dy:
+            if own_drop is not None:
+                # the gradient of dropout(relu(.)): already masked and scaled when the consumer's dgrad did it (the usual case); otherwise
+                # (out > 0) is the mask of both -- a stored value is positive iff it was kept AND past the ReLU -- times 1 / (1 - p)
+                if own_drop["dx"] is not dy:
+                    assert dy.is_contiguous() and out.is_contiguous()
+                    dm = c.empty(tuple(dy.shape), dy.dtype)
+                    _L().call("emrt_mask_bwd", P(dy), P(out), P(dm), dy.numel(), float(drop[0]), None, 0, 0, 1, 1, c.dtype, c.stream)
+                    dy = dm
+            elif relu and getattr(out, "_premasked", None) is not dy:
                 assert dy.is_contiguous() and out.is_contiguous()
                 dm = c.empty(tuple(dy.shape), dy.dtype)
                 _L().call("emrt_mask_bwd", P(dy), P(out), P(dm), dy.numel(), 0.0, None, 0, 0, 1, 1, c.dtype, c.stream)
@@ -434,9 +460,9 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     return out
 
 
-def linear(x, w, relu=False, out_f32=False, need_dx=True):
+def linear(x, w, relu=False, out_f32=False, need_dx=True, drop=None):
     """x [B, L, C] or [M, C] (strided rows allowed) -> [..., OC]: a 1x1 convolution over the row axis."""
-    return conv2d(x, w, 1, 0, relu=relu, out_f32=out_f32, need_dx=need_dx)
+    return conv2d(x, w, 1, 0, relu=relu, out_f32=out_f32, need_dx=need_dx, drop=drop)
 
 
 def colsum_acc(x, dst_f32):
@@ -1283,6 +1309,30 @@ def sigmoid_f32(x):
 # ---------------------------------------------------------------------------------------------------
 # loss
 # ---------------------------------------------------------------------------------------------------
+def softmax_ce_pair(logits_a, logits_b, labels, ignore_index, wa, wb):
+    """CE of two heads on the same labels (MixSoftmaxCrossEntropyLoss: main + aux) in one forward pass and one backward launch.
+    Returns (res_a, res_b, total): device float[2] = {loss, count} per head and float[1] = wa * loss_a + wb * loss_b."""
+    c = ctx()
+    N, C, H, W = logits_a.shape
+    assert tuple(logits_b.shape) == (N, C, H, W) and logits_a.dtype == logits_b.dtype == torch.float32 and logits_a.is_contiguous() and logits_b.is_contiguous()
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    res_a, res_b, total = c.empty((2,), torch.float32), c.empty((2,), torch.float32), c.empty((1,), torch.float32)
+    ws = c.workspace(_L().query("emrt_ce_workspace_bytes"))
+    _L().call("emrt_softmax_ce_pair_fwd", P(logits_a), P(logits_b), P(labels), N, C, H, W, ignore_index, float(wa), float(wb), P(res_a), P(res_b), P(total),
+              P(ws), c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            up_a, up_b = tape.pop_grad(res_a), tape.pop_grad(res_b)      # device scalars or None (== 1)
+            da, db = c.empty((N, C, H, W), torch.float32), c.empty((N, C, H, W), torch.float32)
+            _L().call("emrt_softmax_ce_pair_bwd", P(logits_a), P(logits_b), P(labels), P(res_a), P(up_a), P(up_b), float(wa), float(wb), N, C, H, W,
+                      ignore_index, P(da), P(db), c.stream)
+            tape.add_grad(logits_a, da, owned=True)
+            tape.add_grad(logits_b, db, owned=True)
+        tape.record(bwd)
+    return res_a, res_b, total
+
+
 def softmax_ce(logits, labels, ignore_index, weight=1.0):
     """Mean CE over non-ignored pixels of fp32 NCHW logits; returns a device float[2] = {loss, count}.
     Backward writes weight * upstream * (softmax - onehot)/count as the gradient of `logits`."""

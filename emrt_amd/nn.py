@@ -283,8 +283,8 @@ class Linear(HipLayer):
             self.gw = store.make_gemm(store.offsets[prefix + "weight"], self.cout, self.cin, 1, 1,
                                       store.offsets[prefix + "bias"] if self.bias is not None else None)
 
-    def forward(self, x, relu=False, out_f32=False):
-        return Fn.linear(x, self.gw, relu=relu, out_f32=out_f32)
+    def forward(self, x, relu=False, out_f32=False, drop=None):
+        return Fn.linear(x, self.gw, relu=relu, out_f32=out_f32, drop=drop)
 
 
 class BatchNorm2D(HipLayer):

@@ -224,6 +224,7 @@ class Context:
         # training: a BatchNorm + ReLU whose only consumer streams the map once (x2 resize, 3x3 max-pool) is applied by that consumer's
         # loads instead of its own emrt_bn_apply launch (functional.PendingBN).  0 = always the separate launch (A/B knob).
         self.bn_defer = bool(int(os.environ.get("EMRT_BN_DEFER", "1")))
+        self.fuse_ffn_dropout = bool(int(os.environ.get("EMRT_FFN_DROPOUT_FUSED", "1")))      # A/B: dropout(relu(linear1)) drawn in the GEMM epilogue (emrt_conv2d_drop)
         # the decoder's pyramid maps resized by ONE launch per direction (emrt_pyramid_resize_fwd / _bwd); 0 = one launch per scale (A/B knob)
         self.pyramid_group = bool(int(os.environ.get("EMRT_PYRAMID_GROUP", "1")))
         # EMRT_WGRAD_SIDE=1 (A/B experiment): the batched weight-gradient launches go to a second stream, next to the latency-bound
@@ -306,6 +307,7 @@ class Context:
             # the library keeps the registered pointer: withdraw it before the tensor (and its memory) goes away
             _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(0), ctypes.c_size_t(0), ctypes.c_void_p(0))
             self._scratch = None
+            self._scratch_stream = None
         self._seed = torch.tensor([seed * 0x9E3779B97F4A7C15 % (1 << 63)], dtype=torch.int64, device=self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._arena, self._arena_off, self._arena_live = None, 0, False
@@ -367,7 +369,19 @@ class Context:
         cross-block K split, registered for THIS context's stream by the first bf16 / fp16 forward -- fp32 contexts (the parity mode) never
         pay for it and never take those kernels.  Its address is baked into captured graphs: allocated once, outside any capture (the eager
         warm-up steps come first; TrainEngine._capture and SlidingWindowEngine make sure of it), never reallocated."""
-        if self.dtype == F32 or getattr(self, "_scratch", None) is not None or torch.cuda.is_current_stream_capturing():
+        if self.dtype == F32:
+            return
+        cur = torch.cuda.current_stream().cuda_stream
+        if getattr(self, "_scratch", None) is not None:
+            # the region belongs to ONE stream at a time (partial tiles and their reader are only ordered within a stream).  torch captures a
+            # hipGraph on a side stream of its own, so a step being captured would find the region registered for another stream and silently
+            # bake the fallback kernels into the graph (fp32 atomics instead of the slab + reduce pair, no cross-block K split: round 4's captured
+            # step ran that way); the region follows the stream that launches: a host-side assignment, no device work, legal while capturing.
+            if getattr(self, "_scratch_stream", None) != cur and not self.wgrad_side:
+                _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()), ctypes.c_void_p(cur))
+                self._scratch_stream = cur
+            return
+        if torch.cuda.is_current_stream_capturing():
             return
         # + 64 KiB: the arrival counters of the convolutions' cross-block K split (csrc/conv.hip, igemm_body XK), carved off the tail and zeroed by
         # emrt_set_scratch; the split's partial tiles (<= 8 MiB) share the slab with the weight-gradient kernel -- same stream, one after the other
@@ -378,6 +392,7 @@ class Context:
                 self._wside = torch.cuda.Stream(device=self.device)
             st = ctypes.c_void_p(self._wside.cuda_stream)
         _lib.lib().call("emrt_set_scratch", ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_size_t(self._scratch.numel()), st)
+        self._scratch_stream = st.value if hasattr(st, "value") else cur
 
     def end_step(self):
         """Outside a training step (eval forward) the arena is not re-zeroed: zeros_f64() must hand out fresh zeroed buffers."""

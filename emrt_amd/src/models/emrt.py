@@ -335,8 +335,7 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
         q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
         src2 = self.self_attn(q, reference_points, src, spatial_shapes)
         src = self.norm1(src, src2, drop_p=self.p, drop_salt=self.salts[0])       # LN(src + dropout1(src2)), dropout inside the LN kernels
-        h1 = self.linear1(src, relu=True)
-        h1 = Fn.dropout(h1, self.p, self.salts[1], sole_consumer_is_linear=True)     # its mask and the ReLU's are applied by linear2's dgrad
+        h1 = self.linear1(src, relu=True, drop=(self.p, self.salts[1]))     # dropout(relu(linear1)) in one launch; both masks are applied by linear2's dgrad
         ff = self.linear2(h1)
         return self.norm2(src, ff, post=src_flatten, drop_p=self.p, drop_salt=self.salts[2])    # LN(src + dropout(ffn)) + conv-branch tokens (:202-203)
 
@@ -378,7 +377,7 @@ class TransformerDecoderLayer(hnn.HipLayer):  # :242-295
         q2 = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
         tgt2 = self.cross_attn(q2, reference_points, memory, spatial_shapes, need_dref=True)
         tgt = self.norm2(tgt, tgt2, drop_p=self.p, drop_salt=self.salts[1])
-        h1 = Fn.dropout(self.linear1(tgt, relu=True), self.p, self.salts[2], sole_consumer_is_linear=True)
+        h1 = self.linear1(tgt, relu=True, drop=(self.p, self.salts[2]))
         return self.norm3(tgt, self.linear2(h1), drop_p=self.p, drop_salt=self.salts[3])
 
 

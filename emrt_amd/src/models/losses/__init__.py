@@ -63,7 +63,12 @@ class MixSoftmaxCrossEntropyLoss:
         try:
             target = target.contiguous()
             weights = [1.0] + [self.aux_weight if self.aux else 1.0] * (len(preds) - 1)
-            parts = [Fn.softmax_ce(p, target, self.ignore_index, w) for p, w in zip(preds, weights) if p is not None]
+            live = [(p, w) for p, w in zip(preds, weights) if p is not None]
+            if len(live) == 2 and tuple(live[0][0].shape) == tuple(live[1][0].shape):
+                # the recipe's case (main + aux head at the input size): both heads in one pass, the weighted total formed by the finalize launch
+                ra, rb, total = Fn.softmax_ce_pair(live[0][0], live[1][0], target, self.ignore_index, live[0][1], live[1][1])
+                return LossValue(total, [ra, rb], tape)
+            parts = [Fn.softmax_ce(p, target, self.ignore_index, w) for p, w in live]
         finally:
             c.tape = None
         total = c.empty((1,), parts[0].dtype)

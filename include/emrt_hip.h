@@ -37,7 +37,7 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
  * conv_tile, wgrad_split, no_ksplit128, ln_bwd_rows, ln_bwd_max_blocks, wgrad_no_overwrite, bn_operand_blocks, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
  * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
- * gn_bwd_stat_rows, gn_apply_rows.
+ * gn_bwd_stat_rows, gn_apply_rows, xk.
  * Not thread-safe against concurrent launches; production code never calls these. */
 int emrt_set_tuning(const char* name, int value);
 int emrt_get_tuning(const char* name, int* value);
@@ -46,7 +46,11 @@ int emrt_get_tuning(const char* name, int* value);
  * for train.py:142-149's loss.backward() of the large layers.  Without it that kernel adds its tiles into dW with fp32 atomics.  The
  * memory must stay valid (and the pointer unchanged across hipGraph replays) until it is unregistered.  `stream` (ABI 5) is the ONE stream
  * whose launches may use it: a call on any other stream falls back to the atomic epilogue (partial tiles + reduce launch are only ordered
- * within a stream). */
+ * within a stream).  ABI 7: a region of more than 1 MiB (a multiple of 256 bytes) gives its LAST 64 KiB to the arrival counters of the
+ * convolutions' cross-block K split (emrt_conv2d / emrt_conv2d_bwd on few-tile, long-K layers: partial fp32 tiles of S blocks per output tile
+ * go through the region, the last block to arrive sums them and runs the epilogue -- nn.Conv2D of the 8x8 / 16x16 ResNet stages,
+ * paddle_vision_resnet.py:111-119); the counters are zeroed here with a memset enqueued on `stream` and every launch leaves them zero.  Without
+ * a registered region (fp32 contexts) those layers run the in-block K split. */
 int emrt_set_scratch(void* ptr, size_t bytes, void* stream);
 
 /* ---- convolution / linear as implicit GEMM (MFMA 32x32) ---------------------------------------------------
@@ -61,6 +65,12 @@ int emrt_set_scratch(void* ptr, size_t bytes, void* stream);
  * bn_stats (nullable): fp64 [8][2*OC] (8 replicas, see BatchNorm below), pre-zeroed; the epilogue adds per-channel sum / sum-of-squares of the stored outputs
  * (the BatchNorm statistics of the layer that follows, fused so the activation is not re-read). */
 int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int mode, int relu, int out_f32, double* bn_stats, const void* mask_y, int ldy, long long y_bs, int dilation, const float* out_scale, int dtype, void* stream);
+/* out [M][OC] = dropout_p(relu(in [M][C] . w_packed^T + bias)), the mask drawn in the GEMM epilogue: replaces nn.Linear -> F.relu -> nn.Dropout of
+ * the transformer FFN (EMRT_utils/transformer_encoder_decoder.py:118-121,157-161 encoder; :259-262,276-280 decoder) in one launch.  Row strides
+ * ldin / ldout in elements; 0 < p < 1; seed: the device seed word (emrt_counter_add advances it per step); salt: per call site; OC % 8 == 0;
+ * dtype 0 / 1.  Kept values are scaled by 1 / (1 - p).  Backward: emrt_conv2d_bwd of the CONSUMER with mask_y = out, mask_scale = 1 / (1 - p)
+ * (a stored value > 0 <=> kept and past the ReLU), then emrt_conv2d_bwd of this layer on the masked gradient: no mask tensor, no seed. */
+int emrt_conv2d_drop(const void* in, const void* w_packed, void* out, const float* bias, int M, int C, int ldin, int OC, int ldout, float p, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream);
 /* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE
@@ -235,6 +245,12 @@ int emrt_softmax_nchw_acc(const float* logits, float* acc, int N, int C, int H, 
 size_t emrt_ce_workspace_bytes(void);
 int emrt_softmax_ce_fwd(const float* logits, const long long* labels, int N, int C, int H, int W, int ignore_index, float* result, void* workspace, void* stream);
 int emrt_softmax_ce_bwd(const float* logits, const long long* labels, const float* result, const float* upstream, float weight, int N, int C, int H, int W, int ignore_index, float* dlogits, void* stream);
+/* ABI 7: both heads of MixSoftmaxCrossEntropyLoss (losses/mix_softmax_cross_entropy_loss.py:29-35,44-51: CE(main) + AUX_WEIGHT * CE(aux) on the same
+ * labels) at once -- one streaming launch over both logit tensors + one finalize that also forms total[0] = wa * loss_a + wb * loss_b; backward: one
+ * launch for both gradients (dlogits_x = w_x * up_x * (softmax - onehot) / count; up_x NULL == 1).  Same per-pixel arithmetic as the single-head
+ * entry points.  res_a / res_b: device float[2] = {mean loss, non-ignored count}. */
+int emrt_softmax_ce_pair_fwd(const float* logits_a, const float* logits_b, const long long* labels, int N, int C, int H, int W, int ignore_index, float wa, float wb, float* res_a, float* res_b, float* total, void* workspace, void* stream);
+int emrt_softmax_ce_pair_bwd(const float* logits_a, const float* logits_b, const long long* labels, const float* res_a, const float* up_a, const float* up_b, float wa, float wb, int N, int C, int H, int W, int ignore_index, float* dlogits_a, float* dlogits_b, void* stream);
 int emrt_scalar_axpby(float* out, const float* a, float wa, const float* b, float wb, void* stream);
 
 /* ---- optimizer: ClipGradByGlobalNorm + L2 decay + Momentum over one flat fp32 buffer, PolynomialDecay evaluated
@@ -264,6 +280,8 @@ int emrt_concat_tokens(void* const* parts, const int* n, int nparts, void* whole
 int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const void* src, long long src_bs, long long src_rs, long long B, long long rows, long long cols, int dtype, void* stream);
 int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream);
 int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode, long long hw, int C, int dtype, void* stream);
+/* dx = dy * dropmask(p, seed, salt) / (1 - p) * (relu_out > 0); either mask optional (p == 0 / relu_out == NULL).  ABI 7: p > 0 with seed == NULL and
+ * relu_out given: relu_out is the stored output of emrt_conv2d_drop, whose sign carries BOTH masks: dx = relu_out > 0 ? dy / (1 - p) : 0. */
 int emrt_mask_bwd(const void* dy, const void* relu_out, void* dx, long long n, float p, const unsigned long long* seed, unsigned salt, int mode, long long hw, int C, int dtype, void* stream);
 int emrt_sigmoid_fwd(const float* x, float* y, long long n, void* stream);
 int emrt_sigmoid_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);

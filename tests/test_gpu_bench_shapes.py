@@ -143,6 +143,47 @@ def test_msda_lds_scatter_is_bit_reproducible():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("offsets", ["compass", "spread"])
+def test_msda_scatter_merging_consecutive_points_gives_the_same_value_gradient(offsets):
+    """Knob msda_scatter_merge (csrc/msda.hip: msda_bwd_value_lds_kernel): consecutive points of a query with the same 2 x 2 footprint are
+    added in registers before the LDS atomics.  Same value gradient as the unmerged scatter up to the fixed-point rounding of a merged pair
+    (|sum of two roundings - rounding of the sum| <= 1 unit of 2^-30 / (Lq max|g|)), on the untrained compass offsets of _reset_parameters
+    (t_e_d.py:46-63: many merges in the coarser levels) and on offsets spread by 2.5 px (hardly any); bit-reproducible either way."""
+    import math
+    c = init(BF16)
+    L_ = _lib.lib()
+    cfg = MSDA_BENCH[0]
+    value, offw, ref, shapes, (B, Lq, Lv, M, L, Pn) = _msda_inputs(cfg, 35)
+    if offsets == "compass":      # offsets = head m's compass direction x point index k = 1..P, the same for every query and level; zero logits
+        th = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+        grid = torch.stack([th.cos(), th.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True)[0]
+        grid = grid.reshape(M, 1, 1, 2).repeat(1, L, Pn, 1) * torch.arange(1, Pn + 1, dtype=torch.float32).reshape(1, 1, -1, 1)
+        offw = torch.cat([grid.flatten().expand(B, Lq, -1), torch.zeros(B, Lq, M * L * Pn)], -1).contiguous()
+    vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
+    dy = dev(rnd(torch.randn(B, Lq, M * 32, generator=torch.Generator().manual_seed(36))))
+    res = {}
+    for knob in (0, 1, 1):
+        old = L_.set_tuning("msda_scatter_merge", knob)
+        try:
+            tape = Tape()
+            c.tape = tape
+            y = Fn.msda(vd, od, rd, shapes, M, Pn)
+            c.tape = None
+            tape.watch(vd)
+            dv, = run_bwd(tape, [(y, dy)], [vd])
+            res.setdefault(knob, []).append(host(dv))
+        finally:
+            L_.set_tuning("msda_scatter_merge", old)
+    assert torch.equal(res[1][0], res[1][1]), "the merged scatter is not bit-reproducible"
+    a, b = res[0][0], res[1][0]
+    rel = ((a - b).norm() / a.norm()).item()
+    differ = (a != b).float().mean().item()
+    print("msda scatter merge (%s offsets): value gradient rel L2 %.2e vs unmerged, %.4f %% of the elements differ" % (offsets, rel, 100 * differ))
+    assert rel < 2e-4 and differ < 0.01, (rel, differ)          # a bf16 element flips only where the fixed-point sums differ by a unit right at a rounding boundary
+
+
+
 # -----------------------------------------------------------------------------------------------------------------
 # convolutions at the shapes that carry the step's FLOPs
 # -----------------------------------------------------------------------------------------------------------------

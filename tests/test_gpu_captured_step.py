@@ -31,7 +31,7 @@ from tests.test_gpu_model import calibrated_oracle, make_config, perturb_samplin
 STEPS = 3
 TRACE_REL = 1e-3          # captured vs eager loss, every step (measured: see the printed line)
 WEIGHT_REL = 2e-4         # relative L2 distance of all trainable weights after STEPS updates
-GRAD_REL = 2e-2           # relative L2 distance of step 1's flat gradient, captured vs eager (bf16 activations downstream of fp32-atomic noise)
+GRAD_REL = 2e-2           # ... of step 1's flat gradient, or 2.5 x what two EAGER runs differ by (measured on MI355X: 5-6 %, printed)
 
 
 @pytest.mark.parametrize("B,S,ncls", [(8, 256, 6), (4, 512, 7)], ids=["cfg2-8x256", "cfg3-4x512"])
@@ -47,7 +47,7 @@ def test_captured_bf16_step_equals_eager_and_tracks_the_oracle(B, S, ncls):
     xd, ld = x.cuda(), labels.cuda()
 
     runs = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "eager2", "graph"):          # eager twice: the yardstick for what two runs of the SAME program differ by
         model = get_model(cfg)
         model.load_state_dict(state)
         model.to_hip("cuda:0", BF16)
@@ -78,14 +78,21 @@ def test_captured_bf16_step_equals_eager_and_tracks_the_oracle(B, S, ncls):
         runs[mode] = out
         del eng, opt, model
 
+    def distance(u, v):
+        return (max(abs(a - b) / max(1.0, abs(a)) for a, b in zip(u["loss"], v["loss"])),
+                ((u["grad"] - v["grad"]).norm() / u["grad"].norm()).item(), ((u["weights"] - v["weights"]).norm() / u["weights"].norm()).item())
     e, c = runs["eager"], runs["graph"]
-    trace = max(abs(a - b) / max(1.0, abs(a)) for a, b in zip(e["loss"], c["loss"]))
-    wrel = ((e["weights"] - c["weights"]).norm() / e["weights"].norm()).item()
-    grel = ((e["grad"] - c["grad"]).norm() / e["grad"].norm()).item()
+    trace, grel, wrel = distance(e, c)
+    trace0, grel0, wrel0 = distance(e, runs["eager2"])
     print("CAPTURED vs EAGER %dx%dx%d bf16: loss traces %s vs %s (worst rel %.2e), step-1 gradient rel L2 %.2e, weights after %d steps rel L2 %.2e" % (
         B, S, S, ["%.5f" % v for v in c["loss"]], ["%.5f" % v for v in e["loss"]], trace, grel, STEPS, wrel))
+    print("EAGER vs EAGER (same program twice: fp32-atomic order only): loss %.2e, step-1 gradient %.2e, weights %.2e" % (trace0, grel0, wrel0))
     assert all(v == v and v > 0 for v in c["loss"] + e["loss"])
-    assert trace < TRACE_REL and grel < GRAD_REL and wrel < WEIGHT_REL, (trace, grel, wrel)
+    # the gradient of this random-init network is the sensitive quantity: bf16 activations turn the weight gradients' summation-order noise
+    # into last-bit flips that grow with depth, so two eager runs already differ by percents in the gradient while loss and weights agree
+    # to 1e-5; the captured step must be no further from eager than eager is from itself (x 2.5 + a floor)
+    assert trace < max(TRACE_REL, 2.5 * trace0) and wrel < max(WEIGHT_REL, 2.5 * wrel0), (trace, trace0, wrel, wrel0)
+    assert grel < max(GRAD_REL, 2.5 * grel0), (grel, grel0)
 
     # ---- step 1 of BOTH against the fp32 CPU oracle's train step -----------------------------------------------------------------
     ref.train()
@@ -93,6 +100,8 @@ def test_captured_bf16_step_equals_eager_and_tracks_the_oracle(B, S, ncls):
     loss_r.backward()
     refp = dict(ref.named_parameters())
     for mode, r in runs.items():
+        if mode == "eager2":
+            continue
         rel_loss = abs(r["loss"][0] - loss_r.item()) / abs(loss_r.item())
         dot = n_hip = n_ref = 0.0
         for k, gg in r["named_grads"].items():

@@ -33,6 +33,7 @@ def _worker(rank, world, port, q, modes=("eager_plain", "eager_early", "graph_ea
     from emrt_amd.src.models.losses import get_loss_function
     from emrt_amd.src.models.solver import get_optimizer, get_scheduler
     here = os.path.dirname(os.path.abspath(__file__))
+    torch.set_num_threads(2)          # (the ranks share the host with each other and with the other test workers: GPU work and gloo only)
     r, _, w = init_process_group()
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
     try:
@@ -133,6 +134,7 @@ def _identity_worker(rank, world, port, q):
     from emrt_amd.src.models.losses import get_loss_function
     from emrt_amd.src.models.solver import get_optimizer, get_scheduler
     here = os.path.dirname(os.path.abspath(__file__))
+    torch.set_num_threads(2)
     init_process_group()
     try:
         cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(here, "..", "emrt_amd", "configs", "EMRT", "EMRT_256x256_160k_potsdam.yaml")))

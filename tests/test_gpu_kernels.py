@@ -551,6 +551,103 @@ def test_ffn_dropout_relu_masks_fused_into_linear2_dgrad(dtype, dims):
     close("ffn db2", res["fused"][5], B2.grad, dtype, sc)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dims", [(2, 57, 256, 1024), (3, 110, 64, 96), (8, 1344, 256, 1024)])
+def test_ffn_dropout_drawn_in_linear1_epilogue(dtype, dims):
+    """linear2(dropout(relu(linear1(x)))) with the dropout drawn in linear1's GEMM epilogue (emrt_conv2d_drop; reference: nn.Linear ->
+    F.relu -> nn.Dropout -> nn.Linear, transformer_encoder_decoder.py:157-161): ONE forward launch for the first half, no dropout launch, no
+    mask launch in backward.  Checked: every stored activation is 0 or relu(linear1) / (1 - p); the dropped fraction among the positive ones
+    is p (binomial bounds), evenly over rows, channels and the 8 lanes of a mask group; a second seed gives another mask; forward and every
+    gradient equal torch autograd with the device's own mask read back from the stored activation."""
+    from emrt_amd import _lib
+    B, Lq, C, Hd = dims
+    c = init(dtype)
+    c.training = True
+    p = 0.1
+    g = torch.Generator().manual_seed(78)
+    x = rnd(torch.randn(B, Lq, C, generator=g))
+    dy = rnd(torch.randn(B, Lq, C, generator=g))
+    w1, b1 = rnd(torch.randn(Hd, C, generator=g) / math.sqrt(C)), torch.randn(Hd, generator=g) * 0.1
+    w2, b2 = rnd(torch.randn(C, Hd, generator=g) / math.sqrt(Hd)), torch.randn(C, generator=g) * 0.1
+    l1, l2 = hnn.Linear(C, Hd), hnn.Linear(Hd, C)
+    with torch.no_grad():
+        l1.weight.copy_(w1)
+        l1.bias.copy_(b1)
+        l2.weight.copy_(w2)
+        l2.bias.copy_(b2)
+    Holder(l1=l1, l2=l2).place()
+    xd = dev(x)
+    L = _lib.lib()
+    tape = Tape()
+    c.tape = tape
+    L.start_record()
+    hd = l1(xd, relu=True, drop=(p, 23))
+    o = l2(hd)
+    fwd_names = [n for n, _ in L.stop_record()]
+    c.tape = None
+    tape.watch(xd)
+    assert fwd_names == ["emrt_conv2d_drop", "emrt_conv2d"], fwd_names
+    L.start_record()
+    dx, = run_bwd(tape, [(o, dev(dy))], [xd])
+    bwd_names = [n for n, _ in L.stop_record()]
+    assert "emrt_mask_bwd" not in bwd_names and "emrt_dropout_fwd" not in bwd_names
+    hdd = host(hd)
+    # the mask, read back: a stored value is positive iff it was kept and past the ReLU
+    xr = x.clone().requires_grad_(True)
+    W1 = w1.clone().requires_grad_(True)
+    B1, W2, B2 = b1.clone().requires_grad_(True), w2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    hr = F.relu(F.linear(xr, W1, B1))
+    pos = hr.detach() > (1e-2 if dtype == BF16 else 1e-4)          # (clear of the ReLU's edge: rounding may put a tiny value on either side)
+    keep = (hdd > 0).float()
+    dropped = 1.0 - keep[pos].mean().item()
+    n_pos = int(pos.sum())
+    sd = 5.0 * math.sqrt(p * (1 - p) / n_pos)
+    print("dropout in the GEMM epilogue %s: %.4f of %d positive activations dropped (p = %.2f, 5 sigma = %.4f)" % (dims, dropped, n_pos, p, sd))
+    assert abs(dropped - p) < sd + 2e-4          # (+ the 16-bit threshold's resolution)
+    k3 = keep.reshape(-1, Hd)
+    p3 = pos.reshape(-1, Hd)
+    for lane in range(8):                            # the eight 16-bit fields of a mask group
+        sel = p3[:, lane::8]
+        frac = 1.0 - k3[:, lane::8][sel].mean().item()
+        assert abs(frac - p) < 5.0 * math.sqrt(p * (1 - p) / max(1, int(sel.sum()))) + 2e-4, (lane, frac)
+    rows = (1.0 - (k3 * p3).sum(1) / p3.sum(1).clamp(min=1))
+    assert rows[p3.sum(1) > 16].std().item() < 3.0 * math.sqrt(p * (1 - p) / max(8.0, p3.sum(1).float().mean().item())) + 0.02
+    scale = 1.0 / (1.0 - p)
+    want_h = hr.detach() * keep * scale
+    close("ffn hidden = relu(linear1) * mask / (1 - p)", hdd, want_h, dtype, 2.0)
+    if dtype == BF16:
+        hr = hr + (rnd(hr.detach() * scale) / scale - hr.detach())         # the device rounds the SCALED activation to bf16 once
+    orf = F.linear(hr * keep * scale, W2, B2)
+    (orf * dy).sum().backward()
+    sc = math.sqrt(B * Lq)
+    close("ffn o", host(o), orf.detach(), dtype, 2.0)
+    close("ffn dx", host(dx), xr.grad, dtype, 3.0 * (1.0 if dtype == F32 else 0.3))
+    close("ffn dw1", host(l1.weight.grad), W1.grad, dtype, sc * (1.0 if dtype == F32 else 0.5))
+    close("ffn db1", host(l1.bias.grad), B1.grad, dtype, sc * (1.0 if dtype == F32 else 0.5))
+    close("ffn dw2", host(l2.weight.grad), W2.grad, dtype, sc)
+    close("ffn db2", host(l2.bias.grad), B2.grad, dtype, sc)
+    # another step (the device seed advances): another mask
+    L.call("emrt_counter_add", Fn.P(c._seed), 0x2545F4914F6CDD1D & 0x7FFFFFFFFFFFFFFF, c.stream)
+    hd2 = host(l1(xd, relu=True, drop=(p, 23)))
+    differ = ((hd2 > 0) != (hdd > 0)).float().mean().item()
+    assert 0.5 * 2 * p * (1 - p) * pos.float().mean().item() < differ < 1.5 * 2 * p * (1 - p) + 0.01, differ
+    # a gradient that does NOT come from a masking consumer (the output is used directly): the layer masks and scales it itself
+    tape = Tape()
+    c.tape = tape
+    hd3 = l1(xd, relu=True, drop=(p, 23))
+    c.tape = None
+    tape.watch(xd)
+    gdy = rnd(torch.randn(B, Lq, Hd, generator=g))
+    l1.weight.grad.zero_()
+    L.start_record()
+    dx3, = run_bwd(tape, [(hd3, dev(gdy))], [xd])
+    assert "emrt_mask_bwd" in [n for n, _ in L.stop_record()]
+    keep3 = (host(hd3) > 0).float()
+    xr3 = x.clone().requires_grad_(True)
+    (F.relu(F.linear(xr3, w1, b1)) * keep3 * scale * gdy).sum().backward()
+    close("dropout(relu(linear1)) backward on its own", host(dx3), xr3.grad, dtype, 3.0 * (1.0 if dtype == F32 else 0.3))
+
+
 # -----------------------------------------------------------------------------------------------------------------
 def _msda_ref(value, offw, ref, shapes, M, L, Pn):
     from oracle.emrt_torch import deformable_attention_core_func
@@ -709,6 +806,103 @@ def test_mha_dropout_backward_consistent_with_forward():
     lhs = ((host(y2) - host(y)) * dy).sum().item()
     rhs = (host(dv) * d).sum().item()
     assert abs(lhs - rhs) < 2e-3 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+def test_mha_mfma_kernels_dropout_and_agreement_with_the_valu_kernels():
+    """bf16 takes the MFMA kernels (csrc/attn.hip: mha_fwd_mfma_kernel / mha_bwd_mfma_kernel; layers.py:283-303).  (1) Without dropout they
+    must agree with the VALU kernels (knob mha_valu) on the same bf16 inputs to bf16 rounding, forward and all three gradients, at the
+    decoder's L = 110 and at ragged / full tile counts.  (2) With dropout on the attention weights (layers.py:297) the forward's mask and the
+    backward's two re-derivations of it (row pass: dq; column pass: dk, dv) must be ONE mask: with the mask fixed the output is linear in V,
+    so <dy, o(V + d) - o(V)> == <dV, d>; and it is linear in the scores' gradient direction too: a finite-difference check of dq / dk along a
+    random direction ties the column pass's mask to the forward's.  The dropped fraction is p."""
+    from emrt_amd import _lib
+    L_ = _lib.lib()
+    c = init(BF16)
+    g = torch.Generator().manual_seed(21)
+    E, Mh = 256, 8
+    for L in (110, 128, 37, 16, 2):
+        B = 2
+        c.training = False
+        qk, v = rnd(torch.randn(B, L, 2 * E, generator=g)), rnd(torch.randn(B, L, E, generator=g))
+        dy = rnd(torch.randn(B, L, E, generator=g))
+        outs = {}
+        for knob in (0, 1):
+            old = L_.set_tuning("mha_valu", knob)
+            try:
+                qd, vd = dev(qk), dev(v)
+                tape = Tape()
+                c.tape = tape
+                y = Fn.mha(qd, vd, Mh, 0.1, 3)
+                c.tape = None
+                tape.watch(qd)
+                tape.watch(vd)
+                dqk, dv = run_bwd(tape, [(y, dev(dy))], [qd, vd])
+                outs[knob] = [host(t) for t in (y, dqk, dv)]
+            finally:
+                L_.set_tuning("mha_valu", old)
+        for u, w_, name in zip(outs[0], outs[1], ("out", "dqk", "dv")):
+            rel = ((u - w_).norm() / w_.norm()).item()
+            assert rel < 6e-3, ("L=%d %s: MFMA vs VALU relative L2 %.3g" % (L, name, rel))          # two bf16 roundings (probabilities as MFMA operands)
+    # ---- dropout: one mask in three places -------------------------------------------------------------------------------------
+    c.training = True
+    B, L, p = 2, 110, 0.5
+    qk, v, d = (rnd(torch.randn(B, L, n, generator=g)) for n in (2 * E, E, E))
+    d = rnd(d * 0.25)
+    dy = rnd(torch.randn(B, L, E, generator=g))
+    qd, vd, v2d = dev(qk), dev(v), dev(rnd(v + d))
+    tape = Tape()
+    c.tape = tape
+    y = Fn.mha(qd, vd, Mh, p, 7)
+    c.tape = None
+    tape.watch(vd)
+    tape.watch(qd)
+    y2 = Fn.mha(qd, v2d, Mh, p, 7)
+    c.training = False
+    y0 = Fn.mha(qd, vd, Mh, p, 7)
+    c.training = True
+    assert (host(y) - host(y0)).abs().max() > 1e-2
+    dqk, dv = run_bwd(tape, [(y, dev(dy))], [qd, vd])
+    dvh = host(dv)
+    lhs = ((host(y2) - host(y)) * dy).sum().item()
+    rhs = (dvh * (host(v2d) - host(vd))).sum().item()
+    print("MHA MFMA dropout: <dy, o(V+d) - o(V)> = %.4f, <dV, d> = %.4f" % (lhs, rhs))
+    assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(lhs)), (lhs, rhs)
+    # dq / dk / dv against torch autograd with the DEVICE'S OWN mask: the dropped probabilities are read out of the forward itself with one-hot
+    # values (V_j = e_{j mod 32} for the keys of one block of 32: out_i[d] is then Pd[i][that key]), once with and once without dropout
+    def read_probs(pp, train):
+        c.training = train
+        cols = []
+        for blk in range((L + 31) // 32):
+            vv = torch.zeros(B, L, Mh, 32)
+            for jj in range(blk * 32, min(L, blk * 32 + 32)):
+                vv[:, jj, :, jj - blk * 32] = 1.0
+            o = host(Fn.mha(qd, dev(vv.reshape(B, L, E)), Mh, pp, 7)).reshape(B, L, Mh, 32)
+            cols.append(o[..., :min(32, L - blk * 32)])
+        c.training = True
+        return torch.cat(cols, -1).permute(0, 2, 1, 3)          # [B, Mh, L(query), L(key)]
+    pd_dev, p_dev = read_probs(p, True), read_probs(p, False)
+    mask = (pd_dev > 0).float()
+    frac = 1.0 - mask[p_dev > 1e-4].mean().item()
+    print("MHA MFMA dropout: %.4f of the attention weights dropped (p = %.2f)" % (frac, p))
+    assert abs(frac - p) < 0.01, frac
+    assert ((pd_dev - p_dev * mask / (1 - p)).abs().max() < 2e-2 * p_dev.max()).item()          # kept weights are the undropped ones / (1 - p), to bf16
+    qkr, vr = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    q = qkr[..., :E].reshape(B, L, Mh, 32).transpose(1, 2)
+    k = qkr[..., E:].reshape(B, L, Mh, 32).transpose(1, 2)
+    w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32.0), -1) * mask / (1 - p)
+    o = (w @ vr.reshape(B, L, Mh, 32).transpose(1, 2)).transpose(1, 2).reshape(B, L, E)
+    o.backward(dy)
+    close("mha mfma dropout fwd", host(y), o.detach(), BF16, 2.0)
+    for got, want, name in ((host(dqk), qkr.grad, "dqk"), (dvh, vr.grad, "dv")):
+        rel = ((got - want).norm() / want.norm()).item()
+        print("MHA MFMA dropout: %s vs torch with the device's mask: relative L2 %.3g" % (name, rel))
+        assert rel < 1.5e-2, (name, rel)          # bf16 probabilities / dS as MFMA operands: two roundings of 2^-9
+    # the dropped fraction: zeros among the probabilities cannot be read from outside, but with V = ones(.) every output channel is the
+    # kept probability mass / (1 - p): its mean over queries is 1, its variance that of a p-thinned sum
+    ones = dev(torch.ones(B, L, E))
+    mass = host(Fn.mha(qd, ones, Mh, p, 7))
+    assert abs(mass.mean().item() - 1.0) < 0.03, mass.mean().item()
+    assert 0.05 < mass.std().item() < 0.6, mass.std().item()
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -902,6 +1096,58 @@ def test_softmax_ce_and_optimizer():
     close("ce loss", res[:1].cpu(), ref.detach().reshape(1), F32, atol=1e-5)
     assert int(res[1].item()) == int((labels != 255).sum())
     close("ce dlogits", tape.result(ld).cpu(), lr_.grad, F32, atol=1e-7)
+
+
+def test_softmax_ce_pair_equals_the_two_single_head_calls():
+    """MixSoftmaxCrossEntropyLoss's two heads in one pass (emrt_softmax_ce_pair_fwd / _bwd; mix_softmax_cross_entropy_loss.py:29-35,44-51):
+    losses, counts, the weighted total and both gradients bit-identical to two emrt_softmax_ce calls + the scalar axpby, and equal to torch."""
+    from emrt_amd.src.models.losses import MixSoftmaxCrossEntropyLoss
+    from emrt_amd.runtime import ctx
+    c = init(F32)
+    g = torch.Generator().manual_seed(24)
+    N, C, H, W = 4, 7, 24, 40
+    la, lb = torch.randn(N, C, H, W, generator=g) * 2, torch.randn(N, C, H, W, generator=g) * 3
+    labels = torch.randint(0, C, (N, H, W), generator=g)
+    labels[torch.rand(N, H, W, generator=g) < 0.15] = 255
+    ra_, rb_ = la.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+    ref = F.cross_entropy(ra_, labels, ignore_index=255) + 0.4 * F.cross_entropy(rb_, labels, ignore_index=255)
+    ref.backward()
+    lab = labels.cuda()
+    ad, bd = dev(la, torch.float32), dev(lb, torch.float32)
+    tape = Tape()
+    c.tape = tape
+    sa = Fn.softmax_ce(ad, lab, 255, 1.0)
+    sb = Fn.softmax_ce(bd, lab, 255, 0.4)
+    c.tape = None
+    tape.watch(ad)
+    tape.watch(bd)
+    tape.backward()
+    single = [sa.cpu(), sb.cpu(), tape.result(ad).cpu(), tape.result(bd).cpu()]
+    ad2, bd2 = dev(la, torch.float32), dev(lb, torch.float32)
+    tape = Tape()
+    c.tape = tape
+    pa, pb, total = Fn.softmax_ce_pair(ad2, bd2, lab, 255, 1.0, 0.4)
+    c.tape = None
+    tape.watch(ad2)
+    tape.watch(bd2)
+    tape.backward()
+    pair = [pa.cpu(), pb.cpu(), tape.result(ad2).cpu(), tape.result(bd2).cpu()]
+    for u, v, name in zip(pair, single, ("loss a", "loss b", "dlogits a", "dlogits b")):
+        assert torch.equal(u, v), name
+    assert abs(total.item() - (single[0][0].item() + 0.4 * single[1][0].item())) < 1e-6
+    close("ce pair total", total.cpu(), ref.detach().reshape(1), F32, atol=1e-5)
+    close("ce pair dlogits a", pair[2], ra_.grad, F32, atol=1e-7)
+    close("ce pair dlogits b", pair[3], rb_.grad, F32, atol=1e-7)
+    # the loss object of the recipe takes the pair path (one forward call) and an all-ignored batch gives 0, not 0 / 0
+    class _Out(tuple):
+        tape = None
+    L_ = __import__("emrt_amd._lib", fromlist=["lib"]).lib()
+    L_.start_record()
+    val = MixSoftmaxCrossEntropyLoss(ignore_index=255, aux=True, aux_weight=0.4)(_Out((ad, bd)), lab)
+    names = [n for n, _ in L_.stop_record()]
+    assert names == ["emrt_softmax_ce_pair_fwd"] and abs(val.item() - ref.item()) < 1e-5
+    _, _, t0 = Fn.softmax_ce_pair(ad, bd, torch.full_like(lab, 255), 255, 1.0, 0.4)
+    assert t0.item() == 0.0
 
 
 def test_sgd_momentum_matches_reference_optimizer():

@@ -103,7 +103,8 @@ def test_train_step_launch_sequence(fake, backbone):
     n_ffn = sum(1 for mod in m.modules() if type(mod).__name__ in ("TransformerEncoderLayer", "TransformerDecoderLayer"))
     ffn = [a for a in dgrads if a[25] is not None and a[24] is None]
     assert len(ffn) == n_ffn > 0 and all(abs(a[28] - 1.0 / 0.9) < 1e-6 and a[25].value == a[0].value for a in ffn)
-    assert cnt["emrt_mask_bwd"] == cnt["emrt_dropout_fwd"] - n_ffn
+    # ... and their forward dropout is drawn in linear1's epilogue (emrt_conv2d_drop): the separate dropout launches left are the two Dropout2D
+    assert cnt["emrt_conv2d_drop"] == n_ffn and cnt["emrt_mask_bwd"] == cnt["emrt_dropout_fwd"] == 2
     # residual joins relu(BatchNorm(x) + residual): the dgrad of a conv that consumes the join folds the earlier
     # contributions in (addend a[32], or in place a[6]), masks with the join's output and sums against the BatchNorm INPUT
     # (stat_x a[29]); the join's backward then runs without its reduction pass (sums_vs_x a[21] of emrt_bn_bwd_dx)
@@ -123,7 +124,7 @@ def test_train_step_launch_sequence(fake, backbone):
     assert cnt["emrt_msda_fwd"] == cnt["emrt_msda_bwd"] == 6 and cnt["emrt_mha_fwd"] == cnt["emrt_mha_bwd"] == 2
     assert cnt["emrt_layernorm_fwd"] == cnt["emrt_layernorm_bwd"] == 14
     assert cnt["emrt_groupnorm_fwd"] == cnt["emrt_groupnorm_bwd"] == 0 and cnt["emrt_groupnorm_levels_fwd"] == cnt["emrt_groupnorm_levels_bwd"] == 5
-    assert cnt["emrt_softmax_ce_fwd"] == cnt["emrt_softmax_ce_bwd"] == 2
+    assert cnt["emrt_softmax_ce_pair_fwd"] == cnt["emrt_softmax_ce_pair_bwd"] == 1 and cnt["emrt_softmax_ce_fwd"] == cnt["emrt_scalar_axpby"] == 0      # main + aux head in one pass
     assert cnt["emrt_grad_clip_scale"] == cnt["emrt_sgd_momentum_step"] == cnt["emrt_pack_weights"] == 1
     # wgrad destinations are distinct slices inside the trainable gradient range
     g0 = st.grad.data_ptr()
