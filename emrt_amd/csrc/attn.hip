@@ -414,6 +414,8 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
   for (int t = threadIdx.x; t < 128; t += blockDim.x) {
     sMx[t] = t < L ? stats[t] : 0.f;
     sInv[t] = t < L ? stats[L + t] : 0.f;
+    if (t >= 16 * nt) sDot[t] = 0.f;      // rows of the tiles no wave owns: pass 2 multiplies them by a zero probability, and 0 x (whatever a previous
+                                          // kernel left in LDS -- a NaN pattern under load, round 5) is a NaN in dk / dv
   }
   const unsigned long long seed = a.pdrop > 0.f ? *a.seed : 0ull;
   const uint32_t thr = (uint32_t)(a.pdrop * 65536.f);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
     for (int t = 0; t < MHA_TILES; ++t) {
       float ds[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ds[r] = st[t][r] * (dp[t][r] - dot) * a.scale;
+      for (int r = 0; r < 4; ++r) ds[r] = st[t][r] != 0.f ? st[t][r] * (dp[t][r] - dot) * a.scale : 0.f;      // (padding rows / keys: exactly 0, whatever dot holds)
       pk[t][0] = mha_pack2<T>(ds[0], ds[1]);
       pk[t][1] = mha_pack2<T>(ds[2], ds[3]);
     }
@@ -512,8 +514,8 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
           keep = mha_keep4(h, x & 3, thr);
         }
         const float d = keep ? dp[t][r] * kd : 0.f;
-        ds[r] = p * (d - sDot[i]) * a.scale;
-        pd[r] = keep ? p * kd : 0.f;
+        ds[r] = in ? p * (d - sDot[i]) * a.scale : 0.f;
+        pd[r] = (in && keep) ? p * kd : 0.f;
       }
       pks[t][0] = mha_pack2<T>(ds[0], ds[1]); pks[t][1] = mha_pack2<T>(ds[2], ds[3]);
       pkp[t][0] = mha_pack2<T>(pd[0], pd[1]); pkp[t][1] = mha_pack2<T>(pd[2], pd[3]);

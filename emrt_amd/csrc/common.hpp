@@ -90,9 +90,14 @@ struct Scratch {
   unsigned* tick;                              // arrival counters of the cross-block K split (conv.hip: igemm_body XK), SCRATCH_TICKS words kept ZERO
                                                // between launches (the last block to arrive resets its tile's counter); nullptr when the registered
                                                // region was too small to carve them out
+  float* xk_part;                              // the K split's partial tiles: SCRATCH_XK_BYTES of their OWN.  They are written and read with sc1
+                                               // (write-through / L1-bypassing) accesses only, from every XCD; sharing addresses with the weight-gradient
+                                               // slab -- plain stores and loads that leave dirty and clean lines in the per-XCD L2s -- gave wrong sums
+                                               // under load (round 5: NaN gradients in 3 of 4 runs beside two other processes; never with either user alone)
 };
 constexpr size_t SCRATCH_TICK_BYTES = 65536;   // the tail of the registered region: 16384 counters
 constexpr int SCRATCH_TICKS = (int)(SCRATCH_TICK_BYTES / 4);
+constexpr size_t SCRATCH_XK_BYTES = 8u << 20;  // in front of the counters: 512 partial tiles of 64 x 64 fp32
 extern Scratch g_scratch;
 
 // ---- element types ---------------------------------------------------------------------------

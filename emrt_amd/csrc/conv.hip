@@ -1109,7 +1109,7 @@ template <class T>
 static int igemm_xk_copies(const ConvArgs& a, hipStream_t st, int want) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
-  if (sizeof(T) != 2 || g_tune.xk < 0 || !g_scratch.ptr || !g_scratch.tick || g_scratch.stream != (void*)st) return 0;
+  if (sizeof(T) != 2 || g_tune.xk < 0 || !g_scratch.xk_part || !g_scratch.tick || g_scratch.stream != (void*)st) return 0;
   if (a.OC <= 32 || a.OC % 8 || a.out_f32) return 0;
   auto al = [](const void* q) { return ((uintptr_t)q) % 16 == 0; };
   if (!al(a.out) || (a.res && !al(a.res)) || (a.mask_y && !al(a.mask_y)) || (a.stat_x && !al(a.stat_x))) return 0;
@@ -1132,7 +1132,7 @@ static int igemm_xk_copies(const ConvArgs& a, hipStream_t st, int want) {
     S = 4;
   }
   if (S > nkt) S = nkt;
-  if (S < 2 || nb > SCRATCH_TICKS || (size_t)nb * (size_t)S * 64 * 64 * 4 > g_scratch.bytes) return 0;
+  if (S < 2 || nb > SCRATCH_TICKS || (size_t)nb * (size_t)S * 64 * 64 * 4 > SCRATCH_XK_BYTES) return 0;
   return S;
 }
 
@@ -1141,7 +1141,7 @@ static int launch_igemm_xk(const ConvArgs& a0, hipStream_t st, int S) {
   ConvArgs a = a0;
   const long long M = (long long)a.N * a.OH * a.OW;
   const long long nb = ((M + 63) / 64) * ((a.OC + 63) / 64);
-  a.xk_S = S; a.xk_part = (float*)g_scratch.ptr; a.xk_tick = g_scratch.tick;
+  a.xk_S = S; a.xk_part = g_scratch.xk_part; a.xk_tick = g_scratch.tick;
   hipLaunchKernelGGL((igemm_xk_kernel<T, MODE>), dim3((unsigned)(nb * S)), dim3(256), (size_t)2 * 128 * 144, st, a);
   return check_launch("emrt_conv2d");
 }
@@ -1937,6 +1937,7 @@ struct EmrtConvDesc {
   int ldres; long long res_bs;
   int KH, KW, stride, pad, relu;
   double* bn_stats;
+  int out_f32;
 };
 struct EmrtConvBwdDesc {
   const void* x; const void* dy; const void* w_bwd_packed; void* dx; int lddx; long long dx_bs; int accumulate; float* dw; float* dbias;
@@ -1981,7 +1982,7 @@ static void conv_args_from_desc(ConvArgs& a, const EmrtConvDesc& d) {
   a.N = d.N; a.H = d.H; a.W = d.W; a.C = d.C; a.ldin = d.ldin; a.in_bs = d.in_bs;
   a.OH = d.OH; a.OW = d.OW; a.OC = d.OC; a.ldout = d.ldout; a.out_bs = d.out_bs;
   a.ldres = d.ldres; a.res_bs = d.res_bs;
-  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = 0; a.cmajor = 0; a.stats = d.bn_stats;
+  a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad; a.dil = 1; a.relu = d.relu; a.out_f32 = d.out_f32 ? 1 : 0; a.cmajor = 0; a.stats = d.bn_stats;
   a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
   a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr; a.drop_seed = nullptr; a.drop_salt = 0; a.drop_p = 0.f;
 }

@@ -48,14 +48,14 @@ emrt::Tuning tuning_from_env() {
 }
 }  // namespace
 emrt::Tuning emrt::g_tune = tuning_from_env();
-emrt::Scratch emrt::g_scratch = {nullptr, 0, nullptr, nullptr};
+emrt::Scratch emrt::g_scratch = {nullptr, 0, nullptr, nullptr, nullptr};
 
 extern "C" int emrt_set_scratch(void* ptr, size_t bytes, void* stream) {
   EMRT_REQUIRE((ptr != nullptr) == (bytes > 0) && ((uintptr_t)ptr) % 256 == 0, "scratch must be 256-byte aligned device memory (or nullptr, 0)");
   // the SAME region again: only the stream it belongs to changes (host state, legal during a stream capture: the caller moves the region to the
   // capture stream for the duration of a capture and back -- a graph's kernels are ordered among themselves like one stream's).  No memset:
   // the counters are zero between launches by construction.
-  if (ptr && ptr == emrt::g_scratch.ptr && emrt::g_scratch.tick && bytes == emrt::g_scratch.bytes + emrt::SCRATCH_TICK_BYTES) {
+  if (ptr && ptr == emrt::g_scratch.ptr && emrt::g_scratch.tick && bytes == emrt::g_scratch.bytes + emrt::SCRATCH_TICK_BYTES + emrt::SCRATCH_XK_BYTES) {
     emrt::g_scratch.stream = stream;
     return 0;
   }
@@ -63,11 +63,13 @@ extern "C" int emrt_set_scratch(void* ptr, size_t bytes, void* stream) {
   emrt::g_scratch.bytes = bytes;
   emrt::g_scratch.stream = stream;
   emrt::g_scratch.tick = nullptr;
-  // a region of more than 1 MiB gives its last 64 KiB to the arrival counters of the cross-block K split; they are zeroed HERE, once, on the
-  // registered stream (an enqueued memset, no synchronisation) and every launch leaves them zero again
-  if (ptr && bytes >= (1u << 20) + emrt::SCRATCH_TICK_BYTES && bytes % 256 == 0) {
-    emrt::g_scratch.bytes = bytes - emrt::SCRATCH_TICK_BYTES;
-    emrt::g_scratch.tick = reinterpret_cast<unsigned*>(static_cast<char*>(ptr) + emrt::g_scratch.bytes);
+  emrt::g_scratch.xk_part = nullptr;
+  // a region of more than 16 MiB gives its last 8 MiB + 64 KiB to the cross-block K split: partial tiles, then arrival counters; the counters are
+  // zeroed HERE, once, on the registered stream (an enqueued memset, no synchronisation) and every launch leaves them zero again
+  if (ptr && bytes >= (16u << 20) + emrt::SCRATCH_XK_BYTES + emrt::SCRATCH_TICK_BYTES && bytes % 256 == 0) {
+    emrt::g_scratch.bytes = bytes - emrt::SCRATCH_TICK_BYTES - emrt::SCRATCH_XK_BYTES;
+    emrt::g_scratch.xk_part = reinterpret_cast<float*>(static_cast<char*>(ptr) + emrt::g_scratch.bytes);
+    emrt::g_scratch.tick = reinterpret_cast<unsigned*>(static_cast<char*>(ptr) + emrt::g_scratch.bytes + emrt::SCRATCH_XK_BYTES);
     if (hipMemsetAsync(emrt::g_scratch.tick, 0, emrt::SCRATCH_TICK_BYTES, (hipStream_t)stream) != hipSuccess) {
       emrt::g_scratch.tick = nullptr;
       return emrt::fail("emrt_set_scratch", "cannot zero the arrival counters");

@@ -807,7 +807,7 @@ class _ConvDesc(ctypes.Structure):        # EmrtConvDesc (include/emrt_hip.h)
                 ("ldin", ctypes.c_int), ("in_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int),
                 ("ldout", ctypes.c_int), ("out_bs", ctypes.c_longlong), ("ldres", ctypes.c_int), ("res_bs", ctypes.c_longlong),
                 ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int), ("relu", ctypes.c_int),
-                ("bn_stats", ctypes.c_void_p)]
+                ("bn_stats", ctypes.c_void_p), ("out_f32", ctypes.c_int)]
 
 
 class _ConvBwdDesc(ctypes.Structure):     # EmrtConvBwdDesc
@@ -893,6 +893,68 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             tape.add_grad(src, dout)              # the residual path of every level: one add over the whole token tensor
         tape.record(bwd)
     return out
+
+
+def linear_group(items):
+    """Up to 4 INDEPENDENT linear layers in one launch each way (emrt_conv2d_group / emrt_conv2d_bwd_group): items = [(x [B, L, C] dense, GemmWeight,
+    out_f32)].  The deformable attention's value_proj(value) and its fused offsets | logits projection of the query (transformer_encoder_decoder.py:
+    83-92) are two 1344-token linears of 9 and 13 us that do not depend on each other, forward or backward: side by side they share one launch's
+    ramp and tail.  Returns the outputs.  Weight gradients are deferred to the batched launches as for conv2d."""
+    c = ctx()
+    n = len(items)
+    assert 1 <= n <= 4
+    outs, geo = [], []
+    fd = (_ConvDesc * n)()
+    for d, (x, w, out_f32) in zip(fd, items):
+        assert x.is_contiguous() and x.dim() == 3 and w.KH == w.KW == 1 and x.shape[2] == w.C
+        B, L_, C = x.shape
+        out = c.empty((B, L_, w.OC), torch.float32 if out_f32 else None)
+        d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, out.data_ptr(), _dp(w.bias), None, None
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, 1, L_, C, C, L_ * C
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = 1, L_, w.OC, w.OC, L_ * w.OC
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, 1, 1, 1, 0, 0, int(bool(out_f32))
+        outs.append(out)
+        geo.append((B, L_, C))
+    _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
+    tape = c.tape
+    if tape is not None:
+        def bwd():
+            dys = [tape.pop_grad(o) for o in outs]
+            live = [i for i in range(n) if dys[i] is not None]
+            if not live:
+                return
+            bd = (_ConvBwdDesc * len(live))()
+            fresh = []
+            for d, i in zip(bd, live):
+                x, w, out_f32 = items[i]
+                B, L_, C = geo[i]
+                dy = dys[i]
+                if out_f32 and dy.dtype == torch.float32:      # (a producer may hand the gradient over in the compute dtype already: Fn.msda)
+                    dy = cast_from_f32(dy)
+                assert dy.is_contiguous()
+                dys[i] = dy
+                deferred = wgrad_deferred(w)
+                if deferred:
+                    defer_wgrad(tape, x, dy, w, (B, 1, L_, C, C, L_ * C, 1, L_, w.OC, L_ * w.OC), 1, 0, 1)
+                else:
+                    w.grad_is_zero = False
+                    _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), B, 1, L_, C, C, L_ * C, 1, L_, w.OC, w.OC, L_ * w.OC, 1, 1, 1, 0,
+                              P(w.bias_grad) if w.bias is not None else None, 1, c.dtype, c.stream)
+                slot = tape.grad_slot(x)
+                dx = slot if slot is not None else c.empty((B, L_, C))
+                assert dx.is_contiguous()
+                d.x, d.dy, d.w_bwd_packed, d.dx = x.data_ptr(), dy.data_ptr(), w.bwd_ptr, dx.data_ptr()
+                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = C, L_ * C, int(slot is not None), None, None
+                d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, 1, L_, C, C, L_ * C
+                d.OH, d.OW, d.OC, d.lddy, d.dy_bs = 1, L_, w.OC, w.OC, L_ * w.OC
+                d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+                if slot is None:
+                    fresh.append((x, dx))
+            _L().call("emrt_conv2d_bwd_group", bd, len(live), c.dtype, c.stream)
+            for x, dx in fresh:
+                tape.add_grad(x, dx, owned=True)
+        tape.record(bwd)
+    return outs
 
 
 def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):

@@ -224,6 +224,7 @@ class Context:
         # training: a BatchNorm + ReLU whose only consumer streams the map once (x2 resize, 3x3 max-pool) is applied by that consumer's
         # loads instead of its own emrt_bn_apply launch (functional.PendingBN).  0 = always the separate launch (A/B knob).
         self.bn_defer = bool(int(os.environ.get("EMRT_BN_DEFER", "1")))
+        self.group_attn_proj = bool(int(os.environ.get("EMRT_GROUP_ATTN_PROJ", "1")))      # A/B: value_proj and the offsets | logits projection as one grouped launch
         self.fuse_ffn_dropout = bool(int(os.environ.get("EMRT_FFN_DROPOUT_FUSED", "1")))      # A/B: dropout(relu(linear1)) drawn in the GEMM epilogue (emrt_conv2d_drop)
         # the decoder's pyramid maps resized by ONE launch per direction (emrt_pyramid_resize_fwd / _bwd); 0 = one launch per scale (A/B knob)
         self.pyramid_group = bool(int(os.environ.get("EMRT_PYRAMID_GROUP", "1")))
@@ -383,9 +384,9 @@ class Context:
             return
         if torch.cuda.is_current_stream_capturing():
             return
-        # + 64 KiB: the arrival counters of the convolutions' cross-block K split (csrc/conv.hip, igemm_body XK), carved off the tail and zeroed by
-        # emrt_set_scratch; the split's partial tiles (<= 8 MiB) share the slab with the weight-gradient kernel -- same stream, one after the other
-        self._scratch = torch.empty((64 << 20) + 65536, dtype=torch.uint8, device=self.device)
+        # + 8 MiB + 64 KiB: the partial tiles and the arrival counters of the convolutions' cross-block K split (csrc/conv.hip, igemm_body XK),
+        # carved off the tail by emrt_set_scratch (counters zeroed there); the K split does NOT share addresses with the weight-gradient slab
+        self._scratch = torch.empty((64 << 20) + (8 << 20) + 65536, dtype=torch.uint8, device=self.device)
         st = self.stream
         if self.wgrad_side:          # (every weight gradient, the large layers' included, is then launched from the side stream)
             if self._wside is None:

@@ -250,8 +250,13 @@ class MSDeformableAttention(hnn.HipLayer):  # :21-107
         self.offw_gemm = store.make_gemm(ow, self.total_points * 3, self.embed_dim, 1, 1, ob)
 
     def forward(self, query, reference_points, value, spatial_shapes, need_dref=False):  # :65-107 (value_mask is all ones)
-        value = self.value_proj(value)
-        offw = Fn.linear(query, self.offw_gemm, out_f32=True)      # [B, Lq, 2*tp offsets | tp logits], fp32
+        c = ctx()
+        if c.group_attn_proj and value.dim() == 3 and query.dim() == 3 and value.is_contiguous() and query.is_contiguous() and value is not query:
+            # value_proj(value) and the offsets | logits projection of the query: independent, one grouped launch forward, one for both data gradients
+            value, offw = Fn.linear_group([(value, self.value_proj.gw, False), (query, self.offw_gemm, True)])
+        else:
+            value = self.value_proj(value)
+            offw = Fn.linear(query, self.offw_gemm, out_f32=True)      # [B, Lq, 2*tp offsets | tp logits], fp32
         out = Fn.msda(value, offw, reference_points, spatial_shapes, self.num_heads, self.num_points, need_dref=need_dref)
         return self.output_proj(out)
 

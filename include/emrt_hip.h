@@ -46,7 +46,7 @@ int emrt_get_tuning(const char* name, int* value);
  * for train.py:142-149's loss.backward() of the large layers.  Without it that kernel adds its tiles into dW with fp32 atomics.  The
  * memory must stay valid (and the pointer unchanged across hipGraph replays) until it is unregistered.  `stream` (ABI 5) is the ONE stream
  * whose launches may use it: a call on any other stream falls back to the atomic epilogue (partial tiles + reduce launch are only ordered
- * within a stream).  ABI 7: a region of more than 1 MiB (a multiple of 256 bytes) gives its LAST 64 KiB to the arrival counters of the
+ * within a stream).  ABI 7: a region of more than 24 MiB (a multiple of 256 bytes) gives its LAST 8 MiB + 64 KiB to the partial tiles and arrival counters of the
  * convolutions' cross-block K split (emrt_conv2d / emrt_conv2d_bwd on few-tile, long-K layers: partial fp32 tiles of S blocks per output tile
  * go through the region, the last block to arrive sums them and runs the epilogue -- nn.Conv2D of the 8x8 / 16x16 ResNet stages,
  * paddle_vision_resnet.py:111-119); the counters are zeroed here with a memset enqueued on `stream` and every launch leaves them zero.  Without
@@ -75,13 +75,15 @@ int emrt_conv2d_drop(const void* in, const void* w_packed, void* out, const floa
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream);
 /* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE
  * launch; problems that are not small vector-path ones are launched one by one instead.  Descriptors are host arrays. */
-typedef struct EmrtConvDesc {            /* the arguments of emrt_conv2d, mode 0, compute-dtype output */
+typedef struct EmrtConvDesc {            /* the arguments of emrt_conv2d, mode 0 */
   const void* in; const void* w_packed; void* out; const float* bias; const void* residual;
   int N, H, W, C, ldin; long long in_bs;
   int OH, OW, OC, ldout; long long out_bs;
   int ldres; long long res_bs;
   int KH, KW, stride, pad, relu;
   double* bn_stats;
+  int out_f32;                           /* ABI 7: 1 = fp32 output (the offsets | logits projection of the deformable attention, t_e_d.py:89-92, grouped
+                                            with value_proj of the same layer: two independent linears, one launch) */
 } EmrtConvDesc;
 typedef struct EmrtConvBwdDesc {         /* the arguments of emrt_conv2d_bwd without the fused BatchNorm sums */
   const void* x; const void* dy; const void* w_bwd_packed; void* dx; int lddx; long long dx_bs; int accumulate; float* dw; float* dbias;

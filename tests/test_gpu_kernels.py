@@ -808,6 +808,49 @@ def test_mha_dropout_backward_consistent_with_forward():
     assert abs(lhs - rhs) < 2e-3 * max(1.0, abs(lhs)), (lhs, rhs)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_group_equals_separate_linears(dtype):
+    """Fn.linear_group (value_proj(value) | offsets-logits projection of the query in ONE launch each way, t_e_d.py:83-92): the grouped launch
+    runs the same 64x64 tile with the same k order as the separate launches -- outputs (one of them fp32), data gradients and weight / bias
+    gradients bit-identical; the second data gradient accumulates into an existing gradient of its input."""
+    c = init(dtype)
+    g = torch.Generator().manual_seed(31)
+    B, Lv, Lq, C = 2, 1344, 110, 256
+    value, query = rnd(torch.randn(B, Lv, C, generator=g)), rnd(torch.randn(B, Lq, C, generator=g))
+    dv_, dq_ = rnd(torch.randn(B, Lv, 256, generator=g)), rnd(torch.randn(B, Lq, 432, generator=g))
+    prior = rnd(torch.randn(B, Lv, C, generator=g))
+    res = {}
+    for mode in ("group", "separate"):
+        l1, l2 = hnn.Linear(C, 256), hnn.Linear(C, 432)
+        gg = torch.Generator().manual_seed(32)
+        with torch.no_grad():
+            l1.weight.copy_(rnd(torch.randn(256, C, generator=gg) / 16))
+            l2.weight.copy_(rnd(torch.randn(432, C, generator=gg) / 16))
+            l1.bias.copy_(torch.randn(256, generator=gg))
+            l2.bias.copy_(torch.randn(432, generator=gg))
+        Holder(l1=l1, l2=l2).place()
+        vd, qd = dev(value), dev(query)
+        tape = Tape()
+        c.tape = tape
+        if mode == "group":
+            a, b = Fn.linear_group([(vd, l1.gw, False), (qd, l2.gw, True)])
+        else:
+            a, b = Fn.linear(vd, l1.gw), Fn.linear(qd, l2.gw, out_f32=True)
+        c.tape = None
+        assert b.dtype == torch.float32 and a.dtype == c.tdtype
+        tape.watch(vd)
+        tape.watch(qd)
+        tape.add_grad(vd, dev(prior), owned=True)          # an earlier contribution: the value gradient accumulates into it
+        gx, gq = run_bwd(tape, [(a, dev(dv_)), (b, dev(dq_))], [vd, qd])
+        res[mode] = [host(t) for t in (a, b, gx, gq, l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad)]
+    for u, v, name in zip(res["group"][:4], res["separate"][:4], ("value_proj out", "offsets|logits out", "d value", "d query")):
+        assert torch.equal(u, v), name
+    for u, v, name in zip(res["group"][4:], res["separate"][4:], ("dW1", "db1", "dW2", "db2")):      # (batched weight gradients: fp32 atomics, order-dependent last bits)
+        assert ((u - v).norm() / v.norm()).item() < 2e-6, name
+    want = F.linear(value, l1.weight.detach().cpu().float(), None)          # sanity against torch (weights read back)
+    assert res["group"][0].shape == want.shape
+
+
 def test_mha_mfma_kernels_dropout_and_agreement_with_the_valu_kernels():
     """bf16 takes the MFMA kernels (csrc/attn.hip: mha_fwd_mfma_kernel / mha_bwd_mfma_kernel; layers.py:283-303).  (1) Without dropout they
     must agree with the VALU kernels (knob mha_valu) on the same bf16 inputs to bf16 rounding, forward and all three gradients, at the
@@ -843,6 +886,36 @@ def test_mha_mfma_kernels_dropout_and_agreement_with_the_valu_kernels():
         for u, w_, name in zip(outs[0], outs[1], ("out", "dqk", "dv")):
             rel = ((u - w_).norm() / w_.norm()).item()
             assert rel < 6e-3, ("L=%d %s: MFMA vs VALU relative L2 %.3g" % (L, name, rel))          # two bf16 roundings (probabilities as MFMA operands)
+    # ---- nothing may depend on what an earlier kernel left in LDS: the backward multiplies the rows of the padding tiles by a zero probability,
+    # and round 5's first version read their row sums from uninitialised LDS -- 0 x NaN = NaN in dk / dv whenever a NaN bit pattern happened to
+    # lie there (seen only beside other processes on the GPU).  Here every CU's LDS is filled with NaNs first (the staged value slab of a
+    # deformable-attention forward on an all-NaN value tensor) and the gradients must come out bit-identical to the clean run
+    c.training = False
+    B, L = 8, 110
+    qk, v = rnd(torch.randn(B, L, 2 * E, generator=g)), rnd(torch.randn(B, L, E, generator=g))
+    dy = rnd(torch.randn(B, L, E, generator=g))
+    shapes = [(32, 32), (16, 16), (8, 8)]
+    Lv = sum(h * w for h, w in shapes)
+    nanv = dev(torch.full((8, Lv, 256), float("nan")))
+    offw = dev(torch.zeros(8, Lv, 3 * 8 * 3 * 6), torch.float32)
+    from emrt_amd.src.models.emrt import encoder_reference_points
+    refp = dev(encoder_reference_points(shapes), torch.float32)
+    got = []
+    for poison in (False, True, True):
+        qd, vd = dev(qk), dev(v)
+        tape = Tape()
+        c.tape = tape
+        y = Fn.mha(qd, vd, Mh, 0.0, 3)
+        c.tape = None
+        tape.watch(qd)
+        tape.watch(vd)
+        if poison:
+            for _ in range(3):
+                Fn.msda(nanv, offw, refp, shapes, 8, 6)
+        dqk, dv = run_bwd(tape, [(y, dev(dy))], [qd, vd])
+        got.append((host(dqk), host(dv)))
+    for a_, b_ in zip(got[0], got[1]):
+        assert torch.isfinite(b_).all() and torch.equal(a_, b_), "the attention backward depends on stale LDS contents"
     # ---- dropout: one mask in three places -------------------------------------------------------------------------------------
     c.training = True
     B, L, p = 2, 110, 0.5

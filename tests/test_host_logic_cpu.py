@@ -62,7 +62,10 @@ def test_train_step_launch_sequence(fake, backbone):
     cnt = collections.Counter(n for n, _ in fake.calls)
     assert n_fwd > n_eval                                              # training adds dropout / statistics launches
     n_grouped = sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_bwd_group")     # problems inside grouped backward launches
-    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15       # (4 encoder layers + input_proj) x 3 levels
+    # (4 encoder layers + input_proj) x 3 levels, + value_proj | offsets-logits projection of the 6 deformable attentions as pairs
+    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15 + 12
+    pairs = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 2]
+    assert len(pairs) == 6 and all(a[0][0].out_f32 == 0 and a[0][1].out_f32 == 1 and a[0][1].OC == 432 for a in pairs)
     # every GEMM weight gets exactly one weight gradient: immediately (the 1x1 classifiers' one-pass backward) or in a batched
     # emrt_conv2d_wgrad_group call made while backward runs; a layer whose weight gradient is batched passes dw = NULL to its data gradient
     batched = [a[0][i] for n, a in fake.calls if n == "emrt_conv2d_wgrad_group" for i in range(a[1])]

@@ -250,7 +250,7 @@ def s2():
 def xk():
     """Cross-block K split (igemm_body XK) on the step's few-tile, long-K layers: the old choice (xk = -1: in-block wave-group split) against S = 2 / 4 / 8
     copies of the tile grid, forward and data gradient; agreement with the old kernel and bit-reproducibility of the split over 20 launches."""
-    scratch = torch.empty((64 << 20) + 65536, dtype=torch.uint8, device=dev)
+    scratch = torch.empty((64 << 20) + (8 << 20) + 65536, dtype=torch.uint8, device=dev)
     L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()), stream)
     shapes = [(8, 16, 16, 256, 256, 3, 1, 1), (8, 8, 8, 512, 512, 3, 1, 1), (8, 8, 8, 2048, 512, 1, 1, 0), (8, 8, 8, 512, 2048, 1, 1, 0),
               (8, 16, 16, 1024, 256, 3, 1, 1), (8, 16, 16, 1024, 256, 1, 1, 0), (8, 16, 16, 256, 1024, 1, 1, 0), (8, 16, 16, 512, 512, 3, 2, 1),
