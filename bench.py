@@ -48,8 +48,9 @@ PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.3 TB/s achievable)
 PEAK_LDS_GBPS = 128 * 256 * 2.4   # LDS gather: 128 B/clk/CU (MI355X_MICROARCH.md, LDS: ds_read_b32 rate; random 64-B pixel reads get no more) x 256 CUs x 2.4 GHz
 GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: per-level encoder convs)",
                  "emrt_conv2d_bwd_group": "igemm_group_kernel<mode 1> (emrt_conv2d_bwd_group: data gradients of the per-level convs)",
-                 "emrt_conv2d": "igemm_kernel / igemm8p_kernel (emrt_conv2d: forward convs / linears)",
-                 "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel mode 1 (emrt_conv2d_bwd: data gradients; thin_bwd_kernel for the classifiers)",
+                 "emrt_conv2d": "igemm_kernel / igemm8p_kernel / igemm_xk_kernel (emrt_conv2d: forward convs / linears)",
+                 "emrt_conv2d_drop": "igemm_drop_kernel (emrt_conv2d_drop: dropout(relu(linear1)) of the FFN, the mask drawn in the epilogue)",
+                 "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel / igemm_xk_kernel mode 1 (emrt_conv2d_bwd: data gradients; thin_bwd_kernel for the classifiers)",
                  "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)",
                  "emrt_bn_pointwise_fwd": "thin_fwd_bn_kernel (emrt_bn_pointwise_fwd: the classifier with its BatchNorm operand)",
                  "emrt_bn_pointwise_bwd": "thin_bwd_kernel (emrt_bn_pointwise_bwd: the classifier's data + weight gradient in one pass)",
@@ -57,7 +58,7 @@ GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: pe
 # the roofline's kernel family: every launch that computes a convolution / linear layer's BACKWARD (data gradient + weight gradient) --
 # the same population of work whether a layer's two gradients share a launch (round 3's pair kernel) or not (round 4: batched dW)
 CONV_BWD = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group", "emrt_bn_pointwise_bwd")
-CONV_FWD = ("emrt_conv2d", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
+CONV_FWD = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
 
 
 def log(*a):
@@ -70,6 +71,8 @@ def conv_flops(name, a):
         return 2.0 * a[8] * a[9] * a[10] * a[11]
     if name == "emrt_bn_pointwise_bwd":        # data + weight gradient in one pass: N, HW, C, OC = a[13:17]
         return 4.0 * a[13] * a[14] * a[15] * a[16]
+    if name == "emrt_conv2d_drop":             # (in, w, out, bias, M, C, ldin, OC, ldout, ...)
+        return 2.0 * a[4] * a[5] * a[7]
     if name == "emrt_conv2d":
         N, H, W, C = a[5:9]
         OH, OW, OC = a[11:14]
@@ -111,6 +114,8 @@ def conv_bytes(name, a, esz):
     if name == "emrt_bn_pointwise_bwd":        # raw map + dy read, masked input gradient written, dW read-modify-write
         N, HW, C, OC = a[13:17]
         return 2 * N * HW * C * esz + N * HW * OC * esz + OC * C * esz + 2 * 4 * OC * C
+    if name == "emrt_conv2d_drop":
+        return a[4] * a[5] * esz + a[7] * a[5] * esz + a[4] * a[7] * esz
     if name == "emrt_conv2d":
         N, H, W, C = a[5:9]
         OH, OW, OC = a[11:14]
@@ -175,6 +180,8 @@ def dump_calls(path, calls, esz=2):
             vals = vals_of(a)
             if name == "emrt_conv2d":
                 extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
+            elif name == "emrt_conv2d_drop":
+                extra = "linear+relu+dropout M%d %d->%d gflop %.2f" % (vals[4], vals[5], vals[7], conv_flops(name, vals) / 1e9)
             elif name == "emrt_conv2d_bwd":
                 extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
             elif name == "emrt_conv2d_wgrad":

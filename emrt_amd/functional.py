@@ -361,8 +361,6 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
         _L().call("emrt_conv2d", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(out_shift) if out_scale is not None else P(w.bias), P(residual), N, H, W, C, ldin, in_bs,
                   OH, OW, w.OC, ldout, out_bs, ldres, res_bs, w.KH, w.KW, stride, pad, 0, int(relu), int(out_f32), P(bn_stats), None, 0, 0,
                   dil, P(out_scale), c.dtype, c.stream)
-    if drop is not None and not fused_drop:      # (a geometry the fused entry point does not take: the separate dropout launch)
-        return dropout(out, drop[0], drop[1], sole_consumer_is_linear=True)
     tape = c.tape
     own_drop = None
     if fused_drop and tape is not None:
@@ -457,6 +455,8 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
             if residual is not None:
                 tape.add_grad(residual, dy)
         tape.record(bwd)
+    if drop is not None and not fused_drop:      # (a geometry the fused entry point does not take, or the A/B knob: the separate dropout launch,
+        return dropout(out, drop[0], drop[1], sole_consumer_is_linear=True)      #  recorded AFTER this layer's own backward)
     return out
 
 

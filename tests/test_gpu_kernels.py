@@ -646,6 +646,28 @@ def test_ffn_dropout_drawn_in_linear1_epilogue(dtype, dims):
     xr3 = x.clone().requires_grad_(True)
     (F.relu(F.linear(xr3, w1, b1)) * keep3 * scale * gdy).sum().backward()
     close("dropout(relu(linear1)) backward on its own", host(dx3), xr3.grad, dtype, 3.0 * (1.0 if dtype == F32 else 0.3))
+    # the A/B knob's other arm (Context.fuse_ffn_dropout = False: linear1, then the stand-alone dropout launch) must still run linear1's OWN backward
+    # (round 5: the first version returned before recording it -- a faster, wrong step)
+    c.fuse_ffn_dropout = False
+    try:
+        l1.weight.grad.zero_()
+        tape = Tape()
+        c.tape = tape
+        L.start_record()
+        hd4 = l1(xd, relu=True, drop=(p, 23))
+        o4 = l2(hd4)
+        assert [n for n, _ in L.stop_record()] == ["emrt_conv2d", "emrt_dropout_fwd", "emrt_conv2d"]
+        c.tape = None
+        tape.watch(xd)
+        dx4, = run_bwd(tape, [(o4, dev(dy))], [xd])
+        keep4 = (host(hd4) > 0).float()
+        xr4 = x.clone().requires_grad_(True)
+        W14 = w1.clone().requires_grad_(True)
+        (F.linear(F.relu(F.linear(xr4, W14, b1)) * keep4 * scale, w2, b2) * dy).sum().backward()
+        close("unfused arm dx", host(dx4), xr4.grad, dtype, 3.0 * (1.0 if dtype == F32 else 0.3))
+        close("unfused arm dw1", host(l1.weight.grad), W14.grad, dtype, sc * (1.0 if dtype == F32 else 0.5))
+    finally:
+        c.fuse_ffn_dropout = True
 
 
 # -----------------------------------------------------------------------------------------------------------------
