@@ -1335,6 +1335,189 @@ __global__ __launch_bounds__(256) void msda_bwd_value_finalize_kernel(MsdaArgs a
   }
 }
 
+// ---- value gradient as a matrix product (bf16) ---------------------------------------------------------------------------------------------------
+// The scatter above spends one LDS atomic per (sample corner, CHANNEL): 32 lanes add g[q][ch] * w into the corner's 32 cells, 4 wave
+// instructions of ~7 LDS cycles per sample, and that IS its time (96 atomics x 7 clk per query and level).  The channel
+// dimension carries no sparsity -- every channel of a query goes to the same cells with the same weight -- so it belongs on the matrix core:
+//     dvalue[p][ch] = sum_q  A[p][q] * dout[q][ch],       A[p][q] = sum over the (point, corner) pairs of query q that land on pixel p of  prob * bilinear weight
+// per (batch, head, level).  Only the scalar weights are scattered (one LDS integer add per corner: 32 x fewer), into a [pixels][32 queries]
+// tile of 2^-24 fixed-point integers (adds commute: bit-reproducible; a tile entry is <= 1, the level's probabilities sum to <= 1); the tile
+// is then read as the A operand of v_mfma_f32_16x16x32_bf16 (16 pixels x 32 queries) against dout^T staged as [32 channels][32 queries].
+// One block = one (batch, head) x one band of whole rows of one level (<= 256 pixels = 16 MFMA row tiles over 4 waves), walking ALL queries
+// in chunks of 32; a chunk none of whose samples falls into the band is skipped after its sample arithmetic (queries are stored row-major
+// per level and sample near their own reference point).  Every dvalue element is written exactly once, by the block that owns its pixel.
+// Rounding: the summed weight of a (pixel, query) pair is rounded ONCE to bf16 (2^-9 relative), dout is bf16 already, products and sums are fp32.
+struct MsdaMfPlan { int rows[4], nb[4]; };
+#define MSDA_MF_PITCH 36      // ints per pixel row of the weight tile: 32 queries + 4, so that the 16 rows of a fragment read (16 B per lane) cover all 64 banks
+#define MSDA_MF_NPIX 256
+#define MSDA_MF_GP 40         // bf16 per channel row of dout^T
+typedef __attribute__((ext_vector_type(8))) __bf16 msda_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float msda_f32x4_t;
+
+template <int L, int P>
+__global__ __launch_bounds__(256) void msda_bwd_value_mfma_kernel(MsdaArgs a, MsdaMfPlan pl) {
+  constexpr int LP = L * P;
+  static_assert(32 * P <= 256, "one thread per (query of the chunk, point)");
+  __shared__ __attribute__((aligned(16))) int Ai[MSDA_MF_NPIX * MSDA_MF_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned short Gt[32 * MSDA_MF_GP];
+  const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
+  int lev = 0, bi = blockIdx.y;
+#pragma unroll
+  for (int l = 0; l + 1 < L; ++l)
+    if (lev == l && bi >= pl.nb[l]) { bi -= pl.nb[l]; lev = l + 1; }
+  int H = a.h[0], W = a.w[0], lstart = a.start[0], rows = pl.rows[0];
+#pragma unroll
+  for (int l = 1; l < L; ++l)
+    if (lev == l) { H = a.h[l]; W = a.w[l]; lstart = a.start[l]; rows = pl.rows[l]; }
+  const int r0 = bi * rows;
+  const int nrows = H - r0 < rows ? H - r0 : rows;
+  const int pix0 = r0 * W, npix = nrows * W;                  // level-relative first pixel / pixel count of the band
+  const int ntile = (npix + 15) >> 4;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, lg = lane >> 4;
+  for (int i = t; i < MSDA_MF_NPIX * MSDA_MF_PITCH / 4; i += 256) reinterpret_cast<int4*>(Ai)[i] = make_int4(0, 0, 0, 0);
+
+  const bool smp_role = t < 32 * P;
+  const int sq = t / P, sp = t - sq * P;                      // sample role: query of the chunk, point
+  const int gq = t >> 2, gc = t & 3;                          // staging role (t < 128): query of the chunk, 8-channel group
+  const float fW = (float)W, fH = (float)H, ifW = 1.f / fW, ifH = 1.f / fH;
+  const int smp = lev * P + sp;
+  const unsigned short* gbase = (const unsigned short*)a.dout + (long long)b * a.Lq * (a.M * 32) + m * 32 + gc * 8;
+  const int nchunk = (a.Lq + 31) >> 5;
+
+  float2 o_n = make_float2(0.f, 0.f);
+  float rx_n = 0.f, ry_n = 0.f, aw_n = 0.f;
+  uint4 g_n = make_uint4(0, 0, 0, 0);
+  auto prefetch = [&](int c) {
+    const int q = c * 32 + sq;
+    aw_n = 0.f;
+    if (smp_role && q < a.Lq) {
+      const long long bq = (long long)b * a.Lq + q;
+      o_n = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
+      const float* refq = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
+      rx_n = refq[0];
+      ry_n = refq[1];
+      aw_n = a.probs[bq * (a.M * LP) + m * LP + smp];
+    }
+    const int qg = c * 32 + gq;
+    g_n = make_uint4(0, 0, 0, 0);
+    if (t < 128 && qg < a.Lq) g_n = *reinterpret_cast<const uint4*>(gbase + (long long)qg * (a.M * 32));
+  };
+  prefetch(0);
+  msda_f32x4_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = (msda_f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+
+  for (int c = 0; c < nchunk; ++c) {
+    const float2 o = o_n;
+    const float rx = rx_n, ry = ry_n, aw = aw_n;
+    const uint4 g = g_n;
+    if (c + 1 < nchunk) prefetch(c + 1);
+    // this thread's sample: cell index relative to the band and the four corner weights (probability folded in; 0 = outside the map or the band)
+    const float x = (rx + o.x * ifW) * fW - 0.5f;
+    const float y = (ry + o.y * ifH) * fH - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float lx = x - xf, ly = y - yf;
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int f00 = y0 * W + x0 - pix0;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const bool live = aw != 0.f && x > -2.f && y > -2.f && x < fW + 1.f && y < fH + 1.f;      // (also keeps NaN / huge coordinates away from the int conversions)
+    const bool h00 = live && vy0 && vx0 && (unsigned)f00 < (unsigned)npix;
+    const bool h01 = live && vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix;
+    const bool h10 = live && vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix;
+    const bool h11 = live && vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix;
+    // barrier: the previous chunk's fragment reads (and the zeroes written behind them) are done before anyone adds into the tile again
+    if (!__syncthreads_or(h00 || h01 || h10 || h11)) continue;
+    const float s24 = 16777216.f * aw;
+    if (h00) atomicAdd(&Ai[f00 * MSDA_MF_PITCH + sq], __float2int_rn(s24 * (1.f - ly) * (1.f - lx)));
+    if (h01) atomicAdd(&Ai[(f00 + 1) * MSDA_MF_PITCH + sq], __float2int_rn(s24 * (1.f - ly) * lx));
+    if (h10) atomicAdd(&Ai[(f00 + W) * MSDA_MF_PITCH + sq], __float2int_rn(s24 * ly * (1.f - lx)));
+    if (h11) atomicAdd(&Ai[(f00 + W + 1) * MSDA_MF_PITCH + sq], __float2int_rn(s24 * ly * lx));
+    if (t < 128) {      // dout^T: 8 channels of one query, one 2-byte store per channel row
+      const unsigned gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Gt[(gc * 8 + 2 * e) * MSDA_MF_GP + gq] = (unsigned short)(gv[e] & 0xffffu);
+        Gt[(gc * 8 + 2 * e + 1) * MSDA_MF_GP + gq] = (unsigned short)(gv[e] >> 16);
+      }
+    }
+    __syncthreads();
+    const msda_bf16x8_t b0 = *reinterpret_cast<const msda_bf16x8_t*>(&Gt[lr * MSDA_MF_GP + lg * 8]);
+    const msda_bf16x8_t b1 = *reinterpret_cast<const msda_bf16x8_t*>(&Gt[(16 + lr) * MSDA_MF_GP + lg * 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = wave + 4 * i;
+      if (s < ntile) {
+        int4* cell = reinterpret_cast<int4*>(&Ai[(s * 16 + lr) * MSDA_MF_PITCH + lg * 8]);
+        const int4 lo = cell[0], hi = cell[1];
+        cell[0] = make_int4(0, 0, 0, 0);          // the tile is empty again for the next chunk (this lane is the only reader of these 8 words)
+        cell[1] = make_int4(0, 0, 0, 0);
+        const float sc = 1.f / 16777216.f;
+        msda_bf16x8_t av;
+        av[0] = (__bf16)((float)lo.x * sc); av[1] = (__bf16)((float)lo.y * sc); av[2] = (__bf16)((float)lo.z * sc); av[3] = (__bf16)((float)lo.w * sc);
+        av[4] = (__bf16)((float)hi.x * sc); av[5] = (__bf16)((float)hi.y * sc); av[6] = (__bf16)((float)hi.z * sc); av[7] = (__bf16)((float)hi.w * sc);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[i][1], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // accumulators -> [pixel][33] fp32 in the tile's LDS -> 64-byte rows of dvalue
+  float* fl = reinterpret_cast<float*>(Ai);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = wave + 4 * i;
+    if (s < ntile) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fl[(s * 16 + lg * 4 + r) * 33 + n * 16 + lr] = acc[i][n][r];
+    }
+  }
+  __syncthreads();
+  bf16_t* outp = (bf16_t*)a.dvalue_t + ((long long)b * a.Lv + lstart + pix0) * (a.M * 32) + m * 32;
+  for (int i = t; i < npix * 4; i += 256) {
+    const int pix = i >> 2, c8 = (i & 3) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fl[pix * 33 + c8 + e];
+    Vec8<bf16_t>::store(outp + (long long)pix * (a.M * 32) + c8, v);
+  }
+}
+
+// bands of the matrix-product scatter: whole rows, <= 256 pixels, and at least ~4 bands per level (a level all of whose queries are live in
+// one band -- the small maps -- would otherwise be the launch's critical path)
+static bool msda_mf_plan(const MsdaArgs& a, int L, MsdaMfPlan& pl, int& nbands) {
+  nbands = 0;
+  for (int l = 0; l < 4; ++l) { pl.rows[l] = 1; pl.nb[l] = 0; }
+  const int per_level = g_tune.msda_mf_bands > 0 ? g_tune.msda_mf_bands : 4;
+  for (int l = 0; l < L; ++l) {
+    if (a.w[l] > MSDA_MF_NPIX) return false;
+    int rows = MSDA_MF_NPIX / a.w[l];
+    const int want = (a.h[l] + per_level - 1) / per_level;
+    if (rows > want) rows = want;
+    if (rows < 1) rows = 1;
+    pl.rows[l] = rows;
+    pl.nb[l] = (a.h[l] + rows - 1) / rows;
+    nbands += pl.nb[l];
+  }
+  return nbands <= 65535;
+}
+
+static int msda_launch_mf(const MsdaArgs& a, int L, int P, const MsdaMfPlan& pl, int nbands, hipStream_t st) {
+#define MSDA_MF_CASE(LL, PP)                                                                                  \
+  if (L == LL && P == PP) {                                                                                   \
+    hipLaunchKernelGGL((msda_bwd_value_mfma_kernel<LL, PP>), dim3(a.B * a.M, nbands), dim3(256), 0, st, a, pl); \
+    return check_launch("emrt_msda_bwd(matrix-product scatter)");                                             \
+  }
+  MSDA_MF_CASE(3, 6)
+  MSDA_MF_CASE(4, 4)
+  MSDA_MF_CASE(3, 4)
+  MSDA_MF_CASE(1, 4)
+#undef MSDA_MF_CASE
+  return fail("emrt_msda_bwd", "unsupported (levels, points) for the matrix-product scatter");
+}
+
 // pixels of a scatter range: (npix + 2 guard) * 33 * 4 B of slab + 20 480 B of sample records must fit the 160 KiB LDS
 static int msda_max_npix(int guard) { return ((160 * 1024 - 20480) / (MSDA_SLAB_PITCH * 4) - 2 * guard) & ~3; }
 
@@ -1744,6 +1927,10 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
       }
     }
     if (rc) return rc;
+    if (MsdaMfPlan pl; dtype == EMRT_BF16 && g_tune.msda_scatter_mfma) {
+      int nbands = 0;
+      if (msda_mf_plan(a, L, pl, nbands)) return msda_launch_mf(a, L, P, pl, nbands, st);
+    }
     a.g_npix_max = (npix_max + 2 * guard + 3) & ~3;          // slab + both guard bands; keeps the records 16-byte aligned
     const size_t lds = (size_t)a.g_npix_max * MSDA_SLAB_PITCH * sizeof(int) + 32 * 32 * (sizeof(float4) + sizeof(int));
     EMRT_REQUIRE(a.f_n == 0 || a.gmax_n > 0, "internal: query-split scatter planned without the max |dout| partials");
