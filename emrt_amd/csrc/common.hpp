@@ -79,8 +79,10 @@ struct Tuning {
   int wgroup_min_steps;   // ... fewest 64-pixel tiles per block (32: shorter blocks only buy fp32 atomic traffic)
   int wgroup_max;         // ... most problems per launch (0 = the kernel's limit, 24)
   int msda_scatter_merge; // 1 = the value-gradient scatter adds consecutive points of a query with the same 2 x 2 footprint in registers first (A/B knob)
-  int msda_scatter_mfma;  // 1 (default): bf16 value gradients of the deformable attention as a matrix product (msda_bwd_value_mfma_kernel); 0 = the LDS atomic scatter
-  int msda_mf_bands;      // ... row bands per level the planner aims for (0 = 4)
+  int msda_scatter_mfma;  // bf16 value gradients of the deformable attention as a matrix product (msda_bwd_value_mfma_kernel): 1 (default) = when at most one level needs two
+                          // row bands, 2 = whenever the maps are <= 512 pixels wide, 0 = always the LDS atomic scatter
+  int msda_mf_bands;      // ... most pixels of a row band (0 = 512)
+  int sgd_nt;             // 1 (default): the optimizer pass streams master weights / velocity / gradients with non-temporal accesses (A/B knob)
   int mha_valu;           // 1 = the decoder's softmax attention on the VALU kernels for every dtype (A/B knob; bf16 / fp16 default to the MFMA kernels)
   int xk;                 // cross-block K split of few-tile, long-K convolutions: 0 = the dispatcher's choice, -1 = never, n >= 2 = n copies whenever the shape allows
 };

@@ -290,7 +290,7 @@ struct SgdArgs {
   void* mirror;                  // optional: compute-dtype copy of the parameters, same indexing as p
 };
 
-template <class MT>
+template <class MT, bool NT>
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdArgs a) {
   long long t = a.step ? a.step[0] : 0;
   if (t > a.decay_steps) t = a.decay_steps;
@@ -304,9 +304,20 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdArgs a) {
   const long long n4 = a.n / 4;
   for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
     const long long i = i4 * 4;
-    const float4 p4 = reinterpret_cast<const float4*>(a.p)[i4];
-    const float4 g4 = reinterpret_cast<const float4*>(a.g)[i4];
-    const float4 v4 = reinterpret_cast<const float4*>(a.v)[i4];
+    // master copy, velocity and gradient are touched once per step (1.1 GB at 56 M parameters): non-temporal, so that they do not push the
+    // compute-dtype mirror written below -- the next forward's GEMM operand -- out of the last-level cache (knob sgd_nt, default on)
+    typedef __attribute__((ext_vector_type(4))) float sgd_f32x4;
+    sgd_f32x4 pq, gq, vq;
+    if (NT) {
+      pq = __builtin_nontemporal_load(reinterpret_cast<const sgd_f32x4*>(a.p) + i4);
+      gq = __builtin_nontemporal_load(reinterpret_cast<const sgd_f32x4*>(a.g) + i4);
+      vq = __builtin_nontemporal_load(reinterpret_cast<const sgd_f32x4*>(a.v) + i4);
+    } else {
+      pq = reinterpret_cast<const sgd_f32x4*>(a.p)[i4];
+      gq = reinterpret_cast<const sgd_f32x4*>(a.g)[i4];
+      vq = reinterpret_cast<const sgd_f32x4*>(a.v)[i4];
+    }
+    const float4 p4 = make_float4(pq[0], pq[1], pq[2], pq[3]), g4 = make_float4(gq[0], gq[1], gq[2], gq[3]), v4 = make_float4(vq[0], vq[1], vq[2], vq[3]);
     float p[4] = {p4.x, p4.y, p4.z, p4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
     const float g[4] = {g4.x, g4.y, g4.z, g4.w};
     bool any = false;
@@ -321,8 +332,13 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(SgdArgs a) {
       v[e] = a.momentum * v[e] + gg;
       p[e] = p[e] - lr * mult * v[e];
     }
-    reinterpret_cast<float4*>(a.v)[i4] = make_float4(v[0], v[1], v[2], v[3]);
-    reinterpret_cast<float4*>(a.p)[i4] = make_float4(p[0], p[1], p[2], p[3]);
+    if (NT) {
+      __builtin_nontemporal_store((sgd_f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<sgd_f32x4*>(a.v) + i4);
+      __builtin_nontemporal_store((sgd_f32x4){p[0], p[1], p[2], p[3]}, reinterpret_cast<sgd_f32x4*>(a.p) + i4);
+    } else {
+      reinterpret_cast<float4*>(a.v)[i4] = make_float4(v[0], v[1], v[2], v[3]);
+      reinterpret_cast<float4*>(a.p)[i4] = make_float4(p[0], p[1], p[2], p[3]);
+    }
     if (mirror) Vec4<MT>::store(mirror + i, p);
   }
   if (blockIdx.x == 0) {
@@ -378,8 +394,14 @@ extern "C" int emrt_sgd_momentum_step(float* params, const float* grads, float* 
   int grid = (int)((n / 4 + 255) / 256);
   if (grid > 8192) grid = 8192;
   if (grid < 1) grid = 1;
-  if (mirror && mirror_dtype == EMRT_F16) hipLaunchKernelGGL(sgd_momentum_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(sgd_momentum_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  const bool nt = g_tune.sgd_nt != 0;
+  if (mirror && mirror_dtype == EMRT_F16) {
+    if (nt) hipLaunchKernelGGL((sgd_momentum_kernel<f16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((sgd_momentum_kernel<f16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((sgd_momentum_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((sgd_momentum_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return check_launch("emrt_sgd_momentum_step");
 }
 

@@ -1347,19 +1347,27 @@ __global__ __launch_bounds__(256) void msda_bwd_value_finalize_kernel(MsdaArgs a
 // in chunks of 32; a chunk none of whose samples falls into the band is skipped after its sample arithmetic (queries are stored row-major
 // per level and sample near their own reference point).  Every dvalue element is written exactly once, by the block that owns its pixel.
 // Rounding: the summed weight of a (pixel, query) pair is rounded ONCE to bf16 (2^-9 relative), dout is bf16 already, products and sums are fp32.
-struct MsdaMfPlan { int rows[4], nb[4]; };
+struct MsdaMfPlan { int rows[4], nb[4], npix_cap; };
 #define MSDA_MF_PITCH 36      // ints per pixel row of the weight tile: 32 queries + 4, so that the 16 rows of a fragment read (16 B per lane) cover all 64 banks
-#define MSDA_MF_NPIX 256
+#define MSDA_MF_NPIX 512      // most pixels of a band: 32 MFMA row tiles over 4 consumer waves; TWO weight tiles of 72 KiB (one being filled, one being multiplied)
 #define MSDA_MF_GP 40         // bf16 per channel row of dout^T
 typedef __attribute__((ext_vector_type(8))) __bf16 msda_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float msda_f32x4_t;
 
+// Work split inside a block (512 threads), one barrier per chunk of 32 queries:
+//   waves 0..2  one thread per (query of the chunk, point): sample geometry, <= 4 integer LDS adds into weight tile (c & 1), a flag per touched row tile
+//   wave  3     dout^T of the chunk into Gt (c & 1)
+//   waves 4..7  chunk c - 1: every flagged row tile of weight tile ((c - 1) & 1) -> bf16 A fragment (and zeroes behind it) -> two MFMAs (channels 0..15, 16..31)
+// The per-sample geometry is ~120 wave instructions (4 cycles each on a SIMD16) per chunk and producer wave -- as much as the MFMA side -- which
+// is why the two sides run on different waves at the same time instead of one after the other (the first version: 65 us per encoder call).
 template <int L, int P>
-__global__ __launch_bounds__(256) void msda_bwd_value_mfma_kernel(MsdaArgs a, MsdaMfPlan pl) {
+__global__ __launch_bounds__(512) void msda_bwd_value_mfma_kernel(MsdaArgs a, MsdaMfPlan pl) {
   constexpr int LP = L * P;
-  static_assert(32 * P <= 256, "one thread per (query of the chunk, point)");
-  __shared__ __attribute__((aligned(16))) int Ai[MSDA_MF_NPIX * MSDA_MF_PITCH];
-  __shared__ __attribute__((aligned(16))) unsigned short Gt[32 * MSDA_MF_GP];
+  static_assert(32 * P <= 192, "one thread of waves 0..2 per (query of the chunk, point)");
+  extern __shared__ __attribute__((aligned(16))) int Ai[];                                          // [2][npix_cap][36] fixed-point weights
+  const int asz = pl.npix_cap * MSDA_MF_PITCH;
+  unsigned short* Gt = reinterpret_cast<unsigned short*>(Ai + 2 * asz);                              // [2][32 channels][40] dout^T of a chunk
+  int* tflag = reinterpret_cast<int*>(Gt + 2 * 32 * MSDA_MF_GP);                                     // [2][4 consumer waves][8]: row tile w + 4 i has entries
   const int b = blockIdx.x / a.M, m = blockIdx.x % a.M;
   int lev = 0, bi = blockIdx.y;
 #pragma unroll
@@ -1374,109 +1382,165 @@ __global__ __launch_bounds__(256) void msda_bwd_value_mfma_kernel(MsdaArgs a, Ms
   const int pix0 = r0 * W, npix = nrows * W;                  // level-relative first pixel / pixel count of the band
   const int ntile = (npix + 15) >> 4;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, lg = lane >> 4;
-  for (int i = t; i < MSDA_MF_NPIX * MSDA_MF_PITCH / 4; i += 256) reinterpret_cast<int4*>(Ai)[i] = make_int4(0, 0, 0, 0);
+  for (int i = t; i < 2 * asz / 4; i += 512) reinterpret_cast<int4*>(Ai)[i] = make_int4(0, 0, 0, 0);
+  if (t < 64) tflag[t] = 0;
 
   const bool smp_role = t < 32 * P;
-  const int sq = t / P, sp = t - sq * P;                      // sample role: query of the chunk, point
-  const int gq = t >> 2, gc = t & 3;                          // staging role (t < 128): query of the chunk, 8-channel group
+  const int sq = smp_role ? t / P : 0, sp = t - sq * P;       // sample role: query of the chunk, point
+  const bool stg_role = wave == 3;                            // staging role: lane -> (query, 8-channel group) pairs lane and lane + 64
+  const int gq = lane >> 2, gc = lane & 3;
   const float fW = (float)W, fH = (float)H, ifW = 1.f / fW, ifH = 1.f / fH;
   const int smp = lev * P + sp;
   const unsigned short* gbase = (const unsigned short*)a.dout + (long long)b * a.Lq * (a.M * 32) + m * 32 + gc * 8;
   const int nchunk = (a.Lq + 31) >> 5;
 
-  float2 o_n = make_float2(0.f, 0.f);
-  float rx_n = 0.f, ry_n = 0.f, aw_n = 0.f;
-  uint4 g_n = make_uint4(0, 0, 0, 0);
-  auto prefetch = [&](int c) {
-    const int q = c * 32 + sq;
-    aw_n = 0.f;
-    if (smp_role && q < a.Lq) {
-      const long long bq = (long long)b * a.Lq + q;
-      o_n = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
-      const float* refq = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
-      rx_n = refq[0];
-      ry_n = refq[1];
-      aw_n = a.probs[bq * (a.M * LP) + m * LP + smp];
+  // operands of SC = 4 chunks are loaded at once, one super-chunk ahead of their use
+  constexpr int SC = 4;
+  float2 o_n[SC];
+  float rx_n[SC], ry_n[SC], aw_n[SC];
+  uint4 g_n[SC][2];
+  auto prefetch = [&](int sc) {
+#pragma unroll
+    for (int k = 0; k < SC; ++k) {
+      const int q = (sc * SC + k) * 32 + sq;
+      o_n[k] = make_float2(0.f, 0.f);
+      rx_n[k] = 0.f; ry_n[k] = 0.f; aw_n[k] = 0.f;
+      if (smp_role && q < a.Lq) {
+        const long long bq = (long long)b * a.Lq + q;
+        o_n[k] = *reinterpret_cast<const float2*>(a.offw + bq * a.ldo + (m * LP + smp) * 2);
+        const float* refq = a.ref + (long long)b * a.ref_bs + (long long)q * a.ref_L * 2 + (a.ref_L == 1 ? 0 : lev * 2);
+        rx_n[k] = refq[0];
+        ry_n[k] = refq[1];
+        aw_n[k] = a.probs[bq * (a.M * LP) + m * LP + smp];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int qg = (sc * SC + k) * 32 + gq + 16 * h;
+        g_n[k][h] = make_uint4(0, 0, 0, 0);
+        if (stg_role && qg < a.Lq) g_n[k][h] = *reinterpret_cast<const uint4*>(gbase + (long long)qg * (a.M * 32));
+      }
     }
-    const int qg = c * 32 + gq;
-    g_n = make_uint4(0, 0, 0, 0);
-    if (t < 128 && qg < a.Lq) g_n = *reinterpret_cast<const uint4*>(gbase + (long long)qg * (a.M * 32));
   };
   prefetch(0);
-  msda_f32x4_t acc[4][2];
+  msda_f32x4_t acc[8][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { acc[i][0] = (msda_f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  for (int i = 0; i < 8; ++i) { acc[i][0] = (msda_f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  __syncthreads();
 
-  for (int c = 0; c < nchunk; ++c) {
-    const float2 o = o_n;
-    const float rx = rx_n, ry = ry_n, aw = aw_n;
-    const uint4 g = g_n;
-    if (c + 1 < nchunk) prefetch(c + 1);
-    // this thread's sample: cell index relative to the band and the four corner weights (probability folded in; 0 = outside the map or the band)
-    const float x = (rx + o.x * ifW) * fW - 0.5f;
-    const float y = (ry + o.y * ifH) * fH - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float lx = x - xf, ly = y - yf;
-    const int x0 = (int)xf, y0 = (int)yf;
-    const int f00 = y0 * W + x0 - pix0;
-    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
-    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-    const bool live = aw != 0.f && x > -2.f && y > -2.f && x < fW + 1.f && y < fH + 1.f;      // (also keeps NaN / huge coordinates away from the int conversions)
-    const bool h00 = live && vy0 && vx0 && (unsigned)f00 < (unsigned)npix;
-    const bool h01 = live && vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix;
-    const bool h10 = live && vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix;
-    const bool h11 = live && vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix;
-    // barrier: the previous chunk's fragment reads (and the zeroes written behind them) are done before anyone adds into the tile again
-    if (!__syncthreads_or(h00 || h01 || h10 || h11)) continue;
-    const float s24 = 16777216.f * aw;
-    if (h00) atomicAdd(&Ai[f00 * MSDA_MF_PITCH + sq], __float2int_rn(s24 * (1.f - ly) * (1.f - lx)));
-    if (h01) atomicAdd(&Ai[(f00 + 1) * MSDA_MF_PITCH + sq], __float2int_rn(s24 * (1.f - ly) * lx));
-    if (h10) atomicAdd(&Ai[(f00 + W) * MSDA_MF_PITCH + sq], __float2int_rn(s24 * ly * (1.f - lx)));
-    if (h11) atomicAdd(&Ai[(f00 + W + 1) * MSDA_MF_PITCH + sq], __float2int_rn(s24 * ly * lx));
-    if (t < 128) {      // dout^T: 8 channels of one query, one 2-byte store per channel row
-      const unsigned gv[4] = {g.x, g.y, g.z, g.w};
+  const int nsc = (nchunk + 1 + SC - 1) / SC;          // one more step than chunks: the consumers run one chunk behind
+  for (int sc = 0; sc < nsc; ++sc) {
+    float2 o_c[SC];
+    float rx_c[SC], ry_c[SC], aw_c[SC];
+    uint4 g_c[SC][2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Gt[(gc * 8 + 2 * e) * MSDA_MF_GP + gq] = (unsigned short)(gv[e] & 0xffffu);
-        Gt[(gc * 8 + 2 * e + 1) * MSDA_MF_GP + gq] = (unsigned short)(gv[e] >> 16);
-      }
-    }
-    __syncthreads();
-    const msda_bf16x8_t b0 = *reinterpret_cast<const msda_bf16x8_t*>(&Gt[lr * MSDA_MF_GP + lg * 8]);
-    const msda_bf16x8_t b1 = *reinterpret_cast<const msda_bf16x8_t*>(&Gt[(16 + lr) * MSDA_MF_GP + lg * 8]);
+    for (int k = 0; k < SC; ++k) { o_c[k] = o_n[k]; rx_c[k] = rx_n[k]; ry_c[k] = ry_n[k]; aw_c[k] = aw_n[k]; g_c[k][0] = g_n[k][0]; g_c[k][1] = g_n[k][1]; }
+    if ((sc + 1) * SC < nchunk) prefetch(sc + 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int s = wave + 4 * i;
-      if (s < ntile) {
-        int4* cell = reinterpret_cast<int4*>(&Ai[(s * 16 + lr) * MSDA_MF_PITCH + lg * 8]);
-        const int4 lo = cell[0], hi = cell[1];
-        cell[0] = make_int4(0, 0, 0, 0);          // the tile is empty again for the next chunk (this lane is the only reader of these 8 words)
-        cell[1] = make_int4(0, 0, 0, 0);
-        const float sc = 1.f / 16777216.f;
-        msda_bf16x8_t av;
-        av[0] = (__bf16)((float)lo.x * sc); av[1] = (__bf16)((float)lo.y * sc); av[2] = (__bf16)((float)lo.z * sc); av[3] = (__bf16)((float)lo.w * sc);
-        av[4] = (__bf16)((float)hi.x * sc); av[5] = (__bf16)((float)hi.y * sc); av[6] = (__bf16)((float)hi.z * sc); av[7] = (__bf16)((float)hi.w * sc);
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[i][1], 0, 0, 0);
+    for (int k = 0; k < SC; ++k) {
+      const int c = sc * SC + k;
+      if (c > nchunk) break;
+      if (wave < 4) {
+        if (c < nchunk) {
+          int* A = Ai + (c & 1) * asz;
+          int* tf = tflag + (c & 1) * 32;
+          if (smp_role) {
+            const float2 o = o_c[k];
+            const float aw = aw_c[k];
+            // this thread's sample: cell index relative to the band and the four corner weights (probability folded in)
+            const float x = (rx_c[k] + o.x * ifW) * fW - 0.5f;
+            const float y = (ry_c[k] + o.y * ifH) * fH - 0.5f;
+            const float xf = floorf(x), yf = floorf(y);
+            const float lx = x - xf, ly = y - yf;
+            const int x0 = (int)xf, y0 = (int)yf;
+            const int f00 = y0 * W + x0 - pix0;
+            const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+            const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+            const bool live = aw != 0.f && x > -2.f && y > -2.f && x < fW + 1.f && y < fH + 1.f;      // (also keeps NaN / huge coordinates away from the int conversions)
+            const bool h00 = live && vy0 && vx0 && (unsigned)f00 < (unsigned)npix;
+            const bool h01 = live && vy0 && vx1 && (unsigned)(f00 + 1) < (unsigned)npix;
+            const bool h10 = live && vy1 && vx0 && (unsigned)(f00 + W) < (unsigned)npix;
+            const bool h11 = live && vy1 && vx1 && (unsigned)(f00 + W + 1) < (unsigned)npix;
+            const float s24 = 16777216.f * aw;
+            int* cell = A + f00 * MSDA_MF_PITCH + sq;
+            // slot of row tile s in tf: consumer wave (s & 3) owns it as its entry s >> 2
+            if (h00) { atomicAdd(cell, __float2int_rn(s24 * (1.f - ly) * (1.f - lx))); const int s = f00 >> 4; tf[(s & 3) * 8 + (s >> 2)] = 1; }
+            if (h01) { atomicAdd(cell + MSDA_MF_PITCH, __float2int_rn(s24 * (1.f - ly) * lx)); const int s = (f00 + 1) >> 4; tf[(s & 3) * 8 + (s >> 2)] = 1; }
+            if (h10) { atomicAdd(cell + W * MSDA_MF_PITCH, __float2int_rn(s24 * ly * (1.f - lx))); const int s = (f00 + W) >> 4; tf[(s & 3) * 8 + (s >> 2)] = 1; }
+            if (h11) { atomicAdd(cell + (W + 1) * MSDA_MF_PITCH, __float2int_rn(s24 * ly * lx)); const int s = (f00 + W + 1) >> 4; tf[(s & 3) * 8 + (s >> 2)] = 1; }
+          } else if (stg_role) {      // dout^T: 8 channels of one query, one 2-byte store per channel row
+            unsigned short* G = Gt + (c & 1) * 32 * MSDA_MF_GP;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint4 g = g_c[k][h];
+              const unsigned gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                G[(gc * 8 + 2 * e) * MSDA_MF_GP + gq + 16 * h] = (unsigned short)(gv[e] & 0xffffu);
+                G[(gc * 8 + 2 * e + 1) * MSDA_MF_GP + gq + 16 * h] = (unsigned short)(gv[e] >> 16);
+              }
+            }
+          }
+        }
+      } else if (c >= 1) {
+        const int cw = wave - 4;
+        int* A = Ai + ((c - 1) & 1) * asz;
+        int* tf = tflag + ((c - 1) & 1) * 32;
+        const unsigned short* G = Gt + ((c - 1) & 1) * 32 * MSDA_MF_GP;
+        const int4 fa = reinterpret_cast<const int4*>(tf)[cw * 2], fb = reinterpret_cast<const int4*>(tf)[cw * 2 + 1];      // (wave-uniform: broadcast reads)
+        if ((fa.x | fa.y | fa.z | fa.w | fb.x | fb.y | fb.z | fb.w) != 0) {
+          if (lane == 0) { reinterpret_cast<int4*>(tf)[cw * 2] = make_int4(0, 0, 0, 0); reinterpret_cast<int4*>(tf)[cw * 2 + 1] = make_int4(0, 0, 0, 0); }
+          const int fl8[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+          const msda_bf16x8_t b0 = *reinterpret_cast<const msda_bf16x8_t*>(&G[lr * MSDA_MF_GP + lg * 8]);
+          const msda_bf16x8_t b1 = *reinterpret_cast<const msda_bf16x8_t*>(&G[(16 + lr) * MSDA_MF_GP + lg * 8]);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {      // four row tiles' fragment reads in flight before the first conversion
+            int4 lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = half * 4 + j;
+              if (fl8[i]) {
+                int4* cell = reinterpret_cast<int4*>(&A[((cw + 4 * i) * 16 + lr) * MSDA_MF_PITCH + lg * 8]);
+                lo[j] = cell[0];
+                hi[j] = cell[1];
+                cell[0] = make_int4(0, 0, 0, 0);          // the tile is empty again for chunk c + 1 (this lane is the only reader of these 8 words)
+                cell[1] = make_int4(0, 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = half * 4 + j;
+              if (fl8[i]) {
+                const float sc24 = 1.f / 16777216.f;
+                msda_bf16x8_t av;
+                av[0] = (__bf16)((float)lo[j].x * sc24); av[1] = (__bf16)((float)lo[j].y * sc24); av[2] = (__bf16)((float)lo[j].z * sc24); av[3] = (__bf16)((float)lo[j].w * sc24);
+                av[4] = (__bf16)((float)hi[j].x * sc24); av[5] = (__bf16)((float)hi[j].y * sc24); av[6] = (__bf16)((float)hi[j].z * sc24); av[7] = (__bf16)((float)hi[j].w * sc24);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[i][1], 0, 0, 0);
+              }
+            }
+          }
+        }
       }
+      __syncthreads();
     }
   }
-  __syncthreads();
-  // accumulators -> [pixel][33] fp32 in the tile's LDS -> 64-byte rows of dvalue
+  // accumulators -> [pixel][33] fp32 in the first weight tile's LDS -> 64-byte rows of dvalue
   float* fl = reinterpret_cast<float*>(Ai);
+  if (wave >= 4) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int s = wave + 4 * i;
-    if (s < ntile) {
+    for (int i = 0; i < 8; ++i) {
+      const int s = wave - 4 + 4 * i;
+      if (s < ntile) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fl[(s * 16 + lg * 4 + r) * 33 + n * 16 + lr] = acc[i][n][r];
+          for (int r = 0; r < 4; ++r) fl[(s * 16 + lg * 4 + r) * 33 + n * 16 + lr] = acc[i][n][r];
+      }
     }
   }
   __syncthreads();
   bf16_t* outp = (bf16_t*)a.dvalue_t + ((long long)b * a.Lv + lstart + pix0) * (a.M * 32) + m * 32;
-  for (int i = t; i < npix * 4; i += 256) {
+  for (int i = t; i < npix * 4; i += 512) {
     const int pix = i >> 2, c8 = (i & 3) * 8;
     float v[8];
 #pragma unroll
@@ -1485,29 +1549,35 @@ __global__ __launch_bounds__(256) void msda_bwd_value_mfma_kernel(MsdaArgs a, Ms
   }
 }
 
-// bands of the matrix-product scatter: whole rows, <= 256 pixels, and at least ~4 bands per level (a level all of whose queries are live in
-// one band -- the small maps -- would otherwise be the launch's critical path)
+// bands of the matrix-product scatter: whole rows, <= 512 pixels (a whole level when it fits: every band re-reads the offsets, probabilities and
+// dout of ALL queries -- 152 B per query and head)
 static bool msda_mf_plan(const MsdaArgs& a, int L, MsdaMfPlan& pl, int& nbands) {
   nbands = 0;
+  pl.npix_cap = 16;
   for (int l = 0; l < 4; ++l) { pl.rows[l] = 1; pl.nb[l] = 0; }
-  const int per_level = g_tune.msda_mf_bands > 0 ? g_tune.msda_mf_bands : 4;
+  const int cap = g_tune.msda_mf_bands > 0 ? (g_tune.msda_mf_bands < MSDA_MF_NPIX ? g_tune.msda_mf_bands : MSDA_MF_NPIX) : MSDA_MF_NPIX;      // knob: most pixels per band
   for (int l = 0; l < L; ++l) {
-    if (a.w[l] > MSDA_MF_NPIX) return false;
-    int rows = MSDA_MF_NPIX / a.w[l];
-    const int want = (a.h[l] + per_level - 1) / per_level;
-    if (rows > want) rows = want;
-    if (rows < 1) rows = 1;
+    if (a.w[l] > cap) return false;
+    int rows = cap / a.w[l];
+    if (rows > a.h[l]) rows = a.h[l];
     pl.rows[l] = rows;
     pl.nb[l] = (a.h[l] + rows - 1) / rows;
     nbands += pl.nb[l];
+    const int np = (rows * a.w[l] + 15) & ~15;
+    if (np > pl.npix_cap) pl.npix_cap = np;
   }
   return nbands <= 65535;
 }
 
 static int msda_launch_mf(const MsdaArgs& a, int L, int P, const MsdaMfPlan& pl, int nbands, hipStream_t st) {
+  size_t lds = (size_t)2 * pl.npix_cap * MSDA_MF_PITCH * 4 + 2 * 32 * MSDA_MF_GP * 2 + 64 * 4;
+  const size_t epi = (size_t)pl.npix_cap * 33 * 4;          // the epilogue's fp32 image starts at the first weight tile
+  if (lds < epi) lds = epi;
 #define MSDA_MF_CASE(LL, PP)                                                                                  \
   if (L == LL && P == PP) {                                                                                   \
-    hipLaunchKernelGGL((msda_bwd_value_mfma_kernel<LL, PP>), dim3(a.B * a.M, nbands), dim3(256), 0, st, a, pl); \
+    static bool attr = false;                                                                                 \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msda_bwd_value_mfma_kernel<LL, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr = true; } \
+    hipLaunchKernelGGL((msda_bwd_value_mfma_kernel<LL, PP>), dim3(a.B * a.M, nbands), dim3(512), lds, st, a, pl); \
     return check_launch("emrt_msda_bwd(matrix-product scatter)");                                             \
   }
   MSDA_MF_CASE(3, 6)
@@ -1928,8 +1998,11 @@ extern "C" int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const f
     }
     if (rc) return rc;
     if (MsdaMfPlan pl; dtype == EMRT_BF16 && g_tune.msda_scatter_mfma) {
+      // every band of a level re-reads and re-derives ALL queries' samples of that level: worth it while at most one level is cut in two
+      // (cfg2: 32 x 32 | 16 x 16 | 8 x 8 = 4 bands, 256 blocks at batch 8: 45 vs 59 us; cfg3's 64 x 64 level would be 8 bands: 323 vs 199 us per call).
+      // knob msda_scatter_mfma: 0 = never, 1 = this rule, 2 = whenever a plan exists (tests)
       int nbands = 0;
-      if (msda_mf_plan(a, L, pl, nbands)) return msda_launch_mf(a, L, P, pl, nbands, st);
+      if (msda_mf_plan(a, L, pl, nbands) && (nbands <= L + 1 || g_tune.msda_scatter_mfma >= 2)) return msda_launch_mf(a, L, P, pl, nbands, st);
     }
     a.g_npix_max = (npix_max + 2 * guard + 3) & ~3;          // slab + both guard bands; keeps the records 16-byte aligned
     const size_t lds = (size_t)a.g_npix_max * MSDA_SLAB_PITCH * sizeof(int) + 32 * 32 * (sizeof(float4) + sizeof(int));

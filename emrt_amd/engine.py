@@ -13,6 +13,8 @@ layers (paddle_EMRT.py:64, fcn_head.py:53) all-reduce their statistics in every 
 does: inside a captured stretch the graph is cut at each of those collectives (GraphSequence) and the all-reduce is issued
 eagerly between the two pieces, forward and backward.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -212,6 +214,13 @@ class TrainEngine:
             self.graph_b = GraphSequence(pool=self.graph_a.pool(), mode=mode)
             self.graph_b.capture(self.opt.step)
 
+    @staticmethod
+    def _stage(dst, src):
+        """Next batch into the buffer the captured graph reads: a device-to-device copy through the C-ABI on the step's stream."""
+        src = src.contiguous()
+        assert src.dtype == dst.dtype and src.numel() == dst.numel() and src.is_cuda, (src.dtype, dst.dtype, src.shape, dst.shape)
+        _lib.lib().call("emrt_memcpy", ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), dst.numel() * dst.element_size(), ctx().stream)
+
     # -- public ------------------------------------------------------------------------------------
     def step(self, images, labels):
         """images fp32 [B,3,H,W], labels int64 [B,H,W] on the device.  Returns the device loss tensor (float[1])."""
@@ -223,8 +232,8 @@ class TrainEngine:
             if self.graph_a is None:
                 self._capture(images, labels)
             if images.data_ptr() != self.images.data_ptr():
-                self.images.copy_(images, non_blocking=True)
-                self.labels.copy_(labels, non_blocking=True)
+                self._stage(self.images, images)
+                self._stage(self.labels, labels)
             if self.model.store.dirty:     # master weights edited since the last step (load_state_dict after the capture): refresh the
                 self.model.store.pack()    # compute-dtype mirror eagerly -- inside the graph only the optimizer's own update writes it
             self.graph_a.replay()

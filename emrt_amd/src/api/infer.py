@@ -5,9 +5,11 @@ logit accumulation / count normalisation / argmax follow the reference exactly a
 bilinear resize of the logits when the network output size differs from `ori_shape` (infer.py:146-150; never the case for
 the EMRT configs, whose tiles are evaluated at their own size).
 """
+import ctypes
+
 import torch
 
-from ... import functional as Fn
+from ... import _lib, functional as Fn
 from ...runtime import ctx
 
 
@@ -186,7 +188,9 @@ class SlidingWindowEngine:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):      # (reader threads of a validation loader may make HIP calls meanwhile)
                 self.logits, self.pred = self._run(self.image)
         if img.data_ptr() != self.image.data_ptr():
-            self.image.copy_(img, non_blocking=True)
+            src = img.contiguous()
+            assert src.dtype == self.image.dtype and src.numel() == self.image.numel()
+            _lib.lib().call("emrt_memcpy", ctypes.c_void_p(self.image.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * src.element_size(), ctx().stream)
         if self.model.store.dirty:       # weights edited after the capture (load_state_dict of the next checkpoint): the replayed
             self.model.store.pack()      # kernels read the compute-dtype mirror, which only EMRT.__call__ -- not replay() -- refreshes
         self.graph.replay()

@@ -163,6 +163,7 @@ def test_msda_scatter_merging_consecutive_points_gives_the_same_value_gradient(o
     vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
     dy = dev(rnd(torch.randn(B, Lq, M * 32, generator=torch.Generator().manual_seed(36))))
     res = {}
+    old_mf = L_.set_tuning("msda_scatter_mfma", 0)          # the knob under test belongs to the LDS atomic scatter (bf16 at this shape defaults to the matrix-product kernel)
     for knob in (0, 1, 1):
         old = L_.set_tuning("msda_scatter_merge", knob)
         try:
@@ -175,6 +176,7 @@ def test_msda_scatter_merging_consecutive_points_gives_the_same_value_gradient(o
             res.setdefault(knob, []).append(host(dv))
         finally:
             L_.set_tuning("msda_scatter_merge", old)
+    L_.set_tuning("msda_scatter_mfma", old_mf)
     assert torch.equal(res[1][0], res[1][1]), "the merged scatter is not bit-reproducible"
     a, b = res[0][0], res[1][0]
     rel = ((a - b).norm() / a.norm()).item()
@@ -182,6 +184,38 @@ def test_msda_scatter_merging_consecutive_points_gives_the_same_value_gradient(o
     print("msda scatter merge (%s offsets): value gradient rel L2 %.2e vs unmerged, %.4f %% of the elements differ" % (offsets, rel, 100 * differ))
     assert rel < 2e-4 and differ < 0.01, (rel, differ)          # a bf16 element flips only where the fixed-point sums differ by a unit right at a rounding boundary
 
+
+@pytest.mark.parametrize("cfg", MSDA_BENCH[:2], ids=[c["name"] for c in MSDA_BENCH[:2]])
+def test_msda_value_gradient_as_a_matrix_product_vs_the_atomic_scatter(cfg):
+    """msda_bwd_value_mfma_kernel (knob msda_scatter_mfma) against msda_bwd_value_lds_kernel on the same inputs at the bench shapes: both are
+    within the oracle bound of test_msda_bench_shapes_vs_oracle by that test and the fuzz; HERE they are compared with each other -- the atomic
+    scatter is exact to 2^-30 of Lq max|g| per addend, the matrix product rounds each summed (pixel, query) weight once to bf16 (2^-9 relative,
+    independent errors over the ~100 queries that reach a pixel) -- and the matrix product must be bit-reproducible (integer LDS adds, MFMA)."""
+    c = init(BF16)
+    L_ = _lib.lib()
+    value, offw, ref, shapes, (B, Lq, Lv, M, L, Pn) = _msda_inputs(cfg, 41)
+    vd, od, rd = dev(value), dev(offw, torch.float32), dev(ref, torch.float32)
+    dy = dev(rnd(torch.randn(B, Lq, M * 32, generator=torch.Generator().manual_seed(42))))
+    res = {}
+    for knob in (0, 2, 2):
+        old = L_.set_tuning("msda_scatter_mfma", knob)
+        try:
+            tape = Tape()
+            c.tape = tape
+            y = Fn.msda(vd, od, rd, shapes, M, Pn)
+            c.tape = None
+            tape.watch(vd)
+            dv, = run_bwd(tape, [(y, dy)], [vd])
+            res.setdefault(knob, []).append(host(dv))
+        finally:
+            L_.set_tuning("msda_scatter_mfma", old)
+    assert torch.equal(res[2][0], res[2][1]), "the matrix-product scatter is not bit-reproducible"
+    a, b = res[0][0], res[2][0]
+    rel = ((a - b).norm() / a.norm()).item()
+    worst = ((a - b).abs().max() / a.abs().max()).item()
+    print("msda value gradient %s: matrix product vs atomic scatter rel L2 %.2e, worst element %.2e of max|dvalue|" % (cfg["name"], rel, worst))
+    assert rel > 0.0, "both knob settings ran the same kernel"
+    assert rel < 3e-3 and worst < 1e-2, (rel, worst)
 
 
 # -----------------------------------------------------------------------------------------------------------------

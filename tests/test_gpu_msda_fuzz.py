@@ -67,6 +67,22 @@ def test_msda_random_pyramid_vs_oracle(cfg):
     dv, do = run_bwd(tape, [(y, dev(dy))], [vd, od])
     gv, go = vr.grad, orq.grad
     rel_v = ((host(dv) - gv).norm() / (gv.norm().item() or 1.0)).item()
+    if dt == BF16:      # the other value-gradient kernel too: matrix product forced wherever its plan exists / never (csrc/msda.hip: knob msda_scatter_mfma)
+        from emrt_amd import _lib
+        for knob in (2, 0):
+            old = _lib.lib().set_tuning("msda_scatter_mfma", knob)
+            try:
+                tape2 = Tape()
+                c.tape = tape2
+                y2 = Fn.msda(vd, od, rd, shapes, M, Pn)
+                c.tape = None
+                tape2.watch(vd)
+                dv2, = run_bwd(tape2, [(y2, dev(dy))], [vd])
+            finally:
+                _lib.lib().set_tuning("msda_scatter_mfma", old)
+            rel_k = ((host(dv2) - gv).norm() / (gv.norm().item() or 1.0)).item()
+            print("    msda_scatter_mfma = %d: dvalue rel %.2e" % (knob, rel_k))
+            rel_v = max(rel_v, rel_k)
     rel_o = ((host(do) - go).norm() / (go.norm().item() or 1.0)).item()
     print("%s %s B=%d Lq=%d sigma=%.1f %s: fwd rel %.2e, dvalue rel %.2e, doffw rel %.2e" % (
         cfg["name"], shapes, B, Lq, cfg["sigma"], "bf16" if dt == BF16 else "fp32", rel, rel_v, rel_o))

@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5; mkdir -p $O
+timeout 900 python3 -m pytest tests/test_gpu_msda_fuzz.py tests/test_gpu_kernels.py tests/test_gpu_bench_shapes.py -q -m gpu -k "msda or scatter or deform" -p no:xdist -x > $O/run15_msda.txt 2>&1; grep -E "passed|failed|^E  " $O/run15_msda.txt | tail -8
+for v in "A=1" "EMRT_MSDA_MF_BANDS=512" "EMRT_MSDA_MF_BANDS=256" "EMRT_MSDA_SCATTER_MFMA=0"; do
+  echo "[$v]"; env $v timeout 300 python3 tools/bench_msda.py cfg2 2>&1 | grep -v amdgpu.ids | head -1
+done
+for v in "A=1" "EMRT_MSDA_MF_BANDS=512" "EMRT_MSDA_SCATTER_MFMA=0"; do
+  echo "[$v] cfg3"; env $v timeout 300 python3 tools/bench_msda.py cfg3 2>&1 | grep -v amdgpu.ids | head -1
+done
+for v in "A=default" "EMRT_MSDA_SCATTER_MFMA=0"; do
+  env $v timeout 300 python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-other-configs > $O/run15_bench.json 2> $O/run15_bench.err
+  python3 -c "import json,sys; d=json.loads(open('$O/run15_bench.json').read().strip().splitlines()[-1]); print('[$v]', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['ms_per_step_max'], d['roofline']['frac'], d['final_loss'])"
+done
