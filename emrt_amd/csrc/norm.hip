@@ -1079,8 +1079,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
                                                      int C, int rows_per_block, T* __restrict__ dzb, float pdrop,
                                                      const unsigned long long* __restrict__ seed, unsigned salt,
-                                                     float* __restrict__ dgamma_direct, float* __restrict__ dbeta_direct) {
+                                                     float* __restrict__ dgamma_direct, float* __restrict__ dbeta_direct, const T* __restrict__ addend) {
   // dzb (optional): gradient of the dropped branch input, dz * mask / (1 - p)
+  // addend (optional, [rows][C]): another gradient contribution to the residual input, summed into dz here (dzb does not get it)
   const unsigned long long sd = (dzb && pdrop > 0.f) ? seed[0] : 0ull;
   const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
   extern __shared__ float sm[];  // [4 waves][2][C]
@@ -1148,7 +1149,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs[k] * (gd[k][j][e] - s0[k] - xh[k][j][e] * s1[k]);
-          Vec4<T>::store(dz + row[k] * C + c, o);
+          if (addend) {
+            float ad[4], oa[4];
+            Vec4<T>::load(addend + row[k] * C + c, ad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oa[e] = o[e] + ad[e];
+            Vec4<T>::store(dz + row[k] * C + c, oa);
+          } else {
+            Vec4<T>::store(dz + row[k] * C + c, o);
+          }
           if (dzb) {
             if (pdrop > 0.f) {
               uint32_t hq[2];
@@ -1515,10 +1524,11 @@ extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
 
 extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
                                   float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop,
-                                  const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
+                                  const unsigned long long* seed, unsigned salt, const void* dz_addend, int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(z && dy && dz && gamma && mean && rstd && workspace, "null pointer");
   EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && dz_branch)), "dropout needs 0 <= p < 1, a device seed and dz_branch");
+  EMRT_REQUIRE(!dz_addend || dz_addend != dz, "dz_addend must not alias dz");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
   long long blocks = ln_bwd_blocks(rows);
   int rpb = (int)((rows + blocks - 1) / blocks);
@@ -1530,7 +1540,7 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   const bool direct = (dgamma || dbeta) && g_tune.ln_atomic != 0;       // developer knob: 0 = partials + finalize launch
   const size_t lds = (size_t)8 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr)
+#define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend)
   if (small) DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 4, 1), LN_BWD_LAUNCH(bf16_t, 4, 1));
   else DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 2, 4), LN_BWD_LAUNCH(bf16_t, 2, 4));
 #undef LN_BWD_LAUNCH

@@ -890,7 +890,10 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             _L().call("emrt_conv2d_bwd_group", bd, L, c.dtype, c.stream)
             if slot is None:
                 tape.add_grad(src, dx, owned=True)
-            tape.add_grad(src, dout)              # the residual path of every level: one add over the whole token tensor
+            if id(out) in tape.identity_done:     # a later consumer of src (the encoder layer's norm1, layer_norm(identity_from=out)) has already summed it in
+                tape.identity_done.discard(id(out))
+            else:
+                tape.add_grad(src, dout)          # the residual path of every level: one add over the whole token tensor
         tape.record(bwd)
     return out
 
@@ -1034,10 +1037,13 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
     return src, spans
 
 
-def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0, drop_salt=0):
+def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0, drop_salt=0, identity_from=None):
     """out = LN(a + dropout(b)) * gamma + beta (+ post);  a, b, post contiguous [.., C].  The inverted dropout on the branch
     input b (every residual LayerNorm of the transformer has one in front: t_e_d.py:199,202,287,291,294) runs inside the
-    LayerNorm kernels: the forward drops b on the fly, the backward emits dz for a and the masked dz for b."""
+    LayerNorm kernels: the forward drops b on the fly, the backward emits dz for a and the masked dz for b.
+    identity_from: a tensor t computed EARLIER from `a` with an identity path (t = f(a) + a: level_conv_gn's output) whose consumers all ran
+    AFTER this call, so that t's gradient is complete when this backward runs: the identity's contribution d a += d t is then summed by this
+    kernel (dz_addend) and t's producer is told not to add it again (Tape.identity_done) -- one accumulate launch per encoder layer less."""
     c = ctx()
     assert a.is_contiguous() and (b is None or b.is_contiguous()) and (post is None or post.is_contiguous())
     C = a.shape[-1]
@@ -1062,9 +1068,16 @@ def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0
             dz = c.empty(tuple(a.shape))
             dzb = c.empty(tuple(a.shape)) if (b is not None and p > 0) else None
             ws = c.workspace(_L().query("emrt_layernorm_bwd_workspace_bytes", rows, C))
+            extra = tape.peek_grad(identity_from) if identity_from is not None else None
+            if extra is not None and (not extra.is_contiguous() or tuple(extra.shape) != tuple(a.shape) or extra.dtype != dz.dtype or (b is not None and dzb is None)):
+                extra = None                      # (without branch dropout a and b share dz: the addend must not reach b)
             _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), P(dzb), p,
-                      c.seed_ptr if p > 0 else None, drop_salt, c.dtype, c.stream)
-            tape.add_grad(a, dz)
+                      c.seed_ptr if p > 0 else None, drop_salt, P(extra), c.dtype, c.stream)
+            if extra is not None:
+                tape.identity_done.add(id(identity_from))
+            # dz is a's alone when the branch got its own (masked) gradient: handed over, so that the next contribution to a -- the data gradient of
+            # the GEMM that read a -- accumulates into it in its epilogue instead of through an add launch
+            tape.add_grad(a, dz, owned=(b is None or dzb is not None))
             if b is not None:
                 if dzb is not None:
                     tape.add_grad(b, dzb, owned=True)

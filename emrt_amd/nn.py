@@ -331,10 +331,10 @@ class LayerNorm(HipLayer):
         self.weight = tnn.Parameter(torch.ones(c))
         self.bias = tnn.Parameter(torch.zeros(c))
 
-    def forward(self, a, b=None, post=None, drop_p=0.0, drop_salt=0):
+    def forward(self, a, b=None, post=None, drop_p=0.0, drop_salt=0, identity_from=None):
         """LN(a + dropout(b)) (+ post): the dropout of the residual branch runs inside the LayerNorm kernels."""
         return Fn.layer_norm(a, b, self.weight.data, self.bias.data, self.weight.grad, self.bias.grad, post=post, drop_p=drop_p,
-                             drop_salt=drop_salt)
+                             drop_salt=drop_salt, identity_from=identity_from)
 
 
 class Embedding(HipLayer):

@@ -36,6 +36,8 @@ class Tape:
         self.splits = []    # len(ops) at the model's gradient-exchange marks, in forward order (engine.py: backward runs in
                             # segments between them, newest first, and exchanges the gradients each segment completes)
         self.wgrads = []    # weight-gradient problems whose launch is deferred (functional.defer_wgrad): (descriptor fields, tensors kept alive)
+        self.identity_done = set()   # id(t) of tensors t = f(a) + a whose identity contribution d a += d t a later consumer of a has already summed in
+                                     # (functional.layer_norm(identity_from=t)): t's producer skips it in its backward
 
     @property
     def split(self):
@@ -75,6 +77,13 @@ class Tape:
         e = self.grads.pop(id(t), None)
         if with_count:
             return (None, 0) if e is None else (e[0], e[2])
+        return None if e is None else e[0]
+
+    def peek_grad(self, t):
+        """The gradient accumulated for t so far, left in place (None if none, or if t is a view)."""
+        if id(t) in self.alias:
+            return None
+        e = self.grads.get(id(t))
         return None if e is None else e[0]
 
     def _own(self, t):
@@ -191,6 +200,7 @@ class Tape:
         self.grads = {}
         self.keep = []
         self.alias = {}
+        self.identity_done = set()
 
 
 class Context:

@@ -331,7 +331,9 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
             src_flatten = Fn.level_conv_gn(src, [seq[0].gw for seq in seqs],
                                            [(seq[1].weight.data, seq[1].bias.data, seq[1].weight.grad, seq[1].bias.grad) for seq in seqs],
                                            spatial_shapes, level_spans)
+            identity = src_flatten          # = branch(src) + src, consumed only by norm2 below: norm1's backward sums its gradient into d src
         else:
+            identity = None
             src_flatten = ctx().empty((B, Lv, C))
             for (h, w), (s0, n), seq in zip(spatial_shapes, level_spans, seqs):
                 x_l = Fn.tokens_as_map(Fn.narrow(src, 1, s0, n), h, w)
@@ -339,7 +341,7 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
                 seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
         q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
         src2 = self.self_attn(q, reference_points, src, spatial_shapes)
-        src = self.norm1(src, src2, drop_p=self.p, drop_salt=self.salts[0])       # LN(src + dropout1(src2)), dropout inside the LN kernels
+        src = self.norm1(src, src2, drop_p=self.p, drop_salt=self.salts[0], identity_from=identity)       # LN(src + dropout1(src2)), dropout inside the LN kernels
         h1 = self.linear1(src, relu=True, drop=(self.p, self.salts[1]))     # dropout(relu(linear1)) in one launch; both masks are applied by linear2's dgrad
         ff = self.linear2(h1)
         return self.norm2(src, ff, post=src_flatten, drop_p=self.p, drop_salt=self.salts[2])    # LN(src + dropout(ffn)) + conv-branch tokens (:202-203)

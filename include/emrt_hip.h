@@ -166,7 +166,10 @@ int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void
  * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward. */
 int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma, const float* beta, float* mean, float* rstd, long long rows, int C, float eps, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
 size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C);
-int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
+/* dz_addend (ABI 7, nullable, [rows][C], must not alias dz): a gradient contribution to the residual input that is already known -- the encoder layer's
+ * conv-branch tokens reach the layer input through an identity as well (transformer_encoder_decoder.py:202-203) -- summed into dz here instead of by an add launch;
+ * dz_branch does not receive it. */
+int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop, const unsigned long long* seed, unsigned salt, const void* dz_addend, int dtype, void* stream);
 
 /* ---- multi-scale deformable attention core (fused softmax + sampling locations + bilinear gather + weighted sum)
  * replaces transformer_encoder_decoder.py:89-104 and EMRT_utils/utils.py:64-97 (deformable_attention_core_func).

@@ -492,6 +492,53 @@ def test_layer_norm_with_fused_branch_dropout(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_layer_norm_backward_sums_an_identity_contribution(dtype, p):
+    """The encoder layer's shape (transformer_encoder_decoder.py:184-204): t = f(a) + a is computed first, LN1(a + dropout(b)) second, and t is consumed
+    AFTER it (as norm2's `post`).  layer_norm(identity_from=t) lets LN1's backward kernel add d t into d a (dz_addend) and t's producer skip its own
+    accumulate: same d a as the two-launch form (one rounding fewer in bf16), d b untouched by the addend, and the accumulate launch is gone."""
+    from emrt_amd import _lib
+    c = init(dtype)
+    c.training = True
+    g = torch.Generator().manual_seed(9)
+    B, L, C = 2, 77, 256
+    a, b, w = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(3))
+    dy1, dyt = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(2))
+    res, calls = {}, {}
+    for mode in ("fused", "plain"):
+        ln = hnn.LayerNorm(C)
+        with torch.no_grad():
+            ln.weight.copy_(torch.linspace(0.5, 1.5, C))
+            ln.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        Holder(ln=ln).place()
+        ad, bd, wd = dev(a), dev(b), dev(w)
+        tape = Tape()
+        c.tape = tape
+        t = Fn.add_maps(ad, wd)                      # stands for level_conv_gn: an earlier consumer of a with an identity path
+
+        def t_bwd(t=t, ad=ad, tape=tape):            # its producer's backward, written like level_conv_gn's: skip the identity when a later consumer summed it
+            dt = tape.pop_grad(t)
+            if id(t) in tape.identity_done:
+                tape.identity_done.discard(id(t))
+            else:
+                tape.add_grad(ad, dt)
+        tape.ops[-1] = t_bwd                         # (replaces add_maps' own backward)
+        y = ln(ad, bd, drop_p=p, drop_salt=5, identity_from=t if mode == "fused" else None)
+        c.tape = None
+        tape.watch(ad)
+        tape.watch(bd)
+        _lib.lib().start_record()
+        da, db = run_bwd(tape, [(t, dev(dyt)), (y, dev(dy1))], [ad, bd])
+        calls[mode] = [n for n, _ in _lib.lib().stop_record()]
+        res[mode] = [host(da), host(db)]
+    # (without branch dropout a and b share ONE gradient tensor, so the addend cannot be folded in: nothing changes then)
+    assert calls["plain"].count("emrt_acc3d") + calls["plain"].count("emrt_add3d") == calls["fused"].count("emrt_acc3d") + calls["fused"].count("emrt_add3d") + (1 if p > 0 else 0), calls
+    tol = 2e-2 if dtype == BF16 else 1e-6            # bf16: d a is rounded once (fused) instead of twice
+    assert (res["fused"][0] - res["plain"][0]).abs().max().item() <= tol * max(1.0, res["plain"][0].abs().max().item())
+    assert torch.equal(res["fused"][1], res["plain"][1]), "the branch gradient must not see the addend"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("dims", [(2, 57, 256, 1024), (3, 110, 64, 96)])
 def test_ffn_dropout_relu_masks_fused_into_linear2_dgrad(dtype, dims):
     """linear2(dropout(relu(linear1(x)))) with sole_consumer_is_linear=True: linear2's dgrad applies both masks (one test
