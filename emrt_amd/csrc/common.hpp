@@ -59,6 +59,7 @@ struct Tuning {
   int bn_operand_blocks; // kernels that apply BatchNorm to their input operand (bn_operand.hpp): most blocks per launch (0 = 1024; the classifier kernel 512)
   int ln_bwd_rows;      // LayerNorm backward: rows per block (0 = 32) and most blocks (0 = 512): every block ends with 2C fp32 atomics
   int ln_bwd_max_blocks;
+  int ln_bwd_threads;   // LayerNorm backward at C <= 256: 512 (default: 64 rows per block, <= 256 blocks) or 256 threads per block (32 rows, <= 512 blocks)
   int ln_atomic;        // 1 = LayerNorm / column-sum parameter gradients as atomics, 0 = partials + finalize launch
   int gn_group_blocks;  // 1 = multi-level GroupNorm with one block per (image, group) instead of the row-major stats + apply pair
   int gn_stat_rows;     // row-major GroupNorm: token rows per block of the forward statistics launch (32)

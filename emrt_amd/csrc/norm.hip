@@ -1073,8 +1073,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
 
 // LN backward: dz = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  per-block partial dgamma/dbeta
 // -> partial[blk][2][C]; combined by bn_sum_partials_kernel + bn_bwd_finalize_kernel.
-template <class T, int R, int NQ>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
+template <class T, int R, int NQ, int TPB = 256>
+__global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
                                                      int C, int rows_per_block, T* __restrict__ dzb, float pdrop,
@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
   // addend (optional, [rows][C]): another gradient contribution to the residual input, summed into dz here (dzb does not get it)
   const unsigned long long sd = (dzb && pdrop > 0.f) ? seed[0] : 0ull;
   const float ks = pdrop > 0.f ? 1.f / (1.f - pdrop) : 1.f;
-  extern __shared__ float sm[];  // [4 waves][2][C]
+  extern __shared__ float sm[];  // [NWV waves][2][C]
+  constexpr int NWV = TPB / 64;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nq = C / 256 + ((C % 256) ? 1 : 0);       // <= NQ
   float dg[NQ][4], db[NQ][4];
@@ -1097,15 +1098,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
   if (r1 > rows) r1 = rows;
   // R rows per wave and iteration (rows wv, wv + 4, ...): the kernel is bound by the latency of the per-row load -> wave reduction
   // -> store chain; R independent chains in one basic block let the scheduler overlap them (R = 4 for C <= 256, the EMRT case)
-  for (long long row0 = r0 + wv; row0 < r1; row0 += 4 * R) {
+  for (long long row0 = r0 + wv; row0 < r1; row0 += NWV * R) {
     long long row[R];
     bool ok[R];
     float mu[R], rs[R], s0[R], s1[R];
     float xh[R][NQ][4], gd[R][NQ][4];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      ok[k] = row0 + 4 * k < r1;
-      row[k] = ok[k] ? row0 + 4 * k : row0;
+      ok[k] = row0 + NWV * k < r1;
+      row[k] = ok[k] ? row0 + NWV * k : row0;
       mu[k] = mean[row[k]]; rs[k] = rstd[row[k]];
       s0[k] = 0.f; s1[k] = 0.f;
     }
@@ -1182,9 +1183,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ z, co
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += TPB) {
     float b0 = 0.f, g0 = 0.f;
-    for (int w = 0; w < 4; ++w) { b0 += sm[(w * 2 + 0) * C + c]; g0 += sm[(w * 2 + 1) * C + c]; }
+    for (int w = 0; w < NWV; ++w) { b0 += sm[(w * 2 + 0) * C + c]; g0 += sm[(w * 2 + 1) * C + c]; }
     if (dgamma_direct || dbeta_direct) {
       // <= 512 blocks x 2C fp32 atomics straight into the parameter gradients: they drain while other blocks still run,
       // and the separate finalize launch (a kernel boundary, ~9 us for a few hundred KB) disappears
@@ -1509,9 +1510,13 @@ extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post
 }
 
 // blocks of the LayerNorm backward: ~32 rows (8 per wave) each, at most 512 partial-sum rows for the finalize
-static inline long long ln_bwd_blocks(long long rows) {
-  const int per = g_tune.ln_bwd_rows > 0 ? g_tune.ln_bwd_rows : 32;
-  const int cap = g_tune.ln_bwd_max_blocks > 0 ? g_tune.ln_bwd_max_blocks : 512;
+static inline bool ln_bwd_wide(int C) { return C <= 256 && g_tune.ln_bwd_threads >= 512; }      // 8 waves per block, 32 rows per iteration
+static inline long long ln_bwd_blocks(long long rows, int C) {
+  // every block ends in 2C fp32 atomics on the SAME 2C addresses: few, long blocks (sweep at 10 752 rows x 256: 336 blocks of 256 threads 225 us over the
+  // step's 14 launches, 168 blocks of 512 threads 215 us, 672 blocks of 256 threads 270 us)
+  const bool wide = ln_bwd_wide(C);
+  const int per = g_tune.ln_bwd_rows > 0 ? g_tune.ln_bwd_rows : (wide ? 64 : 32);
+  const int cap = g_tune.ln_bwd_max_blocks > 0 ? g_tune.ln_bwd_max_blocks : (wide ? 256 : 512);
   long long blocks = (rows + per - 1) / per;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
@@ -1519,7 +1524,7 @@ static inline long long ln_bwd_blocks(long long rows) {
 }
 
 extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
-  return ((size_t)(ln_bwd_blocks(rows) + 1) * 2 * C + 2 * (size_t)C) * sizeof(float);
+  return ((size_t)(ln_bwd_blocks(rows, C) + 1) * 2 * C + 2 * (size_t)C) * sizeof(float);
 }
 
 extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
@@ -1530,20 +1535,24 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && dz_branch)), "dropout needs 0 <= p < 1, a device seed and dz_branch");
   EMRT_REQUIRE(!dz_addend || dz_addend != dz, "dz_addend must not alias dz");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
-  long long blocks = ln_bwd_blocks(rows);
+  long long blocks = ln_bwd_blocks(rows, C);
   int rpb = (int)((rows + blocks - 1) / blocks);
   const bool small = C <= 256;                        // four rows in flight per wave (16 per block and iteration), else two
-  const int step = small ? 16 : 8;
+  const bool wide = ln_bwd_wide(C);
+  const int step = wide ? 32 : small ? 16 : 8;
   rpb = (rpb + step - 1) / step * step;
   blocks = (rows + rpb - 1) / rpb;
   float* partial = (float*)workspace;
   const bool direct = (dgamma || dbeta) && g_tune.ln_atomic != 0;       // developer knob: 0 = partials + finalize launch
-  const size_t lds = (size_t)8 * C * sizeof(float);
+  const size_t lds = (size_t)(wide ? 16 : 8) * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+#define LN_BWD_LAUNCH_W(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 512>), dim3((unsigned)blocks), dim3(512), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend)
 #define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend)
-  if (small) DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 4, 1), LN_BWD_LAUNCH(bf16_t, 4, 1));
+  if (wide) DT_SWITCH(dtype, LN_BWD_LAUNCH_W(float, 4, 1), LN_BWD_LAUNCH_W(bf16_t, 4, 1));
+  else if (small) DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 4, 1), LN_BWD_LAUNCH(bf16_t, 4, 1));
   else DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 2, 4), LN_BWD_LAUNCH(bf16_t, 2, 4));
 #undef LN_BWD_LAUNCH
+#undef LN_BWD_LAUNCH_W
   if (!direct) hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }
