@@ -293,8 +293,9 @@ def rooflines(calls, dtype_name, cfg_key, train):
                 "kernel": "emrt_msda_bwd: gradient kernel + value-gradient scatter (+ finalize), encoder call", "bound": "hbm",
                 "achieved": round(byb / avg_b / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(byb / avg_b / 1e6 / PEAK_HBM_GBPS, 4),
                 "traffic": None, "algorithmic_mbytes_per_call": round(byb / 1e6, 2), "avg_call_us": round(1e3 * avg_b, 2),
-                "note": "two or three launches per call, each event-timed (event_timed_trivial_launch_us each); the scatter is bound by LDS atomics "
-                        "(7 cycles per wave instruction), not by HBM: DESIGN.md 5"}
+                "note": "two or three launches per call, each event-timed (event_timed_trivial_launch_us each); the value gradient is a matrix product at "
+                        "cfg2 (msda_bwd_value_mfma_kernel: bound by the per-sample geometry on the VALU) and the LDS atomic scatter at cfg3 (7 cycles per "
+                        "wave instruction); neither is bound by HBM: DESIGN.md 5.000"}
         if pmc is not None and "msda_fwd_kernel_encoder" in pmc:
             m = pmc["msda_fwd_kernel_encoder"]
             roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)

@@ -1329,6 +1329,87 @@ def test_sgd_momentum_matches_reference_optimizer():
     assert int(c.step_counter.item()) == 3
 
 
+def test_optimizer_pass_non_temporal_arm_is_bit_identical():
+    """Knob sgd_nt (csrc/loss_optim.hip): the non-temporal loads / stores of the fp32 streams change caching, not arithmetic -- master weights, velocity
+    and the bf16 mirror after two steps are bit-identical with the knob on and off (odd length: the scalar tail runs too)."""
+    import ctypes
+    from emrt_amd import _lib
+    init(BF16)
+    L_ = _lib.lib()
+    n = 4 * 70001 + 3
+    g = torch.Generator().manual_seed(31)
+    p0, v0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    grads = [torch.randn(n, generator=g) for _ in range(2)]
+    res = {}
+    for knob in (1, 0):
+        old = L_.set_tuning("sgd_nt", knob)
+        try:
+            p, v = p0.cuda(), v0.cuda()
+            mirror = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+            step = torch.zeros(1, dtype=torch.int64, device="cuda")
+            ranges = (ctypes.c_longlong * 2)(1000, 5003)
+            for gr in grads:
+                gd = gr.cuda()
+                L_.call("emrt_sgd_momentum_step", ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(gd.data_ptr()), ctypes.c_void_p(v.data_ptr()), n, None,
+                        ctypes.c_void_p(step.data_ptr()), 0.01, 0.0, 0.9, 100, 0.9, 1e-4, ranges, 1, 0.1, None, ctypes.c_void_p(mirror.data_ptr()), 1,
+                        ctx().stream)
+            torch.cuda.synchronize()
+            res[knob] = (p.cpu(), v.cpu(), mirror.float().cpu())
+        finally:
+            L_.set_tuning("sgd_nt", old)
+    for a, b, name in zip(res[1], res[0], ("master", "velocity", "mirror")):
+        assert torch.equal(a, b), name
+    assert not torch.equal(res[1][0], p0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layer_norm_backward_block_shapes_agree(dtype):
+    """Knob ln_bwd_threads (csrc/norm.hip): 512-thread blocks of 64 rows (default) against 256-thread blocks of 32 rows -- dz / dz_branch per row do not
+    depend on the block shape (bit-identical); dgamma / dbeta are sums of per-block partials added with fp32 atomics (order differs: tolerance)."""
+    from emrt_amd import _lib
+    c = init(dtype)
+    c.training = True
+    g = torch.Generator().manual_seed(33)
+    B, L, C = 3, 211, 256
+    a, b, dy = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(3))
+    res = {}
+    for thr in (512, 256):
+        old = _lib.lib().set_tuning("ln_bwd_threads", thr)
+        try:
+            ln = hnn.LayerNorm(C)
+            with torch.no_grad():
+                ln.weight.copy_(torch.linspace(0.5, 1.5, C))
+            Holder(ln=ln).place()
+            ad, bd = dev(a), dev(b)
+            tape = Tape()
+            c.tape = tape
+            y = ln(ad, bd, drop_p=0.2, drop_salt=3)
+            c.tape = None
+            tape.watch(ad)
+            tape.watch(bd)
+            da, db = run_bwd(tape, [(y, dev(dy))], [ad, bd])
+            res[thr] = [host(da), host(db), host(ln.weight.grad), host(ln.bias.grad)]
+        finally:
+            _lib.lib().set_tuning("ln_bwd_threads", old)
+    assert torch.equal(res[512][0], res[256][0]) and torch.equal(res[512][1], res[256][1])
+    for i in (2, 3):
+        assert (res[512][i] - res[256][i]).abs().max().item() <= 1e-4 * max(1.0, res[256][i].abs().max().item())
+
+
+def test_memcpy_entry_point_stages_a_batch():
+    """emrt_memcpy (engine.TrainEngine._stage, infer.SlidingWindowEngine): device -> device on the context's stream; zero bytes and dst == src are no-ops."""
+    import ctypes
+    from emrt_amd import _lib
+    init(F32)
+    src = torch.arange(100003, dtype=torch.int64, device="cuda")
+    dst = torch.zeros_like(src)
+    _lib.lib().call("emrt_memcpy", ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * 8, ctx().stream)
+    _lib.lib().call("emrt_memcpy", ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel() * 8, ctx().stream)
+    _lib.lib().call("emrt_memcpy", None, None, 0, ctx().stream)
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pack_weights_layouts(dtype):
     c = init(dtype)
