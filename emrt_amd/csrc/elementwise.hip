@@ -126,6 +126,25 @@ __global__ __launch_bounds__(256) void add_f32row_kernel(const T* __restrict__ a
   }
 }
 
+// out[r][:] = a[r][:] + rows[level of r][:]: rows [L][C] fp32, level l = token rows [start[l], start[l + 1]) (the encoder's pos = sine + level_embed[l],
+// transformer_encoder_decoder.py:447-448: one launch for all levels)
+struct LevelStarts { int start[5]; int L; };
+template <class T>
+__global__ __launch_bounds__(256) void add_f32row_levels_kernel(const T* __restrict__ a, const float* __restrict__ rows, T* __restrict__ out,
+                                                                long long n4, int C4, LevelStarts ls) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C4), c4 = (int)(i - (long long)r * C4);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) l += (k < ls.L && r >= ls.start[k]) ? 1 : 0;
+    float x[4];
+    Vec4<T>::load(a + i * 4, x);
+    const float4 y = reinterpret_cast<const float4*>(rows)[(long long)l * C4 + c4];
+    x[0] += y.x; x[1] += y.y; x[2] += y.z; x[3] += y.w;
+    Vec4<T>::store(out + i * 4, x);
+  }
+}
+
 // dst[b][r][c] += src[b][r][c]: three-level strided views (batch stride, row stride, unit column stride) -- covers
 // dense tensors, token slabs of [B, Lv, C] and channel slices of the concat buffer (gradient accumulation into views)
 template <class T>
@@ -348,6 +367,25 @@ extern "C" int emrt_add_f32row(const void* a, const float* row, void* out, long 
   else if (dtype == EMRT_BF16) hipLaunchKernelGGL((add_f32row_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const bf16_t*)a, row, (bf16_t*)out, n / 4, period / 4);
   else hipLaunchKernelGGL((add_f32row_kernel<f16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const f16_t*)a, row, (f16_t*)out, n / 4, period / 4);
   return check_launch("emrt_add_f32row");
+}
+
+extern "C" int emrt_add_f32row_levels(const void* a, const float* rows, void* out, const int* level_start, int L, int Lv, int C, int dtype, void* stream) {
+  EMRT_REQUIRE_FWD_DTYPE(dtype);
+  EMRT_REQUIRE(a && rows && out && level_start, "null pointer");
+  EMRT_REQUIRE(L >= 1 && L <= 4 && C % 4 == 0 && C > 0 && Lv > 0, "1..4 levels, C a multiple of 4");
+  LevelStarts ls;
+  for (int l = 0; l < 5; ++l) ls.start[l] = Lv;
+  ls.L = L;
+  for (int l = 0; l < L; ++l) {
+    EMRT_REQUIRE(level_start[l] >= 0 && level_start[l] < Lv && (l == 0 ? level_start[0] == 0 : level_start[l] > level_start[l - 1]), "level_start must start at 0 and increase");
+    ls.start[l] = level_start[l];
+  }
+  const long long n4 = (long long)Lv * C / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMRT_F32) hipLaunchKernelGGL((add_f32row_levels_kernel<float>), dim3(ew_grid(n4)), dim3(256), 0, st, (const float*)a, rows, (float*)out, n4, C / 4, ls);
+  else if (dtype == EMRT_BF16) hipLaunchKernelGGL((add_f32row_levels_kernel<bf16_t>), dim3(ew_grid(n4)), dim3(256), 0, st, (const bf16_t*)a, rows, (bf16_t*)out, n4, C / 4, ls);
+  else hipLaunchKernelGGL((add_f32row_levels_kernel<f16_t>), dim3(ew_grid(n4)), dim3(256), 0, st, (const f16_t*)a, rows, (f16_t*)out, n4, C / 4, ls);
+  return check_launch("emrt_add_f32row_levels");
 }
 
 extern "C" int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode,

@@ -233,8 +233,8 @@ def cast_to_f32(x):
 
 def dropout(x, p, salt, mode=0, hw=1, sole_consumer_is_linear=False):
     """Inverted dropout (mode 0) / Dropout2D on NHWC (mode 1); identity unless training.
-    sole_consumer_is_linear: the caller promises that x is a fresh conv2d/linear(relu=True) output and that the result
-    feeds exactly one conv2d/linear (the FFN: linear2(dropout(relu(linear1(.))))).  That consumer's data gradient then
+    sole_consumer_is_linear: the caller promises that x is a fresh conv2d/linear(relu=True) or batch_norm(relu=True) output (x >= 0) and that the result
+    feeds exactly one conv2d/linear (the FFN: linear2(dropout(relu(linear1(.)))); the Dropout2D in front of the two heads' classifier convs).  That consumer's data gradient then
     comes out already multiplied by this dropout's mask and the ReLU's (one test `y > 0`, scale 1/(1-p), in its dgrad
     epilogue), and neither this op nor the producer's ReLU runs a mask pass of its own."""
     c = ctx()
@@ -246,7 +246,7 @@ def dropout(x, p, salt, mode=0, hw=1, sole_consumer_is_linear=False):
     _L().call("emrt_dropout_fwd", P(x), P(y), x.numel(), float(p), c.seed_ptr, salt, mode, hw, C, c.dtype, c.stream)
     tape = c.tape
     rec = None
-    if tape is not None and sole_consumer_is_linear and mode == 0:
+    if tape is not None and sole_consumer_is_linear:      # (element or channel mode alike: a stored value is positive iff it was kept and past the ReLU)
         rec = {"scale": 1.0 / (1.0 - float(p)), "dx": None}
         y._drop_rec = rec
     if tape is not None:

@@ -16,6 +16,7 @@ What is different from the reference by design (not by result):
     (the reference recomputes them and syncs to the host ~40 times per forward, SURVEY.md 3.2);
   * Linear weights are stored [out, in]; MHA in_proj_weight [3E, E] (Paddle: transposed) -- see INTEGRATION.md.
 """
+import ctypes
 import math
 
 import torch
@@ -204,7 +205,7 @@ class FCNHead(hnn.HipLayer):
         (EMRT.forward at N > 1: one all-reduce for the pyramid-pooling branches and this head)."""
         N, H, W, _ = x.shape
         o = features if features is not None else Fn.conv_bn(self.convs[0][0], self.convs[0][1], x, relu=True)
-        o = Fn.dropout(o, self.p, self.salt, mode=1, hw=H * W)
+        o = Fn.dropout(o, self.p, self.salt, mode=1, hw=H * W, sole_consumer_is_linear=True)       # conv_seg's data gradient applies the mask (y > 0, 1 / (1 - p))
         o = self.conv_seg(o)
         return Fn.resize_bilinear(o, H * self.up_ratio, W * self.up_ratio, False, out_nchw_f32=True)
 
@@ -282,8 +283,12 @@ class MultiHeadAttention(hnn.HipLayer):  # layers.py:144-311
         self.v_gemm = store.make_gemm(w + 2 * E * E, E, E, 1, 1, b + 2 * E)
 
     def forward(self, qk_in, v_in):  # :236-311 with query == key
-        qk = Fn.linear(qk_in, self.qk_gemm)
-        v = Fn.linear(v_in, self.v_gemm)
+        if ctx().group_attn_proj and qk_in.is_contiguous() and v_in.is_contiguous() and qk_in.dim() == 3:
+            # q | k projection of (tgt + query_pos) and v projection of tgt: two independent 110-row GEMMs, one launch each way
+            qk, v = Fn.linear_group([(qk_in, self.qk_gemm, False), (v_in, self.v_gemm, False)])
+        else:
+            qk = Fn.linear(qk_in, self.qk_gemm)
+            v = Fn.linear(v_in, self.v_gemm)
         out = Fn.mha(qk, v, self.num_heads, self.dropout, self.salt)
         return self.out_proj(out)
 
@@ -482,8 +487,12 @@ class EncoderDecoder(hnn.HipLayer):  # :337-473
         sine, ref_enc = self._constants(spatial_shapes)
         pos = c.empty((Lv, C))
         lvl = self.level_embed.weight
-        for l, (a, n) in enumerate(spans):                                       # pos = sine + level_embed[l]  (:447-448)
-            Fn._L().call("emrt_add_f32row", Fn.P(sine[a:a + n]), Fn.P(lvl.data[l]), Fn.P(pos[a:a + n]), n * C, C, c.dtype, c.stream)
+        if len(spans) <= 4 and lvl.data.is_contiguous():                         # pos = sine + level_embed[l]  (:447-448), all levels in one launch
+            starts = (ctypes.c_int * len(spans))(*[a for a, _ in spans])
+            Fn._L().call("emrt_add_f32row_levels", Fn.P(sine), Fn.P(lvl.data), Fn.P(pos), starts, len(spans), Lv, C, c.dtype, c.stream)
+        else:
+            for l, (a, n) in enumerate(spans):
+                Fn._L().call("emrt_add_f32row", Fn.P(sine[a:a + n]), Fn.P(lvl.data[l]), Fn.P(pos[a:a + n]), n * C, C, c.dtype, c.stream)
 
         # d level_embed[l] = sum over layers, batch and the level's tokens of the query gradients: the layers' gradients are
         # first summed (one add each) and reduced once, by the tape entry below, which runs after every layer's backward
@@ -792,7 +801,7 @@ class EMRT(hnn.HipLayer):  # :184-304
         Fn.pyramid_tokens_to_maps(hs, self.psp_scale, SH, SW, [Fn.narrow(psp_cat, 3, 256 * (1 + i), 256) for i in range(nps)])  # :281-291
         o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True)
         o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
-        o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW)
+        o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW, sole_consumer_is_linear=True)   # UpHead's conv_0 is its only consumer
         logits = self.uphead(o)
         if self.training or self.compute_aux_in_eval:
             aux = self.auxlayer(c3, features=aux_feat)      # x16 bilinear; the reference's final align_corners=True resize is the identity here

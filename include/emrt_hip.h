@@ -284,6 +284,9 @@ int emrt_add3d(const void* a, long long a_bs, long long a_rs, const void* b, lon
 int emrt_concat_tokens(void* const* parts, const int* n, int nparts, void* whole, int B, int C, int split, int dtype, void* stream);
 int emrt_acc3d(void* dst, long long dst_bs, long long dst_rs, const void* src, long long src_bs, long long src_rs, long long B, long long rows, long long cols, int dtype, void* stream);
 int emrt_add_f32row(const void* a, const float* row, void* out, long long n, long long period, int dtype, void* stream);
+/* out[r][:] = a[r][:] + rows[l][:] for the token rows r of level l (level_start: HOST array of L <= 4 increasing first rows, level_start[0] == 0; rows fp32 [L][C]):
+ * pos = sine + level_embed[l] over all levels of the pyramid in one launch (transformer_encoder_decoder.py:447-448) */
+int emrt_add_f32row_levels(const void* a, const float* rows, void* out, const int* level_start, int L, int Lv, int C, int dtype, void* stream);
 int emrt_dropout_fwd(const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned salt, int mode, long long hw, int C, int dtype, void* stream);
 /* dx = dy * dropmask(p, seed, salt) / (1 - p) * (relu_out > 0); either mask optional (p == 0 / relu_out == NULL).  ABI 7: p > 0 with seed == NULL and
  * relu_out given: relu_out is the stored output of emrt_conv2d_drop, whose sign carries BOTH masks: dx = relu_out > 0 ? dy / (1 - p) : 0. */

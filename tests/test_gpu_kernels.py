@@ -539,6 +539,52 @@ def test_layer_norm_backward_sums_an_identity_contribution(dtype, p):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k2", [1, 3])
+def test_channel_dropout_mask_fused_into_the_consumers_dgrad(dtype, k2):
+    """conv_k2(Dropout2D(relu(conv3x3(x)))) as in the two heads (fcn_head.py:62-66, paddle_EMRT.py:209-213: nn.Dropout2D in front of the classifier /
+    UpHead): with sole_consumer_is_linear=True the consumer's data gradient applies the channel mask (stored value > 0, scale 1 / (1 - p)) and no
+    emrt_mask_bwd runs for the dropout; must equal the composed form (same seed and salt => same mask) in outputs and every gradient."""
+    from emrt_amd import _lib
+    c = init(dtype)
+    c.training = True
+    p = 0.25
+    g = torch.Generator().manual_seed(79)
+    N, H, W, C, Cm, Co = 3, 12, 10, 32, 64, (8 if k2 == 1 else 32)
+    x = rnd(torch.randn(N, H, W, C, generator=g))
+    dy = rnd(torch.randn(N, H, W, Co, generator=g))
+    w1 = rnd(torch.randn(Cm, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    w2 = rnd(torch.randn(Co, Cm, k2, k2, generator=g) / math.sqrt(k2 * k2 * Cm))
+    res, names = {}, {}
+    for mode in ("fused", "composed"):
+        c1, c2 = hnn.Conv2D(C, Cm, 3, 1, 1, bias=False), hnn.Conv2D(Cm, Co, k2, 1, k2 // 2)
+        with torch.no_grad():
+            c1.weight.copy_(w1)
+            c2.weight.copy_(w2)
+            c2.bias.zero_()
+        Holder(c1=c1, c2=c2).place()
+        xd = dev(x)
+        tape = Tape()
+        c.tape = tape
+        h = Fn.conv2d(xd, c1.gw, 1, 1, relu=True)
+        hd = Fn.dropout(h, p, 29, mode=1, hw=H * W, sole_consumer_is_linear=(mode == "fused"))
+        o = c2(hd)
+        c.tape = None
+        tape.watch(xd)
+        L = _lib.lib()
+        L.start_record()
+        dx, = run_bwd(tape, [(o, dev(dy))], [xd])
+        names[mode] = [n for n, _ in L.stop_record()]
+        res[mode] = [host(t) for t in (o, dx, c1.weight.grad, c2.weight.grad, c2.bias.grad)] + [host(h), host(hd)]
+    assert names["fused"].count("emrt_mask_bwd") == 0 and names["composed"].count("emrt_mask_bwd") == 2, names      # (dropout mask + conv1's ReLU mask)
+    hh, hdd = res["fused"][5], res["fused"][6]
+    dropped = ((hdd == 0) & (hh > 0)).float().sum((1, 2))                  # per (image, channel): all of its positive pixels or none
+    positive = (hh > 0).float().sum((1, 2))
+    assert torch.all((dropped == 0) | (dropped == positive)) and 0.1 < (dropped > 0).float().mean() < 0.4
+    for u, v, name in zip(res["fused"][:5], res["composed"][:5], ("o", "dx", "dw1", "dw2", "db2")):
+        close("channel dropout fused vs composed " + name, u, v, dtype, max(1.0, v.abs().max().item()) * (0.01 if dtype == F32 else 1.0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("dims", [(2, 57, 256, 1024), (3, 110, 64, 96)])
 def test_ffn_dropout_relu_masks_fused_into_linear2_dgrad(dtype, dims):
     """linear2(dropout(relu(linear1(x)))) with sole_consumer_is_linear=True: linear2's dgrad applies both masks (one test
@@ -1395,6 +1441,30 @@ def test_layer_norm_backward_block_shapes_agree(dtype):
     assert torch.equal(res[512][0], res[256][0]) and torch.equal(res[512][1], res[256][1])
     for i in (2, 3):
         assert (res[512][i] - res[256][i]).abs().max().item() <= 1e-4 * max(1.0, res[256][i].abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_f32row_levels_equals_the_per_level_adds(dtype):
+    """emrt_add_f32row_levels (pos = sine + level_embed[l] for every level in one launch, transformer_encoder_decoder.py:447-448) against one emrt_add_f32row
+    per level: bit-identical (same arithmetic per element)."""
+    import ctypes
+    from emrt_amd import _lib
+    c = init(dtype)
+    g = torch.Generator().manual_seed(37)
+    spans, C = [(0, 35), (35, 12), (47, 5), (52, 1)], 64
+    Lv = 53
+    a = dev(rnd(torch.randn(Lv, C, generator=g)))
+    rows = torch.randn(len(spans), C, generator=g).cuda()
+    one, per = torch.empty_like(a), torch.empty_like(a)
+    L_ = _lib.lib()
+    starts = (ctypes.c_int * len(spans))(*[s0 for s0, _ in spans])
+    L_.call("emrt_add_f32row_levels", Fn.P(a), Fn.P(rows), Fn.P(one), starts, len(spans), Lv, C, c.dtype, c.stream)
+    for l, (s0, n) in enumerate(spans):
+        L_.call("emrt_add_f32row", Fn.P(a[s0:s0 + n]), Fn.P(rows[l]), Fn.P(per[s0:s0 + n]), n * C, C, c.dtype, c.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(one, per)
+    ref = host(a) + rows.cpu().repeat_interleave(torch.tensor([n for _, n in spans]), 0)
+    close("add rows levels", host(one), ref, dtype)
 
 
 def test_memcpy_entry_point_stages_a_batch():

@@ -62,10 +62,14 @@ def test_train_step_launch_sequence(fake, backbone):
     cnt = collections.Counter(n for n, _ in fake.calls)
     assert n_fwd > n_eval                                              # training adds dropout / statistics launches
     n_grouped = sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_bwd_group")     # problems inside grouped backward launches
-    # (4 encoder layers + input_proj) x 3 levels, + value_proj | offsets-logits projection of the 6 deformable attentions as pairs
-    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15 + 12
+    # (4 encoder layers + input_proj) x 3 levels, + value_proj | offsets-logits projection of the 6 deformable attentions as pairs,
+    # + the q|k and v projections of the decoder's 2 softmax attentions as pairs
+    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15 + 12 + 4
     pairs = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 2]
-    assert len(pairs) == 6 and all(a[0][0].out_f32 == 0 and a[0][1].out_f32 == 1 and a[0][1].OC == 432 for a in pairs)
+    msda_pairs = [a for a in pairs if a[0][1].out_f32 == 1]
+    mha_pairs = [a for a in pairs if a[0][1].out_f32 == 0]
+    assert len(msda_pairs) == 6 and all(a[0][0].out_f32 == 0 and a[0][1].OC == 432 for a in msda_pairs)
+    assert len(mha_pairs) == 2 and all(a[0][0].OC == 512 and a[0][1].OC == 256 and a[0][0].W == a[0][1].W == 110 for a in mha_pairs)
     # every GEMM weight gets exactly one weight gradient: immediately (the 1x1 classifiers' one-pass backward) or in a batched
     # emrt_conv2d_wgrad_group call made while backward runs; a layer whose weight gradient is batched passes dw = NULL to its data gradient
     batched = [a[0][i] for n, a in fake.calls if n == "emrt_conv2d_wgrad_group" for i in range(a[1])]
@@ -104,10 +108,12 @@ def test_train_step_launch_sequence(fake, backbone):
     # FFNs: linear2's dgrad applies the dropout mask and the ReLU mask of dropout(relu(linear1)) (mask source = its input,
     # scale 1/(1-p)); no separate mask pass is left for them
     n_ffn = sum(1 for mod in m.modules() if type(mod).__name__ in ("TransformerEncoderLayer", "TransformerDecoderLayer"))
+    # ... and the same for the Dropout2D in front of the aux head's classifier and of UpHead's first conv (two more dgrads with a scaled mask)
     ffn = [a for a in dgrads if a[25] is not None and a[24] is None]
-    assert len(ffn) == n_ffn > 0 and all(abs(a[28] - 1.0 / 0.9) < 1e-6 and a[25].value == a[0].value for a in ffn)
+    assert len(ffn) == n_ffn + 2 > 2 and all(abs(a[28] - 1.0 / 0.9) < 1e-6 and a[25].value == a[0].value for a in ffn)
     # ... and their forward dropout is drawn in linear1's epilogue (emrt_conv2d_drop): the separate dropout launches left are the two Dropout2D
-    assert cnt["emrt_conv2d_drop"] == n_ffn and cnt["emrt_mask_bwd"] == cnt["emrt_dropout_fwd"] == 2
+    # (forward only: their backward mask rides in the consumer's data gradient, above)
+    assert cnt["emrt_conv2d_drop"] == n_ffn and cnt["emrt_mask_bwd"] == 0 and cnt["emrt_dropout_fwd"] == 2
     # residual joins relu(BatchNorm(x) + residual): the dgrad of a conv that consumes the join folds the earlier
     # contributions in (addend a[32], or in place a[6]), masks with the join's output and sums against the BatchNorm INPUT
     # (stat_x a[29]); the join's backward then runs without its reduction pass (sums_vs_x a[21] of emrt_bn_bwd_dx)
