@@ -356,6 +356,26 @@ def check_world(args):
                          % (world, args.gpus, args.gpus, args.gpus))
 
 
+def _pause_gc(args):
+    """Host hygiene for the warm-up + timed region: collect now, then keep Python's collector off until the K steps are through (a generation-2
+    collection of this process's heap -- module trees, recorded launch lists of the configs run before -- is tens of ms of host time; at 12 ms per step
+    that would be one stalled step).  No device work is skipped.  Whether the single 33 / 54 ms step seen in two DEFAULT runs at cfg3 (round 4's driver line,
+    profiles/r5c first run: ms_per_step_max) was such a pause is not established: eight standalone cfg3 runs showed none with the collector on or off
+    (tools/r5/run26.sh).  `slowest_step` in the JSON line says which step it was when it happens again.  --keep-gc leaves the interpreter alone (A/B)."""
+    import gc
+    if getattr(args, "keep_gc", False) or not gc.isenabled():
+        return False
+    gc.collect()
+    gc.disable()
+    return True
+
+
+def _resume_gc(paused):
+    if paused:
+        import gc
+        gc.enable()
+
+
 def dry_run(args):
     """`bench.py --gpus N --dry-run` (also under a launcher): every rank checks its environment, joins a gloo group on the CPU, builds the
     model's parameter layout on the host and derives what the N > 1 step would exchange -- flat-gradient ranges of the three backward
@@ -480,6 +500,7 @@ def main():
     ap.add_argument("--two-phase-no-syncbn", action="store_true", help="--two-phase without the SyncBatchNorm collectives (A/B: what the graph cuts cost)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     ap.add_argument("--exchange-noop", action="store_true", help="A/B: the N > 1 step structure with the gradient all-reduce switched off (NOT a valid throughput)")
+    ap.add_argument("--keep-gc", action="store_true", help="A/B: leave Python's garbage collector enabled during the timed steps (default: collected before, paused during)")
     ap.add_argument("--dry-run", action="store_true", help="--gpus N without a GPU: start the N ranks, rendezvous over gloo, and check rank environment, "
                     "gradient-exchange ranges, SyncBatchNorm group membership and tile sharding; prints a JSON plan, launches no kernel")
     args = ap.parse_args()
@@ -516,7 +537,7 @@ def main():
         for key, steps, warm in (("cfg3", 30, 8), ("cfg5", 30, 8)):
             c2 = dict(CONFIGS[key])
             r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=1)
-            others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "value_at_median",
+            others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "slowest_step", "value_at_median",
                                                "dtype", "config", "end_to_end_tflops", "loss_check", "roofline", "roofline_msda", "cpu_baseline") if k in r2}
         result["other_configs"] = others
     if world > 1:
@@ -576,6 +597,7 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         if first_loss is None:
             first_loss = float(lt.item())
     torch.cuda.synchronize()
+    gc_paused = _pause_gc(args)          # (before the warm-up steps: the collection itself is host time during which the launch queue would drain)
     for _ in range(warmup):
         eng.step(images, labels)
 
@@ -595,6 +617,7 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    _resume_gc(gc_paused)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -659,6 +682,7 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
             "metric": "training tiles/sec at %dx%d" % (S, S), "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
             "ms_per_step_median": round(statistics.median(per_step_ms), 3), "ms_per_step_max": round(max(per_step_ms), 3),
+            "slowest_step": int(max(range(len(per_step_ms)), key=per_step_ms.__getitem__)),
             "value_at_median": round(world * B * 1e3 / statistics.median(per_step_ms), 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": cfg["name"].replace("batch %d" % CONFIGS[cfg_key]["batch"], "batch %d" % B) + ", " + dtype_name,
@@ -710,6 +734,7 @@ def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
     for _ in range(3):
         eng(img)
     torch.cuda.synchronize()
+    gc_paused = _pause_gc(args)
     for _ in range(warmup):
         eng(img)
 
@@ -727,6 +752,7 @@ def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    _resume_gc(gc_paused)
     per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -749,7 +775,8 @@ def run_infer(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
             "metric": "inference tiles/sec at %dx%d (sliding window over %dx%d images)" % (crop, crop, img_h, img_w),
             "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_step_median": round(statistics.median(per_step_ms), 3),
-            "ms_per_step_max": round(max(per_step_ms), 3), "value_at_median": round(world * nwin * 1e3 / statistics.median(per_step_ms), 2),
+            "ms_per_step_max": round(max(per_step_ms), 3), "slowest_step": int(max(range(len(per_step_ms)), key=per_step_ms.__getitem__)),
+            "value_at_median": round(world * nwin * 1e3 / statistics.median(per_step_ms), 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": cfg["name"].replace("1024x1024", "%dx%d" % (img_h, img_w)).replace("16 windows", "%d windows" % nwin) + ", " + dtype_name,

@@ -891,7 +891,8 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             if slot is None:
                 tape.add_grad(src, dx, owned=True)
             if id(out) in tape.identity_done:     # a later consumer of src (the encoder layer's norm1, layer_norm(identity_from=out)) has already summed it in
-                tape.identity_done.discard(id(out))
+                # ... and it summed THIS gradient: a contribution that arrived after it ran would have replaced the tensor (the promise of identity_from is broken)
+                assert tape.identity_done.pop(id(out)) is dout, "layer_norm(identity_from=t): t received another gradient contribution after that LayerNorm's backward"
             else:
                 tape.add_grad(src, dout)          # the residual path of every level: one add over the whole token tensor
         tape.record(bwd)
@@ -1074,7 +1075,7 @@ def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0
             _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), P(dzb), p,
                       c.seed_ptr if p > 0 else None, drop_salt, P(extra), c.dtype, c.stream)
             if extra is not None:
-                tape.identity_done.add(id(identity_from))
+                tape.identity_done[id(identity_from)] = extra
             # dz is a's alone when the branch got its own (masked) gradient: handed over, so that the next contribution to a -- the data gradient of
             # the GEMM that read a -- accumulates into it in its epilogue instead of through an add launch
             tape.add_grad(a, dz, owned=(b is None or dzb is not None))

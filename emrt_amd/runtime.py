@@ -36,7 +36,7 @@ class Tape:
         self.splits = []    # len(ops) at the model's gradient-exchange marks, in forward order (engine.py: backward runs in
                             # segments between them, newest first, and exchanges the gradients each segment completes)
         self.wgrads = []    # weight-gradient problems whose launch is deferred (functional.defer_wgrad): (descriptor fields, tensors kept alive)
-        self.identity_done = set()   # id(t) of tensors t = f(a) + a whose identity contribution d a += d t a later consumer of a has already summed in
+        self.identity_done = {}      # id(t) -> the gradient that was summed, for tensors t = f(a) + a whose identity contribution d a += d t a later consumer of a has already summed in
                                      # (functional.layer_norm(identity_from=t)): t's producer skips it in its backward
 
     @property
@@ -200,7 +200,7 @@ class Tape:
         self.grads = {}
         self.keep = []
         self.alias = {}
-        self.identity_done = set()
+        self.identity_done = {}
 
 
 class Context:

@@ -519,7 +519,7 @@ def test_layer_norm_backward_sums_an_identity_contribution(dtype, p):
         def t_bwd(t=t, ad=ad, tape=tape):            # its producer's backward, written like level_conv_gn's: skip the identity when a later consumer summed it
             dt = tape.pop_grad(t)
             if id(t) in tape.identity_done:
-                tape.identity_done.discard(id(t))
+                assert tape.identity_done.pop(id(t)) is dt
             else:
                 tape.add_grad(ad, dt)
         tape.ops[-1] = t_bwd                         # (replaces add_maps' own backward)
