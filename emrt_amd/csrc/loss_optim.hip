@@ -363,6 +363,41 @@ __global__ void counter_add_kernel(long long* c, long long d) {
   if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += d;
 }
 
+// Per-class areas of a prediction against its labels (reference: src/utils/metrics.py:20-59 calculate_area): intersect / prediction / label pixel counts with
+// ignore_index, accumulated into out[3][ncls] (int64).  Per-block LDS histograms, one global atomic per (block, class, kind).
+template <class LT>
+__global__ __launch_bounds__(256) void seg_areas_kernel(const int* __restrict__ pred, const LT* __restrict__ label, long long n, int ncls, int ignore,
+                                                        unsigned long long* __restrict__ out) {
+  __shared__ unsigned cnt[3 * 256];
+  for (int i = threadIdx.x; i < 3 * ncls; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long l = (long long)label[i];
+    if (l == ignore) continue;
+    const int p = pred[i];
+    const bool pv = p >= 0 && p < ncls, lv = l >= 0 && l < ncls;
+    if (pv) atomicAdd(&cnt[ncls + p], 1u);
+    if (lv) atomicAdd(&cnt[2 * ncls + (int)l], 1u);
+    if (pv && (long long)p == l) atomicAdd(&cnt[p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * ncls; i += blockDim.x)
+    if (cnt[i]) atomicAdd(&out[i], (unsigned long long)cnt[i]);
+}
+
+extern "C" int emrt_segmentation_areas(const int* pred, const void* label, int label_is_int64, long long n, int num_classes, int ignore_index,
+                                       long long* out, void* stream) {
+  EMRT_REQUIRE(pred && label && out, "null pointer");
+  EMRT_REQUIRE(num_classes >= 1 && num_classes <= 256 && n >= 0, "1..256 classes");
+  if (n == 0) return 0;
+  long long grid = (n + 256 * 16 - 1) / (256 * 16);
+  if (grid > 1024) grid = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (label_is_int64) hipLaunchKernelGGL((seg_areas_kernel<long long>), dim3((unsigned)grid), dim3(256), 0, st, pred, (const long long*)label, n, num_classes, ignore_index, (unsigned long long*)out);
+  else hipLaunchKernelGGL((seg_areas_kernel<int>), dim3((unsigned)grid), dim3(256), 0, st, pred, (const int*)label, n, num_classes, ignore_index, (unsigned long long*)out);
+  return check_launch("emrt_segmentation_areas");
+}
+
 extern "C" size_t emrt_gradnorm_workspace_bytes(void) { return 2048 * sizeof(float); }
 
 extern "C" int emrt_grad_clip_scale(const float* grads, long long n, float clip, float* state /*[2]*/, void* workspace, void* stream) {

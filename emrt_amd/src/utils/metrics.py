@@ -5,7 +5,18 @@ import torch
 
 
 def calculate_area(pred, label, num_classes, ignore_index=255):
-    """pred/label integer tensors of equal shape -> (intersect, pred_area, label_area) int64 [ncls] tensors."""
+    """pred/label integer tensors of equal shape -> (intersect, pred_area, label_area) int64 [ncls] tensors.
+    Device tensors in the dtypes the inference engines and loaders produce (int32 predictions, int64 / int32 labels) are counted by one HIP kernel through the
+    C-ABI (emrt_segmentation_areas); anything else (CPU tensors: the oracle-side tests) takes the torch expression below."""
+    if (pred.is_cuda and label.is_cuda and pred.dtype == torch.int32 and label.dtype in (torch.int64, torch.int32) and pred.numel() == label.numel()
+            and pred.is_contiguous() and label.is_contiguous() and num_classes <= 256):
+        import ctypes
+        from ... import _lib
+        from ...runtime import ctx
+        out = torch.zeros(3, num_classes, dtype=torch.int64, device=pred.device)
+        _lib.lib().call("emrt_segmentation_areas", ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(label.data_ptr()), int(label.dtype == torch.int64),
+                        pred.numel(), int(num_classes), int(ignore_index), ctypes.c_void_p(out.data_ptr()), ctx().stream)
+        return out[0], out[1], out[2]
     pred = pred.reshape(-1).to(torch.int64)
     label = label.reshape(-1).to(torch.int64)
     if pred.shape != label.shape:

@@ -268,6 +268,10 @@ int emrt_scalar_axpby(float* out, const float* a, float wa, const float* b, floa
 size_t emrt_gradnorm_workspace_bytes(void);
 int emrt_grad_clip_scale(const float* grads, long long n, float clip, float* state, void* workspace, void* stream);
 int emrt_sgd_momentum_step(float* params, const float* grads, float* velocity, long long n, const float* clip_state, const long long* step, float base_lr, float end_lr, float power, long long decay_steps, float momentum, float weight_decay, const long long* ranges, int nranges, float range_mult, float* lr_out, void* mirror, int mirror_dtype, void* stream);
+/* ---- evaluation metric counts (src/utils/metrics.py:20-59 calculate_area; val.py:197-209): out[3][num_classes] (int64, ACCUMULATED into: the caller zeroes it
+ * once per evaluation) += per-class pixel counts of (pred == label), pred, label over the pixels whose label != ignore_index; predictions / labels outside
+ * [0, num_classes) are counted nowhere.  pred int32 (the argmax map of emrt_argmax / the sliding-window engine), label int64 (label_is_int64) or int32. */
+int emrt_segmentation_areas(const int* pred, const void* label, int label_is_int64, long long n, int num_classes, int ignore_index, long long* out, void* stream);
 int emrt_counter_add(long long* counter, long long delta, void* stream);
 /* fp32 master weights -> compute-dtype forward copy [OC][taps][C] and transposed dgrad copy [C][taps][OC];
  * desc_dev: DEVICE int64 [ndesc][8] = {src_off, fwd_off|-1, bwd_off|-1, OC, taps, C, first 32x32 tile, first 64x64 tile};

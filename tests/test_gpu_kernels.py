@@ -1467,6 +1467,25 @@ def test_add_f32row_levels_equals_the_per_level_adds(dtype):
     close("add rows levels", host(one), ref, dtype)
 
 
+@pytest.mark.parametrize("label_dtype", [torch.int64, torch.int32])
+def test_segmentation_areas_kernel_equals_the_torch_expression(label_dtype):
+    """emrt_segmentation_areas (metrics.calculate_area on device tensors; reference src/utils/metrics.py:20-59) against the torch bincount expression the CPU
+    path keeps: ignore_index pixels dropped, predictions / labels outside [0, ncls) counted nowhere, exact integer counts."""
+    from emrt_amd.src.utils import metrics
+    init(F32)
+    g = torch.Generator().manual_seed(41)
+    ncls, n = 7, 3 * 517 * 389
+    pred = torch.randint(-1, ncls + 1, (n,), generator=g).to(torch.int32)          # includes -1 and ncls: out of range
+    lab = torch.randint(0, ncls + 2, (n,), generator=g)                            # includes ncls and ncls + 1
+    lab[torch.rand(n, generator=g) < 0.1] = 255
+    want = metrics.calculate_area(pred, lab, ncls, 255)                            # CPU tensors: the torch expression
+    got = metrics.calculate_area(pred.cuda().reshape(3, 517, 389), lab.to(label_dtype).cuda().reshape(3, 517, 389), ncls, 255)
+    torch.cuda.synchronize()
+    for a, b, name in zip(got, want, ("intersect", "pred", "label")):
+        assert a.is_cuda and torch.equal(a.cpu(), b), name
+    assert int(want[2].sum()) > 0 and int(want[0].sum()) > 0
+
+
 def test_memcpy_entry_point_stages_a_batch():
     """emrt_memcpy (engine.TrainEngine._stage, infer.SlidingWindowEngine): device -> device on the context's stream; zero bytes and dst == src are no-ops."""
     import ctypes
