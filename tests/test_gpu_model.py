@@ -81,9 +81,9 @@ def assert_argmax_match(got, ref, tol=1e-3, max_flips=None):
     assert not bad.any(), "%d pixels differ with a decisive margin (max margin %.3g)" % (int(bad.sum()), margin[bad].max().item())
     flips = int((ga != ra).sum())
     if max_flips is None:
-        # <= 0.02 % of the pixels (measured: 0 / 3 / 4 / 19 / 106 of 8k / 33k / 65k / 262k / 1049k, i.e. <= 0.0101 %); every one of them is
-        # a pixel whose float64 top-2 margin is below 2 * tol (asserted above): two fp32 summation orders cannot agree on those
-        max_flips = max(8, ga.numel() // 5000)
+        # <= 0.0133 % of the pixels = 1.3 x the worst measured (0 / 3 / 4 / 19 / 106 of 8k / 33k / 65k / 262k / 1049k, i.e. <= 0.0101 %; round 4 allowed
+        # 2 x); every one of them is a pixel whose float64 top-2 margin is below 2 * tol (asserted above): two fp32 summation orders cannot agree on those
+        max_flips = max(8, ga.numel() // 7500)
     # near-tie flips are bounded too: at most max_flips pixels, and never more than the oracle itself has near-ties
     assert flips <= max_flips and flips <= int((margin <= 2 * tol).sum()), "%d argmax flips (allowed %d)" % (flips, max_flips)
     return flips
