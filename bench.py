@@ -361,7 +361,7 @@ def _pause_gc(args):
     collection of this process's heap -- module trees, recorded launch lists of the configs run before -- is tens of ms of host time; at 12 ms per step
     that would be one stalled step).  No device work is skipped.  Whether the single 33 / 54 ms step seen in two DEFAULT runs at cfg3 (round 4's driver line,
     profiles/r5c first run: ms_per_step_max) was such a pause is not established: eight standalone cfg3 runs showed none with the collector on or off
-    (tools/r5/run26.sh).  `slowest_step` in the JSON line says which step it was when it happens again.  --keep-gc leaves the interpreter alone (A/B)."""
+    (tools/r5/ab_gc_cfg3.sh).  `slowest_step` in the JSON line says which step it was when it happens again.  --keep-gc leaves the interpreter alone (A/B)."""
     import gc
     if getattr(args, "keep_gc", False) or not gc.isenabled():
         return False
