@@ -296,6 +296,11 @@ def rooflines(calls, dtype_name, cfg_key, train):
                 "note": "two or three launches per call, each event-timed (event_timed_trivial_launch_us each); the value gradient is a matrix product at "
                         "cfg2 (msda_bwd_value_mfma_kernel: bound by the per-sample geometry on the VALU) and the LDS atomic scatter at cfg3 (7 cycles per "
                         "wave instruction); neither is bound by HBM: DESIGN.md 5.000"}
+        if pmc is not None and "msda_bwd_encoder_call" in pmc and "backward" in roofline_msda:
+            mb = pmc["msda_bwd_encoder_call"]
+            roofline_msda["backward"]["traffic"] = int(mb["traffic_mb_corrected"] * 1e6)
+            roofline_msda["backward"]["traffic_unit"] = ("bytes per encoder call (2*FETCH_SIZE + WRITE_SIZE summed over the call's kernels: %s)"
+                                                         % ", ".join(k_["kernel"].split("<")[0] for k_ in mb["kernels"]))
         if pmc is not None and "msda_fwd_kernel_encoder" in pmc:
             m = pmc["msda_fwd_kernel_encoder"]
             roofline_msda["traffic"] = int((m["fetch_mb_raw"] + m["write_mb"]) * 1e6)

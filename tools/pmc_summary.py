@@ -119,6 +119,18 @@ def main():
         enc_name = [k for k, g in enc if g == enc_grid][0]
         js["msda_fwd_kernel_encoder"] = family(lambda k: k == enc_name, enc_grid)
         js["msda_fwd_kernel_encoder"]["kernel"] = enc_name
+    # the deformable attention's backward, encoder calls: per kernel name the dispatches with that name's LARGEST grid (the decoder's 110-query calls run the
+    # same kernels on smaller grids), summed over the kernels of one call (gradient kernel + value-gradient kernel [+ finalize])
+    bwd_names = sorted({k for k, f, w, g in step if "msda_bwd" in k})
+    if bwd_names:
+        parts, tot = [], {"fetch_mb_raw": 0.0, "write_mb": 0.0, "traffic_mb_corrected": 0.0}
+        for nm in bwd_names:
+            gmax = max(g for k, f, w, g in step if k == nm)
+            fam = family(lambda k, nm=nm: k == nm, gmax)
+            parts.append({"kernel": nm, "dispatches_per_step": fam["dispatches_per_step"], "traffic_mb_corrected": fam["traffic_mb_corrected"]})
+            for key in tot:
+                tot[key] += fam[key]
+        js["msda_bwd_encoder_call"] = dict({k_: round(v_, 3) for k_, v_ in tot.items()}, kernels=parts)
     js = {k: v for k, v in js.items() if v is not None}
     js["dispatches_in_step"] = b - a
     calls_path = calls_only or (sys.argv[6] if len(sys.argv) >= 7 else None)
