@@ -361,12 +361,40 @@ def check_world(args):
                          % (world, args.gpus, args.gpus, args.gpus))
 
 
+def _ride_along(args, key, steps, warm):
+    """One ride-along config of the default command in a child process (a fresh interpreter on the same GPU): returns its JSON line as a dict, or None when
+    the child could not be run -- the caller then measures in-process.  The launcher's rank environment is not passed on (the child is a plain one-process run)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", key, "--steps", str(steps), "--warmup", str(warm), "--no-other-configs", "--cpu-steps", "1"]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.cpu_threads:
+        cmd += ["--cpu-threads", str(args.cpu_threads)]
+    if args.keep_gc:
+        cmd.append("--keep-gc")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                              "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        sys.stderr.write("[bench] ride-along %s: child process not usable (%s): measuring in-process\n" % (key, e))
+        return None
+    sys.stderr.write(r.stderr)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write("[bench] ride-along %s: child exited %d without a JSON line: measuring in-process\n" % (key, r.returncode))
+        return None
+    try:
+        return json.loads(lines[-1])
+    except ValueError:
+        return None
+
+
 def _pause_gc(args):
     """Host hygiene for the warm-up + timed region: collect now, then keep Python's collector off until the K steps are through (a generation-2
-    collection of this process's heap -- module trees, recorded launch lists of the configs run before -- is tens of ms of host time; at 12 ms per step
-    that would be one stalled step).  No device work is skipped.  Whether the single 33 / 54 ms step seen in two DEFAULT runs at cfg3 (round 4's driver line,
-    profiles/r5c first run: ms_per_step_max) was such a pause is not established: eight standalone cfg3 runs showed none with the collector on or off
-    (tools/r5/ab_gc_cfg3.sh).  `slowest_step` in the JSON line says which step it was when it happens again.  --keep-gc leaves the interpreter alone (A/B)."""
+    collection of this process's heap is tens of ms of host time; at 12 ms per step that would be one stalled step).  No device work is skipped.
+    It is NOT what stalled cfg3's first timed step in the default command (that needed the ride-along configs in child processes: _ride_along, DESIGN.md 5.000);
+    `slowest_step` in the JSON line says which step was the slowest.  --keep-gc leaves the interpreter alone (A/B)."""
     import gc
     if getattr(args, "keep_gc", False) or not gc.isenabled():
         return False
@@ -505,6 +533,8 @@ def main():
     ap.add_argument("--two-phase-no-syncbn", action="store_true", help="--two-phase without the SyncBatchNorm collectives (A/B: what the graph cuts cost)")
     ap.add_argument("--dump-calls", default=None, help="write the per-launch HIP-event timings of the profiled step to this file")
     ap.add_argument("--exchange-noop", action="store_true", help="A/B: the N > 1 step structure with the gradient all-reduce switched off (NOT a valid throughput)")
+    ap.add_argument("--inprocess-others", action="store_true", help="A/B: measure the ride-along configs in this process instead of in child processes")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="timed steps of the CPU baseline (0 = the config's default)")
     ap.add_argument("--keep-gc", action="store_true", help="A/B: leave Python's garbage collector enabled during the timed steps (default: collected before, paused during)")
     ap.add_argument("--dry-run", action="store_true", help="--gpus N without a GPU: start the N ranks, rendezvous over gloo, and check rank environment, "
                     "gradient-exchange ranges, SyncBatchNorm group membership and tile sharding; prints a JSON plan, launches no kernel")
@@ -531,7 +561,7 @@ def main():
         cfg["size"] = args.size
     dtype_name = args.dtype or cfg["dtype"]
     run = run_infer if cfg["mode"] == "infer" else run_train
-    result = run(args, args.config, cfg, dtype_name, env, args.steps, args.warmup, cpu=not args.no_cpu_baseline, dump=args.dump_calls)
+    result = run(args, args.config, cfg, dtype_name, env, args.steps, args.warmup, cpu=not args.no_cpu_baseline, dump=args.dump_calls, cpu_steps=args.cpu_steps or None)
     # The driver only ever runs the default command: the other two single-GPU configurations of BASELINE.json ride along as short runs
     # (metric / config / value above stay configs[1]'s).  Not at N > 1, not for experiments that changed the workload.
     default_workload = (args.config == "cfg2" and not args.batch and not args.size and not args.dtype and not args.no_graph and not args.overlap
@@ -541,7 +571,12 @@ def main():
         # (30 timed steps after 8 warm-up steps each: round 4's 12-step mean moved 18 % on ONE stalled step in the driver's run)
         for key, steps, warm in (("cfg3", 30, 8), ("cfg5", 30, 8)):
             c2 = dict(CONFIGS[key])
-            r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=1)
+            # each in a FRESH interpreter (a child process; this one keeps running and keeps its GPU context): run in-process after cfg2, cfg3's first timed
+            # step stalled for 54 / 136 ms in three default runs of seven, never in eight stand-alone runs (DESIGN.md 5.000 "Bench hygiene"); --inprocess-others
+            # restores the old behaviour, and a child that fails falls back to it
+            r2 = None if args.inprocess_others else _ride_along(args, key, steps, warm)
+            if r2 is None:
+                r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=1)
             others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "slowest_step", "value_at_median",
                                                "dtype", "config", "end_to_end_tflops", "loss_check", "roofline", "roofline_msda", "cpu_baseline") if k in r2}
         result["other_configs"] = others
