@@ -145,3 +145,17 @@ def test_bench_dry_run_validates_the_eight_rank_plan_without_a_gpu():
     # under a launcher whose size disagrees with --gpus the dry run fails before any rendezvous
     r = _run([sys.executable, "bench.py", "--gpus", "8", "--dry-run"], WORLD_SIZE="4", RANK="0")
     assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 8" in r.stderr
+
+
+def test_ride_along_child_failure_falls_back(monkeypatch, capsys):
+    """bench.py measures the ride-along configs of the default command in child processes; a child that cannot run or prints no JSON line must make
+    the caller fall back to the in-process measurement (return None), never break the default command."""
+    import argparse
+    import bench
+    args = argparse.Namespace(no_cpu_baseline=True, cpu_threads=0, keep_gc=False)
+    monkeypatch.setattr(sys, "executable", "/bin/false")
+    assert bench._ride_along(args, "cfg3", 2, 1) is None
+    monkeypatch.setattr(sys, "executable", "/nonexistent/python")
+    assert bench._ride_along(args, "cfg3", 2, 1) is None
+    assert "measuring in-process" in capsys.readouterr().err
+
