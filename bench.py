@@ -671,11 +671,19 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
     import math
     untrained = 1.4 * math.log(ncls)
     band = (0.3 * untrained, 1.35 * untrained)
-    loss_ok = (loss_val == loss_val and first_loss == first_loss and band[0] < loss_val < band[1] and loss_val < first_loss * (1.0 + 1e-3))
+    # "below the first step's" compares two noisy losses (dropout is on; the recorded slope is ~0.005 per step): it is enforced once enough steps
+    # were taken for the trend to clear the noise (>= 16), short profiling runs (--steps 2 --warmup 0) keep the NaN and band checks only
+    decreasing_checked = eng.calls >= 16
+    loss_ok = (loss_val == loss_val and first_loss == first_loss and band[0] < loss_val < band[1]
+               and (not decreasing_checked or loss_val < first_loss * (1.0 + 1e-3)))
+    if world > 1:      # every rank leaves together: a rank that raised alone would leave the others waiting in the next collective
+        okt = torch.tensor([1.0 if loss_ok else 0.0], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)
+        loss_ok = bool(okt.item() > 0.5)
     loss_check = {"first_step": round(first_loss, 4), "final": round(loss_val, 4), "band": [round(band[0], 3), round(band[1], 3)],
-                  "steps_taken": eng.calls, "ok": bool(loss_ok)}
+                  "steps_taken": eng.calls, "decreasing_checked": decreasing_checked, "ok": bool(loss_ok)}
     if not loss_ok:
-        raise SystemExit("[bench] loss check failed: %r" % (loss_check,))
+        raise SystemExit("[bench] loss check failed (on this or another rank): %r" % (loss_check,))
     probe = exposed = None
     if world > 1 and eng.reducer is not None and not args.exchange_noop:
         # what the gradient exchange costs the step: the same structure (graphs, SyncBatchNorm cuts, optimizer graph) with the all-reduce

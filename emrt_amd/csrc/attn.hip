@@ -312,8 +312,8 @@ __device__ __forceinline__ uint4 mha_frag_t(const T* sXt, int dt, int s, int lan
 }
 // four 16-bit uniforms for (row, quad of 4 consecutive columns); keep iff u16 >= thr
 __device__ __forceinline__ void mha_drop4(unsigned long long seed, unsigned salt, unsigned group, uint32_t (&h)[2]) {
-  h[0] = mix32(group ^ (uint32_t)seed);
-  h[1] = mix32(h[0] ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+  h[0] = mix32((group ^ (uint32_t)seed) + salt * 0x9E3779B9U);      // (the salt in the first round: see common.hpp drop_quad)
+  h[1] = mix32(h[0] ^ (uint32_t)(seed >> 32) ^ (salt * 0x85EBCA6BU));
 }
 __device__ __forceinline__ bool mha_keep4(const uint32_t (&h)[2], int e, uint32_t thr) { return ((h[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
 
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
 
 extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs,
                             int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt,
-                            int dtype, void* stream) {
+                            int* path_out, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(q && k && v && o && probs, "null pointer");
   EMRT_REQUIRE(D == MHA_D, "head dim must be 32");
@@ -566,6 +566,7 @@ extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, cons
   // floats of each (batch, head) slab -- the backward of the SAME dtype reads them back.  mha_valu = 1: the VALU kernels for every dtype (A/B).
   const bool mfma = dtype != EMRT_F32 && !g_tune.mha_valu && L >= 2 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 &&
                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0) && ((uintptr_t)o % 8 == 0);
+  if (path_out) *path_out = mfma ? 1 : 0;      // what `probs` holds now: the backward must be told (emrt_mha_bwd: path)
   if (mfma) {
     const int threads = 64 * ((L + 15) / 16);
     if (dtype == EMRT_BF16) hipLaunchKernelGGL((mha_fwd_mfma_kernel<bf16_t>), dim3(B * M), dim3(threads), 0, st, a);
@@ -580,10 +581,11 @@ extern "C" int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, cons
 
 extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* probs,
                             const void* dout, int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int M,
-                            int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype,
+                            int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int path, int dtype,
                             void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(q && k && v && probs && dout && dq && dk && dv, "null pointer");
+  EMRT_REQUIRE(path == 0 || path == 1, "path: what emrt_mha_fwd reported for the call that filled `probs` (0: L x L probabilities, 1: row statistics)");
   EMRT_REQUIRE(D == MHA_D, "head dim must be 32");
   EMRT_REQUIRE(L >= 1 && L <= MHA_MAXL, "sequence length must be <= 128");
   EMRT_REQUIRE(pdrop == 0.f || seed, "dropout needs a device seed");
@@ -603,11 +605,16 @@ extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, cons
       return fail("emrt_mha_bwd", "cannot raise the dynamic LDS limit");
     attr_done = true;
   }
-  // (the same condition as the forward's: the two must agree on what `probs` holds)
-  const bool mfma = dtype != EMRT_F32 && !g_tune.mha_valu && L >= 2 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 &&
-                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) % 16 == 0) &&
-                    lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 == 0);
+  // `probs` holds (row max, 1 / row sum) after the MFMA forward and the L x L probabilities after the VALU forward: the backward runs the kernel
+  // that matches what the forward REPORTED (round 5 re-derived the choice from its own operands and the mutable knob: a dout view with another
+  // alignment, or the knob flipped in between, made it read the slab as the other layout)
+  const bool mfma = path == 1;
   if (mfma) {
+    EMRT_REQUIRE(dtype == EMRT_BF16 && L >= 2 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 &&
+                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) % 16 == 0) && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 &&
+                     (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 == 0),
+                 "the forward took the MFMA kernel (probs = row statistics) but these gradient operands cannot run its backward: 16-byte aligned q / k / v / dout "
+                 "with row strides that are multiples of 8, 8-byte aligned dq / dk / dv with row strides that are multiples of 4");
     hipLaunchKernelGGL((mha_bwd_mfma_kernel<bf16_t>), dim3(B * M), dim3(64 * ((L + 15) / 16)), 0, st, a);
     return check_launch("emrt_mha_bwd");
   }

@@ -284,9 +284,11 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint32_t salt, uint64_
 // the kernels move 4 consecutive elements per lane, so ONE 64-bit draw per aligned quad of the flat index gives their four 16-bit uniforms --
 // 2 hash rounds per 4 elements where uniform01() needs 12 (the hash was most of the VALU work of the LayerNorm kernels: 14 + 14 launches a step).
 // keep iff u16 >= p * 65536.  Every kernel that must agree on a mask calls these two functions with the same (seed, salt, quad index).
+// The salt (one per dropout site) enters the FIRST round: every word of the draw -- hence every element of the quad -- differs between two sites
+// that share the step's seed and the flat index (round 5 kept it out of h[0]: elements 0 and 1 of every quad had the same mask at every site).
 __device__ __forceinline__ void drop_quad(uint64_t seed, uint32_t salt, uint64_t quad, uint32_t (&h)[2]) {
-  h[0] = mix32((uint32_t)quad ^ (uint32_t)seed);
-  h[1] = mix32(h[0] ^ (uint32_t)(quad >> 32) ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+  h[0] = mix32(((uint32_t)quad ^ (uint32_t)seed) + salt * 0x9E3779B9U);
+  h[1] = mix32(h[0] ^ (uint32_t)(quad >> 32) ^ (uint32_t)(seed >> 32) ^ (salt * 0x85EBCA6BU));
 }
 __device__ __forceinline__ bool drop_quad_keep(const uint32_t (&h)[2], int e, uint32_t thr) { return ((h[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thr; }
 __device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.f); }
@@ -296,8 +298,8 @@ __device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 
 // 8 consecutive channels of a row draws four 32-bit words = eight 16-bit uniforms (~4 instructions per element); keep iff u16 >= p * 65536.
 // The backward never re-derives this mask: the consumer's data gradient masks with (stored output > 0) (functional.conv2d: drop_rec).
 __device__ __forceinline__ void drop_words8(uint64_t seed, uint32_t salt, uint32_t group, uint32_t (&h)[4]) {
-  h[0] = mix32(group ^ (uint32_t)seed);
-  h[1] = mix32(h[0] ^ (uint32_t)(seed >> 32) ^ (salt * 0x9E3779B9U));
+  h[0] = mix32((group ^ (uint32_t)seed) + salt * 0x9E3779B9U);      // (the salt in the first round: see drop_quad)
+  h[1] = mix32(h[0] ^ (uint32_t)(seed >> 32) ^ (salt * 0x85EBCA6BU));
   h[2] = mix32(h[1] + 0x9E3779B9U + (h[0] << 6));
   h[3] = mix32(h[2] ^ 0x85EBCA6BU ^ (h[1] >> 2));
 }

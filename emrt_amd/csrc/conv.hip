@@ -496,7 +496,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its stores before the block's ticket is taken
         __syncthreads();
         volatile unsigned* arrived = reinterpret_cast<volatile unsigned*>(smem_all + BM * CP * 4);      // (past the fp32 tile)
+        // the ticket is the release / acquire point of the seam (agent scope): the partial-tile stores above are ordered before it by the memory model,
+        // not only by the write-through stores' behaviour (-DEMRT_XK_RELAXED_TICKET: round 5's relaxed ticket, for the A/B)
+#ifdef EMRT_XK_RELAXED_TICKET
         if (t == 0) *arrived = __hip_atomic_fetch_add(p.xk_tick + xk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        if (t == 0) *arrived = __hip_atomic_fetch_add(p.xk_tick + xk_tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         __syncthreads();
         if (*arrived != (unsigned)(S - 1)) return;
         if (t == 0) {
@@ -1132,6 +1138,10 @@ static int igemm_xk_copies(const ConvArgs& a, hipStream_t st, int want) {
     S = 4;
   }
   if (S > nkt) S = nkt;
+  if (S >= 2) {      // every copy owns at least one k-tile: copy s walks [s * per, (s + 1) * per), so S = ceil(nkt / per) (9 k-tiles on 8 copies: per = 2 -> 5 copies)
+    const int per = (nkt + S - 1) / S;
+    S = (nkt + per - 1) / per;
+  }
   if (S < 2 || nb > SCRATCH_TICKS || (size_t)nb * (size_t)S * 64 * 64 * 4 > SCRATCH_XK_BYTES) return 0;
   return S;
 }

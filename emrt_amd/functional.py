@@ -859,7 +859,7 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
     tape = c.tape
     if tape is not None:
         def bwd():
-            dout = tape.pop_grad(out)
+            dout, dout_n = tape.pop_grad(out, with_count=True)
             if dout is None:
                 return
             assert dout.is_contiguous()
@@ -892,7 +892,9 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
                 tape.add_grad(src, dx, owned=True)
             if id(out) in tape.identity_done:     # a later consumer of src (the encoder layer's norm1, layer_norm(identity_from=out)) has already summed it in
                 # ... and it summed THIS gradient: a contribution that arrived after it ran would have replaced the tensor (the promise of identity_from is broken)
-                assert tape.identity_done.pop(id(out)) is dout, "layer_norm(identity_from=t): t received another gradient contribution after that LayerNorm's backward"
+                # (a gradient the tape owns is accumulated IN PLACE: the tensor's identity alone would not show a late contribution, the count does)
+                summed, summed_n = tape.identity_done.pop(id(out))
+                assert summed is dout and summed_n == dout_n, "layer_norm(identity_from=t): t received another gradient contribution after that LayerNorm's backward"
             else:
                 tape.add_grad(src, dout)          # the residual path of every level: one add over the whole token tensor
         tape.record(bwd)
@@ -1075,7 +1077,7 @@ def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0
             _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), P(dzb), p,
                       c.seed_ptr if p > 0 else None, drop_salt, P(extra), c.dtype, c.stream)
             if extra is not None:
-                tape.identity_done[id(identity_from)] = extra
+                tape.identity_done[id(identity_from)] = (extra, tape.grad_count(identity_from))
             # dz is a's alone when the branch got its own (masked) gradient: handed over, so that the next contribution to a -- the data gradient of
             # the GEMM that read a -- accumulates into it in its epilogue instead of through an add launch
             tape.add_grad(a, dz, owned=(b is None or dzb is not None))
@@ -1152,8 +1154,9 @@ def mha(qk, v, n_heads, pdrop, salt):
     scale = 1.0 / math.sqrt(32.0)
     q_ptr = qk.data_ptr()
     k_ptr = qk.data_ptr() + E * qk.element_size()
+    path = ctypes.c_int(-1)          # which kernel filled `probs` (row statistics or L x L probabilities): the backward is told, it does not guess
     _L().call("emrt_mha_fwd", ctypes.c_void_p(q_ptr), E2, ctypes.c_void_p(k_ptr), E2, P(v), E, P(out), E, P(probs), B, n_heads, L, 32, scale, p,
-              c.seed_ptr, salt, c.dtype, c.stream)
+              c.seed_ptr, salt, ctypes.byref(path), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():
@@ -1165,7 +1168,7 @@ def mha(qk, v, n_heads, pdrop, salt):
             dv = c.empty((B, L, E))
             _L().call("emrt_mha_bwd", ctypes.c_void_p(q_ptr), E2, ctypes.c_void_p(k_ptr), E2, P(v), E, P(probs), P(dy), E,
                       ctypes.c_void_p(dqk.data_ptr()), E2, ctypes.c_void_p(dqk.data_ptr() + E * dqk.element_size()), E2, P(dv), E,
-                      B, n_heads, L, 32, scale, p, c.seed_ptr, salt, c.dtype, c.stream)
+                      B, n_heads, L, 32, scale, p, c.seed_ptr, salt, path.value, c.dtype, c.stream)
             tape.add_grad(qk, dqk, owned=True)
             tape.add_grad(v, dv, owned=True)
         tape.record(bwd)

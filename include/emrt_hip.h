@@ -194,9 +194,12 @@ int emrt_msda_bwd_uses_lds(const int* shapes_hw, int L);
 size_t emrt_msda_bwd_workspace_bytes(int B, int Lq, int M, int L, int P, const int* shapes_hw, int dtype);
 int emrt_msda_bwd(const void* value, int ldv, long long v_bs, const float* offw, int ldo, const float* ref, long long ref_bs, int ref_L, const void* dout, void* dvalue, void* doffw, int doffw_compute_dtype, float* dref, int B, int Lq, int Lv, int M, int D, int L, int P, const int* shapes_hw, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
-/* ---- fused softmax(QK^T/sqrt(d)) V with dropout on the weights: EMRT_utils/layers.py:283-303 (L <= 128, D = 32) */
-int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
-int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* probs, const void* dout, int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
+/* ---- fused softmax(QK^T/sqrt(d)) V with dropout on the weights: EMRT_utils/layers.py:283-303 (L <= 128, D = 32).
+ * ABI 8: emrt_mha_fwd reports through path_out (nullable) which kernel filled `probs` -- 0: the L x L probabilities (VALU kernel), 1: (row max,
+ * 1 / row sum) in the first 2 L floats of each (batch, head) slab (MFMA kernel, bf16 / fp16) -- and emrt_mha_bwd takes that value as `path`: it runs the
+ * matching backward or fails (it no longer re-derives the choice from its own operands). */
+int emrt_mha_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* probs, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int* path_out, int dtype, void* stream);
+int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* probs, const void* dout, int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int M, int L, int D, float scale, float pdrop, const unsigned long long* seed, unsigned salt, int path, int dtype, void* stream);
 
 /* ---- bilinear F.interpolate (align_corners True/False), optional fused "+ add", strided (concat-slice) output,
  * optional fp32 NCHW output for the returned logits: paddle_EMRT.py:40,44,169,174,180,288-289,301; fcn_head.py:80 */

@@ -164,7 +164,8 @@ def test_stride2_data_gradient_parity_class_kernel(case):
 # cross-block K split (csrc/conv.hip: igemm_body XK): S copies of the 64x64 tile grid, partial tiles through the registered scratch, the last
 # block to arrive sums them and runs the epilogue.  Forced on every fuzz geometry (ragged M / OC / K tails, stride, dilation, bias), forward
 # and data gradient (pair_max 0, batched weight gradients: the data gradient is its own launch), S = 2 / 3 / 8 (3: copies with unequal k ranges;
-# 8 on the short-K cases: trailing copies with NO k-tile, which still have to arrive)
+# 8 on the short-K cases: the dispatcher cuts the copies down to ceil(k-tiles / ceil(k-tiles / 8)) so that each owns at least one k-tile -- round 5
+# launched trailing copies without any, which only arrived with zeros)
 @pytest.mark.parametrize("copies", [2, 3, 8])
 @pytest.mark.parametrize("case", BIG, ids=[c[0] for c in BIG])
 def test_conv_random_geometry_cross_block_k_split(case, copies):

@@ -1263,6 +1263,55 @@ def test_dropout_statistics_and_determinism():
     assert ((per == 0).all(1) | (per != 0).all(1)).all()
 
 
+def _assert_masks_independent(name, m1, m2, p, lanes):
+    """two keep masks ([rows, cols] bool, the column index is the position inside the hash's group modulo `lanes`) drawn at rate 1 - p: each
+    keeps 1 - p, and they agree on (1 - p)^2 + p^2 of the elements at EVERY position of the group (a shared hash word shows up as agreement 1)"""
+    want = (1 - p) ** 2 + p ** 2
+    for e in range(lanes):
+        a, b = m1[:, e::lanes], m2[:, e::lanes]
+        n = a.numel()
+        keep = a.float().mean().item()
+        agree = (a == b).float().mean().item()
+        sd_k, sd_a = 5.0 * math.sqrt(p * (1 - p) / n), 5.0 * math.sqrt(want * (1 - want) / n)
+        assert abs(keep - (1 - p)) < sd_k + 1e-3, "%s: position %d keeps %.4f" % (name, e, keep)
+        assert abs(agree - want) < sd_a + 1e-3, "%s: position %d of the group: two sites agree on %.4f of the elements, independent masks on %.4f" % (name, e, agree, want)
+
+
+def test_dropout_masks_of_two_sites_are_independent():
+    """Every nn.Dropout of the reference draws its own mask (transformer_encoder_decoder.py:118-121,157-161,259-262; layers.py:297).  Here one
+    step's sites share the device seed and differ by their salt: the salt has to reach EVERY word of a group's draw (round 5's cheap hashes
+    left it out of the first word, so elements 0 and 1 of every quad -- 2 of 8 in the GEMM epilogue's groups, 2 of 4 attention columns -- were
+    dropped together at every site of a step).  All three hashes: drop_quad (element dropout / LayerNorm's branch dropout), drop_words8
+    (emrt_conv2d_drop) and mha_drop4 (attention weights)."""
+    c = init(BF16)
+    c.training = True
+    p = 0.3
+    # (1) element mode: quads of the flat index
+    xd = dev(torch.ones(512, 1024))
+    m = [host(Fn.dropout(xd, p, s)) != 0 for s in (5, 6)]
+    _assert_masks_independent("drop_quad", m[0], m[1], p, 4)
+    # (2) the FFN's dropout drawn in linear1's epilogue: groups of 8 output channels; all pre-activations positive, so the stored sign IS the mask
+    C, Hd, rows = 64, 256, 2048
+    lin = hnn.Linear(C, Hd)
+    with torch.no_grad():
+        lin.weight.fill_(1.0 / C)
+        lin.bias.fill_(0.5)
+    Holder(l1=lin).place()
+    xin = dev(torch.rand(1, rows, C) + 0.5)
+    m = [host(lin(xin, relu=True, drop=(p, s))).reshape(rows, Hd) > 0 for s in (11, 12)]
+    _assert_masks_independent("drop_words8", m[0], m[1], p, 8)
+    # (3) attention-weight dropout: quads of key columns; the dropped probabilities read out with one-hot values (L = 32 keys = the head dim)
+    B, L, E, Mh = 4, 32, 256, 8
+    g = torch.Generator().manual_seed(3)
+    qk = rnd(torch.randn(B, L, 2 * E, generator=g) * 0.1)          # near-uniform attention: every probability is far from 0
+    vv = torch.zeros(B, L, Mh, 32)
+    for j in range(L):
+        vv[:, j, :, j] = 1.0
+    qd, vd = dev(qk), dev(vv.reshape(B, L, E))
+    m = [(host(Fn.mha(qd, vd, Mh, p, s)).reshape(B, L, Mh, 32).permute(0, 2, 1, 3).reshape(B * Mh * L, 32) > 0) for s in (7, 8)]
+    _assert_masks_independent("mha_drop4", m[0], m[1], p, 4)
+
+
 # -----------------------------------------------------------------------------------------------------------------
 def test_softmax_ce_and_optimizer():
     c = init(F32)
