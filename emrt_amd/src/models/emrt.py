@@ -652,6 +652,15 @@ class EMRT(hnn.HipLayer):  # :184-304
             # the auxiliary head's x16 upsample (fcn_head.py:80) then lands on 2H x 2W and the reference's final resize to the
             # input size (paddle_EMRT.py:301) is no longer the identity this path drops; no EMRT yaml uses OUTPUT_STRIDE 8
             raise NotImplementedError("MODEL.OUTPUT_STRIDE 8 is not supported by the EMRT HIP path (16 and 32 are)")
+        if backbone == "resnet50c" and config is not None:
+            # options the reference's ResNetV1 constructor reads (backbones/resnet.py:106-124,175-207) that this path does not build: refused, not
+            # ignored -- a silently different backbone would still "run".  No EMRT yaml sets them ("resnet50c options").
+            enc = config.MODEL.ENCODER
+            if bool(getattr(enc, "MULTI_GRID", False)) or getattr(enc, "MULTI_DILATION", None) not in (None, [], ()):
+                raise NotImplementedError("MODEL.ENCODER.MULTI_GRID / MULTI_DILATION (backbones/resnet.py:186-199) are not supported by the EMRT HIP path")
+            if float(getattr(config.MODEL, "BACKBONE_SCALE", 1.0)) != 1.0:
+                raise NotImplementedError("MODEL.BACKBONE_SCALE != 1.0 (backbones/resnet.py:108,122-124) is not supported by the EMRT HIP path: "
+                                          "EMRT hard-codes the stage widths [512, 1024, 2048] (paddle_EMRT.py:188-192)")
         self.nclass = num_classes
         # resnet18/34: build-side extension (the reference hard-codes [512,1024,2048], paddle_EMRT.py:188-192)
         self.backbone_num_channels = [128, 256, 512] if depth in (18, 34) else [512, 1024, 2048]

@@ -74,3 +74,24 @@ def test_get_model_dispatch():
         cfg.MODEL.NAME = name
         with pytest.raises(NotImplementedError):
             get_model(cfg)
+
+
+def test_resnet50c_options_the_build_does_not_honour_are_refused():
+    """backbones/resnet.py:106-124,175-207 reads MODEL.OUTPUT_STRIDE (8 / 16 / 32), MODEL.BACKBONE_SCALE and MODEL.ENCODER.MULTI_GRID /
+    MULTI_DILATION; the HIP path builds output strides 16 and 32 at scale 1 without the multi-grid: anything else raises instead of
+    silently building a different backbone (no shipped EMRT yaml sets them)."""
+    from emrt_amd.src.models import get_model
+
+    def cfg50c():
+        cfg = update_config(get_config(), argparse.Namespace(cfg=os.path.join(CFG_DIR, "EMRT_256x256_160k_potsdam.yaml")))
+        cfg.MODEL.ENCODER.TYPE = "resnet50c"
+        cfg.MODEL.OUTPUT_STRIDE = 16
+        return cfg
+
+    assert type(get_model(cfg50c())).__name__ == "EMRT"
+    for mutate in (lambda c: setattr(c.MODEL, "OUTPUT_STRIDE", 8), lambda c: setattr(c.MODEL, "BACKBONE_SCALE", 0.5),
+                   lambda c: setattr(c.MODEL.ENCODER, "MULTI_GRID", True), lambda c: setattr(c.MODEL.ENCODER, "MULTI_DILATION", [4, 8, 16])):
+        cfg = cfg50c()
+        mutate(cfg)
+        with pytest.raises(NotImplementedError):
+            get_model(cfg)
