@@ -1000,7 +1000,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
                                                      T* __restrict__ z, T* __restrict__ out, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, long long rows, int C, float eps, float pdrop,
-                                                     const unsigned long long* __restrict__ seed, unsigned salt) {
+                                                     const unsigned long long* __restrict__ seed, unsigned salt,
+                                                     const T* __restrict__ qpos, int qpos_rows, T* __restrict__ q_out) {
+  // q_out (optional): out + qpos[row % qpos_rows] -- the NEXT attention's query, with_pos_embed(out, pos) (transformer_encoder_decoder.py:186,283-289),
+  // written beside `out` instead of by an add launch that re-reads it (same value: the stored `out`, rounded through T, plus the embedding)
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -1067,6 +1070,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
         for (int e = 0; e < 4; ++e) o[e] += w[e];
       }
       Vec4<T>::store(out + row * C + c, o);
+      if (q_out) {
+        float w[4];
+        Vec4<T>::load(qpos + (row % qpos_rows) * C + c, w);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] += to_f32(from_f32<T>(o[e]));
+        Vec4<T>::store(q_out + row * C + c, w);
+      }
     }
   }
 }
@@ -1079,7 +1089,11 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ z, co
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
                                                      int C, int rows_per_block, T* __restrict__ dzb, float pdrop,
                                                      const unsigned long long* __restrict__ seed, unsigned salt,
-                                                     float* __restrict__ dgamma_direct, float* __restrict__ dbeta_direct, const T* __restrict__ addend) {
+                                                     float* __restrict__ dgamma_direct, float* __restrict__ dbeta_direct, const T* __restrict__ addend,
+                                                     const T* __restrict__ dy2, T* __restrict__ dysum) {
+  // dysum (optional, with dy2): dy + dy2 written out -- the gradient of the forward's `post` addend, which saw both
+  // dy2 (optional, [rows][C]): a second gradient of the LayerNorm output -- the gradient of the query q_out = out + qpos that the forward wrote beside
+  // `out` -- summed with dy as it is loaded (the accumulate launch that used to merge the two is gone)
   // dzb (optional): gradient of the dropped branch input, dz * mask / (1 - p)
   // addend (optional, [rows][C]): another gradient contribution to the residual input, summed into dz here (dzb does not get it)
   const unsigned long long sd = (dzb && pdrop > 0.f) ? seed[0] : 0ull;
@@ -1119,6 +1133,13 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ z, co
         for (int k = 0; k < R; ++k) {
           Vec4<T>::load(z + row[k] * C + c, zz[k]);
           Vec4<T>::load(dy + row[k] * C + c, dd[k]);
+          if (dy2) {
+            float d2[4];
+            Vec4<T>::load(dy2 + row[k] * C + c, d2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dd[k][e] += d2[e];
+            if (dysum && ok[k]) Vec4<T>::store(dysum + row[k] * C + c, dd[k]);
+          }
         }
         float gm[4];
 #pragma unroll
@@ -1495,17 +1516,18 @@ extern "C" int emrt_groupnorm_bwd(const void* x, int ldx, long long x_bs, const 
 
 extern "C" int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma,
                                   const float* beta, float* mean, float* rstd, long long rows, int C, float eps, float pdrop,
-                                  const unsigned long long* seed, unsigned salt, int dtype, void* stream) {
+                                  const unsigned long long* seed, unsigned salt, const void* qpos, int qpos_rows, void* q_out, int dtype, void* stream) {
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   EMRT_REQUIRE(a && out && gamma && beta, "null pointer");
+  EMRT_REQUIRE((q_out == nullptr) == (qpos == nullptr) && (!q_out || (qpos_rows > 0 && q_out != out)), "q_out needs qpos [qpos_rows][C] and a buffer of its own");
   EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && b)), "dropout needs 0 <= p < 1, a device seed and a branch input b");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)((rows + 3) / 4);
   DT_SWITCH3(dtype,
-            hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)post, (float*)z, (float*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt),
-            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt),
-            hipLaunchKernelGGL((ln_fwd_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (const f16_t*)post, (f16_t*)z, (f16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt));
+            hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)post, (float*)z, (float*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt, (const float*)qpos, qpos_rows, (float*)q_out),
+            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)post, (bf16_t*)z, (bf16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt, (const bf16_t*)qpos, qpos_rows, (bf16_t*)q_out),
+            hipLaunchKernelGGL((ln_fwd_kernel<f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)a, (const f16_t*)b, (const f16_t*)post, (f16_t*)z, (f16_t*)out, gamma, beta, mean, rstd, rows, C, eps, pdrop, seed, salt, (const f16_t*)qpos, qpos_rows, (f16_t*)q_out));
   return check_launch("emrt_layernorm_fwd");
 }
 
@@ -1529,9 +1551,10 @@ extern "C" size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C) {
 
 extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd,
                                   float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop,
-                                  const unsigned long long* seed, unsigned salt, const void* dz_addend, int dtype, void* stream) {
+                                  const unsigned long long* seed, unsigned salt, const void* dz_addend, const void* dy2, void* dysum, int dtype, void* stream) {
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   EMRT_REQUIRE(z && dy && dz && gamma && mean && rstd && workspace, "null pointer");
+  EMRT_REQUIRE(!dysum || (dy2 && dysum != dz && dysum != dy && dysum != dy2), "dysum (= dy + dy2) needs dy2 and a buffer of its own");
   EMRT_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (pdrop == 0.f || (seed && dz_branch)), "dropout needs 0 <= p < 1, a device seed and dz_branch");
   EMRT_REQUIRE(!dz_addend || dz_addend != dz, "dz_addend must not alias dz");
   EMRT_REQUIRE(C % 4 == 0 && C <= 1024, "C must be a multiple of 4 and <= 1024");
@@ -1546,8 +1569,8 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   const bool direct = (dgamma || dbeta) && g_tune.ln_atomic != 0;       // developer knob: 0 = partials + finalize launch
   const size_t lds = (size_t)(wide ? 16 : 8) * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define LN_BWD_LAUNCH_W(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 512>), dim3((unsigned)blocks), dim3(512), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend)
-#define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend)
+#define LN_BWD_LAUNCH_W(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 512>), dim3((unsigned)blocks), dim3(512), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend, (const T*)dy2, (T*)dysum)
+#define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend, (const T*)dy2, (T*)dysum)
   if (wide) DT_SWITCH(dtype, LN_BWD_LAUNCH_W(float, 4, 1), LN_BWD_LAUNCH_W(bf16_t, 4, 1));
   else if (small) DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 4, 1), LN_BWD_LAUNCH(bf16_t, 4, 1));
   else DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 2, 4), LN_BWD_LAUNCH(bf16_t, 2, 4));

@@ -1040,42 +1040,58 @@ def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):
     return src, spans
 
 
-def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0, drop_salt=0, identity_from=None):
+def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0, drop_salt=0, identity_from=None, q_pos=None, q_bgrad=None):
     """out = LN(a + dropout(b)) * gamma + beta (+ post);  a, b, post contiguous [.., C].  The inverted dropout on the branch
     input b (every residual LayerNorm of the transformer has one in front: t_e_d.py:199,202,287,291,294) runs inside the
     LayerNorm kernels: the forward drops b on the fly, the backward emits dz for a and the masked dz for b.
     identity_from: a tensor t computed EARLIER from `a` with an identity path (t = f(a) + a: level_conv_gn's output) whose consumers all ran
     AFTER this call, so that t's gradient is complete when this backward runs: the identity's contribution d a += d t is then summed by this
-    kernel (dz_addend) and t's producer is told not to add it again (Tape.identity_done) -- one accumulate launch per encoder layer less."""
+    kernel (dz_addend) and t's producer is told not to add it again (Tape.identity_done) -- one accumulate launch per encoder layer less.
+    q_pos ([Lp, C] contiguous, a is [B, Lp, C]): also returns q = out + q_pos (broadcast over the batch) -- the next attention's query
+    with_pos_embed(out, pos) -- written by the same launch; returns (out, q).  Backward: q's gradient is summed with out's as the kernel loads
+    them (dy2) and handed to q_bgrad (the embedding's gradient, as Fn.add(bgrad=)) -- no add launch forward, no accumulate launch backward."""
     c = ctx()
     assert a.is_contiguous() and (b is None or b.is_contiguous()) and (post is None or post.is_contiguous())
     C = a.shape[-1]
     rows = a.numel() // C
     out = c.empty(tuple(a.shape))
+    q = None
+    if q_pos is not None:
+        assert q_pos.is_contiguous() and q_pos.dtype == a.dtype and q_pos.shape[-1] == C and rows % (q_pos.numel() // C) == 0
+        q = c.empty(tuple(a.shape))
     keep = c.tape is not None
     p = float(drop_p) if (c.training and b is not None) else 0.0
     z = c.empty(tuple(a.shape)) if (keep and b is not None) else None
     mean = c.empty((rows,), torch.float32) if keep else None
     rstd = c.empty((rows,), torch.float32) if keep else None
     _L().call("emrt_layernorm_fwd", P(a), P(b), P(post), P(z), P(out), P(gamma), P(beta), P(mean), P(rstd), rows, C, eps, p,
-              c.seed_ptr if p > 0 else None, drop_salt, c.dtype, c.stream)
+              c.seed_ptr if p > 0 else None, drop_salt, P(q_pos) if q is not None else None, (q_pos.numel() // C) if q is not None else 0, P(q),
+              c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         zz = z if z is not None else a
 
         def bwd():
             dy = tape.pop_grad(out)
+            dq = tape.pop_grad(q) if q is not None else None
+            if dq is not None:
+                assert dq.is_contiguous() and dq.dtype == out.dtype
+                if q_bgrad is not None:
+                    q_bgrad(dq)
+                if dy is None:
+                    dy, dq = dq, None
             if dy is None:
                 return
             assert dy.is_contiguous()
             dz = c.empty(tuple(a.shape))
             dzb = c.empty(tuple(a.shape)) if (b is not None and p > 0) else None
             ws = c.workspace(_L().query("emrt_layernorm_bwd_workspace_bytes", rows, C))
+            dysum = c.empty(tuple(a.shape)) if (dq is not None and post is not None) else None      # (the post addend saw out AND q = out + q_pos)
             extra = tape.peek_grad(identity_from) if identity_from is not None else None
             if extra is not None and (not extra.is_contiguous() or tuple(extra.shape) != tuple(a.shape) or extra.dtype != dz.dtype or (b is not None and dzb is None)):
                 extra = None                      # (without branch dropout a and b share dz: the addend must not reach b)
             _L().call("emrt_layernorm_bwd", P(zz), P(dy), P(dz), P(gamma), P(mean), P(rstd), P(dgamma), P(dbeta), rows, C, P(ws), P(dzb), p,
-                      c.seed_ptr if p > 0 else None, drop_salt, P(extra), c.dtype, c.stream)
+                      c.seed_ptr if p > 0 else None, drop_salt, P(extra), P(dq), P(dysum), c.dtype, c.stream)
             if extra is not None:
                 tape.identity_done[id(identity_from)] = (extra, tape.grad_count(identity_from))
             # dz is a's alone when the branch got its own (masked) gradient: handed over, so that the next contribution to a -- the data gradient of
@@ -1087,9 +1103,9 @@ def layer_norm(a, b, gamma, beta, dgamma, dbeta, post=None, eps=1e-5, drop_p=0.0
                 else:
                     tape.add_grad(b, dz)
             if post is not None:
-                tape.add_grad(post, dy)
+                tape.add_grad(post, dy if dysum is None else dysum, owned=dysum is not None)
         tape.record(bwd)
-    return out
+    return out if q is None else (out, q)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1156,7 +1172,7 @@ def mha(qk, v, n_heads, pdrop, salt):
     k_ptr = qk.data_ptr() + E * qk.element_size()
     path = ctypes.c_int(-1)          # which kernel filled `probs` (row statistics or L x L probabilities): the backward is told, it does not guess
     _L().call("emrt_mha_fwd", ctypes.c_void_p(q_ptr), E2, ctypes.c_void_p(k_ptr), E2, P(v), E, P(out), E, P(probs), B, n_heads, L, 32, scale, p,
-              c.seed_ptr, salt, ctypes.byref(path), c.dtype, c.stream)
+              c.seed_ptr, salt, ctypes.pointer(path), c.dtype, c.stream)
     tape = c.tape
     if tape is not None:
         def bwd():

@@ -331,10 +331,11 @@ class LayerNorm(HipLayer):
         self.weight = tnn.Parameter(torch.ones(c))
         self.bias = tnn.Parameter(torch.zeros(c))
 
-    def forward(self, a, b=None, post=None, drop_p=0.0, drop_salt=0, identity_from=None):
-        """LN(a + dropout(b)) (+ post): the dropout of the residual branch runs inside the LayerNorm kernels."""
+    def forward(self, a, b=None, post=None, drop_p=0.0, drop_salt=0, identity_from=None, q_pos=None, q_bgrad=None):
+        """LN(a + dropout(b)) (+ post): the dropout of the residual branch runs inside the LayerNorm kernels.  q_pos: also returns
+        out + q_pos (the next attention's query) from the same launch -> (out, q)."""
         return Fn.layer_norm(a, b, self.weight.data, self.bias.data, self.weight.grad, self.bias.grad, post=post, drop_p=drop_p,
-                             drop_salt=drop_salt, identity_from=identity_from)
+                             drop_salt=drop_salt, identity_from=identity_from, q_pos=q_pos, q_bgrad=q_bgrad)
 
 
 class Embedding(HipLayer):

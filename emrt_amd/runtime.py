@@ -236,6 +236,9 @@ class Context:
         self.bn_defer = bool(int(os.environ.get("EMRT_BN_DEFER", "1")))
         self.group_attn_proj = bool(int(os.environ.get("EMRT_GROUP_ATTN_PROJ", "1")))      # A/B: value_proj and the offsets | logits projection as one grouped launch
         self.fuse_ffn_dropout = bool(int(os.environ.get("EMRT_FFN_DROPOUT_FUSED", "1")))      # A/B: dropout(relu(linear1)) drawn in the GEMM epilogue (emrt_conv2d_drop)
+        # the query of the NEXT attention (out + pos) written by the LayerNorm launch that produces `out`, its gradient summed by that LayerNorm's backward
+        # as it loads (functional.layer_norm(q_pos=)); 0 = the separate add / accumulate launches (A/B knob)
+        self.ln_query = bool(int(os.environ.get("EMRT_LN_QUERY", "1")))
         # the decoder's pyramid maps resized by ONE launch per direction (emrt_pyramid_resize_fwd / _bwd); 0 = one launch per scale (A/B knob)
         self.pyramid_group = bool(int(os.environ.get("EMRT_PYRAMID_GROUP", "1")))
         # EMRT_WGRAD_SIDE=1 (A/B experiment): the batched weight-gradient launches go to a second stream, next to the latency-bound

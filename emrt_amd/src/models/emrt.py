@@ -328,7 +328,9 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
             tnn.init.xavier_uniform_(self.linear1.weight)
             tnn.init.xavier_uniform_(self.linear2.weight)
 
-    def forward(self, src, reference_points, spatial_shapes, level_spans, pos, pos_bgrad):  # :184-204
+    def forward(self, src, reference_points, spatial_shapes, level_spans, pos, pos_bgrad, q=None, next_q=False):  # :184-204
+        """q: with_pos_embed(src, pos) when the previous layer's norm2 already wrote it (Fn.layer_norm(q_pos=)); next_q: this layer's norm2 writes
+        the next layer's query -> returns (out, q_next)."""
         B, Lv, C = src.shape
         seqs = (self.conv0, self.conv1, self.conv2)
         if src.is_contiguous() and all(n == h * w and n <= 4096 for (h, w), (_, n) in zip(spatial_shapes, level_spans)):
@@ -344,12 +346,14 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
                 x_l = Fn.tokens_as_map(Fn.narrow(src, 1, s0, n), h, w)
                 y = seq[0](x_l)
                 seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
-        q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
+        if q is None:
+            q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
         src2 = self.self_attn(q, reference_points, src, spatial_shapes)
         src = self.norm1(src, src2, drop_p=self.p, drop_salt=self.salts[0], identity_from=identity)       # LN(src + dropout1(src2)), dropout inside the LN kernels
         h1 = self.linear1(src, relu=True, drop=(self.p, self.salts[1]))     # dropout(relu(linear1)) in one launch; both masks are applied by linear2's dgrad
         ff = self.linear2(h1)
-        return self.norm2(src, ff, post=src_flatten, drop_p=self.p, drop_salt=self.salts[2])    # LN(src + dropout(ffn)) + conv-branch tokens (:202-203)
+        # LN(src + dropout(ffn)) + conv-branch tokens (:202-203) [+ the next layer's query in the same launch]
+        return self.norm2(src, ff, post=src_flatten, drop_p=self.p, drop_salt=self.salts[2], q_pos=pos if next_q else None, q_bgrad=pos_bgrad)
 
 
 class TransformerEncoder(hnn.HipLayer):  # :207-239
@@ -382,15 +386,21 @@ class TransformerDecoderLayer(hnn.HipLayer):  # :242-295
             tnn.init.xavier_uniform_(self.linear1.weight)
             tnn.init.xavier_uniform_(self.linear2.weight)
 
-    def forward(self, tgt, reference_points, memory, spatial_shapes, query_pos, qpos_bgrad):  # :282-295
+    def forward(self, tgt, reference_points, memory, spatial_shapes, query_pos, qpos_bgrad, q=None, next_q=False):  # :282-295
+        """q / next_q: as TransformerEncoderLayer.forward (the queries tgt + query_pos written by the LayerNorm launches that produce tgt)."""
         Lq, C = tgt.shape[1], tgt.shape[2]
-        q = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
-        tgt = self.norm1(tgt, self.self_attn(q, tgt), drop_p=self.p, drop_salt=self.salts[0])        # dropout inside the LN kernels
-        q2 = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
+        fuse = ctx().ln_query
+        if q is None:
+            q = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
+        if fuse:
+            tgt, q2 = self.norm1(tgt, self.self_attn(q, tgt), drop_p=self.p, drop_salt=self.salts[0], q_pos=query_pos, q_bgrad=qpos_bgrad)
+        else:
+            tgt = self.norm1(tgt, self.self_attn(q, tgt), drop_p=self.p, drop_salt=self.salts[0])        # dropout inside the LN kernels
+            q2 = Fn.add(tgt, query_pos, period=Lq * C, bgrad=qpos_bgrad)
         tgt2 = self.cross_attn(q2, reference_points, memory, spatial_shapes, need_dref=True)
         tgt = self.norm2(tgt, tgt2, drop_p=self.p, drop_salt=self.salts[1])
         h1 = self.linear1(tgt, relu=True, drop=(self.p, self.salts[2]))
-        return self.norm3(tgt, self.linear2(h1), drop_p=self.p, drop_salt=self.salts[3])
+        return self.norm3(tgt, self.linear2(h1), drop_p=self.p, drop_salt=self.salts[3], q_pos=query_pos if next_q else None, q_bgrad=qpos_bgrad)
 
 
 class TransformerDecoder(hnn.HipLayer):  # :298-334
@@ -514,9 +524,12 @@ class EncoderDecoder(hnn.HipLayer):  # :337-473
                     pos_acc.clear()
             c.tape.record(pos_reduce)
 
-        memory = src
-        for layer in self.encoder.layers:
-            memory = layer(memory, ref_enc, spatial_shapes, spans, pos, pos_bgrad)
+        memory, q = src, None
+        n_enc = len(self.encoder.layers)
+        for i, layer in enumerate(self.encoder.layers):
+            nq = c.ln_query and i + 1 < n_enc
+            res = layer(memory, ref_enc, spatial_shapes, spans, pos, pos_bgrad, q=q, next_q=nq)
+            memory, q = res if nq else (res, None)
 
         qpe = self.query_pos_embed.weight
         query_pos = Fn.param_input(qpe.data, qpe.grad)                           # [110, C] in the compute dtype
@@ -526,9 +539,12 @@ class EncoderDecoder(hnn.HipLayer):  # :337-473
 
         ref_logit = self.reference_points(query_pos, out_f32=True)               # [110, 2] fp32   (:466)
         ref_dec = Fn.view_as(Fn.sigmoid_f32(ref_logit), (1, self.num_queries, 1, 2))   # one point per query, all levels
-        tgt = src_psp
-        for layer in self.decoder.layers:
-            tgt = layer(tgt, ref_dec, memory, spatial_shapes, query_pos, qpos_bgrad)
+        tgt, q = src_psp, None
+        n_dec = len(self.decoder.layers)
+        for i, layer in enumerate(self.decoder.layers):
+            nq = c.ln_query and i + 1 < n_dec
+            res = layer(tgt, ref_dec, memory, spatial_shapes, query_pos, qpos_bgrad, q=q, next_q=nq)
+            tgt, q = res if nq else (res, None)
         return tgt, memory, spatial_shapes, spans
 
 

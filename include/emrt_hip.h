@@ -163,13 +163,17 @@ int emrt_groupnorm_levels_fwd(const void* x, int ldx, long long x_bs, const void
 int emrt_groupnorm_levels_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, void* dx, int lddx, long long dx_bs, const float* const* gamma, const float* const* beta, const float* mean, const float* rstd, float* const* dgamma, float* const* dbeta, const int* level_start, const int* level_hw, int L, int N, int C, int G, int gelu, double* stat_ws, int dtype, void* stream);
 
 /* ---- residual add + LayerNorm (+ post add): transformer_encoder_decoder.py:199-203,159-160,285-291,278-279
- * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward. */
-int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma, const float* beta, float* mean, float* rstd, long long rows, int C, float eps, float pdrop, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
+ * z = a (+ b); out = LN(z) * gamma + beta (+ post).  z, mean, rstd are saved for backward.
+ * ABI 8: qpos / qpos_rows / q_out (nullable together): q_out[row] = out[row] + qpos[row % qpos_rows] -- the next attention's query with_pos_embed(out, pos)
+ * (transformer_encoder_decoder.py:186,283-289) written beside `out`; emrt_layernorm_bwd's dy2 (nullable, [rows][C]) is that query's gradient, summed with dy
+ * as it is loaded (dysum, nullable, receives dy + dy2: the gradient of the forward's `post` addend).  One add launch forward and one accumulate launch
+ * backward less per attention. */
+int emrt_layernorm_fwd(const void* a, const void* b, const void* post, void* z, void* out, const float* gamma, const float* beta, float* mean, float* rstd, long long rows, int C, float eps, float pdrop, const unsigned long long* seed, unsigned salt, const void* qpos, int qpos_rows, void* q_out, int dtype, void* stream);
 size_t emrt_layernorm_bwd_workspace_bytes(long long rows, int C);
 /* dz_addend (ABI 7, nullable, [rows][C], must not alias dz): a gradient contribution to the residual input that is already known -- the encoder layer's
  * conv-branch tokens reach the layer input through an identity as well (transformer_encoder_decoder.py:202-203) -- summed into dz here instead of by an add launch;
  * dz_branch does not receive it. */
-int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop, const unsigned long long* seed, unsigned salt, const void* dz_addend, int dtype, void* stream);
+int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta, long long rows, int C, void* workspace, void* dz_branch, float pdrop, const unsigned long long* seed, unsigned salt, const void* dz_addend, const void* dy2, void* dysum, int dtype, void* stream);
 
 /* ---- multi-scale deformable attention core (fused softmax + sampling locations + bilinear gather + weighted sum)
  * replaces transformer_encoder_decoder.py:89-104 and EMRT_utils/utils.py:64-97 (deformable_attention_core_func).

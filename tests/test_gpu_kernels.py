@@ -492,6 +492,61 @@ def test_layer_norm_with_fused_branch_dropout(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("with_post", [False, True])
+def test_layer_norm_writes_the_next_query_and_sums_its_gradient(dtype, with_post):
+    """with_pos_embed(LN(...), pos) (transformer_encoder_decoder.py:186,283-289) from the LayerNorm launch itself: layer_norm(q_pos=) returns (out, q)
+    with q = out + pos broadcast over the batch, bit-identical to the separate add launch (the stored out, rounded, plus pos); backward sums the two
+    output gradients as it loads them (dy2), hands q's gradient to the embedding's callback and gives `post` the sum (dysum).  Against the two-launch
+    form: the same gradients (fp32: to the last bits of one reassociated add; bf16: one rounding fewer), one add and one accumulate launch less."""
+    from emrt_amd import _lib
+    c = init(dtype)
+    c.training = True
+    g = torch.Generator().manual_seed(19)
+    B, L, C = 3, 110, 256
+    a, b, post = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(3))
+    pos = rnd(torch.randn(L, C, generator=g))
+    dy1, dyq = (rnd(torch.randn(B, L, C, generator=g)) for _ in range(2))
+    res, calls, seen = {}, {}, {}
+    for mode in ("fused", "plain"):
+        ln = hnn.LayerNorm(C)
+        with torch.no_grad():
+            ln.weight.copy_(torch.linspace(0.5, 1.5, C))
+            ln.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        Holder(ln=ln).place()
+        ad, bd, pd, posd = dev(a), dev(b), dev(post) if with_post else None, dev(pos)
+        got = []
+        tape = Tape()
+        c.tape = tape
+        _lib.lib().start_record()
+        if mode == "fused":
+            y, q = ln(ad, bd, post=pd, drop_p=0.2, drop_salt=5, q_pos=posd, q_bgrad=lambda gq: got.append(gq))
+        else:
+            y = ln(ad, bd, post=pd, drop_p=0.2, drop_salt=5)
+            q = Fn.add(y, posd, period=L * C, bgrad=lambda gq: got.append(gq))
+        fwd = [n for n, _ in _lib.lib().stop_record()]
+        c.tape = None
+        watch = [ad, bd] + ([pd] if with_post else [])
+        for t in watch:
+            tape.watch(t)
+        _lib.lib().start_record()
+        grads = run_bwd(tape, [(y, dev(dy1)), (q, dev(dyq))], watch)
+        calls[mode] = fwd + [n for n, _ in _lib.lib().stop_record()]
+        assert len(got) == 1
+        res[mode] = [host(y), host(q)] + [host(t) for t in grads] + [host(ln.weight.grad), host(ln.bias.grad), host(got[0])]
+    assert calls["fused"] == ["emrt_layernorm_fwd", "emrt_layernorm_bwd"], calls["fused"]
+    assert calls["plain"].count("emrt_add") == 1 and calls["plain"].count("emrt_acc3d") + calls["plain"].count("emrt_add3d") == 1, calls["plain"]
+    names = ["out", "q", "da", "db"] + (["dpost"] if with_post else []) + ["dgamma", "dbeta", "dq handed to the embedding"]
+    for u, v, name in zip(res["fused"], res["plain"], names):
+        if name in ("out", "q", "dq handed to the embedding"):
+            assert torch.equal(u, v), name
+        else:
+            tol = 2e-2 if dtype == BF16 else 2e-6
+            assert (u - v).abs().max().item() <= tol * max(1.0, v.abs().max().item()), (name, (u - v).abs().max().item())
+    want_q = rnd(res["plain"][0]) + pos          # q really is out + pos
+    close("q = out + pos", res["fused"][1], want_q, dtype, atol=1e-6 if dtype == F32 else None)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("p", [0.0, 0.3])
 def test_layer_norm_backward_sums_an_identity_contribution(dtype, p):
     """The encoder layer's shape (transformer_encoder_decoder.py:184-204): t = f(a) + a is computed first, LN1(a + dropout(b)) second, and t is consumed
@@ -517,9 +572,10 @@ def test_layer_norm_backward_sums_an_identity_contribution(dtype, p):
         t = Fn.add_maps(ad, wd)                      # stands for level_conv_gn: an earlier consumer of a with an identity path
 
         def t_bwd(t=t, ad=ad, tape=tape):            # its producer's backward, written like level_conv_gn's: skip the identity when a later consumer summed it
-            dt = tape.pop_grad(t)
+            dt, dt_n = tape.pop_grad(t, with_count=True)
             if id(t) in tape.identity_done:
-                assert tape.identity_done.pop(id(t)) is dt
+                summed, summed_n = tape.identity_done.pop(id(t))
+                assert summed is dt and summed_n == dt_n
             else:
                 tape.add_grad(ad, dt)
         tape.ops[-1] = t_bwd                         # (replaces add_maps' own backward)
