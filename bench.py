@@ -50,6 +50,7 @@ GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: pe
                  "emrt_conv2d_bwd_group": "igemm_group_kernel<mode 1> (emrt_conv2d_bwd_group: data gradients of the per-level convs)",
                  "emrt_conv2d": "igemm_kernel / igemm8p_kernel / igemm_xk_kernel (emrt_conv2d: forward convs / linears)",
                  "emrt_conv2d_drop": "igemm_drop_kernel (emrt_conv2d_drop: dropout(relu(linear1)) of the FFN, the mask drawn in the epilogue)",
+                 "emrt_conv2d_bna": "igemm_bna_kernel / igemm_xk_bna_kernel (emrt_conv2d_bna: forward convs that apply their input's BatchNorm + ReLU on load)",
                  "emrt_conv2d_bwd": "igemm_kernel / igemm8p_kernel / igemm_xk_kernel mode 1 (emrt_conv2d_bwd: data gradients; thin_bwd_kernel for the classifiers)",
                  "emrt_conv2d_wgrad": "wgrad_kernel (emrt_conv2d_wgrad)",
                  "emrt_bn_pointwise_fwd": "thin_fwd_bn_kernel (emrt_bn_pointwise_fwd: the classifier with its BatchNorm operand)",
@@ -58,7 +59,7 @@ GEMM_FAMILIES = {"emrt_conv2d_group": "igemm_group_kernel (emrt_conv2d_group: pe
 # the roofline's kernel family: every launch that computes a convolution / linear layer's BACKWARD (data gradient + weight gradient) --
 # the same population of work whether a layer's two gradients share a launch (round 3's pair kernel) or not (round 4: batched dW)
 CONV_BWD = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group", "emrt_bn_pointwise_bwd")
-CONV_FWD = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
+CONV_FWD = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_bna", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
 
 
 def log(*a):
@@ -73,6 +74,8 @@ def conv_flops(name, a):
         return 4.0 * a[13] * a[14] * a[15] * a[16]
     if name == "emrt_conv2d_drop":             # (in, w, out, bias, M, C, ldin, OC, ldout, ...)
         return 2.0 * a[4] * a[5] * a[7]
+    if name == "emrt_conv2d_bna":              # emrt_conv2d's leading arguments without `mode` (always forward)
+        return 2.0 * a[5] * a[11] * a[12] * a[13] * a[18] * a[19] * a[8]
     if name == "emrt_conv2d":
         N, H, W, C = a[5:9]
         OH, OW, OC = a[11:14]
@@ -116,6 +119,10 @@ def conv_bytes(name, a, esz):
         return 2 * N * HW * C * esz + N * HW * OC * esz + OC * C * esz + 2 * 4 * OC * C
     if name == "emrt_conv2d_drop":
         return a[4] * a[5] * esz + a[7] * a[5] * esz + a[4] * a[7] * esz
+    if name == "emrt_conv2d_bna":              # the raw map read, the normalised map and the output written, the weight read (+ a residual)
+        N, H, W, C = a[5:9]
+        OH, OW, OC = a[11:14]
+        return one(N, H, W, C, OH, OW, OC, a[18], a[19], True, False, False, extra_in=1 if a[4] else 0) + N * H * W * C * esz
     if name == "emrt_conv2d":
         N, H, W, C = a[5:9]
         OH, OW, OC = a[11:14]
@@ -182,6 +189,8 @@ def dump_calls(path, calls, esz=2):
                 extra = "mode%d N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[22], vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], vals[20], conv_flops(name, vals) / 1e9)
             elif name == "emrt_conv2d_drop":
                 extra = "linear+relu+dropout M%d %d->%d gflop %.2f" % (vals[4], vals[5], vals[7], conv_flops(name, vals) / 1e9)
+            elif name == "emrt_conv2d_bna":
+                extra = "bn+relu on load N%d in%dx%dx%d out%dx%dx%d k%d gflop %.2f" % (vals[5], vals[6], vals[7], vals[8], vals[11], vals[12], vals[13], vals[18], conv_flops(name, vals) / 1e9)
             elif name == "emrt_conv2d_bwd":
                 extra = "N%d in%dx%dx%d out%dx%dx%d k%d s%d gflop %.2f" % (vals[9], vals[10], vals[11], vals[12], vals[15], vals[16], vals[17], vals[20], vals[22], conv_flops(name, vals) / 1e9)
             elif name == "emrt_conv2d_wgrad":

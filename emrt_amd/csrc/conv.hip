@@ -69,6 +69,15 @@ struct ConvArgs {
   const unsigned long long* drop_seed;
   unsigned drop_salt;
   float drop_p;
+  // A-operand BatchNorm (igemm_body<..., BNA>; emrt_conv2d_bna): `in` is the RAW output of the producing conv whose training-mode BatchNorm (+ ReLU) has
+  // not been applied.  Every block derives the per-channel scale / shift from the complete fp64 batch sums in its preamble (bn_operand.hpp, as the
+  // other consumers that apply a BatchNorm on load) and turns every 16-byte chunk it loads into [relu](x * scale + shift) between the global load and
+  // the LDS write -- the same fmaf + max + rounding as bn_apply_kernel, so the GEMM sees the bits the separate launch would have stored.  The tiles of
+  // the first column of the tile grid (bn == 0) also WRITE the transformed chunks of the centre tap to a_out (dense [N][H][W][C]): backward (the weight
+  // gradient's operand, the ReLU mask and BatchNorm sums of this layer's data gradient) keeps reading a materialised map, only the emrt_bn_apply
+  // launch and its read of the raw map are gone.  bna.sums == nullptr everywhere else.
+  BnOperand bna = {};
+  void* a_out = nullptr;
 };
 
 template <class T>
@@ -149,10 +158,11 @@ __device__ __forceinline__ uint32_t buf_load_elem<float>(__amdgpu_buffer_rsrc_t 
 // scratch with write-through (sc1) stores, every storing wave drains its stores, one lane takes a ticket (agent-scope atomic add), and the
 // block whose ticket is the last one acquires (agent scope), sums the S partials in s order and runs the usual epilogue (bias / residual / mask
 // / BatchNorm sums / store) -- no finishing launch.  MI355X_MICROARCH.md "splitk-seam"; cdna_hip_programming.md Guideline 16, R1.
-template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false, bool XK = false, bool DROP = false>
+template <class T, int TM, int TN, int WR, int WC, int MODE, bool VEC, int NST, int G, bool S2 = false, bool XK = false, bool DROP = false, bool BNA = false>
 __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id, const int block_count, unsigned char* smem_all) {
   static_assert(!S2 || (MODE == 1 && VEC && G == 1 && TM == 1 && TN == 1), "S2 is the 64x64 vector-path data gradient");
   static_assert(!XK || (VEC && G == 1 && !S2), "XK is a vector-path tile without the in-block K split");
+  static_assert(!BNA || (MODE == 0 && VEC && !S2 && !DROP), "BNA is the forward vector path");
   constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BK = 8 * EPC;
@@ -236,6 +246,20 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
     b_off[j] = n < p.OC ? (unsigned)((long long)n * K * (long long)sizeof(T)) : BUF_OOB;
   }
 
+  // BNA: scale / shift table [2][C] behind every group's k-tile buffers (dead once the k loop is over: the parked accumulators may overwrite it)
+  // and, per ring stage, what the transform needs to know about the chunk that stage holds: bits 0-15 its first channel, bit 16 "centre tap", bit 17 + i "row i was in range" (padding taps stay exact zeros)
+  float* bn_tab = reinterpret_cast<float*>(smem_all + (size_t)G * 2 * STAGE_BYTES);
+  unsigned rmeta[BNA ? NST : 1];
+  unsigned wb_off[BNA ? AR : 1];      // byte offset of the row's own pixel in a_out (BUF_OOB: not this block's to write)
+  __amdgpu_buffer_rsrc_t rs_aout;
+  if constexpr (BNA) {
+    rs_aout = __builtin_amdgcn_make_buffer_rsrc(p.a_out, 0, (int)BUF_RANGE, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const unsigned m = (unsigned)bm * (unsigned)BM + (unsigned)(row0 + 32 * i);
+      wb_off[i] = (bn == 0 && a_ok[i]) ? m * (unsigned)p.C * (unsigned)sizeof(T) : BUF_OOB;
+    }
+  }
   uint4 ra[NST][AR], rb[NST][BR];
   // byte offset of input pixel (row i, tap kh,kw), or BUF_OOB when the tap falls on padding / a stride hole / m >= M
   auto a_pixel = [&](int i, int kh, int kw) -> unsigned {
@@ -280,12 +304,18 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
 #pragma unroll
     for (int i = 0; i < AR; ++i) a_cur[i] = a_pixel(i, ld_kh, ld_kw);
   }
-  auto load_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR]) {
+  auto load_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR], unsigned& meta_) {
     if constexpr (VEC) {
       const unsigned kbad = (S2 ? ld_kh < p.KH : ld_kc < K) ? 0u : BUF_OOB;      // OR-ing BUF_OOB into an offset < BUF_OOB puts it out of range
       const unsigned cbytes = (unsigned)ld_c0 * (unsigned)sizeof(T), kbytes = (unsigned)ld_kc * (unsigned)sizeof(T);
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra_[i] = buf_load16(rs_in, (a_cur[i] | kbad) + cbytes);
+      if constexpr (BNA) {
+        unsigned mt = (unsigned)ld_c0 | ((ld_kh == (p.KH >> 1) && ld_kw == (p.KW >> 1)) ? 0x10000u : 0u);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) mt |= ((a_cur[i] | kbad) < BUF_OOB) ? (0x20000u << i) : 0u;
+        meta_ = mt;
+      }
 #pragma unroll
       for (int j = 0; j < BR; ++j) rb_[j] = buf_load16(rs_w, (b_off[j] | kbad) + kbytes);
       ld_kc += KSTEP;
@@ -369,15 +399,77 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   const int frow = lane & 31, fh = lane >> 5;
   // one k-tile: ring stage d -> LDS buffer `par`, barrier, (refill stage d), MFMAs.  A buffer is rewritten two tiles
   // later, i.e. after the barrier of the tile in between, which every wave reaches only after its reads of this one.
-  auto k_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR], int par, bool refill) {
+  auto k_tile = [&](uint4 (&ra_)[AR], uint4 (&rb_)[BR], unsigned& meta_, int par, bool refill) {
     unsigned char* sA = smem + par * STAGE_BYTES;
     unsigned char* sB = sA + BM * PITCH;
+    if constexpr (BNA) {
+      // one 32-bit word of the chunk (2 elements; 1 in fp32) at a time for all rows: the per-channel constants are read from LDS right where they are
+      // used and at most two of them are live (the first version read the chunk's 16 constants up front: 15-20 registers spilled at the 128-register cap)
+      const unsigned mt = meta_;
+      const int c0 = (int)(mt & 0xffffu);
+      const float lo = p.bna.relu ? 0.f : -INFINITY;
+      const unsigned ctr_bad = (mt & 0x10000u) ? 0u : BUF_OOB;
+      const float* tsc = bn_tab + c0;
+      const float* tsh = bn_tab + p.C + c0;
+      // (member by member: indexing the 32-bit words of a uint4 through a pointer sent the whole register ring to scratch memory)
+      // two 16-bit elements per call, six instructions: unpack (2), v_pk_fma_f32, v_cvt_pk_bf16_f32, the ReLU as a packed signed-integer max on the
+      // rounded pair (a negative value has its sign bit set; max(x, 0) then rounds to the same bits as rounding max(x, 0.f)), the validity select.
+      // The first version spent 56 instructions per 8-element chunk -- half of the 64x64 loop's own arithmetic per k-tile.
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      typedef short i16x2_t __attribute__((ext_vector_type(2)));
+      const bool do_relu = p.bna.relu != 0;
+      auto word2 = [&](uint32_t w, const float2 s2, const float2 h2, bool ok) -> uint32_t {
+        uint32_t o = 0u;
+        if constexpr (std::is_same<T, bf16_t>::value) {
+          const f32x2_t e = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+          const f32x2_t r = __builtin_elementwise_fma(e, f32x2_t{s2.x, s2.y}, f32x2_t{h2.x, h2.y});
+          const bf16x2_t b = __builtin_convertvector(r, bf16x2_t);
+          i16x2_t bi = __builtin_bit_cast(i16x2_t, b);
+          if (do_relu) bi = __builtin_elementwise_max(bi, i16x2_t{0, 0});
+          o = __builtin_bit_cast(uint32_t, bi);
+        } else if constexpr (sizeof(T) == 2) {
+          float e0, e1;
+          unpack_f16x2(w, e0, e1);
+          e0 = fmaxf(fmaf(e0, s2.x, h2.x), lo);
+          e1 = fmaxf(fmaf(e1, s2.y, h2.y), lo);
+          o = pack_f16x2(e0, e1);
+        }
+        return ok ? o : 0u;      // a padding tap (or a row past M) is a zero of the NORMALISED map, not relu(shift)
+      };
+      auto word1 = [&](uint32_t w, float s1, float h1, bool ok) -> uint32_t {      // one fp32 element
+        return ok ? __float_as_uint(fmaxf(fmaf(__uint_as_float(w), s1, h1), lo)) : 0u;
+      };
+      // (through a local copy and ONE whole-vector assignment per row: member-wise updates of the ring's registers sent the ring to scratch memory)
+      uint32_t wq[AR][4];
+#pragma unroll
+      for (int i = 0; i < AR; ++i) { wq[i][0] = ra_[i].x; wq[i][1] = ra_[i].y; wq[i][2] = ra_[i].z; wq[i][3] = ra_[i].w; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (sizeof(T) == 2) {
+          const float2 s2 = *reinterpret_cast<const float2*>(tsc + 2 * q), h2 = *reinterpret_cast<const float2*>(tsh + 2 * q);
+#pragma unroll
+          for (int i = 0; i < AR; ++i) wq[i][q] = word2(wq[i][q], s2, h2, (mt & (0x20000u << i)) != 0u);
+        } else {
+          const float s1 = tsc[q], h1 = tsh[q];
+#pragma unroll
+          for (int i = 0; i < AR; ++i) wq[i][q] = word1(wq[i][q], s1, h1, (mt & (0x20000u << i)) != 0u);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra_[i] = make_uint4(wq[i][0], wq[i][1], wq[i][2], wq[i][3]);
+      // the first tile column writes the normalised map (each pixel once: the centre tap, whose input pixel IS the output pixel at stride 1); every
+      // other store has an out-of-range offset and is dropped by the hardware
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ra_[i].x, ra_[i].y, ra_[i].z, ra_[i].w}, rs_aout, (int)((wb_off[i] | ctr_bad) + (unsigned)c0 * (unsigned)sizeof(T)), 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(sA + (row0 + 32 * i) * PITCH + chunk * 16) = ra_[i];
 #pragma unroll
     for (int j = 0; j < BR; ++j) *reinterpret_cast<uint4*>(sB + (row0 + 32 * j) * PITCH + chunk * 16) = rb_[j];
     __syncthreads();
-    if (refill) load_tile(ra_, rb_);
+    if (refill) load_tile(ra_, rb_, meta_);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       uint4 fa[TM], fb[TN];
@@ -395,16 +487,19 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& p, const int block_id
   };
 
 #pragma unroll
-  for (int d = 0; d < NST; ++d) load_tile(ra[d], rb[d]);
+  for (int d = 0; d < NST; ++d) load_tile(ra[d], rb[d], rmeta[BNA ? d : 0]);
+  // (the table is built AFTER the ring's first loads went out: they do not depend on it, and in front of them the preamble's memory round trip
+  // -- fp64 sums -> scale / shift -> LDS -> barrier -- was a serial ~1 us at the head of every block)
+  if constexpr (BNA) bn_operand_preamble(p.bna, p.C, bn_tab, block_id == 0);
   int kt = 0;
   for (; kt + NST <= nkt; kt += NST) {
 #pragma unroll
-    for (int d = 0; d < NST; ++d) k_tile(ra[d], rb[d], (kt + d) & 1, true);
+    for (int d = 0; d < NST; ++d) k_tile(ra[d], rb[d], rmeta[BNA ? d : 0], (kt + d) & 1, true);
   }
   const int rem = nkt - kt;
 #pragma unroll
   for (int d = 0; d < NST - 1; ++d)
-    if (d < rem) k_tile(ra[d], rb[d], (kt + d) & 1, false);
+    if (d < rem) k_tile(ra[d], rb[d], rmeta[BNA ? d : 0], (kt + d) & 1, false);
 
   // (group / thread indices re-derived from an opaque copy of the thread id: the compiler otherwise keeps the prologue's copies alive across the
   // k loop for the code below, and at the 128-register cap of the 1024-thread block that cost the K-split variants two spilled registers)
@@ -707,6 +802,18 @@ template <class T>
 __global__ __launch_bounds__(256, 4) void igemm_s2_kernel(ConvArgs p) {      // data gradient of a stride-2 convolution: see igemm_body, S2
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   igemm_body<T, 1, 1, 2, 2, 1, true, 3, 1, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
+}
+
+// forward 64x64 tiles whose A operand is the RAW map of a conv -> BatchNorm (-> ReLU) chain: see ConvArgs::bna.  G wave groups as igemm_kernel.
+template <class T, int G>
+__global__ __launch_bounds__(256 * G, G == 1 ? 4 : 1) void igemm_bna_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  igemm_body<T, 1, 1, 2, 2, 0, true, (G == 2 ? 6 : 2), G, false, false, false, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
+}
+template <class T>
+__global__ __launch_bounds__(256, 4) void igemm_xk_bna_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  igemm_body<T, 1, 1, 2, 2, 0, true, 2, 1, false, true, false, true>(p, (int)blockIdx.x, (int)gridDim.x, smem_all);
 }
 
 #include "igemm8p.hpp"
@@ -1299,6 +1406,137 @@ extern "C" int emrt_conv2d_drop(const void* in, const void* w_packed, void* out,
   EMRT_REQUIRE(M > 0 && C > 0 && OC > 0 && OC % 8 == 0 && (long long)M * OC < (1ll << 32), "bad dims (OC a multiple of 8, fewer than 2^32 outputs)");
   return conv2d_impl(in, w_packed, out, bias, nullptr, 1, 1, M, C, ldin, (long long)M * ldin, 1, M, OC, ldout, (long long)M * ldout, 0, 0, 1, 1, 1, 0,
                      0, 1, 0, nullptr, nullptr, 0, 0, 1, nullptr, p, seed, salt, dtype, stream);
+}
+
+// ---- forward convolution whose input BatchNorm (+ ReLU) is applied by the operand loads (ABI 8) -------------------------------------------------
+// Which kernel would run this layer with the BatchNorm on its A operand: 0 = none (the dispatcher would take a tile the transform is not built
+// into -- 256x32, 128x128, the 256x256 LDS-DMA kernel -- or the geometry is outside it), 1 / 2 / 4 = the 64x64 tile with that many wave groups,
+// 100 + S = the cross-block K split with S copies.  Mirrors conv_pick_tile's order of decisions for a forward vector-path layer.
+template <class T>
+static int bna_choice(const ConvArgs& a, hipStream_t st) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  const bool vec = (a.C % EPC == 0) && (a.ldin % EPC == 0) && (a.in_bs % EPC == 0) && (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.w) % 16 == 0);
+  if (!vec || a.C % BK != 0 || a.C > 1024 || a.OC <= 32) return 0;
+  if (a.stride != 1 || a.KH != a.KW || (a.KH != 1 && a.KH != 3) || a.pad != a.dil * (a.KH >> 1) || a.OH != a.H || a.OW != a.W) return 0;
+  if (((uintptr_t)a.a_out) % 16 != 0) return 0;
+  // Measured on MI355X (tools/r6/bench_bna.py, profiles/r6_bna_microbench.txt; batch 8, bf16, us: emrt_bn_apply + emrt_conv2d -> this kernel):
+  //   1x1  64x64x64->256   20.0 -> 18.0    32x32x128->512   15.0 -> 12.0    16x16x256->1024  12.3 -> 11.0    8x8x512->2048    14.5 -> 13.2
+  //   3x3  64x64x64->64    17.0 -> 16.5    32x32x128->128   16.2 -> 15.0    16x16x256->256   19.9 -> 21.2    8x8x512->512     25.8 -> 28.2
+  //        32x32x256->256  30.2 -> 37.1    32x32x512->256   56.3 -> 72.4
+  // The transform runs once per loaded chunk, i.e. once per N-tile and nine times per pixel of a 3x3 layer: it pays where the k loop is short (every
+  // 1x1; 3x3 up to 128 channels = 18 k-tiles) and loses where the loop is long -- there the separate launch stays (knob no_bna = -1: tests take them all)
+  if (a.KH == 3 && a.C > 128 && g_tune.no_bna != -1) return 0;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  auto blocks = [&](int bmv, int bnv) { return ((M + bmv - 1) / bmv) * ((a.OC + bnv - 1) / bnv); };
+  if (g_tune.conv_tile) return g_tune.conv_tile == 1 ? 1 : g_tune.conv_tile == 5 ? 2 : g_tune.conv_tile == 6 ? 4 : 0;
+  if constexpr (sizeof(T) == 2) {
+    const int S = igemm_xk_copies<T>(a, st, g_tune.xk > 0 ? g_tune.xk : 0);
+    if (S >= 2) return 100 + S;
+    const long long nb256 = blocks(256, 256);
+    const int nkt64 = a.KH * a.KW * a.C / 64;
+    const int minb = g_tune.igemm8p_min_blocks;
+    if (minb > 0 && nkt64 >= 16 && (nb256 >= minb || (nb256 >= (minb * 3) / 5 && nkt64 >= 144)) && igemm8p_ok<T>(a)) return 0;
+  }
+  const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
+  if (a.OC > 64 && nkt >= 16 && blocks(128, 128) >= 256) return 0;
+  const long long nb = blocks(64, 64);
+  if (nb <= 128 && nkt >= 32) return 4;
+  if (nb <= 256 && nkt >= 16) return 2;
+  return 1;
+}
+
+template <class T>
+static int launch_bna(const ConvArgs& a0, hipStream_t st, int choice) {
+  ConvArgs a = a0;
+  const long long M = (long long)a.N * a.OH * a.OW;
+  const long long nb = ((M + 63) / 64) * ((a.OC + 63) / 64);
+  const size_t tab = (size_t)2 * a.C * sizeof(float);
+  if (choice >= 100) {
+    a.xk_S = choice - 100; a.xk_part = g_scratch.xk_part; a.xk_tick = g_scratch.tick;
+    hipLaunchKernelGGL((igemm_xk_bna_kernel<T>), dim3((unsigned)(nb * a.xk_S)), dim3(256), (size_t)2 * 128 * 144 + tab, st, a);
+    return check_launch("emrt_conv2d_bna");
+  }
+  const int G = choice;
+  size_t lds = (size_t)G * 2 * 128 * 144 + tab;
+  if (G > 1 && lds < (size_t)(G - 1) * 16 * 256 * 4) lds = (size_t)(G - 1) * 16 * 256 * 4;
+  static bool attr_done = false;      // one flag per element type
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_bna_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_bna_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail("emrt_conv2d_bna", "cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  if (G == 1) hipLaunchKernelGGL((igemm_bna_kernel<T, 1>), dim3((unsigned)nb), dim3(256), lds, st, a);
+  else if (G == 2) hipLaunchKernelGGL((igemm_bna_kernel<T, 2>), dim3((unsigned)nb), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((igemm_bna_kernel<T, 4>), dim3((unsigned)nb), dim3(1024), lds, st, a);
+  return check_launch("emrt_conv2d_bna");
+}
+
+static int bna_fill(ConvArgs& a, const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin,
+                    long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad,
+                    int relu, int out_f32, double* bn_stats, int dilation, const double* sums, double count, float eps, float momentum, float* mean,
+                    float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int in_relu, void* a_out) {
+  a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.scale = nullptr; a.res = residual;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.ldin = ldin; a.in_bs = in_bs; a.OH = OH; a.OW = OW; a.OC = OC; a.ldout = ldout; a.out_bs = out_bs;
+  a.ldres = ldres; a.res_bs = res_bs; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dilation; a.relu = relu; a.out_f32 = out_f32;
+  a.cmajor = 0; a.stats = bn_stats; a.mask_y = nullptr; a.ldy = 0; a.y_bs = 0; a.mask_scale = 1.f; a.stat_x = nullptr; a.ldsx = 0; a.sx_bs = 0;
+  a.xk_S = 0; a.xk_part = nullptr; a.xk_tick = nullptr; a.drop_seed = nullptr; a.drop_salt = 0; a.drop_p = 0.f;
+  a.bna.sums = sums; a.bna.inv_count = count > 0.0 ? 1.0 / count : 0.0; a.bna.eps = eps; a.bna.momentum = momentum; a.bna.mean = mean; a.bna.invstd = invstd;
+  a.bna.run_mean = run_mean; a.bna.run_var = run_var; a.bna.gamma = gamma; a.bna.beta = beta; a.bna.relu = in_relu;
+  a.a_out = a_out;
+  return 0;
+}
+
+// 1 when emrt_conv2d_bna would run these arguments (same argument list), 0 when the caller has to apply the BatchNorm with its own launch
+// (emrt_bn_apply) and call emrt_conv2d -- the layer's tile has no operand transform, or the geometry is outside it (not 1x1 / 3x3 "same" stride 1,
+// C not a multiple of 64 (32 in fp32) or > 1024, OC <= 32, unaligned rows).  No launch, no error state.
+extern "C" int emrt_conv2d_bna_supported(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C,
+                                         int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH,
+                                         int KW, int stride, int pad, int relu, int out_f32, double* bn_stats, int dilation, const double* sums, double count,
+                                         float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                                         const float* beta, int in_relu, void* a_out, int dtype, void* stream) {
+  if (!(dtype == EMRT_F32 || dtype == EMRT_BF16) || !in || !w_packed || !out || !sums || !mean || !invstd || !gamma || !beta || !a_out || count <= 0.0) return 0;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OC <= 0 || dilation < 1 || g_tune.no_bna == 1) return 0;
+  const long long esz = dtype == EMRT_F32 ? 4 : 2;
+  if ((long long)N * H * W * C * esz >= (1ll << 31) || (long long)N * H * W + 512 >= (1ll << 31)) return 0;
+  if (((long long)(N - 1) * in_bs + ((long long)H * W - 1) * ldin + C) * esz >= (1ll << 31) || (long long)OC * KH * KW * C * esz >= (1ll << 31)) return 0;
+  ConvArgs a;
+  bna_fill(a, in, w_packed, out, bias, residual, N, H, W, C, ldin, in_bs, OH, OW, OC, ldout, out_bs, ldres, res_bs, KH, KW, stride, pad, relu, out_f32, bn_stats,
+           dilation, sums, count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, in_relu, a_out);
+  hipStream_t st = (hipStream_t)stream;
+  return (dtype == EMRT_F32 ? bna_choice<float>(a, st) : bna_choice<bf16_t>(a, st)) != 0 ? 1 : 0;
+}
+
+// out = conv([relu](BatchNorm_train(in))) with the BatchNorm applied by the convolution's own operand loads and the normalised map written to a_out
+// (dense [N][H][W][C]) on the way: replaces emrt_bn_apply + emrt_conv2d for the BatchNorm -> ReLU -> conv chains of the backbone
+// (paddle_vision_resnet.py:129-149: bn1 -> relu -> conv2, bn2 -> relu -> conv3), of Conv2dBlock and cls_psp (paddle_EMRT.py:16-23,201-209).  The
+// convolution's arguments are emrt_conv2d's (forward: mode 0, no mask, no folded scale), the BatchNorm's are emrt_bn_apply's (sums complete; mean /
+// invstd saved and the running statistics updated by one block).  Fails when emrt_conv2d_bna_supported says 0.
+extern "C" int emrt_conv2d_bna(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C,
+                               int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH,
+                               int KW, int stride, int pad, int relu, int out_f32, double* bn_stats, int dilation, const double* sums, double count,
+                               float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                               const float* beta, int in_relu, void* a_out, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(in && w_packed && out && sums && mean && invstd && gamma && beta && a_out, "null pointer");
+  EMRT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && OC > 0 && dilation >= 1 && count > 0.0, "bad dims");
+  EMRT_REQUIRE((run_mean != nullptr) == (run_var != nullptr), "running statistics come in pairs");
+  EMRT_REQUIRE(a_out != out && a_out != in, "a_out is a buffer of its own");
+  EMRT_REQUIRE((long long)N * OH * OW + 512 < (1ll << 31), "more than 2^31 pixels (32-bit pixel arithmetic)");
+  {
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long in_ext = ((long long)(N - 1) * in_bs + ((long long)H * W - 1) * ldin + C) * esz;
+    EMRT_REQUIRE(in_bs >= 0 && in_ext < (1ll << 31) && (long long)OC * KH * KW * C * esz < (1ll << 31) && (long long)N * H * W * C * esz < (1ll << 31),
+                 "operand spans 2 GiB or more (32-bit buffer offsets)");
+  }
+  ConvArgs a;
+  bna_fill(a, in, w_packed, out, bias, residual, N, H, W, C, ldin, in_bs, OH, OW, OC, ldout, out_bs, ldres, res_bs, KH, KW, stride, pad, relu, out_f32, bn_stats,
+           dilation, sums, count, eps, momentum, mean, invstd, run_mean, run_var, gamma, beta, in_relu, a_out);
+  hipStream_t st = (hipStream_t)stream;
+  const int choice = dtype == EMRT_F32 ? bna_choice<float>(a, st) : bna_choice<bf16_t>(a, st);
+  EMRT_REQUIRE(choice != 0, "this layer has no operand-transform kernel (ask emrt_conv2d_bna_supported first)");
+  return dtype == EMRT_F32 ? launch_bna<float>(a, st, choice) : launch_bna<bf16_t>(a, st, choice);
 }
 
 // vector path eligibility of a weight-gradient problem

@@ -334,9 +334,14 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     c = ctx()
     if drop is not None and not (c.training and drop[0] > 0.0):
         drop = None
+    pend = None
     if isinstance(x, PendingBN):
-        assert stride == 1 and pad == 0 and not relu and residual is None and out is None and not out_f32 and bn_stats is None and out_scale is None
-        return _pointwise_on_pending(x, w)
+        if pointwise_takes_pending(w, x.C) and x.relu:
+            assert stride == 1 and pad == 0 and not relu and residual is None and out is None and not out_f32 and bn_stats is None and out_scale is None
+            return _pointwise_on_pending(x, w)
+        # a conv -> BatchNorm (-> ReLU) -> conv chain: this convolution applies the BatchNorm with its own operand loads when its kernel has the
+        # transform (emrt_conv2d_bna_supported, asked below once the geometry is known); otherwise the BatchNorm gets its own launch after all
+        pend, x = x, x.raw
     N, H, W, C, ldin, in_bs = _check_map(x)
     assert C == w.C, (C, w.C)
     dil = int(dilation)
@@ -353,8 +358,25 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
     assert out_scale is None or c.tape is None, "BatchNorm folding is inference only"     # (out_shift already holds w.bias * scale)
     fused_drop = (drop is not None and relu and w.KH * w.KW == 1 and stride == 1 and pad == 0 and residual is None and not out_f32 and bn_stats is None
                   and out_scale is None and w.OC % 8 == 0 and in_bs == H * W * ldin and out_bs == OH * OW * ldout and c.fuse_ffn_dropout
-                  and C % 8 == 0 and ldin % 8 == 0 and ldout % 8 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
-    if fused_drop:
+                  and C % 8 == 0 and ldin % 8 == 0 and ldout % 8 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and pend is None)
+    bna_done = False
+    if pend is not None:
+        bn = pend.bn
+        a = c.empty(tuple(x.shape))          # relu(BatchNorm(raw)): written by the convolution (its first tile column) when it takes the operand form
+        bna_args = (P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), P(residual), N, H, W, C, ldin, in_bs, OH, OW, w.OC, ldout, out_bs, ldres, res_bs,
+                    w.KH, w.KW, stride, pad, int(relu), int(out_f32), P(bn_stats), dil, P(pend.sums), float(pend.count), bn.eps, bn.momentum, P(pend.mean),
+                    P(pend.invstd), P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), int(pend.relu), P(a), c.dtype, c.stream)
+        if c.training and c.bn_conv and drop is None and out_scale is None and _L().query("emrt_conv2d_bna_supported", *bna_args):
+            _L().call("emrt_conv2d_bna", *bna_args)
+            # the BatchNorm's backward, recorded BEFORE this layer's own (it runs after it): as if emrt_bn_apply had written `a`
+            x = batch_norm(x, bn, relu=pend.relu, out=a, sums=pend.sums, _applied=(pend.mean, pend.invstd, pend.count))
+            bna_done = True
+        else:
+            x = pend.materialize()
+        _, _, _, _, ldin, in_bs = _check_map(x)
+    if bna_done:
+        pass
+    elif fused_drop:
         _L().call("emrt_conv2d_drop", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), N * H * W, C, ldin, w.OC, ldout, float(drop[0]), c.seed_ptr,
                   int(drop[1]), c.dtype, c.stream)
     else:
@@ -505,9 +527,12 @@ def _allreduce_sums(sums, count):
     return count * dist.get_world_size()
 
 
-def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
+def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None, _applied=None):
     """y = [relu](BN(x) [+ residual]).  Training uses batch statistics from the fp64 `sums` [2C] that the producing conv's
-    epilogue accumulated (or from a statistics pass when `sums` is None), all-reduced over ranks when bn.sync."""
+    epilogue accumulated (or from a statistics pass when `sums` is None), all-reduced over ranks when bn.sync.
+    _applied = (mean, invstd, count): `out` already holds the result and mean / invstd are (being) saved -- the consuming convolution applied this
+    BatchNorm with its own operand loads and wrote the normalised map on the way (conv2d on a PendingBN: emrt_conv2d_bna) -- so nothing is launched
+    here and only the backward is recorded, exactly as for the separate launch."""
     c = ctx()
     N, H, W, C, ldx, x_bs = _check_map(x)
     assert x_bs == H * W * ldx, "batch_norm input must be a dense NHWC tensor (possibly channel-sliced)"
@@ -527,7 +552,10 @@ def batch_norm(x, bn, relu=False, residual=None, out=None, sums=None):
         assert r_bs == H * W * ldres
     count = M
     mean = invstd = None
-    if c.training:
+    if _applied is not None:
+        assert c.training and residual is None and out is not None
+        mean, invstd, count = _applied
+    elif c.training:
         mean = c.empty((C,), torch.float32)
         invstd = c.empty((C,), torch.float32)
         if sums is None:
@@ -613,6 +641,16 @@ class PendingBN:
         self.mean = c.empty((C,), torch.float32)
         self.invstd = c.empty((C,), torch.float32)
 
+    def materialize(self):
+        """The ordinary path after all: relu(BatchNorm(raw)) through emrt_bn_apply (the sums are complete, and all-reduced where the layer is a
+        SyncBatchNorm), with the usual backward.  For a consumer that turns out not to take the operand form (conv2d: emrt_conv2d_bna_supported)."""
+        c = ctx()
+        bn, C = self.bn, self.C
+        out = c.empty(tuple(self.raw.shape))
+        _L().call("emrt_bn_apply", P(self.raw), C, None, 0, P(out), C, P(self.sums), float(self.count), bn.eps, bn.momentum, P(self.mean), P(self.invstd),
+                  P(bn.run_mean), P(bn.run_var), P(bn.gamma), P(bn.beta), self.M, C, int(self.relu), c.dtype, c.stream)
+        return batch_norm(self.raw, bn, relu=self.relu, out=out, sums=self.sums, _applied=(self.mean, self.invstd, self.count))
+
     def operand(self):
         """the BatchNorm arguments of emrt_bn_resize_bilinear_fwd / emrt_bn_maxpool_fwd"""
         bn = self.bn
@@ -686,7 +724,9 @@ def _pointwise_on_pending(pend, w):
 def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
     """conv -> BatchNorm with the batch statistics accumulated in the conv's epilogue (training).  Inference: the BatchNorm is
     an affine map of running statistics and is folded into the conv's epilogue -- no BatchNorm launch, no intermediate tensor.
-    defer=True (training, when the only consumer is resize_bilinear or maxpool): returns a PendingBN instead of launching emrt_bn_apply."""
+    defer=True (training, when the only consumer is resize_bilinear or maxpool): returns a PendingBN instead of launching emrt_bn_apply.
+    defer="conv" (training, when the only consumer is a conv2d / conv_bn): the same; that convolution applies the BatchNorm with its operand loads
+    (emrt_conv2d_bna) or, when its kernel has no such form, launches emrt_bn_apply itself (PendingBN.materialize)."""
     c = ctx()
     if c.fold_live and not c.training and c.tape is None and (conv.gw.bias is None or bn.state.fold_conv is conv):
         scale, shift = bn.state.fold_scale, bn.state.fold_shift      # ParamStore.fold_bn(): refreshed at the top of every eval forward
@@ -698,7 +738,9 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
     # a divisor of 256 -- C / 4 in fp32); a PendingBN has no fallback once created, so anything else takes the separate emrt_bn_apply here
     per16 = 4 if c.dtype == F32 else 8
     fits = bn.C % per16 == 0 and bn.C <= 1024 and 256 % (bn.C // per16) == 0
-    if defer and c.training and c.bn_defer and residual is None and out is None and (fits or defer == "join"):
+    if defer == "conv" and not c.bn_conv:
+        defer = False
+    if defer and c.training and c.bn_defer and residual is None and out is None and (fits or defer in ("join", "conv")):
         count = y.shape[0] * y.shape[1] * y.shape[2]
         if _sync_active(bn.state):
             count = _allreduce_sums(sums, count)

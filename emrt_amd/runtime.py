@@ -234,6 +234,9 @@ class Context:
         # training: a BatchNorm + ReLU whose only consumer streams the map once (x2 resize, 3x3 max-pool) is applied by that consumer's
         # loads instead of its own emrt_bn_apply launch (functional.PendingBN).  0 = always the separate launch (A/B knob).
         self.bn_defer = bool(int(os.environ.get("EMRT_BN_DEFER", "1")))
+        # ... and a BatchNorm + ReLU between two convolutions by the consuming convolution's operand loads (emrt_conv2d_bna: the 64x64-tile kernels transform
+        # the raw map between its global load and the LDS write, the first tile column writes the normalised map backward needs).  0 = A/B knob.
+        self.bn_conv = bool(int(os.environ.get("EMRT_BN_CONV", "1")))
         self.group_attn_proj = bool(int(os.environ.get("EMRT_GROUP_ATTN_PROJ", "1")))      # A/B: value_proj and the offsets | logits projection as one grouped launch
         self.fuse_ffn_dropout = bool(int(os.environ.get("EMRT_FFN_DROPOUT_FUSED", "1")))      # A/B: dropout(relu(linear1)) drawn in the GEMM epilogue (emrt_conv2d_drop)
         # the query of the NEXT attention (out + pos) written by the LayerNorm launch that produces `out`, its gradient summed by that LayerNorm's backward

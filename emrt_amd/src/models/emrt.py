@@ -58,7 +58,7 @@ class BasicBlock(hnn.HipLayer):  # :43-88
         self.downsample = downsample
 
     def forward(self, x):
-        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True, defer="conv")      # BatchNorm + ReLU applied by conv2's operand loads
         # (the shortcut's BatchNorm is applied by the join's loads: Fn.batch_norm with a PendingBN residual)
         identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x, defer="join")
         return Fn.conv_bn(self.conv2, self.bn2, out, relu=True, residual=identity)
@@ -78,8 +78,10 @@ class BottleneckBlock(hnn.HipLayer):  # :91-149
         self.downsample = downsample
 
     def forward(self, x):
-        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True)
-        out = Fn.conv_bn(self.conv2, self.bn2, out, relu=True)
+        # bn1 -> relu -> conv2 and bn2 -> relu -> conv3 (paddle_vision_resnet.py:129-149): each BatchNorm + ReLU is applied by the NEXT convolution's
+        # operand loads (Fn.conv2d on a PendingBN: emrt_conv2d_bna), which writes the normalised map backward needs on the way
+        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True, defer="conv")
+        out = Fn.conv_bn(self.conv2, self.bn2, out, relu=True, defer="conv")
         identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x, defer="join")
         return Fn.conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
 
@@ -558,7 +560,7 @@ class Conv2dBlock(hnn.HipLayer):  # :13-29
         self.conv2 = hnn.Sequential(hnn.Conv2D(cout, cout, 3, 1, 1, bias=False), hnn.BatchNorm2D(cout), None)
 
     def forward(self, x):
-        o = Fn.conv_bn(self.conv1[0], self.conv1[1], x, relu=True)
+        o = Fn.conv_bn(self.conv1[0], self.conv1[1], x, relu=True, defer="conv")
         o = Fn.conv_bn(self.conv2[0], self.conv2[1], o, relu=True)
         return Fn.add_maps(o, x)
 
@@ -824,7 +826,7 @@ class EMRT(hnn.HipLayer):  # :184-304
         nps = len(self.psp_scale)
         self.EFP(maps[0], maps[1], maps[2], out=Fn.narrow(psp_cat, 3, 256 * (1 + nps), 256))
         Fn.pyramid_tokens_to_maps(hs, self.psp_scale, SH, SW, [Fn.narrow(psp_cat, 3, 256 * (1 + i), 256) for i in range(nps)])  # :281-291
-        o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True)
+        o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True, defer="conv")
         o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
         o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW, sole_consumer_is_linear=True)   # UpHead's conv_0 is its only consumer
         logits = self.uphead(o)

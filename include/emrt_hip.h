@@ -37,7 +37,7 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
  * conv_tile, wgrad_split, no_ksplit128, ln_bwd_rows, ln_bwd_max_blocks, wgrad_no_overwrite, bn_operand_blocks, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
  * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
- * gn_bwd_stat_rows, gn_apply_rows, xk, mha_valu, msda_scatter_merge, msda_scatter_mfma, msda_mf_bands, sgd_nt, ln_bwd_threads.
+ * gn_bwd_stat_rows, gn_apply_rows, xk, mha_valu, msda_scatter_merge, msda_scatter_mfma, msda_mf_bands, sgd_nt, ln_bwd_threads, no_bna.
  * Not thread-safe against concurrent launches; production code never calls these. */
 int emrt_set_tuning(const char* name, int value);
 int emrt_get_tuning(const char* name, int* value);
@@ -71,6 +71,15 @@ int emrt_conv2d(const void* in, const void* w_packed, void* out, const float* bi
  * dtype 0 / 1.  Kept values are scaled by 1 / (1 - p).  Backward: emrt_conv2d_bwd of the CONSUMER with mask_y = out, mask_scale = 1 / (1 - p)
  * (a stored value > 0 <=> kept and past the ReLU), then emrt_conv2d_bwd of this layer on the masked gradient: no mask tensor, no seed. */
 int emrt_conv2d_drop(const void* in, const void* w_packed, void* out, const float* bias, int M, int C, int ldin, int OC, int ldout, float p, const unsigned long long* seed, unsigned salt, int dtype, void* stream);
+
+/* ABI 8: out = conv([relu](BatchNorm_train(in))) with the BatchNorm applied by the convolution's own operand loads (`in` is the RAW output of the producing
+ * conv; the normalised map is written to a_out, dense [N][H][W][C], on the way) -- emrt_bn_apply + emrt_conv2d in one launch for the BatchNorm -> ReLU -> conv
+ * chains of paddle_vision_resnet.py:129-149 (bn1 -> relu -> conv2, bn2 -> relu -> conv3), paddle_EMRT.py:16-23 (Conv2dBlock) and :201-209 (cls_psp).  Convolution
+ * arguments as emrt_conv2d (forward), BatchNorm arguments as emrt_bn_apply (sums complete; mean / invstd saved, running statistics updated).  1x1 / 3x3 "same"
+ * stride-1 layers on the 64x64-tile kernels only: emrt_conv2d_bna_supported (same arguments; no launch, no error state) says whether this layer is one, and
+ * the caller keeps the two-launch form otherwise.  Bit-identical to the two-launch form (out AND a_out). */
+int emrt_conv2d_bna_supported(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int relu, int out_f32, double* bn_stats, int dilation, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int in_relu, void* a_out, int dtype, void* stream);
+int emrt_conv2d_bna(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int relu, int out_f32, double* bn_stats, int dilation, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int in_relu, void* a_out, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream);
 /* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE

@@ -1708,6 +1708,129 @@ def test_adaptive_pool_split_bins(dtype, H, W, C, Ctot):
 
 
 # -----------------------------------------------------------------------------------------------------------------
+# BatchNorm + ReLU between two convolutions applied by the CONSUMING convolution's operand loads (emrt_conv2d_bna; csrc/conv.hip: igemm_body BNA)
+# -----------------------------------------------------------------------------------------------------------------
+BNA_CASES = [
+    # name, N, H, W, Cin, C (the BatchNorm's channels), OC, k, dilation, knobs forcing the kernel variant, consumer ReLU
+    ("layer1 bn2->conv3 1x1, plain tile", 2, 32, 32, 64, 64, 256, 1, 1, {}, False),
+    ("layer1 bn1->conv2 3x3, plain tile", 2, 32, 32, 32, 64, 64, 3, 1, {}, False),
+    ("ragged M, 3x3, two wave groups", 3, 7, 9, 64, 128, 128, 3, 1, {"conv_tile": 5}, False),
+    ("ragged M, 3x3, four wave groups", 3, 7, 9, 64, 256, 256, 3, 1, {"conv_tile": 6}, False),
+    ("layer4-like 3x3, cross-block K split x3", 2, 8, 8, 64, 512, 512, 3, 1, {"xk": 3}, False),
+    ("1x1, cross-block K split x2", 2, 8, 8, 64, 512, 128, 1, 1, {"xk": 2}, False),
+    ("dilated 3x3 (resnet50c)", 2, 12, 12, 64, 128, 128, 3, 2, {}, False),
+    ("1x1 with ragged OC and consumer ReLU", 1, 10, 14, 64, 128, 72, 1, 1, {}, True),
+    ("auto dispatch at a layer3 shape (3x3, 256 ch, 16x16)", 8, 16, 16, 64, 256, 256, 3, 1, {}, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", BNA_CASES, ids=[c_[0] for c_ in BNA_CASES])
+def test_batchnorm_relu_applied_by_the_consuming_convolutions_loads(dtype, case):
+    """conv -> BatchNorm(train) -> ReLU -> conv -> BatchNorm (paddle_vision_resnet.py:129-149 bn1 -> relu -> conv2, bn2 -> relu -> conv3; paddle_EMRT.py:16-23,
+    201-209) with the first BatchNorm applied by the SECOND convolution's operand loads: the raw map goes through relu(x * scale + shift) between the
+    global load and the LDS write, the first tile column writes the normalised map on the way, and no emrt_bn_apply is launched.  The arithmetic is the
+    separate launch's (same fmaf, max, rounding), so EVERYTHING must be bit-identical to the two-launch form: the consumer's output and its batch sums
+    (through the second BatchNorm's output), the normalised map (through every gradient of the backward, which reads it), saved mean / invstd and the
+    running statistics.  Negative gammas, padding taps (zeros of the NORMALISED map), ragged M / OC, dilation, every kernel variant forced in turn."""
+    from emrt_amd import _lib
+    name, N, H, W, Cin, C, OC, k, dil, knobs, relu2 = case
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w1 = torch.randn(C, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    w2 = torch.randn(OC, C, k, k, generator=g) / math.sqrt(C * k * k)
+    gam = torch.rand(C, generator=g) + 0.5
+    gam[::3] *= -1.0
+    bet = torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(N, OC, H, W, generator=g)
+    L = _lib.lib()
+    with_bn2 = 256 % (OC // 4) == 0 if OC % 4 == 0 else False
+
+    def run(fused):
+        c = init(dtype)
+        c.bn_conv = fused
+        conv1, bn1 = hnn.Conv2D(Cin, C, 1, bias=False), hnn.BatchNorm2D(C)
+        conv2, bn2 = hnn.Conv2D(C, OC, k, 1, dil * (k // 2), bias=False, dilation=dil), hnn.BatchNorm2D(OC)
+        with torch.no_grad():
+            conv1.weight.copy_(rnd(w1))
+            conv2.weight.copy_(rnd(w2))
+            bn1.weight.copy_(gam)
+            bn1.bias.copy_(bet)
+        Holder(conv1=conv1, bn1=bn1, conv2=conv2, bn2=bn2).place()
+        xd = dev_map(rnd(x))
+        old = [(kk, L.set_tuning(kk, v)) for kk, v in list(knobs.items()) + [("no_bna", -1)]]      # (-1: also the long-k 3x3 layers the dispatcher declines)
+        try:
+            tape = Tape()
+            c.tape = tape
+            L.start_record()
+            a = Fn.conv_bn(conv1, bn1, xd, relu=True, defer="conv")
+            if with_bn2:
+                out = Fn.conv_bn(conv2, bn2, a, relu=relu2)
+            else:      # (a channel count emrt_bn_apply does not take: the consumer alone, with its ReLU in the GEMM epilogue)
+                out = Fn.conv2d(a, conv2.gw, 1, dil * (k // 2), relu=relu2, dilation=dil)
+            names = [n for n, _ in L.stop_record()]
+            c.tape = None
+            tape.watch(xd)
+            dx, = run_bwd(tape, [(out, dev_map(rnd(dy)))], [xd])
+            torch.cuda.synchronize()
+        finally:
+            for kk, v in old:
+                L.set_tuning(kk, v)
+            c.bn_conv = True
+        return names, [host_map(out), host_map(dx), host(conv1.weight.grad), host(conv2.weight.grad), host(bn1.weight.grad), host(bn1.bias.grad),
+                       host(bn2.weight.grad), host(bn2.bias.grad), host(bn1._buffers["_mean"]), host(bn1._buffers["_variance"]),
+                       host(bn2._buffers["_mean"]), host(bn2._buffers["_variance"])]
+
+    names, res = run(True)
+    names0, res0 = run(False)
+    assert names.count("emrt_conv2d_bna") == 1 and names.count("emrt_bn_apply") == int(with_bn2), names          # (the one left is the second BatchNorm's)
+    assert names0.count("emrt_conv2d_bna") == 0 and names0.count("emrt_bn_apply") == 1 + int(with_bn2), names0
+    labels = ("out", "dx", "dW1", "dW2", "dgamma1", "dbeta1", "dgamma2", "dbeta2", "running mean 1", "running var 1", "running mean 2", "running var 2")
+    for u, v, lab in zip(res, res0, labels):
+        assert torch.isfinite(u).all(), lab
+        if lab in ("dW1", "dW2"):      # (batched weight gradients: fp32 atomics, the order of the last bits is free)
+            assert ((u - v).norm() / v.norm().clamp_min(1e-20)).item() < 2e-6, lab
+        else:
+            assert torch.equal(u, v), "%s: %s differs from the two-launch form by up to %.3g" % (name, lab, (u - v).abs().max().item())
+    # ... and the two-launch form is what torch computes (fp32)
+    if dtype == F32:
+        xr = x.clone()
+        y1 = F.conv2d(xr, w1)
+        a1 = F.relu(F.batch_norm(y1, None, None, gam, bet, True, 0.1, 1e-5))
+        y2 = F.conv2d(a1, w2, padding=dil * (k // 2), dilation=dil)
+        o = F.batch_norm(y2, None, None, None, None, True, 0.1, 1e-5) if with_bn2 else y2
+        if relu2:
+            o = F.relu(o)
+        close("fused chain vs torch", res[0], o, dtype, 4.0)
+
+
+def test_conv2d_bna_is_refused_outside_its_kernels():
+    """emrt_conv2d_bna_supported answers 0 -- and the host then launches emrt_bn_apply itself (PendingBN.materialize) -- for a stride-2 consumer, for the
+    thin OC <= 32 tile, and with the A/B knob; emrt_conv2d_bna itself fails loudly on such a layer instead of running something else."""
+    from emrt_amd import _lib
+    L = _lib.lib()
+    c = init(BF16)
+    g = torch.Generator().manual_seed(4)
+    for (C, OC, k, stride, knob) in ((64, 64, 3, 2, None), (64, 16, 1, 1, None), (64, 64, 3, 1, "no_bna"), (256, 64, 3, 1, None)):
+        conv1, bn1 = hnn.Conv2D(32, C, 1, bias=False), hnn.BatchNorm2D(C)
+        conv2, bn2 = hnn.Conv2D(C, OC, k, stride, k // 2, bias=False), hnn.BatchNorm2D(OC)
+        Holder(conv1=conv1, bn1=bn1, conv2=conv2, bn2=bn2).place()
+        xd = dev_map(rnd(torch.randn(2, 32, 16, 16, generator=g)))
+        old = L.set_tuning(knob, 1) if knob else None
+        try:
+            tape = Tape()
+            c.tape = tape
+            L.start_record()
+            out = Fn.conv_bn(conv2, bn2, Fn.conv_bn(conv1, bn1, xd, relu=True, defer="conv"), relu=True)
+            names = [n for n, _ in L.stop_record()]
+            c.tape = None
+        finally:
+            if knob:
+                L.set_tuning(knob, old)
+        assert "emrt_conv2d_bna" not in names and names.count("emrt_bn_apply") == 2 and torch.isfinite(out.float()).all(), names
+
+
+# -----------------------------------------------------------------------------------------------------------------
 # BatchNorm + ReLU applied by the loads of a streaming consumer (functional.PendingBN, csrc/bn_operand.hpp)
 # -----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -95,12 +95,21 @@ def test_train_step_launch_sequence(fake, backbone):
     # ... and the shortcut BatchNorm of every stage's first block by the join that adds it (emrt_bn_apply_join)
     n_join_defer = cnt["emrt_bn_apply_join"]
     assert n_join_defer == sum(1 for mod in m.modules() if getattr(mod, "downsample", None) is not None) > 0
-    n_defer = n_stream + 1 + n_join_defer
+    # ... and the BatchNorm + ReLU between two convolutions by the consuming convolution's operand loads (emrt_conv2d_bna; the fake library says
+    # "supported" for every layer): bn1 -> conv2 of every block, bn2 -> conv3 of every bottleneck, Conv2dBlock's first BatchNorm (x3), cls_psp's first
+    n_blocks = sum(1 for mod in m.modules() if type(mod).__name__ in ("BasicBlock", "BottleneckBlock"))
+    n_bottle = sum(1 for mod in m.modules() if type(mod).__name__ == "BottleneckBlock")
+    n_conv_fused = cnt["emrt_conv2d_bna"]
+    assert n_conv_fused == n_blocks + n_bottle + 3 + 1
+    bna = [a for n, a in fake.calls if n == "emrt_conv2d_bna"]
+    assert all(a[26] is not None and a[37] is not None and a[36] == 1 for a in bna)      # sums, a_out, ReLU
+    n_defer = n_stream + 1 + n_join_defer + n_conv_fused
     assert cnt["emrt_bn_apply"] + cnt["emrt_bn_apply_join"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
+    bna_stats = sum(1 for a in bna if a[24] is not None)      # (emrt_conv2d_bna: bn_stats is argument 24)
     assert not any(n == "emrt_conv2d" and a[22] == 1 for n, a in fake.calls)      # data gradients go through emrt_conv2d_bwd
     dgrads = [a for n, a in fake.calls if n == "emrt_conv2d_bwd"]
-    assert sum(1 for a in fwd_convs if a[25] is not None) == n_bn     # forward statistics fused into the conv epilogue
+    assert sum(1 for a in fwd_convs if a[25] is not None) + bna_stats == n_bn     # forward statistics fused into the conv epilogue
     # BatchNorm -> ReLU -> conv chains: the conv's dgrad carries the ReLU mask and the BatchNorm's backward sums, and the
     # separate reduction pass only remains for the other BatchNorms (residual joins, multi-consumer outputs, no ReLU)
     n_fused = sum(1 for a in dgrads if a[24] is not None)

@@ -64,7 +64,7 @@ CONV_FWD = lambda k: ("igemm" in k or "thin_fwd" in k) and not CONV_BWD(k)
 
 
 CONV_BWD_CALLS = ("emrt_conv2d_bwd", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group", "emrt_bn_pointwise_bwd")
-CONV_FWD_CALLS = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
+CONV_FWD_CALLS = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_bna", "emrt_conv2d_group", "emrt_bn_pointwise_fwd")
 
 
 def call_counts(calls_path):
@@ -163,7 +163,7 @@ def layer_table(dst, step, a, b, names, sq_d, trace_d, calls_path):
         m = re.match(r"(\S+)\s+([\d.]+) ms\s+(.*)", ln)
         if m:
             calls.append((m.group(1), float(m.group(2)) * 1e3, m.group(3)))
-    conv_names = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_bwd", "emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group",
+    conv_names = ("emrt_conv2d", "emrt_conv2d_drop", "emrt_conv2d_bna", "emrt_conv2d_bwd", "emrt_conv2d_group", "emrt_conv2d_bwd_group", "emrt_conv2d_wgrad", "emrt_conv2d_wgrad_group",
                   "emrt_bn_pointwise_fwd", "emrt_bn_pointwise_bwd")
     is_conv_kernel = lambda k: "igemm" in k or "wgrad" in k or "thin_bwd" in k or "thin_fwd" in k or "bwd_pair" in k or "bwd_group" in k
     wg_kernels = lambda k: "wgrad" in k
