@@ -229,17 +229,30 @@ def rooflines(calls, dtype_name, cfg_key, train):
     # what a HIP-event pair costs around a launch that does nothing: the per-launch figures above all contain it
     trivial = [ms_ for name, a, ms_ in calls if name in ("emrt_counter_add", "emrt_scalar_axpby")]
     triv_ms = min(trivial) if trivial else 0.0
-    net_ms = max(ms - cnt * triv_ms, 1e-6)
-    roofline = {"kernel": "; ".join(GEMM_FAMILIES[k] for k in names if k in fam), "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
+    # ONE clock for `achieved` / `frac`: the kernel-duration clock (what rocprofv3 --kernel-trace reports per dispatch).  A HIP-event pair reads the
+    # kernel's duration PLUS what the pair itself costs; that cost is measured in the same replay (the pair around nothing, 64 times: EMPTY_PAIR_MS)
+    # and subtracted once per event pair -- a C-ABI call that makes several dispatches (a batched weight gradient: kernel + reduce) still has ONE pair.
+    pair_ms = EMPTY_PAIR_MS[0]
+    kern_ms = max(ms - cnt * pair_ms, 1e-6)
+    all_cnt = sum(fam.get(k, [0, 0.0, 0.0])[0] for k in GEMM_FAMILIES)
+    all_kern_ms = max(all_ms - all_cnt * pair_ms, 1e-6)
+    total_kern_ms = max(total_ms - len(calls) * pair_ms, 1e-6)
+    ach_k = fl / kern_ms / 1e9
+    roofline = {"kernel": "; ".join(GEMM_FAMILIES[k] for k in names if k in fam), "bound": "mfma", "achieved": round(ach_k, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach_k / peak, 4), "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(1e3 * kern_ms / cnt, 2),
+                "clock": "kernel durations: HIP-event pair per launch minus the empty pair's reading (event_pair_us)",
+                "event_pair_us": round(1e3 * pair_ms, 2),
                 "algorithmic_gflop_per_step": round(fl / 1e9, 1), "algorithmic_bytes_per_launch": int(by / cnt),
-                "achieved_net_of_event_cost": round(fl / net_ms / 1e9, 2), "frac_net_of_event_cost": round(fl / net_ms / 1e9 / peak, 4),
-                "share_of_step_kernel_time": round(ms / total_ms, 3),
-                "all_gemm_tflops": round(all_fl / all_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_ms / total_ms, 3),
+                "achieved_event_clock": round(ach, 2), "frac_event_clock": round(ach / peak, 4),
+                "share_of_step_kernel_time": round(kern_ms / total_kern_ms, 3),
+                "all_gemm_tflops": round(all_fl / all_kern_ms / 1e9, 2), "all_gemm_share_of_step_kernel_time": round(all_kern_ms / total_kern_ms, 3),
+                "step_kernel_time_ms": round(total_kern_ms, 3),
                 "event_timed_trivial_launch_us": round(1e3 * triv_ms, 2) if trivial else None,
                 "method": "recorded launches of one step replayed back-to-back behind a backlog, HIP-event pair on the launch stream around each launch; "
-                          "achieved = algorithmic FLOPs / sum of those times (event_timed_trivial_launch_us = what the same pair reads around a one-thread "
-                          "kernel: included in every launch's figure; *_net_of_event_cost subtracts it per launch)"}
+                          "kernel time of a launch = its pair's reading minus the reading of the same pair around nothing (event_pair_us, median of 64 in "
+                          "the same replay); achieved = algorithmic FLOPs / sum of those kernel times -- the clock rocprofv3 --kernel-trace uses "
+                          "(profiles/r6*_timeline_summary_cfg2.txt holds the same families from rocprofv3).  *_event_clock: the uncorrected readings; "
+                          "event_timed_trivial_launch_us: what the pair reads around a one-thread kernel"}
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this config (bench.py cannot profile itself): newest round
     pmc = None
     import glob
@@ -249,6 +262,11 @@ def rooflines(calls, dtype_name, cfg_key, train):
         with open(cands[-1]) as f:
             pmc = json.load(f)
         pmc_src = os.path.relpath(cands[-1], ROOT)
+    if pmc is not None and "binding_roof" in pmc:
+        # per layer max(FLOPs / MFMA peak, algorithmic bytes / HBM peak) over the measured kernel time, summed over every conv / linear call of a step
+        # (tools/pmc_summary.py layer table of the committed profile: a profile figure, not a live one)
+        roofline["binding_roof_frac"] = pmc["binding_roof"]["frac"]
+        roofline["binding_roof"] = dict(pmc["binding_roof"], source=pmc_src)
     if pmc is not None:
         key = "conv_backward_family" if train else "conv_forward_family"
         if key in pmc:
@@ -274,7 +292,7 @@ def rooflines(calls, dtype_name, cfg_key, train):
         v = enc[0][0]
         by = msda_bytes(v, esz)
         lds_by = v[9] * v[10] * v[12] * v[14] * v[15] * 4 * v[13] * esz       # B * Lq * M * L * P * 4 corners * D channels
-        avg_ms = sum(ms for _, ms in enc) / len(enc)
+        avg_ms = max(sum(ms for _, ms in enc) / len(enc) - EMPTY_PAIR_MS[0], 1e-6)      # (kernel-duration clock: the empty event pair's reading taken off)
         ideal_us = by / PEAK_HBM_GBPS / 1e3
         roofline_msda = {"kernel": "msda_fwd_lds_kernel / msda_fwd_kernel (encoder call, B=%d Lq=Lv=%d, %s)" % (v[9], v[10], dtype_name), "bound": "hbm",
                          "achieved": round(by / avg_ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -288,21 +306,21 @@ def rooflines(calls, dtype_name, cfg_key, train):
                          # the same bytes against the conflict-free ds_read_b128 rate (256 B/clk/CU): what a layout whose 16-lane groups never collide would allow
                          "lds_peak_b128": 2 * PEAK_LDS_GBPS, "lds_frac_b128": round(lds_by / avg_ms / 1e6 / (2 * PEAK_LDS_GBPS), 4),
                          "binding_roof": "lds" if lds_by / PEAK_LDS_GBPS > by / PEAK_HBM_GBPS else "hbm",
-                         "note": "a launch that moves nothing already reads event_timed_trivial_launch_us (roofline) on this clock: at %.1f MB the HBM "
+                         "note": "kernel-duration clock (roofline.clock); at %.1f MB the HBM "
                                  "time is %.1f us and the LDS gather floor %.1f us, so the HBM fraction is bounded below %.2f by the gather alone and lower "
-                                 "still by the launch; see DESIGN.md 5 for the per-shape table (bench.py --config cfg5 --batch 64 / 128 gives the large-batch rows)"
+                                 "still by the launch's fixed latency; see DESIGN.md 5 for the per-shape table (bench.py --config cfg5 --batch 64 / 128 gives the large-batch rows)"
                                  % (by / 1e6, ideal_us, lds_by / PEAK_LDS_GBPS / 1e3, min(1.0, ideal_us / (lds_by / PEAK_LDS_GBPS / 1e3)))}
         encb = [(vals_of(a), ms) for name, a, ms in calls if name == "emrt_msda_bwd"]
         encb = [(vb, ms) for vb, ms in encb if vb[14] == vb[15]]     # Lq == Lv: encoder self-attention calls
         if encb:
             vb = encb[0][0]
             byb = msda_bwd_bytes(vb, esz)
-            avg_b = sum(ms for _, ms in encb) / len(encb)
+            avg_b = max(sum(ms for _, ms in encb) / len(encb) - EMPTY_PAIR_MS[0], 1e-6)
             roofline_msda["backward"] = {
                 "kernel": "emrt_msda_bwd: gradient kernel + value-gradient scatter (+ finalize), encoder call", "bound": "hbm",
                 "achieved": round(byb / avg_b / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(byb / avg_b / 1e6 / PEAK_HBM_GBPS, 4),
                 "traffic": None, "algorithmic_mbytes_per_call": round(byb / 1e6, 2), "avg_call_us": round(1e3 * avg_b, 2),
-                "note": "two or three launches per call, each event-timed (event_timed_trivial_launch_us each); the value gradient is a matrix product at "
+                "note": "two or three dispatches per call inside ONE event pair (kernel-duration clock: roofline.clock); the value gradient is a matrix product at "
                         "cfg2 (msda_bwd_value_mfma_kernel: bound by the per-sample geometry on the VALU) and the LDS atomic scatter at cfg3 (7 cycles per "
                         "wave instruction); neither is bound by HBM: DESIGN.md 5.000"}
         if pmc is not None and "msda_bwd_encoder_call" in pmc and "backward" in roofline_msda:
@@ -319,6 +337,9 @@ def rooflines(calls, dtype_name, cfg_key, train):
     return roofline, roofline_msda, lines
 
 
+EMPTY_PAIR_MS = [0.0]      # what a HIP-event pair reads around nothing, from the last timed_replay()
+
+
 def timed_replay(record_fn, world=1):
     """Record the C-ABI launches of record_fn(), replay them behind a backlog with a HIP-event pair around each."""
     from emrt_amd import _lib
@@ -332,6 +353,7 @@ def timed_replay(record_fn, world=1):
     torch.cuda.synchronize()
     L.replay(rec)                          # backlog: the host gets ~20 ms ahead of the GPU
     calls = L.replay(rec, timed=True)      # HIP events on the launch stream around every launch
+    EMPTY_PAIR_MS[0] = L.empty_pair_ms
     c.keepalive = None
     return calls
 
@@ -370,12 +392,13 @@ def check_world(args):
                          % (world, args.gpus, args.gpus, args.gpus))
 
 
-def _ride_along(args, key, steps, warm):
+def _ride_along(args, key, steps, warm, extra=()):
     """One ride-along config of the default command in a child process (a fresh interpreter on the same GPU): returns its JSON line as a dict, or None when
     the child could not be run -- the caller then measures in-process.  The launcher's rank environment is not passed on (the child is a plain one-process run)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", key, "--steps", str(steps), "--warmup", str(warm), "--no-other-configs", "--cpu-steps", "1"]
-    if args.no_cpu_baseline:
+    # (CPU baseline of a ride-along: 3 timed steps, median -- BASELINE.md 3's protocol; round 5 took one)
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", key, "--steps", str(steps), "--warmup", str(warm), "--no-other-configs", "--cpu-steps", "3"] + list(extra)
+    if args.no_cpu_baseline and "--no-cpu-baseline" not in cmd:
         cmd.append("--no-cpu-baseline")
     if args.cpu_threads:
         cmd += ["--cpu-threads", str(args.cpu_threads)]
@@ -585,9 +608,15 @@ def main():
             # restores the old behaviour, and a child that fails falls back to it
             r2 = None if args.inprocess_others else _ride_along(args, key, steps, warm)
             if r2 is None:
-                r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=1)
+                r2 = (run_infer if c2["mode"] == "infer" else run_train)(args, key, c2, c2["dtype"], env, steps, warm, cpu=not args.no_cpu_baseline, dump=None, cpu_steps=3)
             others[key] = {k: r2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "slowest_step", "value_at_median",
                                                "dtype", "config", "end_to_end_tflops", "loss_check", "roofline", "roofline_msda", "cpu_baseline") if k in r2}
+        # the reference computes in fp32 throughout (paddle_EMRT.py has no AMP); BASELINE configs[1] names bf16, so the headline is bf16 -- the same
+        # workload in the reference's own precision rides along every run (child process; no CPU leg: it is the same oracle step as cfg2's)
+        r32 = _ride_along(args, "cfg2", 20, 5, extra=["--dtype", "fp32", "--no-cpu-baseline"])
+        if r32 is not None:
+            others["cfg2_fp32"] = {k: r32[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "slowest_step",
+                                                        "value_at_median", "dtype", "config", "end_to_end_tflops", "loss_check", "roofline", "roofline_msda") if k in r32}
         result["other_configs"] = others
     if world > 1:
         torch.distributed.barrier()

@@ -1443,6 +1443,73 @@ extern "C" int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch,
   return check_launch("emrt_colsum_acc");
 }
 
+// dst[l][c] += sum over the T tensors, the B batch elements and the tokens of level l of x_t[b][tok][c]: the gradient of the level embedding
+// (transformer_encoder_decoder.py:447-448: pos = sine + level_embed[l], added to the query of EVERY encoder layer) from the layers' query gradients
+// in ONE launch -- round 5 summed the layers' gradients pairwise (an add per layer) and then reduced each level on its own (three launches).
+struct ColsumLevelsArgs {
+  const void* x[8];
+  int T, L, B, Lv, C;
+  int start[4], count[4];
+  float* dst;
+};
+template <class T>
+__global__ __launch_bounds__(256) void colsum_levels_kernel(ColsumLevelsArgs a) {
+  // block (j, l): token rows j, j + gridDim.x, ... of level l, every tensor and batch element; thread = (row lane, channel quad)
+  const int quads = a.C / 4;
+  const int cq = threadIdx.x % quads, lane_row = threadIdx.x / quads, lanes = 256 / quads;
+  const int l = blockIdx.y;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = blockIdx.x * lanes + lane_row; r < a.count[l]; r += gridDim.x * lanes) {
+    const long long row = a.start[l] + r;
+    for (int t = 0; t < a.T; ++t) {
+      const T* x = (const T*)a.x[t];
+      for (int b = 0; b < a.B; ++b) {
+        float v[4];
+        Vec4<T>::load(x + ((long long)b * a.Lv + row) * a.C + cq * 4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      }
+    }
+  }
+  __shared__ float red[256 * 4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[(lane_row * quads + cq) * 4 + e] = acc[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float s = 0.f;
+    for (int q = 0; q < lanes; ++q) s += red[(q * quads + c / 4) * 4 + (c & 3)];
+    atomicAdd(a.dst + (long long)l * a.C + c, s);
+  }
+}
+
+extern "C" int emrt_colsum_levels_multi(const void* const* xs, int T, const int* level_start, const int* level_count, int L, int B, int Lv, int C,
+                                        float* dst, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(xs && level_start && level_count && dst, "null pointer");
+  EMRT_REQUIRE(T >= 1 && T <= 8 && L >= 1 && L <= 4 && B > 0 && Lv > 0, "1..8 tensors, 1..4 levels");
+  EMRT_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "C / 4 must divide 256");
+  ColsumLevelsArgs a;
+  memset(&a, 0, sizeof(a));
+  int most = 0;
+  for (int t = 0; t < T; ++t) {
+    EMRT_REQUIRE(xs[t] && ((uintptr_t)xs[t]) % 16 == 0, "null or unaligned tensor");
+    a.x[t] = xs[t];
+  }
+  for (int l = 0; l < L; ++l) {
+    EMRT_REQUIRE(level_start[l] >= 0 && level_count[l] > 0 && level_start[l] + level_count[l] <= Lv, "level outside the token axis");
+    a.start[l] = level_start[l]; a.count[l] = level_count[l];
+    most = level_count[l] > most ? level_count[l] : most;
+  }
+  a.T = T; a.L = L; a.B = B; a.Lv = Lv; a.C = C; a.dst = dst;
+  const int lanes = 256 / (C / 4);
+  int gx = (most + lanes - 1) / lanes;          // one token row per row lane and block at most: the (tensor, batch) loop is the work
+  if (gx > 128) gx = 128;
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_levels_kernel<float>), dim3(gx, L), dim3(256), 0, st, a),
+            hipLaunchKernelGGL((colsum_levels_kernel<bf16_t>), dim3(gx, L), dim3(256), 0, st, a));
+  return check_launch("emrt_colsum_levels_multi");
+}
+
 // one block per (image, group) when the slice is small enough for two cheap passes and the group is 4..256 channels wide
 static inline bool gn_use_fused(int HW, int C, int G) {
   const int cpg = C / G;

@@ -511,19 +511,23 @@ class EncoderDecoder(hnn.HipLayer):  # :337-473
         pos_acc = []
 
         def pos_bgrad(g):
-            if not pos_acc:
-                pos_acc.append([g, False])
-            elif pos_acc[0][1]:
-                Fn.add_into(pos_acc[0][0], g)
-            else:
-                pos_acc[0] = [Fn.add_maps(pos_acc[0][0], g), True]
+            pos_acc.append(g)          # kept until pos_reduce: ONE launch sums every layer's query gradient per level (emrt_colsum_levels_multi)
 
         if c.tape is not None:
             def pos_reduce():
-                if pos_acc:
-                    for l, (a, n) in enumerate(spans):
-                        Fn.colsum_acc(pos_acc[0][0].narrow(1, a, n), lvl.grad[l])
-                    pos_acc.clear()
+                if not pos_acc:
+                    return
+                if (len(pos_acc) <= 8 and len(spans) <= 4 and all(g.is_contiguous() and tuple(g.shape) == (B, Lv, C) and g.dtype == pos_acc[0].dtype for g in pos_acc)
+                        and lvl.grad.is_contiguous() and C % 4 == 0 and 256 % (C // 4) == 0):
+                    ptrs = (ctypes.c_void_p * len(pos_acc))(*[g.data_ptr() for g in pos_acc])
+                    st_ = (ctypes.c_int * len(spans))(*[a for a, _ in spans])
+                    cn_ = (ctypes.c_int * len(spans))(*[n for _, n in spans])
+                    Fn._L().call("emrt_colsum_levels_multi", ptrs, len(pos_acc), st_, cn_, len(spans), B, Lv, C, Fn.P(lvl.grad), Fn.dtype_of(pos_acc[0]), c.stream)
+                else:
+                    for g in pos_acc:
+                        for l, (a, n) in enumerate(spans):
+                            Fn.colsum_acc(g.narrow(1, a, n), lvl.grad[l])
+                pos_acc.clear()
             c.tape.record(pos_reduce)
 
         memory, q = src, None

@@ -160,6 +160,9 @@ int emrt_bn_pointwise_fwd(const void* x, int ldx, long long x_bs, const void* w_
 int emrt_bn_pointwise_bwd(const void* x, int ldx, long long x_bs, const void* dy, int lddy, long long dy_bs, const void* w_bwd_packed, void* da, int ldda, long long da_bs, float* dw, float* dbias, double* stats, int N, int HW, int C, int OC, const float* mean, const float* invstd, const float* gamma, const float* beta, int dtype, void* stream);
 /* per-channel sum accumulated into dbias (bias / embedding gradients) */
 int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long x_bs, long long M, int C, float* dbias, void* workspace, int dtype, void* stream);
+/* ABI 8: dst[l][c] += sum over the T (<= 8) tensors xs[t] ([B][Lv][C], dense), the batch and the tokens [level_start[l], + level_count[l]) of level l
+ * (<= 4 levels; host arrays): the level embedding's gradient (transformer_encoder_decoder.py:447-448) from every encoder layer's query gradient in one launch. */
+int emrt_colsum_levels_multi(const void* const* xs, int T, const int* level_start, const int* level_count, int L, int B, int Lv, int C, float* dst, int dtype, void* stream);
 
 /* ---- GroupNorm(32) [+ erf-GELU] [+ residual]: transformer_encoder_decoder.py:125-144 (conv branch), :378 (input_proj).
  * workspace: PRE-ZEROED fp64, [N*G*2] for fwd (group sums), [N*C*2] for bwd (per-image channel sums). */

@@ -75,3 +75,30 @@ def close(name, got, ref, dtype, scale=1.0, atol=None, rtol=None):
             name, int(bad.sum()), bad.numel(), err.max().item(), ref.abs().max().item(), idx,
             got[tuple(idx)].item(), ref[tuple(idx)].item()))
     assert torch.isfinite(got).all(), "%s: non-finite values" % name
+
+
+def close_gemm(name, got, ref, dtype, out_bits=None):
+    """Tolerance of a GEMM-shaped kernel (convolution / linear forward, data gradient, weight gradient) from what can actually differ, instead of
+    the flat 6e-2 of TOL[BF16].  The reference is fp32 torch on the SAME rounded operands, the kernel multiplies them exactly (bf16 x bf16 fits
+    fp32) and accumulates in fp32, so the only differences are
+      * the rounding of the stored result: 2^-9 relative for a bf16 output (out_bits = 8 significant bits), none for an fp32 output;
+      * the fp32 summation order over the contraction: ~2^-23 sqrt(K) of the terms' magnitude, i.e. parts in 10^5..10^6 of the output's RMS.
+    bound = 2^-out_bits |ref| + 2^-(out_bits + 2) rms(ref) for a rounded output (twice the rounding; the RMS floor covers outputs that cancel to
+    ~0), 2^-12 (|ref| + rms(ref)) for an fp32 output (fp32 atomics / split reductions in any order).  A mis-weighted tap of a 3x3 kernel moves an
+    output by ~rms(ref) / 3: 40 to 100 times these bounds (the flat tolerance let it pass at kernel level)."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(ref.shape))
+    assert torch.isfinite(got).all(), "%s: non-finite values" % name
+    rms = ref.pow(2).mean().sqrt().item()
+    if dtype == F32:
+        bound = 2e-4 * ref.abs() + 2e-4 * max(rms, 1e-30)
+    elif out_bits is None:          # fp32 output of bf16 operands
+        bound = 2.0 ** -12 * (ref.abs() + rms)
+    else:
+        bound = 2.0 ** -out_bits * ref.abs() + 2.0 ** -(out_bits + 2) * rms
+    err = (got - ref).abs()
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError("%s: %d/%d elements beyond the contraction-derived bound; max |diff| %.4g at rms(ref) %.4g; first at %s got %.6g ref %.6g" % (
+            name, int(bad.sum()), bad.numel(), err.max().item(), rms, idx, got[tuple(idx)].item(), ref[tuple(idx)].item()))

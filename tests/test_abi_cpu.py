@@ -127,3 +127,23 @@ def test_product_never_imports_the_oracle():
     for f in glob.glob(os.path.join(ROOT, "emrt_amd/**/*.py"), recursive=True):
         src = open(f).read()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_build_is_keyed_on_the_content_of_its_inputs(tmp_path):
+    """build_ext decides what to rebuild from a sha256 of the sources, headers, compiler path and flags recorded beside every object and the
+    library (not from modification times, which mean nothing once the built files have travelled to another machine): an untouched tree is
+    "reused" whatever the timestamps say, and the recorded digest is the digest of the tree."""
+    import os
+    from emrt_amd import build_ext
+    build_ext.build(verbose=False)
+    assert build_ext.LAST_BUILD["mode"] in ("reused", "linked", "compiled")
+    # timestamps shuffled: the sources now look newer than the objects -- still nothing to do
+    for src in build_ext.SOURCES:
+        os.utime(os.path.join(build_ext.CSRC, src), None)
+    build_ext.build(verbose=False)
+    assert build_ext.LAST_BUILD["mode"] == "reused" and build_ext.LAST_BUILD["compiled"] == []
+    assert build_ext.LAST_BUILD["digest"] == build_ext.source_digest()
+    with open(build_ext.LIB + ".inputs") as f:
+        assert f.read().strip() == build_ext.source_digest()
+    # a different flag set (or source byte) is a different digest
+    assert build_ext._digest([os.path.join(build_ext.CSRC, build_ext.SOURCES[0])], ["x"]) != build_ext._digest([os.path.join(build_ext.CSRC, build_ext.SOURCES[0])], ["y"])

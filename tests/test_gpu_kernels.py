@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 from emrt_amd import functional as Fn          # noqa: E402
 from emrt_amd import nn as hnn                  # noqa: E402
 from emrt_amd.runtime import ctx, F32, BF16, Tape   # noqa: E402
-from tests.hip_utils import init, dev_map, host_map, dev, host, rnd, Holder, close   # noqa: E402
+from tests.hip_utils import close_gemm, init, dev_map, host_map, dev, host, rnd, Holder, close   # noqa: E402
 
 DTYPES = [F32, BF16]
 
@@ -71,15 +71,13 @@ def test_conv2d_fwd_dgrad_wgrad(dtype, case):
     y = conv(xd)
     c.tape = None
     tape.watch(xd)
-    scale = 1.0
-    close("conv fwd", host_map(y), yr.detach(), dtype, scale)
+    # tolerances from what can differ (tests/hip_utils.close_gemm): the output's rounding (bf16: 8 significant bits) and the fp32 summation order
+    close_gemm("conv fwd", host_map(y), yr.detach(), dtype, out_bits=8)
     dx, = run_bwd(tape, [(y, dev_map(dy))], [xd])
-    kscale = math.sqrt(Cout * k * k / (stride * stride))
-    close("conv dgrad", host_map(dx), xr.grad, dtype, kscale * (1.0 if dtype == F32 else 0.3))
-    wscale = math.sqrt(N * yr.shape[2] * yr.shape[3])
-    close("conv wgrad", host(conv.weight.grad), wr.grad, dtype, wscale * (1.0 if dtype == F32 else 0.3))
+    close_gemm("conv dgrad", host_map(dx), xr.grad, dtype, out_bits=8)
+    close_gemm("conv wgrad", host(conv.weight.grad), wr.grad, dtype)          # fp32 gradients of bf16 operands: summation order only
     if bias:
-        close("conv bias grad", host(conv.bias.grad), br.grad, dtype, wscale)
+        close_gemm("conv bias grad", host(conv.bias.grad), br.grad, dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1317,6 +1315,31 @@ def test_dropout_statistics_and_determinism():
     y4 = host(Fn.dropout(x4, 0.3, 7, mode=1, hw=25))
     per = y4.reshape(4, 25, 64)
     assert ((per == 0).all(1) | (per != 0).all(1)).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_level_embedding_gradient_from_every_layers_query_gradient_in_one_launch(dtype):
+    """emrt_colsum_levels_multi: dst[l][c] += sum over T tensors, the batch and the tokens of level l (transformer_encoder_decoder.py:447-448: the level
+    embedding is added to the query of every encoder layer, so its gradient sums every layer's query gradient over the level's tokens)."""
+    import ctypes
+    from emrt_amd import _lib
+    c = init(dtype)
+    g = torch.Generator().manual_seed(31)
+    B, C = 3, 256
+    spans = [(0, 20 * 20), (400, 10 * 10), (500, 5 * 5)]
+    Lv = 525
+    xs = [rnd(torch.randn(B, Lv, C, generator=g)) for _ in range(4)]
+    xd = [dev(x) for x in xs]
+    dst0 = torch.randn(3, C, generator=g)
+    dst = dst0.clone().cuda()
+    ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in xd])
+    st_ = (ctypes.c_int * 3)(*[a for a, _ in spans])
+    cn_ = (ctypes.c_int * 3)(*[n for _, n in spans])
+    _lib.lib().call("emrt_colsum_levels_multi", ptrs, 4, st_, cn_, 3, B, Lv, C, ctypes.c_void_p(dst.data_ptr()), c.dtype, c.stream)
+    want = dst0.clone()
+    for l, (a, n) in enumerate(spans):
+        want[l] += sum(x[:, a:a + n].double().sum((0, 1)) for x in xs).float()
+    close("level sums", dst.cpu(), want, F32, scale=math.sqrt(4 * B * 400))          # fp32 sums of (rounded) inputs, any order
 
 
 def _assert_masks_independent(name, m1, m2, p, lanes):

@@ -71,6 +71,17 @@ def calibrated_oracle(backbone, x, seed=0, ncls=6, condition=None):
     return ref
 
 
+# Pixels whose argmax differs from the float64 oracle's in the fp32 eval forward, per parity case: ceilings frozen from the measured counts
+# (rounds 4 / 5 / 6 on five boxes: 0 | 1-3 | 4 | 19-21 | 1 | 29-30 | 104-106 | 0 | 4 | 25-26 | 24; profiles/r6_parity_measured.txt) + ~20 % for the
+# run-to-run spread of two fp32 summation orders.  Every counted pixel is also asserted to be a near-tie of the float64 oracle (margin < 2e-3).
+ARGMAX_FLIP_CEILING = {("resnet18", 2, 64): 1, ("resnet50", 2, 128): 4, ("resnet50", 1, 256): 6, ("resnet50", 1, 512): 26, ("resnet18", 1, 256): 2,
+                       ("resnet50", 8, 256): 36, ("resnet50", 4, 512): 126, ("resnet34", 1, 128): 1, ("resnet50", 2, 224): 7, ("resnet50", 2, 384): 32,
+                       ("resnet50", 2, 448): 30}
+# north_star's "fp32 logits within 1e-3" holds against the float64 oracle for every case but this one: at ResNet-101 depth the randomly initialised
+# BatchNorm network amplifies fp32 rounding until the float32 CPU oracle ITSELF is 6.3e-3 from float64 (measured); bound there: 1.25 x that distance
+LOGIT_1E3_EXCEPTIONS = {("resnet101", 1, 128)}
+
+
 def assert_argmax_match(got, ref, tol=1e-3, max_flips=None):
     """argmax masks must agree everywhere the oracle's decision is not a near-tie: a pixel whose top-2 logit margin
     is below 2*tol can legitimately flip between two fp32 implementations that differ by <= tol."""
@@ -166,11 +177,18 @@ def test_forward_logits_match_oracle_eval(backbone, B, S, ncls):
         # 1e-3 (north_star) wherever fp32 arithmetic itself can hold it: at ResNet-101 depth the randomly initialised BatchNorm network
         # amplifies rounding so much that the float32 CPU oracle is 6.3e-3 from float64 (measured); there the HIP path must be no
         # further from float64 than 1.25 x the fp32 oracle's own distance
-        assert e64 < max(1e-3, 1.25 * o32), "%s logits: max |diff| vs float64 oracle %.3g (fp32 oracle itself: %.3g)" % (name, e64, o32)
-        assert e32 < max(2e-3, 2.0 * o32), "%s logits: max |diff| vs float32 oracle %.3g" % (name, e32)
-    tol = max(1e-3, 1.25 * (want32[0] - want64[0]).abs().max().item())
+        if (backbone, B, S) in LOGIT_1E3_EXCEPTIONS:
+            assert o32 > 1e-3, "the fp32 oracle is within 1e-3 of float64 here: %s no longer needs its exception" % backbone
+            assert e64 < 1.25 * o32, "%s logits: max |diff| vs float64 oracle %.3g (fp32 oracle itself: %.3g)" % (name, e64, o32)
+            assert e32 < 2.0 * o32, "%s logits: max |diff| vs float32 oracle %.3g" % (name, e32)
+        else:
+            # the north_star bound as written: |hip - float64| < 1e-3, no escape through the fp32 oracle's own error (measured: <= 7e-4 on every case)
+            assert e64 < 1e-3, "%s logits: max |diff| vs float64 oracle %.3g (north_star: 1e-3)" % (name, e64)
+            assert e32 < 2e-3, "%s logits: max |diff| vs float32 oracle %.3g" % (name, e32)
+    exception = (backbone, B, S) in LOGIT_1E3_EXCEPTIONS
+    tol = 1.25 * (want32[0] - want64[0]).abs().max().item() if exception else 1e-3
     # (where fp32 itself is beyond 1e-3 -- ResNet-101 -- the count bound is the number of near-ties at that tolerance)
-    flips = assert_argmax_match(got[0].cpu(), want64[0], tol=tol, max_flips=None if tol <= 1e-3 else B * S * S)
+    flips = assert_argmax_match(got[0].cpu(), want64[0], tol=tol, max_flips=B * S * S if exception else ARGMAX_FLIP_CEILING[(backbone, B, S)])
     exact = int((got[0].cpu().argmax(1) != want64[0].argmax(1)).sum())
     print("ARGMAX %s %dx%dx%d fp32 eval: %d of %d pixels differ from the float64 oracle's mask (every one a near-tie: float64 top-2 margin < %.1e); "
           "vs the fp32 oracle's mask: %d" % (backbone, B, S, S, exact, B * S * S, 2 * tol, int((got[0].cpu().argmax(1) != want32[0].argmax(1)).sum())))

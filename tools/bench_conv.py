@@ -297,8 +297,45 @@ def xk():
         print(line, flush=True)
 
 
+def mid():
+    """The step's mid-size GEMMs (10 752 token rows; the encoder's per-level 3x3 convs): every tile the dispatcher can be forced to, forward and data
+    gradient, with the achieved TFLOP/s -- which tile bounds them (round 6: are they L2-operand-traffic bound on 64x64, latency bound on 128x128?)."""
+    scratch = torch.empty((64 << 20) + (8 << 20) + 65536, dtype=torch.uint8, device=dev)
+    L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()), stream)
+    shapes = [(8, 1, 1344, 256, 1024, 1, 1, 0), (8, 1, 1344, 1024, 256, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 432, 1, 1, 0),
+              (8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1), (8, 64, 64, 64, 256, 1, 1, 0), (8, 64, 64, 256, 64, 1, 1, 0),
+              (8, 32, 32, 128, 512, 1, 1, 0), (8, 32, 32, 512, 128, 1, 1, 0)]
+    for (N, H, W, C, OC, k, s, pad) in shapes:
+        OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        x = torch.randn(N, H, W, C, device=dev).bfloat16()
+        wf = (torch.randn(OC, k, k, C, device=dev) * 0.05).bfloat16()
+        wb = (torch.randn(C, k, k, OC, device=dev) * 0.05).bfloat16()
+        y = torch.empty(N, OH, OW, OC, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty_like(x)
+        gf = 2.0 * N * OH * OW * OC * k * k * C / 1e9
+
+        def fwd():
+            L._raw_emrt_conv2d(P(x), P(wf), P(y), None, None, N, H, W, C, C, H * W * C, OH, OW, OC, OC, OH * OW * OC, 0, 0,
+                               k, k, s, pad, 0, 0, 0, None, None, 0, 0, 1, None, 1, stream)
+
+        def dgrad():
+            L._raw_emrt_conv2d(P(y), P(wb), P(dx), None, None, N, OH, OW, OC, OC, OH * OW * OC, H, W, C, C, H * W * C, 0, 0,
+                               k, k, s, pad, 1, 0, 0, None, None, 0, 0, 1, None, 1, stream)
+        line = "N%d %dx%dx%d->%d k%d %6.2f GF |" % (N, H, W, C, OC, k, gf)
+        for name, fn in (("fwd", fwd), ("dgrad", dgrad)):
+            res = []
+            for tile in (0, 1, 2, 3, 8, 7):
+                L.set_tuning("conv_tile", tile)
+                res.append(min(timed(fn), timed(fn)))
+            L.set_tuning("conv_tile", 0)
+            line += " %s auto %.1f (%.0f TF/s) 64x64 %.1f 128x64 %.1f 128x128 %.1f 128x128-k2 %.1f 256x256-8p %.1f |" % ((name, res[0], gf / res[0] * 1e3) + tuple(res[1:]))
+        print(line, flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "mid":
+        return mid()
     if which == "xk":
         return xk()
     if which == "s2":

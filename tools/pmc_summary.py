@@ -201,6 +201,28 @@ def layer_table(dst, step, a, b, names, sq_d, trace_d, calls_path):
             fo.write('%s,"%s",%d,%s,%.2f,%.3f,%.1f,%d,%d,%.2f,%.3f,%.2f\n' % r)
     tot_us = sum(r[4] for r in out if r[4] == r[4])
     print("[layers] %d conv calls, %.3f ms of kernel time, %.1f GFLOP -> %.1f TFLOP/s; table in %s_layers.csv" % (len(out), tot_us / 1e3, sum(r[5] for r in out), sum(r[5] for r in out) / tot_us * 1e3 if tot_us else 0, dst))
+    # every layer against ITS binding roof: ideal = max(FLOPs at the dense bf16 MFMA peak, algorithmic bytes at the HBM peak); the fraction of the family
+    # is sum(ideal) / sum(measured kernel time) -- what a per-kernel "fraction of roofline" averages to when each kernel is priced against the roof that binds it
+    PEAK_TF, PEAK_GBS = 2500.0, 8000.0
+    rows = [r for r in out if r[4] == r[4] and r[4] > 0]
+    if rows:
+        ideal = [max(r[5] / PEAK_TF * 1e3, r[7] / PEAK_GBS / 1e3) for r in rows]      # us: GFLOP / (TFLOP/s) * 1e3; bytes / (GB/s) / 1e3
+        mfma_bound = [i for i, r in enumerate(rows) if r[5] / PEAK_TF * 1e3 >= r[7] / PEAK_GBS / 1e3]
+        hbm_bound = [i for i in range(len(rows)) if i not in set(mfma_bound)]
+        br = {"ideal_us": round(sum(ideal), 1), "measured_us": round(sum(r[4] for r in rows), 1), "frac": round(sum(ideal) / sum(r[4] for r in rows), 4),
+              "calls": len(rows),
+              "mfma_bound": {"calls": len(mfma_bound), "ideal_us": round(sum(ideal[i] for i in mfma_bound), 1), "measured_us": round(sum(rows[i][4] for i in mfma_bound), 1)},
+              "hbm_bound": {"calls": len(hbm_bound), "ideal_us": round(sum(ideal[i] for i in hbm_bound), 1), "measured_us": round(sum(rows[i][4] for i in hbm_bound), 1)},
+              "peaks": {"mfma_tflops": PEAK_TF, "hbm_gbs": PEAK_GBS},
+              "note": "every convolution / linear C-ABI call of one eager step: max(algorithmic FLOPs / MFMA peak, algorithmic bytes / HBM peak) summed, over the summed rocprofv3 kernel durations"}
+        try:
+            js = json.load(open(dst + ".json"))
+            js["binding_roof"] = br
+            json.dump(js, open(dst + ".json", "w"), indent=1)
+        except (OSError, ValueError):
+            pass
+        print("[layers] binding-roof fraction %.4f (ideal %.1f us / measured %.1f us; MFMA-bound %d calls, HBM-bound %d)" % (
+            br["frac"], br["ideal_us"], br["measured_us"], len(mfma_bound), len(hbm_bound)))
 
 
 if __name__ == "__main__":
