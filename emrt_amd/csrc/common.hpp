@@ -87,6 +87,7 @@ struct Tuning {
   int mha_valu;           // 1 = the decoder's softmax attention on the VALU kernels for every dtype (A/B knob; bf16 / fp16 default to the MFMA kernels)
   int no_bna;             // 1 = emrt_conv2d_bna_supported always answers 0: every BatchNorm between convolutions keeps its own emrt_bn_apply launch (A/B knob);
                           // -1 = also the long-k 3x3 layers the dispatcher leaves to the separate launch (tests)
+  int memcpy_kernel;      // 1: emrt_memcpy is a copy kernel of the stream; 0 (default): hipMemcpyAsync (A/B knob, measured neutral)
   int xk;                 // cross-block K split of few-tile, long-K convolutions: 0 = the dispatcher's choice, -1 = never, n >= 2 = n copies whenever the shape allows
 };
 extern Tuning g_tune;

@@ -30,7 +30,7 @@ const TuneEntry kTune[] = {
     {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160}, {"igemm8p_cmajor", &emrt::Tuning::igemm8p_cmajor, 0},
     {"wgrad8p_min_steps", &emrt::Tuning::wgrad8p_min_steps, 8}, {"wgrad8p_slab", &emrt::Tuning::wgrad8p_slab, 1}, {"wgrad8p_force", &emrt::Tuning::wgrad8p_force, 0}, {"wgrad8p_xcd", &emrt::Tuning::wgrad8p_xcd, 1},
     {"wgrad_no_overwrite", &emrt::Tuning::wgrad_no_overwrite, 0}, {"no_ksplit128", &emrt::Tuning::no_ksplit128, 0}, {"ln_bwd_rows", &emrt::Tuning::ln_bwd_rows, 0}, {"ln_bwd_max_blocks", &emrt::Tuning::ln_bwd_max_blocks, 0}, {"bn_operand_blocks", &emrt::Tuning::bn_operand_blocks, 0}, {"no_s2_dgrad", &emrt::Tuning::no_s2_dgrad, 0}, {"wgroup_blocks", &emrt::Tuning::wgroup_blocks, 1024}, {"wgroup_min_steps", &emrt::Tuning::wgroup_min_steps, 32}, {"wgroup_max", &emrt::Tuning::wgroup_max, 0},
-    {"no_bna", &emrt::Tuning::no_bna, 0}, {"xk", &emrt::Tuning::xk, 0}, {"mha_valu", &emrt::Tuning::mha_valu, 0}, {"msda_scatter_merge", &emrt::Tuning::msda_scatter_merge, 0},
+    {"no_bna", &emrt::Tuning::no_bna, 0}, {"memcpy_kernel", &emrt::Tuning::memcpy_kernel, 0}, {"xk", &emrt::Tuning::xk, 0}, {"mha_valu", &emrt::Tuning::mha_valu, 0}, {"msda_scatter_merge", &emrt::Tuning::msda_scatter_merge, 0},
     {"msda_scatter_mfma", &emrt::Tuning::msda_scatter_mfma, 1}, {"sgd_nt", &emrt::Tuning::sgd_nt, 1}, {"ln_bwd_threads", &emrt::Tuning::ln_bwd_threads, 512}, {"msda_mf_bands", &emrt::Tuning::msda_mf_bands, 0},
 };
 emrt::Tuning tuning_from_env() {
@@ -445,9 +445,24 @@ extern "C" int emrt_memset(void* ptr, int value, size_t bytes, void* stream) {
   return 0;
 }
 
+// 16 bytes per lane, grid-stride: the staging copy as an ordinary kernel of the stream (see emrt_memcpy)
+__global__ __launch_bounds__(256) void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 extern "C" int emrt_memcpy(void* dst, const void* src, size_t bytes, void* stream) {
   EMRT_REQUIRE((dst && src) || bytes == 0, "null pointer");
   if (bytes == 0 || dst == src) return 0;
+  // Knob memcpy_kernel = 1 (A/B, default 0): the copy as an ordinary kernel of the stream instead of the runtime's hipMemcpyAsync.  The per-dispatch
+  // timeline (profiles/r5c_timeline_cfg2.txt) shows ~85 us of idle queue in front of the runtime's copy between two hipGraph launches, but the step
+  // time is the same with either form and with no staging copy at all (round 6: 947.6 / 948.0 / 948.2 tiles/s): the gap is the profiler's, not the step's.
+  if (g_tune.memcpy_kernel && bytes % 16 == 0 && ((uintptr_t)dst | (uintptr_t)src) % 16 == 0) {
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src, n16);
+    return emrt::check_launch("emrt_memcpy");
+  }
   hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
   if (e != hipSuccess) return emrt::fail("emrt_memcpy", hipGetErrorString(e));
   return 0;
