@@ -1271,12 +1271,6 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
     if constexpr (MODE == 0 && VEC && sizeof(T) != 0) {
       constexpr int EPC = 16 / (int)sizeof(T);
       const bool vec_out = ((uintptr_t)a.out) % 16 == 0 && a.ldout % EPC == 0 && a.out_bs % EPC == 0 && a.OC % 8 == 0 && !a.out_f32 && !a.res && !a.mask_y;
-      if constexpr (sizeof(T) == 2) {
-        // ... or, at the encoder's size (168 tiles of 256x256, OC >= 1024), the 256x256 kernel with the same draw in its epilogue: see the rule below
-        const long long nb256 = blocks(256, 256);
-        const int nkt64 = a.KH * a.KW * a.C / 64, minb = g_tune.igemm8p_min_blocks;
-        if (vec_out && !g_tune.conv_tile && minb > 0 && nkt64 >= 4 && nb256 >= minb && a.OC >= 1024 && igemm8p_ok<T>(a)) return launch_igemm8p<T, MODE>(a, st);
-      }
       if (vec_out) {
         hipLaunchKernelGGL((igemm_drop_kernel<T>), dim3((unsigned)blocks(64, 64)), dim3(256), (size_t)2 * 128 * 144, st, a);
         return check_launch("emrt_conv2d_drop");
@@ -1319,11 +1313,10 @@ static int conv_pick_tile(const ConvArgs& a, hipStream_t st) {
     const int nkt64 = a.KH * a.KW * a.C / 64;
     const int minb = g_tune.igemm8p_min_blocks;
     if (minb > 0 && nkt64 >= 16 && (nb256 >= minb || (nb256 >= (minb * 3) / 5 && nkt64 >= 144)) && igemm8p_ok<T>(a)) return launch_igemm8p<T, MODE>(a, st);
-    // ... and with a SHORT k loop when the output is wide: the FFN's 256 <-> 1024 linears over 10 752 token rows (linear2's data gradient; linear1's forward
-    // when it does not draw dropout) are 2 688 tiles of 64x64 that each pull 64 KiB of operands for 2 MFLOP -- 172 MB through the L2s per launch, the
-    // bound of that kernel -- against 168 tiles of 256x256 at a quarter of the bytes.  Measured (tools/bench_conv.py mid, round 6): forward 21.4 -> 17.5 us,
-    // data gradient 20.4 -> 16.9 us; 256 -> 256 / 432 (42-84 tiles) lose, which is what the >= 1024 is for.
-    if (minb > 0 && nkt64 >= 4 && nkt64 < 16 && nb256 >= minb && a.OC >= 1024 && igemm8p_ok<T>(a)) return launch_igemm8p<T, MODE>(a, st);
+    // (Round 6 tried the FFN's 256 <-> 1024 linears over 10 752 rows here as well -- a SHORT k loop with a wide output: 168 tiles of 256x256 pull a quarter
+    // of the 64x64 grid's 172 MB of operands.  Alone the kernels win (tools/bench_conv.py mid: forward 21.4 -> 17.5 us, data gradient 20.4 -> 16.9 us);
+    // inside the captured step, with linear2's mask epilogue reading the 22 MB activation, the data gradient took 29.8 us against 27.5 us on the 64x64 tile
+    // and the forward 22.4 against 24.2 (profiles/r6a_timeline_cfg2.txt): +1 us per layer in all, not kept.)
   }
   // measured on MI355X (tools/bench_conv.py): 128x128 tiles win only when the k loop is long enough to amortise their
   // prologue / epilogue (>= 16 k-tiles) and there is at least one block per CU; everything else is fastest on 64x64
@@ -1448,7 +1441,6 @@ static int bna_choice(const ConvArgs& a, hipStream_t st) {
     const int nkt64 = a.KH * a.KW * a.C / 64;
     const int minb = g_tune.igemm8p_min_blocks;
     if (minb > 0 && nkt64 >= 16 && (nb256 >= minb || (nb256 >= (minb * 3) / 5 && nkt64 >= 144)) && igemm8p_ok<T>(a)) return 0;
-    if (minb > 0 && nkt64 >= 4 && nkt64 < 16 && nb256 >= minb && a.OC >= 1024 && igemm8p_ok<T>(a)) return 0;
   }
   const int nkt = (a.KH * a.KW * a.C + BK - 1) / BK;
   if (a.OC > 64 && nkt >= 16 && blocks(128, 128) >= 256) return 0;

@@ -316,13 +316,6 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
   for (int e = 0; e < 8; ++e) { bv[e] = (p.bias && col_ok) ? p.bias[n0 + e] : 0.f; sv[e] = (p.scale && col_ok) ? p.scale[n0 + e] : 1.f; ss[e] = 0.f; sq[e] = 0.f; }
   const T* resp = (const T*)p.res;
   const T* ymask = (const T*)p.mask_y;
-  // optional inverted dropout after the ReLU (emrt_conv2d_drop: the FFN's linear1 at 10 752 token rows x 1024 channels takes this kernel): the SAME
-  // draw as igemm_body's DROP epilogue -- drop_words8(seed, salt, (row * OC + column) / 8), 16-bit fields against p * 65536 -- so the mask does not
-  // depend on which kernel the dispatcher picked
-  const bool do_drop = p.drop_seed != nullptr;
-  const unsigned long long drop_sd = do_drop ? p.drop_seed[0] : 0ull;
-  const uint32_t drop_thr = do_drop ? (uint32_t)(p.drop_p * 65536.f) : 0u;
-  const float drop_ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -357,12 +350,6 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
       if (p.relu) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (do_drop) {
-        uint32_t hw[4];
-        drop_words8(drop_sd, p.drop_salt, (m * (unsigned)p.OC + (unsigned)n0) >> 3, hw);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = drop_keep8(hw, e, drop_thr) ? v[e] * drop_ks : 0.f;
       }
       float second[8];
       if (ymask) {
@@ -422,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(ConvArgs p) {
 // host side: can this problem take the 256 x 256 kernel?  (vector operand path, whole k-tiles per tap, vector epilogue)
 template <class T>
 static bool igemm8p_ok(const ConvArgs& a) {
-  if (sizeof(T) != 2) return false;
+  if (sizeof(T) != 2 || a.drop_seed) return false;      // (the dropout epilogue lives in igemm_body only)
   if (a.C % 64 != 0 || a.OC % 8 != 0) return false;
   if (a.ldin % 8 || a.in_bs % 8 || ((uintptr_t)a.in) % 16 || ((uintptr_t)a.w) % 16) return false;
   const int eo = a.out_f32 ? 4 : 8;

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
 
 // LN backward: dz = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat));  per-block partial dgamma/dbeta
 // -> partial[blk][2][C]; combined by bn_sum_partials_kernel + bn_bwd_finalize_kernel.
-template <class T, int R, int NQ, int TPB = 256>
+template <class T, int R, int NQ, int TPB = 256, bool DY2 = false>
 __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ partial, long long rows,
@@ -1133,11 +1133,16 @@ __global__ __launch_bounds__(TPB) void ln_bwd_kernel(const T* __restrict__ z, co
         for (int k = 0; k < R; ++k) {
           Vec4<T>::load(z + row[k] * C + c, zz[k]);
           Vec4<T>::load(dy + row[k] * C + c, dd[k]);
-          if (dy2) {
-            float d2[4];
-            Vec4<T>::load(dy2 + row[k] * C + c, d2);
+        }
+        if constexpr (DY2) {      // (its own instantiation: as a run-time branch in this load phase it cost EVERY LayerNorm backward 2-5 us -- 14 more registers
+                                  // and the R independent load chains no longer in one basic block; profiles/r6a_timeline_cfg2.txt)
+          float d2[R][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dd[k][e] += d2[e];
+          for (int k = 0; k < R; ++k) Vec4<T>::load(dy2 + row[k] * C + c, d2[k]);
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dd[k][e] += d2[k][e];
             if (dysum && ok[k]) Vec4<T>::store(dysum + row[k] * C + c, dd[k]);
           }
         }
@@ -1459,16 +1464,24 @@ __global__ __launch_bounds__(256) void colsum_levels_kernel(ColsumLevelsArgs a) 
   const int cq = threadIdx.x % quads, lane_row = threadIdx.x / quads, lanes = 256 / quads;
   const int l = blockIdx.y;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // (tensor, batch) pairs p = t * B + b; blockIdx.z takes every gridDim.z-th pair, four loads in flight per thread (the first version walked all
+  // T * B = 32 rows of a token one after the other in 384 blocks: 27.8 us of load latency, profiles/r6a_timeline_cfg2.txt)
+  const int npair = a.T * a.B;
   for (int r = blockIdx.x * lanes + lane_row; r < a.count[l]; r += gridDim.x * lanes) {
     const long long row = a.start[l] + r;
-    for (int t = 0; t < a.T; ++t) {
-      const T* x = (const T*)a.x[t];
-      for (int b = 0; b < a.B; ++b) {
-        float v[4];
-        Vec4<T>::load(x + ((long long)b * a.Lv + row) * a.C + cq * 4, v);
+    for (int p0 = blockIdx.z; p0 < npair; p0 += 4 * gridDim.z) {
+      float v[4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p0 + u * gridDim.z;
+        const int t = pp < npair ? pp / a.B : 0, b = pp < npair ? pp - t * a.B : 0;
+        Vec4<T>::load((const T*)a.x[t] + ((long long)b * a.Lv + row) * a.C + cq * 4, v[u]);
+        if (pp >= npair) { v[u][0] = 0.f; v[u][1] = 0.f; v[u][2] = 0.f; v[u][3] = 0.f; }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
     }
   }
   __shared__ float red[256 * 4];
@@ -1502,11 +1515,12 @@ extern "C" int emrt_colsum_levels_multi(const void* const* xs, int T, const int*
   }
   a.T = T; a.L = L; a.B = B; a.Lv = Lv; a.C = C; a.dst = dst;
   const int lanes = 256 / (C / 4);
-  int gx = (most + lanes - 1) / lanes;          // one token row per row lane and block at most: the (tensor, batch) loop is the work
-  if (gx > 128) gx = 128;
+  int gx = (most + lanes - 1) / lanes;          // one token row per row lane and block at most
+  if (gx > 64) gx = 64;
+  const int gz = T * B >= 8 ? 4 : 1;            // the (tensor, batch) pairs over 4 blocks: <= 64 x L x 4 blocks, each ending in C fp32 atomics
   hipStream_t st = (hipStream_t)stream;
-  DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_levels_kernel<float>), dim3(gx, L), dim3(256), 0, st, a),
-            hipLaunchKernelGGL((colsum_levels_kernel<bf16_t>), dim3(gx, L), dim3(256), 0, st, a));
+  DT_SWITCH(dtype, hipLaunchKernelGGL((colsum_levels_kernel<float>), dim3(gx, L, gz), dim3(256), 0, st, a),
+            hipLaunchKernelGGL((colsum_levels_kernel<bf16_t>), dim3(gx, L, gz), dim3(256), 0, st, a));
   return check_launch("emrt_colsum_levels_multi");
 }
 
@@ -1636,13 +1650,17 @@ extern "C" int emrt_layernorm_bwd(const void* z, const void* dy, void* dz, const
   const bool direct = (dgamma || dbeta) && g_tune.ln_atomic != 0;       // developer knob: 0 = partials + finalize launch
   const size_t lds = (size_t)(wide ? 16 : 8) * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define LN_BWD_LAUNCH_W(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 512>), dim3((unsigned)blocks), dim3(512), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend, (const T*)dy2, (T*)dysum)
-#define LN_BWD_LAUNCH(T, R, NQ) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend, (const T*)dy2, (T*)dysum)
+#define LN_BWD_ARGS(T) (const T*)z, (const T*)dy, (T*)dz, gamma, mean, rstd, partial, rows, C, rpb, (T*)dz_branch, pdrop, seed, salt, direct ? dgamma : nullptr, direct ? dbeta : nullptr, (const T*)dz_addend, (const T*)dy2, (T*)dysum
+#define LN_BWD_LAUNCH_W(T, R, NQ) do { if (dy2) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 512, true>), dim3((unsigned)blocks), dim3(512), lds, st, LN_BWD_ARGS(T)); \
+                                       else hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 512, false>), dim3((unsigned)blocks), dim3(512), lds, st, LN_BWD_ARGS(T)); } while (0)
+#define LN_BWD_LAUNCH(T, R, NQ) do { if (dy2) hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 256, true>), dim3((unsigned)blocks), dim3(256), lds, st, LN_BWD_ARGS(T)); \
+                                     else hipLaunchKernelGGL((ln_bwd_kernel<T, R, NQ, 256, false>), dim3((unsigned)blocks), dim3(256), lds, st, LN_BWD_ARGS(T)); } while (0)
   if (wide) DT_SWITCH(dtype, LN_BWD_LAUNCH_W(float, 4, 1), LN_BWD_LAUNCH_W(bf16_t, 4, 1));
   else if (small) DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 4, 1), LN_BWD_LAUNCH(bf16_t, 4, 1));
   else DT_SWITCH(dtype, LN_BWD_LAUNCH(float, 2, 4), LN_BWD_LAUNCH(bf16_t, 2, 4));
 #undef LN_BWD_LAUNCH
 #undef LN_BWD_LAUNCH_W
+#undef LN_BWD_ARGS
   if (!direct) hipLaunchKernelGGL(partials_acc_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta);
   return check_launch("emrt_layernorm_bwd");
 }

@@ -773,19 +773,6 @@ def test_ffn_dropout_drawn_in_linear1_epilogue(dtype, dims):
     close("ffn db1", host(l1.bias.grad), B1.grad, dtype, sc * (1.0 if dtype == F32 else 0.5))
     close("ffn dw2", host(l2.weight.grad), W2.grad, dtype, sc)
     close("ffn db2", host(l2.bias.grad), B2.grad, dtype, sc)
-    # the mask is a function of (seed, salt, row, column group) only, not of the kernel the dispatcher picked: at the encoder's size (168 tiles of
-    # 256 x 256 at OC = 1024, bf16) the 256x256 LDS-DMA kernel draws it in ITS epilogue (round 6) -- the same mask as the 64x64 kernel's, the kept values
-    # equal to the rounding of two fp32 summation orders (a pre-activation within an ulp of 0 may land on either side of the ReLU)
-    if dtype == BF16 and B * Lq >= 10752 and Hd >= 1024:
-        old_min = L.set_tuning("igemm8p_min_blocks", 0)
-        try:
-            hd64 = host(l1(xd, relu=True, drop=(p, 23)))
-        finally:
-            L.set_tuning("igemm8p_min_blocks", old_min)
-        flips = int(((hd64 > 0) != (hdd > 0)).sum())
-        assert flips <= 8, "%d of %d elements kept by one kernel and dropped by the other" % (flips, hdd.numel())
-        both = (hd64 > 0) & (hdd > 0)
-        assert ((hd64 - hdd).abs()[both] <= 2.0 ** -7 * hdd.abs()[both] + 1e-6).all()
     # another step (the device seed advances): another mask
     L.call("emrt_counter_add", Fn.P(c._seed), 0x2545F4914F6CDD1D & 0x7FFFFFFFFFFFFFFF, c.stream)
     hd2 = host(l1(xd, relu=True, drop=(p, 23)))
