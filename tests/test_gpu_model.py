@@ -143,12 +143,15 @@ def assert_train_logits(out, out32, out64, what):
         assert e32 < 2e-3, "%s %s: |hip - float32 oracle| = %.3g" % (what, name, e32)
 
 
+# (the three full-size cases -- resnet50 1 x 512 x 512 and configs[1] / configs[2] at their real batch sizes, 8 x 256 x 256 and 4 x 512 x 512 -- run
+# the same body from tests/test_gpu_model_full.py: their float64 oracle evaluations are 4 minutes of host time, and pytest-xdist hands out whole files)
+FORWARD_CASES_FULL = [("resnet50", 1, 512, 7),      # BASELINE configs[2] geometry (LoveDA 512x512, 7 classes, Lv = 5376)
+                      ("resnet50", 8, 256, 6),      # configs[1]: batch 8
+                      ("resnet50", 4, 512, 7)]      # configs[2]: batch 4
+
+
 @pytest.mark.parametrize("backbone,B,S,ncls", [("resnet18", 2, 64, 6), ("resnet50", 2, 128, 6), ("resnet50", 1, 256, 6),
-                                                ("resnet50", 1, 512, 7),      # BASELINE configs[2] geometry (LoveDA 512x512, 7 classes, Lv = 5376)
-                                                # the BASELINE configs at their REAL batch sizes (the kernels are selected by size):
                                                 ("resnet18", 1, 256, 6),      # configs[0]: ResNet-18, one 256x256 tile, on the HIP path
-                                                ("resnet50", 8, 256, 6),      # configs[1]: batch 8
-                                                ("resnet50", 4, 512, 7),      # configs[2]: batch 4
                                                 # the other depths the reference's constructor accepts (paddle_EMRT.py:229-234)
                                                 ("resnet34", 1, 128, 6), ("resnet101", 1, 128, 6),
                                                 # the reference's other shipped EMRT tile sizes (configs/EMRT/EMRT_{224x224,384x384,448x448}_160k_potsdam.yaml):
@@ -156,6 +159,10 @@ def assert_train_logits(out, out32, out64, what):
                                                 # MSDA kernels, the adaptive-pool bins and the x2 / x4 resizes
                                                 ("resnet50", 2, 224, 6), ("resnet50", 2, 384, 6), ("resnet50", 2, 448, 6)])
 def test_forward_logits_match_oracle_eval(backbone, B, S, ncls):
+    forward_logits_case(backbone, B, S, ncls)
+
+
+def forward_logits_case(backbone, B, S, ncls):
     """fp32 logits within 1e-3 of the oracle evaluated in float64 (the exact result of the reference's arithmetic; the
     fp32 CPU oracle itself deviates from it by a few 1e-4), and within 2e-3 of the fp32 oracle; argmax masks agree
     wherever the decision is not a sub-tolerance tie."""
