@@ -764,7 +764,14 @@ def run_train(args, cfg_key, cfg, dtype_name, env, steps, warmup, cpu=True, dump
         # ---- live per-kernel timing: one extra eager step with a HIP event pair around every C-ABI launch --------------
         eng_prof = TrainEngine(model, opt, loss_fn, 1, use_graph=False, overlap=False)   # serialised: per-kernel durations
         eng_prof.reducer = None
-        calls = timed_replay(lambda: eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels))
+        # (the profiled step is serialised on ONE stream: the recorded launches are replayed without the fork / join events of the step prologue's
+        # side stream, so that prologue runs on the main stream here)
+        from emrt_amd.runtime import ctx as _ctx
+        _side_was, _ctx().prologue_side = _ctx().prologue_side, False
+        try:
+            calls = timed_replay(lambda: eng_prof._eager_step(images, labels) if world == 1 else eng_prof._fwd_bwd(images, labels))
+        finally:
+            _ctx().prologue_side = _side_was
         if dump:
             dump_calls(dump, calls, 4 if dtype_name == "fp32" else 2)
         roofline, roofline_msda, lines = rooflines(calls, dtype_name, cfg_key if (B, S) == (CONFIGS[cfg_key]["batch"], CONFIGS[cfg_key]["size"]) else "custom", True)

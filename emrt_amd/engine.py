@@ -136,9 +136,23 @@ class TrainEngine:
         only and returns (loss tensor, [callable per remaining segment])."""
         c = ctx()
         _lib.lib().call("emrt_counter_add", Fn.P(c._seed), _SEED_STRIDE & 0x7FFFFFFFFFFFFFFF, c.stream)   # fresh dropout masks
-        self.model.clear_gradients()
-        out = self.model(images)
+        side = c.prologue_side and not c.overlap and not c.wgrad_side and getattr(self.model.store, "desc", None) is not None
+        if side and self.model.store.dirty:      # master weights edited since the last step: the full refresh (forward mirror first) on this stream, now
+            self.model.store.pack()
+        if side:
+            # gradient zeroing + the transposed data-gradient weight copies on the prologue stream, beside the forward (runtime.Context.prologue_stream)
+            with torch.cuda.stream(c.prologue_stream()):
+                self.model.clear_gradients()
+                self.model.store.pack(bwd_only=True)
+            c.pack_bwd_done = True
+        else:
+            self.model.clear_gradients()
+        try:
+            out = self.model(images)
+        finally:
+            c.pack_bwd_done = False
         loss = self.loss_fn(out, labels)
+        c.prologue_join()               # backward reads the zeroed gradients and the transposed copies
         if split:
             rest = loss.backward_until_split(segments=True)
             if rest:

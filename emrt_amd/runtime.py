@@ -249,6 +249,17 @@ class Context:
         self.wgrad_side = bool(int(os.environ.get("EMRT_WGRAD_SIDE", "0")))
         self._wside = None
         self._wside_keep = []
+        # Step prologue off the critical path (engine.TrainEngine): zeroing the 216 MB gradient buffer and transposing the data-gradient weight copies
+        # (emrt_pack_weights bwd_only: 211 MB) need nothing from the forward and nothing in the forward needs them -- ~70 us of pure HBM streaming that
+        # round 5 ran in front of the forward / in front of the backward.  They go to a second stream forked at the top of the step and joined before the
+        # first backward launch (or the first collective that cuts a captured step): ONE fork and ONE join per step, beside a forward whose small
+        # launches leave the memory system mostly idle.  MEASURED (round 6, same box, captured step): 909.8 / 909.9 tiles/s with it against 949.2 / 950.7
+        # without -- one pair of cross-stream edges inside the hipGraph costs 0.36 ms per replay, five times what it hides (the same finding as round 3's
+        # two-stream weight gradients).  Default OFF; EMRT_PROLOGUE_SIDE=1 for the A/B.
+        self.prologue_side = bool(int(os.environ.get("EMRT_PROLOGUE_SIDE", "0")))
+        self._pside = None
+        self._prologue_pending = False
+        self.pack_bwd_done = False      # set by the engine when this step's transposed weight copies are already (being) made on the side stream
 
     def collective(self, fn):
         """Run a host-issued collective (fn enqueues it on the current stream's timeline) at this point of the step.  Eager:
@@ -256,6 +267,7 @@ class Context:
         replay -- between the graphs, and continue capturing in a new graph (engine.GraphSequence.interlude).  The transports
         differ in what they can capture (gloo stages through the host; RCCL kernels can be captured but then cost graph-side
         cross-stream edges), an eager call between two graph launches is right for all of them."""
+        self.prologue_join()            # (a forked stream must be joined inside the graph it was forked in)
         if self.capture is not None:
             self.capture.interlude(fn)
         else:
@@ -266,6 +278,20 @@ class Context:
     # far on the current stream.  "pair": the caller join()s right after the overlapping main-stream kernel.  "deferred":
     # nothing is joined until join_all() (before the optimizer); the buffers the side-stream kernels read are parked in
     # _side_keep so that the allocator cannot hand them out again meanwhile.
+    def prologue_stream(self):
+        """Fork: the side stream of the step prologue, ordered after everything issued so far on the current stream (use as `with torch.cuda.stream(s)`)."""
+        if self._pside is None:
+            self._pside = torch.cuda.Stream(device=self.device)
+        self._pside.wait_stream(torch.cuda.current_stream())
+        self._prologue_pending = True
+        return self._pside
+
+    def prologue_join(self):
+        """The current stream waits for the step prologue (idempotent; called before backward and before any collective that cuts a captured step)."""
+        if self._prologue_pending:
+            torch.cuda.current_stream().wait_stream(self._pside)
+            self._prologue_pending = False
+
     def fork(self, *keep):
         if not self.overlap:
             return None

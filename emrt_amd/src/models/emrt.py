@@ -797,7 +797,9 @@ class EMRT(hnn.HipLayer):  # :184-304
             if tape is not None:
                 # newest model op = first to run in backward (after the loss's own): transposed dgrad copies of the weights from
                 # the forward operands the optimizer keeps current (ParamStore.pack, solver.Momentum.step)
-                tape.record(lambda: self.store.pack(bwd_only=True))
+                # (the engine's step makes them beside the forward on its prologue stream instead: Context.pack_bwd_done)
+                if not c.pack_bwd_done:
+                    tape.record(lambda: self.store.pack(bwd_only=True))
         finally:
             c.tape = None
             c.fold_live = False
