@@ -1524,6 +1524,214 @@ extern "C" int emrt_colsum_levels_multi(const void* const* xs, int T, const int*
   return check_launch("emrt_colsum_levels_multi");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped BatchNorm over several SMALL, independent problems in one launch per pass (ABI 8): the four pyramid-pooling branches
+// (paddle_EMRT.py:61-66,70-78: AdaptiveAvgPool(k) -> conv1x1 -> SyncBatchNorm -> ReLU, k = 1 / 3 / 6 / 8: 8 ... 512 rows of 256 channels at batch 8)
+// were 4 emrt_bn_apply launches forward and 4 x (emrt_bn_bwd_reduce + emrt_bn_bwd_dx) backward of ~5 us each for a few hundred KB.  Same arithmetic
+// as the single-problem kernels (bn_chan / bn_scale_shift / one fmaf: the forward is bit-identical to emrt_bn_apply); plain kernels, not tuned for
+// streaming -- every problem here is latency, which is the point of sharing the launch.  Not for SyncBatchNorm over ranks (the sums would have to be
+// all-reduced between the passes: functional.conv_bn_group keeps its own path for that).
+// ------------------------------------------------------------------------------------------------
+#define EMRT_MAX_BNGROUP 8
+struct EmrtBnGroupDesc {
+  const void* x;          // raw map [M][C], row stride ldx
+  void* y;                // forward: out = [relu](BN(x)); backward: the forward's output (ReLU mask source; nullable when relu == 0)
+  const void* dy;         // backward: gradient of y
+  void* dx;               // backward: gradient of x
+  double* sums;           // forward: complete (sum x, sum x^2) [8][2C]; backward: ZEROED [8][2C], receives (sum dy', sum dy' * xhat)
+  float* mean; float* invstd; float* run_mean; float* run_var;
+  const float* gamma; const float* beta; float* dgamma; float* dbeta;
+  double count;
+  float eps, momentum;
+  int M, C, ldx, ldy, lddy, lddx, relu;
+};
+struct BnGroupArgs { EmrtBnGroupDesc d[EMRT_MAX_BNGROUP]; int first[EMRT_MAX_BNGROUP + 1]; int n; };
+
+__device__ __forceinline__ int bn_group_pick(const BnGroupArgs& g, int& local, int& nblk) {
+  int i = 0;
+  for (int k = 1; k < g.n; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
+  local = (int)blockIdx.x - g.first[i];
+  nblk = g.first[i + 1] - g.first[i];
+  return i;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_group_apply_kernel(BnGroupArgs g) {
+  int local, nblk;
+  const EmrtBnGroupDesc& d = g.d[bn_group_pick(g, local, nblk)];
+  extern __shared__ float bn_lds[];      // [2][C]
+  const int C = d.C, quads = C / 4, lanes = 256 / quads;
+  const int c = ((int)threadIdx.x % quads) * 4, lane_row = (int)threadIdx.x / quads;
+  const double inv_count = 1.0 / d.count;
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const BnChan k = bn_chan(d.sums, nullptr, nullptr, C, ch, inv_count, d.eps);
+    float sc, sh;
+    bn_scale_shift(k.mean, k.invstd, d.gamma[ch], d.beta[ch], sc, sh);
+    bn_lds[ch] = sc;
+    bn_lds[C + ch] = sh;
+    if (local == 0) {
+      d.mean[ch] = k.mean;
+      d.invstd[ch] = k.invstd;
+      if (d.run_mean) {
+        const double mu = rep_sum(d.sums, C, ch) * inv_count;
+        double var = rep_sum(d.sums, C, C + ch) * inv_count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        d.run_mean[ch] = d.momentum * d.run_mean[ch] + (1.f - d.momentum) * (float)mu;
+        d.run_var[ch] = d.momentum * d.run_var[ch] + (1.f - d.momentum) * (float)var;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane_row >= lanes) return;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = bn_lds[c + e]; sh[e] = bn_lds[C + c + e]; }
+  const T* x = (const T*)d.x;
+  T* y = (T*)d.y;
+  for (int r = local * lanes + lane_row; r < d.M; r += nblk * lanes) {
+    float v[4], o[4];
+    Vec4<T>::load(x + (long long)r * d.ldx + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = fmaf(v[e], sc[e], sh[e]); if (d.relu) o[e] = fmaxf(o[e], 0.f); }
+    Vec4<T>::store(y + (long long)r * d.ldy + c, o);
+  }
+}
+
+// backward, pass 1: sums[0][c] += sum_r dy', sums[0][C + c] += sum_r dy' * xhat   (dy' = dy where y > 0; xhat from the raw x and the saved statistics)
+template <class T>
+__global__ __launch_bounds__(256) void bn_group_bwd_reduce_kernel(BnGroupArgs g) {
+  int local, nblk;
+  const EmrtBnGroupDesc& d = g.d[bn_group_pick(g, local, nblk)];
+  __shared__ float red[2][256 * 4];
+  const int C = d.C, quads = C / 4, lanes = 256 / quads;
+  const int c = ((int)threadIdx.x % quads) * 4, lane_row = (int)threadIdx.x / quads;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (lane_row < lanes) {
+    float mu[4], is[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mu[e] = d.mean[c + e]; is[e] = d.invstd[c + e]; }
+    const T* x = (const T*)d.x;
+    const T* dy = (const T*)d.dy;
+    const T* y = (const T*)d.y;
+    for (int r = local * lanes + lane_row; r < d.M; r += nblk * lanes) {
+      float v[4], gq[4], yy[4];
+      Vec4<T>::load(x + (long long)r * d.ldx + c, v);
+      Vec4<T>::load(dy + (long long)r * d.lddy + c, gq);
+      if (d.relu) Vec4<T>::load(y + (long long)r * d.ldy + c, yy);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gd = (!d.relu || yy[e] > 0.f) ? gq[e] : 0.f;
+        s1[e] += gd;
+        s2[e] = fmaf(gd, (v[e] - mu[e]) * is[e], s2[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x * 4 + e] = s1[e]; red[1][threadIdx.x * 4 + e] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, ch = i - which * C;
+    float a = 0.f;
+    for (int q = 0; q < lanes; ++q) a += red[which][(q * quads + ch / 4) * 4 + (ch & 3)];
+    atomicAdd(d.sums + (long long)(local & 7) * 2 * C + i, (double)a);
+  }
+}
+
+// backward, pass 2: dx = gamma * invstd * (dy' - S1 / count - xhat * S2 / count); the problem's first block adds dgamma += S2, dbeta += S1
+template <class T>
+__global__ __launch_bounds__(256) void bn_group_bwd_dx_kernel(BnGroupArgs g) {
+  int local, nblk;
+  const EmrtBnGroupDesc& d = g.d[bn_group_pick(g, local, nblk)];
+  extern __shared__ float bn_lds[];      // [4][C]: k = gamma * invstd, m1 = S1 / count, m2 = S2 / count, (unused)
+  const int C = d.C, quads = C / 4, lanes = 256 / quads;
+  const int c = ((int)threadIdx.x % quads) * 4, lane_row = (int)threadIdx.x / quads;
+  const double inv_count = 1.0 / d.count;
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const double S1 = rep_sum(d.sums, C, ch), S2 = rep_sum(d.sums, C, C + ch);
+    bn_lds[ch] = d.gamma[ch] * d.invstd[ch];
+    bn_lds[C + ch] = (float)(S1 * inv_count);
+    bn_lds[2 * C + ch] = (float)(S2 * inv_count);
+    if (local == 0) {
+      if (d.dbeta) d.dbeta[ch] += (float)S1;
+      if (d.dgamma) d.dgamma[ch] += (float)S2;
+    }
+  }
+  __syncthreads();
+  if (lane_row >= lanes) return;
+  float k[4], m1[4], m2[4], mu[4], is[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { k[e] = bn_lds[c + e]; m1[e] = bn_lds[C + c + e]; m2[e] = bn_lds[2 * C + c + e]; mu[e] = d.mean[c + e]; is[e] = d.invstd[c + e]; }
+  const T* x = (const T*)d.x;
+  const T* dy = (const T*)d.dy;
+  const T* y = (const T*)d.y;
+  T* dx = (T*)d.dx;
+  for (int r = local * lanes + lane_row; r < d.M; r += nblk * lanes) {
+    float v[4], gq[4], yy[4], o[4];
+    Vec4<T>::load(x + (long long)r * d.ldx + c, v);
+    Vec4<T>::load(dy + (long long)r * d.lddy + c, gq);
+    if (d.relu) Vec4<T>::load(y + (long long)r * d.ldy + c, yy);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gd = (!d.relu || yy[e] > 0.f) ? gq[e] : 0.f;
+      o[e] = k[e] * (gd - m1[e] - (v[e] - mu[e]) * is[e] * m2[e]);
+    }
+    Vec4<T>::store(dx + (long long)r * d.lddx + c, o);
+  }
+}
+
+static int bn_group_fill(BnGroupArgs& g, const EmrtBnGroupDesc* descs, int n, int pass, const char* fn) {
+  int total = 0;
+  g.n = n;
+  for (int i = 0; i < n; ++i) {
+    const EmrtBnGroupDesc& d = descs[i];
+    if (!d.x || !d.sums || !d.mean || !d.invstd || !d.gamma || !d.beta || d.M <= 0 || !(d.count > 0.0)) return fail(fn, "null pointer / bad sizes");
+    if (d.C % 4 != 0 || d.C / 4 > 256 || 256 % (d.C / 4) != 0) return fail(fn, "C / 4 must divide 256");
+    if (d.ldx % 4 || ((uintptr_t)d.x) % 8) return fail(fn, "x rows must be 8-byte aligned");
+    if (pass == 0 && (!d.y || d.ldy % 4)) return fail(fn, "forward needs y");
+    if (pass != 0 && (!d.dy || (pass == 2 && !d.dx) || (d.relu && !d.y) || d.lddy % 4 || (pass == 2 && d.lddx % 4))) return fail(fn, "backward needs dy, dx and (with relu) y");
+    if ((d.run_mean != nullptr) != (d.run_var != nullptr)) return fail(fn, "running statistics come in pairs");
+    g.d[i] = d;
+    g.first[i] = total;
+    const int lanes = 256 / (d.C / 4);
+    int nb = (d.M + lanes * 4 - 1) / (lanes * 4);          // ~4 rows per thread
+    if (nb < 1) nb = 1;
+    if (nb > 64) nb = 64;
+    total += nb;
+  }
+  for (int i = n; i <= EMRT_MAX_BNGROUP; ++i) g.first[i] = total;
+  for (int i = n; i < EMRT_MAX_BNGROUP; ++i) g.d[i] = g.d[0];
+  return total > 0 ? 0 : fail(fn, "no work");
+}
+
+extern "C" int emrt_bn_group_apply(const EmrtBnGroupDesc* descs, int n, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_BNGROUP, "1..8 problems");
+  BnGroupArgs g;
+  if (bn_group_fill(g, descs, n, 0, "emrt_bn_group_apply")) return -1;
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) cmax = descs[i].C > cmax ? descs[i].C : cmax;
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_group_apply_kernel<float>), dim3(g.first[n]), dim3(256), 2 * cmax * sizeof(float), st, g),
+            hipLaunchKernelGGL((bn_group_apply_kernel<bf16_t>), dim3(g.first[n]), dim3(256), 2 * cmax * sizeof(float), st, g));
+  return check_launch("emrt_bn_group_apply");
+}
+
+// both backward passes (reduce, then dx: two launches); `sums` of every problem must be ZERO on entry
+extern "C" int emrt_bn_group_bwd(const EmrtBnGroupDesc* descs, int n, int dtype, void* stream) {
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_BNGROUP, "1..8 problems");
+  BnGroupArgs g;
+  if (bn_group_fill(g, descs, n, 2, "emrt_bn_group_bwd")) return -1;
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) cmax = descs[i].C > cmax ? descs[i].C : cmax;
+  hipStream_t st = (hipStream_t)stream;
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_group_bwd_reduce_kernel<float>), dim3(g.first[n]), dim3(256), 0, st, g),
+            hipLaunchKernelGGL((bn_group_bwd_reduce_kernel<bf16_t>), dim3(g.first[n]), dim3(256), 0, st, g));
+  DT_SWITCH(dtype, hipLaunchKernelGGL((bn_group_bwd_dx_kernel<float>), dim3(g.first[n]), dim3(256), 4 * cmax * sizeof(float), st, g),
+            hipLaunchKernelGGL((bn_group_bwd_dx_kernel<bf16_t>), dim3(g.first[n]), dim3(256), 4 * cmax * sizeof(float), st, g));
+  return check_launch("emrt_bn_group_bwd");
+}
+
 // one block per (image, group) when the slice is small enough for two cheap passes and the group is 4..256 channels wide
 static inline bool gn_use_fused(int HW, int C, int G) {
   const int cpg = C / G;

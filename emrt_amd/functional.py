@@ -748,6 +748,116 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 
 
+class _BnGroupDesc(ctypes.Structure):      # EmrtBnGroupDesc (include/emrt_hip.h)
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("sums", ctypes.c_void_p),
+                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("run_mean", ctypes.c_void_p), ("run_var", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+                ("count", ctypes.c_double), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("M", ctypes.c_int), ("C", ctypes.c_int), ("ldx", ctypes.c_int), ("ldy", ctypes.c_int), ("lddy", ctypes.c_int), ("lddx", ctypes.c_int),
+                ("relu", ctypes.c_int)]
+
+
+def _small_group_ok(convs, bns, xs):
+    """the grouped form of conv_bn_group: 2..4 independent 1x1 conv -> BatchNorm (-> ReLU) branches on small token slices, one rank"""
+    c = ctx()
+    if not (c.training and c.bn_small_group and 2 <= len(convs) <= 4 and c.tape is not None and not c.overlap):
+        return False
+    per16 = 4 if c.dtype == F32 else 8
+    for cv, b, x in zip(convs, bns, xs):
+        w = cv.gw
+        if not (x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2] and w.KH == w.KW == 1 and cv.stride == 1 and cv.padding == 0
+                and getattr(cv, "dilation", 1) == 1 and w.bias is None and w.OC > 32 and w.C % per16 == 0 and w.OC % per16 == 0
+                and x.stride(0) % per16 == 0 and x.data_ptr() % 16 == 0 and w.OC % 4 == 0 and 256 % (w.OC // 4) == 0
+                and x.shape[0] * x.shape[1] <= 8192 and cv.need_dx and b.C == w.OC):
+            return False
+    return True
+
+
+def conv_bn_small_group(convs, bns, xs, relu=True):
+    """[conv1x1_i -> BatchNorm_i (-> ReLU)] for 2..4 INDEPENDENT small branches (the pyramid-pooling branches, paddle_EMRT.py:61-66,70-78: 8 ... 512
+    pooled tokens of 256 channels at batch 8) in ONE launch per pass: grouped convolution with the batch statistics in its epilogue
+    (emrt_conv2d_group), grouped BatchNorm apply (emrt_bn_group_apply); backward: grouped BatchNorm backward (reduce + dx: emrt_bn_group_bwd) and
+    grouped data gradient (emrt_conv2d_bwd_group), the weight gradients batched as everywhere.  Round 5 launched 8 kernels forward and 12 backward
+    for these four branches, ~5 us each.  xs: [B, n_i, C] token slices (views of the pooled token tensor)."""
+    c = ctx()
+    n = len(convs)
+    tape = c.tape
+    states = [b.state for b in bns]
+    fd = (_ConvDesc * n)()
+    gd = (_BnGroupDesc * n)()
+    raws, outs, sums, saved, geo = [], [], [], [], []
+    for d, q, cv, st, x in zip(fd, gd, convs, states, xs):
+        w = cv.gw
+        B, L_, C = x.shape
+        raw = c.empty((B, L_, w.OC))
+        out = c.empty((B, L_, w.OC))
+        sm = c.zeros_f64(BN_REPLICAS * 2 * w.OC)
+        mean, invstd = c.empty((w.OC,), torch.float32), c.empty((w.OC,), torch.float32)
+        d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, raw.data_ptr(), None, None, sm.data_ptr()
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, 1, L_, C, x.stride(1), x.stride(0)
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = 1, L_, w.OC, w.OC, L_ * w.OC
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, 1, 1, 1, 0, 0, 0
+        q.x, q.y, q.dy, q.dx, q.sums = raw.data_ptr(), out.data_ptr(), None, None, sm.data_ptr()
+        q.mean, q.invstd, q.run_mean, q.run_var = mean.data_ptr(), invstd.data_ptr(), _dp(st.run_mean), _dp(st.run_var)
+        q.gamma, q.beta, q.dgamma, q.dbeta = st.gamma.data_ptr(), st.beta.data_ptr(), None, None
+        q.count, q.eps, q.momentum = float(B * L_), st.eps, st.momentum
+        q.M, q.C, q.ldx, q.ldy, q.lddy, q.lddx, q.relu = B * L_, w.OC, w.OC, w.OC, w.OC, w.OC, int(relu)
+        raws.append(raw); outs.append(out); sums.append(sm); saved.append((mean, invstd)); geo.append((B, L_, C))
+    _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
+    _L().call("emrt_bn_group_apply", gd, n, c.dtype, c.stream)
+
+    def bwd():
+        dys = [tape.pop_grad(o) for o in outs]
+        live = [i for i in range(n) if dys[i] is not None]
+        if not live:
+            return
+        m = len(live)
+        bq = (_BnGroupDesc * m)()
+        bd = (_ConvBwdDesc * m)()
+        keep, fresh = [], []
+        for q, d, i in zip(bq, bd, live):
+            cv, st, x = convs[i], states[i], xs[i]
+            w = cv.gw
+            B, L_, C = geo[i]
+            dy = dys[i]
+            assert dy.is_contiguous() and dy.dtype == outs[i].dtype
+            draw = c.empty((B, L_, w.OC))                  # gradient of the raw conv output
+            sm2 = c.zeros_f64(BN_REPLICAS * 2 * w.OC)
+            q.x, q.y, q.dy, q.dx, q.sums = raws[i].data_ptr(), outs[i].data_ptr(), dy.data_ptr(), draw.data_ptr(), sm2.data_ptr()
+            q.mean, q.invstd, q.run_mean, q.run_var = saved[i][0].data_ptr(), saved[i][1].data_ptr(), None, None
+            q.gamma, q.beta, q.dgamma, q.dbeta = st.gamma.data_ptr(), st.beta.data_ptr(), st.dgamma.data_ptr(), st.dbeta.data_ptr()
+            q.count, q.eps, q.momentum = float(B * L_), st.eps, st.momentum
+            q.M, q.C, q.ldx, q.ldy, q.lddy, q.lddx, q.relu = B * L_, w.OC, w.OC, w.OC, w.OC, w.OC, int(relu)
+            deferred = wgrad_deferred(w)
+            if deferred:
+                defer_wgrad(tape, x, draw, w, (B, 1, L_, C, x.stride(1), x.stride(0), 1, L_, w.OC, L_ * w.OC), 1, 0, 1)
+            slot = tape.grad_slot(x)
+            dx = slot if slot is not None else c.empty((B, L_, C))
+            assert dx.stride(2) == 1
+            d.x, d.dy, d.w_bwd_packed, d.dx = x.data_ptr(), draw.data_ptr(), w.bwd_ptr, dx.data_ptr()
+            d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = dx.stride(1), dx.stride(0), int(slot is not None), None, None
+            d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, 1, L_, C, x.stride(1), x.stride(0)
+            d.OH, d.OW, d.OC, d.lddy, d.dy_bs = 1, L_, w.OC, w.OC, L_ * w.OC
+            d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+            keep.append((draw, sm2, deferred))
+            if slot is None:
+                fresh.append((x, dx))
+        _L().call("emrt_bn_group_bwd", bq, m, c.dtype, c.stream)
+        if all(k[2] for k in keep):
+            _L().call("emrt_conv2d_bwd_group", bd, m, c.dtype, c.stream)
+        else:           # (weight gradients not batched: EMRT_WGRAD_BATCH=0 / outside Tape.backward): the ordinary one-layer calls
+            for d, i, k in zip(bd, live, keep):
+                w = convs[i].gw
+                w.grad_is_zero = False
+                _L().call("emrt_conv2d_bwd", ctypes.c_void_p(d.x), ctypes.c_void_p(d.dy), ctypes.c_void_p(w.bwd_ptr), ctypes.c_void_p(d.dx), d.lddx, d.dx_bs, d.accumulate,
+                          P(w.grad), None, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, 1, 1, 1, 0, None, None, 0, 0, 1.0,
+                          None, 0, 0, None, 0, 0, 1, c.dtype, c.stream)
+        for x, dx in fresh:
+            tape.add_grad(x, dx, owned=True)
+    tape.record(bwd)
+    return outs
+
+
 def conv_bn_group(convs, bns, xs, relu=True):
     """[conv_i -> SyncBatchNorm_i (-> ReLU)] for several INDEPENDENT branches (the four pyramid-pooling branches,
     paddle_EMRT.py:61-66,70-78) with ONE cross-rank all-reduce of all their statistics per direction instead of one per
@@ -757,6 +867,8 @@ def conv_bn_group(convs, bns, xs, relu=True):
     n = len(convs)
     states = [b.state for b in bns]
     if not (c.training and any(_sync_active(st) for st in states)):
+        if _small_group_ok(convs, bns, xs):
+            return conv_bn_small_group(convs, bns, xs, relu=relu)
         return [conv_bn(cv, b, x, relu=relu) for cv, b, x in zip(convs, bns, xs)]
     assert all(_sync_active(st) for st in states)
     sizes = [BN_REPLICAS * 2 * st.C for st in states]

@@ -164,6 +164,20 @@ int emrt_colsum_acc(const void* x, int ldx, long long rows_per_batch, long long 
  * (<= 4 levels; host arrays): the level embedding's gradient (transformer_encoder_decoder.py:447-448) from every encoder layer's query gradient in one launch. */
 int emrt_colsum_levels_multi(const void* const* xs, int T, const int* level_start, const int* level_count, int L, int B, int Lv, int C, float* dst, int dtype, void* stream);
 
+/* ABI 8: training-mode BatchNorm (+ ReLU) of up to 8 SMALL independent problems in one launch per pass: the four pyramid-pooling branches
+ * (paddle_EMRT.py:61-66,70-78: conv1x1 -> SyncBatchNorm -> ReLU on 1 / 9 / 36 / 64 pooled tokens per image) instead of one emrt_bn_apply forward and one
+ * emrt_bn_bwd_reduce + emrt_bn_bwd_dx backward launch per branch.  x / y / dy / dx: [M][C] rows with their strides; `sums`: forward the COMPLETE fp64
+ * (sum x, sum x^2) [8][2C] of the producing conv's epilogue, backward a ZEROED [8][2C]; mean / invstd are written by the forward and read by the backward;
+ * dgamma / dbeta are accumulated.  Forward bit-identical to emrt_bn_apply.  One rank only (no statistics all-reduce between the passes). */
+typedef struct EmrtBnGroupDesc {
+  const void* x; void* y; const void* dy; void* dx; double* sums;
+  float* mean; float* invstd; float* run_mean; float* run_var; const float* gamma; const float* beta; float* dgamma; float* dbeta;
+  double count; float eps, momentum;
+  int M, C, ldx, ldy, lddy, lddx, relu;
+} EmrtBnGroupDesc;
+int emrt_bn_group_apply(const EmrtBnGroupDesc* descs, int n, int dtype, void* stream);
+int emrt_bn_group_bwd(const EmrtBnGroupDesc* descs, int n, int dtype, void* stream);
+
 /* ---- GroupNorm(32) [+ erf-GELU] [+ residual]: transformer_encoder_decoder.py:125-144 (conv branch), :378 (input_proj).
  * workspace: PRE-ZEROED fp64, [N*G*2] for fwd (group sums), [N*C*2] for bwd (per-image channel sums). */
 int emrt_groupnorm_fwd(const void* x, int ldx, long long x_bs, const void* res, int ldres, long long res_bs, void* out, int ldout, long long out_bs, const float* gamma, const float* beta, float* mean, float* rstd, double* workspace, int N, int HW, int C, int G, float eps, int gelu, int dtype, void* stream);

@@ -1733,6 +1733,77 @@ def test_adaptive_pool_split_bins(dtype, H, W, C, Ctot):
     close("pool dx %dx%d" % (H, W), host_map(dx), xr.grad, dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pyramid_pooling_branches_as_grouped_launches(dtype):
+    """The four pyramid-pooling branches conv1x1 -> BatchNorm(train) -> ReLU on 1 / 9 / 36 / 64 pooled tokens per image (paddle_EMRT.py:61-66,70-78) as ONE
+    grouped launch per pass (functional.conv_bn_small_group: emrt_conv2d_group with the statistics in its epilogue, emrt_bn_group_apply; backward
+    emrt_bn_group_bwd + emrt_conv2d_bwd_group) against one launch per branch and pass: forward bit-identical (same arithmetic), every gradient and the
+    running statistics equal to reduction-order noise; and against torch."""
+    from emrt_amd import _lib
+    B, C = 8, 256
+    scales = [1, 3, 6, 8]
+    g = torch.Generator().manual_seed(55)
+    tok = torch.randn(B, sum(k * k for k in scales), C, generator=g)
+    ws = [torch.randn(C, C, 1, 1, generator=g) / math.sqrt(C) for _ in scales]
+    gams = [torch.rand(C, generator=g) + 0.5 for _ in scales]
+    bets = [torch.randn(C, generator=g) * 0.3 for _ in scales]
+    dys = [torch.randn(B, k * k, C, generator=g) for k in scales]
+    L = _lib.lib()
+
+    def run(grouped):
+        c = init(dtype)
+        c.bn_small_group = grouped
+        convs = [hnn.Conv2D(C, C, 1, bias=False) for _ in scales]
+        bns = [hnn.BatchNorm2D(C) for _ in scales]
+        with torch.no_grad():
+            for cv, b, w_, ga, be in zip(convs, bns, ws, gams, bets):
+                cv.weight.copy_(rnd(w_))
+                b.weight.copy_(ga)
+                b.bias.copy_(be)
+        Holder(**{"c%d" % i: m_ for i, m_ in enumerate(convs)}, **{"b%d" % i: m_ for i, m_ in enumerate(bns)}).place()
+        td = dev(rnd(tok))
+        tape = Tape()
+        c.tape = tape
+        L.start_record()
+        slices, s0 = [], 0
+        for k in scales:
+            slices.append(Fn.narrow(td, 1, s0, k * k))
+            s0 += k * k
+        outs = Fn.conv_bn_group(convs, bns, slices)
+        names = [n for n, _ in L.stop_record() if n != "emrt_memset"]      # (outside a training step the fp64 sums are zeroed one by one)
+        c.tape = None
+        tape.watch(td)
+        L.start_record()
+        dtok, = run_bwd(tape, [(o, dev(rnd(d_))) for o, d_ in zip(outs, dys)], [td])
+        names_b = [n for n, _ in L.stop_record()]
+        torch.cuda.synchronize()
+        c.bn_small_group = True
+        return names, names_b, ([host(o) for o in outs] + [host(dtok)] + [host(cv.weight.grad) for cv in convs] + [host(b.weight.grad) for b in bns]
+                                + [host(b.bias.grad) for b in bns] + [host(b._buffers["_mean"]) for b in bns] + [host(b._buffers["_variance"]) for b in bns])
+
+    n1, nb1, r1 = run(True)
+    n0, nb0, r0 = run(False)
+    assert n1 == ["emrt_conv2d_group", "emrt_bn_group_apply"], n1
+    assert n0.count("emrt_conv2d") == 4 and n0.count("emrt_bn_apply") == 4, n0
+    assert nb1.count("emrt_bn_group_bwd") == 1 and nb1.count("emrt_conv2d_bwd_group") == 1 and "emrt_bn_bwd_dx" not in nb1, nb1
+    assert nb0.count("emrt_bn_bwd_dx") == 4, nb0
+    for i in range(4):
+        assert torch.equal(r1[i], r0[i]), "branch %d: grouped forward differs from emrt_bn_apply's" % i
+    tol = 2e-2 if dtype == BF16 else 2e-5
+    for u, v in zip(r1[4:], r0[4:]):
+        assert torch.isfinite(u).all()
+        assert (u - v).abs().max().item() <= tol * max(1.0, v.abs().max().item()), (u - v).abs().max().item()
+    # ... and torch (fp32): branch 2
+    if dtype == F32:
+        a, b_ = sum(k * k for k in scales[:2]), sum(k * k for k in scales[:3])
+        xr = tok[:, a:b_].clone().requires_grad_(True)
+        y = F.conv2d(xr.permute(0, 2, 1).unsqueeze(-1), ws[2])
+        o = F.relu(F.batch_norm(y, None, None, gams[2], bets[2], True, 0.1, 1e-5)).squeeze(-1).permute(0, 2, 1)
+        o.backward(dys[2])
+        close("grouped branch vs torch", r1[2], o.detach(), dtype, 4.0)
+        close("grouped d tokens vs torch", r1[4][:, a:b_], xr.grad, dtype, 8.0)
+
+
 # -----------------------------------------------------------------------------------------------------------------
 # BatchNorm + ReLU between two convolutions applied by the CONSUMING convolution's operand loads (emrt_conv2d_bna; csrc/conv.hip: igemm_body BNA)
 # -----------------------------------------------------------------------------------------------------------------

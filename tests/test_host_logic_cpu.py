@@ -64,7 +64,10 @@ def test_train_step_launch_sequence(fake, backbone):
     n_grouped = sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_bwd_group")     # problems inside grouped backward launches
     # (4 encoder layers + input_proj) x 3 levels, + value_proj | offsets-logits projection of the 6 deformable attentions as pairs,
     # + the q|k and v projections of the decoder's 2 softmax attentions as pairs
-    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15 + 12 + 4
+    # + the four pyramid-pooling branches (conv1x1 -> BatchNorm -> ReLU: functional.conv_bn_small_group) as one grouped launch each way
+    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15 + 12 + 4 + 4
+    assert cnt["emrt_bn_group_apply"] == cnt["emrt_bn_group_bwd"] == 1
+    assert all(a[1] == 4 for n, a in fake.calls if n in ("emrt_bn_group_apply", "emrt_bn_group_bwd"))
     pairs = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 2]
     msda_pairs = [a for a in pairs if a[0][1].out_f32 == 1]
     mha_pairs = [a for a in pairs if a[0][1].out_f32 == 0]
@@ -103,13 +106,15 @@ def test_train_step_launch_sequence(fake, backbone):
     assert n_conv_fused == n_blocks + n_bottle + 3 + 1
     bna = [a for n, a in fake.calls if n == "emrt_conv2d_bna"]
     assert all(a[26] is not None and a[37] is not None and a[36] == 1 for a in bna)      # sums, a_out, ReLU
-    n_defer = n_stream + 1 + n_join_defer + n_conv_fused
-    assert cnt["emrt_bn_apply"] + cnt["emrt_bn_apply_join"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn and cnt["emrt_bn_stats"] == 0
+    n_psp = 4          # the pyramid-pooling branches: grouped apply / backward launches of their own (emrt_bn_group_apply / _bwd)
+    n_defer = n_stream + 1 + n_join_defer + n_conv_fused + n_psp
+    assert cnt["emrt_bn_apply"] + cnt["emrt_bn_apply_join"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn - n_psp and cnt["emrt_bn_stats"] == 0
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
     bna_stats = sum(1 for a in bna if a[24] is not None)      # (emrt_conv2d_bna: bn_stats is argument 24)
     assert not any(n == "emrt_conv2d" and a[22] == 1 for n, a in fake.calls)      # data gradients go through emrt_conv2d_bwd
     dgrads = [a for n, a in fake.calls if n == "emrt_conv2d_bwd"]
-    assert sum(1 for a in fwd_convs if a[25] is not None) + bna_stats == n_bn     # forward statistics fused into the conv epilogue
+    grouped_stats = sum(1 for n, a in fake.calls if n == "emrt_conv2d_group" for i in range(a[1]) if a[0][i].bn_stats)
+    assert sum(1 for a in fwd_convs if a[25] is not None) + bna_stats + grouped_stats == n_bn     # forward statistics fused into the conv epilogue
     # BatchNorm -> ReLU -> conv chains: the conv's dgrad carries the ReLU mask and the BatchNorm's backward sums, and the
     # separate reduction pass only remains for the other BatchNorms (residual joins, multi-consumer outputs, no ReLU)
     n_fused = sum(1 for a in dgrads if a[24] is not None)
@@ -135,7 +140,7 @@ def test_train_step_launch_sequence(fake, backbone):
     assert not any(a[20] is not None and a[21] == 1 for n, a in fake.calls if n == "emrt_bn_bwd_dx")
     assert all(a[4] is None for n, a in fake.calls if n == "emrt_bn_bwd_dx" and (a[20] is not None or a[21] == 1))     # fused: dy arrives masked
     # (the classifier's one-pass backward hands its BatchNorm the (sum, sum * y) form too, without being an emrt_conv2d_bwd call)
-    assert fused_y + fused_x + cnt["emrt_bn_bwd_reduce"] == n_bn and 0 < fused_y + fused_x <= n_fused + 1
+    assert fused_y + fused_x + cnt["emrt_bn_bwd_reduce"] == n_bn - n_psp and 0 < fused_y + fused_x <= n_fused + 1
     n_join_bn = sum(1 for n, a in fake.calls if n == "emrt_bn_apply" and a[2] is not None and a[18] == 1) + cnt["emrt_bn_apply_join"]
     assert 0 < fused_x <= n_join_bn and fused_x >= n_join_bn - 4, (fused_x, n_join_bn)     # every join inside the backbone stages
     assert fused_y >= n_bn // 3, (fused_y, n_bn)
