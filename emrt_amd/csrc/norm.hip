@@ -1544,6 +1544,9 @@ struct EmrtBnGroupDesc {
   double count;
   float eps, momentum;
   int M, C, ldx, ldy, lddy, lddx, relu;
+  const void* res;        // forward, nullable: y = [relu](BN(x)) + res  (Conv2dBlock's "conv2(conv1(x)) + x", paddle_EMRT.py:24-29; its gradient is dy itself)
+  int ldres, res_hw;      // row r of the problem is pixel r % res_hw of image r / res_hw: res + image * res_bs + pixel * ldres (a level slab of the token tensor)
+  long long res_bs;
 };
 struct BnGroupArgs { EmrtBnGroupDesc d[EMRT_MAX_BNGROUP]; int first[EMRT_MAX_BNGROUP + 1]; int n; };
 
@@ -1593,10 +1596,19 @@ __global__ __launch_bounds__(256) void bn_group_apply_kernel(BnGroupArgs g) {
     Vec4<T>::load(x + (long long)r * d.ldx + c, v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { o[e] = fmaf(v[e], sc[e], sh[e]); if (d.relu) o[e] = fmaxf(o[e], 0.f); }
+    if (d.res) {
+      float w[4];
+      const int img = r / d.res_hw;
+      Vec4<T>::load((const T*)d.res + (long long)img * d.res_bs + (long long)(r - img * d.res_hw) * d.ldres + c, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += w[e];
+    }
     Vec4<T>::store(y + (long long)r * d.ldy + c, o);
   }
 }
 
+// backward: the ReLU mask is re-derived from the raw x with the forward's own expression (bn_scale_shift + one fmaf on the saved mean / invstd: the same
+// bits, so forward and backward agree on every element) -- the output y may hold "+ res" and is not read
 // backward, pass 1: sums[0][c] += sum_r dy', sums[0][C + c] += sum_r dy' * xhat   (dy' = dy where y > 0; xhat from the raw x and the saved statistics)
 template <class T>
 __global__ __launch_bounds__(256) void bn_group_bwd_reduce_kernel(BnGroupArgs g) {
@@ -1607,20 +1619,18 @@ __global__ __launch_bounds__(256) void bn_group_bwd_reduce_kernel(BnGroupArgs g)
   const int c = ((int)threadIdx.x % quads) * 4, lane_row = (int)threadIdx.x / quads;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (lane_row < lanes) {
-    float mu[4], is[4];
+    float mu[4], is[4], sc[4], sh[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { mu[e] = d.mean[c + e]; is[e] = d.invstd[c + e]; }
+    for (int e = 0; e < 4; ++e) { mu[e] = d.mean[c + e]; is[e] = d.invstd[c + e]; bn_scale_shift(mu[e], is[e], d.gamma[c + e], d.beta[c + e], sc[e], sh[e]); }
     const T* x = (const T*)d.x;
     const T* dy = (const T*)d.dy;
-    const T* y = (const T*)d.y;
     for (int r = local * lanes + lane_row; r < d.M; r += nblk * lanes) {
-      float v[4], gq[4], yy[4];
+      float v[4], gq[4];
       Vec4<T>::load(x + (long long)r * d.ldx + c, v);
       Vec4<T>::load(dy + (long long)r * d.lddy + c, gq);
-      if (d.relu) Vec4<T>::load(y + (long long)r * d.ldy + c, yy);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float gd = (!d.relu || yy[e] > 0.f) ? gq[e] : 0.f;
+        const float gd = (!d.relu || fmaf(v[e], sc[e], sh[e]) > 0.f) ? gq[e] : 0.f;
         s1[e] += gd;
         s2[e] = fmaf(gd, (v[e] - mu[e]) * is[e], s2[e]);
       }
@@ -1658,21 +1668,22 @@ __global__ __launch_bounds__(256) void bn_group_bwd_dx_kernel(BnGroupArgs g) {
   }
   __syncthreads();
   if (lane_row >= lanes) return;
-  float k[4], m1[4], m2[4], mu[4], is[4];
+  float k[4], m1[4], m2[4], mu[4], is[4], sc[4], sh[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { k[e] = bn_lds[c + e]; m1[e] = bn_lds[C + c + e]; m2[e] = bn_lds[2 * C + c + e]; mu[e] = d.mean[c + e]; is[e] = d.invstd[c + e]; }
+  for (int e = 0; e < 4; ++e) {
+    k[e] = bn_lds[c + e]; m1[e] = bn_lds[C + c + e]; m2[e] = bn_lds[2 * C + c + e]; mu[e] = d.mean[c + e]; is[e] = d.invstd[c + e];
+    bn_scale_shift(mu[e], is[e], d.gamma[c + e], d.beta[c + e], sc[e], sh[e]);
+  }
   const T* x = (const T*)d.x;
   const T* dy = (const T*)d.dy;
-  const T* y = (const T*)d.y;
   T* dx = (T*)d.dx;
   for (int r = local * lanes + lane_row; r < d.M; r += nblk * lanes) {
-    float v[4], gq[4], yy[4], o[4];
+    float v[4], gq[4], o[4];
     Vec4<T>::load(x + (long long)r * d.ldx + c, v);
     Vec4<T>::load(dy + (long long)r * d.lddy + c, gq);
-    if (d.relu) Vec4<T>::load(y + (long long)r * d.ldy + c, yy);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gd = (!d.relu || yy[e] > 0.f) ? gq[e] : 0.f;
+      const float gd = (!d.relu || fmaf(v[e], sc[e], sh[e]) > 0.f) ? gq[e] : 0.f;
       o[e] = k[e] * (gd - m1[e] - (v[e] - mu[e]) * is[e] * m2[e]);
     }
     Vec4<T>::store(dx + (long long)r * d.lddx + c, o);
@@ -1688,14 +1699,15 @@ static int bn_group_fill(BnGroupArgs& g, const EmrtBnGroupDesc* descs, int n, in
     if (d.C % 4 != 0 || d.C / 4 > 256 || 256 % (d.C / 4) != 0) return fail(fn, "C / 4 must divide 256");
     if (d.ldx % 4 || ((uintptr_t)d.x) % 8) return fail(fn, "x rows must be 8-byte aligned");
     if (pass == 0 && (!d.y || d.ldy % 4)) return fail(fn, "forward needs y");
-    if (pass != 0 && (!d.dy || (pass == 2 && !d.dx) || (d.relu && !d.y) || d.lddy % 4 || (pass == 2 && d.lddx % 4))) return fail(fn, "backward needs dy, dx and (with relu) y");
+    if (pass != 0 && (!d.dy || (pass == 2 && !d.dx) || d.lddy % 4 || (pass == 2 && d.lddx % 4))) return fail(fn, "backward needs dy and dx");
+    if (pass == 0 && d.res && (d.ldres % 4 || d.res_bs % 4 || d.res_hw <= 0)) return fail(fn, "res rows must be 8-byte aligned, res_hw > 0");
     if ((d.run_mean != nullptr) != (d.run_var != nullptr)) return fail(fn, "running statistics come in pairs");
     g.d[i] = d;
     g.first[i] = total;
     const int lanes = 256 / (d.C / 4);
     int nb = (d.M + lanes * 4 - 1) / (lanes * 4);          // ~4 rows per thread
     if (nb < 1) nb = 1;
-    if (nb > 64) nb = 64;
+    if (nb > 256) nb = 256;
     total += nb;
   }
   for (int i = n; i <= EMRT_MAX_BNGROUP; ++i) g.first[i] = total;

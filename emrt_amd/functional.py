@@ -754,57 +754,83 @@ class _BnGroupDesc(ctypes.Structure):      # EmrtBnGroupDesc (include/emrt_hip.h
                 ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
                 ("count", ctypes.c_double), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
                 ("M", ctypes.c_int), ("C", ctypes.c_int), ("ldx", ctypes.c_int), ("ldy", ctypes.c_int), ("lddy", ctypes.c_int), ("lddx", ctypes.c_int),
-                ("relu", ctypes.c_int)]
+                ("relu", ctypes.c_int), ("res", ctypes.c_void_p), ("ldres", ctypes.c_int), ("res_hw", ctypes.c_int), ("res_bs", ctypes.c_longlong)]
 
 
-def _small_group_ok(convs, bns, xs):
-    """the grouped form of conv_bn_group: 2..4 independent 1x1 conv -> BatchNorm (-> ReLU) branches on small token slices, one rank"""
+def _small_group_ok(convs, bns, xs, post_adds=None):
+    """the grouped form: 2..4 independent stride-1 "same" conv -> BatchNorm (-> ReLU) branches on token slices / NHWC map views, one rank"""
     c = ctx()
     if not (c.training and c.bn_small_group and 2 <= len(convs) <= 4 and c.tape is not None and not c.overlap):
         return False
     per16 = 4 if c.dtype == F32 else 8
-    for cv, b, x in zip(convs, bns, xs):
+    tiles = 0
+    for i, (cv, b, x) in enumerate(zip(convs, bns, xs)):
         w = cv.gw
-        if not (x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2] and w.KH == w.KW == 1 and cv.stride == 1 and cv.padding == 0
-                and getattr(cv, "dilation", 1) == 1 and w.bias is None and w.OC > 32 and w.C % per16 == 0 and w.OC % per16 == 0
-                and x.stride(0) % per16 == 0 and x.data_ptr() % 16 == 0 and w.OC % 4 == 0 and 256 % (w.OC // 4) == 0
-                and x.shape[0] * x.shape[1] <= 8192 and cv.need_dx and b.C == w.OC):
+        if isinstance(x, PendingBN) or x.dim() not in (3, 4) or x.stride(-1) != 1:
             return False
-    return True
+        N, H, W, C, ld, bs = _check_map(x)
+        pad = cv.padding
+        if not (w.KH == w.KW and w.KH in (1, 3) and cv.stride == 1 and pad == w.KH // 2 and getattr(cv, "dilation", 1) == 1 and w.bias is None
+                and w.OC > 32 and C == w.C and C % per16 == 0 and w.OC % per16 == 0 and ld % per16 == 0 and bs % per16 == 0 and x.data_ptr() % 16 == 0
+                and w.OC % 4 == 0 and 256 % (w.OC // 4) == 0 and N * H * W <= 16384 and cv.need_dx and b.C == w.OC and not _sync_active(b.state)):
+            return False
+        if post_adds is not None and post_adds[i] is not None:
+            r = post_adds[i]
+            if tuple(r.shape[:-1]) != tuple(x.shape[:-1]) or r.shape[-1] != w.OC or r.stride(-1) != 1 or r.dtype != x.dtype:
+                return False
+            rN, rH, rW, rC, rld, rbs = _check_map(r)
+            if rld % 4 or rbs % 4:
+                return False
+        tiles += ((N * H * W + 63) // 64) * ((w.OC + 63) // 64)
+    return tiles <= 4096
 
 
-def conv_bn_small_group(convs, bns, xs, relu=True):
-    """[conv1x1_i -> BatchNorm_i (-> ReLU)] for 2..4 INDEPENDENT small branches (the pyramid-pooling branches, paddle_EMRT.py:61-66,70-78: 8 ... 512
-    pooled tokens of 256 channels at batch 8) in ONE launch per pass: grouped convolution with the batch statistics in its epilogue
-    (emrt_conv2d_group), grouped BatchNorm apply (emrt_bn_group_apply); backward: grouped BatchNorm backward (reduce + dx: emrt_bn_group_bwd) and
-    grouped data gradient (emrt_conv2d_bwd_group), the weight gradients batched as everywhere.  Round 5 launched 8 kernels forward and 12 backward
-    for these four branches, ~5 us each.  xs: [B, n_i, C] token slices (views of the pooled token tensor)."""
+def conv_bn_small_group(convs, bns, xs, relu=True, post_adds=None):
+    """[conv_i -> BatchNorm_i (-> ReLU) (+ post_add_i)] for 2..4 INDEPENDENT small branches in ONE launch per pass: grouped convolution with the batch
+    statistics in its epilogue (emrt_conv2d_group), grouped BatchNorm apply (emrt_bn_group_apply); backward: grouped BatchNorm backward (reduce + dx:
+    emrt_bn_group_bwd) and grouped data gradient (emrt_conv2d_bwd_group), the weight gradients batched as everywhere.
+      * the four pyramid-pooling branches (paddle_EMRT.py:61-66,70-78: conv1x1 on 8 ... 512 pooled tokens of 256 channels at batch 8): round 5 launched
+        8 kernels forward and 12 backward for them, ~5 us each;
+      * the three Conv2dBlocks of EFP (paddle_EMRT.py:13-48: 3x3 convs on the 32^2 / 16^2 / 8^2 level maps, "conv2(conv1(x)) + x"): the three levels side
+        by side fill the machine where each alone is a latency-bound launch (as the encoder's per-level convs, level_conv_gn).
+    xs: [B, n_i, C] token slices or [B, h_i, w_i, C] map views (strided views of a token slab are fine); post_adds[i] (optional, dense rows): added AFTER
+    the ReLU by the BatchNorm launch; its gradient is the output's."""
     c = ctx()
     n = len(convs)
     tape = c.tape
     states = [b.state for b in bns]
     fd = (_ConvDesc * n)()
     gd = (_BnGroupDesc * n)()
-    raws, outs, sums, saved, geo = [], [], [], [], []
-    for d, q, cv, st, x in zip(fd, gd, convs, states, xs):
+    raws, outs, saved, geo, alive = [], [], [], [], []
+    for i, (d, q, cv, st, x) in enumerate(zip(fd, gd, convs, states, xs)):
         w = cv.gw
-        B, L_, C = x.shape
-        raw = c.empty((B, L_, w.OC))
-        out = c.empty((B, L_, w.OC))
+        N, H, W, C, ld, bs = _check_map(x)
+        oshape = _like_shape(x, w.OC)
+        raw = c.empty(oshape)
+        out = c.empty(oshape)
         sm = c.zeros_f64(BN_REPLICAS * 2 * w.OC)
         mean, invstd = c.empty((w.OC,), torch.float32), c.empty((w.OC,), torch.float32)
+        M = N * H * W
         d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, raw.data_ptr(), None, None, sm.data_ptr()
-        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, 1, L_, C, x.stride(1), x.stride(0)
-        d.OH, d.OW, d.OC, d.ldout, d.out_bs = 1, L_, w.OC, w.OC, L_ * w.OC
-        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, 1, 1, 1, 0, 0, 0
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = N, H, W, C, ld, bs
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = H, W, w.OC, w.OC, H * W * w.OC
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, w.KH, w.KW, 1, cv.padding, 0, 0
+        r = post_adds[i] if post_adds is not None else None
         q.x, q.y, q.dy, q.dx, q.sums = raw.data_ptr(), out.data_ptr(), None, None, sm.data_ptr()
         q.mean, q.invstd, q.run_mean, q.run_var = mean.data_ptr(), invstd.data_ptr(), _dp(st.run_mean), _dp(st.run_var)
         q.gamma, q.beta, q.dgamma, q.dbeta = st.gamma.data_ptr(), st.beta.data_ptr(), None, None
-        q.count, q.eps, q.momentum = float(B * L_), st.eps, st.momentum
-        q.M, q.C, q.ldx, q.ldy, q.lddy, q.lddx, q.relu = B * L_, w.OC, w.OC, w.OC, w.OC, w.OC, int(relu)
-        raws.append(raw); outs.append(out); sums.append(sm); saved.append((mean, invstd)); geo.append((B, L_, C))
+        q.count, q.eps, q.momentum = float(M), st.eps, st.momentum
+        q.M, q.C, q.ldx, q.ldy, q.lddy, q.lddx, q.relu = M, w.OC, w.OC, w.OC, w.OC, w.OC, int(relu)
+        if r is not None:
+            _, rH, rW, _, rld, rbs = _check_map(r)
+            q.res, q.ldres, q.res_hw, q.res_bs = r.data_ptr(), rld, rH * rW, rbs
+        else:
+            q.res, q.ldres, q.res_hw, q.res_bs = None, 0, 1, 0
+        raws.append(raw); outs.append(out); saved.append((mean, invstd)); geo.append((N, H, W, C, ld, bs))
+        alive.append(sm)          # (outside a training step the sums are buffers of their own: they must outlive the two launches below)
     _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
     _L().call("emrt_bn_group_apply", gd, n, c.dtype, c.stream)
+    del alive
 
     def bwd():
         dys = [tape.pop_grad(o) for o in outs]
@@ -818,27 +844,33 @@ def conv_bn_small_group(convs, bns, xs, relu=True):
         for q, d, i in zip(bq, bd, live):
             cv, st, x = convs[i], states[i], xs[i]
             w = cv.gw
-            B, L_, C = geo[i]
+            N, H, W, C, ld, bs = geo[i]
+            M = N * H * W
             dy = dys[i]
-            assert dy.is_contiguous() and dy.dtype == outs[i].dtype
-            draw = c.empty((B, L_, w.OC))                  # gradient of the raw conv output
+            # (a gradient may arrive as a channel slice of a wider buffer -- the concat buffer's gradient: rows uniformly strided, which is all the kernels need)
+            _, dH, dW, _, lddy, dy_bs = _check_map(dy)
+            assert dy.dtype == outs[i].dtype and dy_bs == dH * dW * lddy and lddy % 4 == 0, (tuple(dy.shape), dy.stride())
+            if post_adds is not None and post_adds[i] is not None:
+                tape.add_grad(post_adds[i], dy)                 # d(x + f(x)) / dx, the identity part
+            draw = c.empty(tuple(outs[i].shape))                # gradient of the raw conv output
             sm2 = c.zeros_f64(BN_REPLICAS * 2 * w.OC)
             q.x, q.y, q.dy, q.dx, q.sums = raws[i].data_ptr(), outs[i].data_ptr(), dy.data_ptr(), draw.data_ptr(), sm2.data_ptr()
             q.mean, q.invstd, q.run_mean, q.run_var = saved[i][0].data_ptr(), saved[i][1].data_ptr(), None, None
             q.gamma, q.beta, q.dgamma, q.dbeta = st.gamma.data_ptr(), st.beta.data_ptr(), st.dgamma.data_ptr(), st.dbeta.data_ptr()
-            q.count, q.eps, q.momentum = float(B * L_), st.eps, st.momentum
-            q.M, q.C, q.ldx, q.ldy, q.lddy, q.lddx, q.relu = B * L_, w.OC, w.OC, w.OC, w.OC, w.OC, int(relu)
+            q.count, q.eps, q.momentum = float(M), st.eps, st.momentum
+            q.M, q.C, q.ldx, q.ldy, q.lddy, q.lddx, q.relu = M, w.OC, w.OC, w.OC, lddy, w.OC, int(relu)
+            q.res, q.ldres, q.res_hw, q.res_bs = None, 0, 1, 0
             deferred = wgrad_deferred(w)
             if deferred:
-                defer_wgrad(tape, x, draw, w, (B, 1, L_, C, x.stride(1), x.stride(0), 1, L_, w.OC, L_ * w.OC), 1, 0, 1)
+                defer_wgrad(tape, x, draw, w, (N, H, W, C, ld, bs, H, W, w.OC, H * W * w.OC), 1, cv.padding, 1)
             slot = tape.grad_slot(x)
-            dx = slot if slot is not None else c.empty((B, L_, C))
-            assert dx.stride(2) == 1
+            dx = slot if slot is not None else c.empty(tuple(x.shape))
+            _, _, _, _, lddx, dx_bs = _check_map(dx)
             d.x, d.dy, d.w_bwd_packed, d.dx = x.data_ptr(), draw.data_ptr(), w.bwd_ptr, dx.data_ptr()
-            d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = dx.stride(1), dx.stride(0), int(slot is not None), None, None
-            d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, 1, L_, C, x.stride(1), x.stride(0)
-            d.OH, d.OW, d.OC, d.lddy, d.dy_bs = 1, L_, w.OC, w.OC, L_ * w.OC
-            d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+            d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = lddx, dx_bs, int(slot is not None), None, None
+            d.N, d.H, d.W, d.C, d.ldx, d.x_bs = N, H, W, C, ld, bs
+            d.OH, d.OW, d.OC, d.lddy, d.dy_bs = H, W, w.OC, w.OC, H * W * w.OC
+            d.KH, d.KW, d.stride, d.pad = w.KH, w.KW, 1, cv.padding
             keep.append((draw, sm2, deferred))
             if slot is None:
                 fresh.append((x, dx))
@@ -846,11 +878,11 @@ def conv_bn_small_group(convs, bns, xs, relu=True):
         if all(k[2] for k in keep):
             _L().call("emrt_conv2d_bwd_group", bd, m, c.dtype, c.stream)
         else:           # (weight gradients not batched: EMRT_WGRAD_BATCH=0 / outside Tape.backward): the ordinary one-layer calls
-            for d, i, k in zip(bd, live, keep):
+            for d, i in zip(bd, live):
                 w = convs[i].gw
                 w.grad_is_zero = False
                 _L().call("emrt_conv2d_bwd", ctypes.c_void_p(d.x), ctypes.c_void_p(d.dy), ctypes.c_void_p(w.bwd_ptr), ctypes.c_void_p(d.dx), d.lddx, d.dx_bs, d.accumulate,
-                          P(w.grad), None, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, 1, 1, 1, 0, None, None, 0, 0, 1.0,
+                          P(w.grad), None, d.N, d.H, d.W, d.C, d.ldx, d.x_bs, d.OH, d.OW, d.OC, d.lddy, d.dy_bs, d.KH, d.KW, 1, d.pad, None, None, 0, 0, 1.0,
                           None, 0, 0, None, 0, 0, 1, c.dtype, c.stream)
         for x, dx in fresh:
             tape.add_grad(x, dx, owned=True)

@@ -575,6 +575,18 @@ class EFP(hnn.HipLayer):  # :31-48
         self.conv0, self.conv1, self.conv2 = Conv2dBlock(cin, cout), Conv2dBlock(cin, cout), Conv2dBlock(cin, cout)
 
     def forward(self, x0, x1, x2, out):
+        blocks, xs = (self.conv0, self.conv1, self.conv2), (x0, x1, x2)
+        c1, b1 = [b.conv1[0] for b in blocks], [b.conv1[1] for b in blocks]
+        c2, b2 = [b.conv2[0] for b in blocks], [b.conv2[1] for b in blocks]
+        if Fn._small_group_ok(c1, b1, xs):
+            # the three Conv2dBlocks level by level in grouped launches: conv1 of all levels | BatchNorm + ReLU | conv2 | BatchNorm + ReLU + x
+            mid = Fn.conv_bn_small_group(c1, b1, xs, relu=True)
+            if Fn._small_group_ok(c2, b2, mid, post_adds=xs):
+                o0, o1, o2 = Fn.conv_bn_small_group(c2, b2, mid, relu=True, post_adds=xs)
+            else:
+                o0, o1, o2 = [Fn.add_maps(Fn.conv_bn(cv, b, m_, relu=True), x) for cv, b, m_, x in zip(c2, b2, mid, xs)]
+            x21 = Fn.resize_bilinear(o2, x1.shape[1], x1.shape[2], True, add_t=o1)
+            return Fn.resize_bilinear(x21, x0.shape[1], x0.shape[2], True, add_t=o0, out=out)
         o2 = self.conv2(x2)
         o1 = self.conv1(x1)
         x21 = Fn.resize_bilinear(o2, x1.shape[1], x1.shape[2], True, add_t=o1)            # conv1(x1) + up(conv2(x2))

@@ -174,6 +174,8 @@ typedef struct EmrtBnGroupDesc {
   float* mean; float* invstd; float* run_mean; float* run_var; const float* gamma; const float* beta; float* dgamma; float* dbeta;
   double count; float eps, momentum;
   int M, C, ldx, ldy, lddy, lddx, relu;
+  const void* res; int ldres, res_hw; long long res_bs;      /* forward, nullable: y = [relu](BN(x)) + res (paddle_EMRT.py:24-29), row r = pixel r % res_hw of image r / res_hw at
+                                                                res + image * res_bs + pixel * ldres; the backward re-derives the ReLU mask from x, y is not read */
 } EmrtBnGroupDesc;
 int emrt_bn_group_apply(const EmrtBnGroupDesc* descs, int n, int dtype, void* stream);
 int emrt_bn_group_bwd(const EmrtBnGroupDesc* descs, int n, int dtype, void* stream);

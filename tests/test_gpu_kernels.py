@@ -1804,6 +1804,81 @@ def test_pyramid_pooling_branches_as_grouped_launches(dtype):
         close("grouped d tokens vs torch", r1[4][:, a:b_], xr.grad, dtype, 8.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_efp_conv2d_blocks_level_by_level_in_grouped_launches(dtype):
+    """EFP's three Conv2dBlocks (paddle_EMRT.py:13-48: relu(bn(conv3x3(relu(bn(conv3x3(x)))))) + x on the three pyramid levels, whose inputs are strided
+    level slabs of the token tensor) as grouped launches -- conv1 of all levels | BatchNorm + ReLU | conv2 | BatchNorm + ReLU + x (the residual added by the
+    BatchNorm launch, the ReLU mask re-derived from the raw map in backward) -- against one Conv2dBlock at a time, and against torch in fp32."""
+    from emrt_amd import _lib
+    from emrt_amd.src.models.emrt import EFP
+    B, C = 2, 256
+    shapes = [(16, 16), (8, 8), (4, 4)]
+    Lv = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(77)
+    mem = torch.randn(B, Lv, C, generator=g)
+    wts = [torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C) for _ in range(6)]
+    dy = torch.randn(B, C, 16, 16, generator=g)
+    L = _lib.lib()
+
+    def run(grouped):
+        c = init(dtype)
+        c.bn_small_group = grouped
+        efp = EFP(C, C)
+        convs = [efp.conv0.conv1[0], efp.conv0.conv2[0], efp.conv1.conv1[0], efp.conv1.conv2[0], efp.conv2.conv1[0], efp.conv2.conv2[0]]
+        with torch.no_grad():
+            for cv, w_ in zip(convs, wts):
+                cv.weight.copy_(rnd(w_))
+        Holder(efp=efp).place()
+        md = dev(rnd(mem))
+        tape = Tape()
+        c.tape = tape
+        maps, s0 = [], 0
+        for h, w_ in shapes:
+            maps.append(Fn.tokens_as_map(Fn.narrow(md, 1, s0, h * w_), h, w_))
+            s0 += h * w_
+        out = c.empty((B, 16, 16, C))
+        L.start_record()
+        y = efp(maps[0], maps[1], maps[2], out=out)
+        names = [n for n, _ in L.stop_record() if n != "emrt_memset"]
+        c.tape = None
+        tape.watch(md)
+        dmem, = run_bwd(tape, [(y, dev_map(rnd(dy)))], [md])
+        torch.cuda.synchronize()
+        c.bn_small_group = True
+        return names, [host_map(y), host(dmem)] + [host(cv.weight.grad) for cv in convs]
+
+    n1, r1 = run(True)
+    n0, r0 = run(False)
+    assert n1.count("emrt_conv2d_group") == 2 and n1.count("emrt_bn_group_apply") == 2 and "emrt_add3d" not in n1 and "emrt_bn_apply" not in n1, n1
+    assert "emrt_conv2d_group" not in n0 and n0.count("emrt_add3d") == 3, n0
+    for u, v, lab in zip(r1, r0, ["out", "d memory"] + ["dW%d" % i for i in range(6)]):
+        assert torch.isfinite(u).all(), lab
+        if dtype == F32:
+            assert (u - v).abs().max().item() <= 2e-5 * max(1.0, v.abs().max().item()), (lab, (u - v).abs().max().item())
+        else:
+            # bf16: the grouped form rounds relu(bn(.)) + x once where the separate add rounds twice; with 32 ... 512 rows per BatchNorm a last-bit change
+            # flips a few ReLUs, and each flip moves single weight-gradient elements by O(1) (both forms are ~25 % max-norm from fp32 torch here, and equal
+            # to each other in the norm): the sharp comparison is the fp32 one
+            rel = ((u - v).norm() / v.norm().clamp_min(1e-20)).item()
+            assert rel < 0.2, (lab, rel)
+    if dtype == F32:
+        xr = mem.clone().requires_grad_(True)
+        lv, s0 = [], 0
+        for h, w_ in shapes:
+            lv.append(xr[:, s0:s0 + h * w_].transpose(1, 2).reshape(B, C, h, w_))
+            s0 += h * w_
+
+        def blk(x, wa, wb):
+            a = F.relu(F.batch_norm(F.conv2d(x, wa, padding=1), None, None, None, None, True, 0.1, 1e-5))
+            return F.relu(F.batch_norm(F.conv2d(a, wb, padding=1), None, None, None, None, True, 0.1, 1e-5)) + x
+        o0, o1, o2 = blk(lv[0], wts[0], wts[1]), blk(lv[1], wts[2], wts[3]), blk(lv[2], wts[4], wts[5])
+        x21 = F.interpolate(o2, size=(8, 8), mode="bilinear", align_corners=True) + o1
+        o = F.interpolate(x21, size=(16, 16), mode="bilinear", align_corners=True) + o0
+        o.backward(dy)
+        close("EFP grouped vs torch", r1[0], o.detach(), dtype, 8.0)
+        close("EFP grouped d memory vs torch", r1[1], xr.grad, dtype, 40.0)
+
+
 # -----------------------------------------------------------------------------------------------------------------
 # BatchNorm + ReLU between two convolutions applied by the CONSUMING convolution's operand loads (emrt_conv2d_bna; csrc/conv.hip: igemm_body BNA)
 # -----------------------------------------------------------------------------------------------------------------
