@@ -326,11 +326,13 @@ def launch_wgrads(pending):
 
 
 def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1,
-           out_scale=None, out_shift=None, drop=None):
+           out_scale=None, out_shift=None, drop=None, _launched=False):
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice).
     out_scale / out_shift (fp32 [OC], inference only): out = conv * out_scale + out_shift -- an eval-mode BatchNorm folded in.
     drop=(p, salt) with relu=True (training, 1x1): out = dropout_p(relu(linear(x))) with the mask drawn in the GEMM epilogue
-    (emrt_conv2d_drop); the caller promises that the result feeds exactly one conv2d / linear, whose data gradient applies both masks."""
+    (emrt_conv2d_drop); the caller promises that the result feeds exactly one conv2d / linear, whose data gradient applies both masks.
+    _launched=True: the forward has already been launched into `out` (with these arguments, as one problem of a grouped launch: conv_bn_pair); only the
+    backward is recorded."""
     c = ctx()
     if drop is not None and not (c.training and drop[0] > 0.0):
         drop = None
@@ -374,7 +376,9 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
         else:
             x = pend.materialize()
         _, _, _, _, ldin, in_bs = _check_map(x)
-    if bna_done:
+    if _launched:
+        assert out is not None and pend is None and not fused_drop and residual is None and out_scale is None
+    if bna_done or _launched:
         pass
     elif fused_drop:
         _L().call("emrt_conv2d_drop", P(x), ctypes.c_void_p(w.fwd_ptr), P(out), P(w.bias), N * H * W, C, ldin, w.OC, ldout, float(drop[0]), c.seed_ptr,
@@ -888,6 +892,51 @@ def conv_bn_small_group(convs, bns, xs, relu=True, post_adds=None):
             tape.add_grad(x, dx, owned=True)
     tape.record(bwd)
     return outs
+
+
+def conv_bn_pair(items, x):
+    """Two (or more, <= 4) conv -> BatchNorm stages that read the SAME input and are both consumed in their deferred form (PendingBN): conv1 of a ResNet
+    stage's first block (-> bn1 -> relu, applied by conv2's loads) and the stage's shortcut conv (-> BatchNorm, applied by the join)
+    (paddle_vision_resnet.py:108-123,129-147,226-233).  Their forward convolutions go out as ONE grouped launch (emrt_conv2d_group, statistics in the
+    epilogue); each keeps its own backward.  items: [(conv, bn, relu, defer)], defer as conv_bn's.  Returns the conv_bn results in order, or None when the
+    pair cannot be grouped (the caller then calls conv_bn one by one)."""
+    c = ctx()
+    n = len(items)
+    if not (c.training and c.bn_defer and c.conv_pair and 2 <= n <= 4 and not isinstance(x, PendingBN) and x.dim() == 4):
+        return None
+    per16 = 4 if c.dtype == F32 else 8
+    N, H, W, C, ld, bs = _check_map(x)
+    tiles = 0
+    for cv, bn, relu, defer in items:
+        w = cv.gw
+        if defer == "conv" and not c.bn_conv:
+            return None
+        if not (w.KH == w.KW == 1 and cv.padding == 0 and getattr(cv, "dilation", 1) == 1 and w.bias is None and w.OC > 32 and w.C == C and C % per16 == 0
+                and w.OC % per16 == 0 and ld % per16 == 0 and bs % per16 == 0 and x.data_ptr() % 16 == 0 and not _sync_active(bn.state)):
+            return None
+        OH, OW = (H - 1) // cv.stride + 1, (W - 1) // cv.stride + 1
+        tiles += ((N * OH * OW + 63) // 64) * ((w.OC + 63) // 64)
+    if tiles > 4096:
+        return None
+    fd = (_ConvDesc * n)()
+    ys, sums = [], []
+    for d, (cv, bn, relu, defer) in zip(fd, items):
+        w = cv.gw
+        OH, OW = (H - 1) // cv.stride + 1, (W - 1) // cv.stride + 1
+        y = c.empty((N, OH, OW, w.OC))
+        sm = c.zeros_f64(BN_REPLICAS * 2 * bn.C)
+        d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, y.data_ptr(), None, None, sm.data_ptr()
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = N, H, W, C, ld, bs
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = OH, OW, w.OC, w.OC, OH * OW * w.OC
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, 1, 1, cv.stride, 0, 0, 0
+        ys.append(y); sums.append(sm)
+    _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
+    res = []
+    for (cv, bn, relu, defer), y, sm in zip(items, ys, sums):
+        conv2d(x, cv.gw, cv.stride, 0, need_dx=cv.need_dx, bn_stats=sm, out=y, _launched=True)      # records this layer's backward
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        res.append(PendingBN(y, bn.state, sm, count, relu))
+    return res
 
 
 def conv_bn_group(convs, bns, xs, relu=True):

@@ -240,6 +240,8 @@ class Context:
         # the four pyramid-pooling branches (conv1x1 -> BatchNorm -> ReLU on 8 ... 512 pooled tokens) as grouped launches, 4 forward + 3 backward instead of
         # 8 + 12 (functional.conv_bn_small_group); 0 = one launch per branch and pass (A/B knob)
         self.bn_small_group = bool(int(os.environ.get("EMRT_BN_SMALL_GROUP", "1")))
+        # conv1 and the shortcut conv of a bottleneck stage's first block (same input) as one grouped forward launch (functional.conv_bn_pair); 0 = A/B knob
+        self.conv_pair = bool(int(os.environ.get("EMRT_CONV_PAIR", "1")))
         self.group_attn_proj = bool(int(os.environ.get("EMRT_GROUP_ATTN_PROJ", "1")))      # A/B: value_proj and the offsets | logits projection as one grouped launch
         self.fuse_ffn_dropout = bool(int(os.environ.get("EMRT_FFN_DROPOUT_FUSED", "1")))      # A/B: dropout(relu(linear1)) drawn in the GEMM epilogue (emrt_conv2d_drop)
         # the query of the NEXT attention (out + pos) written by the LayerNorm launch that produces `out`, its gradient summed by that LayerNorm's backward

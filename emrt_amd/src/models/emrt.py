@@ -80,9 +80,18 @@ class BottleneckBlock(hnn.HipLayer):  # :91-149
     def forward(self, x):
         # bn1 -> relu -> conv2 and bn2 -> relu -> conv3 (paddle_vision_resnet.py:129-149): each BatchNorm + ReLU is applied by the NEXT convolution's
         # operand loads (Fn.conv2d on a PendingBN: emrt_conv2d_bna), which writes the normalised map backward needs on the way
-        out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True, defer="conv")
+        pair = None
+        if self.downsample is not None:
+            # conv1 and the stage's shortcut conv read the same x: one grouped forward launch (Fn.conv_bn_pair)
+            pair = Fn.conv_bn_pair([(self.conv1, self.bn1, True, "conv"), (self.downsample[0], self.downsample[1], False, "join")], x)
+        if pair is not None:
+            out, identity = pair
+        else:
+            out = Fn.conv_bn(self.conv1, self.bn1, x, relu=True, defer="conv")
+            identity = None
         out = Fn.conv_bn(self.conv2, self.bn2, out, relu=True, defer="conv")
-        identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x, defer="join")
+        if identity is None:
+            identity = x if self.downsample is None else Fn.conv_bn(self.downsample[0], self.downsample[1], x, defer="join")
         return Fn.conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 

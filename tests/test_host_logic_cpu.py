@@ -66,11 +66,16 @@ def test_train_step_launch_sequence(fake, backbone):
     # + the q|k and v projections of the decoder's 2 softmax attentions as pairs
     # + the four pyramid-pooling branches (conv1x1 -> BatchNorm -> ReLU: functional.conv_bn_small_group) as one grouped launch each way
     # + EFP's three Conv2dBlocks level by level: conv1 of the three levels, then conv2 (+ x), grouped each way
-    assert n_grouped == sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == 15 + 12 + 4 + 4 + 6
+    # forward only: conv1 and the shortcut conv of every bottleneck stage's first block share one grouped launch (functional.conv_bn_pair)
+    n_pairs = sum(1 for mod in m.modules() if type(mod).__name__ == "BottleneckBlock" and mod.downsample is not None)
+    assert n_grouped == 15 + 12 + 4 + 4 + 6 and sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == n_grouped + 2 * n_pairs
     assert cnt["emrt_bn_group_apply"] == cnt["emrt_bn_group_bwd"] == 3
     assert sorted(a[1] for n, a in fake.calls if n == "emrt_bn_group_apply") == [3, 3, 4]
     assert sum(1 for n, a in fake.calls if n == "emrt_bn_group_apply" for i in range(a[1]) if a[0][i].res) == 3      # "conv2(conv1(x)) + x" added by the BatchNorm launch
     pairs = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 2]
+    stage_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats]          # conv1 | shortcut conv of a stage's first block
+    assert len(stage_pairs) == n_pairs and all(a[0][0].inp == a[0][1].inp and a[0][1].OC == 4 * a[0][0].OC for a in stage_pairs)
+    pairs = [a for a in pairs if not (a[0][0].bn_stats and a[0][1].bn_stats)]
     msda_pairs = [a for a in pairs if a[0][1].out_f32 == 1]
     mha_pairs = [a for a in pairs if a[0][1].out_f32 == 0]
     assert len(msda_pairs) == 6 and all(a[0][0].out_f32 == 0 and a[0][1].OC == 432 for a in msda_pairs)
