@@ -79,6 +79,12 @@ struct Tuning {
   int wgroup_blocks;      // batched weight gradients (emrt_conv2d_wgrad_group): blocks a launch aims for (1024 = 4 per CU)
   int wgroup_min_steps;   // ... fewest 64-pixel tiles per block (32: shorter blocks only buy fp32 atomic traffic)
   int wgroup_max;         // ... most problems per launch (0 = the kernel's limit, 24)
+  int wgroup8;            // 1: the problems of a batch that fit the 256x256 LDS-DMA weight-gradient kernel's shape rules go out together on THAT kernel
+                          // (wgrad8p_group_kernel) when they amount to wgroup8_min_work block-steps; 0 (default) = all on the 128x128 group kernel.  Measured
+                          // (round 6, profiles/r6c_wgroup8.txt): an encoder layer's batch 186.7 -> 174.9 us and layer4's 51.0 -> 47.6 us alone, layer3 and the
+                          // heads lose (52.7 -> 64.9, 93.6 -> 122.2 us); in the captured step 989.9 (off) vs 988.4 tiles/s (encoder batches only): not taken
+  int wgroup8_blocks;     // ... 0 (default): the block length of the grouped 256x256 launch is chosen by simulating the schedule; n > 0: aim at n blocks (developer knob)
+  int wgroup8_min_work;   // ... fewest (output tile x 64-pixel step) units worth a launch of its own (6000: the encoder batches)
   int msda_scatter_merge; // 1 = the value-gradient scatter adds consecutive points of a query with the same 2 x 2 footprint in registers first (A/B knob)
   int msda_scatter_mfma;  // bf16 value gradients of the deformable attention as a matrix product (msda_bwd_value_mfma_kernel): 1 (default) = when at most one level needs two
                           // row bands, 2 = whenever the maps are <= 512 pixels wide, 0 = always the LDS atomic scatter

@@ -2519,14 +2519,36 @@ static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t s
     hipLaunchKernelGGL(kern, dim3(8u * (unsigned)((total + 7) / 8)), dim3(256), lds, st, g);
     return check_launch("emrt_conv2d_wgrad_group");
   };
+  // the problems that fit the 256x256 LDS-DMA kernel's shape rules but not its "fills the machine alone" clause go out TOGETHER on that kernel
+  // (wgrad8p.hpp: launch_wgrad8p_group) when the call holds enough of them: an encoder layer's FFN linears and 3x3 convolutions (3 192 tile-steps),
+  // ResNet layer3 / layer4 (few pixels, large dW: one slice each, tiles stored)
+  WgradArgs pend8[EMRT_MAX_WGROUP8];
+  int npend8 = 0;
+  auto flush8 = [&]() -> int {
+    if (npend8 == 0) return 0;
+    const int rc = launch_wgrad8p_group(pend8, npend8, st);
+    npend8 = 0;
+    return rc;
+  };
+  auto aliased = [&](int i) { for (int j = 0; j < n; ++j) if (j != i && descs[j].dw == descs[i].dw) return true; return false; };
+  long long work8 = 0;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    for (int i = 0; i < n && g_tune.wgroup8 > 0; ++i) {
+      WgradArgs a;
+      wgrad_args_from_desc(a, descs[i]);
+      int tk, toc, S8, per, tiles8, steps8;
+      if (wgrad_is_vec<T>(a) && !wgrad8p_plan<T>(a, tk, toc, S8, per) && wgrad8p_group_ok<T>(a, tiles8, steps8) && !aliased(i)) work8 += (long long)tiles8 * steps8;
+    }
+  }
+  const bool use8 = g_tune.wgroup8 > 0 && work8 >= (g_tune.wgroup8_min_work > 0 ? g_tune.wgroup8_min_work : 1);
   for (int i = 0; i < n; ++i) {
     WgradArgs a;
     wgrad_args_from_desc(a, descs[i]);
     // a weight used more than once in the step (a shared layer) appears as several problems with the same dw: a stored tile of one would
     // race with the atomic adds of the other (same launch), or land after them ('alone' problems are launched before the pended batch):
     // every problem whose dw another problem of this call also writes accumulates
-    for (int j = 0; j < n && a.overwrite; ++j)
-      if (j != i && descs[j].dw == descs[i].dw) a.overwrite = 0;
+    const bool alias = aliased(i);
+    if (alias) a.overwrite = 0;
     bool alone = !wgrad_is_vec<T>(a) || a.KH * a.KW * a.C >= 32768 * 128 || a.OC >= 32768 * 128;     // (tile counts are shorts)
     if constexpr (std::is_same<T, bf16_t>::value) {
       int tk, toc, S8, per;
@@ -2537,11 +2559,26 @@ static int wgrad_group_dispatch(const EmrtWgradDesc* descs, int n, hipStream_t s
       if (rc) return rc;
       continue;
     }
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      int tiles8, steps8;
+      if (use8 && !alias && wgrad8p_group_ok<T>(a, tiles8, steps8)) {
+        pend8[npend8++] = a;
+        if (npend8 == EMRT_MAX_WGROUP8) {
+          const int rc = flush8();
+          if (rc) return rc;
+        }
+        continue;
+      }
+    }
     pend[npend++] = a;
     if (npend == EMRT_MAX_WGROUP || (g_tune.wgroup_max > 0 && npend >= g_tune.wgroup_max)) {
       const int rc = flush();
       if (rc) return rc;
     }
+  }
+  {
+    const int rc = flush8();
+    if (rc) return rc;
   }
   return flush();
 }

@@ -38,6 +38,7 @@ struct Wgrad8pArgs {
   int KH, KW, stride, pad, dil;
   int steps_per_split, steps_total;
   int tiles_k, tiles_oc, S, xcd_aware;
+  int direct;           // 1: this launch is the ONLY contribution to a dW the caller vouches is all zero (S == 1): the tile is stored, neither slab nor atomics
 };
 
 // LDS-DMA wave instruction with a wave-uniform byte offset in the instruction's soffset (not part of the range check)
@@ -52,21 +53,18 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad8p_kernel(Wgrad8pArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One block's work: work item w = (slice, oc tile, channel block, tap) of problem p (the caller has mapped its block id to w).  smem = the block's whole
+// LDS (128 KiB, at LDS address 0: the DMA writes take absolute LDS addresses).
+__device__ __forceinline__ void wgrad8p_body(const Wgrad8pArgs& p, const int w, unsigned char* smem) {
   constexpr unsigned BUFB = 65536u, AB = 32768u;      // bytes per step buffer; offset of the x tile inside it
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int cblks = p.C >> 8, ntap = p.KH * p.KW;
-  // work item of this block (see the header); integer divisions run on the vector ALU: their wave-uniform results go back to scalar registers
+  // the work item's coordinates; integer divisions run on the vector ALU: their wave-uniform results go back to scalar registers
   int bz, by, kt, tap, c0;
   {
-    const int tiles = p.tiles_k * p.tiles_oc, nb = tiles * p.S;
-    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    const int w0 = (int)(((long long)xcd * nb) >> 3), w1 = (int)(((long long)(xcd + 1) * nb) >> 3);
-    const int w = p.xcd_aware ? w0 + idx : (int)blockIdx.x;      // (0: A/B knob wgrad8p_xcd, work items in launch order)
-    if (w >= (p.xcd_aware ? w1 : nb)) return;          // (the grid is 8 x the longest range)
+    const int tiles = p.tiles_k * p.tiles_oc;
     bz = __builtin_amdgcn_readfirstlane(w / tiles);
     const int t = __builtin_amdgcn_readfirstlane(w - bz * tiles);
     by = __builtin_amdgcn_readfirstlane(t / p.tiles_k);
@@ -285,6 +283,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8p_kernel(Wgrad8pArgs p) {
         if (p.slab) {
           float* dst = p.slab + (((long long)bz * p.tiles_oc + by) * p.tiles_k + kt) * 65536ll + ocl * 256 + kl;
           __builtin_nontemporal_store(acc[it][jb][r], dst);
+        } else if (p.direct) {
+          p.dw[(long long)(oc0 + ocl) * K + (long long)tap * p.C + c0 + kl] = acc[it][jb][r];
         } else {
           atomicAdd(p.dw + (long long)(oc0 + ocl) * K + (long long)tap * p.C + c0 + kl, acc[it][jb][r]);
         }
@@ -299,9 +299,42 @@ __global__ __launch_bounds__(512, 2) void wgrad8p_kernel(Wgrad8pArgs p) {
   }
 }
 
+__global__ __launch_bounds__(512, 2) void wgrad8p_kernel(Wgrad8pArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // work item of this block (see the header)
+  const int nb = p.tiles_k * p.tiles_oc * p.S;
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+  const int w0 = (int)(((long long)xcd * nb) >> 3), w1 = (int)(((long long)(xcd + 1) * nb) >> 3);
+  const int w = p.xcd_aware ? w0 + idx : (int)blockIdx.x;      // (0: A/B knob wgrad8p_xcd, work items in launch order)
+  if (w >= (p.xcd_aware ? w1 : nb)) return;            // (the grid is 8 x the longest range)
+  wgrad8p_body(p, w, smem);
+}
+
+// Several weight gradients on 256 x 256 tiles in ONE launch (emrt_conv2d_wgrad_group): the layers of a batch that fit the kernel's shape rules but are too
+// small to fill 256 CUs alone -- an encoder layer's FFN linears and 3x3 convolutions, ResNet layer3 / layer4 (8-32 steps of 64 pixels, 4-36 tiles each).
+// The work items of all problems form one list (problem-major, each problem slice-major as above); the host cuts it into 8 contiguous ranges of about
+// equal COST (a block's steps + its prologue / epilogue), XCD k = block id % 8 walks range k: the blocks that stream the same pixels still share an L2.
+#define EMRT_MAX_WGROUP8 20
+struct Wgrad8pGroupArgs {
+  Wgrad8pArgs w[EMRT_MAX_WGROUP8];
+  int first[EMRT_MAX_WGROUP8 + 1];      // work items of problem i: [first[i], first[i + 1])
+  int xfirst[9];                        // work items of XCD k: [xfirst[k], xfirst[k + 1])
+  int n;
+};
+__global__ __launch_bounds__(512, 2) void wgrad8p_group_kernel(Wgrad8pGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+  const int w = g.xfirst[xcd] + idx;
+  if (w >= g.xfirst[xcd + 1]) return;
+  int i = 0;
+  for (int k = 1; k < g.n; ++k) i += w >= g.first[k] ? 1 : 0;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const Wgrad8pArgs p = g.w[i];      // a private copy (scalar registers): through the reference every field would be re-read from the kernel-argument segment in the loop
+  wgrad8p_body(p, __builtin_amdgcn_readfirstlane(w - g.first[i]), smem);
+}
+
 // dW[oc][tap * C + c] += sum over the pixel slices z of slab[z][oc tile][k tile][oc % 256][k % 256]; grid (64, tiles), one float4 per thread
-__global__ __launch_bounds__(256) void wgrad8p_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int tiles_k, int tiles_oc, int K) {
-  const long long tile = blockIdx.y;                   // oc_tile * tiles_k + k_tile
+__device__ __forceinline__ void wgrad8p_reduce_tile(const float* __restrict__ slab, float* __restrict__ dw, int S, int tiles_k, int tiles_oc, int K, const long long tile) {
   const int kt = (int)(tile % tiles_k), ot = (int)(tile / tiles_k);
   const long long zstride = (long long)tiles_k * tiles_oc * 65536ll;
   const int i4 = (int)(blockIdx.x * blockDim.x + threadIdx.x);      // < 16384
@@ -321,6 +354,25 @@ __global__ __launch_bounds__(256) void wgrad8p_reduce_kernel(const float* __rest
   float4 o = *d;
   o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
   *d = o;
+}
+
+__global__ __launch_bounds__(256) void wgrad8p_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int tiles_k, int tiles_oc, int K) {
+  wgrad8p_reduce_tile(slab, dw, S, tiles_k, tiles_oc, K, (long long)blockIdx.y);      // oc_tile * tiles_k + k_tile
+}
+
+// the same for the multi-slice problems of a grouped launch: blockIdx.y walks the output tiles of all of them
+struct Wgrad8pReduceGroupArgs {
+  const float* slab[EMRT_MAX_WGROUP8];
+  float* dw[EMRT_MAX_WGROUP8];
+  int S[EMRT_MAX_WGROUP8], tiles_k[EMRT_MAX_WGROUP8], tiles_oc[EMRT_MAX_WGROUP8], K[EMRT_MAX_WGROUP8];
+  int tfirst[EMRT_MAX_WGROUP8 + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad8p_reduce_group_kernel(Wgrad8pReduceGroupArgs g) {
+  const int t = (int)blockIdx.y;
+  int i = 0;
+  for (int k = 1; k < g.n; ++k) i += t >= g.tfirst[k] ? 1 : 0;
+  wgrad8p_reduce_tile(g.slab[i], g.dw[i], g.S[i], g.tiles_k[i], g.tiles_oc[i], g.K[i], (long long)(t - g.tfirst[i]));
 }
 
 template <class T>
@@ -365,11 +417,178 @@ static int launch_wgrad8p(const WgradArgs& a, int tiles_k, int tiles_oc, int S, 
       return fail("emrt_conv2d_wgrad", "cannot raise the dynamic LDS limit to 128 KiB");
     attr_done = true;
   }
-  w.tiles_k = tiles_k; w.tiles_oc = tiles_oc; w.S = S; w.xcd_aware = g_tune.wgrad8p_xcd;
+  w.tiles_k = tiles_k; w.tiles_oc = tiles_oc; w.S = S; w.xcd_aware = g_tune.wgrad8p_xcd; w.direct = 0;
   const int nb = tiles_k * tiles_oc * S;
   hipLaunchKernelGGL(kern, dim3(8 * ((nb + 7) / 8)), dim3(512), 131072, st, w);
   int rc = check_launch("emrt_conv2d_wgrad(8-phase)");
   if (rc || !w.slab) return rc;
   hipLaunchKernelGGL(wgrad8p_reduce_kernel, dim3(64, tiles_k * tiles_oc), dim3(256), 0, st, (const float*)w.slab, a.dw, S, tiles_k, tiles_oc, a.KH * a.KW * a.C);
   return check_launch("emrt_conv2d_wgrad(8-phase reduce)");
+}
+
+// ---- grouped launch (emrt_conv2d_wgrad_group) ------------------------------------------------------------------------------------------------
+// Shape rules of the kernel without wgrad8p_plan's "fills the machine alone" clause: what may JOIN a grouped launch.
+template <class T>
+static bool wgrad8p_group_ok(const WgradArgs& a, int& tiles, int& steps) {
+  if (!std::is_same<T, bf16_t>::value || g_tune.wgroup8 <= 0 || g_tune.wgrad8p_min_steps <= 0) return false;
+  if (a.C % 256 != 0 || a.OC % 256 != 0) return false;
+  if (a.ldx % 8 || a.lddy % 8 || a.x_bs % 8 || a.dy_bs % 8 || ((uintptr_t)a.x) % 16 || ((uintptr_t)a.dy) % 16 || ((uintptr_t)a.dw) % 16) return false;
+  if ((a.OH * a.OW) % 64 != 0) return false;           // whole 64-pixel steps, none across two images
+  steps = (int)((long long)a.N * a.OH * a.OW / 64);
+  tiles = a.KH * a.KW * (a.C / 256) * (a.OC / 256);
+  return tiles <= 256 && steps >= g_tune.wgrad8p_min_steps;
+}
+
+// n (2 .. EMRT_MAX_WGROUP8) problems that passed wgrad8p_group_ok, none of them sharing its dw with another problem of the call.  Plan: ONE block length
+// T (steps) for the whole batch (chosen below); problem i is cut into ceil(steps_i / T) pixel slices.  One slice and a
+// dW known to be zero: the block stores its tile; one slice otherwise: atomics; several slices: partial tiles in the registered scratch (while it lasts:
+// 256 tiles) + ONE grouped reduce launch, else atomics.
+static int launch_wgrad8p_group(const WgradArgs* a, int n, hipStream_t st) {
+  int tiles[EMRT_MAX_WGROUP8], steps[EMRT_MAX_WGROUP8], S[EMRT_MAX_WGROUP8], per[EMRT_MAX_WGROUP8], order[EMRT_MAX_WGROUP8];
+  long long work = 0;
+  for (int i = 0; i < n; ++i) {
+    tiles[i] = a[i].KH * a[i].KW * (a[i].C / 256) * (a[i].OC / 256);
+    steps[i] = (int)((long long)a[i].N * a[i].OH * a[i].OW / 64);
+    work += (long long)tiles[i] * steps[i];
+  }
+  const int min_steps = g_tune.wgrad8p_min_steps > 0 ? g_tune.wgrad8p_min_steps : 8;
+  const double c0 = 8.0;             // a block's prologue + 256 KiB epilogue in steps (tools/bench_conv.py wgroup8)
+  // One block per CU (128 KiB of LDS), XCD k's 32 CUs take the blocks of range k in order: a plan's time is the longest XCD's greedy schedule, and a
+  // block count just above a multiple of 256 costs a whole extra round.  The block length T is therefore CHOSEN BY SIMULATING the candidates (a dozen
+  // schedules of a few hundred blocks: microseconds of host time) instead of aimed at a block count; multi-slice plans also pay for their partial tiles'
+  // trip through the slab (the grouped reduce launch).
+  auto plan = [&](long long Tt, bool commit) -> double {
+    int S_[EMRT_MAX_WGROUP8], per_[EMRT_MAX_WGROUP8], ord[EMRT_MAX_WGROUP8];
+    long long slab_tiles = 0;
+    double cost = 0.0;
+    for (int i = 0; i < n; ++i) {
+      int sl = (int)((steps[i] + Tt - 1) / Tt);
+      if (sl > steps[i] / min_steps) sl = steps[i] / min_steps;
+      if (sl < 1) sl = 1;
+      per_[i] = (steps[i] + sl - 1) / sl;
+      S_[i] = (steps[i] + per_[i] - 1) / per_[i];
+      ord[i] = i;
+      if (S_[i] > 1) slab_tiles += (long long)S_[i] * tiles[i];
+      cost += (double)tiles[i] * S_[i] * (per_[i] + c0);
+    }
+    for (int i = 1; i < n; ++i)      // longest blocks first
+      for (int j = i; j > 0 && per_[ord[j]] > per_[ord[j - 1]]; --j) { const int t_ = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t_; }
+    if (commit) {
+      for (int i = 0; i < n; ++i) { S[i] = S_[i]; per[i] = per_[i]; order[i] = ord[i]; }
+      return 0.0;
+    }
+    // greedy schedule of the blocks in order, cut into 8 ranges of equal cost, 32 CUs each
+    double makespan = 0.0, fin[32], acc = 0.0;
+    int k = 0, q = 0, left = n > 0 ? tiles[ord[0]] * S_[ord[0]] : 0;
+    for (int c = 0; c < 32; ++c) fin[c] = 0.0;
+    while (q < n) {
+      if (left == 0) { if (++q < n) left = tiles[ord[q]] * S_[ord[q]]; continue; }
+      const double len = per_[ord[q]] + c0;
+      if (k < 7 && acc + 0.5 * len > cost * (k + 1) / 8.0) {      // this block opens the next XCD's range
+        for (int c = 0; c < 32; ++c) { makespan = fin[c] > makespan ? fin[c] : makespan; fin[c] = 0.0; }
+        ++k;
+        continue;
+      }
+      int cmin = 0;
+      for (int c = 1; c < 32; ++c) cmin = fin[c] < fin[cmin] ? c : cmin;
+      fin[cmin] += len;
+      acc += len;
+      --left;
+    }
+    for (int c = 0; c < 32; ++c) makespan = fin[c] > makespan ? fin[c] : makespan;
+    return makespan + (slab_tiles > 0 ? 3.0 + 0.03 * (double)slab_tiles : 0.0);      // reduce launch: ~6 us + 16 GB/s-equivalents per tile, in 2-us steps
+  };
+  long long Tbest = 0;
+  // (the same batches come back every step: the chosen T of the last few (tiles, steps) signatures is remembered -- eager steps pay the simulation once)
+  static unsigned long long memo_key[16];
+  static int memo_T[16], memo_n = 0;
+  unsigned long long key = 1469598103934665603ull ^ (unsigned long long)min_steps;
+  for (int i = 0; i < n; ++i) key = (key ^ (unsigned long long)(unsigned)(tiles[i] * 65536 + steps[i])) * 1099511628211ull;
+  int memo_hit = -1;
+  for (int m = 0; m < (memo_n < 16 ? memo_n : 16); ++m) if (memo_key[m] == key) memo_hit = m;
+  if (g_tune.wgroup8_blocks > 0) {     // developer knob: aim at a block count (tools/bench_conv.py wgroup8)
+    Tbest = (work + g_tune.wgroup8_blocks - 1) / g_tune.wgroup8_blocks;
+  } else if (memo_hit >= 0) {
+    Tbest = memo_T[memo_hit];
+  } else {
+    double best = 1e30;
+    int smax = 1;
+    for (int i = 0; i < n; ++i) smax = steps[i] > smax ? steps[i] : smax;
+    static const int cand[] = {64, 96, 128, 160, 192, 208, 224, 240, 256, 288, 320, 384, 448, 512, 640, 768};
+    for (int ci = -1; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
+      long long Tt = ci < 0 ? smax : (work + cand[ci] - 1) / cand[ci];
+      if (Tt < min_steps) Tt = min_steps;
+      const double t = plan(Tt, false);
+      if (t < best) { best = t; Tbest = Tt; }
+    }
+    memo_key[memo_n & 15] = key; memo_T[memo_n & 15] = (int)Tbest; ++memo_n;
+  }
+  if (Tbest < min_steps) Tbest = min_steps;
+  (void)plan(Tbest, true);
+  const bool slab_ok = g_tune.wgrad8p_slab && g_scratch.ptr && g_scratch.stream == (void*)st;
+  long long slab_tiles_left = slab_ok ? (long long)(g_scratch.bytes / 262144) : 0, slab_off = 0;
+  Wgrad8pGroupArgs g;
+  Wgrad8pReduceGroupArgs r;
+  r.n = 0; r.tfirst[0] = 0;
+  long long total = 0;
+  double cost = 0.0, cum[EMRT_MAX_WGROUP8 + 1];
+  for (int q = 0; q < n; ++q) {
+    const int i = order[q];
+    const WgradArgs& s = a[i];
+    Wgrad8pArgs& w = g.w[q];
+    w.x = s.x; w.dy = s.dy; w.dw = s.dw; w.dbias = s.dbias;
+    w.N = s.N; w.H = s.H; w.W = s.W; w.C = s.C; w.ldx = s.ldx; w.x_bs = s.x_bs;
+    w.OH = s.OH; w.OW = s.OW; w.OC = s.OC; w.lddy = s.lddy; w.dy_bs = s.dy_bs;
+    w.KH = s.KH; w.KW = s.KW; w.stride = s.stride; w.pad = s.pad; w.dil = s.dil;
+    w.steps_per_split = per[i]; w.steps_total = steps[i];
+    w.tiles_k = s.KH * s.KW * (s.C / 256); w.tiles_oc = s.OC / 256; w.S = S[i]; w.xcd_aware = 1;
+    w.slab = nullptr; w.direct = 0;
+    if (S[i] == 1) {
+      w.direct = (s.overwrite && !g_tune.wgrad_no_overwrite) ? 1 : 0;
+    } else if ((long long)S[i] * tiles[i] <= slab_tiles_left) {
+      w.slab = (float*)g_scratch.ptr + slab_off * 65536ll;
+      slab_off += (long long)S[i] * tiles[i];
+      slab_tiles_left -= (long long)S[i] * tiles[i];
+      r.slab[r.n] = w.slab; r.dw[r.n] = s.dw; r.S[r.n] = S[i]; r.tiles_k[r.n] = w.tiles_k; r.tiles_oc[r.n] = w.tiles_oc; r.K[r.n] = s.KH * s.KW * s.C;
+      r.tfirst[r.n + 1] = r.tfirst[r.n] + tiles[i];
+      ++r.n;
+    }
+    g.first[q] = (int)total;
+    cum[q] = cost;
+    total += (long long)tiles[i] * S[i];
+    cost += (double)tiles[i] * S[i] * (per[i] + c0);
+  }
+  cum[n] = cost;
+  for (int q = n; q <= EMRT_MAX_WGROUP8; ++q) g.first[q] = (int)total;
+  for (int q = n; q < EMRT_MAX_WGROUP8; ++q) g.w[q] = g.w[0];
+  for (int q = r.n; q < EMRT_MAX_WGROUP8; ++q) { r.slab[q] = nullptr; r.dw[q] = nullptr; r.S[q] = 1; r.tiles_k[q] = 1; r.tiles_oc[q] = 1; r.K[q] = 0; r.tfirst[q + 1] = r.tfirst[r.n]; }
+  g.n = n;
+  // 8 contiguous ranges of about equal cost: range k starts at the first work item whose cumulative cost reaches k / 8 of the total
+  int longest = 0;
+  g.xfirst[0] = 0; g.xfirst[8] = (int)total;
+  for (int k = 1; k < 8; ++k) {
+    const double want = cost * k / 8.0;
+    int q = 0;
+    while (q + 1 < n && cum[q + 1] <= want) ++q;
+    const int i = order[q];
+    const double unit = per[i] + c0;
+    long long wq = g.first[q] + (long long)((want - cum[q]) / unit + 0.5);
+    if (wq > g.first[q + 1]) wq = g.first[q + 1];
+    if (wq < g.xfirst[k - 1]) wq = g.xfirst[k - 1];
+    g.xfirst[k] = (int)wq;
+  }
+  for (int k = 0; k < 8; ++k) longest = g.xfirst[k + 1] - g.xfirst[k] > longest ? g.xfirst[k + 1] - g.xfirst[k] : longest;
+  if (longest < 1) return 0;
+  auto kern = wgrad8p_group_kernel;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
+      return fail("emrt_conv2d_wgrad_group", "cannot raise the dynamic LDS limit to 128 KiB");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(8 * longest), dim3(512), 131072, st, g);
+  int rc = check_launch("emrt_conv2d_wgrad_group(8-phase)");
+  if (rc || r.n == 0) return rc;
+  hipLaunchKernelGGL(wgrad8p_reduce_group_kernel, dim3(64, r.tfirst[r.n]), dim3(256), 0, st, r);
+  return check_launch("emrt_conv2d_wgrad_group(8-phase reduce)");
 }

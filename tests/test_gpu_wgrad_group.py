@@ -219,3 +219,93 @@ def test_a_weight_used_twice_in_one_step_sums_both_contributions(dtype):
         torch.cuda.synchronize()
         rel = ((host(conv.weight.grad) - wr.grad).norm() / wr.grad.norm()).item()
         assert rel < tol, (trial, rel)
+
+
+# ---- the problems of a batch that fit the 256x256 LDS-DMA kernel, grouped on it (csrc/wgrad8p.hpp: wgrad8p_group_kernel) ----------------------------
+_GEOMS_256 = [
+    # (N, H, W, Cin, Cout, k, stride, pad, dil, bias): C and OC multiples of 256, OH * OW multiples of 64, >= 8 steps of 64 pixels
+    (8, 8, 8, 512, 512, 3, 1, 1, 1, True),         # 36 tiles x 8 steps (ResNet layer4 conv2)
+    (2, 16, 16, 256, 256, 3, 1, 1, 1, False),      # 9 tiles x 8 steps
+    (4, 16, 16, 1024, 256, 1, 1, 0, 1, False),     # 4 tiles x 16 steps (layer3 conv1)
+    (2, 24, 32, 256, 512, 1, 1, 0, 1, True),       # 2 tiles x 24 steps, non-square map
+    (4, 32, 32, 256, 256, 3, 2, 1, 1, False),      # stride 2
+    (2, 16, 16, 256, 256, 3, 1, 2, 2, True),       # dilation 2
+    (2, 1, 1344, 256, 1024, 1, 1, 0, 1, True),     # a linear layer over 1344 tokens: 4 tiles x 42 steps
+    (2, 1, 1344, 1024, 256, 1, 1, 0, 1, False),
+    # not eligible: stay on the 128x128 group kernel of the same call
+    (2, 10, 10, 256, 256, 3, 1, 1, 1, True),       # 100 pixels per image
+    (3, 16, 16, 128, 256, 1, 1, 0, 1, False),      # C = 128
+    (1, 8, 8, 256, 256, 1, 1, 0, 1, True),         # one step
+]
+
+
+@pytest.mark.parametrize("cleared", [False, True], ids=["accumulate", "dw-known-zero"])
+@pytest.mark.parametrize("knobs", [dict(), dict(wgroup8_blocks=16), dict(wgroup8_blocks=4096), dict(wgroup8_blocks=4096, wgrad8p_slab=0),
+                                   dict(wgroup8_blocks=100000, wgrad8p_min_steps=1)],
+                         ids=["default-plan", "one-slice-each", "many-slices", "many-slices-atomics", "more-slices-than-slab-tiles"])
+def test_grouped_256_tile_weight_gradients(knobs, cleared):
+    """Eight layers of one batch on wgrad8p_group_kernel (stored tiles / atomics / partial tiles + the grouped reduce launch, whatever the plan gives
+    each), three on the 128x128 group kernel: every dW and dbias against torch and against the same call with the knob off."""
+    L_ = _lib.lib()
+    old0 = L_.set_tuning("wgroup8", 0)
+    try:
+        base, refs, _ = _run(_GEOMS_256, BF16, 24, 17, cleared=cleared)
+    finally:
+        L_.set_tuning("wgroup8", old0)
+    old = [(k, L_.set_tuning(k, v)) for k, v in dict(wgroup8=1, wgroup8_min_work=1, **knobs).items()]
+    try:
+        got, _, names = _run(_GEOMS_256, BF16, 24, 17, cleared=cleared)
+        twice, _, _ = _run(_GEOMS_256, BF16, 24, 17, cleared=cleared, passes=2)
+    finally:
+        for k, v in old:
+            L_.set_tuning(k, v)
+    assert names.count("emrt_conv2d_wgrad_group") == 1
+    for i, ((dw, db, _), (bw, bb, _), (tw, tb, _), (rw, rb, _)) in enumerate(zip(got, base, twice, refs)):
+        rel, relb = ((dw - rw).norm() / rw.norm()).item(), ((dw - bw).norm() / bw.norm()).item()
+        print("layer %d %s: dW vs torch %.2e, vs the 128x128 group kernel %.2e" % (i, _GEOMS_256[i], rel, relb))
+        assert rel < 1e-3 and relb < 2e-5, (i, _GEOMS_256[i], rel, relb)
+        assert ((tw - 2 * rw).norm() / rw.norm()).item() < 2e-3, (i, _GEOMS_256[i])          # a second backward without clearing ADDS
+        if db is not None:
+            assert ((db - rb).norm() / rb.norm()).item() < 1e-3 and ((db - bb).norm() / bb.norm()).item() < 2e-5
+            assert ((tb - 2 * rb).norm() / rb.norm()).item() < 2e-3
+
+
+def test_grouped_256_tile_weight_gradients_leave_shared_weights_to_the_atomic_kernels():
+    """A weight used twice in one call (two problems, one dw) never joins the 256x256 group (its reduce launch adds without atomics): through the C-ABI,
+    both contributions plus an unrelated eligible layer."""
+    import ctypes
+    from emrt_amd.functional import _WgradDesc
+    c = init(BF16)
+    c.ensure_scratch()
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, OC = 4, 16, 16, 256, 256
+    xs = [rnd(torch.randn(N, H, W, C, generator=g)) for _ in range(3)]
+    dys = [rnd(torch.randn(N, H, W, OC, generator=g)) for _ in range(3)]
+    dws = [torch.zeros(OC, 3, 3, C, device="cuda"), torch.zeros(OC, 3, 3, C, device="cuda")]
+    xd, dyd = [x.cuda().bfloat16() for x in xs], [d.cuda().bfloat16() for d in dys]
+    arr = (_WgradDesc * 3)()
+    for i, d in enumerate(arr):
+        dw = dws[0] if i < 2 else dws[1]
+        d.x, d.dy, d.dw, d.dbias = xd[i].data_ptr(), dyd[i].data_ptr(), dw.data_ptr(), None
+        d.N, d.H, d.W, d.C, d.ldx, d.x_bs = N, H, W, C, C, H * W * C
+        d.OH, d.OW, d.OC, d.lddy, d.dy_bs = H, W, OC, OC, H * W * OC
+        d.KH, d.KW, d.stride, d.pad, d.dilation, d.dw_is_zero = 3, 3, 1, 1, 1, 1
+    L_ = _lib.lib()
+    old = [(k, L_.set_tuning(k, v)) for k, v in dict(wgroup8=1, wgroup8_min_work=1, wgroup8_blocks=4096).items()]
+    try:
+        L_.call("emrt_conv2d_wgrad_group", arr, 3, BF16, c.stream)
+    finally:
+        for k, v in old:
+            L_.set_tuning(k, v)
+    torch.cuda.synchronize()
+
+    def ref(x, dy):      # dW[oc][kh][kw][c] = sum_m dy[m][oc] * x[pix(m) + tap][c]
+        xw = x.permute(0, 3, 1, 2).clone().requires_grad_(False)
+        w = torch.zeros(OC, C, 3, 3, requires_grad=True)
+        y = F.conv2d(xw, w, padding=1)
+        y.backward(dy.permute(0, 3, 1, 2))
+        return w.grad.permute(0, 2, 3, 1)
+    r0 = ref(xs[0], dys[0]) + ref(xs[1], dys[1])
+    r1 = ref(xs[2], dys[2])
+    assert ((dws[0].cpu() - r0).norm() / r0.norm()).item() < 1e-3
+    assert ((dws[1].cpu() - r1).norm() / r1.norm()).item() < 1e-3

@@ -169,7 +169,58 @@ class _WD(ctypes.Structure):       # EmrtWgradDesc
                 ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("ldx", ctypes.c_int),
                 ("x_bs", ctypes.c_longlong), ("OH", ctypes.c_int), ("OW", ctypes.c_int), ("OC", ctypes.c_int), ("lddy", ctypes.c_int),
                 ("dy_bs", ctypes.c_longlong), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
-                ("dilation", ctypes.c_int)]
+                ("dilation", ctypes.c_int), ("dw_is_zero", ctypes.c_int)]
+
+
+def wgroup8():
+    """The step's weight-gradient batches with the problems that fit the 256x256 LDS-DMA kernel grouped on it (wgrad8p_group_kernel, knob wgroup8) against
+    all of them on the 128x128 group kernel; block-count sweep of the grouped 256x256 launch.  dW declared zero (as after zero_grad in the step): one-slice
+    problems store their tiles."""
+    scratch = torch.empty((64 << 20) + (8 << 20) + 65536, dtype=torch.uint8, device=dev)
+    L.call("emrt_set_scratch", P(scratch), ctypes.c_size_t(scratch.numel()), stream)
+
+    def problems(shapes):
+        keep, arr = [], (_WD * len(shapes))()
+        gf = 0.0
+        for d, (N, H, W, C, OC, k, s, pad) in zip(arr, shapes):
+            OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+            x = torch.randn(N, H, W, C, device=dev).bfloat16()
+            dy = torch.randn(N, OH, OW, OC, device=dev).bfloat16()
+            dw = torch.zeros(OC, k, k, C, device=dev, dtype=torch.float32)
+            keep += [x, dy, dw]
+            d.x, d.dy, d.dw, d.dbias = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None
+            d.N, d.H, d.W, d.C, d.ldx, d.x_bs = N, H, W, C, C, H * W * C
+            d.OH, d.OW, d.OC, d.lddy, d.dy_bs = OH, OW, OC, OC, OH * OW * OC
+            d.KH, d.KW, d.stride, d.pad, d.dilation, d.dw_is_zero = k, k, s, pad, 1, 1
+            gf += 2.0 * N * OH * OW * OC * k * k * C / 1e9
+        return arr, keep, gf
+
+    enc1 = [(8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 432, 1, 1, 0), (8, 1, 1344, 256, 256, 1, 1, 0), (8, 1, 1344, 256, 1024, 1, 1, 0), (8, 1, 1344, 1024, 256, 1, 1, 0),
+            (8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1), (8, 8, 8, 256, 256, 3, 1, 1)]
+    mixes = (("encoder layers x24", enc1 * 3),
+             ("resnet layer3 x18+2", [(8, 16, 16, 1024, 256, 1, 1, 0), (8, 16, 16, 256, 256, 3, 1, 1), (8, 16, 16, 256, 1024, 1, 1, 0)] * 6 + [(8, 32, 32, 512, 1024, 1, 2, 0), (8, 32, 32, 256, 256, 3, 2, 1)]),
+             ("resnet layer4 x9+2", [(8, 8, 8, 2048, 512, 1, 1, 0), (8, 8, 8, 512, 512, 3, 1, 1), (8, 8, 8, 512, 2048, 1, 1, 0)] * 3 + [(8, 16, 16, 1024, 2048, 1, 2, 0), (8, 16, 16, 512, 512, 3, 2, 1)]),
+             ("decoder + heads", [(8, 1, 110, 256, 256, 1, 1, 0), (8, 1, 110, 256, 512, 1, 1, 0), (8, 1, 110, 256, 1024, 1, 1, 0), (8, 1, 110, 1024, 256, 1, 1, 0)] * 2 +
+              [(8, 32, 32, 512, 256, 3, 1, 1), (8, 16, 16, 1024, 256, 3, 1, 1), (8, 32, 32, 256, 256, 3, 1, 1), (8, 16, 16, 256, 256, 3, 1, 1)]))
+    for name, mix in mixes:
+        arr, keep, gf = problems(mix)
+        run = lambda: L._raw_emrt_conv2d_wgrad_group(arr, len(mix), 1, stream)
+        old = L.set_tuning("wgroup8", 0)
+        t0 = min(timed(run, 20), timed(run, 20))
+        L.set_tuning("wgroup8", 1)
+        t1 = min(timed(run, 20), timed(run, 20))
+        line = "%-22s %6.1f GF | 128x128 group %6.1f us | + 256x256 group %6.1f us | blocks:" % (name, gf, t0, t1)
+        for blocks in (128, 192, 256, 320, 384, 512, 768):
+            ob = L.set_tuning("wgroup8_blocks", blocks)
+            t = min(timed(run, 20), timed(run, 20))
+            L.set_tuning("wgroup8_blocks", ob)
+            line += " %4d: %6.1f |" % (blocks, t)
+        ob = L.set_tuning("wgrad8p_slab", 0)
+        t = min(timed(run, 20), timed(run, 20))
+        L.set_tuning("wgrad8p_slab", ob)
+        line += " atomics: %6.1f |" % t
+        L.set_tuning("wgroup8", old)
+        print(line, flush=True)
 
 
 def wgroup():
@@ -342,6 +393,8 @@ def main():
         return s2()
     if which == "wgroup":
         return wgroup()
+    if which == "wgroup8":
+        return wgroup8()
     if which == "wbig":
         return wbig()
     if which == "thin":
