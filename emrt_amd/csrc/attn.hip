@@ -403,13 +403,19 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
   __shared__ __attribute__((aligned(16))) T sGt[32 * MHA_TP];
   __shared__ float sMx[128], sInv[128], sDot[128];
   const int L = a.L, bm = blockIdx.x, b = bm / a.M, m = bm % a.M;
+  // TWO blocks per (batch, head) (gridDim.y == 2; 64 (batch, head) pairs are a quarter of the CUs and the launch is one dependent chain of
+  // load -> MFMA -> exp -> MFMA -> store): both run pass 1's front (probabilities, dP, every row's rowdot -- a few MFMAs, redundantly),
+  // block 0 then finishes dq, block 1 runs pass 2 (dk, dv): the launch lasts front + max(dq, pass 2) instead of their sum.  gridDim.y == 1: one block does all.
+  const int role = gridDim.y == 2 ? (int)blockIdx.y : -1;      // 0: dq only, 1: dk / dv only, -1: everything
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nt = (L + 15) >> 4;
   const int il = lane & 15, g = lane >> 4;
   const long long r0 = (long long)b * L;
   const int col = m * MHA_D;
-  mha_stage_t<T>(a.k, r0, L, a.ldk, col, sKt);
-  mha_stage_t<T>(a.q, r0, L, a.ldq, col, sQt);
-  mha_stage_t<T>(a.dout, r0, L, a.lddo, col, sGt);
+  if (role != 1) mha_stage_t<T>(a.k, r0, L, a.ldk, col, sKt);
+  if (role != 0) {
+    mha_stage_t<T>(a.q, r0, L, a.ldq, col, sQt);
+    mha_stage_t<T>(a.dout, r0, L, a.lddo, col, sGt);
+  }
   const float* stats = a.probs + (long long)bm * L * L;
   for (int t = threadIdx.x; t < 128; t += blockDim.x) {
     sMx[t] = t < L ? stats[t] : 0.f;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
       pk[t][1] = mha_pack2<T>(ds[2], ds[3]);
     }
     __syncthreads();                                              // transposed images, statistics and every row's rowdot are in LDS
-    if (w < nt) {
+    if (w < nt && role != 1) {
       mha_f32x4_t dq[2] = {(mha_f32x4_t){0.f, 0.f, 0.f, 0.f}, (mha_f32x4_t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int s = 0; s < MHA_TILES / 2; ++s) {
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(64 * MHA_TILES) void mha_bwd_mfma_kernel(MhaArgs a)
       }
     }
   }
-  if (w >= nt) return;
+  if (w >= nt || role == 0) return;
   // ---- pass 2: the column strip of key tile w: S[i][j], dPd[i][j] with the lane's key j = x fixed and the queries i in the registers ----
   {
     const uint4 kf = mha_row16<T>(a.k, r0, x, L, a.ldk, col + 8 * g), vf = mha_row16<T>(a.v, r0, x, L, a.ldv, col + 8 * g);
@@ -615,7 +621,7 @@ extern "C" int emrt_mha_bwd(const void* q, int ldq, const void* k, int ldk, cons
                      (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 == 0),
                  "the forward took the MFMA kernel (probs = row statistics) but these gradient operands cannot run its backward: 16-byte aligned q / k / v / dout "
                  "with row strides that are multiples of 8, 8-byte aligned dq / dk / dv with row strides that are multiples of 4");
-    hipLaunchKernelGGL((mha_bwd_mfma_kernel<bf16_t>), dim3(B * M), dim3(64 * ((L + 15) / 16)), 0, st, a);
+    hipLaunchKernelGGL((mha_bwd_mfma_kernel<bf16_t>), dim3(B * M, g_tune.mha_bwd_split ? 2 : 1), dim3(64 * ((L + 15) / 16)), 0, st, a);
     return check_launch("emrt_mha_bwd");
   }
   if (dtype == EMRT_F32) hipLaunchKernelGGL((mha_bwd_kernel<float>), dim3(B * M), dim3(MHA_THREADS), lds, st, a);

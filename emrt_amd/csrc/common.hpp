@@ -90,6 +90,7 @@ struct Tuning {
                           // row bands, 2 = whenever the maps are <= 512 pixels wide, 0 = always the LDS atomic scatter
   int msda_mf_bands;      // ... most pixels of a row band (0 = 512)
   int sgd_nt;             // 1 (default): the optimizer pass streams master weights / velocity / gradients with non-temporal accesses (A/B knob)
+  int mha_bwd_split;      // 1 (default): the MFMA softmax-attention backward as two blocks per (batch, head) -- dq | dk, dv (A/B knob)
   int mha_valu;           // 1 = the decoder's softmax attention on the VALU kernels for every dtype (A/B knob; bf16 / fp16 default to the MFMA kernels)
   int no_bna;             // 1 = emrt_conv2d_bna_supported always answers 0: every BatchNorm between convolutions keeps its own emrt_bn_apply launch (A/B knob);
                           // -1 = also the long-k 3x3 layers the dispatcher leaves to the separate launch (tests)

@@ -30,7 +30,7 @@ const TuneEntry kTune[] = {
     {"igemm8p_probe", &emrt::Tuning::igemm8p_probe, 0}, {"igemm8p_min_blocks", &emrt::Tuning::igemm8p_min_blocks, 160}, {"igemm8p_cmajor", &emrt::Tuning::igemm8p_cmajor, 0},
     {"wgrad8p_min_steps", &emrt::Tuning::wgrad8p_min_steps, 8}, {"wgrad8p_slab", &emrt::Tuning::wgrad8p_slab, 1}, {"wgrad8p_force", &emrt::Tuning::wgrad8p_force, 0}, {"wgrad8p_xcd", &emrt::Tuning::wgrad8p_xcd, 1},
     {"wgrad_no_overwrite", &emrt::Tuning::wgrad_no_overwrite, 0}, {"no_ksplit128", &emrt::Tuning::no_ksplit128, 0}, {"ln_bwd_rows", &emrt::Tuning::ln_bwd_rows, 0}, {"ln_bwd_max_blocks", &emrt::Tuning::ln_bwd_max_blocks, 0}, {"bn_operand_blocks", &emrt::Tuning::bn_operand_blocks, 0}, {"no_s2_dgrad", &emrt::Tuning::no_s2_dgrad, 0}, {"wgroup_blocks", &emrt::Tuning::wgroup_blocks, 1024}, {"wgroup_min_steps", &emrt::Tuning::wgroup_min_steps, 32}, {"wgroup_max", &emrt::Tuning::wgroup_max, 0},
-    {"no_bna", &emrt::Tuning::no_bna, 0}, {"memcpy_kernel", &emrt::Tuning::memcpy_kernel, 0}, {"xk", &emrt::Tuning::xk, 0}, {"mha_valu", &emrt::Tuning::mha_valu, 0}, {"msda_scatter_merge", &emrt::Tuning::msda_scatter_merge, 0},
+    {"no_bna", &emrt::Tuning::no_bna, 0}, {"memcpy_kernel", &emrt::Tuning::memcpy_kernel, 0}, {"xk", &emrt::Tuning::xk, 0}, {"mha_valu", &emrt::Tuning::mha_valu, 0}, {"mha_bwd_split", &emrt::Tuning::mha_bwd_split, 1}, {"msda_scatter_merge", &emrt::Tuning::msda_scatter_merge, 0},
     {"wgroup8", &emrt::Tuning::wgroup8, 0}, {"wgroup8_blocks", &emrt::Tuning::wgroup8_blocks, 0}, {"wgroup8_min_work", &emrt::Tuning::wgroup8_min_work, 6000},
     {"msda_scatter_mfma", &emrt::Tuning::msda_scatter_mfma, 1}, {"sgd_nt", &emrt::Tuning::sgd_nt, 1}, {"ln_bwd_threads", &emrt::Tuning::ln_bwd_threads, 512}, {"msda_mf_bands", &emrt::Tuning::msda_mf_bands, 0},
 };

@@ -1020,6 +1020,42 @@ def test_linear_group_equals_separate_linears(dtype):
     assert res["group"][0].shape == want.shape
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1], ids=["no-dropout", "dropout"])
+def test_mha_backward_split_over_two_blocks_is_bit_identical(p):
+    """mha_bwd_mfma_kernel as two blocks per (batch, head) -- dq | dk, dv, both re-deriving the row dots (knob mha_bwd_split, default on) -- against the
+    one-block form: the same arithmetic on the same lanes, so every gradient bit for bit (layers.py:283-303), at the decoder's L = 110 and ragged lengths."""
+    from emrt_amd import _lib
+    L_ = _lib.lib()
+    c = init(BF16)
+    g = torch.Generator().manual_seed(33)
+    E, Mh = 256, 8
+    for L in (110, 128, 37, 2):
+        B = 3
+        c.training = p > 0.0
+        qk, v = rnd(torch.randn(B, L, 2 * E, generator=g)), rnd(torch.randn(B, L, E, generator=g))
+        dy = rnd(torch.randn(B, L, E, generator=g))
+        outs = {}
+        for knob in (0, 1):
+            old = L_.set_tuning("mha_bwd_split", knob)
+            try:
+                c.salt_counter = 100
+                qd, vd = dev(qk), dev(v)
+                tape = Tape()
+                c.tape = tape
+                y = Fn.mha(qd, vd, Mh, p, 3)
+                c.tape = None
+                tape.watch(qd)
+                tape.watch(vd)
+                dqk, dv = run_bwd(tape, [(y, dev(dy))], [qd, vd])
+                outs[knob] = [host(t) for t in (y, dqk, dv)]
+            finally:
+                L_.set_tuning("mha_bwd_split", old)
+        for u, w_, name in zip(outs[0], outs[1], ("out", "dqk", "dv")):
+            assert torch.equal(u, w_), (L, name, (u - w_).abs().max().item())
+            assert torch.isfinite(u).all()
+    c.training = True
+
+
 def test_mha_mfma_kernels_dropout_and_agreement_with_the_valu_kernels():
     """bf16 takes the MFMA kernels (csrc/attn.hip: mha_fwd_mfma_kernel / mha_bwd_mfma_kernel; layers.py:283-303).  (1) Without dropout they
     must agree with the VALU kernels (knob mha_valu) on the same bf16 inputs to bf16 rounding, forward and all three gradients, at the

@@ -37,6 +37,9 @@ def _geoms(seed, n, odd=False):
     return out
 
 
+_REFS = {}
+
+
 def _run(geoms, dtype, batch, seed, cleared=False, passes=1):
     """-> per layer (dW, dbias, dx) on the host; all layers' backward on one tape.  cleared: the gradients are cleared through
     ParamStore.zero_grad() first, which also marks every weight gradient 'known zero' (one-slice problems then STORE their tiles);
@@ -45,20 +48,29 @@ def _run(geoms, dtype, batch, seed, cleared=False, passes=1):
     c.wgrad_batch = batch
     g = torch.Generator().manual_seed(seed)
     layers, xs, dys, refs = {}, [], [], []
+    memo = _REFS.get((tuple(geoms), dtype, seed))      # the CPU reference of a (geometry list, seed) is computed once per process (it is most of a case's time)
     for i, (N, H, W, Cin, Cout, k, stride, pad, dil, bias) in enumerate(geoms):
         conv = hnn.Conv2D(Cin, Cout, k, stride, pad, bias=bias, dilation=dil)
         with torch.no_grad():
             conv.weight.copy_(rnd(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)))
         layers["l%d" % i] = conv
         x = rnd(torch.randn(N, Cin, H, W, generator=g))
-        xr, wr = x.clone().requires_grad_(True), conv.weight.detach().clone().requires_grad_(True)
-        br = torch.zeros(Cout, requires_grad=True) if bias else None
-        yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
-        dy = rnd(torch.randn(yr.shape, generator=g))
-        yr.backward(dy)
+        OHs = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        OWs = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        dy = rnd(torch.randn((N, Cout, OHs, OWs), generator=g))
+        if memo is None:
+            xr, wr = x.clone().requires_grad_(True), conv.weight.detach().clone().requires_grad_(True)
+            br = torch.zeros(Cout, requires_grad=True) if bias else None
+            yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+            assert tuple(yr.shape) == tuple(dy.shape)
+            yr.backward(dy)
+            refs.append((wr.grad, br.grad if bias else None, xr.grad))
         xs.append(x)
         dys.append(dy)
-        refs.append((wr.grad, br.grad if bias else None, xr.grad))
+    if memo is None:
+        _REFS[(tuple(geoms), dtype, seed)] = refs
+    else:
+        refs = memo
     holder = Holder(**layers).place()
     if cleared:
         holder.store.grad.fill_(7.0)         # (whatever was there is cleared by zero_grad, not by the kernels)
@@ -239,10 +251,10 @@ _GEOMS_256 = [
 ]
 
 
-@pytest.mark.parametrize("cleared", [False, True], ids=["accumulate", "dw-known-zero"])
-@pytest.mark.parametrize("knobs", [dict(), dict(wgroup8_blocks=16), dict(wgroup8_blocks=4096), dict(wgroup8_blocks=4096, wgrad8p_slab=0),
-                                   dict(wgroup8_blocks=100000, wgrad8p_min_steps=1)],
-                         ids=["default-plan", "one-slice-each", "many-slices", "many-slices-atomics", "more-slices-than-slab-tiles"])
+@pytest.mark.parametrize("knobs,cleared", [(dict(), False), (dict(), True), (dict(wgroup8_blocks=16), True), (dict(wgroup8_blocks=4096), False),
+                                           (dict(wgroup8_blocks=4096, wgrad8p_slab=0), True), (dict(wgroup8_blocks=100000, wgrad8p_min_steps=1), False)],
+                         ids=["default-plan-accumulate", "default-plan-dw-known-zero", "one-slice-each-stored", "many-slices-slab", "many-slices-atomics",
+                              "more-slices-than-slab-tiles"])
 def test_grouped_256_tile_weight_gradients(knobs, cleared):
     """Eight layers of one batch on wgrad8p_group_kernel (stored tiles / atomics / partial tiles + the grouped reduce launch, whatever the plan gives
     each), three on the 128x128 group kernel: every dW and dbias against torch and against the same call with the knob off."""
