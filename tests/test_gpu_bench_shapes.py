@@ -455,8 +455,12 @@ BF16_GRAD_COSINE = 0.985        # cosine between the whole bf16 gradient vector 
 BF16_GRAD_NORM_RATIO = 0.02     # | ||g_bf16|| / ||g_ref|| - 1 |
 
 
-@pytest.mark.parametrize("B,S,ncls", [(8, 256, 6), (4, 512, 7)], ids=["cfg2-8x256", "cfg3-4x512"])
+@pytest.mark.parametrize("B,S,ncls", [(8, 256, 6)], ids=["cfg2-8x256"])      # (cfg3-4x512: tests/test_gpu_bench_shapes_cfg3.py, a file of its own for pytest-xdist)
 def test_full_size_bf16_model_vs_fp32_oracle(B, S, ncls):
+    full_size_bf16_model_case(B, S, ncls)
+
+
+def full_size_bf16_model_case(B, S, ncls):
     """BASELINE configs[1] (ResNet-50, batch 8, 256x256, 6 classes) and configs[2] (LoveDA geometry: batch 4, 512x512, 7 classes,
     Lv = 5376 -- the row-band MSDA kernels, the query-split scatter) in THEIR OWN dtype and batch: bf16 storage / fp32 accumulation
     against the fp32 CPU oracle (the reference is fp32 throughout, train.py:141-159): eval-mode logits and argmax masks, then one

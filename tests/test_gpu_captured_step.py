@@ -34,8 +34,12 @@ WEIGHT_REL = 2e-4         # relative L2 distance of all trainable weights after 
 GRAD_REL = 2e-2           # ... of step 1's flat gradient, or 2.5 x what two EAGER runs differ by (measured on MI355X: 5-6 %, printed)
 
 
-@pytest.mark.parametrize("B,S,ncls", [(8, 256, 6), (4, 512, 7)], ids=["cfg2-8x256", "cfg3-4x512"])
+@pytest.mark.parametrize("B,S,ncls", [(8, 256, 6)], ids=["cfg2-8x256"])      # (cfg3-4x512: tests/test_gpu_captured_step_cfg3.py)
 def test_captured_bf16_step_equals_eager_and_tracks_the_oracle(B, S, ncls):
+    captured_step_case(B, S, ncls)
+
+
+def captured_step_case(B, S, ncls):
     g = torch.Generator().manual_seed(29)
     x = torch.randn(B, 3, S, S, generator=g)
     labels = torch.randint(0, ncls, (B, S, S), generator=g)

@@ -145,6 +145,10 @@ def assert_train_logits(out, out32, out64, what):
 
 # (the three full-size cases -- resnet50 1 x 512 x 512 and configs[1] / configs[2] at their real batch sizes, 8 x 256 x 256 and 4 x 512 x 512 -- run
 # the same body from tests/test_gpu_model_full.py: their float64 oracle evaluations are 4 minutes of host time, and pytest-xdist hands out whole files)
+# the reference's other shipped EMRT tile sizes (configs/EMRT/EMRT_{224x224,384x384,448x448}_160k_potsdam.yaml): pyramids 28/14/7, 48/24/12, 56/28/14 --
+# odd and non-power-of-two levels through the LDS-staged MSDA kernels, the adaptive-pool bins and the x2 / x4 resizes.  Run from
+# tests/test_gpu_model_tiles.py (4 minutes of float64 host time: a file of their own for pytest-xdist)
+FORWARD_CASES_TILES = [("resnet50", 2, 224, 6), ("resnet50", 2, 384, 6), ("resnet50", 2, 448, 6)]
 FORWARD_CASES_FULL = [("resnet50", 1, 512, 7),      # BASELINE configs[2] geometry (LoveDA 512x512, 7 classes, Lv = 5376)
                       ("resnet50", 8, 256, 6),      # configs[1]: batch 8
                       ("resnet50", 4, 512, 7)]      # configs[2]: batch 4
@@ -154,10 +158,7 @@ FORWARD_CASES_FULL = [("resnet50", 1, 512, 7),      # BASELINE configs[2] geomet
                                                 ("resnet18", 1, 256, 6),      # configs[0]: ResNet-18, one 256x256 tile, on the HIP path
                                                 # the other depths the reference's constructor accepts (paddle_EMRT.py:229-234)
                                                 ("resnet34", 1, 128, 6), ("resnet101", 1, 128, 6),
-                                                # the reference's other shipped EMRT tile sizes (configs/EMRT/EMRT_{224x224,384x384,448x448}_160k_potsdam.yaml):
-                                                # pyramids 28/14/7, 48/24/12, 56/28/14 -- odd and non-power-of-two levels through the LDS-staged
-                                                # MSDA kernels, the adaptive-pool bins and the x2 / x4 resizes
-                                                ("resnet50", 2, 224, 6), ("resnet50", 2, 384, 6), ("resnet50", 2, 448, 6)])
+                                                ])
 def test_forward_logits_match_oracle_eval(backbone, B, S, ncls):
     forward_logits_case(backbone, B, S, ncls)
 
@@ -202,7 +203,7 @@ def forward_logits_case(backbone, B, S, ncls):
     assert exact == flips
 
 
-def test_train_forward_and_gradients_match_oracle():
+def train_forward_and_gradients_case():      # run from tests/test_gpu_model_train.py (a file of its own for pytest-xdist: 1-2 minutes of oracle time)
     """Train-mode forward, loss and EVERY parameter gradient against the oracle evaluated in float64.
     This random-initialised, tiny-batch network is ill-conditioned: the float32 CPU oracle's own gradients are 1-4 %
     (norm-wise) away from float64 (measured, see tools/debug_stages.py), so the HIP gradients are held to the same
@@ -261,7 +262,7 @@ def test_train_forward_and_gradients_match_oracle():
         assert (b.cpu() - refb[n].float()).abs().max().item() < 1e-3 * (1 + refb[n].abs().max().item()), n
 
 
-def test_full_size_train_step_matches_oracle():
+def full_size_train_step_case():      # run from tests/test_gpu_model_train.py
     """The benchmark workload itself (BASELINE configs[1]: ResNet-50, batch 8, 256x256, 6 classes), one train-mode
     forward + loss + backward in fp32 against the fp32 CPU oracle: logits, loss, the whole gradient as one vector
     (norm and direction) and the per-parameter relative errors."""
