@@ -2177,11 +2177,11 @@ extern "C" int emrt_conv2d_bwd(const void* x, const void* dy, const void* w_bwd_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Grouped launches: up to 4 independent small problems (the per-level 3x3 convs of an encoder layer, ...) in ONE launch.
+// Grouped launches: up to 6 independent small problems (the per-level 3x3 convs of an encoder layer, ...) in ONE launch.
 // Each problem alone is a 10-30 us, latency-bound launch that fills a fraction of the GPU; their tiles side by side
 // share the launch and hide each other's latency.  Plain-C descriptors (include/emrt_hip.h).
 // ------------------------------------------------------------------------------------------------
-#define EMRT_MAX_GROUP 4
+#define EMRT_MAX_GROUP 6
 struct EmrtConvDesc {
   const void* in; const void* w_packed; void* out; const float* bias; const void* residual;
   int N, H, W, C, ldin; long long in_bs;
@@ -2272,7 +2272,7 @@ static int conv_group_dispatch(const EmrtConvDesc* descs, int n, hipStream_t st)
 }
 
 extern "C" int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream) {
-  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..4 problems");
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..6 problems");
   EMRT_REQUIRE_FWD_DTYPE(dtype);
   for (int i = 0; i < n; ++i) {
     const EmrtConvDesc& d = descs[i];
@@ -2379,7 +2379,7 @@ static int conv_bwd_group_dispatch(const EmrtConvBwdDesc* descs, int n, hipStrea
 }
 
 extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream) {
-  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..4 problems");
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..6 problems");
   EMRT_REQUIRE_TRAIN_DTYPE(dtype);
   for (int i = 0; i < n; ++i) {
     const EmrtConvBwdDesc& b = descs[i];

@@ -1058,12 +1058,28 @@ def _dp(t):
     return t.data_ptr() if t is not None else None
 
 
-def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
+def level_conv_gn_takes_linears(src, convs, linears):
+    """True when level_conv_gn(linears=) can put the projections into the level convolutions' forward launch: the grouped kernel's limits (6 problems,
+    4096 tiles of 64 x 64 in all -- beyond that emrt_conv2d_group falls back to one launch per problem)"""
+    B, Lv, C = src.shape
+    tiles = ((B * Lv + 63) // 64) * ((C + 63) // 64)          # (an upper bound for the level convs: their rows are the levels' pixels)
+    for x, w, _f32 in linears:
+        if not (x.dim() == 3 and x.is_contiguous() and w.KH == w.KW == 1 and x.shape[2] == w.C):
+            return False
+        tiles += ((x.shape[0] * x.shape[1] + 63) // 64) * ((w.OC + 63) // 64)
+    return len(convs) + len(linears) <= 6 and tiles + len(convs) * ((C + 63) // 64) <= 4096
+
+
+def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5, linears=None):
     """The conv branch of an encoder layer (transformer_encoder_decoder.py:125-144, 163-182) over ALL levels at once:
         out[:, level l] = GELU(GroupNorm_l(conv3x3_l(src[:, level l] as an h_l x w_l map))) + src[:, level l]
     src: dense tokens [B, Lv, C]; convs: GemmWeight per level (3x3, stride 1, pad 1, no bias); gns: (gamma, beta, dgamma,
     dbeta) per level.  Two launches forward (grouped conv, multi-level GroupNorm) and two backward instead of six each:
-    the per-level problems are small, latency-bound launches on their own."""
+    the per-level problems are small, latency-bound launches on their own.
+    linears (optional, as linear_group's items): independent linear layers that ride in the FORWARD grouped launch of the level convolutions -- the
+    deformable attention's value_proj(src) and its offsets | logits projection of the query, which read the same tokens and depend on nothing the conv
+    branch produces (transformer_encoder_decoder.py:83-92, 184-204).  Their backward is linear_group's own (a data-gradient launch of its own: value_proj's
+    gradient accumulates into the same d src rows as the level convolutions', which two problems of ONE launch must not).  -> (out, [linear outputs])."""
     c = ctx()
     assert src.is_contiguous() and src.dim() == 3
     B, Lv, C = src.shape
@@ -1073,7 +1089,12 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
     esz = src.element_size()
     y = c.empty((B, Lv, C))
     out = c.empty((B, Lv, C))
-    fd = (_ConvDesc * L)()
+    nl = len(linears) if linears else 0
+    fd = (_ConvDesc * (L + nl))()
+    lin_outs, lin_geo = [], []
+    for j in range(nl):
+        lin_outs.append(_linear_desc(fd[L + j], *linears[j]))
+        lin_geo.append(tuple(linears[j][0].shape))
     for l, (w, (h, wd), (s0, n)) in enumerate(zip(convs, spatial_shapes, level_spans)):
         assert n == h * wd
         d = fd[l]
@@ -1082,7 +1103,9 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
         d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, h, wd, C, C, Lv * C
         d.OH, d.OW, d.OC, d.ldout, d.out_bs = h, wd, C, C, Lv * C
         d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu = 0, 0, 3, 3, 1, 1, 0
-    _L().call("emrt_conv2d_group", fd, L, c.dtype, c.stream)
+    _L().call("emrt_conv2d_group", fd, L + nl, c.dtype, c.stream)
+    if nl and c.tape is not None:
+        _record_linear_group_bwd(linears, lin_outs, lin_geo)
     starts = (ctypes.c_int * L)(*[s0 for s0, _ in level_spans])
     hws = (ctypes.c_int * L)(*[n for _, n in level_spans])
     gam = (ctypes.c_void_p * L)(*[g[0].data_ptr() for g in gns])
@@ -1133,6 +1156,19 @@ def level_conv_gn(src, convs, gns, spatial_shapes, level_spans, G=32, eps=1e-5):
             else:
                 tape.add_grad(src, dout)          # the residual path of every level: one add over the whole token tensor
         tape.record(bwd)
+    return (out, lin_outs) if linears else out
+
+
+def _linear_desc(d, x, w, out_f32):
+    """fills one EmrtConvDesc with the linear layer y = x W^T + b over dense tokens x [B, L, C]; -> the output tensor"""
+    c = ctx()
+    assert x.is_contiguous() and x.dim() == 3 and w.KH == w.KW == 1 and x.shape[2] == w.C
+    B, L_, C = x.shape
+    out = c.empty((B, L_, w.OC), torch.float32 if out_f32 else None)
+    d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, out.data_ptr(), _dp(w.bias), None, None
+    d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, 1, L_, C, C, L_ * C
+    d.OH, d.OW, d.OC, d.ldout, d.out_bs = 1, L_, w.OC, w.OC, L_ * w.OC
+    d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, 1, 1, 1, 0, 0, int(bool(out_f32))
     return out
 
 
@@ -1147,55 +1183,56 @@ def linear_group(items):
     outs, geo = [], []
     fd = (_ConvDesc * n)()
     for d, (x, w, out_f32) in zip(fd, items):
-        assert x.is_contiguous() and x.dim() == 3 and w.KH == w.KW == 1 and x.shape[2] == w.C
-        B, L_, C = x.shape
-        out = c.empty((B, L_, w.OC), torch.float32 if out_f32 else None)
-        d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, out.data_ptr(), _dp(w.bias), None, None
-        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = B, 1, L_, C, C, L_ * C
-        d.OH, d.OW, d.OC, d.ldout, d.out_bs = 1, L_, w.OC, w.OC, L_ * w.OC
-        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, 1, 1, 1, 0, 0, int(bool(out_f32))
-        outs.append(out)
-        geo.append((B, L_, C))
+        outs.append(_linear_desc(d, x, w, out_f32))
+        geo.append(tuple(x.shape))
     _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
-    tape = c.tape
-    if tape is not None:
-        def bwd():
-            dys = [tape.pop_grad(o) for o in outs]
-            live = [i for i in range(n) if dys[i] is not None]
-            if not live:
-                return
-            bd = (_ConvBwdDesc * len(live))()
-            fresh = []
-            for d, i in zip(bd, live):
-                x, w, out_f32 = items[i]
-                B, L_, C = geo[i]
-                dy = dys[i]
-                if out_f32 and dy.dtype == torch.float32:      # (a producer may hand the gradient over in the compute dtype already: Fn.msda)
-                    dy = cast_from_f32(dy)
-                assert dy.is_contiguous()
-                dys[i] = dy
-                deferred = wgrad_deferred(w)
-                if deferred:
-                    defer_wgrad(tape, x, dy, w, (B, 1, L_, C, C, L_ * C, 1, L_, w.OC, L_ * w.OC), 1, 0, 1)
-                else:
-                    w.grad_is_zero = False
-                    _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), B, 1, L_, C, C, L_ * C, 1, L_, w.OC, w.OC, L_ * w.OC, 1, 1, 1, 0,
-                              P(w.bias_grad) if w.bias is not None else None, 1, c.dtype, c.stream)
-                slot = tape.grad_slot(x)
-                dx = slot if slot is not None else c.empty((B, L_, C))
-                assert dx.is_contiguous()
-                d.x, d.dy, d.w_bwd_packed, d.dx = x.data_ptr(), dy.data_ptr(), w.bwd_ptr, dx.data_ptr()
-                d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = C, L_ * C, int(slot is not None), None, None
-                d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, 1, L_, C, C, L_ * C
-                d.OH, d.OW, d.OC, d.lddy, d.dy_bs = 1, L_, w.OC, w.OC, L_ * w.OC
-                d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
-                if slot is None:
-                    fresh.append((x, dx))
-            _L().call("emrt_conv2d_bwd_group", bd, len(live), c.dtype, c.stream)
-            for x, dx in fresh:
-                tape.add_grad(x, dx, owned=True)
-        tape.record(bwd)
+    if c.tape is not None:
+        _record_linear_group_bwd(items, outs, geo)
     return outs
+
+
+def _record_linear_group_bwd(items, outs, geo):
+    """the backward of linear_group (and of the linears that rode in level_conv_gn's forward launch): ONE grouped data-gradient launch, weight gradients batched"""
+    c = ctx()
+    tape = c.tape
+    n = len(items)
+
+    def bwd():
+        dys = [tape.pop_grad(o) for o in outs]
+        live = [i for i in range(n) if dys[i] is not None]
+        if not live:
+            return
+        bd = (_ConvBwdDesc * len(live))()
+        fresh = []
+        for d, i in zip(bd, live):
+            x, w, out_f32 = items[i]
+            B, L_, C = geo[i]
+            dy = dys[i]
+            if out_f32 and dy.dtype == torch.float32:      # (a producer may hand the gradient over in the compute dtype already: Fn.msda)
+                dy = cast_from_f32(dy)
+            assert dy.is_contiguous()
+            dys[i] = dy
+            deferred = wgrad_deferred(w)
+            if deferred:
+                defer_wgrad(tape, x, dy, w, (B, 1, L_, C, C, L_ * C, 1, L_, w.OC, L_ * w.OC), 1, 0, 1)
+            else:
+                w.grad_is_zero = False
+                _L().call("emrt_conv2d_wgrad", P(x), P(dy), P(w.grad), B, 1, L_, C, C, L_ * C, 1, L_, w.OC, w.OC, L_ * w.OC, 1, 1, 1, 0,
+                          P(w.bias_grad) if w.bias is not None else None, 1, c.dtype, c.stream)
+            slot = tape.grad_slot(x)
+            dx = slot if slot is not None else c.empty((B, L_, C))
+            assert dx.is_contiguous()
+            d.x, d.dy, d.w_bwd_packed, d.dx = x.data_ptr(), dy.data_ptr(), w.bwd_ptr, dx.data_ptr()
+            d.lddx, d.dx_bs, d.accumulate, d.dw, d.dbias = C, L_ * C, int(slot is not None), None, None
+            d.N, d.H, d.W, d.C, d.ldx, d.x_bs = B, 1, L_, C, C, L_ * C
+            d.OH, d.OW, d.OC, d.lddy, d.dy_bs = 1, L_, w.OC, w.OC, L_ * w.OC
+            d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
+            if slot is None:
+                fresh.append((x, dx))
+        _L().call("emrt_conv2d_bwd_group", bd, len(live), c.dtype, c.stream)
+        for x, dx in fresh:
+            tape.add_grad(x, dx, owned=True)
+    tape.record(bwd)
 
 
 def level_proj_gn(feats, convs, gns, G=32, eps=1e-5):

@@ -242,6 +242,10 @@ class Context:
         self.bn_small_group = bool(int(os.environ.get("EMRT_BN_SMALL_GROUP", "1")))
         # conv1 and the shortcut conv of a bottleneck stage's first block (same input) as one grouped forward launch (functional.conv_bn_pair); 0 = A/B knob
         self.conv_pair = bool(int(os.environ.get("EMRT_CONV_PAIR", "1")))
+        # cls_psp's second conv -> BatchNorm -> ReLU and the auxiliary head's in one grouped launch per pass (EMRT.forward, one rank); 0 = A/B knob
+        self.head_pair = bool(int(os.environ.get("EMRT_HEAD_PAIR", "1")))
+        # an encoder layer's value_proj | offsets-logits projections in the forward grouped launch of its per-level 3x3 convolutions (Fn.level_conv_gn(linears=)); 0 = A/B knob
+        self.enc_front = bool(int(os.environ.get("EMRT_ENC_FRONT", "1")))
         self.group_attn_proj = bool(int(os.environ.get("EMRT_GROUP_ATTN_PROJ", "1")))      # A/B: value_proj and the offsets | logits projection as one grouped launch
         self.fuse_ffn_dropout = bool(int(os.environ.get("EMRT_FFN_DROPOUT_FUSED", "1")))      # A/B: dropout(relu(linear1)) drawn in the GEMM epilogue (emrt_conv2d_drop)
         # the query of the NEXT attention (out + pos) written by the LayerNorm launch that produces `out`, its gradient summed by that LayerNorm's backward

@@ -261,9 +261,13 @@ class MSDeformableAttention(hnn.HipLayer):  # :21-107
         assert store.offsets[prefix + "attention_weights.bias"] == ob + self.total_points * 2
         self.offw_gemm = store.make_gemm(ow, self.total_points * 3, self.embed_dim, 1, 1, ob)
 
-    def forward(self, query, reference_points, value, spatial_shapes, need_dref=False):  # :65-107 (value_mask is all ones)
+    def forward(self, query, reference_points, value, spatial_shapes, need_dref=False, projected=None):  # :65-107 (value_mask is all ones)
+        """projected = (value_proj(value), offsets | logits projection of the query) when the caller already ran both (the encoder layer puts them into
+        its conv branch's grouped launch: Fn.level_conv_gn(linears=))"""
         c = ctx()
-        if c.group_attn_proj and value.dim() == 3 and query.dim() == 3 and value.is_contiguous() and query.is_contiguous() and value is not query:
+        if projected is not None:
+            value, offw = projected
+        elif c.group_attn_proj and value.dim() == 3 and query.dim() == 3 and value.is_contiguous() and query.is_contiguous() and value is not query:
             # value_proj(value) and the offsets | logits projection of the query: independent, one grouped launch forward, one for both data gradients
             value, offw = Fn.linear_group([(value, self.value_proj.gw, False), (query, self.offw_gemm, True)])
         else:
@@ -344,11 +348,20 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
         the next layer's query -> returns (out, q_next)."""
         B, Lv, C = src.shape
         seqs = (self.conv0, self.conv1, self.conv2)
+        projected = None
         if src.is_contiguous() and all(n == h * w and n <= 4096 for (h, w), (_, n) in zip(spatial_shapes, level_spans)):
             # all levels in one grouped conv launch + one multi-level GroupNorm launch (Fn.level_conv_gn)
-            src_flatten = Fn.level_conv_gn(src, [seq[0].gw for seq in seqs],
-                                           [(seq[1].weight.data, seq[1].bias.data, seq[1].weight.grad, seq[1].bias.grad) for seq in seqs],
-                                           spatial_shapes, level_spans)
+            gws = [seq[0].gw for seq in seqs]
+            gns = [(seq[1].weight.data, seq[1].bias.data, seq[1].weight.grad, seq[1].bias.grad) for seq in seqs]
+            c = ctx()
+            if q is None:
+                q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
+            lin = [(src, self.self_attn.value_proj.gw, False), (q, self.self_attn.offw_gemm, True)]
+            if c.enc_front and c.group_attn_proj and q.is_contiguous() and q is not src and Fn.level_conv_gn_takes_linears(src, gws, lin):
+                # ... and the attention's two input projections, which read the same tokens, in that launch too (forward)
+                src_flatten, projected = Fn.level_conv_gn(src, gws, gns, spatial_shapes, level_spans, linears=lin)
+            else:
+                src_flatten = Fn.level_conv_gn(src, gws, gns, spatial_shapes, level_spans)
             identity = src_flatten          # = branch(src) + src, consumed only by norm2 below: norm1's backward sums its gradient into d src
         else:
             identity = None
@@ -359,7 +372,7 @@ class TransformerEncoderLayer(hnn.HipLayer):  # :109-204
                 seq[1](y, gelu=True, residual=x_l, out=Fn.tokens_as_map(Fn.narrow(src_flatten, 1, s0, n), h, w))
         if q is None:
             q = Fn.add(src, pos, period=Lv * C, bgrad=pos_bgrad)
-        src2 = self.self_attn(q, reference_points, src, spatial_shapes)
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes, projected=projected)
         src = self.norm1(src, src2, drop_p=self.p, drop_salt=self.salts[0], identity_from=identity)       # LN(src + dropout1(src2)), dropout inside the LN kernels
         h1 = self.linear1(src, relu=True, drop=(self.p, self.salts[1]))     # dropout(relu(linear1)) in one launch; both masks are applied by linear2's dgrad
         ff = self.linear2(h1)
@@ -854,7 +867,18 @@ class EMRT(hnn.HipLayer):  # :184-304
         self.EFP(maps[0], maps[1], maps[2], out=Fn.narrow(psp_cat, 3, 256 * (1 + nps), 256))
         Fn.pyramid_tokens_to_maps(hs, self.psp_scale, SH, SW, [Fn.narrow(psp_cat, 3, 256 * (1 + i), 256) for i in range(nps)])  # :281-291
         o = Fn.conv_bn(self.cls_psp[0], self.cls_psp[1], psp_cat, relu=True, defer="conv")
-        o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
+        # One rank: cls_psp's second conv -> BatchNorm -> ReLU (32^2 x 512 -> 256, paddle_EMRT.py:201-209) and the auxiliary head's (16^2 x 1024 -> 256 on c3,
+        # fcn_head.py:47-56) are independent 3x3 stages of 512 + 128 tiles: side by side in ONE grouped launch per pass (Fn.conv_bn_small_group) instead
+        # of two latency-bound chains of conv | BatchNorm apply and col_reduce | BatchNorm backward | data gradient
+        if aux_feat is None and self.training and c.head_pair and B * SH * SW <= 16384:
+            om = o.materialize() if isinstance(o, Fn.PendingBN) else o
+            pair_convs, pair_bns = [self.cls_psp[3], head0[0]], [self.cls_psp[4], head0[1]]
+            if Fn._small_group_ok(pair_convs, pair_bns, [om, c3]):
+                o, aux_feat = Fn.conv_bn_small_group(pair_convs, pair_bns, [om, c3], relu=True)
+            else:
+                o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], om, relu=True)
+        else:
+            o = Fn.conv_bn(self.cls_psp[3], self.cls_psp[4], o, relu=True)
         o = Fn.dropout(o, self.cls_p, self.cls_salt, mode=1, hw=SH * SW, sole_consumer_is_linear=True)   # UpHead's conv_0 is its only consumer
         logits = self.uphead(o)
         if self.training or self.compute_aux_in_eval:

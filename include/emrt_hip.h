@@ -82,7 +82,7 @@ int emrt_conv2d_bna_supported(const void* in, const void* w_packed, void* out, c
 int emrt_conv2d_bna(const void* in, const void* w_packed, void* out, const float* bias, const void* residual, int N, int H, int W, int C, int ldin, long long in_bs, int OH, int OW, int OC, int ldout, long long out_bs, int ldres, long long res_bs, int KH, int KW, int stride, int pad, int relu, int out_f32, double* bn_stats, int dilation, const double* sums, double count, float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, int in_relu, void* a_out, int dtype, void* stream);
 /* weight gradient, ACCUMULATED (fp32 atomics) into dw [OC][KH][KW][C]; dbias (nullable, [OC]) += sum over pixels of dy */
 int emrt_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ldx, long long x_bs, int OH, int OW, int OC, int lddy, long long dy_bs, int KH, int KW, int stride, int pad, float* dbias, int dilation, int dtype, void* stream);
-/* ---- grouped launches: up to 4 independent SMALL problems (the per-level 3x3 convs of an encoder layer, ...) as ONE
+/* ---- grouped launches: up to 6 independent SMALL problems (the per-level 3x3 convs of an encoder layer + its attention projections, ...) as ONE
  * launch; problems that are not small vector-path ones are launched one by one instead.  Descriptors are host arrays. */
 typedef struct EmrtConvDesc {            /* the arguments of emrt_conv2d, mode 0 */
   const void* in; const void* w_packed; void* out; const float* bias; const void* residual;

@@ -68,17 +68,26 @@ def test_train_step_launch_sequence(fake, backbone):
     # + EFP's three Conv2dBlocks level by level: conv1 of the three levels, then conv2 (+ x), grouped each way
     # forward only: conv1 and the shortcut conv of every bottleneck stage's first block share one grouped launch (functional.conv_bn_pair)
     n_pairs = sum(1 for mod in m.modules() if type(mod).__name__ == "BottleneckBlock" and mod.downsample is not None)
-    assert n_grouped == 15 + 12 + 4 + 4 + 6 and sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == n_grouped + 2 * n_pairs
-    assert cnt["emrt_bn_group_apply"] == cnt["emrt_bn_group_bwd"] == 3
-    assert sorted(a[1] for n, a in fake.calls if n == "emrt_bn_group_apply") == [3, 3, 4]
+    # + cls_psp's second conv -> BatchNorm -> ReLU beside the auxiliary head's (two independent 3x3 stages: EMRT.forward, one rank), grouped each way
+    assert n_grouped == 15 + 12 + 4 + 4 + 6 + 2 and sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == n_grouped + 2 * n_pairs
+    assert cnt["emrt_bn_group_apply"] == cnt["emrt_bn_group_bwd"] == 4
+    assert sorted(a[1] for n, a in fake.calls if n == "emrt_bn_group_apply") == [2, 3, 3, 4]
     assert sum(1 for n, a in fake.calls if n == "emrt_bn_group_apply" for i in range(a[1]) if a[0][i].res) == 3      # "conv2(conv1(x)) + x" added by the BatchNorm launch
     pairs = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 2]
-    stage_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats]          # conv1 | shortcut conv of a stage's first block
-    assert len(stage_pairs) == n_pairs and all(a[0][0].inp == a[0][1].inp and a[0][1].OC == 4 * a[0][0].OC for a in stage_pairs)
+    stage_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats and a[0][0].inp == a[0][1].inp]          # conv1 | shortcut conv of a stage's first block
+    assert len(stage_pairs) == n_pairs and all(a[0][1].OC == 4 * a[0][0].OC for a in stage_pairs)
+    head_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats and a[0][0].inp != a[0][1].inp]
+    assert len(head_pairs) == 1 and head_pairs[0][0][0].KH == head_pairs[0][0][1].KH == 3 and head_pairs[0][0][0].OC == 256 and head_pairs[0][0][1].W * 2 == head_pairs[0][0][0].W
     pairs = [a for a in pairs if not (a[0][0].bn_stats and a[0][1].bn_stats)]
     msda_pairs = [a for a in pairs if a[0][1].out_f32 == 1]
     mha_pairs = [a for a in pairs if a[0][1].out_f32 == 0]
-    assert len(msda_pairs) == 6 and all(a[0][0].out_f32 == 0 and a[0][1].OC == 432 for a in msda_pairs)
+    # the decoder's two deformable attentions as pairs; the four encoder layers' projections ride in the forward launch of their layer's per-level 3x3
+    # convolutions (functional.level_conv_gn(linears=): 3 levels + value_proj + offsets | logits = 5 problems), their data gradients stay a pair of their own
+    assert len(msda_pairs) == 2 and all(a[0][0].out_f32 == 0 and a[0][1].OC == 432 for a in msda_pairs)
+    fronts = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 5]
+    assert len(fronts) == 4 and all(a[0][0].KH == a[0][1].KH == a[0][2].KH == 3 and a[0][3].KH == 1 and a[0][3].OC == 256 and a[0][3].out_f32 == 0
+                                    and a[0][4].OC == 432 and a[0][4].out_f32 == 1 and a[0][3].inp == a[0][0].inp for a in fronts)
+    assert sum(1 for n, a in fake.calls if n == "emrt_conv2d_bwd_group" and a[1] == 2 and a[0][1].OC == 432) == 6      # (backward: six pairs as before)
     assert len(mha_pairs) == 2 and all(a[0][0].OC == 512 and a[0][1].OC == 256 and a[0][0].W == a[0][1].W == 110 for a in mha_pairs)
     # every GEMM weight gets exactly one weight gradient: immediately (the 1x1 classifiers' one-pass backward) or in a batched
     # emrt_conv2d_wgrad_group call made while backward runs; a layer whose weight gradient is batched passes dw = NULL to its data gradient
@@ -106,15 +115,15 @@ def test_train_step_launch_sequence(fake, backbone):
     n_join_defer = cnt["emrt_bn_apply_join"]
     assert n_join_defer == sum(1 for mod in m.modules() if getattr(mod, "downsample", None) is not None) > 0
     # ... and the BatchNorm + ReLU between two convolutions by the consuming convolution's operand loads (emrt_conv2d_bna; the fake library says
-    # "supported" for every layer): bn1 -> conv2 of every block, bn2 -> conv3 of every bottleneck, cls_psp's first (EFP's Conv2dBlocks go level by level in
+    # "supported" for every layer): bn1 -> conv2 of every block, bn2 -> conv3 of every bottleneck (EFP's Conv2dBlocks go level by level in
     # grouped launches instead: conv_bn_small_group)
     n_blocks = sum(1 for mod in m.modules() if type(mod).__name__ in ("BasicBlock", "BottleneckBlock"))
     n_bottle = sum(1 for mod in m.modules() if type(mod).__name__ == "BottleneckBlock")
     n_conv_fused = cnt["emrt_conv2d_bna"]
-    assert n_conv_fused == n_blocks + n_bottle + 1
+    assert n_conv_fused == n_blocks + n_bottle      # (cls_psp's first BatchNorm is materialised: its consumer runs beside the auxiliary head's conv in one grouped launch)
     bna = [a for n, a in fake.calls if n == "emrt_conv2d_bna"]
     assert all(a[26] is not None and a[37] is not None and a[36] == 1 for a in bna)      # sums, a_out, ReLU
-    n_psp = 4 + 6      # the pyramid-pooling branches and EFP's six BatchNorms: grouped apply / backward launches of their own (emrt_bn_group_apply / _bwd)
+    n_psp = 4 + 6 + 2  # the pyramid-pooling branches, EFP's six BatchNorms, cls_psp's second beside the auxiliary head's: grouped apply / backward launches of their own (emrt_bn_group_apply / _bwd)
     n_defer = n_stream + 1 + n_join_defer + n_conv_fused + n_psp
     assert cnt["emrt_bn_apply"] + cnt["emrt_bn_apply_join"] == n_bn - n_defer and cnt["emrt_bn_bwd_dx"] == n_bn - n_psp and cnt["emrt_bn_stats"] == 0
     fwd_convs = [a for n, a in fake.calls if n == "emrt_conv2d" and a[22] == 0]
