@@ -124,6 +124,7 @@ class TrainEngine:
             self.seg_ranges = model.store.segment_ranges(segs)
             self.early_ranges = self.seg_ranges[0]
             self.late_ranges = [r for seg in self.seg_ranges[1:] for r in seg]
+        c.segment_order = self.seg_ranges is not None      # (EMRT.forward: no spatial-branch stages inside layer3 / layer4's launches then)
         self.graph_rest = []         # hipGraphs of backward segments 2.. (graph_a holds forward + segment 1)
 
     @property

@@ -739,17 +739,8 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None, defer=False):
     sums = c.zeros_f64(BN_REPLICAS * 2 * bn.C) if c.training else None
     y = conv2d(x, conv.gw, conv.stride, conv.padding, need_dx=conv.need_dx, bn_stats=sums, dilation=getattr(conv, "dilation", 1))
     # what the consumers' fused entry points accept (emrt_bn_resize_bilinear_fwd, emrt_bn_maxpool_fwd: C <= 1024 and C / (elements per 16 bytes)
-    # a divisor of 256 -- C / 4 in fp32); a PendingBN has no fallback once created, so anything else takes the separate emrt_bn_apply here
-    per16 = 4 if c.dtype == F32 else 8
-    fits = bn.C % per16 == 0 and bn.C <= 1024 and 256 % (bn.C // per16) == 0
-    if defer == "conv" and not c.bn_conv:
-        defer = False
-    if defer and c.training and c.bn_defer and residual is None and out is None and (fits or defer in ("join", "conv")):
-        count = y.shape[0] * y.shape[1] * y.shape[2]
-        if _sync_active(bn.state):
-            count = _allreduce_sums(sums, count)
-        return PendingBN(y, bn.state, sums, count, relu)
-    return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
+    # a divisor of 256 -- C / 4 in fp32); a PendingBN has no fallback once created, so anything else takes the separate emrt_bn_apply here (_bn_tail)
+    return _bn_tail(y, bn, sums, relu, residual, out, defer)
 
 
 class _BnGroupDesc(ctypes.Structure):      # EmrtBnGroupDesc (include/emrt_hip.h)
@@ -892,6 +883,95 @@ def conv_bn_small_group(convs, bns, xs, relu=True, post_adds=None):
             tape.add_grad(x, dx, owned=True)
     tape.record(bwd)
     return outs
+
+
+class SideJobs:
+    """A second, INDEPENDENT chain of layers run beside the main one (EMRT's spatial branch beside the ResNet: paddle_EMRT.py:99-113, 252-262).  `gen` is a
+    generator that does its own launches and, whenever it needs a conv -> BatchNorm stage, yields (conv, bn, x, relu, defer, out) and is sent the result
+    (what conv_bn would have returned).  The main chain, at a layer whose own launch leaves most of the machine idle, takes the pending request into ITS
+    grouped launch (conv_bn_many) and delivers the result; finish() runs whatever is left the ordinary way and returns the generator's return value."""
+
+    def __init__(self, gen):
+        self.gen, self.req, self.done, self.result, self.hosted = gen, None, False, None, 0
+        self._advance(None)
+
+    def _advance(self, value):
+        try:
+            self.req = self.gen.send(value)
+        except StopIteration as e:
+            self.req, self.done, self.result = None, True, e.value
+
+    def pending(self):
+        return self.req
+
+    def deliver(self, value):
+        self.hosted += 1
+        self._advance(value)
+
+    def finish(self):
+        while not self.done:
+            cv, bn, x, relu, defer, out = self.req
+            self._advance(conv_bn(cv, bn, x, relu=relu, out=out, defer=defer))
+        return self.result
+
+
+def _bn_tail(y, bn, sums, relu, residual, out, defer):
+    """what conv_bn does with the raw convolution output y and its batch sums: a PendingBN (deferred forms) or the BatchNorm launch"""
+    c = ctx()
+    per16 = 4 if c.dtype == F32 else 8
+    fits = bn.C % per16 == 0 and bn.C <= 1024 and 256 % (bn.C // per16) == 0
+    if defer == "conv" and not c.bn_conv:
+        defer = False
+    if defer and c.training and c.bn_defer and residual is None and out is None and (fits or defer in ("join", "conv")):
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        if _sync_active(bn.state):
+            count = _allreduce_sums(sums, count)
+        return PendingBN(y, bn.state, sums, count, relu)
+    return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
+
+
+def conv_bn_many(items, host_tiles=256):
+    """items: [(conv, bn, x, relu, defer, out)], 2..6 INDEPENDENT conv -> BatchNorm stages on materialised maps (different inputs, 1x1 / 3x3, any stride)
+    whose forward convolutions go out as ONE grouped launch (emrt_conv2d_group, statistics in the epilogue).  Each keeps conv_bn's own tail (PendingBN or
+    the BatchNorm launch) and its own backward.  The first items are the HOST's (a ResNet layer3 / layer4 block's conv1 [+ shortcut conv]: <= host_tiles
+    tiles of 64 x 64, a launch that fills a fraction of the 256 CUs), the last one a guest from another chain (SideJobs).  Returns the conv_bn results in
+    order, or None when the launch cannot be grouped (the caller then runs them one by one)."""
+    c = ctx()
+    n = len(items)
+    if not (c.training and c.bn_defer and c.tape is not None and 2 <= n <= 6 and not c.overlap):
+        return None
+    per16 = 4 if c.dtype == F32 else 8
+    tiles, geo = [], []
+    for cv, bn, x, relu, defer, out in items:
+        w = cv.gw
+        if isinstance(x, PendingBN) or x.dim() != 4 or (defer == "conv" and not c.bn_conv):
+            return None
+        N, H, W, C, ld, bs = _check_map(x)
+        if not (w.KH == w.KW and w.KH in (1, 3) and getattr(cv, "dilation", 1) == 1 and w.bias is None and w.OC > 32 and w.C == C and C % per16 == 0
+                and w.OC % per16 == 0 and ld % per16 == 0 and bs % per16 == 0 and x.data_ptr() % 16 == 0 and not _sync_active(bn.state)):
+            return None
+        OH, OW = (H + 2 * cv.padding - w.KH) // cv.stride + 1, (W + 2 * cv.padding - w.KW) // cv.stride + 1
+        tiles.append(((N * OH * OW + 63) // 64) * ((w.OC + 63) // 64))
+        geo.append((N, H, W, C, ld, bs, OH, OW))
+    if sum(tiles[:-1]) > host_tiles or sum(tiles) > 4096:
+        return None
+    fd = (_ConvDesc * n)()
+    ys, sums = [], []
+    for d, (cv, bn, x, relu, defer, out), (N, H, W, C, ld, bs, OH, OW) in zip(fd, items, geo):
+        w = cv.gw
+        y = c.empty((N, OH, OW, w.OC))
+        sm = c.zeros_f64(BN_REPLICAS * 2 * bn.C)
+        d.inp, d.w_packed, d.out, d.bias, d.residual, d.bn_stats = x.data_ptr(), w.fwd_ptr, y.data_ptr(), None, None, sm.data_ptr()
+        d.N, d.H, d.W, d.C, d.ldin, d.in_bs = N, H, W, C, ld, bs
+        d.OH, d.OW, d.OC, d.ldout, d.out_bs = OH, OW, w.OC, w.OC, OH * OW * w.OC
+        d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, w.KH, w.KW, cv.stride, cv.padding, 0, 0
+        ys.append(y); sums.append(sm)
+    _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
+    res = []
+    for (cv, bn, x, relu, defer, out), y, sm in zip(items, ys, sums):
+        conv2d(x, cv.gw, cv.stride, cv.padding, need_dx=cv.need_dx, bn_stats=sm, out=y, _launched=True)      # records this layer's backward
+        res.append(_bn_tail(y, bn, sm, relu, None, out, defer))
+    return res
 
 
 def conv_bn_pair(items, x):

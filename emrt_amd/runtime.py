@@ -242,6 +242,10 @@ class Context:
         self.bn_small_group = bool(int(os.environ.get("EMRT_BN_SMALL_GROUP", "1")))
         # conv1 and the shortcut conv of a bottleneck stage's first block (same input) as one grouped forward launch (functional.conv_bn_pair); 0 = A/B knob
         self.conv_pair = bool(int(os.environ.get("EMRT_CONV_PAIR", "1")))
+        # the spatial branch's conv -> BatchNorm stages in the forward launches of the ResNet's layer3 / layer4 blocks (functional.SideJobs, one rank); 0 = A/B knob
+        self.side_branch = bool(int(os.environ.get("EMRT_SIDE_BRANCH", "1")))
+        self.side = None
+        self.segment_order = False      # True: an engine exchanges gradient segments while backward runs (engine.TrainEngine, N > 1): layers keep the reference's order
         # cls_psp's second conv -> BatchNorm -> ReLU and the auxiliary head's in one grouped launch per pass (EMRT.forward, one rank); 0 = A/B knob
         self.head_pair = bool(int(os.environ.get("EMRT_HEAD_PAIR", "1")))
         # an encoder layer's value_proj | offsets-logits projections in the forward grouped launch of its per-level 3x3 convolutions (Fn.level_conv_gn(linears=)); 0 = A/B knob

@@ -81,7 +81,18 @@ class BottleneckBlock(hnn.HipLayer):  # :91-149
         # bn1 -> relu -> conv2 and bn2 -> relu -> conv3 (paddle_vision_resnet.py:129-149): each BatchNorm + ReLU is applied by the NEXT convolution's
         # operand loads (Fn.conv2d on a PendingBN: emrt_conv2d_bna), which writes the normalised map backward needs on the way
         pair = None
-        if self.downsample is not None:
+        c = ctx()
+        side = c.side.pending() if c.side is not None else None
+        if side is not None:
+            # a layer3 / layer4 block (<= 256 tiles of 64 x 64): the spatial branch's pending conv -> BatchNorm stage rides in conv1's launch (Fn.conv_bn_many)
+            items = [(self.conv1, self.bn1, x, True, "conv", None)]
+            if self.downsample is not None:
+                items.append((self.downsample[0], self.downsample[1], x, False, "join", None))
+            res = Fn.conv_bn_many(items + [side])
+            if res is not None:
+                pair = (res[0], res[1] if self.downsample is not None else None)
+                c.side.deliver(res[-1])
+        if pair is None and self.downsample is not None:
             # conv1 and the stage's shortcut conv read the same x: one grouped forward launch (Fn.conv_bn_pair)
             pair = Fn.conv_bn_pair([(self.conv1, self.bn1, True, "conv"), (self.downsample[0], self.downsample[1], False, "join")], x)
         if pair is not None:
@@ -665,6 +676,15 @@ class spatial_branch(hnn.HipLayer):  # :99-113
     def forward(self, x, out):
         return self.Enc2(self.Enc1(self.Enc0(x)), out=out)
 
+    def jobs(self, x, out):
+        """forward() as a generator for Fn.SideJobs: the same launches in the same order, but every conv -> BatchNorm stage is REQUESTED (yielded) so that the
+        ResNet's layer3 / layer4 blocks can take it into their own under-filled launches -- the spatial branch depends on nothing the backbone computes"""
+        for blk, o in ((self.Enc0, None), (self.Enc1, None), (self.Enc2, out)):
+            x = Fn.maxpool(x, 3, 2, 1, need_dx=not blk.first)
+            x = yield (blk.encode[0], blk.encode[1], x, True, False, None)
+            x = yield (blk.encode[3], blk.encode[4], x, True, o is None, o)
+        return x
+
 
 class UpHead(hnn.HipLayer):  # :115-181 (num_conv == 3)
     def __init__(self, embed_dim=256, num_classes=6):
@@ -847,10 +867,21 @@ class EMRT(hnn.HipLayer):  # :184-304
             "EMRT expects fp32 NCHW images whose H and W are multiples of 32 (paddle_EMRT.py:293)"
         x = Fn.nchw_to_nhwc(inputs.contiguous(), c_out=IMAGE_CHANNELS)
         B, H, W, _ = x.shape
-        c1, c2, c3, c4 = self.backbone(x)
         SH, SW = H // 8, W // 8                 # x_context.shape[2:] (:283-288); tiles need not be square
         psp_cat = c.empty((B, SH, SW, 256 * (2 + len(self.psp_scale))))
-        x_context = self.spatial_branch(x, out=Fn.narrow(psp_cat, 3, 0, 256))
+        if (self.training and c.side_branch and c.tape is not None and c.world_size == 1 and not c.sync_always and not c.segment_order and not c.overlap
+                and isinstance(self.backbone, ResNet)):
+            # one rank: the spatial branch's conv stages ride in the launches of the ResNet's layer3 / layer4 blocks (Fn.SideJobs); with more ranks the
+            # reference's order is kept (the early gradient exchange counts on the order in which the segments' gradients become final)
+            c.side = Fn.SideJobs(self.spatial_branch.jobs(x, out=Fn.narrow(psp_cat, 3, 0, 256)))
+            try:
+                c1, c2, c3, c4 = self.backbone(x)
+                x_context = c.side.finish()
+            finally:
+                c.side = None
+        else:
+            c1, c2, c3, c4 = self.backbone(x)
+            x_context = self.spatial_branch(x, out=Fn.narrow(psp_cat, 3, 0, 256))
         # data-parallel training: the five SyncBatchNorm layers (paddle_EMRT.py:64, fcn_head.py:53) all-reduce their statistics, and inside a
         # captured step every such collective is a cut between two hipGraphs.  The auxiliary head's conv -> SyncBN only needs c3, so it joins
         # the pyramid-pooling group here: ONE collective per direction for all five layers (2 cuts per step instead of 4).  With one rank

@@ -69,14 +69,20 @@ def test_train_step_launch_sequence(fake, backbone):
     # forward only: conv1 and the shortcut conv of every bottleneck stage's first block share one grouped launch (functional.conv_bn_pair)
     n_pairs = sum(1 for mod in m.modules() if type(mod).__name__ == "BottleneckBlock" and mod.downsample is not None)
     # + cls_psp's second conv -> BatchNorm -> ReLU beside the auxiliary head's (two independent 3x3 stages: EMRT.forward, one rank), grouped each way
-    assert n_grouped == 15 + 12 + 4 + 4 + 6 + 2 and sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == n_grouped + 2 * n_pairs
+    # forward only: the spatial branch's six conv -> BatchNorm stages ride as GUESTS in the conv1 launches of six bottleneck blocks (functional.SideJobs /
+    # conv_bn_many: the host's 1x1 conv1 [+ the shortcut conv of a stage's first block] first, the guest last, another input); BasicBlock backbones host none
+    hosted = [a for n, a in fake.calls if n == "emrt_conv2d_group" and all(a[0][i].bn_stats for i in range(a[1])) and a[0][0].KH == 1
+              and a[0][a[1] - 1].KH == 3 and a[0][a[1] - 1].inp != a[0][0].inp]
+    assert len(hosted) == (6 if n_pairs else 0) and all(a[1] in (2, 3) for a in hosted)
+    n_hosted_extra = sum(1 + (1 if a[1] == 2 else 0) for a in hosted)      # the guest, and a host conv1 that used to be a launch of its own
+    assert n_grouped == 15 + 12 + 4 + 4 + 6 + 2 and sum(a[1] for n, a in fake.calls if n == "emrt_conv2d_group") == n_grouped + 2 * n_pairs + n_hosted_extra
     assert cnt["emrt_bn_group_apply"] == cnt["emrt_bn_group_bwd"] == 4
     assert sorted(a[1] for n, a in fake.calls if n == "emrt_bn_group_apply") == [2, 3, 3, 4]
     assert sum(1 for n, a in fake.calls if n == "emrt_bn_group_apply" for i in range(a[1]) if a[0][i].res) == 3      # "conv2(conv1(x)) + x" added by the BatchNorm launch
     pairs = [a for n, a in fake.calls if n == "emrt_conv2d_group" and a[1] == 2]
     stage_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats and a[0][0].inp == a[0][1].inp]          # conv1 | shortcut conv of a stage's first block
-    assert len(stage_pairs) == n_pairs and all(a[0][1].OC == 4 * a[0][0].OC for a in stage_pairs)
-    head_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats and a[0][0].inp != a[0][1].inp]
+    assert len(stage_pairs) == n_pairs - sum(1 for a in hosted if a[1] == 3) and all(a[0][1].OC == 4 * a[0][0].OC for a in stage_pairs)
+    head_pairs = [a for a in pairs if a[0][0].bn_stats and a[0][1].bn_stats and a[0][0].inp != a[0][1].inp and a[0][0].KH == 3]      # (KH == 1 first: a hosted guest)
     assert len(head_pairs) == 1 and head_pairs[0][0][0].KH == head_pairs[0][0][1].KH == 3 and head_pairs[0][0][0].OC == 256 and head_pairs[0][0][1].W * 2 == head_pairs[0][0][0].W
     pairs = [a for a in pairs if not (a[0][0].bn_stats and a[0][1].bn_stats)]
     msda_pairs = [a for a in pairs if a[0][1].out_f32 == 1]
@@ -280,7 +286,14 @@ def test_backward_split_keeps_early_gradient_ranges_final(fake, backbone):
     x, lab = torch.randn(2, 3, 64, 64), torch.randint(0, 6, (2, 64, 64))
     m.train()
     m.clear_gradients()
-    out = m(x)
+    # the N > 1 engine's order: the spatial branch after the backbone (with one rank its conv stages ride in layer3 / layer4's launches -- functional.SideJobs --
+    # and its gradients would become final in the middle of a later segment; EMRT.forward keeps the reference's order whenever world_size > 1 or sync_always)
+    from emrt_amd.runtime import ctx as _ctx
+    old_side, _ctx().side_branch = _ctx().side_branch, False      # (what world_size > 1 / sync_always switch off in EMRT.forward)
+    try:
+        out = m(x)
+    finally:
+        _ctx().side_branch = old_side
     loss = MixSoftmaxCrossEntropyLoss()(out, lab)
     fake.calls.clear()
     rest = loss.backward_until_split()
@@ -299,7 +312,11 @@ def test_backward_split_keeps_early_gradient_ranges_final(fake, backbone):
     assert allr[0][0] == 0 and allr[-1][1] == st.n_train and all(a[1] == b[0] for a, b in zip(allr, allr[1:]))
     assert seg_ranges[0] == early and sum(e - a for seg in seg_ranges[1:] for a, e in seg) == sum(e - a for a, e in late)
     m.clear_gradients()
-    out = m(x)
+    old_side, _ctx().side_branch = _ctx().side_branch, False
+    try:
+        out = m(x)
+    finally:
+        _ctx().side_branch = old_side
     loss = MixSoftmaxCrossEntropyLoss()(out, lab)
     fake.calls.clear()
     segs = loss.backward_until_split(segments=True)
