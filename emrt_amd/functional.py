@@ -930,7 +930,7 @@ def _bn_tail(y, bn, sums, relu, residual, out, defer):
     return batch_norm(y, bn.state, relu=relu, residual=residual, out=out, sums=sums)
 
 
-def conv_bn_many(items, host_tiles=256):
+def conv_bn_many(items, host_tiles=128):
     """items: [(conv, bn, x, relu, defer, out)], 2..6 INDEPENDENT conv -> BatchNorm stages on materialised maps (different inputs, 1x1 / 3x3, any stride)
     whose forward convolutions go out as ONE grouped launch (emrt_conv2d_group, statistics in the epilogue).  Each keeps conv_bn's own tail (PendingBN or
     the BatchNorm launch) and its own backward.  The first items are the HOST's (a ResNet layer3 / layer4 block's conv1 [+ shortcut conv]: <= host_tiles

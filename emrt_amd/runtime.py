@@ -245,6 +245,7 @@ class Context:
         # the spatial branch's conv -> BatchNorm stages in the forward launches of the ResNet's layer3 / layer4 blocks (functional.SideJobs, one rank); 0 = A/B knob
         self.side_branch = bool(int(os.environ.get("EMRT_SIDE_BRANCH", "1")))
         self.side = None
+        self.side_host_tiles = int(os.environ.get("EMRT_SIDE_HOST_TILES", "128"))      # largest host launch (64 x 64 tiles) that takes a guest
         self.segment_order = False      # True: an engine exchanges gradient segments while backward runs (engine.TrainEngine, N > 1): layers keep the reference's order
         # cls_psp's second conv -> BatchNorm -> ReLU and the auxiliary head's in one grouped launch per pass (EMRT.forward, one rank); 0 = A/B knob
         self.head_pair = bool(int(os.environ.get("EMRT_HEAD_PAIR", "1")))

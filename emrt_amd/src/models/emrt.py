@@ -88,7 +88,7 @@ class BottleneckBlock(hnn.HipLayer):  # :91-149
             items = [(self.conv1, self.bn1, x, True, "conv", None)]
             if self.downsample is not None:
                 items.append((self.downsample[0], self.downsample[1], x, False, "join", None))
-            res = Fn.conv_bn_many(items + [side])
+            res = Fn.conv_bn_many(items + [side], host_tiles=c.side_host_tiles)
             if res is not None:
                 pair = (res[0], res[1] if self.downsample is not None else None)
                 c.side.deliver(res[-1])
