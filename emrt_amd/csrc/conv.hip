@@ -2399,6 +2399,81 @@ extern "C" int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dt
   return dtype == EMRT_F32 ? conv_bwd_group_dispatch<float>(descs, n, st) : conv_bwd_group_dispatch<bf16_t>(descs, n, st);
 }
 
+// ---- data gradients of INDEPENDENT layers with their fused epilogues, side by side (ABI 9) ----------------------------------------------------
+// emrt_conv2d_bwd_group's descriptor has no room for what the ResNet's data gradients carry in their epilogues (the producer's ReLU mask, the
+// BatchNorm backward sums, an addend).  This one mirrors the data-gradient half of emrt_conv2d_bwd argument by argument, so that a layer3 block's
+// conv1 data gradient (512 tiles of 4 k-tiles: a launch that is all ramp and tail) can take the spatial branch's pending 3x3 data gradient
+// into its launch (functional.py: the tape's stash).  n == 1 is emrt_conv2d_bwd with dw == NULL.
+struct EmrtConvDgradDesc {
+  const void* dy; const void* w_bwd_packed; void* dx; int lddx; long long dx_bs; int accumulate;
+  int N, H, W, C, OH, OW, OC, lddy; long long dy_bs; int KH, KW, stride, pad, dilation;
+  double* bn_stats; const void* mask_y; int ldy; long long y_bs; float mask_scale; const void* stat_x; int ldsx; long long sx_bs;
+  const void* addend; int ldadd; long long add_bs;
+};
+
+static void dgrad_args_from_desc(ConvArgs& d, const EmrtConvDgradDesc& b) {
+  d.in = b.dy; d.w = b.w_bwd_packed; d.out = b.dx; d.bias = nullptr; d.scale = nullptr; d.res = nullptr;
+  d.N = b.N; d.H = b.OH; d.W = b.OW; d.C = b.OC; d.ldin = b.lddy; d.in_bs = b.dy_bs;
+  d.OH = b.H; d.OW = b.W; d.OC = b.C; d.ldout = b.lddx; d.out_bs = b.dx_bs;
+  d.ldres = 0; d.res_bs = 0;
+  if (b.accumulate) { d.res = b.dx; d.ldres = b.lddx; d.res_bs = b.dx_bs; }
+  else if (b.addend) { d.res = b.addend; d.ldres = b.ldadd; d.res_bs = b.add_bs; }
+  d.KH = b.KH; d.KW = b.KW; d.stride = b.stride; d.pad = b.pad; d.dil = b.dilation; d.relu = 0; d.out_f32 = 0; d.cmajor = g_tune.igemm8p_cmajor; d.stats = b.bn_stats;
+  d.mask_y = b.mask_y; d.ldy = b.ldy; d.y_bs = b.y_bs; d.mask_scale = b.mask_scale; d.stat_x = b.stat_x; d.ldsx = b.ldsx; d.sx_bs = b.sx_bs;
+  d.xk_S = 0; d.xk_part = nullptr; d.xk_tick = nullptr; d.drop_seed = nullptr; d.drop_salt = 0; d.drop_p = 0.f;
+}
+
+template <class T>
+static int conv_dgrad_multi_dispatch(const EmrtConvDgradDesc* descs, int n, hipStream_t st) {
+  ConvGroupArgs g;
+  bool groupable = n >= 2;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvArgs& d = g.p[i];
+    dgrad_args_from_desc(d, descs[i]);
+    const long long Md = (long long)d.N * d.OH * d.OW;
+    const long long nb = ((Md + 63) / 64) * ((d.OC + 63) / 64);
+    g.first[i] = (int)total;
+    total += nb;
+    groupable = groupable && conv_desc_is_vec<T>(d) && d.OC > 32 && nb <= 2048;
+  }
+  for (int i = n; i <= EMRT_MAX_GROUP; ++i) g.first[i] = (int)total;
+  for (int i = n; i < EMRT_MAX_GROUP; ++i) g.p[i] = g.p[0];
+  if (!groupable || total > 4096) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = conv_dispatch<T, 1>(g.p[i], st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL((igemm_group_kernel<T, 1>), dim3((unsigned)total), dim3(256), (size_t)2 * 128 * 144, st, g);
+  return check_launch("emrt_conv2d_dgrad_multi");
+}
+
+extern "C" int emrt_conv2d_dgrad_multi(const EmrtConvDgradDesc* descs, int n, int dtype, void* stream) {
+  EMRT_REQUIRE(descs && n >= 1 && n <= EMRT_MAX_GROUP, "1..6 problems");
+  EMRT_REQUIRE_TRAIN_DTYPE(dtype);
+  for (int i = 0; i < n; ++i) {
+    const EmrtConvDgradDesc& b = descs[i];
+    EMRT_REQUIRE(b.dy && b.w_bwd_packed && b.dx, "null pointer");
+    EMRT_REQUIRE(b.N > 0 && b.H > 0 && b.W > 0 && b.C > 0 && b.OH > 0 && b.OW > 0 && b.OC > 0, "bad dims");
+    EMRT_REQUIRE(b.KH > 0 && b.KW > 0 && b.stride > 0 && b.pad >= 0 && b.dilation >= 1, "bad kernel geometry");
+    EMRT_REQUIRE(b.OH == (b.H + 2 * b.pad - b.dilation * (b.KH - 1) - 1) / b.stride + 1 && b.OW == (b.W + 2 * b.pad - b.dilation * (b.KW - 1) - 1) / b.stride + 1, "output size mismatch");
+    EMRT_REQUIRE((long long)b.N * b.OH * b.OW + 512 < (1ll << 31) && (long long)b.N * b.H * b.W + 512 < (1ll << 31), "more than 2^31 pixels (32-bit pixel arithmetic)");
+    const long long esz = dtype == EMRT_F32 ? 4 : 2;
+    const long long dy_ext = ((long long)(b.N - 1) * b.dy_bs + ((long long)b.OH * b.OW - 1) * b.lddy + b.OC) * esz;
+    const long long w_ext = (long long)b.OC * b.KH * b.KW * b.C * esz;
+    EMRT_REQUIRE(b.dy_bs >= 0 && dy_ext < (1ll << 31) && w_ext < (1ll << 31), "operand spans 2 GiB or more (32-bit buffer offsets)");
+    EMRT_REQUIRE((long long)b.OH * b.OW < (1 << 24) && (long long)b.lddy * esz < (1 << 24) && b.stride < (1 << 12), "map too large for the 24-bit address arithmetic");
+    EMRT_REQUIRE(b.lddx >= b.C && b.dx_bs >= 0, "bad dx strides");
+    EMRT_REQUIRE(!(b.accumulate && b.addend), "accumulate adds into dx itself; addend is a different tensor");
+    EMRT_REQUIRE(!b.stat_x || b.mask_y, "stat_x replaces the mask tensor in the second statistic: it needs mask_y");
+    for (int j = 0; j < i; ++j) EMRT_REQUIRE(descs[j].dx != b.dx, "two problems of one launch must not write the same dx");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EMRT_F32 ? conv_dgrad_multi_dispatch<float>(descs, n, st) : conv_dgrad_multi_dispatch<bf16_t>(descs, n, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched weight gradients.  dW(L) needs only x(L) and dy(L): nothing in backward waits for it, so the caller (functional.py) runs each
 // small layer's DATA gradient as its own launch (emrt_conv2d_bwd with dw == NULL: 64x64 tiles at 4 blocks per CU instead of the pair

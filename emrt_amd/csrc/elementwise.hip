@@ -9,7 +9,7 @@ using namespace emrt;
 thread_local char emrt::g_err[512] = {0};
 
 extern "C" const char* emrt_last_error(void) { return emrt::g_err; }
-extern "C" int emrt_abi_version(void) { return 8; }
+extern "C" int emrt_abi_version(void) { return 9; }
 
 // ---- tuning knobs: one table, environment read once at load time --------------------------------------------------
 namespace {

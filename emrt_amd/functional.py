@@ -325,14 +325,27 @@ def launch_wgrads(pending):
     _L().call("emrt_conv2d_wgrad_group", arr, len(pending), c.dtype, stream)
 
 
+class _DgradDesc(ctypes.Structure):       # EmrtConvDgradDesc (include/emrt_hip.h)
+    _fields_ = [("dy", ctypes.c_void_p), ("w_bwd_packed", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("lddx", ctypes.c_int), ("dx_bs", ctypes.c_longlong),
+                ("accumulate", ctypes.c_int), ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("OH", ctypes.c_int),
+                ("OW", ctypes.c_int), ("OC", ctypes.c_int), ("lddy", ctypes.c_int), ("dy_bs", ctypes.c_longlong), ("KH", ctypes.c_int), ("KW", ctypes.c_int),
+                ("stride", ctypes.c_int), ("pad", ctypes.c_int), ("dilation", ctypes.c_int), ("bn_stats", ctypes.c_void_p), ("mask_y", ctypes.c_void_p),
+                ("ldy", ctypes.c_int), ("y_bs", ctypes.c_longlong), ("mask_scale", ctypes.c_float), ("stat_x", ctypes.c_void_p), ("ldsx", ctypes.c_int),
+                ("sx_bs", ctypes.c_longlong), ("addend", ctypes.c_void_p), ("ldadd", ctypes.c_int), ("add_bs", ctypes.c_longlong)]
+
+
+_PAIR_IDS = [0]
+
+
 def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=False, need_dx=True, bn_stats=None, dilation=1,
-           out_scale=None, out_shift=None, drop=None, _launched=False):
+           out_scale=None, out_shift=None, drop=None, _launched=False, _pair=None):
     """x [N,H,W,C] view -> [N,OH,OW,OC].  bias comes from w.bias.  `out` may be a strided view (concat slice).
     out_scale / out_shift (fp32 [OC], inference only): out = conv * out_scale + out_shift -- an eval-mode BatchNorm folded in.
     drop=(p, salt) with relu=True (training, 1x1): out = dropout_p(relu(linear(x))) with the mask drawn in the GEMM epilogue
     (emrt_conv2d_drop); the caller promises that the result feeds exactly one conv2d / linear, whose data gradient applies both masks.
     _launched=True: the forward has already been launched into `out` (with these arguments, as one problem of a grouped launch: conv_bn_pair); only the
-    backward is recorded."""
+    backward is recorded.  _pair=(group id, "host" | "guest") (conv_bn_many): in backward the guest's data gradient waits in the tape's stash for the
+    closure that runs next -- its host's -- and goes out in THAT launch (emrt_conv2d_dgrad_multi: both keep their fused epilogues)."""
     c = ctx()
     if drop is not None and not (c.training and drop[0] > 0.0):
         drop = None
@@ -453,7 +466,33 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                     ymask, stat = x, res_rec["x"]
                     ldsx, sx_bs = _check_map(stat)[4:6]
                 side = c.fork(x, dy)
-                if side is None:
+                if side is None and deferred and _pair is not None and c.dgrad_pair and dil == 1:
+                    me = _DgradDesc()
+                    me.dy, me.w_bwd_packed, me.dx, me.lddx, me.dx_bs, me.accumulate = dy.data_ptr(), w.bwd_ptr, dx.data_ptr(), lddx, dx_bs, int(slot is not None)
+                    me.N, me.H, me.W, me.C, me.OH, me.OW, me.OC, me.lddy, me.dy_bs = N, H, W, C, OH, OW, w.OC, lddy, dy_bs
+                    me.KH, me.KW, me.stride, me.pad, me.dilation = w.KH, w.KW, stride, pad, dil
+                    me.bn_stats, me.mask_y = _dp(ysums), _dp(ymask)
+                    me.ldy, me.y_bs, me.mask_scale = (ldin, in_bs, float(mscale)) if ymask is not None else (0, 0, float(mscale))
+                    me.stat_x, me.ldsx, me.sx_bs = _dp(stat), ldsx, sx_bs
+                    me.addend, me.ldadd, me.add_bs = _dp(addend), ldadd, add_bs
+                    keep = (dy, dx, ysums, ymask, stat, addend)
+
+                    def launch(host, me=me, keep=keep):
+                        arr = (_DgradDesc * (2 if host is not None else 1))()
+                        if host is not None:
+                            arr[0] = host
+                        arr[len(arr) - 1] = me
+                        _L().call("emrt_conv2d_dgrad_multi", arr, len(arr), c.dtype, c.stream)
+                    if _pair[1] == "guest":
+                        tape.flush_stash()
+                        tape.stash = (_pair[0], launch)
+                    elif tape.stash is not None and tape.stash[0] == _pair[0]:
+                        guest_launch = tape.stash[1]
+                        tape.stash = None
+                        guest_launch(me)          # [host, guest] in one launch
+                    else:
+                        launch(None)
+                elif side is None:
                     # one call for both gradients: small layers run their dgrad and wgrad tiles in ONE launch
                     _L().call("emrt_conv2d_bwd", P(x), P(dy), ctypes.c_void_p(w.bwd_ptr), P(dx), lddx, dx_bs, int(slot is not None),
                               None if deferred else P(w.grad), None if deferred else dbias, N, H, W, C, ldin, in_bs,
@@ -480,6 +519,8 @@ def conv2d(x, w, stride=1, pad=0, relu=False, residual=None, out=None, out_f32=F
                     drop_rec["dx"] = dx
             if residual is not None:
                 tape.add_grad(residual, dy)
+        if _pair is not None:
+            bwd._group = _pair[0]
         tape.record(bwd)
     if drop is not None and not fused_drop:      # (a geometry the fused entry point does not take, or the A/B knob: the separate dropout launch,
         return dropout(out, drop[0], drop[1], sole_consumer_is_linear=True)      #  recorded AFTER this layer's own backward)
@@ -967,9 +1008,12 @@ def conv_bn_many(items, host_tiles=128):
         d.ldres, d.res_bs, d.KH, d.KW, d.stride, d.pad, d.relu, d.out_f32 = 0, 0, w.KH, w.KW, cv.stride, cv.padding, 0, 0
         ys.append(y); sums.append(sm)
     _L().call("emrt_conv2d_group", fd, n, c.dtype, c.stream)
+    _PAIR_IDS[0] += 1
+    gid = _PAIR_IDS[0]
     res = []
-    for (cv, bn, x, relu, defer, out), y, sm in zip(items, ys, sums):
-        conv2d(x, cv.gw, cv.stride, cv.padding, need_dx=cv.need_dx, bn_stats=sm, out=y, _launched=True)      # records this layer's backward
+    for i, ((cv, bn, x, relu, defer, out), y, sm) in enumerate(zip(items, ys, sums)):
+        # records this layer's backward; the guest's (last item) data gradient rides in the launch of the host whose closure runs right after it
+        conv2d(x, cv.gw, cv.stride, cv.padding, need_dx=cv.need_dx, bn_stats=sm, out=y, _launched=True, _pair=(gid, "guest" if i == n - 1 else "host"))
         res.append(_bn_tail(y, bn, sm, relu, None, out, defer))
     return res
 

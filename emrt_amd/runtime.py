@@ -28,6 +28,7 @@ def dtype_of(t):
 class Tape:
     def __init__(self):
         self.ops = []
+        self.stash = None   # (group id, launch(host_desc_or_None)): a guest data gradient waiting for its host's closure (functional.conv2d, _pair=)
         self.grads = {}
         self.keep = []      # keeps every registered tensor alive so id() keys stay unique for the step
         self.alias = {}     # id(view) -> (base, slicer)
@@ -180,6 +181,12 @@ class Tape:
             pending, self.wgrads = self.wgrads, []
             Fn.launch_wgrads(pending)
 
+    def flush_stash(self):
+        if self.stash is not None:
+            _gid, launch = self.stash
+            self.stash = None
+            launch(None)
+
     def backward(self, stop_at=0):
         """Run the recorded closures newest-first.  stop_at > 0 stops once only the first `stop_at` ops are left (the
         engine's early gradient exchange: everything recorded after `self.split` first, the rest in a second call)."""
@@ -187,7 +194,13 @@ class Tape:
         _CTX._in_backward = True
         try:
             while len(self.ops) > stop_at:
-                self.ops.pop()()
+                op = self.ops.pop()
+                # a data gradient waiting for the host it rode with in forward (functional.conv_bn_many): only the very next closure, and only a
+                # member of the same group, may take it into its launch; anything else sends it out on its own first
+                if self.stash is not None and getattr(op, "_group", None) != self.stash[0]:
+                    self.flush_stash()
+                op()
+            self.flush_stash()
             # the weight gradients this segment deferred: the caller (optimizer, or the gradient exchange of this segment's ranges) needs them now
             self.flush_wgrads()
             _CTX.wgrad_join()
@@ -245,6 +258,8 @@ class Context:
         # the spatial branch's conv -> BatchNorm stages in the forward launches of the ResNet's layer3 / layer4 blocks (functional.SideJobs, one rank); 0 = A/B knob
         self.side_branch = bool(int(os.environ.get("EMRT_SIDE_BRANCH", "1")))
         self.side = None
+        # backward of the forward pairings: the guest's data gradient in the host's launch (emrt_conv2d_dgrad_multi); 0 = A/B knob
+        self.dgrad_pair = bool(int(os.environ.get("EMRT_DGRAD_PAIR", "1")))
         self.side_host_tiles = int(os.environ.get("EMRT_SIDE_HOST_TILES", "128"))      # largest host launch (64 x 64 tiles) that takes a guest
         self.segment_order = False      # True: an engine exchanges gradient segments while backward runs (engine.TrainEngine, N > 1): layers keep the reference's order
         # cls_psp's second conv -> BatchNorm -> ReLU and the auxiliary head's in one grouped launch per pass (EMRT.forward, one rank); 0 = A/B knob

@@ -101,6 +101,17 @@ typedef struct EmrtConvBwdDesc {         /* the arguments of emrt_conv2d_bwd wit
 int emrt_conv2d_group(const EmrtConvDesc* descs, int n, int dtype, void* stream);
 /* dw == NULL in EVERY descriptor (then dbias must be NULL too): the data gradients only, one grouped launch of dgrad tiles */
 int emrt_conv2d_bwd_group(const EmrtConvBwdDesc* descs, int n, int dtype, void* stream);
+/* ABI 9: data gradients of 1..6 INDEPENDENT layers WITH the fused epilogues of emrt_conv2d_bwd (the producer's ReLU mask, its BatchNorm backward sums,
+ * an addend), argument for argument the data-gradient half of that entry point; small vector-path problems (<= 2048 tiles of 64 x 64 each, <= 4096 in
+ * all) run as ONE grouped launch, anything else one launch each.  n == 1 is emrt_conv2d_bwd with dw == NULL.  No two problems may write the same dx.
+ * Replaces nothing in the reference: paddle's autograd launches every layer's backward on its own (train.py:142-149). */
+typedef struct EmrtConvDgradDesc {
+  const void* dy; const void* w_bwd_packed; void* dx; int lddx; long long dx_bs; int accumulate;
+  int N, H, W, C, OH, OW, OC, lddy; long long dy_bs; int KH, KW, stride, pad, dilation;
+  double* bn_stats; const void* mask_y; int ldy; long long y_bs; float mask_scale; const void* stat_x; int ldsx; long long sx_bs;
+  const void* addend; int ldadd; long long add_bs;
+} EmrtConvDgradDesc;
+int emrt_conv2d_dgrad_multi(const EmrtConvDgradDesc* descs, int n, int dtype, void* stream);
 /* ---- batched weight gradients (ABI 5): dW(L) needs only x(L) and dy(L), nothing in loss.backward() (train.py:142-149) waits for it.  A
  * caller may therefore run each layer's DATA gradient alone (emrt_conv2d_bwd / emrt_conv2d_bwd_group with dw == NULL), keep x and dy
  * alive, and hand the weight gradients of many layers (any n >= 1; HOST array) to one call here: small vector-path problems run as grouped

@@ -50,7 +50,7 @@ def test_loader_binds_all_entry_points(built):
     from emrt_amd import _lib
     _lib._LIB = None
     L = _lib.lib()
-    assert L.query("emrt_abi_version") == 8
+    assert L.query("emrt_abi_version") == 9
     assert L.query("emrt_colreduce_workspace_bytes", 1000, 256) > 0
     import ctypes
     small = (ctypes.c_int * 6)(2, 2, 2, 2, 1, 2)                   # Lv = 10

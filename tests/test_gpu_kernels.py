@@ -2322,3 +2322,90 @@ def test_pyramid_maps_resized_in_one_launch(dtype, OH, OW, C):
     full.backward(dcat[..., C:])
     close("pyramid fwd", cat[..., C:], full.detach(), dtype)
     close("pyramid dtokens", dtok, tr.grad, dtype, math.sqrt(OH * OW))
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# An independent chain's conv -> BatchNorm stages as guests of a bottleneck block's launches (functional.SideJobs / conv_bn_many, emrt_conv2d_dgrad_multi)
+# -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
+def test_side_chain_rides_in_the_bottleneck_blocks_launches(dtype):
+    """Two bottleneck blocks (the first with a shortcut conv) beside a two-stage branch block (maxpool -> conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> ReLU,
+    paddle_EMRT.py:80-97) on another input: with Context.side set, the branch's conv -> BatchNorm stages ride in the blocks' conv1 launches forward
+    (emrt_conv2d_group) and their data gradients in the blocks' conv1 / shortcut data-gradient launches backward (emrt_conv2d_dgrad_multi, every fused
+    epilogue kept: the join's ReLU mask, the BatchNorm sums, the addend).  Against the same layers run one after the other: fp32 to rounding, bf16 in the norm."""
+    from emrt_amd import _lib
+    from emrt_amd.src.models.emrt import BottleneckBlock, branch_block
+    from emrt_amd import nn as hnn
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(91)
+    B = 2
+    x_main = torch.randn(B, 256, 16, 16, generator=g)
+    x_side = torch.randn(B, 64, 32, 32, generator=g)
+    dy_main = torch.randn(B, 512, 16, 16, generator=g)
+    dy_side = torch.randn(B, 128, 16, 16, generator=g)
+    seeds = {}
+
+    def run(side_on, dgrad_pair=True):
+        c = init(dtype)
+        c.dgrad_pair = dgrad_pair
+        torch.manual_seed(5)
+        b0 = BottleneckBlock(256, 128, 1, hnn.Sequential(hnn.Conv2D(256, 512, 1, 1, 0, bias=False), hnn.BatchNorm2D(512)))
+        b1 = BottleneckBlock(512, 128)
+        br = branch_block(64, 128)
+        mods = dict(b0=b0, b1=b1, br=br)
+        for name, m in mods.items():
+            for pn, p_ in m.named_parameters():
+                if (name, pn) not in seeds:
+                    seeds[(name, pn)] = rnd(p_.detach().clone() if p_.dim() == 1 else torch.randn(p_.shape, generator=g) / math.sqrt(p_[0].numel()))
+                with torch.no_grad():
+                    p_.copy_(seeds[(name, pn)])
+        Holder(**mods).place()
+        xm, xs = dev_map(rnd(x_main)), dev_map(rnd(x_side))
+        tape = Tape()
+        c.tape = tape
+
+        def jobs(x):
+            x = Fn.maxpool(x, 3, 2, 1)
+            x = yield (br.encode[0], br.encode[1], x, True, False, None)
+            x = yield (br.encode[3], br.encode[4], x, True, False, None)
+            return x
+        L.start_record()
+        if side_on:
+            c.side = Fn.SideJobs(jobs(xs))
+            try:
+                ym = b1(b0(xm))
+                ys = c.side.finish()
+                hosted = c.side.hosted
+            finally:
+                c.side = None
+        else:
+            ym = b1(b0(xm))
+            ys = Fn.maxpool(xs, 3, 2, 1)
+            ys = Fn.conv_bn(br.encode[0], br.encode[1], ys, relu=True)
+            ys = Fn.conv_bn(br.encode[3], br.encode[4], ys, relu=True)
+            hosted = 0
+        names = [n for n, _ in L.stop_record()]
+        c.tape = None
+        tape.watch(xm)
+        tape.watch(xs)
+        L.start_record()
+        dxm, dxs = run_bwd(tape, [(ym, dev_map(rnd(dy_main))), (ys, dev_map(rnd(dy_side)))], [xm, xs])
+        bnames = [(n, a) for n, a in L.stop_record()]
+        torch.cuda.synchronize()
+        c.dgrad_pair = True
+        grads = [host(p_.grad) for m in mods.values() for p_ in m.parameters()]
+        return names, bnames, hosted, [host_map(ym), host_map(ys), host_map(dxm), host_map(dxs)] + grads
+
+    n1, bn1, hosted, r1 = run(True)
+    n0, bn0, _, r0 = run(False)
+    n2, bn2, _, r2 = run(True, dgrad_pair=False)
+    assert hosted == 2 and n1.count("emrt_conv2d_group") == 2 and n0.count("emrt_conv2d_group") == 1      # (alone, the first block still pairs conv1 with its shortcut conv)
+    multi = [a for n, a in bn1 if n == "emrt_conv2d_dgrad_multi"]
+    assert sum(1 for a in multi if a[1] == 2) == 2 and not any(n == "emrt_conv2d_dgrad_multi" and a[1] == 2 for n, a in bn2)
+    for u, v, w_ in zip(r1, r0, r2):
+        assert torch.isfinite(u).all()
+        if dtype == F32:
+            assert (u - v).abs().max().item() <= 3e-5 * max(1.0, v.abs().max().item()), (u - v).abs().max().item()
+            assert (u - w_).abs().max().item() <= 3e-5 * max(1.0, v.abs().max().item())
+        else:
+            assert ((u - v).norm() / v.norm().clamp_min(1e-20)).item() < 0.05 and ((u - w_).norm() / v.norm().clamp_min(1e-20)).item() < 0.05

@@ -141,6 +141,12 @@ def test_train_step_launch_sequence(fake, backbone):
     # BatchNorm -> ReLU -> conv chains: the conv's dgrad carries the ReLU mask and the BatchNorm's backward sums, and the
     # separate reduction pass only remains for the other BatchNorms (residual joins, multi-consumer outputs, no ReLU)
     n_fused = sum(1 for a in dgrads if a[24] is not None)
+    # the data gradients of the layers that shared a forward launch with a guest (conv_bn_many) go through emrt_conv2d_dgrad_multi -- the same arguments as
+    # emrt_conv2d_bwd's data-gradient half, fused epilogues included: the guest's waits in the tape's stash and rides in its host's launch
+    multi = [a for n, a in fake.calls if n == "emrt_conv2d_dgrad_multi"]
+    assert sum(1 for a in multi if a[1] == 2) == max(len(hosted) - 1, 0) and all(a[1] in (1, 2) for a in multi)      # (the branch's first conv reads the image: no data gradient)
+    assert all(a[0][0].KH == 1 and a[0][1].KH == 3 and a[0][0].dx != a[0][1].dx for a in multi if a[1] == 2)      # [host conv1 / shortcut, guest 3x3]
+    n_fused += sum(1 for a in multi for i in range(a[1]) if a[0][i].bn_stats)
     assert all(a[25] is not None and a[28] == 1.0 for a in dgrads if a[24] is not None)
     # FFNs: linear2's dgrad applies the dropout mask and the ReLU mask of dropout(relu(linear1)) (mask source = its input,
     # scale 1/(1-p)); no separate mask pass is left for them
