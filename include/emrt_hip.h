@@ -37,7 +37,8 @@ int emrt_device_info(int* cu_count, size_t* lds_bytes, char* arch, int arch_len)
  * environment (EMRT_<NAME>) when the library is loaded; no entry point calls getenv() afterwards.  name (HOST string) is one of:
  * conv_tile, wgrad_split, no_ksplit128, ln_bwd_rows, ln_bwd_max_blocks, wgrad_no_overwrite, bn_operand_blocks, no_s2_dgrad, wgroup_blocks, wgroup_min_steps, wgroup_max, thin_cblk, thin_blocks, thin_ch, no_thin_bwd, pair_max, msda_fwd_global, msda_bwd_global, msda_fwd_chunks,
  * msda_fwd_threads, msda_fwd_probe, wgrad_nst, igemm64_nst, bn_block_kb, ln_atomic, gn_group_blocks, gn_stat_rows, msda_lds_min_pairs, msda_bwd_dref_lds,
- * gn_bwd_stat_rows, gn_apply_rows, xk, mha_valu, msda_scatter_merge, msda_scatter_mfma, msda_mf_bands, sgd_nt, ln_bwd_threads, no_bna, memcpy_kernel.
+ * gn_bwd_stat_rows, gn_apply_rows, xk, mha_valu, msda_scatter_merge, msda_scatter_mfma, msda_mf_bands, sgd_nt, ln_bwd_threads, no_bna, memcpy_kernel,
+ * wgroup8, wgroup8_blocks, wgroup8_min_work, mha_bwd_split.
  * Not thread-safe against concurrent launches; production code never calls these. */
 int emrt_set_tuning(const char* name, int value);
 int emrt_get_tuning(const char* name, int* value);
