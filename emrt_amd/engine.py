@@ -148,10 +148,14 @@ class TrainEngine:
             c.pack_bwd_done = True
         else:
             self.model.clear_gradients()
+        seg_prev = c.segment_order
+        if split:      # backward in segments whose gradients must be final at the marks: the layers keep the reference's order (EMRT.forward: no side chain)
+            c.segment_order = True
         try:
             out = self.model(images)
         finally:
             c.pack_bwd_done = False
+            c.segment_order = seg_prev
         loss = self.loss_fn(out, labels)
         c.prologue_join()               # backward reads the zeroed gradients and the transposed copies
         if split:
