@@ -332,7 +332,7 @@ def test_three_step_training_trace_matches_oracle():
         assert abs(opt.grad_norm() - ropt.last_grad_norm) < 2e-2 * ropt.last_grad_norm, (step, opt.grad_norm(), ropt.last_grad_norm)
 
 
-def test_fifty_step_training_trajectory_tracks_the_oracle():
+def fifty_step_training_trajectory_case():      # run from tests/test_gpu_model_traj.py (a file of its own for pytest-xdist)
     """The whole loop of train.py:141-159 (forward, loss, backward, clip, SGD-momentum with decay, polynomial LR) for 50 steps on a
     ResNet-18 / 64x64 variant, fp32, dropout off, HIP path against the CPU oracle from the same weights on the same two batches: loss,
     gradient norm and a weight checksum at every step.  The two are different fp32 programs integrating a non-linear recurrence, so
@@ -732,7 +732,7 @@ def test_non_square_tiles_match_oracle(B, H, W):
     assert cos > 0.999 and (num / den) ** 0.5 < 0.05
 
 
-def test_large_tile_train_step_matches_oracle_512():
+def large_tile_train_step_512_case():      # run from tests/test_gpu_model_traj.py
     """BASELINE configs[2] geometry (LoveDA: 512x512 tiles, 7 classes, Lv = 5376) in fp32 against the fp32 CPU oracle, one train-mode
     forward + loss + backward at batch 2: the large-map paths (global-gather MSDA forward and gradient kernels, the |dout| pre-pass,
     the scatter's four LDS ranges on level 0, 128x128 conv tiles everywhere) at model level, not only kernel by kernel."""
