@@ -24,7 +24,7 @@ def pytest_configure(config):
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """`pytest -m gpu` is spread over 4 worker processes, FILE BY FILE (pytest-xdist, --dist loadfile): most of the suite's wall time is the
+    """`pytest -m gpu` is spread over 6 worker processes, FILE BY FILE (pytest-xdist, --dist loadfile): most of the suite's wall time is the
     CPU oracle (fp32 / float64 torch on the host cores) and process start-up of the multi-rank tests, not GPU time, and the files are
     independent (every test initialises the device context it needs; knobs of the library are per process).  Tests of one file still run in
     order in one process.  EMRT_TEST_WORKERS=n overrides (1 = in-process); an explicit -n on the command line wins; without pytest-xdist
@@ -33,7 +33,7 @@ def pytest_cmdline_main(config):
         return None
     want = os.environ.get("EMRT_TEST_WORKERS")
     if want is None and (config.option.markexpr or "").strip() == "gpu":
-        want = "4"
+        want = "6"      # (4 until round 6: the suite's wall time is then ~total / 4 with a 100 s tail; the heavy files are split so that 6 balance, threads per worker = cores / 6)
     if want and int(want) > 1 and config.option.numprocesses is None and not config.option.collectonly and not config.getoption("usepdb", False):
         config.option.numprocesses = int(want)
         config.option.dist = "loadfile"

@@ -154,13 +154,11 @@ FORWARD_CASES_FULL = [("resnet50", 1, 512, 7),      # BASELINE configs[2] geomet
                       ("resnet50", 4, 512, 7)]      # configs[2]: batch 4
 
 
-@pytest.mark.parametrize("backbone,B,S,ncls", [("resnet18", 2, 64, 6), ("resnet50", 2, 128, 6), ("resnet50", 1, 256, 6),
-                                                ("resnet18", 1, 256, 6),      # configs[0]: ResNet-18, one 256x256 tile, on the HIP path
-                                                # the other depths the reference's constructor accepts (paddle_EMRT.py:229-234)
-                                                ("resnet34", 1, 128, 6), ("resnet101", 1, 128, 6),
-                                                ])
-def test_forward_logits_match_oracle_eval(backbone, B, S, ncls):
-    forward_logits_case(backbone, B, S, ncls)
+# (the small cases run from tests/test_gpu_model_eval.py: a file of its own for pytest-xdist)
+FORWARD_CASES_SMALL = [("resnet18", 2, 64, 6), ("resnet50", 2, 128, 6), ("resnet50", 1, 256, 6),
+                       ("resnet18", 1, 256, 6),      # configs[0]: ResNet-18, one 256x256 tile, on the HIP path
+                       # the other depths the reference's constructor accepts (paddle_EMRT.py:229-234)
+                       ("resnet34", 1, 128, 6), ("resnet101", 1, 128, 6)]
 
 
 def forward_logits_case(backbone, B, S, ncls):
